@@ -1,0 +1,232 @@
+/*
+ * libinternevo_hip.so -- C ABI of the MI355X (gfx950) kernels that stand behind the native-op import
+ * sites of InternEvo's training step (boundary #2).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch / C++ types in any signature;
+ *   - every entry point is stream-ordered: `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream); nothing here calls hipDeviceSynchronize, allocates, or keeps a pointer past the call;
+ *   - tensors are row-major; bf16 is the raw 16-bit pattern; `ld*` are row strides in ELEMENTS;
+ *   - return value: IE_OK (0) or a negative IE_ERR_* code; ie_last_error() gives the reason
+ *     (thread-local, so the autograd thread and the main thread do not clobber each other);
+ *   - re-entrant from several host threads (the reference runs backward on the autograd thread).
+ *
+ * Each function names the reference interface it replaces (paths relative to the InternEvo tree).
+ */
+#ifndef INTERNEVO_HIP_H
+#define INTERNEVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IE_OK 0
+#define IE_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, misaligned) */
+#define IE_ERR_UNSUPPORTED (-2) /* shape/dtype this build has no kernel for */
+#define IE_ERR_LAUNCH (-3)      /* HIP reported a launch error */
+
+#define IE_BF16 0
+#define IE_F32 1
+
+#define IE_ABI_VERSION 1
+
+int ie_abi_version(void);
+const char* ie_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  RMSNorm.  Replaces apex.normalization.fused_layer_norm.MixedFusedRMSNorm
+ *     (internlm/model/utils.py:662-675) == internlm/model/ops/norm.py:10-23 manual_rms_norm.
+ *     y = w * cast_w(x * rsqrt(mean(x^2) + eps)); statistics in fp32; x bf16 or fp32; w bf16 or fp32;
+ *     y has w's dtype.  rstd[rows] (fp32) is saved for backward.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, void* y, float* rstd,
+                   int64_t rows, int64_t cols, float eps, void* stream);
+
+/* Fused residual add + RMSNorm (modeling_internlm2.py:696-702, 721-727: `_dropped + _residual` then
+ * norm): r = bf16(a + b) is written to r_out (may alias a or b), y = RMSNorm(r).  bf16 only. */
+int ie_add_rmsnorm_fwd(const void* a, const void* b, void* r_out, const void* w, void* y, float* rstd,
+                       int64_t rows, int64_t cols, float eps, void* stream);
+
+/* Backward.  dx = rstd * (dy*w - xhat * mean(dy*w*xhat)); if dres != NULL, dx += dres (the gradient
+ * that reaches the same tensor through the residual connection).  dw partials: dw_partial
+ * [ie_rmsnorm_bwd_partials(rows)][cols] fp32 workspace; finish with ie_rmsnorm_dw_reduce. */
+int64_t ie_rmsnorm_bwd_partials(int64_t rows);
+int ie_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype,
+                   const float* rstd, const void* dres, void* dx, float* dw_partial, int64_t rows,
+                   int64_t cols, void* stream);
+/* dw (w's dtype) = [accumulate ? dw : 0] + sum_p dw_partial[p][:] */
+int ie_rmsnorm_dw_reduce(const float* dw_partial, int64_t nparts, void* dw, int w_dtype, int64_t cols,
+                         int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  Rotary.  ie_apply_rotary replaces rotary_emb.apply_rotary(x1, x2, cos, sin, out1, out2, conj)
+ *     (internlm/model/modules/embedding.py:115-120,142-153; torch restatement :63-86).
+ *     x1/x2/out1/out2 are [batch, seq, heads, half] views given by element strides (out may alias
+ *     in); cos/sin are [seq, half] with row stride cs_ld, broadcast over batch and heads.
+ *     conj=0: o1 = x1*cos - x2*sin, o2 = x1*sin + x2*cos;  conj=1: o1 = x1*cos + x2*sin,
+ *     o2 = -x1*sin + x2*cos.  Math in fp32, result rounded to dtype.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_apply_rotary(const void* x1, const void* x2, const void* cos_, const void* sin_, void* out1,
+                    void* out2, int dtype, int64_t batch, int64_t seq, int64_t heads, int64_t half,
+                    int64_t xs_b, int64_t xs_s, int64_t xs_h, int64_t os_b, int64_t os_s, int64_t os_h,
+                    int64_t cs_ld, int conj, void* stream);
+
+/* Fused InternLM2 q/k/v split + even/odd de-interleave + position gather + rotation
+ * (modeling_internlm2.py:416-434 + embedding.py:367-371).  qkv [T, hkv, gs=q_per_kv+2, d] bf16;
+ * q_out [T, hkv*q_per_kv, d]; kv_out [T, 2, hkv, d]; cos/sin [max_pos, d/2] bf16; pos[T] int64
+ * ("indexes").  interleaved=1 is the reference's `not rot_embed_HF_impl` branch.  d must be 128 or 64. */
+int ie_qkv_rotary_fwd(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos,
+                      void* q_out, void* kv_out, int64_t T, int hkv, int q_per_kv, int d,
+                      int interleaved, void* stream);
+/* Backward of the above: (dq, dkv) -> dqkv in the wqkv output layout (conjugate rotation,
+ * re-interleave). */
+int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* cos_, const void* sin_,
+                      const int64_t* pos, void* dqkv, int64_t T, int hkv, int q_per_kv, int d,
+                      int interleaved, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  SwiGLU gate.  Replaces torch.jit.script(Silu) (internlm/model/utils.py:684-688;
+ *     modules/mlp.py:85).  out = bf16(bf16(silu(a)) * b).  a, b, out: [rows, cols] bf16 with row
+ *     strides lda/ldb/ldo.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_swiglu_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                  int64_t rows, int64_t cols, void* stream);
+/* da = dout*b*silu'(a), db = dout*silu(a); act_out (optional, may be NULL) = recomputed forward. */
+int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* b,
+                  int64_t ldb, void* da, int64_t ldda, void* db, int64_t lddb, void* act_out,
+                  int64_t ldact, int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  Softmax cross-entropy.  Replaces flash_attn.losses.cross_entropy.CrossEntropyLoss
+ *     (internlm/model/losses/ce_loss.py:26-36) / nn.CrossEntropyLoss (:37-40).
+ *     logits [rows, vocab] bf16 or fp32 (row stride ld); labels int64, ignore_index rows give 0.
+ *     fwd: loss_rows[rows] fp32 (per-token loss), lse[rows] fp32.
+ *     ie_ce_mean: loss_out[0] = sum(loss_rows)/n_valid, count_out[0] = n_valid (as float).
+ *     bwd (in place when dlogits == logits, as inplace_backward=True):
+ *       dlogits = (softmax - (1-ls)*onehot - ls/vocab) * gscale, gscale = *dloss * dloss_mul / *count.
+ *     dloss and count are DEVICE scalars so the loss scale never round-trips through the host.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows,
+              float* lse, int64_t rows, int64_t vocab, int64_t ignore_index, float label_smoothing,
+              void* stream);
+int ie_ce_mean(const float* loss_rows, const int64_t* labels, int64_t rows, int64_t ignore_index,
+               float* loss_out, float* count_out, void* stream);
+int ie_ce_bwd(const void* logits, void* dlogits, int dtype, int64_t ld, const int64_t* labels,
+              const float* lse, const float* dloss, float dloss_mul, const float* count, int64_t rows,
+              int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  L2 norm.  Replaces amp_C.multi_tensor_l2norm via multi_tensor_applier
+ *     (internlm/solver/optimizer/utils.py:30-37,191-204; torch restatement :177-188).
+ *     ie_sumsq_partial: partial[part_offset + i] = sum of squares of a slice of x (fp32 accumulate of
+ *     fp32-cast elements); returns through *nparts_out how many partials it wrote.
+ *     ie_sumsq_finish:  out[0] = [accumulate ? out[0] : 0] + sum(partial[0..nparts)), fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ie_sumsq_max_partials(void);
+int ie_sumsq_partial(const void* x, int dtype, int64_t n, float* partial, int64_t part_offset,
+                     int64_t* nparts_out, void* stream);
+int ie_sumsq_finish(const float* partial, int64_t nparts, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a15/a17  Step control on device: DynamicGradScaler.update + overflow check + unscale/clip factor
+ *     (internlm/solver/optimizer/hybrid_zero_optim.py:695-779,863-876; optimizer/utils.py:431-543).
+ *     One tiny kernel; no host sync.  state layout: see IeStepState.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct IeStepState {
+    float loss_scale;       /* current dynamic loss scale                                   */
+    int growth_step;        /* DynamicGradScaler._growth_step                               */
+    int hysteresis_step;    /* DynamicGradScaler._hysteresis_step                           */
+    int adam_step;          /* number of successful optimizer steps (bias correction)       */
+    int skip;               /* 1 = this step is skipped (inf/nan)                            */
+    int found_inf;          /* grad-norm sentinel -1 of compute_norm                         */
+    int found_nan;          /* grad-norm sentinel -2                                        */
+    float inv_scale;        /* 1/(loss_scale*max(1,clip)) applied to grads by ie_adamw_step  */
+    float grad_norm;        /* unscaled global grad norm of this step (for logging)          */
+    float loss_scale_used;  /* the loss scale the grads of this step were produced with      */
+    int skipped_total;
+    int _pad;
+} IeStepState;
+
+typedef struct IeScalerConfig {
+    float growth_factor, backoff_factor, min_scale, max_scale;
+    int growth_interval, hysteresis;
+    float clip_grad_norm; /* <= 0: no clipping */
+    int dynamic;          /* 0 for fp32 models: scaler frozen, no unscale/clip (hybrid_zero_optim.py:712,773) */
+} IeScalerConfig;
+
+int ie_step_state_init(IeStepState* state_dev, float initial_scale, void* stream);
+/* sumsq_dev: device scalar = squared L2 norm of the (scaled) grads, already reduced across ranks. */
+int ie_step_control(IeStepState* state_dev, const float* sumsq_dev, const IeScalerConfig* cfg_host,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7  AdamW on a flat partition.  Replaces torch.optim.AdamW(fused=True) == torch._fused_adamw_
+ *     (internlm/train/pipeline.py:305-315, stepped at hybrid_zero_optim.py:787) fused with the
+ *     fp16->fp32 grad cast, unscale/clip (:749-779) and the fp32->bf16 param copy (:791-797).
+ *     g: grads (bf16 or fp32), p32/m/v fp32, p16 (optional) bf16 shadow.  Reads skip, inv_scale,
+ *     adam_step from state_dev.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n,
+                  const IeStepState* state_dev, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a10 Embedding.  F.embedding fwd (internlm/model/modules/embedding.py:52-60) and its dense
+ *     backward (scatter-add), deterministic, fp32 accumulate.  present: int32[vocab] workspace.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t T, int64_t vocab,
+                     int64_t dim, void* stream);
+int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* present, int64_t T,
+                     int64_t vocab, int64_t dim, int accumulate, void* stream);
+
+/* elementwise helpers used around the path */
+int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3/K3b  bf16 GEMM on MFMA, fp32 accumulate, bf16 output.
+ *     C[M,N] = opA(A)[M,K] * opB(B)[K,N]   (+ C if accumulate)
+ *       a_kmajor = 0: A stored [M][K] (lda >= K);  1: A stored [K][M] (lda >= M)
+ *       b_kmajor = 0: B stored [N][K] (ldb >= K);  1: B stored [K][N] (ldb >= N)
+ *     F.linear fwd  y = x W^T          (model/utils.py:275)          : a_kmajor=0, b_kmajor=0
+ *     dgrad         dx = dy W          (model/utils.py:315)          : a_kmajor=0, b_kmajor=1
+ *     fused_dense_lib.linear_bias_wgrad  dW = dy^T x (utils.py:293)  : a_kmajor=1, b_kmajor=1
+ *     accumulate=1 reproduces autograd's bf16 `param.grad += grad`: C = bf16(C + bf16(acc)).
+ * ---------------------------------------------------------------------------------------------- */
+int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+                 void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream);
+/* column sums of a [rows, cols] bf16 matrix (bias gradient of linear_bias_wgrad, has_bias=True) */
+int ie_colsum_bf16(const void* x, int64_t ld, void* out, int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  Flash attention, varlen, causal or full, GQA, head dim 128 (or 64), bf16.
+ *     Replaces flash_attn.flash_attn_varlen_kvpacked_func (modeling_internlm2.py:446-468) and
+ *     FlashSelfAttention/FlashCrossAttention (multi_head_attention.py:381-392).
+ *     q [T, hq, d] (token stride q_ts elements, head stride d), k/v [T, hkv, d] given as separate
+ *     base pointers with token stride kv_ts (kv-packed [T,2,hkv,d]: k = kv, v = kv + hkv*d,
+ *     kv_ts = 2*hkv*d; qkv-packed likewise).  cu_seqlens int32[nseq+1] (device); seqlen_q ==
+ *     seqlen_k per sequence.  out [T, hq, d] (token stride o_ts), lse [hq, T] fp32.
+ *     dropout is not supported (the path runs with attn_drop_rate = 0).
+ * ---------------------------------------------------------------------------------------------- */
+int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts,
+                      void* out, int64_t o_ts, float* lse, const int32_t* cu_seqlens, int nseq,
+                      int64_t T, int max_seqlen, int hq, int hkv, int d, float softmax_scale,
+                      int causal, void* stream);
+/* delta [hq, T] fp32 workspace.  dq [T,hq,d] (stride dq_ts), dk/dv [T,hkv,d] (stride dkv_ts). */
+int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k,
+                      const void* v, int64_t kv_ts, const void* out, int64_t o_ts, const float* lse,
+                      float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
+                      const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
+                      int d, float softmax_scale, int causal, void* stream);
+
+/* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
+ * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.
+ * Lets the test-suite pin the fragment layout on real hardware. */
+int ie_mfma_probe(const void* a, const void* b, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTERNEVO_HIP_H */

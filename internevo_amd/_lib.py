@@ -1,0 +1,128 @@
+"""ctypes binding of libinternevo_hip.so (the C ABI declared in include/internevo_hip.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing or an entry point
+cannot be resolved, importing the kernels fails loudly (``InternEvoHipError``), and every non-zero
+return code of the C ABI is raised as ``InternEvoHipError`` carrying ``ie_last_error()``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libinternevo_hip.so")
+
+IE_BF16 = 0
+IE_F32 = 1
+ABI_VERSION = 1
+
+
+class InternEvoHipError(RuntimeError):
+    pass
+
+
+class IeStepState(Structure):
+    _fields_ = [
+        ("loss_scale", c_float),
+        ("growth_step", c_int),
+        ("hysteresis_step", c_int),
+        ("adam_step", c_int),
+        ("skip", c_int),
+        ("found_inf", c_int),
+        ("found_nan", c_int),
+        ("inv_scale", c_float),
+        ("grad_norm", c_float),
+        ("loss_scale_used", c_float),
+        ("skipped_total", c_int),
+        ("_pad", c_int),
+    ]
+
+
+class IeScalerConfig(Structure):
+    _fields_ = [
+        ("growth_factor", c_float),
+        ("backoff_factor", c_float),
+        ("min_scale", c_float),
+        ("max_scale", c_float),
+        ("growth_interval", c_int),
+        ("hysteresis", c_int),
+        ("clip_grad_norm", c_float),
+        ("dynamic", c_int),
+    ]
+
+
+P = c_void_p
+I64 = c_int64
+I = c_int
+F = c_float
+Dbl = c_double
+
+# name -> (restype, argtypes).  Must list EVERY symbol of include/internevo_hip.h
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "ie_abi_version": (I, []),
+    "ie_last_error": (c_char_p, []),
+    "ie_rmsnorm_fwd": (I, [P, I, P, I, P, P, I64, I64, F, P]),
+    "ie_add_rmsnorm_fwd": (I, [P, P, P, P, P, P, I64, I64, F, P]),
+    "ie_rmsnorm_bwd_partials": (I64, [I64]),
+    "ie_rmsnorm_bwd": (I, [P, P, I, P, I, P, P, P, P, I64, I64, P]),
+    "ie_rmsnorm_dw_reduce": (I, [P, I64, P, I, I64, I, P]),
+    "ie_apply_rotary": (I, [P, P, P, P, P, P, I, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, P]),
+    "ie_qkv_rotary_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),
+    "ie_qkv_rotary_bwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),
+    "ie_swiglu_fwd": (I, [P, I64, P, I64, P, I64, I64, I64, P]),
+    "ie_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, P]),
+    "ie_ce_fwd": (I, [P, I, I64, P, P, P, I64, I64, I64, F, P]),
+    "ie_ce_mean": (I, [P, P, I64, I64, P, P, P]),
+    "ie_ce_bwd": (I, [P, P, I, I64, P, P, P, F, P, I64, I64, I64, F, P]),
+    "ie_sumsq_max_partials": (I64, []),
+    "ie_sumsq_partial": (I, [P, I, I64, P, I64, POINTER(c_int64), P]),
+    "ie_sumsq_finish": (I, [P, I64, P, I, P]),
+    "ie_step_state_init": (I, [P, F, P]),
+    "ie_step_control": (I, [P, P, POINTER(IeScalerConfig), P]),
+    "ie_adamw_step": (I, [P, I, P, P, P, P, I64, P, Dbl, Dbl, Dbl, Dbl, Dbl, P]),
+    "ie_embedding_fwd": (I, [P, P, P, I64, I64, I64, P]),
+    "ie_embedding_bwd": (I, [P, P, P, P, I64, I64, I64, I, P]),
+    "ie_add_bf16": (I, [P, P, P, I64, P]),
+    "ie_cast": (I, [P, I, P, I, I64, P]),
+    "ie_gemm_bf16": (I, [P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),
+    "ie_colsum_bf16": (I, [P, I64, P, I64, I64, P]),
+    "ie_flash_attn_fwd": (I, [P, I64, P, P, I64, P, I64, P, P, I, I64, I, I, I, I, F, I, P]),
+    "ie_flash_attn_bwd": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, I64, P, P, I64, P, I, I64, I, I, I, I, F, I, P]),
+    "ie_mfma_probe": (I, [P, P, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise InternEvoHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for the hot path."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the ROCm runtime being present
+        raise InternEvoHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise InternEvoHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.ie_abi_version()
+    if ver != ABI_VERSION:
+        raise InternEvoHipError(f"ABI version mismatch: library {ver}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ie_last_error()
+        raise InternEvoHipError(f"{what or 'libinternevo_hip'} failed (code {rc}): {msg.decode() if msg else ''}")

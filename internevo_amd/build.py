@@ -1,0 +1,67 @@
+"""Build libinternevo_hip.so (and the oracle's C pieces, if any) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU.  Objects are cached by source mtime so rebuilding after a
+one-file edit takes seconds.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(CSRC, "libinternevo_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libinternevo_hip.so)")
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "internevo_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    spath = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
+        return obj, False
+    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or force or not os.path.exists(LIB):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(f"[internevo_amd.build] {LIB} ({'rebuilt' if rebuilt else 'up to date'}; {len(srcs)} HIP sources)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

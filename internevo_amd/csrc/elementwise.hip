@@ -1,0 +1,423 @@
+// K2 rotary, K8 SwiGLU, embedding and small elementwise kernels for gfx950.  All HBM-bound:
+// 16-byte accesses per lane, grid sized to the problem, no LDS.
+#include "ie_common.h"
+
+namespace {
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// Generic strided rotary (drop-in for rotary_emb.apply_rotary; reference restatement
+// internlm/model/modules/embedding.py:63-86).
+template <bool BF>
+__global__ __launch_bounds__(256) void apply_rotary_k(const void* __restrict__ x1, const void* __restrict__ x2,
+                                                      const void* __restrict__ cs, const void* __restrict__ sn,
+                                                      void* out1, void* out2, int64_t batch, int64_t seq, int64_t heads,
+                                                      int64_t half, int64_t xs_b, int64_t xs_s, int64_t xs_h, int64_t os_b,
+                                                      int64_t os_s, int64_t os_h, int64_t cs_ld, int conj) {
+    const int64_t total = batch * seq * heads * half;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx % half;
+        int64_t r = idx / half;
+        const int64_t h = r % heads; r /= heads;
+        const int64_t s = r % seq;
+        const int64_t b = r / seq;
+        const int64_t xo = b * xs_b + s * xs_s + h * xs_h + i;
+        const int64_t oo = b * os_b + s * os_s + h * os_h + i;
+        float a, c, co, si;
+        if (BF) {
+            a = bf2f(((const bf16_t*)x1)[xo]); c = bf2f(((const bf16_t*)x2)[xo]);
+            co = bf2f(((const bf16_t*)cs)[s * cs_ld + i]); si = bf2f(((const bf16_t*)sn)[s * cs_ld + i]);
+        } else {
+            a = ((const float*)x1)[xo]; c = ((const float*)x2)[xo];
+            co = ((const float*)cs)[s * cs_ld + i]; si = ((const float*)sn)[s * cs_ld + i];
+        }
+        float o1, o2;
+        if (conj) { o1 = a * co + c * si; o2 = -a * si + c * co; }
+        else      { o1 = a * co - c * si; o2 = a * si + c * co; }
+        if (BF) { ((bf16_t*)out1)[oo] = f2bf(o1); ((bf16_t*)out2)[oo] = f2bf(o2); }
+        else    { ((float*)out1)[oo] = o1; ((float*)out2)[oo] = o2; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused wqkv-output split + de-interleave + cos/sin gather + rotate (fwd) and its adjoint (bwd).
+// One thread = one 16-element span of one (token, kv-group, slot) head.  D = head dim.
+template <int D, bool INTERLEAVED>
+__global__ __launch_bounds__(256) void qkv_rotary_fwd_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cs,
+                                                        const bf16_t* __restrict__ sn, const int64_t* __restrict__ pos,
+                                                        bf16_t* __restrict__ q_out, bf16_t* __restrict__ kv_out, int64_t T,
+                                                        int hkv, int qpk) {
+    constexpr int CH = D / 16;  // 16-element spans per head
+    constexpr int H2 = D / 2;
+    const int gs = qpk + 2;
+    const int64_t total = T * hkv * gs * CH;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % CH);
+    int64_t r = idx / CH;
+    const int s = (int)(r % gs); r /= gs;
+    const int g = (int)(r % hkv);
+    const int64_t t = r / hkv;
+    const bf16_t* src = qkv + ((t * hkv + g) * gs + s) * D;
+    bf16_t* dst;
+    if (s < qpk) dst = q_out + (t * (int64_t)(hkv * qpk) + (g * qpk + s)) * D;
+    else if (s == qpk) dst = kv_out + ((t * 2 + 0) * hkv + g) * D;
+    else dst = kv_out + ((t * 2 + 1) * hkv + g) * D;
+    if (s == qpk + 1) {  // v: plain copy
+        st16(dst + ch * 16, ld16(src + ch * 16));
+        st16(dst + ch * 16 + 8, ld16(src + ch * 16 + 8));
+        return;
+    }
+    const int i0 = ch * 8;  // first rotary-pair index of this span
+    float x1[8], x2[8];
+    if (INTERLEAVED) {
+        float lo[8], hi[8];
+        unpack8(ld16(src + ch * 16), lo);
+        unpack8(ld16(src + ch * 16 + 8), hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x1[e] = lo[2 * e]; x2[e] = lo[2 * e + 1];
+            x1[4 + e] = hi[2 * e]; x2[4 + e] = hi[2 * e + 1];
+        }
+    } else {
+        unpack8(ld16(src + i0), x1);
+        unpack8(ld16(src + H2 + i0), x2);
+    }
+    const int64_t p = pos[t];
+    float co[8], si[8], o1[8], o2[8];
+    unpack8(ld16(cs + p * H2 + i0), co);
+    unpack8(ld16(sn + p * H2 + i0), si);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = x1[e] * co[e] - x2[e] * si[e];
+        o2[e] = x1[e] * si[e] + x2[e] * co[e];
+    }
+    st16(dst + i0, pack8(o1));
+    st16(dst + H2 + i0, pack8(o2));
+}
+
+template <int D, bool INTERLEAVED>
+__global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dkv,
+                                                        const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
+                                                        const int64_t* __restrict__ pos, bf16_t* __restrict__ dqkv, int64_t T,
+                                                        int hkv, int qpk) {
+    constexpr int CH = D / 16;
+    constexpr int H2 = D / 2;
+    const int gs = qpk + 2;
+    const int64_t total = T * hkv * gs * CH;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % CH);
+    int64_t r = idx / CH;
+    const int s = (int)(r % gs); r /= gs;
+    const int g = (int)(r % hkv);
+    const int64_t t = r / hkv;
+    bf16_t* dst = dqkv + ((t * hkv + g) * gs + s) * D;
+    const bf16_t* src;
+    if (s < qpk) src = dq + (t * (int64_t)(hkv * qpk) + (g * qpk + s)) * D;
+    else if (s == qpk) src = dkv + ((t * 2 + 0) * hkv + g) * D;
+    else src = dkv + ((t * 2 + 1) * hkv + g) * D;
+    if (s == qpk + 1) {
+        st16(dst + ch * 16, ld16(src + ch * 16));
+        st16(dst + ch * 16 + 8, ld16(src + ch * 16 + 8));
+        return;
+    }
+    const int i0 = ch * 8;
+    float d1[8], d2[8], co[8], si[8], x1[8], x2[8];
+    unpack8(ld16(src + i0), d1);
+    unpack8(ld16(src + H2 + i0), d2);
+    const int64_t p = pos[t];
+    unpack8(ld16(cs + p * H2 + i0), co);
+    unpack8(ld16(sn + p * H2 + i0), si);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x1[e] = d1[e] * co[e] + d2[e] * si[e];
+        x2[e] = -d1[e] * si[e] + d2[e] * co[e];
+    }
+    if (INTERLEAVED) {
+        float lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[2 * e] = x1[e]; lo[2 * e + 1] = x2[e];
+            hi[2 * e] = x1[4 + e]; hi[2 * e + 1] = x2[4 + e];
+        }
+        st16(dst + ch * 16, pack8(lo));
+        st16(dst + ch * 16 + 8, pack8(hi));
+    } else {
+        st16(dst + i0, pack8(x1));
+        st16(dst + H2 + i0, pack8(x2));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU.  Reference: Silu(w1_o, w3_o) = F.silu(w1_o) * w3_o on bf16 tensors (model/utils.py:684-688):
+// silu evaluated in fp32, rounded to bf16, product rounded to bf16.
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + __expf(-a)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_k(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b,
+                                                    int64_t ldb, bf16_t* __restrict__ out, int64_t ldo, int64_t rows,
+                                                    int64_t cols8) {
+    const int64_t total = rows * cols8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols8, c = (idx % cols8) * 8;
+        float av[8], bv[8], o[8];
+        unpack8(ld16(a + r * lda + c), av);
+        unpack8(ld16(b + r * ldb + c), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rbf(av[e] * sigmoidf_(av[e])) * bv[e];
+        st16(out + r * ldo + c, pack8(o));
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_k(const bf16_t* __restrict__ dout, int64_t lddo, const bf16_t* __restrict__ a,
+                                                    int64_t lda, const bf16_t* __restrict__ b, int64_t ldb, bf16_t* __restrict__ da,
+                                                    int64_t ldda, bf16_t* __restrict__ db, int64_t lddb, bf16_t* __restrict__ act,
+                                                    int64_t ldact, int64_t rows, int64_t cols8) {
+    const int64_t total = rows * cols8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols8, c = (idx % cols8) * 8;
+        float av[8], bv[8], gv[8], oa[8], ob[8], oc[8];
+        unpack8(ld16(a + r * lda + c), av);
+        unpack8(ld16(b + r * ldb + c), bv);
+        unpack8(ld16(dout + r * lddo + c), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = sigmoidf_(av[e]);
+            const float s = rbf(av[e] * sg);                  // bf16 silu(a), as saved by autograd
+            const float ds = rbf(gv[e] * bv[e]);              // grad wrt silu output (bf16 mul backward)
+            oa[e] = ds * (sg * (1.f + av[e] * (1.f - sg)));   // silu'(a)
+            ob[e] = gv[e] * s;
+            oc[e] = s * bv[e];
+        }
+        st16(da + r * ldda + c, pack8(oa));
+        st16(db + r * lddb + c, pack8(ob));
+        if (act) st16(act + r * ldact + c, pack8(oc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_bf16_k(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o,
+                                                  int64_t n8, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n8) {
+        float av[8], bv[8];
+        unpack8(ld16(a + idx * 8), av);
+        unpack8(ld16(b + idx * 8), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] += bv[e];
+        st16(o + idx * 8, pack8(av));
+    }
+    if (idx == 0) {
+        for (int64_t i = n8 * 8; i < n; ++i) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_k(const void* __restrict__ src, int sdt, void* __restrict__ dst, int ddt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = sdt == IE_BF16 ? bf2f(((const bf16_t*)src)[i]) : ((const float*)src)[i];
+        if (ddt == IE_BF16) ((bf16_t*)dst)[i] = f2bf(v); else ((float*)dst)[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding gather: one wave per token row, 16 B per lane.
+__global__ __launch_bounds__(256) void embedding_fwd_k(const bf16_t* __restrict__ w, const int64_t* __restrict__ ids,
+                                                       bf16_t* __restrict__ out, int64_t T, int64_t vocab, int64_t dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    int64_t id = ids[t];
+    if (id < 0 || id >= vocab) id = 0;  // reference F.embedding would raise; never hit on valid input
+    const bf16_t* src = w + id * dim;
+    bf16_t* dst = out + t * dim;
+    if ((dim & 7) == 0) {
+        for (int64_t c = lane * 8; c < dim; c += 512) st16(dst + c, ld16(src + c));
+    } else {
+        for (int64_t c = lane; c < dim; c += 64) dst[c] = src[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_mark_k(const int64_t* __restrict__ ids, int* __restrict__ present, int64_t T,
+                                                        int64_t vocab) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) {
+        const int64_t id = ids[t];
+        if (id >= 0 && id < vocab) present[id] = 1;
+    }
+}
+
+// One block per vocabulary row; rows nobody referenced exit at once.  Tokens are visited in index
+// order and summed in fp32, so the result is deterministic (torch's CUDA embedding backward also
+// accumulates in fp32 per row).
+__global__ __launch_bounds__(256) void embedding_bwd_k(const bf16_t* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                       bf16_t* __restrict__ dw, const int* __restrict__ present, int64_t T,
+                                                       int64_t dim, int accumulate) {
+    const int64_t v = blockIdx.x;
+    const bool hit = present[v] != 0;
+    if (!hit) {
+        if (!accumulate)
+            for (int64_t c = threadIdx.x; c < dim; c += blockDim.x) dw[v * dim + c] = 0;
+        return;
+    }
+    constexpr int KC = 8;  // columns per thread per pass
+    for (int64_t cbase = 0; cbase < dim; cbase += (int64_t)blockDim.x * KC) {
+        float acc[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) acc[k] = 0.f;
+        for (int64_t t = 0; t < T; ++t) {
+            if (ids[t] != v) continue;  // block-uniform branch
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int64_t c = cbase + threadIdx.x + (int64_t)k * blockDim.x;
+                if (c < dim) acc[k] += bf2f(dout[t * dim + c]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int64_t c = cbase + threadIdx.x + (int64_t)k * blockDim.x;
+            if (c < dim) {
+                float r = rbf(acc[k]);
+                if (accumulate) r += bf2f(dw[v * dim + c]);
+                dw[v * dim + c] = f2bf(r);
+            }
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n, int per_block = 256, int64_t cap = 1 << 20) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int ie_apply_rotary(const void* x1, const void* x2, const void* cos_, const void* sin_, void* out1, void* out2,
+                               int dtype, int64_t batch, int64_t seq, int64_t heads, int64_t half, int64_t xs_b, int64_t xs_s,
+                               int64_t xs_h, int64_t os_b, int64_t os_s, int64_t os_h, int64_t cs_ld, int conj, void* stream) {
+    IE_CHECK_ARG(x1 && x2 && cos_ && sin_ && out1 && out2, "ie_apply_rotary: null pointer");
+    IE_CHECK_ARG(batch >= 0 && seq >= 0 && heads >= 0 && half >= 0, "ie_apply_rotary: bad shape");
+    IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_apply_rotary: bad dtype");
+    const int64_t total = batch * seq * heads * half;
+    if (total == 0) return IE_OK;
+    dim3 grid(grid_for(total, 256, 65536));
+    if (dtype == IE_BF16)
+        hipLaunchKernelGGL((apply_rotary_k<true>), grid, dim3(256), 0, (hipStream_t)stream, x1, x2, cos_, sin_, out1, out2, batch, seq,
+                           heads, half, xs_b, xs_s, xs_h, os_b, os_s, os_h, cs_ld, conj);
+    else
+        hipLaunchKernelGGL((apply_rotary_k<false>), grid, dim3(256), 0, (hipStream_t)stream, x1, x2, cos_, sin_, out1, out2, batch, seq,
+                           heads, half, xs_b, xs_s, xs_h, os_b, os_s, os_h, cs_ld, conj);
+    return ie_launch_status("ie_apply_rotary launch");
+}
+
+extern "C" int ie_qkv_rotary_fwd(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos, void* q_out, void* kv_out,
+                                 int64_t T, int hkv, int q_per_kv, int d, int interleaved, void* stream) {
+    IE_CHECK_ARG(qkv && cos_ && sin_ && pos && q_out && kv_out, "ie_qkv_rotary_fwd: null pointer");
+    IE_CHECK_ARG(T >= 0 && hkv > 0 && q_per_kv > 0, "ie_qkv_rotary_fwd: bad shape");
+    IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_qkv_rotary_fwd: head dim must be 64 or 128");
+    IE_CHECK_ARG(aligned16(qkv) && aligned16(cos_) && aligned16(sin_) && aligned16(q_out) && aligned16(kv_out),
+                 "ie_qkv_rotary_fwd: pointers must be 16-byte aligned");
+    if (T == 0) return IE_OK;
+    const int64_t total = T * hkv * (q_per_kv + 2) * (d / 16);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+#define IE_L(DD, IL)                                                                                                      \
+    hipLaunchKernelGGL((qkv_rotary_fwd_k<DD, IL>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)cos_,         \
+                       (const bf16_t*)sin_, pos, (bf16_t*)q_out, (bf16_t*)kv_out, T, hkv, q_per_kv)
+    if (d == 128) { if (interleaved) IE_L(128, true); else IE_L(128, false); }
+    else          { if (interleaved) IE_L(64, true); else IE_L(64, false); }
+#undef IE_L
+    return ie_launch_status("ie_qkv_rotary_fwd launch");
+}
+
+extern "C" int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* cos_, const void* sin_, const int64_t* pos, void* dqkv,
+                                 int64_t T, int hkv, int q_per_kv, int d, int interleaved, void* stream) {
+    IE_CHECK_ARG(dq && dkv && cos_ && sin_ && pos && dqkv, "ie_qkv_rotary_bwd: null pointer");
+    IE_CHECK_ARG(T >= 0 && hkv > 0 && q_per_kv > 0, "ie_qkv_rotary_bwd: bad shape");
+    IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_qkv_rotary_bwd: head dim must be 64 or 128");
+    IE_CHECK_ARG(aligned16(dq) && aligned16(dkv) && aligned16(cos_) && aligned16(sin_) && aligned16(dqkv),
+                 "ie_qkv_rotary_bwd: pointers must be 16-byte aligned");
+    if (T == 0) return IE_OK;
+    const int64_t total = T * hkv * (q_per_kv + 2) * (d / 16);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+#define IE_L(DD, IL)                                                                                                   \
+    hipLaunchKernelGGL((qkv_rotary_bwd_k<DD, IL>), grid, dim3(256), 0, st, (const bf16_t*)dq, (const bf16_t*)dkv,       \
+                       (const bf16_t*)cos_, (const bf16_t*)sin_, pos, (bf16_t*)dqkv, T, hkv, q_per_kv)
+    if (d == 128) { if (interleaved) IE_L(128, true); else IE_L(128, false); }
+    else          { if (interleaved) IE_L(64, true); else IE_L(64, false); }
+#undef IE_L
+    return ie_launch_status("ie_qkv_rotary_bwd launch");
+}
+
+extern "C" int ie_swiglu_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows,
+                             int64_t cols, void* stream) {
+    IE_CHECK_ARG(a && b && out, "ie_swiglu_fwd: null pointer");
+    IE_CHECK_ARG(rows >= 0 && cols >= 0, "ie_swiglu_fwd: bad shape");
+    IE_CHECK_SUPPORTED(cols % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 && aligned16(a) && aligned16(b) && aligned16(out),
+                       "ie_swiglu_fwd: cols/strides must be multiples of 8 and pointers 16-byte aligned");
+    if (rows * cols == 0) return IE_OK;
+    dim3 grid(grid_for(rows * (cols / 8), 256, 1 << 16));
+    hipLaunchKernelGGL(swiglu_fwd_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       (bf16_t*)out, ldo, rows, cols / 8);
+    return ie_launch_status("ie_swiglu_fwd launch");
+}
+
+extern "C" int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* b, int64_t ldb, void* da,
+                             int64_t ldda, void* db, int64_t lddb, void* act_out, int64_t ldact, int64_t rows, int64_t cols,
+                             void* stream) {
+    IE_CHECK_ARG(dout && a && b && da && db, "ie_swiglu_bwd: null pointer");
+    IE_CHECK_ARG(rows >= 0 && cols >= 0, "ie_swiglu_bwd: bad shape");
+    IE_CHECK_SUPPORTED(cols % 8 == 0 && lddo % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldda % 8 == 0 && lddb % 8 == 0 &&
+                           (!act_out || ldact % 8 == 0) && aligned16(dout) && aligned16(a) && aligned16(b) && aligned16(da) &&
+                           aligned16(db) && (!act_out || aligned16(act_out)),
+                       "ie_swiglu_bwd: cols/strides must be multiples of 8 and pointers 16-byte aligned");
+    if (rows * cols == 0) return IE_OK;
+    dim3 grid(grid_for(rows * (cols / 8), 256, 1 << 16));
+    hipLaunchKernelGGL(swiglu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, lddo, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, (bf16_t*)da, ldda, (bf16_t*)db, lddb, (bf16_t*)act_out, ldact, rows, cols / 8);
+    return ie_launch_status("ie_swiglu_bwd launch");
+}
+
+extern "C" int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    IE_CHECK_ARG(a && b && out && n >= 0, "ie_add_bf16: bad argument");
+    IE_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(out), "ie_add_bf16: pointers must be 16-byte aligned");
+    if (n == 0) return IE_OK;
+    const int64_t n8 = n / 8;
+    dim3 grid((unsigned)((n8 + 256) / 256));
+    hipLaunchKernelGGL(add_bf16_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n8, n);
+    return ie_launch_status("ie_add_bf16 launch");
+}
+
+extern "C" int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    IE_CHECK_ARG(src && dst && n >= 0, "ie_cast: bad argument");
+    IE_CHECK_ARG((src_dtype == IE_BF16 || src_dtype == IE_F32) && (dst_dtype == IE_BF16 || dst_dtype == IE_F32), "ie_cast: bad dtype");
+    if (n == 0) return IE_OK;
+    hipLaunchKernelGGL(cast_k, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, dst, dst_dtype, n);
+    return ie_launch_status("ie_cast launch");
+}
+
+extern "C" int ie_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t T, int64_t vocab, int64_t dim, void* stream) {
+    IE_CHECK_ARG(weight && ids && out && T >= 0 && vocab > 0 && dim > 0, "ie_embedding_fwd: bad argument");
+    IE_CHECK_ARG(dim % 8 != 0 || (aligned16(weight) && aligned16(out)), "ie_embedding_fwd: pointers must be 16-byte aligned");
+    if (T == 0) return IE_OK;
+    hipLaunchKernelGGL(embedding_fwd_k, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)weight, ids,
+                       (bf16_t*)out, T, vocab, dim);
+    return ie_launch_status("ie_embedding_fwd launch");
+}
+
+extern "C" int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* present, int64_t T, int64_t vocab,
+                                int64_t dim, int accumulate, void* stream) {
+    IE_CHECK_ARG(dout && ids && dweight && present && T >= 0 && vocab > 0 && dim > 0, "ie_embedding_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(present, 0, sizeof(int) * vocab, st) != hipSuccess) {
+        ie_set_error("ie_embedding_bwd: memset failed");
+        return IE_ERR_LAUNCH;
+    }
+    if (T > 0) hipLaunchKernelGGL(embedding_mark_k, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ids, present, T, vocab);
+    hipLaunchKernelGGL(embedding_bwd_k, dim3((unsigned)vocab), dim3(256), 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, present, T,
+                       dim, accumulate);
+    return ie_launch_status("ie_embedding_bwd launch");
+}

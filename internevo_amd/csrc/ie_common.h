@@ -1,0 +1,124 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libinternevo_hip.so.
+// Not a portability layer: everything here assumes a 64-lane wavefront and gfx950 builtins.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/internevo_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;  // 8 bf16 = one MFMA A/B fragment
+
+extern "C" void ie_set_error(const char* msg);
+
+#define IE_CHECK_ARG(cond, msg)  \
+    do {                         \
+        if (!(cond)) {           \
+            ie_set_error(msg);   \
+            return IE_ERR_INVALID; \
+        }                        \
+    } while (0)
+
+#define IE_CHECK_SUPPORTED(cond, msg) \
+    do {                              \
+        if (!(cond)) {                \
+            ie_set_error(msg);        \
+            return IE_ERR_UNSUPPORTED; \
+        }                             \
+    } while (0)
+
+static inline int ie_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ie_set_error(what);
+        return IE_ERR_LAUNCH;
+    }
+    return IE_OK;
+}
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved; identical to torch's cast) -------------
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float bflo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round an f32 to the nearest bf16 and return it as f32 (mimics a bf16 intermediate in the reference)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bflo(v.x); f[1] = bfhi(v.x);
+    f[2] = bflo(v.y); f[3] = bfhi(v.y);
+    f[4] = bflo(v.z); f[5] = bfhi(v.z);
+    f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]);
+    v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]);
+    v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// ---- wave64 / block reductions --------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a block of NW waves; result valid in every thread. `scratch` holds >= NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += scratch[i];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float t = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ uint2 ld8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ void st8(void* p, const uint2& v) { *reinterpret_cast<uint2*>(p) = v; }

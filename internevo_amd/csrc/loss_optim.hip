@@ -1,0 +1,468 @@
+// K4 softmax cross-entropy, K6 squared-L2-norm, a15/a17 step control (grad scaler + clip factor on
+// device) and K7 fused ZeRO AdamW for gfx950.  All HBM-bound streaming kernels.
+//
+// Algorithmic bytes: CE fwd reads vocab*sizeof(logit) per token; CE bwd reads + writes it;
+// sumsq reads 2 B/param (bf16 grads); AdamW reads g(2)+p,m,v(12) and writes p,m,v(12)+bf16 p(2)
+// = 28 B/param.
+#include "ie_common.h"
+
+#include <math.h>
+
+namespace {
+
+__host__ __device__ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------ CE fwd
+// One 256-thread block per token row: per-thread online (max, sum-exp) over 16-byte chunks, then a
+// block combine.  Mirrors flash-attn's xentropy forward / nn.CrossEntropyLoss on fp32 logits: the
+// bf16 -> fp32 cast of NaiveAMPModel (internlm/core/naive_amp.py:157-158) is exact, so reading bf16
+// logits directly gives the same numbers while halving the traffic.
+template <bool BF>
+__global__ __launch_bounds__(256) void ce_fwd_k(const void* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                float* __restrict__ loss_rows, float* __restrict__ lse_out, int64_t vocab,
+                                                int64_t ignore_index, float ls, int vec_ok) {
+    __shared__ float scratch[8];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    float m = -INFINITY, s = 0.f, sx = 0.f;
+    if (BF) {
+        const bf16_t* x = (const bf16_t*)logits + row * ld;
+        if (vec_ok) {
+            const int64_t n8 = vocab / 8;
+            for (int64_t i = tid; i < n8; i += 256) {
+                float v[8];
+                unpack8(ld16(x + i * 8), v);
+                float cm = v[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e) cm = fmaxf(cm, v[e]);
+                if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s += __expf(v[e] - m); sx += v[e]; }
+            }
+            for (int64_t i = n8 * 8 + tid; i < vocab; i += 256) {
+                const float v = bf2f(x[i]);
+                if (v > m) { s *= __expf(m - v); m = v; }
+                s += __expf(v - m); sx += v;
+            }
+        } else {
+            for (int64_t i = tid; i < vocab; i += 256) {
+                const float v = bf2f(x[i]);
+                if (v > m) { s *= __expf(m - v); m = v; }
+                s += __expf(v - m); sx += v;
+            }
+        }
+    } else {
+        const float* x = (const float*)logits + row * ld;
+        if (vec_ok) {
+            const int64_t n4 = vocab / 4;
+            for (int64_t i = tid; i < n4; i += 256) {
+                const float4 q = *reinterpret_cast<const float4*>(x + i * 4);
+                const float v[4] = {q.x, q.y, q.z, q.w};
+                const float cm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s += __expf(v[e] - m); sx += v[e]; }
+            }
+            for (int64_t i = n4 * 4 + tid; i < vocab; i += 256) {
+                const float v = x[i];
+                if (v > m) { s *= __expf(m - v); m = v; }
+                s += __expf(v - m); sx += v;
+            }
+        } else {
+            for (int64_t i = tid; i < vocab; i += 256) {
+                const float v = x[i];
+                if (v > m) { s *= __expf(m - v); m = v; }
+                s += __expf(v - m); sx += v;
+            }
+        }
+    }
+    const float mb = block_max<4>(m, scratch);
+    const float contrib = (m == -INFINITY) ? 0.f : s * __expf(m - mb);
+    const float sb = block_sum<4>(contrib, scratch);
+    const float sxb = block_sum<4>(sx, scratch);
+    if (tid == 0) {
+        const float lse = mb + logf(sb);
+        lse_out[row] = lse;
+        const int64_t lab = labels[row];
+        float loss = 0.f;
+        if (lab != ignore_index && lab >= 0 && lab < vocab) {
+            const float xl = BF ? bf2f(((const bf16_t*)logits)[row * ld + lab]) : ((const float*)logits)[row * ld + lab];
+            loss = lse - xl;
+            if (ls > 0.f) loss = (1.f - ls) * loss + ls * (lse - sxb / (float)vocab);
+        }
+        loss_rows[row] = loss;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ce_mean_k(const float* __restrict__ loss_rows, const int64_t* __restrict__ labels, int64_t rows,
+                                                  int64_t ignore_index, float* __restrict__ loss_out, float* __restrict__ count_out) {
+    __shared__ double sd[16];
+    __shared__ double sc[16];
+    double acc = 0.0, cnt = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) {
+        if (labels[i] != ignore_index) { acc += (double)loss_rows[i]; cnt += 1.0; }
+    }
+    acc = wave_sum_d(acc);
+    cnt = wave_sum_d(cnt);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sd[w] = acc; sc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0;
+        for (int i = 0; i < 16; ++i) { a += sd[i]; c += sc[i]; }
+        loss_out[0] = (float)(a / c);
+        count_out[0] = (float)c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ CE bwd
+template <bool BF>
+__global__ __launch_bounds__(256) void ce_bwd_k(const void* __restrict__ logits, void* dlogits, int64_t ld,
+                                                const int64_t* __restrict__ labels, const float* __restrict__ lse,
+                                                const float* __restrict__ dloss, float dloss_mul, const float* __restrict__ count,
+                                                int64_t vocab, int64_t ignore_index, float ls, int vec_ok) {
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t lab = labels[row];
+    const bool valid = lab != ignore_index;
+    const float g = valid ? dloss[0] * dloss_mul / count[0] : 0.f;
+    const float l = lse[row];
+    const float smooth = ls / (float)vocab;
+    const float hot = 1.f - ls;
+    if (BF) {
+        const bf16_t* x = (const bf16_t*)logits + row * ld;
+        bf16_t* d = (bf16_t*)dlogits + row * ld;
+        if (vec_ok) {
+            const int64_t n8 = vocab / 8;
+            for (int64_t i = tid; i < n8; i += 256) {
+                float v[8];
+                unpack8(ld16(x + i * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float p = __expf(v[e] - l) - smooth;
+                    if (i * 8 + e == lab) p -= hot;
+                    v[e] = valid ? p * g : 0.f;
+                }
+                st16(d + i * 8, pack8(v));
+            }
+            for (int64_t i = n8 * 8 + tid; i < vocab; i += 256) {
+                float p = __expf(bf2f(x[i]) - l) - smooth;
+                if (i == lab) p -= hot;
+                d[i] = f2bf(valid ? p * g : 0.f);
+            }
+        } else {
+            for (int64_t i = tid; i < vocab; i += 256) {
+                float p = __expf(bf2f(x[i]) - l) - smooth;
+                if (i == lab) p -= hot;
+                d[i] = f2bf(valid ? p * g : 0.f);
+            }
+        }
+    } else {
+        const float* x = (const float*)logits + row * ld;
+        float* d = (float*)dlogits + row * ld;
+        for (int64_t i = tid; i < vocab; i += 256) {
+            float p = __expf(x[i] - l) - smooth;
+            if (i == lab) p -= hot;
+            d[i] = valid ? p * g : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sumsq
+constexpr int kSumsqMaxBlocks = 1024;
+
+template <bool BF>
+__global__ __launch_bounds__(256) void sumsq_partial_k(const void* __restrict__ x, int64_t n, float* __restrict__ partial) {
+    __shared__ float scratch[8];
+    float acc = 0.f;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    if (BF) {
+        const bf16_t* p = (const bf16_t*)x;
+        const int64_t n8 = aligned16(x) ? n / 8 : 0;
+        for (int64_t i = tid; i < n8; i += nthreads) {
+            float v[8];
+            unpack8(ld16(p + i * 8), v);
+            float c = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c += v[e] * v[e];
+            acc += c;
+        }
+        for (int64_t i = n8 * 8 + tid; i < n; i += nthreads) { const float v = bf2f(p[i]); acc += v * v; }
+    } else {
+        const float* p = (const float*)x;
+        const int64_t n4 = aligned16(x) ? n / 4 : 0;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const float4 q = *reinterpret_cast<const float4*>(p + i * 4);
+            acc += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+        }
+        for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) acc += p[i] * p[i];
+    }
+    const float t = block_sum<4>(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_k(const float* __restrict__ partial, int64_t nparts, float* out, int accumulate) {
+    __shared__ double sd[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sd[0] + sd[1] + sd[2] + sd[3];
+        if (accumulate) t += (double)out[0];
+        out[0] = (float)t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ step control
+__global__ void step_state_init_k(IeStepState* s, float initial_scale) {
+    s->loss_scale = initial_scale;
+    s->growth_step = 0;
+    s->hysteresis_step = 0;
+    s->adam_step = 0;
+    s->skip = 0;
+    s->found_inf = 0;
+    s->found_nan = 0;
+    s->inv_scale = 1.f;
+    s->grad_norm = 0.f;
+    s->loss_scale_used = initial_scale;
+    s->skipped_total = 0;
+    s->_pad = 0;
+}
+
+// Mirrors HybridZeroOptimizer._step (hybrid_zero_optim.py:695-779), DynamicGradScaler.update
+// (optimizer/utils.py:484-509) and _unscale_and_clip_grads (:863-876), in that order.
+__global__ void step_control_k(IeStepState* s, const float* __restrict__ sumsq, IeScalerConfig cfg) {
+    const float ss = sumsq[0];
+    const bool found_inf = isinf(ss);   // compute_norm sentinel -1 (optimizer/utils.py:371-373)
+    const bool found_nan = isnan(ss);   // sentinel -2 (:375-376)
+    const float scale_backup = s->loss_scale;  // `loss_scale = float(self.loss_scale.item())  # backup`
+    s->loss_scale_used = scale_backup;
+    if (cfg.dynamic) {
+        if (found_inf) {
+            s->hysteresis_step += 1;
+            s->growth_step = 0;
+            if (s->hysteresis_step >= cfg.hysteresis) {
+                float ns = s->loss_scale * cfg.backoff_factor;
+                if (cfg.min_scale > 0.f) ns = fmaxf(ns, cfg.min_scale);
+                s->loss_scale = ns;
+            }
+        } else {
+            s->growth_step += 1;
+            if (s->growth_step == cfg.growth_interval) {
+                s->growth_step = 0;
+                s->hysteresis_step = 0;
+                float ns = s->loss_scale * cfg.growth_factor;
+                if (cfg.max_scale > 0.f) ns = fminf(ns, cfg.max_scale);
+                s->loss_scale = ns;
+            }
+        }
+    }
+    s->found_inf = found_inf ? 1 : 0;
+    s->found_nan = found_nan ? 1 : 0;
+    if (found_inf || found_nan) {
+        s->skip = 1;
+        s->skipped_total += 1;
+        s->inv_scale = 0.f;
+        s->grad_norm = found_inf ? -1.f : -2.f;
+        return;
+    }
+    s->skip = 0;
+    s->adam_step += 1;
+    const double norm = sqrt((double)ss);  // global_norm_groups[...] = norm ** 0.5
+    double combined = (double)scale_backup;
+    if (cfg.dynamic && cfg.clip_grad_norm > 0.f) {
+        const double clip = (norm / (double)scale_backup + 1e-6) / (double)cfg.clip_grad_norm;
+        if (clip > 1.0) combined = clip * (double)scale_backup;
+    }
+    // fp32 models: the reference neither unscales nor clips (hybrid_zero_optim.py:773), scale is 1.
+    s->inv_scale = cfg.dynamic ? (float)(1.0 / combined) : 1.f;
+    s->grad_norm = (float)(norm / (double)scale_backup);
+}
+
+// ------------------------------------------------------------------------------------------ AdamW
+struct AdamConsts {
+    float decay;      // 1 - lr*wd
+    float one_m_b1;   // 1 - beta1
+    float beta2;
+    float one_m_b2;
+    float step_size;  // lr / (1 - beta1^t)
+    float bc2_sqrt;   // sqrt(1 - beta2^t)
+    float eps;
+    float inv_scale;
+};
+
+__device__ __forceinline__ void adam_one(float g, float& p, float& m, float& v, const AdamConsts& c) {
+    g *= c.inv_scale;
+    p *= c.decay;
+    m = m + c.one_m_b1 * (g - m);
+    v = v * c.beta2 + c.one_m_b2 * g * g;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p - c.step_size * (m / denom);
+}
+
+template <bool GBF>
+__global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float* __restrict__ p32, float* __restrict__ m,
+                                               float* __restrict__ v, bf16_t* __restrict__ p16, int64_t n,
+                                               const IeStepState* __restrict__ state, double lr, double beta1, double beta2,
+                                               float eps, double wd, int vec_ok) {
+    __shared__ AdamConsts sc;
+    __shared__ int skip;
+    if (threadIdx.x == 0) {
+        skip = state->skip;
+        const int step = state->adam_step;
+        const double bc1 = 1.0 - pow(beta1, (double)step);
+        const double bc2 = 1.0 - pow(beta2, (double)step);
+        sc.decay = (float)(1.0 - lr * wd);
+        sc.one_m_b1 = (float)(1.0 - beta1);
+        sc.beta2 = (float)beta2;
+        sc.one_m_b2 = (float)(1.0 - beta2);
+        sc.step_size = (float)(lr / bc1);
+        sc.bc2_sqrt = (float)sqrt(bc2);
+        sc.eps = eps;
+        sc.inv_scale = state->inv_scale;
+    }
+    __syncthreads();
+    if (skip) return;
+    const AdamConsts c = sc;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    const int64_t n4 = vec_ok ? n / 4 : 0;
+    for (int64_t i = tid; i < n4; i += nthreads) {
+        float gv[4];
+        if (GBF) {
+            const uint2 q = ld8((const bf16_t*)g + i * 4);
+            gv[0] = bflo(q.x); gv[1] = bfhi(q.x); gv[2] = bflo(q.y); gv[3] = bfhi(q.y);
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>((const float*)g + i * 4);
+            gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
+        }
+        float4 pp = *reinterpret_cast<float4*>(p32 + i * 4);
+        float4 mm = *reinterpret_cast<float4*>(m + i * 4);
+        float4 vv = *reinterpret_cast<float4*>(v + i * 4);
+        adam_one(gv[0], pp.x, mm.x, vv.x, c);
+        adam_one(gv[1], pp.y, mm.y, vv.y, c);
+        adam_one(gv[2], pp.z, mm.z, vv.z, c);
+        adam_one(gv[3], pp.w, mm.w, vv.w, c);
+        *reinterpret_cast<float4*>(p32 + i * 4) = pp;
+        *reinterpret_cast<float4*>(m + i * 4) = mm;
+        *reinterpret_cast<float4*>(v + i * 4) = vv;
+        if (p16) {
+            uint2 o;
+            o.x = pack2bf(pp.x, pp.y);
+            o.y = pack2bf(pp.z, pp.w);
+            st8(p16 + i * 4, o);
+        }
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) {
+        const float gg = GBF ? bf2f(((const bf16_t*)g)[i]) : ((const float*)g)[i];
+        float pp = p32[i], mm = m[i], vv = v[i];
+        adam_one(gg, pp, mm, vv, c);
+        p32[i] = pp; m[i] = mm; v[i] = vv;
+        if (p16) p16[i] = f2bf(pp);
+    }
+}
+
+}  // namespace
+
+extern "C" int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows, float* lse, int64_t rows,
+                         int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream) {
+    IE_CHECK_ARG(logits && labels && loss_rows && lse, "ie_ce_fwd: null pointer");
+    IE_CHECK_ARG(rows >= 0 && vocab > 0 && ld >= vocab, "ie_ce_fwd: bad shape");
+    IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_ce_fwd: bad dtype");
+    if (rows == 0) return IE_OK;
+    const int esz = dtype == IE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(logits) && ((ld * esz) % 16 == 0);
+    if (dtype == IE_BF16)
+        hipLaunchKernelGGL((ce_fwd_k<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_rows, lse,
+                           vocab, ignore_index, label_smoothing, vec_ok);
+    else
+        hipLaunchKernelGGL((ce_fwd_k<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_rows, lse,
+                           vocab, ignore_index, label_smoothing, vec_ok);
+    return ie_launch_status("ie_ce_fwd launch");
+}
+
+extern "C" int ie_ce_mean(const float* loss_rows, const int64_t* labels, int64_t rows, int64_t ignore_index, float* loss_out,
+                          float* count_out, void* stream) {
+    IE_CHECK_ARG(loss_rows && labels && loss_out && count_out && rows >= 0, "ie_ce_mean: bad argument");
+    hipLaunchKernelGGL(ce_mean_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_rows, labels, rows, ignore_index, loss_out, count_out);
+    return ie_launch_status("ie_ce_mean launch");
+}
+
+extern "C" int ie_ce_bwd(const void* logits, void* dlogits, int dtype, int64_t ld, const int64_t* labels, const float* lse,
+                         const float* dloss, float dloss_mul, const float* count, int64_t rows, int64_t vocab, int64_t ignore_index,
+                         float label_smoothing, void* stream) {
+    IE_CHECK_ARG(logits && dlogits && labels && lse && dloss && count, "ie_ce_bwd: null pointer");
+    IE_CHECK_ARG(rows >= 0 && vocab > 0 && ld >= vocab, "ie_ce_bwd: bad shape");
+    IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_ce_bwd: bad dtype");
+    if (rows == 0) return IE_OK;
+    const int esz = dtype == IE_BF16 ? 2 : 4;
+    const int vec_ok = aligned16(logits) && aligned16(dlogits) && ((ld * esz) % 16 == 0);
+    if (dtype == IE_BF16)
+        hipLaunchKernelGGL((ce_bwd_k<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, dlogits, ld, labels, lse,
+                           dloss, dloss_mul, count, vocab, ignore_index, label_smoothing, vec_ok);
+    else
+        hipLaunchKernelGGL((ce_bwd_k<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, dlogits, ld, labels, lse,
+                           dloss, dloss_mul, count, vocab, ignore_index, label_smoothing, vec_ok);
+    return ie_launch_status("ie_ce_bwd launch");
+}
+
+extern "C" int64_t ie_sumsq_max_partials(void) { return kSumsqMaxBlocks; }
+
+extern "C" int ie_sumsq_partial(const void* x, int dtype, int64_t n, float* partial, int64_t part_offset, int64_t* nparts_out,
+                                void* stream) {
+    IE_CHECK_ARG(x && partial && n >= 0 && part_offset >= 0, "ie_sumsq_partial: bad argument");
+    IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_sumsq_partial: bad dtype");
+    int64_t blocks = (n + 256 * 32 - 1) / (256 * 32);
+    if (blocks > kSumsqMaxBlocks) blocks = kSumsqMaxBlocks;
+    if (blocks < 1) blocks = 1;
+    if (nparts_out) *nparts_out = blocks;
+    if (dtype == IE_BF16)
+        hipLaunchKernelGGL((sumsq_partial_k<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, partial + part_offset);
+    else
+        hipLaunchKernelGGL((sumsq_partial_k<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, partial + part_offset);
+    return ie_launch_status("ie_sumsq_partial launch");
+}
+
+extern "C" int ie_sumsq_finish(const float* partial, int64_t nparts, float* out, int accumulate, void* stream) {
+    IE_CHECK_ARG(partial && out && nparts >= 0, "ie_sumsq_finish: bad argument");
+    hipLaunchKernelGGL(sumsq_finish_k, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nparts, out, accumulate);
+    return ie_launch_status("ie_sumsq_finish launch");
+}
+
+extern "C" int ie_step_state_init(IeStepState* state_dev, float initial_scale, void* stream) {
+    IE_CHECK_ARG(state_dev, "ie_step_state_init: null pointer");
+    hipLaunchKernelGGL(step_state_init_k, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, initial_scale);
+    return ie_launch_status("ie_step_state_init launch");
+}
+
+extern "C" int ie_step_control(IeStepState* state_dev, const float* sumsq_dev, const IeScalerConfig* cfg_host, void* stream) {
+    IE_CHECK_ARG(state_dev && sumsq_dev && cfg_host, "ie_step_control: null pointer");
+    IE_CHECK_ARG(cfg_host->growth_factor > 1.f && cfg_host->backoff_factor > 0.f && cfg_host->backoff_factor < 1.f &&
+                     cfg_host->hysteresis >= 0,
+                 "ie_step_control: bad scaler config");
+    hipLaunchKernelGGL(step_control_k, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, sumsq_dev, *cfg_host);
+    return ie_launch_status("ie_step_control launch");
+}
+
+extern "C" int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n,
+                             const IeStepState* state_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                             void* stream) {
+    IE_CHECK_ARG(g && p32 && m && v && state_dev && n >= 0, "ie_adamw_step: bad argument");
+    IE_CHECK_ARG(g_dtype == IE_BF16 || g_dtype == IE_F32, "ie_adamw_step: bad dtype");
+    if (n == 0) return IE_OK;
+    const int vec_ok = aligned16(p32) && aligned16(m) && aligned16(v) && ((((uintptr_t)g) & (g_dtype == IE_BF16 ? 7u : 15u)) == 0) &&
+                       (!p16 || (((uintptr_t)p16) & 7u) == 0);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    if (g_dtype == IE_BF16)
+        hipLaunchKernelGGL((adamw_k<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n,
+                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok);
+    else
+        hipLaunchKernelGGL((adamw_k<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n,
+                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok);
+    return ie_launch_status("ie_adamw_step launch");
+}

@@ -1,0 +1,385 @@
+"""Thin torch-tensor wrappers over the C ABI (include/internevo_hip.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream.  Every function passes raw
+device pointers + sizes + ``torch.cuda.current_stream().cuda_stream`` to libinternevo_hip.so and raises
+``InternEvoHipError`` on a non-zero return code.  There is no CPU / eager fallback: a tensor that is not
+on a HIP device is a ``ValueError``.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import IE_BF16, IE_F32, IeScalerConfig, IeStepState, InternEvoHipError, check
+
+_DT = {torch.bfloat16: IE_BF16, torch.float32: IE_F32}
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise ValueError("internevo_amd kernels need HIP device tensors (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype}") from None
+
+
+def _contig(t, name):
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ RMSNorm
+def rmsnorm_fwd(x, w, eps):
+    """x [..., C] (bf16|fp32), w [C] -> (y [..., C] in w.dtype, rstd [rows] fp32)."""
+    _contig(x, "x"); _contig(w, "w")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(x.shape, dtype=w.dtype, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_L().ie_rmsnorm_fwd(_p(x), _dt(x), _p(w), _dt(w), _p(y), _p(rstd), rows, C, eps, _stream()), "ie_rmsnorm_fwd")
+    return y, rstd
+
+
+def add_rmsnorm_fwd(a, b, w, eps, r_out=None):
+    """r = bf16(a+b); y = RMSNorm(r).  Returns (r, y, rstd)."""
+    _contig(a, "a"); _contig(b, "b")
+    C = a.shape[-1]
+    rows = a.numel() // C
+    r = torch.empty_like(a) if r_out is None else r_out
+    y = torch.empty_like(a)
+    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    check(_L().ie_add_rmsnorm_fwd(_p(a), _p(b), _p(r), _p(w), _p(y), _p(rstd), rows, C, eps, _stream()), "ie_add_rmsnorm_fwd")
+    return r, y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw_out=None, accumulate=False, partial_ws=None):
+    """Returns (dx [x.dtype], dw [w.dtype]).  dres (optional, x.dtype) is added to dx."""
+    _contig(dy, "dy"); _contig(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    L = _L()
+    nparts = L.ie_rmsnorm_bwd_partials(rows)
+    if partial_ws is None or partial_ws.numel() < nparts * C:
+        partial_ws = torch.empty(nparts * C, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check(L.ie_rmsnorm_bwd(_p(dy), _p(x), _dt(x), _p(w), _dt(w), _p(rstd), _p(dres), _p(dx), _p(partial_ws), rows, C, _stream()),
+          "ie_rmsnorm_bwd")
+    if dw_out is None:
+        dw_out = torch.empty_like(w)
+        accumulate = False
+    check(L.ie_rmsnorm_dw_reduce(_p(partial_ws), nparts, _p(dw_out), _dt(w), C, int(accumulate), _stream()), "ie_rmsnorm_dw_reduce")
+    return dx, dw_out
+
+
+# ------------------------------------------------------------------------------------------ rotary
+def apply_rotary(x1, x2, cos, sin, out1, out2, conj):
+    """rotary_emb.apply_rotary: x1/x2/out1/out2 [B, S, H, half] strided views (last dim stride 1),
+    cos/sin [S, 1, half] or [S, half]."""
+    if x1.dim() == 3:  # packed (total, heads, half)
+        x1, x2, out1, out2 = (t.unsqueeze(0) for t in (x1, x2, out1, out2))
+    B, S, H, half = x1.shape
+    cos2 = cos.reshape(cos.shape[0], cos.shape[-1])
+    sin2 = sin.reshape(sin.shape[0], sin.shape[-1])
+    for t in (x1, x2, out1, out2, cos2, sin2):
+        if t.stride(-1) != 1:
+            raise ValueError("apply_rotary: last dim must have stride 1")
+    if x1.stride() != x2.stride() or out1.stride() != out2.stride():
+        raise ValueError("apply_rotary: x1/x2 (and out1/out2) must share strides")
+    if cos2.stride(0) != sin2.stride(0):
+        raise ValueError("apply_rotary: cos/sin must share strides")
+    if cos2.shape[0] < S:
+        raise ValueError("apply_rotary: cos/sin shorter than seqlen")
+    check(_L().ie_apply_rotary(_p(x1), _p(x2), _p(cos2), _p(sin2), _p(out1), _p(out2), _dt(x1), B, S, H, half,
+                               x1.stride(0), x1.stride(1), x1.stride(2), out1.stride(0), out1.stride(1), out1.stride(2),
+                               cos2.stride(0), int(bool(conj)), _stream()), "ie_apply_rotary")
+
+
+def qkv_rotary_fwd(qkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, q_out=None, kv_out=None):
+    """qkv [T, hkv*(q_per_kv+2)*d] -> q [T, hkv*q_per_kv, d], kv [T, 2, hkv, d]."""
+    _contig(qkv, "qkv")
+    T = qkv.numel() // (hkv * (q_per_kv + 2) * d)
+    if q_out is None:
+        q_out = torch.empty((T, hkv * q_per_kv, d), dtype=qkv.dtype, device=qkv.device)
+    if kv_out is None:
+        kv_out = torch.empty((T, 2, hkv, d), dtype=qkv.dtype, device=qkv.device)
+    check(_L().ie_qkv_rotary_fwd(_p(qkv), _p(cos), _p(sin), _p(pos), _p(q_out), _p(kv_out), T, hkv, q_per_kv, d, int(interleaved),
+                                 _stream()), "ie_qkv_rotary_fwd")
+    return q_out, kv_out
+
+
+def qkv_rotary_bwd(dq, dkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, dqkv_out=None):
+    _contig(dq, "dq"); _contig(dkv, "dkv")
+    T = dq.numel() // (hkv * q_per_kv * d)
+    if dqkv_out is None:
+        dqkv_out = torch.empty((T, hkv * (q_per_kv + 2) * d), dtype=dq.dtype, device=dq.device)
+    check(_L().ie_qkv_rotary_bwd(_p(dq), _p(dkv), _p(cos), _p(sin), _p(pos), _p(dqkv_out), T, hkv, q_per_kv, d, int(interleaved),
+                                 _stream()), "ie_qkv_rotary_bwd")
+    return dqkv_out
+
+
+# ------------------------------------------------------------------------------------------ SwiGLU
+def _rows_ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("expected a 2-D tensor with unit column stride")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def swiglu_fwd(a, b, out=None):
+    rows, cols, lda = _rows_ld(a)
+    _, _, ldb = _rows_ld(b)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=a.dtype, device=a.device)
+    check(_L().ie_swiglu_fwd(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), rows, cols, _stream()), "ie_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(dout, a, b, da=None, db=None, act_out=None):
+    rows, cols, lda = _rows_ld(a)
+    _, _, ldb = _rows_ld(b)
+    _, _, lddo = _rows_ld(dout)
+    if da is None:
+        da = torch.empty((rows, cols), dtype=a.dtype, device=a.device)
+    if db is None:
+        db = torch.empty((rows, cols), dtype=a.dtype, device=a.device)
+    check(_L().ie_swiglu_bwd(_p(dout), lddo, _p(a), lda, _p(b), ldb, _p(da), da.stride(0), _p(db), db.stride(0), _p(act_out),
+                             act_out.stride(0) if act_out is not None else 0, rows, cols, _stream()), "ie_swiglu_bwd")
+    return da, db
+
+
+# ------------------------------------------------------------------------------------------ CE
+def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0):
+    """logits [rows, V] (bf16|fp32, row stride arbitrary), labels int64 [rows] ->
+    (loss_rows fp32, lse fp32, loss_mean fp32[1], count fp32[1])."""
+    rows, V, ld = _rows_ld(logits)
+    _contig(labels, "labels")
+    dev = logits.device
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    L = _L()
+    check(L.ie_ce_fwd(_p(logits), _dt(logits), ld, _p(labels), _p(loss_rows), _p(lse), rows, V, ignore_index, label_smoothing, _stream()),
+          "ie_ce_fwd")
+    check(L.ie_ce_mean(_p(loss_rows), _p(labels), rows, ignore_index, _p(out[0:1]), _p(out[1:2]), _stream()), "ie_ce_mean")
+    return loss_rows, lse, out[0:1], out[1:2]
+
+
+def ce_bwd(logits, labels, lse, dloss, count, dloss_mul=1.0, ignore_index=-100, label_smoothing=0.0, dlogits=None):
+    """dlogits (in place over logits when dlogits is None).  dloss/count are device fp32 scalars."""
+    rows, V, ld = _rows_ld(logits)
+    if dlogits is None:
+        dlogits = logits
+    check(_L().ie_ce_bwd(_p(logits), _p(dlogits), _dt(logits), ld, _p(labels), _p(lse), _p(dloss), dloss_mul, _p(count), rows, V,
+                         ignore_index, label_smoothing, _stream()), "ie_ce_bwd")
+    return dlogits
+
+
+# ------------------------------------------------------------------------------------------ L2 norm
+def sumsq(tensors, out=None, accumulate=False, partial_ws=None):
+    """Squared L2 norm of a tensor or list of tensors (fp32 accumulate) -> fp32[1] on device."""
+    if torch.is_tensor(tensors):
+        tensors = [tensors]
+    L = _L()
+    maxp = L.ie_sumsq_max_partials()
+    dev = tensors[0].device
+    if partial_ws is None or partial_ws.numel() < maxp * len(tensors):
+        partial_ws = torch.empty(maxp * len(tensors), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        accumulate = False
+    off = 0
+    n_out = ctypes.c_int64(0)
+    for t in tensors:
+        t = _contig(t, "tensor")
+        check(L.ie_sumsq_partial(_p(t), _dt(t), t.numel(), _p(partial_ws), off, ctypes.byref(n_out), _stream()), "ie_sumsq_partial")
+        off += n_out.value
+    check(L.ie_sumsq_finish(_p(partial_ws), off, _p(out), int(accumulate), _stream()), "ie_sumsq_finish")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ step control + AdamW
+STATE_BYTES = ctypes.sizeof(IeStepState)
+
+
+def step_state_new(device, initial_scale):
+    st = torch.zeros(STATE_BYTES, dtype=torch.uint8, device=device)
+    check(_L().ie_step_state_init(_p(st), float(initial_scale), _stream()), "ie_step_state_init")
+    return st
+
+
+def step_state_read(st):
+    """Host copy of the device step state (this DOES synchronise; use for logging/tests only)."""
+    raw = bytes(st.cpu().numpy().tobytes())
+    return IeStepState.from_buffer_copy(raw)
+
+
+def step_control(st, sumsq_dev, cfg: IeScalerConfig):
+    check(_L().ie_step_control(_p(st), _p(sumsq_dev), ctypes.byref(cfg), _stream()), "ie_step_control")
+
+
+def adamw_step(g, p32, m, v, p16, st, lr, beta1, beta2, eps, weight_decay):
+    n = p32.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or (p16 is not None and p16.numel() != n):
+        raise ValueError("adamw_step: size mismatch")
+    check(_L().ie_adamw_step(_p(g), _dt(g), _p(p32), _p(m), _p(v), _p(p16), n, _p(st), lr, beta1, beta2, eps, weight_decay, _stream()),
+          "ie_adamw_step")
+
+
+# ------------------------------------------------------------------------------------------ embedding / elementwise
+def embedding_fwd(weight, ids, out=None):
+    V, dim = weight.shape
+    T = ids.numel()
+    if out is None:
+        out = torch.empty((T, dim), dtype=weight.dtype, device=weight.device)
+    check(_L().ie_embedding_fwd(_p(weight), _p(ids), _p(out), T, V, dim, _stream()), "ie_embedding_fwd")
+    return out
+
+
+def embedding_bwd(dout, ids, dweight, accumulate, present_ws=None):
+    V, dim = dweight.shape
+    T = ids.numel()
+    if present_ws is None:
+        present_ws = torch.empty(V, dtype=torch.int32, device=dweight.device)
+    check(_L().ie_embedding_bwd(_p(dout), _p(ids), _p(dweight), _p(present_ws), T, V, dim, int(accumulate), _stream()), "ie_embedding_bwd")
+    return dweight
+
+
+def add_bf16(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(_L().ie_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "ie_add_bf16")
+    return out
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_L().ie_cast(_p(src), _dt(src), _p(out), _dt(out), src.numel(), _stream()), "ie_cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False):
+    """C[M,N] = op(A) @ op(B)  (bf16 in, fp32 accumulate, bf16 out).
+    a_kmajor=False: A is [M,K];  True: A is [K,M].   b_kmajor=False: B is [N,K];  True: B is [K,N]."""
+    if A.dim() != 2 or B.dim() != 2 or A.stride(1) != 1 or B.stride(1) != 1:
+        raise ValueError("gemm: 2-D operands with unit column stride expected")
+    if a_kmajor:
+        K, M = A.shape
+    else:
+        M, K = A.shape
+    if b_kmajor:
+        Kb, N = B.shape
+    else:
+        N, Kb = B.shape
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+        accumulate = False
+    if out.shape != (M, N) or out.stride(1) != 1:
+        raise ValueError("gemm: bad output")
+    check(_L().ie_gemm_bf16(_p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
+                            int(accumulate), _stream()), "ie_gemm_bf16")
+    return out
+
+
+def linear_fwd(x, w, out=None):
+    """y[T,N] = x[T,K] @ w[N,K]^T"""
+    return gemm(x, w, False, False, out)
+
+
+def linear_dgrad(dy, w, out=None):
+    """dx[T,K] = dy[T,N] @ w[N,K]"""
+    return gemm(dy, w, False, True, out)
+
+
+def linear_wgrad(dy, x, out=None, accumulate=False):
+    """dw[N,K] = dy[T,N]^T @ x[T,K]"""
+    return gemm(dy, x, True, True, out, accumulate)
+
+
+def colsum(x, out=None):
+    rows, cols, ld = _rows_ld(x)
+    if out is None:
+        out = torch.empty(cols, dtype=x.dtype, device=x.device)
+    check(_L().ie_colsum_bf16(_p(x), ld, _p(out), rows, cols, _stream()), "ie_colsum_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ flash attention
+def _tok_stride(t, d):
+    # t: [T, H, d] view with strides (ts, d, 1)
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != d:
+        raise ValueError("attention operand must be a [T, H, d] view with strides (ts, d, 1)")
+    return t.stride(0)
+
+
+def flash_attn_fwd(q, k, v, cu_seqlens, max_seqlen, softmax_scale=None, causal=True, out=None):
+    """q [T,hq,d], k/v [T,hkv,d] (views allowed) -> (out [T,hq,d], lse [hq,T] fp32)."""
+    T, hq, d = q.shape
+    hkv = k.shape[1]
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(d)
+    q_ts = _tok_stride(q, d)
+    kv_ts = _tok_stride(k, d)
+    if _tok_stride(v, d) != kv_ts:
+        raise ValueError("k and v must share the token stride")
+    if out is None:
+        out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((hq, T), dtype=torch.float32, device=q.device)
+    if cu_seqlens.dtype != torch.int32:
+        raise ValueError("cu_seqlens must be int32")
+    nseq = cu_seqlens.numel() - 1
+    check(_L().ie_flash_attn_fwd(_p(q), q_ts, _p(k), _p(v), kv_ts, _p(out), _tok_stride(out, d), _p(lse), _p(cu_seqlens), nseq, T,
+                                 int(max_seqlen), hq, hkv, d, float(softmax_scale), int(bool(causal)), _stream()), "ie_flash_attn_fwd")
+    return out, lse
+
+
+def flash_attn_bwd(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale=None, causal=True, dq=None, dk=None, dv=None,
+                   delta_ws=None):
+    T, hq, d = q.shape
+    hkv = k.shape[1]
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(d)
+    if dq is None:
+        dq = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    if dk is None or dv is None:
+        dkv = torch.empty((T, 2, hkv, d), dtype=q.dtype, device=q.device)
+        dk, dv = dkv[:, 0], dkv[:, 1]
+    if delta_ws is None or delta_ws.numel() < hq * T:
+        delta_ws = torch.empty(hq * T, dtype=torch.float32, device=q.device)
+    kv_ts = _tok_stride(k, d)
+    if _tok_stride(v, d) != kv_ts:
+        raise ValueError("k and v must share the token stride")
+    dkv_ts = _tok_stride(dk, d)
+    if _tok_stride(dv, d) != dkv_ts:
+        raise ValueError("dk and dv must share the token stride")
+    nseq = cu_seqlens.numel() - 1
+    check(_L().ie_flash_attn_bwd(_p(dout), _tok_stride(dout, d), _p(q), _tok_stride(q, d), _p(k), _p(v), kv_ts, _p(out),
+                                 _tok_stride(out, d), _p(lse), _p(delta_ws), _p(dq), _tok_stride(dq, d), _p(dk), _p(dv), dkv_ts,
+                                 _p(cu_seqlens), nseq, T, int(max_seqlen), hq, hkv, d, float(softmax_scale), int(bool(causal)),
+                                 _stream()), "ie_flash_attn_bwd")
+    return dq, dk, dv
+
+
+def mfma_probe(a, b):
+    c = torch.empty((32, 32), dtype=torch.float32, device=a.device)
+    check(_L().ie_mfma_probe(_p(a), _p(b), _p(c), _stream()), "ie_mfma_probe")
+    return c

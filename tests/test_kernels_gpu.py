@@ -1,0 +1,391 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (stated per test): bf16 outputs are compared with the oracle's bf16 result allowing a
+couple of bf16 ulps (rtol 1.6e-2) because reduction order / rsqrt / exp differ in the last fp32 bit;
+integer/index work is exact.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O  # noqa: E402  (tests may use the oracle; the product never does)
+
+
+def K():
+    from internevo_amd import kernels
+
+    return kernels
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.numel()} mismatches; max abs err {err.max():.4e}; first at {idx}: "
+            f"got {got[tuple(idx)]:.6e} ref {ref[tuple(idx)]:.6e}; ref absmax {ref.abs().max():.4e}"
+        )
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------- layout pin
+def test_mfma_fragment_layout(dev):
+    a = torch.randint(-4, 5, (32, 16), generator=g(0)).float()
+    b = torch.randint(-4, 5, (16, 32), generator=g(1)).float() + torch.arange(32).float()[None, :] % 3  # asymmetric
+    c = K().mfma_probe(bf(a).to(dev), bf(b).to(dev))
+    close(c, a @ b, 0, 0, "mfma 32x32x16 bf16 layout")
+
+
+# ---------------------------------------------------------------------------------------------- K5
+@pytest.mark.parametrize("rows,cols", [(8, 512), (4096, 4096), (33, 1024), (5, 4), (7, 200), (16, 8192)])
+def test_rmsnorm_fwd_bf16(dev, rows, cols):
+    x = bf(torch.randn(rows, cols, generator=g(2)) * 3)
+    w = bf(1 + 0.1 * torch.randn(cols, generator=g(3)))
+    y, rstd = K().rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    close(y, O.rms_norm(x, w, 1e-5), 8e-3, 1e-6, "rmsnorm fwd")
+    close(rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5), 1e-5, 1e-7, "rstd")
+
+
+@pytest.mark.parametrize("xdt,wdt", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.float32)])
+def test_rmsnorm_fwd_mixed(dev, xdt, wdt):
+    x = (torch.randn(64, 512, generator=g(4)) * 2).to(xdt)
+    w = (1 + 0.1 * torch.randn(512, generator=g(5))).to(wdt)
+    y, _ = K().rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    assert y.dtype == wdt
+    close(y, O.rms_norm(x, w, 1e-5), 8e-3 if wdt == torch.bfloat16 else 2e-6, 1e-6, "rmsnorm mixed")
+
+
+def test_rmsnorm_reference_golden_4x4(dev):
+    # the reference's own known-answer test, tests/test_model/test_norm.py:30-61
+    x = torch.tensor([[-0.0566, 0.8950, -0.1777, 0.1815], [-0.6640, 0.1811, -0.2262, 0.5229],
+                      [-1.9652, -0.1221, -0.4910, -0.4373], [-0.5084, -0.2669, 1.4810, -0.0498]])
+    golden = torch.tensor([[-0.1213, 1.9178, -0.3808, 0.3889], [-1.4620, 0.3987, -0.4980, 1.1514],
+                           [-1.9089, -0.1186, -0.4769, -0.4248], [-0.6343, -0.3330, 1.8477, -0.0621]])
+    y, _ = K().rmsnorm_fwd(x.to(dev), torch.ones(4, device=dev), 1e-5)
+    close(y, golden, 1e-3, 5e-3, "test_norm.py golden")
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 512), (4096, 4096), (9, 1024), (5, 200)])
+def test_add_rmsnorm_fwd(dev, rows, cols):
+    a = bf(torch.randn(rows, cols, generator=g(6)))
+    b = bf(torch.randn(rows, cols, generator=g(7)))
+    w = bf(1 + 0.1 * torch.randn(cols, generator=g(8)))
+    r, y, _ = K().add_rmsnorm_fwd(a.to(dev), b.to(dev), w.to(dev), 1e-5)
+    r_ref = a + b
+    close(r, r_ref, 0, 0, "residual add (bit exact)")
+    close(y, O.rms_norm(r_ref, w, 1e-5), 8e-3, 1e-6, "add+rmsnorm")
+
+
+@pytest.mark.parametrize("rows,cols,res", [(64, 512, False), (4096, 4096, True), (37, 1024, True), (6, 200, True)])
+def test_rmsnorm_bwd(dev, rows, cols, res):
+    x = bf(torch.randn(rows, cols, generator=g(9)))
+    dy = bf(torch.randn(rows, cols, generator=g(10)))
+    w = bf(1 + 0.1 * torch.randn(cols, generator=g(11)))
+    dres = bf(torch.randn(rows, cols, generator=g(12))) if res else None
+    _, rstd = K().rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    dx, dw = K().rmsnorm_bwd(dy.to(dev), x.to(dev), w.to(dev), rstd, dres.to(dev) if res else None)
+    dx_ref, dw_ref = O.rms_norm_bwd_fp32(dy, x, w, 1e-5)
+    if res:
+        dx_ref = dx_ref + dres.float()
+    close(dx, dx_ref, 1.6e-2, 2e-2, "rmsnorm dx")
+    close(dw, dw_ref, 1.6e-2, 2e-2 * math.sqrt(rows), "rmsnorm dw")
+
+
+def test_rmsnorm_bwd_accumulate(dev):
+    x = bf(torch.randn(128, 512, generator=g(13)))
+    dy = bf(torch.randn(128, 512, generator=g(14)))
+    w = bf(torch.ones(512))
+    _, rstd = K().rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    dw0 = bf(torch.randn(512, generator=g(15))).to(dev)
+    dw_acc = dw0.clone()
+    _, dw1 = K().rmsnorm_bwd(dy.to(dev), x.to(dev), w.to(dev), rstd)
+    K().rmsnorm_bwd(dy.to(dev), x.to(dev), w.to(dev), rstd, dw_out=dw_acc, accumulate=True)
+    close(dw_acc, (dw0.float() + dw1.float()).to(torch.bfloat16), 0, 0, "dw accumulate = bf16(old + bf16(new))")
+
+
+# ---------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("conj", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_apply_rotary_generic(dev, conj, dtype):
+    B, S, H, D = 2, 33, 3, 64
+    x = torch.randn(B, S, H, D, generator=g(16)).to(dtype)
+    cos, sin = O.rotary_cos_sin(S, D, dtype=dtype)
+    xd = x.to(dev)
+    out = torch.empty_like(xd)
+    x1, x2 = xd[..., : D // 2], xd[..., D // 2 :]
+    o1, o2 = out[..., : D // 2], out[..., D // 2 :]
+    K().apply_rotary(x1, x2, cos.to(dev)[:, None, :], sin.to(dev)[:, None, :], o1, o2, conj)
+    r1, r2 = O.apply_rotary(x[..., : D // 2], x[..., D // 2 :], cos[:, None, :], sin[:, None, :], conj)
+    close(out, torch.cat([r1, r2], -1), 8e-3 if dtype == torch.bfloat16 else 1e-6, 1e-6, "apply_rotary")
+
+
+def test_apply_rotary_inplace_interleaved_view(dev):
+    # q1 = q[..., ::2] style strided views are NOT unit-stride; the reference only ever passes chunk() halves
+    S, H, D = 17, 4, 128
+    x = bf(torch.randn(1, S, H, D, generator=g(17)))
+    cos, sin = O.rotary_cos_sin(S, D)
+    xd = x.to(dev).clone()
+    K().apply_rotary(xd[..., :64], xd[..., 64:], cos.to(dev)[:, None], sin.to(dev)[:, None], xd[..., :64], xd[..., 64:], False)
+    r1, r2 = O.apply_rotary(x[..., :64], x[..., 64:], cos[:, None, :], sin[:, None, :])
+    close(xd, torch.cat([r1, r2], -1), 8e-3, 1e-6, "apply_rotary in place")
+
+
+@pytest.mark.parametrize("d,hkv,qpk,T,interleaved", [(128, 8, 4, 256, True), (64, 2, 4, 100, True), (128, 2, 1, 64, False), (64, 1, 2, 33, True)])
+def test_qkv_rotary_fwd_bwd(dev, d, hkv, qpk, T, interleaved):
+    qkv = bf(torch.randn(T, hkv * (qpk + 2) * d, generator=g(18)))
+    cos, sin = O.rotary_cos_sin(512, d)
+    pos = torch.randint(0, 512, (T,), generator=g(19))
+    q, kv = K().qkv_rotary_fwd(qkv.to(dev), cos.to(dev), sin.to(dev), pos.to(dev), hkv, qpk, d, interleaved)
+    q_ref, kv_ref = O.qkv_split_rotary(qkv, cos, sin, pos, hkv, qpk, d, interleaved)
+    close(q, q_ref, 8e-3, 1e-6, "qkv_rotary q")
+    close(kv, kv_ref, 8e-3, 1e-6, "qkv_rotary kv")
+    # backward = adjoint: check with fp32 autograd of the oracle
+    x32 = qkv.float().requires_grad_(True)
+    q32, kv32 = O.qkv_split_rotary(x32, cos.float(), sin.float(), pos, hkv, qpk, d, interleaved)
+    dq = bf(torch.randn(q32.shape, generator=g(20)))
+    dkv = bf(torch.randn(kv32.shape, generator=g(21)))
+    (q32 * dq.float()).sum().backward(retain_graph=True)
+    (kv32 * dkv.float()).sum().backward()
+    dqkv = K().qkv_rotary_bwd(dq.to(dev), dkv.to(dev), cos.to(dev), sin.to(dev), pos.to(dev), hkv, qpk, d, interleaved)
+    close(dqkv, x32.grad, 8e-3, 1e-6, "qkv_rotary bwd")
+
+
+# ---------------------------------------------------------------------------------------------- K8
+@pytest.mark.parametrize("rows,cols", [(16, 1792), (4096, 14336), (3, 8)])
+def test_swiglu(dev, rows, cols):
+    ab = bf(torch.randn(rows, 2 * cols, generator=g(22)) * 2)
+    a, b = ab[:, :cols], ab[:, cols:]
+    abd = ab.to(dev)
+    out = K().swiglu_fwd(abd[:, :cols], abd[:, cols:])
+    close(out, O.swiglu(a, b), 4e-3, 1e-30, "swiglu fwd (<= 1 bf16 ulp)")
+    do = bf(torch.randn(rows, cols, generator=g(23)))
+    a32, b32 = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    (O.swiglu(a32, b32) * do.float()).sum().backward()
+    act = torch.empty(rows, cols, dtype=torch.bfloat16, device=dev)
+    da, db = K().swiglu_bwd(do.to(dev), abd[:, :cols], abd[:, cols:], act_out=act)
+    close(da, a32.grad, 2e-2, 1e-3, "swiglu da")
+    close(db, b32.grad, 2e-2, 1e-3, "swiglu db")
+    close(act, O.swiglu(a, b), 4e-3, 1e-30, "swiglu recomputed act")
+
+
+# ---------------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("rows,V,dtype,ls", [(64, 1024, torch.bfloat16, 0.0), (16, 92544, torch.bfloat16, 0.0), (33, 1000, torch.float32, 0.0),
+                                             (20, 517, torch.bfloat16, 0.0), (32, 1024, torch.float32, 0.1)])
+def test_cross_entropy(dev, rows, V, dtype, ls):
+    logits = (torch.randn(rows, V, generator=g(24)) * 3).to(dtype)
+    labels = torch.randint(0, V, (rows,), generator=g(25))
+    labels[::5] = -100
+    lo32 = logits.float().requires_grad_(True)
+    ref = O.cross_entropy(lo32, labels, ls)
+    ref.backward()
+    ld = logits.to(dev).clone()
+    loss_rows, lse, loss, count = K().ce_fwd(ld, labels.to(dev), -100, ls)
+    close(loss, ref.reshape(1), 2e-5, 1e-5, "CE mean loss")
+    close(count, torch.tensor([float((labels != -100).sum())]), 0, 0, "CE count")
+    close(lse, torch.logsumexp(logits.float(), -1), 2e-5, 1e-5, "CE lse")
+    dloss = torch.tensor([3.0], device=dev)
+    K().ce_bwd(ld, labels.to(dev), lse, dloss, count, 0.5, -100, ls)  # in place; grad_out = 3 * 0.5
+    close(ld, lo32.grad * 1.5, 1.6e-2 if dtype == torch.bfloat16 else 1e-4, 1e-6, "CE dlogits (in place)")
+
+
+# ---------------------------------------------------------------------------------------------- K6
+@pytest.mark.parametrize("n,dtype", [(1, torch.bfloat16), (1000003, torch.bfloat16), (4096 * 4096, torch.bfloat16), (77777, torch.float32)])
+def test_sumsq(dev, n, dtype):
+    x = torch.randn(n, generator=g(26)).to(dtype)
+    got = K().sumsq(x.to(dev))
+    close(got, x.double().pow(2).sum().float().reshape(1), 1e-5, 0, "sumsq")
+
+
+def test_sumsq_list_and_overflow(dev):
+    xs = [bf(torch.randn(n, generator=g(27 + i))) for i, n in enumerate([5, 4096, 100001])]
+    got = K().sumsq([x.to(dev) for x in xs])
+    close(got.sqrt(), O.l2_norm(xs).reshape(1), 1e-5, 0, "multi-tensor l2norm")
+    bad = xs[1].clone()
+    bad[7] = float("inf")
+    assert math.isinf(K().sumsq(bad.to(dev)).item())
+    bad[7] = float("nan")
+    assert math.isnan(K().sumsq(bad.to(dev)).item())
+
+
+# ---------------------------------------------------------------------------------------------- a15 / a17
+def test_step_control_matches_reference_logic(dev):
+    from internevo_amd._lib import IeScalerConfig
+
+    k = K()
+    cfg = IeScalerConfig(2.0, 0.5, 1.0, float(2**24), 3, 2, 1.0, 1)  # growth every 3 clean steps for the test
+    st = k.step_state_new(dev, 2.0**16)
+    ref = O.DynamicGradScaler(2**16, 2, 0.5, 3, 1, 2**24, 2)
+    seq = [4.0e9, float("inf"), 1.0e8, float("inf"), float("inf"), 9.0e6, 1e3, float("nan"), 2.5e9, 1e2, 1e2, 1e2]
+    adam_steps = 0
+    for ss in seq:
+        k.step_control(st, torch.tensor([ss], device=dev), cfg)
+        s = k.step_state_read(st)
+        backup = ref.scale
+        found_inf, found_nan = math.isinf(ss), math.isnan(ss)
+        ref.update(found_inf)
+        assert s.loss_scale == ref.scale and s.growth_step == ref.growth_step and s.hysteresis_step == ref.hysteresis_step
+        assert s.loss_scale_used == backup
+        assert s.skip == int(found_inf or found_nan)
+        if not s.skip:
+            adam_steps += 1
+            norm = ss**0.5
+            comb = O.unscale_clip_factor(norm, backup, 1.0)
+            assert abs(s.inv_scale - 1.0 / comb) <= 1e-7 / comb
+            assert abs(s.grad_norm - norm / backup) <= 1e-6 * norm / backup
+        assert s.adam_step == adam_steps
+
+
+def test_adamw_matches_torch(dev):
+    k = K()
+    from internevo_amd._lib import IeScalerConfig
+
+    n = 100003
+    p0 = torch.randn(n, generator=g(30))
+    p_ref, m_ref, v_ref = p0.clone(), torch.zeros(n), torch.zeros(n)
+    p32, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    st = k.step_state_new(dev, 65536.0)
+    cfg = IeScalerConfig(2.0, 0.5, 1.0, float(2**24), 1000, 2, 1.0, 1)
+    lr, b1, b2, eps, wd = 1e-4, 0.9, 0.95, 1e-8, 0.01
+    for step in range(1, 4):
+        gr = bf(torch.randn(n, generator=g(30 + step)) * 65536 * 0.01)
+        ss = k.sumsq(gr.to(dev))
+        k.step_control(st, ss, cfg)
+        k.adamw_step(gr.to(dev), p32, m, v, p16, st, lr, b1, b2, eps, wd)
+        norm = float(gr.double().pow(2).sum().sqrt())
+        comb = O.unscale_clip_factor(norm, 65536.0, 1.0)
+        g32 = gr.float() * (1.0 / comb)
+        O.adamw_step(p_ref, g32, m_ref, v_ref, step, lr, b1, b2, eps, wd)
+        close(p32, p_ref, 2e-6, 1e-7, f"adam p step {step}")
+        close(m, m_ref, 2e-5, 1e-9, f"adam m step {step}")
+        close(v, v_ref, 2e-5, 1e-12, f"adam v step {step}")
+        close(p16, p_ref.to(torch.bfloat16), 8e-3, 0, "bf16 shadow")
+    # a skipped step leaves everything untouched
+    k.step_control(st, torch.tensor([float("inf")], device=dev), cfg)
+    before = p32.clone()
+    k.adamw_step(gr.to(dev), p32, m, v, p16, st, lr, b1, b2, eps, wd)
+    assert torch.equal(before, p32)
+
+
+# ---------------------------------------------------------------------------------------------- a10
+def test_embedding(dev):
+    V, dim, T = 1000, 512, 300
+    w = bf(torch.randn(V, dim, generator=g(40)))
+    ids = torch.randint(0, 30, (T,), generator=g(41))
+    ids[5] = 999
+    out = K().embedding_fwd(w.to(dev), ids.to(dev))
+    close(out, w[ids], 0, 0, "embedding fwd (exact)")
+    dout = bf(torch.randn(T, dim, generator=g(42)))
+    dw = torch.full((V, dim), 7.0, dtype=torch.bfloat16, device=dev)
+    K().embedding_bwd(dout.to(dev), ids.to(dev), dw, accumulate=False)
+    ref = torch.zeros(V, dim).index_add_(0, ids, dout.float())
+    close(dw, ref, 8e-3, 1e-3, "embedding bwd")
+    K().embedding_bwd(dout.to(dev), ids.to(dev), dw, accumulate=True)
+    close(dw, 2 * ref, 1.6e-2, 2e-3, "embedding bwd accumulate")
+
+
+def test_add_and_cast(dev):
+    a = bf(torch.randn(100003, generator=g(43)))
+    b = bf(torch.randn(100003, generator=g(44)))
+    close(K().add_bf16(a.to(dev), b.to(dev)), a + b, 0, 0, "add (exact)")
+    x = torch.randn(4099, generator=g(45))
+    close(K().cast(x.to(dev), torch.bfloat16), x.to(torch.bfloat16), 0, 0, "cast fp32->bf16 (exact RNE)")
+
+
+# ---------------------------------------------------------------------------------------------- K3
+GEMM_SHAPES = [(128, 128, 64), (256, 256, 256), (128, 384, 512), (200, 136, 72), (8, 8, 8), (1000, 1016, 200), (512, 1792, 512)]
+
+
+@pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_small(dev, M, N, Kd, akm, bkm):
+    A = bf(torch.randn((Kd, M) if akm else (M, Kd), generator=g(50)))
+    B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(51)))
+    ref = (A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t())
+    C = K().gemm(A.to(dev), B.to(dev), akm, bkm)
+    close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"gemm {M}x{N}x{Kd} akm={akm} bkm={bkm}")
+
+
+def test_gemm_accumulate_and_strided(dev):
+    M, N, Kd = 256, 384, 320
+    Abig = bf(torch.randn(M, Kd + 64, generator=g(52)))
+    B = bf(torch.randn(N, Kd, generator=g(53)))
+    A = Abig[:, :Kd]
+    C0 = bf(torch.randn(M, N, generator=g(54)))
+    Cd = C0.to(dev).clone()
+    K().gemm(Abig.to(dev)[:, :Kd], B.to(dev), out=Cd, accumulate=True)
+    prod = (A.float() @ B.float().t()).to(torch.bfloat16)
+    close(Cd, (C0.float() + prod.float()).to(torch.bfloat16), 8e-3, 6e-2, "gemm accumulate")
+
+
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True)])
+def test_gemm_large_vs_torch(dev, akm, bkm):
+    M, N, Kd = 4096, 4096, 4096
+    A = bf(torch.randn((Kd, M) if akm else (M, Kd), generator=g(55))).to(dev)
+    B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(56))).to(dev)
+    ref = (A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t())  # torch fp32 on GPU: test reference only
+    C = K().gemm(A, B, akm, bkm)
+    close(C, ref, 8e-3, 0.5, "gemm 4096^3")
+
+
+# ---------------------------------------------------------------------------------------------- K1
+def _attn_case(dev, lens, hq, hkv, d, causal, seed):
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(seed)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(seed + 1)))
+    do = bf(torch.randn(T, hq, d, generator=g(seed + 2)))
+    q32, kv32 = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, causal)
+    (ref * do.float()).sum().backward()
+    qd, kvd = q.to(dev), kv.to(dev)
+    out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), None, causal)
+    close(out, ref, 1.6e-2, 2e-2, f"flash fwd lens={lens} hq={hq} hkv={hkv} d={d} causal={causal}")
+    dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
+    close(dq, q32.grad, 2e-2, 3e-2, "flash dq")
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "flash dk")
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "flash dv")
+
+
+@pytest.mark.parametrize("lens,hq,hkv,d,causal", [
+    ([128], 4, 4, 128, True),
+    ([64], 2, 1, 64, True),
+    ([256], 8, 2, 128, True),
+    ([37, 200, 19], 4, 1, 128, True),
+    ([1, 129, 300, 64], 4, 2, 64, True),
+    ([100, 157], 2, 2, 128, False),
+    ([512], 8, 2, 64, True),
+])
+def test_flash_attention(dev, lens, hq, hkv, d, causal):
+    _attn_case(dev, lens, hq, hkv, d, causal, 60)
+
+
+def test_flash_attention_lse_and_big_scores(dev):
+    # large-magnitude scores exercise the online-softmax rescale path (guide section 5.4 rule 26)
+    T, hq, hkv, d = 300, 2, 1, 128
+    cu = torch.tensor([0, T], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(70)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(71)))
+    kv[200, 0] *= 12.0  # one spiky key late in the sequence
+    out, lse = K().flash_attn_fwd(q.to(dev), kv.to(dev)[:, 0], kv.to(dev)[:, 1], cu.to(dev), T, None, True)
+    ref = O.attention_varlen(q.float(), kv.float(), cu, True)
+    close(out, ref, 1.6e-2, 2e-2, "flash fwd with spike")
+    k = kv[:, 0].float().repeat_interleave(hq // hkv, 1)
+    s = torch.einsum("thd,shd->hts", q.float(), k) / math.sqrt(d)
+    s = s.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
+    close(lse, torch.logsumexp(s, -1), 1e-3, 1e-2, "flash lse")
