@@ -1,0 +1,206 @@
+"""Benchmark of the hot path: full training steps of InternLM2-7B (bf16, seq 4096, micro_bsz 1 x micro_num 4,
+ZeRO-1 over the data-parallel group) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = NonPipelineScheduler.forward_backward_step over micro_num micro-batches + HybridZeroOptimizer.step
+(forward, backward, gradient exchange, grad-norm, loss-scale logic, AdamW, parameter exchange) on synthetic
+data of the reference's RandomDataset/packed shape, random-init weights.  Rank 0 prints ONE JSON line.
+
+metric/value : whole-job tokens/s (= TGS x n_gpus); `tgs` and the two TFLOPS/GPU figures (reference Megatron
+               formula internlm/utils/common.py:208-238, and exact causal-aware GQA count) are in the same line.
+roofline     : the dominant kernel (the bf16 MFMA GEMM, ~85 % of step flops): algorithmic flops per launch /
+               average launch duration measured with HIP events on the launch stream over the timed region,
+               against the 2.5 PFLOP/s dense bf16 MFMA peak.
+cpu_baseline : the CPU oracle (oracle/, a restatement of the reference's pure-torch path) timed on this box's
+               host cores on a bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK = 2.5e15  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def exact_flops_per_token(mc, seq_len, causal=True):
+    """fwd+bwd algorithmic flops per token, GQA-aware (47.37 GFLOP causal / 50.59 dense at 7B, s=4096)."""
+    h, f, v = mc.hidden_size, mc.ffn_dim, mc.vocab_size
+    lin = 2 * (mc.qkv_dim * h + h * h + 3 * f * h)
+    attn = 4 * seq_len * h * (0.5 if causal else 1.0)
+    return 3 * ((lin + attn) * mc.num_layers + 2 * v * h)
+
+
+def cpu_baseline(cfg, budget_note=True):
+    """Time the CPU oracle on a bounded sample of the same workload: one 4096-token micro-batch through a
+    7B-shaped model with 0 and with 1 transformer layer (fwd + bwd + optimizer), extrapolated linearly to
+    the full depth.  ~10-40 s of host work."""
+    import copy
+
+    from oracle.step import OracleTrainer
+
+    threads = torch.get_num_threads()
+    tc = cfg.train
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 30, (1, tc.packed_length), generator=gen)
+    labels = torch.cat([ids[:, 1:], torch.full((1, 1), -100)], 1)
+    times = {}
+    for nl in (0, 1):
+        c = copy.deepcopy(cfg)
+        c.model.num_layers = nl
+        c.train.micro_num = 1
+        tr = OracleTrainer(c, torch.bfloat16, init_fn=lambda n, s: torch.empty(s).normal_(0, 0.02, generator=gen) if len(s) > 1 else torch.ones(s))
+        batch = {"input_ids": ids, "cu_seqlens": None, "indexes": None}
+        t0 = time.time()
+        tr.train_step(batch, labels)
+        times[nl] = time.time() - t0
+        del tr
+    t_layer = max(times[1] - times[0], 1e-9)
+    full = times[0] + cfg.model.num_layers * t_layer
+    return {
+        "value": tc.packed_length / full,
+        "unit": "tokens/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle fwd+bwd+AdamW of one {tc.packed_length}-token micro-batch, 7B-shaped model with 0 layers ({times[0]:.2f} s) and 1 layer "
+                  f"({times[1]:.2f} s), linearly extrapolated to {cfg.model.num_layers} layers ({full:.1f} s); torch CPU bf16, {threads} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="7B_internlm2", choices=["7B_internlm2", "tiny"])
+    ap.add_argument("--seq-len", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from internevo_amd import kernels as K
+    from internevo_amd.config import internlm2_7b, tiny
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    cfg = internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else tiny(seq_len=min(args.seq_len, 256))
+    cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
+    tc, mc = cfg.train, cfg.model
+    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024)
+    if world > 1:
+        eng.comm.broadcast_params(eng.params)
+        eng.sync_master_from_params()
+    loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, 1_000_000 if args.config != "tiny" else 4000,
+                                  data_rank=rank, data_world_size=world))
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    prof = None
+    if not args.no_kernel_timing:
+        prof = K.KernelProfiler()
+        K.GEMM_PROFILER = prof
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    K.GEMM_PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    st = eng.read_state()
+    loss_val = float(loss)
+
+    tokens_step = tc.packed_length * tc.micro_num * world
+    sec_step = dt / args.steps
+    total_tps = tokens_step / sec_step
+    tgs = total_tps / world
+    # reference metric (train/pipeline.py:500-556 + utils/common.py:208-238)
+    ref_flops_tok = (3 * ((8 + mc.mlp_ratio * 1.5 * 4) * mc.hidden_size**2 + 4 * tc.seq_len * mc.hidden_size) * mc.num_layers
+                     + 6 * mc.hidden_size * mc.vocab_size)
+    out = {
+        "metric": "tokens_per_second (TGS x n_gpus), InternLM2-7B bf16 seq4096 training step" if args.config == "7B_internlm2" else "tokens_per_second (tiny plumbing config)",
+        "value": total_tps,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": sec_step * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (reference RandomDataset/PackedDatasetWithCut shape, fixed_random_dataset_seqlen=True), random-init weights",
+        "config": {"workload": f"configs/7B_internlm2.py (BASELINE.json configs[1]): InternLM2-7B, seq_len {tc.seq_len}, micro_bsz {tc.micro_bsz} x micro_num {tc.micro_num} per GPU, "
+                               f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2" else "tiny InternLM2 (hidden 512, 2 layers)",
+                   "tokens_per_step": tokens_step, "parallelism": f"dp{world}"},
+        "tgs": tgs,
+        "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
+        "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,
+        "frac_bf16_mfma_peak": exact_flops_per_token(mc, tc.seq_len) * tgs / MFMA_PEAK,
+        "loss_last_step": loss_val,
+        "grad_norm_last_step": st.grad_norm,
+        "loss_scale": st.loss_scale,
+        "skipped_steps": st.skipped_total,
+    }
+    if prof is not None:
+        s = prof.summary()
+        ach = s["flops"] / max(s["seconds"], 1e-12)
+        out["roofline"] = {
+            "kernel": "gemm_bf16_k (v_mfma_f32_32x32x16_bf16; fwd/dgrad/wgrad of every linear layer)",
+            "bound": "mfma",
+            "achieved": ach / 1e12,
+            "peak": MFMA_PEAK / 1e12,
+            "unit": "TFLOP/s",
+            "frac": ach / MFMA_PEAK,
+            "traffic": None,
+            "launches": s["launches"],
+            "avg_launch_us": s["avg_us"],
+            "algorithmic_flops_per_launch": s["flops"] / max(s["launches"], 1),
+            "share_of_step_time": s["seconds"] / dt,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        except Exception as e:  # the baseline must never take the measurement down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,15 +50,13 @@ int ie_add_rmsnorm_fwd(const void* a, const void* b, void* r_out, const void* w,
                        int64_t rows, int64_t cols, float eps, void* stream);
 
 /* Backward.  dx = rstd * (dy*w - xhat * mean(dy*w*xhat)); if dres != NULL, dx += dres (the gradient
- * that reaches the same tensor through the residual connection).  dw partials: dw_partial
- * [ie_rmsnorm_bwd_partials(rows)][cols] fp32 workspace; finish with ie_rmsnorm_dw_reduce. */
+ * that reaches the same tensor through the residual connection).  dw (w's dtype) = [accumulate ? dw : 0]
+ * + sum_rows dy * xhat, reduced deterministically through dw_partial, an fp32 workspace of
+ * ie_rmsnorm_bwd_partials(rows) * cols elements. */
 int64_t ie_rmsnorm_bwd_partials(int64_t rows);
 int ie_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype,
-                   const float* rstd, const void* dres, void* dx, float* dw_partial, int64_t rows,
-                   int64_t cols, void* stream);
-/* dw (w's dtype) = [accumulate ? dw : 0] + sum_p dw_partial[p][:] */
-int ie_rmsnorm_dw_reduce(const float* dw_partial, int64_t nparts, void* dw, int w_dtype, int64_t cols,
-                         int accumulate, void* stream);
+                   const float* rstd, const void* dres, void* dx, float* dw_partial, void* dw,
+                   int accumulate, int64_t rows, int64_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K2  Rotary.  ie_apply_rotary replaces rotary_emb.apply_rotary(x1, x2, cos, sin, out1, out2, conj)
@@ -174,11 +172,11 @@ int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, float* v, vo
 
 /* ------------------------------------------------------------------------------------------------
  * a10 Embedding.  F.embedding fwd (internlm/model/modules/embedding.py:52-60) and its dense
- *     backward (scatter-add), deterministic, fp32 accumulate.  present: int32[vocab] workspace.
+ *     backward (scatter-add), deterministic, fp32 accumulate.  ws: int32[vocab + 1 + T] workspace.
  * ---------------------------------------------------------------------------------------------- */
 int ie_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t T, int64_t vocab,
                      int64_t dim, void* stream);
-int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* present, int64_t T,
+int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* ws, int64_t T,
                      int64_t vocab, int64_t dim, int accumulate, void* stream);
 
 /* elementwise helpers used around the path */

@@ -64,8 +64,7 @@ SIGNATURES = {
     "ie_rmsnorm_fwd": (I, [P, I, P, I, P, P, I64, I64, F, P]),
     "ie_add_rmsnorm_fwd": (I, [P, P, P, P, P, P, I64, I64, F, P]),
     "ie_rmsnorm_bwd_partials": (I64, [I64]),
-    "ie_rmsnorm_bwd": (I, [P, P, I, P, I, P, P, P, P, I64, I64, P]),
-    "ie_rmsnorm_dw_reduce": (I, [P, I64, P, I, I64, I, P]),
+    "ie_rmsnorm_bwd": (I, [P, P, I, P, I, P, P, P, P, P, I, I64, I64, P]),
     "ie_apply_rotary": (I, [P, P, P, P, P, P, I, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, P]),
     "ie_qkv_rotary_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),
     "ie_qkv_rotary_bwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),

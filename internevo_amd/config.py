@@ -1,0 +1,161 @@
+"""Configuration of the hot path, read from the reference's own `configs/*.py` schema.
+
+`load_reference_config(path)` executes an InternEvo config file exactly like
+internlm/core/context/parallel_context.py:77-127 (Config.from_file: the .py is run and its module
+globals become the config) and maps the keys the training step needs onto `PathConfig`.
+Anything the path does not implement (pipeline parallel, MoE, checkpointing ...) is rejected loudly
+instead of being ignored.
+"""
+import dataclasses
+import math
+import runpy
+from typing import Optional
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    # configs/7B_internlm2.py:5-11,122-141
+    vocab_size: int = 92544
+    hidden_size: int = 4096
+    num_layers: int = 32
+    num_attention_heads: int = 32
+    num_kv_attention_heads: int = 8
+    mlp_ratio: float = 3.5
+    layer_norm_epsilon: float = 1e-5
+    rope_base: int = 10000
+    adapt_hf: bool = True           # builder default (modeling_internlm2.py:1071); False = even/odd de-interleave before rotary (:425-427)
+    multiple_of: int = 256          # modules/mlp.py:52
+    dtype: str = "torch.bfloat16"
+    # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
+    init_std: float = 0.02
+    use_scaled_init: bool = True
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def q_per_kv(self):
+        return self.num_attention_heads // self.num_kv_attention_heads
+
+    @property
+    def qkv_dim(self):
+        return (self.num_attention_heads + 2 * self.num_kv_attention_heads) * self.head_dim
+
+    @property
+    def ffn_dim(self):
+        f = int(self.hidden_size * self.mlp_ratio)
+        return self.multiple_of * ((f + self.multiple_of - 1) // self.multiple_of)
+
+    def num_params(self):
+        h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size
+        per_layer = self.qkv_dim * h + h * h + 3 * f * h + 2 * h
+        return per_layer * self.num_layers + 2 * v * h + h
+
+
+@dataclasses.dataclass
+class TrainConfig:
+    seq_len: int = 4096
+    micro_bsz: int = 1
+    micro_num: int = 4
+    total_steps: int = 20
+    fixed_random_dataset_seqlen: bool = False
+    # adam (configs/7B_internlm2.py:92-99)
+    lr: float = 1e-4
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.95
+    adam_beta2_c: float = 0.0
+    adam_eps: float = 1e-8
+    weight_decay: float = 0.01
+    # lr scheduler (:101-107)
+    warmup_ratio: float = 0.01
+    eta_min: float = 1e-5
+    init_steps: int = 0
+    # grad scaler (:73-83) / hybrid zero (:84-89)
+    initial_scale: float = 2.0**16
+    min_scale: float = 1.0
+    growth_interval: int = 1000
+    growth_factor: float = 2.0
+    backoff_factor: float = 0.5
+    max_scale: float = 2.0**24
+    hysteresis: int = 2
+    clip_grad_norm: float = 1.0
+    label_smoothing: float = 0.0
+    zero1_size: int = -1
+
+    @property
+    def packed_length(self):
+        return self.seq_len * self.micro_bsz
+
+
+@dataclasses.dataclass
+class PathConfig:
+    model: ModelConfig
+    train: TrainConfig
+
+
+_UNSUPPORTED = "internevo_amd implements the data-parallel InternLM2 hot path only"
+
+
+def _parse_dtype(s):
+    s = str(s)
+    return s if s.startswith("torch.") else "torch." + s
+
+
+def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
+    m, d = cfg["model"], cfg["data"]
+    par = cfg.get("parallel", {})
+    if par.get("pipeline", {}).get("size", 1) != 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallel size must be 1")
+    if par.get("tensor", {}).get("size", 1) != 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: tensor/sequence parallel size must be 1 (round 1)")
+    if cfg.get("model_type", "INTERNLM2_PUBLIC") not in ("INTERNLM2_PUBLIC",):
+        raise NotImplementedError(f"{_UNSUPPORTED}: model_type {cfg.get('model_type')}")
+    if m.get("num_experts", 1) > 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: MoE")
+    if m.get("checkpoint", False) not in (False, 0, 0.0):
+        raise NotImplementedError(f"{_UNSUPPORTED}: activation checkpointing (not needed with 288 GB HBM)")
+    if not m.get("no_bias", True):
+        raise NotImplementedError(f"{_UNSUPPORTED}: linear bias")
+    if _parse_dtype(m.get("dtype", "torch.bfloat16")) != "torch.bfloat16":
+        raise NotImplementedError(f"{_UNSUPPORTED}: the HIP path computes in bf16")
+    model = ModelConfig(
+        vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], num_layers=m["num_layers"],
+        num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
+        mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
+        adapt_hf=m.get("adapt_hf", True),
+    )
+    adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
+    hz = cfg["hybrid_zero_optimizer"]
+    train = TrainConfig(
+        seq_len=seq_len or d["seq_len"], micro_bsz=d["micro_bsz"], micro_num=d["micro_num"], total_steps=d["total_steps"],
+        fixed_random_dataset_seqlen=d.get("fixed_random_dataset_seqlen", False),
+        lr=adam["lr"], adam_beta1=adam["adam_beta1"], adam_beta2=adam["adam_beta2"], adam_beta2_c=adam.get("adam_beta2_c", 0),
+        adam_eps=adam["adam_eps"], weight_decay=adam["weight_decay"],
+        warmup_ratio=ls.get("warmup_ratio", 0.0), eta_min=ls.get("eta_min", 0.0), init_steps=ls.get("init_steps", 0),
+        initial_scale=gs["fp16"]["initial_scale"], min_scale=gs["fp16"].get("min_scale", 1), growth_interval=gs["fp16"]["growth_interval"],
+        growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
+        clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
+        zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
+    )
+    return PathConfig(model, train)
+
+
+def load_reference_config(path: str, seq_len: Optional[int] = None) -> PathConfig:
+    """Run an InternEvo `configs/*.py` and map it (parallel_context.py:77-127 semantics)."""
+    g = runpy.run_path(path)
+    cfg = {k: v for k, v in g.items() if not k.startswith("__")}
+    return from_reference_dict(cfg, seq_len)
+
+
+def internlm2_7b(seq_len=4096) -> PathConfig:
+    """configs/7B_internlm2.py with BASELINE.json's seq-4096 override."""
+    return PathConfig(ModelConfig(), TrainConfig(seq_len=seq_len))
+
+
+def tiny(hidden=512, layers=2, heads=8, kv_heads=2, vocab=1024, seq_len=256, micro_num=2, lr=1e-3, total_steps=5) -> PathConfig:
+    """BASELINE.json configs[0]: the CPU-runnable plumbing case (SURVEY.md section 8d "tiny config")."""
+    return PathConfig(
+        ModelConfig(vocab_size=vocab, hidden_size=hidden, num_layers=layers, num_attention_heads=heads, num_kv_attention_heads=kv_heads),
+        TrainConfig(seq_len=seq_len, micro_bsz=1, micro_num=micro_num, total_steps=total_steps, lr=lr, fixed_random_dataset_seqlen=True),
+    )

@@ -238,50 +238,39 @@ __global__ __launch_bounds__(256) void embedding_fwd_k(const bf16_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void embedding_mark_k(const int64_t* __restrict__ ids, int* __restrict__ present, int64_t T,
-                                                        int64_t vocab) {
+// ws layout (int32): present[vocab] | count | list[T]
+__global__ __launch_bounds__(256) void embedding_mark_k(const int64_t* __restrict__ ids, int* __restrict__ ws, int64_t T, int64_t vocab) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) {
         const int64_t id = ids[t];
-        if (id >= 0 && id < vocab) present[id] = 1;
+        if (id >= 0 && id < vocab) {
+            if (atomicExch(&ws[id], 1) == 0) {
+                const int slot = atomicAdd(&ws[vocab], 1);
+                ws[vocab + 1 + slot] = (int)id;
+            }
+        }
     }
 }
 
-// One block per vocabulary row; rows nobody referenced exit at once.  Tokens are visited in index
-// order and summed in fp32, so the result is deterministic (torch's CUDA embedding backward also
-// accumulates in fp32 per row).
+// grid (max distinct rows, column chunks of 256).  Each block owns one referenced vocabulary row and
+// 256 columns; tokens are visited in index order and summed in fp32, so the result is deterministic
+// whatever order the rows were appended to the list in (torch's embedding backward also accumulates
+// in fp32 per row).  Rows nobody referenced are left untouched (accumulate) or were zeroed (memset).
 __global__ __launch_bounds__(256) void embedding_bwd_k(const bf16_t* __restrict__ dout, const int64_t* __restrict__ ids,
-                                                       bf16_t* __restrict__ dw, const int* __restrict__ present, int64_t T,
+                                                       bf16_t* __restrict__ dw, const int* __restrict__ ws, int64_t T, int64_t vocab,
                                                        int64_t dim, int accumulate) {
-    const int64_t v = blockIdx.x;
-    const bool hit = present[v] != 0;
-    if (!hit) {
-        if (!accumulate)
-            for (int64_t c = threadIdx.x; c < dim; c += blockDim.x) dw[v * dim + c] = 0;
-        return;
+    if ((int)blockIdx.x >= ws[vocab]) return;
+    const int64_t v = ws[vocab + 1 + blockIdx.x];
+    const int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    float acc = 0.f;
+    for (int64_t t = 0; t < T; ++t) {
+        if (ids[t] != v) continue;  // block-uniform branch
+        if (c < dim) acc += bf2f(dout[t * dim + c]);
     }
-    constexpr int KC = 8;  // columns per thread per pass
-    for (int64_t cbase = 0; cbase < dim; cbase += (int64_t)blockDim.x * KC) {
-        float acc[KC];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) acc[k] = 0.f;
-        for (int64_t t = 0; t < T; ++t) {
-            if (ids[t] != v) continue;  // block-uniform branch
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int64_t c = cbase + threadIdx.x + (int64_t)k * blockDim.x;
-                if (c < dim) acc[k] += bf2f(dout[t * dim + c]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int64_t c = cbase + threadIdx.x + (int64_t)k * blockDim.x;
-            if (c < dim) {
-                float r = rbf(acc[k]);
-                if (accumulate) r += bf2f(dw[v * dim + c]);
-                dw[v * dim + c] = f2bf(r);
-            }
-        }
+    if (c < dim) {
+        float r = rbf(acc);
+        if (accumulate) r += bf2f(dw[v * dim + c]);
+        dw[v * dim + c] = f2bf(r);
     }
 }
 
@@ -408,16 +397,22 @@ extern "C" int ie_embedding_fwd(const void* weight, const int64_t* ids, void* ou
     return ie_launch_status("ie_embedding_fwd launch");
 }
 
-extern "C" int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* present, int64_t T, int64_t vocab,
+extern "C" int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* ws, int64_t T, int64_t vocab,
                                 int64_t dim, int accumulate, void* stream) {
-    IE_CHECK_ARG(dout && ids && dweight && present && T >= 0 && vocab > 0 && dim > 0, "ie_embedding_bwd: bad argument");
+    IE_CHECK_ARG(dout && ids && dweight && ws && T >= 0 && vocab > 0 && dim > 0, "ie_embedding_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(present, 0, sizeof(int) * vocab, st) != hipSuccess) {
+    if (hipMemsetAsync(ws, 0, sizeof(int) * (vocab + 1), st) != hipSuccess) {
         ie_set_error("ie_embedding_bwd: memset failed");
         return IE_ERR_LAUNCH;
     }
-    if (T > 0) hipLaunchKernelGGL(embedding_mark_k, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ids, present, T, vocab);
-    hipLaunchKernelGGL(embedding_bwd_k, dim3((unsigned)vocab), dim3(256), 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, present, T,
-                       dim, accumulate);
+    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(bf16_t) * vocab * dim, st) != hipSuccess) {
+        ie_set_error("ie_embedding_bwd: memset failed");
+        return IE_ERR_LAUNCH;
+    }
+    if (T == 0) return IE_OK;
+    hipLaunchKernelGGL(embedding_mark_k, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ids, ws, T, vocab);
+    const int64_t max_rows = T < vocab ? T : vocab;
+    hipLaunchKernelGGL(embedding_bwd_k, dim3((unsigned)max_rows, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, (const bf16_t*)dout, ids,
+                       (bf16_t*)dweight, ws, T, vocab, dim, accumulate);
     return ie_launch_status("ie_embedding_bwd launch");
 }

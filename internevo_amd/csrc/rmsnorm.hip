@@ -149,26 +149,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec(const bf16_t* __restrict_
             st16(dx + row * C + c, pack8(o));
         }
     }
-    float* prow = dw_partial + (int64_t)wave_global * C;
+    // block-level reduction of the 4 waves' dw accumulators through LDS, one partial row per block
+    __shared__ float red[C];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c = j * 512 + lane * 8;
-        *reinterpret_cast<float4*>(prow + c) = make_float4(dwacc[j][0], dwacc[j][1], dwacc[j][2], dwacc[j][3]);
-        *reinterpret_cast<float4*>(prow + c + 4) = make_float4(dwacc[j][4], dwacc[j][5], dwacc[j][6], dwacc[j][7]);
+    for (int wv = 0; wv < kWavesPerBlock; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = j * 512 + lane * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (wv == 0) red[c + e] = dwacc[j][e];
+                    else red[c + e] += dwacc[j][e];
+                }
+            }
+        }
+        __syncthreads();
     }
+    float* prow = dw_partial + (int64_t)blockIdx.x * C;
+    for (int c = threadIdx.x * 4; c < C; c += 256 * 4)
+        *reinterpret_cast<float4*>(prow + c) = *reinterpret_cast<const float4*>(red + c);
 }
 
 // ---------------------------------------------------------------- generic backward
 template <typename XT>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_gen(const bf16_t* __restrict__ dy_bf, const float* __restrict__ dy_f,
+__global__ __launch_bounds__(64) void rmsnorm_bwd_gen(const bf16_t* __restrict__ dy_bf, const float* __restrict__ dy_f,
                                                        const void* __restrict__ x, const void* __restrict__ w, int w_bf16,
                                                        const float* __restrict__ rstd, const void* __restrict__ dres,
                                                        void* __restrict__ dx, float* __restrict__ dw_partial,
                                                        int64_t rows, int64_t cols) {
-    // dy has w's dtype (it is the grad of y); dx and dres have x's dtype.
+    // dy has w's dtype (it is the grad of y); dx and dres have x's dtype.  One wave per block.
     const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int wave_global = blockIdx.x;
+    const int nwaves = gridDim.x;
     float* prow = dw_partial + (int64_t)wave_global * cols;
     for (int64_t c = lane; c < cols; c += 64) prow[c] = 0.f;
     for (int64_t row = wave_global; row < rows; row += nwaves) {
@@ -198,20 +212,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_gen(const bf16_t* __restrict_
     }
 }
 
+// 32 columns per block; 8 row-groups of partials are summed in parallel and combined through LDS.
 __global__ __launch_bounds__(256) void rmsnorm_dw_reduce_k(const float* __restrict__ part, int64_t nparts, void* __restrict__ dw,
                                                             int w_bf16, int64_t cols, int accumulate) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c = (int64_t)blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int64_t p = 0; p < nparts; ++p) s += part[p * cols + c];
-    if (w_bf16) {
-        bf16_t* o = (bf16_t*)dw;
-        float r = rbf(s);
-        if (accumulate) r = bf2f(o[c]) + r;
-        o[c] = f2bf(r);
-    } else {
-        float* o = (float*)dw;
-        o[c] = accumulate ? o[c] + s : s;
+    if (c < cols)
+        for (int64_t p = ty; p < nparts; p += 8) s += part[p * cols + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][tx];
+        if (w_bf16) {
+            bf16_t* o = (bf16_t*)dw;
+            float r = rbf(s);
+            if (accumulate) r = bf2f(o[c]) + r;
+            o[c] = f2bf(r);
+        } else {
+            float* o = (float*)dw;
+            o[c] = accumulate ? o[c] + s : s;
+        }
     }
 }
 
@@ -289,45 +313,46 @@ extern "C" int ie_add_rmsnorm_fwd(const void* a, const void* b, void* r_out, con
 
 static inline int64_t bwd_blocks(int64_t rows) {
     int64_t b = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (b > 512) b = 512;
+    if (b > 256) b = 256;
     if (b < 1) b = 1;
     return b;
 }
 
+// workspace rows: the generic path runs one wave per block with 4x as many blocks
 extern "C" int64_t ie_rmsnorm_bwd_partials(int64_t rows) { return bwd_blocks(rows) * kWavesPerBlock; }
 
 extern "C" int ie_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd,
-                              const void* dres, void* dx, float* dw_partial, int64_t rows, int64_t cols, void* stream) {
-    IE_CHECK_ARG(dy && x && w && rstd && dx && dw_partial, "ie_rmsnorm_bwd: null pointer");
+                              const void* dres, void* dx, float* dw_partial, void* dw, int accumulate, int64_t rows, int64_t cols,
+                              void* stream) {
+    IE_CHECK_ARG(dy && x && w && rstd && dx && dw_partial && dw, "ie_rmsnorm_bwd: null pointer");
     IE_CHECK_ARG(rows >= 0 && cols > 0, "ie_rmsnorm_bwd: bad shape");
     IE_CHECK_ARG((x_dtype == IE_BF16 || x_dtype == IE_F32) && (w_dtype == IE_BF16 || w_dtype == IE_F32),
                  "ie_rmsnorm_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)bwd_blocks(rows));
+    int64_t nparts = 0;
+    bool done = false;
     if (x_dtype == IE_BF16 && w_dtype == IE_BF16 && cols % 512 == 0 && cols <= 4096 && aligned16(dy) && aligned16(x) &&
         aligned16(w) && aligned16(dx) && aligned16(dw_partial) && (!dres || aligned16(dres))) {
+        dim3 grid((unsigned)bwd_blocks(rows));
         int ok = dres ? launch_bwd_vec<true>((int)(cols / 512), grid, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w,
                                              rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_partial, rows)
                       : launch_bwd_vec<false>((int)(cols / 512), grid, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w,
                                               rstd, nullptr, (bf16_t*)dx, dw_partial, rows);
-        if (ok) return ie_launch_status("ie_rmsnorm_bwd launch");
+        if (ok) { done = true; nparts = grid.x; }
     }
-    const bf16_t* dyb = w_dtype == IE_BF16 ? (const bf16_t*)dy : nullptr;
-    const float* dyf = w_dtype == IE_F32 ? (const float*)dy : nullptr;
-    if (x_dtype == IE_BF16)
-        hipLaunchKernelGGL((rmsnorm_bwd_gen<bf16_t>), grid, dim3(256), 0, st, dyb, dyf, x, w, (int)(w_dtype == IE_BF16), rstd,
-                           dres, dx, dw_partial, rows, cols);
-    else
-        hipLaunchKernelGGL((rmsnorm_bwd_gen<float>), grid, dim3(256), 0, st, dyb, dyf, x, w, (int)(w_dtype == IE_BF16), rstd,
-                           dres, dx, dw_partial, rows, cols);
-    return ie_launch_status("ie_rmsnorm_bwd launch");
-}
-
-extern "C" int ie_rmsnorm_dw_reduce(const float* dw_partial, int64_t nparts, void* dw, int w_dtype, int64_t cols,
-                                    int accumulate, void* stream) {
-    IE_CHECK_ARG(dw_partial && dw && nparts >= 0 && cols > 0, "ie_rmsnorm_dw_reduce: bad argument");
-    dim3 grid((unsigned)((cols + 255) / 256));
-    hipLaunchKernelGGL(rmsnorm_dw_reduce_k, grid, dim3(256), 0, (hipStream_t)stream, dw_partial, nparts, dw,
+    if (!done) {
+        dim3 grid((unsigned)(bwd_blocks(rows) * kWavesPerBlock));
+        nparts = grid.x;
+        const bf16_t* dyb = w_dtype == IE_BF16 ? (const bf16_t*)dy : nullptr;
+        const float* dyf = w_dtype == IE_F32 ? (const float*)dy : nullptr;
+        if (x_dtype == IE_BF16)
+            hipLaunchKernelGGL((rmsnorm_bwd_gen<bf16_t>), grid, dim3(64), 0, st, dyb, dyf, x, w, (int)(w_dtype == IE_BF16), rstd,
+                               dres, dx, dw_partial, rows, cols);
+        else
+            hipLaunchKernelGGL((rmsnorm_bwd_gen<float>), grid, dim3(64), 0, st, dyb, dyf, x, w, (int)(w_dtype == IE_BF16), rstd,
+                               dres, dx, dw_partial, rows, cols);
+    }
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, st, dw_partial, nparts, dw,
                        (int)(w_dtype == IE_BF16), cols, accumulate);
-    return ie_launch_status("ie_rmsnorm_dw_reduce launch");
+    return ie_launch_status("ie_rmsnorm_bwd launch");
 }

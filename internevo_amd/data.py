@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference's synthetic-data path for the packed hot path.
+
+Same observable batches as InternEvo's
+  RandomDataset            internlm/data/tokenized/dummy_dataset.py:8-49
+  PackedDatasetWithCut     internlm/data/tokenized/packed_dataset.py:204-331 (build_pack)
+  StaticBatchSampler       internlm/data/tokenized/batch_sampler.py:110-247
+  packed_collate_fn        internlm/data/tokenized/collaters.py:7-58
+but built for a 288 GB-HBM node with modest host RAM: samples are generated on demand from the
+pre-drawn (n, r) arrays instead of materialising a million Python lists (the reference needs
+13-21 GB RSS and 2-5 minutes per rank at seq 4096), and a batch is assembled
+straight into int64 numpy buffers.  tests/test_data.py pins the first batches against fixtures
+produced by the real reference pipeline (tests/golden/data.json).
+"""
+import bisect
+import itertools
+
+import numpy as np
+import torch
+
+DEFAULT_SEED = 1024  # internlm/data/tokenized/packed_dataset.py:21
+
+
+class RandomDataset:
+    """dummy_dataset.py:8-49.  tokens(i) = ([n, r] + list(range(n)) * r)[:max_len] with r doubled until the
+    sample is at least max_len long when fixed_seqlen."""
+
+    def __init__(self, num_samples=10000, max_len=1024, fixed_seqlen=False):
+        rng = np.random.RandomState(1999)
+        self.max_num = rng.randint(1, 30, size=(num_samples,))
+        self.rep_num = rng.randint(10, 200, size=(num_samples,))
+        self.max_len = max_len
+        n, r = self.max_num.astype(np.int64), self.rep_num.astype(np.int64)
+        if fixed_seqlen:
+            # `while len(d) < max_len: r *= 2` -- the check is on n*r BEFORE the [n, r] prefix is added
+            r = r.copy()
+            need = n * r < max_len
+            while need.any():
+                r[need] *= 2
+                need = n * r < max_len
+        self._r = r
+        self.lengths = np.minimum(n * r + 2, max_len).astype(int)
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def tokens(self, index, start=0, stop=None):
+        """tokens[start:stop] of sample `index` as an int64 array (no materialisation of the full list)."""
+        n, r = int(self.max_num[index]), int(self._r[index])
+        length = int(self.lengths[index])
+        stop = length if stop is None else min(stop, length)
+        pos = np.arange(start, stop, dtype=np.int64)
+        out = (pos - 2) % n
+        if start < 2:
+            head = np.array([n, r], dtype=np.int64)[start : min(2, stop)]
+            out[: len(head)] = head
+        return out
+
+    def token_at(self, index, pos):
+        n, r = int(self.max_num[index]), int(self._r[index])
+        return n if pos == 0 else (r if pos == 1 else (pos - 2) % n)
+
+
+class PackedDatasetWithCut:
+    """packed_dataset.py:204-331, packed (`use_packed_dataset=True`) path only."""
+
+    def __init__(self, dataset, max_length_per_sample=2048, packed_length=4096):
+        self.dataset = dataset
+        self.max_length_per_sample = max_length_per_sample
+        self.packed_length = packed_length
+        self.lengths = dataset.lengths
+        rng = np.random.RandomState(DEFAULT_SEED)
+        self.sample_indices = np.arange(len(self.lengths))
+        rng.shuffle(self.sample_indices)
+        self.len_samples_shuffled = self.lengths[self.sample_indices]
+        self.acm_len_samples = np.cumsum(self.len_samples_shuffled)
+        self.num_tokens = int(self.lengths.sum())
+
+    def __len__(self):
+        return self.num_tokens // self.packed_length
+
+    def _cal_map(self, carriage_idx):
+        return int(np.searchsorted(self.acm_len_samples, (carriage_idx + 1) * self.packed_length, side="left"))
+
+    def _mapping(self, pack_idx):
+        pre_pos, pre_token_id = 0, 0
+        if pack_idx > 0:
+            pre_pos = self._cal_map(pack_idx - 1)
+            pre_token_id = int(self.len_samples_shuffled[pre_pos] - (self.acm_len_samples[pre_pos] - pack_idx * self.packed_length))
+            if pre_token_id == self.len_samples_shuffled[pre_pos]:
+                pre_pos += 1
+                pre_token_id = 0
+        pos = self._cal_map(pack_idx)
+        token_id = int(self.len_samples_shuffled[pos] - (self.acm_len_samples[pos] - (pack_idx + 1) * self.packed_length))
+        return pre_pos, pre_token_id, pos, token_id
+
+    def __getitem__(self, item):
+        pre_pos, pre_token_id, pos, token_id = self._mapping(item)
+        toks, labs, cu, idxs = [], [], [0], []
+        mlen = self.max_length_per_sample
+
+        def close_chunk(n):
+            full, left = divmod(n, mlen)
+            for _ in range(full):
+                cu.append(cu[-1] + mlen)
+                idxs.append(np.arange(mlen, dtype=np.int64))
+            if left > 0:
+                cu.append(cu[-1] + left)
+                idxs.append(np.arange(left, dtype=np.int64))
+
+        while pre_pos < pos:
+            si = int(self.sample_indices[pre_pos])
+            chunk = self.dataset.tokens(si, pre_token_id)
+            toks.append(chunk)
+            labs.append(np.concatenate([chunk[1:], np.array([-100], dtype=np.int64)]))
+            close_chunk(len(chunk))
+            pre_pos += 1
+            pre_token_id = 0
+        si = int(self.sample_indices[pos])
+        chunk = self.dataset.tokens(si, pre_token_id, token_id)
+        toks.append(chunk)
+        last = -100 if token_id == int(self.dataset.lengths[si]) else self.dataset.token_at(si, token_id)
+        labs.append(np.concatenate([chunk[1:], np.array([last], dtype=np.int64)]))
+        close_chunk(len(chunk))
+        return {
+            "tokens": np.concatenate(toks),
+            "labels": np.concatenate(labs),
+            "cu_seqlens": np.array(cu, dtype=np.int32),
+            "indexes": np.concatenate(idxs) if idxs else np.zeros(0, dtype=np.int64),
+            "type_ids": np.zeros(self.packed_length, dtype=np.int64),
+        }
+
+
+class StaticBatchSampler:
+    """batch_sampler.py:110-247 without batch-size ramp-up (rampup_batch_size="" in every config of the path)."""
+
+    def __init__(self, num_samples, batch_size, seed=1024, data_rank=0, data_world_size=1):
+        self.num_samples = num_samples
+        self.batch_size = batch_size
+        self.rng = np.random.RandomState(seed)
+        self.data_rank, self.data_world_size = data_rank, data_world_size
+        self.batch_count = 0
+        self._get_indices()
+
+    def _get_indices(self):
+        indices = np.arange(self.num_samples)
+        self.rng.shuffle(indices)
+        n = self.num_samples // (self.batch_size * self.data_world_size) * self.batch_size * self.data_world_size
+        self.indices = indices[:n]
+        assert len(self.indices) >= self.batch_size, "The number of samples should be larger than batch_size"
+        self.consumed = 0
+
+    def __iter__(self):
+        while True:
+            mine = self.indices[self.data_rank :: self.data_world_size]
+            while self.consumed < len(mine):
+                batch = mine[self.consumed : self.consumed + self.batch_size]
+                self.consumed += len(batch)
+                self.batch_count += 1
+                yield batch
+            self._get_indices()
+
+
+def packed_collate(items, packed_length):
+    """collaters.py:7-58: tokens -> abs(), labels <= 0 -> -100 (sic: label 0 is ignored too)."""
+    xs = np.stack([np.abs(b["tokens"]) for b in items])
+    ys = np.stack([np.where(b["labels"] > 0, b["labels"], -100) for b in items])
+    assert xs.shape[1] == packed_length and ys.shape[1] == packed_length
+    return {
+        "input_ids": torch.from_numpy(xs),
+        "cu_seqlens": [torch.from_numpy(b["cu_seqlens"]) for b in items],
+        "indexes": torch.from_numpy(np.stack([b["indexes"] for b in items])),
+        "type_ids": torch.from_numpy(np.stack([b["type_ids"] for b in items])),
+    }, torch.from_numpy(ys)
+
+
+class SyntheticLoader:
+    """build_dataloader.py:26-66 + :84-116 for train_folder=None: yields (batch_dict, labels) with
+    micro_num packed rows of micro_bsz*seq_len tokens each, this rank's shard of every global batch."""
+
+    def __init__(self, seq_len, micro_bsz, micro_num, fixed_seqlen=False, num_samples=1_000_000, data_rank=0, data_world_size=1,
+                 seed=1024):
+        self.packed_length = seq_len * micro_bsz
+        base = RandomDataset(num_samples=num_samples, max_len=seq_len, fixed_seqlen=fixed_seqlen)
+        self.ds = PackedDatasetWithCut(base, max_length_per_sample=seq_len, packed_length=self.packed_length)
+        self.sampler = StaticBatchSampler(len(self.ds), micro_num, seed, data_rank, data_world_size)
+
+    def __iter__(self):
+        for idx in self.sampler:
+            yield packed_collate([self.ds[int(i)] for i in idx], self.packed_length)

@@ -1,0 +1,307 @@
+"""The MI355X training-step engine: InternLM2 forward / backward / hybrid-ZeRO AdamW on hand-written
+HIP kernels, one process per GPU.
+
+It is the host-side mirror of the reference's hot path:
+  PackedFlashLlama1D.forward            internlm/model/modeling_internlm2.py:966-1009   -> _forward_micro
+  PackedFlashLlamaLayer1D._forward      :684-740                                        -> per-layer block
+  MHA._packed_forward                   :404-478                                        -> wqkv / rotary / flash / wo
+  FeedForward.forward                   modules/mlp.py:82-86                            -> w13 GEMM / SwiGLU / w2
+  FlashGPTLMLoss.forward                losses/ce_loss.py:42-58                         -> fused CE on bf16 logits
+  NonPipelineScheduler.forward_backward_step  core/scheduler/no_pipeline_scheduler.py:163-239 -> forward_backward
+  HybridZeroOptimizer.backward/step/_step     solver/optimizer/hybrid_zero_optim.py:592-807   -> step
+
+MI355X-first differences that do not change results beyond rounding order:
+  * no autograd: the backward is an explicit reverse sweep over pre-allocated activation buffers
+    (288 GB HBM holds params + grads + fp32 state + all activations of a micro-batch, so nothing is
+    re-materialised and nothing is recomputed except the SwiGLU product);
+  * parameters and gradients live in single flat bf16 buffers (layout.py); weight-gradient GEMMs
+    accumulate straight into the flat gradient buffer (bf16 `+=`, as autograd's AccumulateGrad does);
+  * the loss scale, overflow check, clip factor and Adam step counter live on the device
+    (IeStepState): a training step has no host synchronisation at all;
+  * ZeRO-1 uses reduce-scatter(AVG) of gradient buckets + all-gather of updated bf16 shards
+    (half the bytes of the reference's all-reduce + broadcast), launched per layer bucket as soon as
+    the bucket's last weight-gradient GEMM is queued on the last micro-batch, overlapping backward.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from ._lib import IeScalerConfig
+from .config import PathConfig
+from .layout import FlatLayout
+from .schedule import Beta2Scheduler, CosineWarmupLR
+from .zero import ZeroComm
+
+BF16 = torch.bfloat16
+
+
+class InternLM2Engine:
+    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None):
+        self.cfg = cfg
+        self.mc, self.tc = cfg.model, cfg.train
+        self.dev = device
+        self.world, self.rank = world_size, rank
+        mc, tc = self.mc, self.tc
+        if mc.head_dim not in (64, 128):
+            raise NotImplementedError("head dim must be 64 or 128")
+        K._L()  # fail loudly now if libinternevo_hip.so is missing
+        self.layout = FlatLayout(mc, world_size)
+        L = self.layout
+        self.comm = ZeroComm(L, process_group, world_size, rank)
+
+        # ---- flat parameter / gradient buffers + ZeRO-1 fp32 state of this rank's shards
+        self.params = torch.zeros(L.total, dtype=BF16, device=device)
+        self.grads = torch.zeros(L.total, dtype=BF16, device=device)
+        nloc = L.local_numel()
+        self.master = torch.zeros(nloc, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(nloc, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(nloc, dtype=torch.float32, device=device)
+        self.p = {n: self.params[s.offset : s.offset + s.numel].view(s.shape) for n, s in L.params.items()}
+        self.g = {n: self.grads[s.offset : s.offset + s.numel].view(s.shape) for n, s in L.params.items()}
+        self._init_params(init, seed, init_fn)
+        self.sync_master_from_params()
+
+        # ---- device-resident step state
+        self.state = K.step_state_new(device, tc.initial_scale)
+        self.scaler_cfg = IeScalerConfig(tc.growth_factor, tc.backoff_factor, tc.min_scale, tc.max_scale, tc.growth_interval, tc.hysteresis,
+                                         tc.clip_grad_norm, 1)
+        self.lr_sched = CosineWarmupLR(tc.lr, tc.total_steps, tc.warmup_ratio, tc.eta_min, tc.init_steps)
+        self.beta2_sched = Beta2Scheduler(tc.adam_beta2, tc.adam_beta2_c)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self.sumsq_ws = torch.empty(K._L().ie_sumsq_max_partials() * (len(L.buckets) + 1), dtype=torch.float32, device=device)
+
+        # ---- rotary tables (embedding.py:301-327: fp32 -> bf16), sized on demand
+        self._rot_len = 0
+        self._ensure_rotary(tc.seq_len)
+
+        # ---- activation / workspace buffers for T tokens per micro-batch
+        self.T = tc.packed_length
+        self._alloc(self.T)
+        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
+        self.step_count = 0
+
+    # ------------------------------------------------------------------------------------------ setup
+    def _init_params(self, init, seed, init_fn):
+        """modeling_internlm2.py:646-672 + :890-893,:955-961: normal(0.02); wo / w2 scaled by 1/sqrt(2*(layer+1)); norms = 1."""
+        mc = self.mc
+        if init_fn is not None:
+            for n, s in self.layout.params.items():
+                self.p[n].copy_(init_fn(n, s.shape).to(self.dev, BF16))
+            return
+        gen = torch.Generator(device=self.dev).manual_seed(seed + self.rank * 0)  # same weights on every DP rank
+        for n, s in self.layout.params.items():
+            if s.kind == "norm":
+                self.p[n].fill_(1.0)
+                continue
+            std = mc.init_std
+            if mc.use_scaled_init and s.kind in ("wo", "w2"):
+                std = mc.init_std / math.sqrt(2.0 * (s.layer + 1))
+            w = torch.empty(s.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
+            self.p[n].copy_(w)
+
+    def sync_master_from_params(self):
+        """fp32 master copy of this rank's shards (hybrid_zero_optim.py:214-233)."""
+        L = self.layout
+        for b, lo in zip(L.buckets, L.local_offsets()):
+            s, n = b.shard(self.rank, self.world)
+            self.master[lo : lo + n].copy_(self.params[s : s + n])
+
+    def _ensure_rotary(self, seqlen):
+        if seqlen <= self._rot_len:
+            return
+        d = self.mc.head_dim
+        inv_freq = 1.0 / (self.mc.rope_base ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        freqs = torch.outer(torch.arange(seqlen, dtype=torch.float32), inv_freq)
+        self.cos = torch.cos(freqs).to(BF16).to(self.dev)
+        self.sin = torch.sin(freqs).to(BF16).to(self.dev)
+        self._rot_len = seqlen
+
+    def _alloc(self, T):
+        mc, dev = self.mc, self.dev
+        h, F, V, L = mc.hidden_size, mc.ffn_dim, mc.vocab_size, mc.num_layers
+        hq, hkv, d = mc.num_attention_heads, mc.num_kv_attention_heads, mc.head_dim
+
+        def e(*shape, dtype=BF16):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        # saved per layer
+        self.a_x = [e(T, h) for _ in range(L)]        # layer input (residual stream)
+        self.a_n1 = [e(T, h) for _ in range(L)]
+        self.a_rstd1 = [e(T, dtype=torch.float32) for _ in range(L)]
+        self.a_q = [e(T, hq, d) for _ in range(L)]
+        self.a_kv = [e(T, 2, hkv, d) for _ in range(L)]
+        self.a_ctx = [e(T, hq, d) for _ in range(L)]
+        self.a_lse = [e(hq, T, dtype=torch.float32) for _ in range(L)]
+        self.a_r2 = [e(T, h) for _ in range(L)]
+        self.a_n2 = [e(T, h) for _ in range(L)]
+        self.a_rstd2 = [e(T, dtype=torch.float32) for _ in range(L)]
+        self.a_w13 = [e(T, 2 * F) for _ in range(L)]
+        self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
+        # transient
+        self.t_qkv = e(T, mc.qkv_dim)
+        self.t_h0, self.t_h1, self.t_h2 = e(T, h), e(T, h), e(T, h)
+        self.t_act = e(T, F)
+        self.t_dact = e(T, F)
+        self.t_dw13 = e(T, 2 * F)
+        self.t_dq = e(T, hq, d)
+        self.t_dkv = e(T, 2, hkv, d)
+        self.t_logits = e(T, V)
+        self.t_loss_rows = e(T, dtype=torch.float32)
+        self.t_lse = e(T, dtype=torch.float32)
+        self.t_loss = e(2, dtype=torch.float32)       # [mean loss of the micro-batch, valid-token count]
+        self.t_delta = e(hq * T, dtype=torch.float32)
+        self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
+        self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
+        self.scale_view = self.state[:4].view(torch.float32)  # IeStepState.loss_scale, read by the CE backward on device
+
+    # ------------------------------------------------------------------------------------------ forward / backward
+    def _w13(self, l):
+        s = self.layout.params[f"layers.{l}.feed_forward.w1.weight"]
+        F, h = self.mc.ffn_dim, self.mc.hidden_size
+        return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
+
+    def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
+        mc = self.mc
+        L, F, eps = mc.num_layers, mc.ffn_dim, mc.layer_norm_epsilon
+        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
+        p = self.p
+        K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
+        ffn_out = None
+        for l in range(L):
+            pre = f"layers.{l}."
+            if l == 0:
+                K.rmsnorm_fwd(self.a_x[0], p[pre + "attention_norm.weight"], eps, self.a_n1[0], self.a_rstd1[0])
+            else:
+                K.add_rmsnorm_fwd(ffn_out, self.a_r2[l - 1], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[l], self.a_rstd1[l])
+            K.linear_fwd(self.a_n1[l], p[pre + "attention.wqkv.weight"], self.t_qkv)
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[l], self.a_kv[l])
+            K.flash_attn_fwd(self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], cu, max_seqlen, None, True, self.a_ctx[l], self.a_lse[l])
+            K.linear_fwd(self.a_ctx[l].view(self.T, -1), p[pre + "attention.wo.weight"], self.t_h0)
+            K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
+            w13, _ = self._w13(l)
+            K.linear_fwd(self.a_n2[l], w13, self.a_w13[l])
+            K.swiglu_fwd(self.a_w13[l][:, :F], self.a_w13[l][:, F:], self.t_act)
+            ffn_out = K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+        K.add_rmsnorm_fwd(ffn_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
+        K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
+        K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+
+    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro):
+        mc, tc = self.mc, self.tc
+        L, F = mc.num_layers, mc.ffn_dim
+        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
+        p, g = self.p, self.g
+        T = self.T
+        ws = self.t_norm_ws
+        # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
+        K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+        dlog = self.t_logits
+        K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
+        K.linear_wgrad(dlog, self.a_nf, g["output.weight"], True)
+        d_out = self.t_h1
+        K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], True, ws, d_out)
+        if last_micro:
+            self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
+        spare = [self.t_h0, self.t_h2]
+        for l in range(L - 1, -1, -1):
+            pre = f"layers.{l}."
+            w13, gw13 = self._w13(l)
+            # feed-forward
+            K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
+            K.swiglu_bwd(self.t_dact, self.a_w13[l][:, :F], self.a_w13[l][:, F:], self.t_dw13[:, :F], self.t_dw13[:, F:], self.t_act)
+            K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], True)
+            d_n2 = spare[0]
+            K.linear_dgrad(self.t_dw13, w13, d_n2)
+            K.linear_wgrad(self.t_dw13, self.a_n2[l], gw13, True)
+            d_r2 = spare[1]
+            K.rmsnorm_bwd(d_n2, self.a_r2[l], p[pre + "ffn_norm.weight"], self.a_rstd2[l], d_out, g[pre + "ffn_norm.weight"], True, ws, d_r2)
+            # attention
+            d_ctx = d_n2  # reuse
+            K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
+            K.linear_wgrad(d_r2, self.a_ctx[l].view(T, -1), g[pre + "attention.wo.weight"], True)
+            K.flash_attn_bwd(d_ctx.view(T, -1, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu,
+                             max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+            K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
+            d_n1 = d_ctx
+            K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
+            K.linear_wgrad(self.t_qkv, self.a_n1[l], g[pre + "attention.wqkv.weight"], True)
+            d_x = d_out  # the old d_out buffer is free now
+            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[l], d_r2, g[pre + "attention_norm.weight"], True, ws, d_x)
+            # rotate buffers: next d_out = d_x; spare = the two others
+            spare = [d_n2, d_r2]
+            d_out = d_x
+            if last_micro:
+                self.comm.reduce_bucket_async(self.grads, 1 + l)
+        K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], True, self.t_emb_ws)
+        if last_micro:
+            self.comm.reduce_bucket_async(self.grads, 0)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def forward_backward(self, batch, labels):
+        """One NonPipelineScheduler.forward_backward_step: micro_num micro-batches with gradient accumulation.
+        batch: dict with input_ids [micro_num, T] int64, cu_seqlens (list of int32 [n+1]), indexes [micro_num, T] int64
+        (host tensors).  Returns the device scalar sum_i loss_i / micro_num."""
+        tc = self.tc
+        M = batch["input_ids"].shape[0]
+        assert M == tc.micro_num and batch["input_ids"].shape[1] == self.T
+        self.zero_grad()
+        self.loss_acc.zero_()
+        ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
+        lab_d = labels.to(self.dev, non_blocking=True)
+        pos_d = batch["indexes"].to(self.dev, non_blocking=True)
+        for i in range(M):
+            cu_h = batch["cu_seqlens"][i]
+            max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())  # host-side: no `.item()` sync (modeling_internlm2.py:989 syncs here)
+            self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
+            cu = cu_h.to(self.dev, non_blocking=True)
+            self._forward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen)
+            self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
+            self._backward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen, i == M - 1)
+        return self.loss_acc
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    def step(self):
+        """HybridZeroOptimizer.step + Engine.step (engine.py:105-126): norm, scaler, clip, AdamW, param sync,
+        schedulers -- all stream-ordered, no host sync.  Returns nothing; read results with `read_state()`."""
+        tc, L = self.tc, self.layout
+        self.comm.wait_all()
+        # squared grad norm over this rank's (already averaged) shards, then summed over ranks (compute_norm, utils.py:265-378)
+        shards = []
+        for b in L.buckets:
+            s, n = b.shard(self.rank, self.world)
+            shards.append(self.grads[s : s + n])
+        K.sumsq(shards, self.sumsq, False, self.sumsq_ws)
+        self.comm.all_reduce_sum(self.sumsq)
+        K.step_control(self.state, self.sumsq, self.scaler_cfg)
+        lr = self.lr_sched.lr()
+        beta2 = self.beta2_sched.beta2()
+        for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
+            s, n = b.shard(self.rank, self.world)
+            K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
+                         self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
+            self.comm.gather_bucket_async(self.params, b.index)
+        self.comm.wait_all()
+        # Engine.step steps the schedulers only after a successful update; success lives on the device, so the
+        # host-side schedule advances optimistically and is corrected lazily when a skip is observed (read_state()).
+        self.lr_sched.step()
+        self.beta2_sched.step()
+        self.step_count += 1
+
+    def read_state(self):
+        """Host copy of the step state (synchronises).  Also rewinds the host schedulers for skipped steps."""
+        st = K.step_state_read(self.state)
+        self.lr_sched.set_successful_steps(st.adam_step)
+        self.beta2_sched.set_successful_steps(st.adam_step)
+        return st
+
+    # ------------------------------------------------------------------------------------------ utilities
+    def named_parameters(self):
+        return self.p.items()
+
+    def load_named_parameters(self, named):
+        for n, t in named.items():
+            self.p[n].copy_(t.to(self.dev, BF16))
+        self.sync_master_from_params()

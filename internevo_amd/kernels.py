@@ -46,30 +46,34 @@ def _contig(t, name):
 
 
 # ------------------------------------------------------------------------------------------ RMSNorm
-def rmsnorm_fwd(x, w, eps):
+def rmsnorm_fwd(x, w, eps, y=None, rstd=None):
     """x [..., C] (bf16|fp32), w [C] -> (y [..., C] in w.dtype, rstd [rows] fp32)."""
     _contig(x, "x"); _contig(w, "w")
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty(x.shape, dtype=w.dtype, device=x.device)
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if y is None:
+        y = torch.empty(x.shape, dtype=w.dtype, device=x.device)
+    if rstd is None:
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     check(_L().ie_rmsnorm_fwd(_p(x), _dt(x), _p(w), _dt(w), _p(y), _p(rstd), rows, C, eps, _stream()), "ie_rmsnorm_fwd")
     return y, rstd
 
 
-def add_rmsnorm_fwd(a, b, w, eps, r_out=None):
+def add_rmsnorm_fwd(a, b, w, eps, r_out=None, y=None, rstd=None):
     """r = bf16(a+b); y = RMSNorm(r).  Returns (r, y, rstd)."""
     _contig(a, "a"); _contig(b, "b")
     C = a.shape[-1]
     rows = a.numel() // C
     r = torch.empty_like(a) if r_out is None else r_out
-    y = torch.empty_like(a)
-    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    if y is None:
+        y = torch.empty_like(a)
+    if rstd is None:
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
     check(_L().ie_add_rmsnorm_fwd(_p(a), _p(b), _p(r), _p(w), _p(y), _p(rstd), rows, C, eps, _stream()), "ie_add_rmsnorm_fwd")
     return r, y, rstd
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw_out=None, accumulate=False, partial_ws=None):
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw_out=None, accumulate=False, partial_ws=None, dx=None):
     """Returns (dx [x.dtype], dw [w.dtype]).  dres (optional, x.dtype) is added to dx."""
     _contig(dy, "dy"); _contig(x, "x")
     C = x.shape[-1]
@@ -78,13 +82,13 @@ def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw_out=None, accumulate=False, partia
     nparts = L.ie_rmsnorm_bwd_partials(rows)
     if partial_ws is None or partial_ws.numel() < nparts * C:
         partial_ws = torch.empty(nparts * C, dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x)
-    check(L.ie_rmsnorm_bwd(_p(dy), _p(x), _dt(x), _p(w), _dt(w), _p(rstd), _p(dres), _p(dx), _p(partial_ws), rows, C, _stream()),
-          "ie_rmsnorm_bwd")
+    if dx is None:
+        dx = torch.empty_like(x)
     if dw_out is None:
         dw_out = torch.empty_like(w)
         accumulate = False
-    check(L.ie_rmsnorm_dw_reduce(_p(partial_ws), nparts, _p(dw_out), _dt(w), C, int(accumulate), _stream()), "ie_rmsnorm_dw_reduce")
+    check(L.ie_rmsnorm_bwd(_p(dy), _p(x), _dt(x), _p(w), _dt(w), _p(rstd), _p(dres), _p(dx), _p(partial_ws), _p(dw_out),
+                           int(accumulate), rows, C, _stream()), "ie_rmsnorm_bwd")
     return dx, dw_out
 
 
@@ -164,15 +168,18 @@ def swiglu_bwd(dout, a, b, da=None, db=None, act_out=None):
 
 
 # ------------------------------------------------------------------------------------------ CE
-def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0):
+def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=None, lse=None, out=None):
     """logits [rows, V] (bf16|fp32, row stride arbitrary), labels int64 [rows] ->
     (loss_rows fp32, lse fp32, loss_mean fp32[1], count fp32[1])."""
     rows, V, ld = _rows_ld(logits)
     _contig(labels, "labels")
     dev = logits.device
-    loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
-    lse = torch.empty(rows, dtype=torch.float32, device=dev)
-    out = torch.empty(2, dtype=torch.float32, device=dev)
+    if loss_rows is None:
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
+    if lse is None:
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=dev)
     L = _L()
     check(L.ie_ce_fwd(_p(logits), _dt(logits), ld, _p(labels), _p(loss_rows), _p(lse), rows, V, ignore_index, label_smoothing, _stream()),
           "ie_ce_fwd")
@@ -254,8 +261,8 @@ def embedding_fwd(weight, ids, out=None):
 def embedding_bwd(dout, ids, dweight, accumulate, present_ws=None):
     V, dim = dweight.shape
     T = ids.numel()
-    if present_ws is None:
-        present_ws = torch.empty(V, dtype=torch.int32, device=dweight.device)
+    if present_ws is None or present_ws.numel() < V + 1 + T:
+        present_ws = torch.empty(V + 1 + T, dtype=torch.int32, device=dweight.device)
     check(_L().ie_embedding_bwd(_p(dout), _p(ids), _p(dweight), _p(present_ws), T, V, dim, int(accumulate), _stream()), "ie_embedding_bwd")
     return dweight
 
@@ -295,9 +302,45 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False):
         accumulate = False
     if out.shape != (M, N) or out.stride(1) != 1:
         raise ValueError("gemm: bad output")
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
     check(_L().ie_gemm_bf16(_p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
                             int(accumulate), _stream()), "ie_gemm_bf16")
+    if prof is not None:
+        prof.end(2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
     return out
+
+
+class KernelProfiler:
+    """Times every launch of one kernel class with HIP events recorded on the launch stream (torch's
+    current stream) and sums algorithmic flops / bytes.  Used by bench.py for the `roofline` object."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+        self.bytes = 0.0
+        self._s = None
+
+    def begin(self):
+        self._s = torch.cuda.Event(enable_timing=True)
+        self._s.record()
+
+    def end(self, flops, nbytes):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.append((self._s, e))
+        self.flops += flops
+        self.bytes += nbytes
+
+    def summary(self):
+        torch.cuda.synchronize()
+        sec = sum(s.elapsed_time(e) for s, e in self.pairs) * 1e-3
+        n = len(self.pairs)
+        return {"launches": n, "seconds": sec, "avg_us": sec / max(n, 1) * 1e6, "flops": self.flops, "bytes": self.bytes}
+
+
+GEMM_PROFILER = None
 
 
 def linear_fwd(x, w, out=None):
@@ -326,12 +369,12 @@ def colsum(x, out=None):
 # ------------------------------------------------------------------------------------------ flash attention
 def _tok_stride(t, d):
     # t: [T, H, d] view with strides (ts, d, 1)
-    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != d:
+    if t.dim() != 3 or t.stride(2) != 1 or (t.shape[1] > 1 and t.stride(1) != d):
         raise ValueError("attention operand must be a [T, H, d] view with strides (ts, d, 1)")
     return t.stride(0)
 
 
-def flash_attn_fwd(q, k, v, cu_seqlens, max_seqlen, softmax_scale=None, causal=True, out=None):
+def flash_attn_fwd(q, k, v, cu_seqlens, max_seqlen, softmax_scale=None, causal=True, out=None, lse=None):
     """q [T,hq,d], k/v [T,hkv,d] (views allowed) -> (out [T,hq,d], lse [hq,T] fp32)."""
     T, hq, d = q.shape
     hkv = k.shape[1]
@@ -343,7 +386,8 @@ def flash_attn_fwd(q, k, v, cu_seqlens, max_seqlen, softmax_scale=None, causal=T
         raise ValueError("k and v must share the token stride")
     if out is None:
         out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
-    lse = torch.empty((hq, T), dtype=torch.float32, device=q.device)
+    if lse is None:
+        lse = torch.empty((hq, T), dtype=torch.float32, device=q.device)
     if cu_seqlens.dtype != torch.int32:
         raise ValueError("cu_seqlens must be int32")
     nseq = cu_seqlens.numel() - 1

@@ -1,0 +1,353 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REAL REFERENCE (/root/reference) on CPU.
+
+Only runs in the build container (the GPU box has no /root/reference).  Nothing here is imported by
+the tests; they read the committed .json/.npz it writes.
+
+    python tests/golden/make_golden.py            # ops + data + tiny training runs
+
+What it pins
+  ops.npz / ops.json   outputs of the reference's own pure-torch op fallbacks on seeded inputs
+                       (manual_rms_norm, _torch_apply_rotary_func, RotaryEmbedding tables, CrossAttention,
+                       Silu, nn.CrossEntropyLoss, multi_tensor_l2norm_torch, DynamicGradScaler trace,
+                       get_megatron_flops) -> oracle/ops.py must reproduce them.
+  data.json            first batches of RandomDataset -> PackedDatasetWithCut -> StaticBatchSampler ->
+                       packed_collate_fn -> internevo_amd/data.py must reproduce them.
+  train_*.json         loss / grad-norm / loss-scale trajectories of the unmodified reference training
+                       loop (internlm.core.trainer + HybridZeroOptimizer) on a tiny InternLM2, fp32 and
+                       bf16, with weights set by the closed-form init of oracle/model.py:formula_init
+                       -> oracle/model.py + oracle/step.py must reproduce them.
+
+The CPU accelerator shim is the one described in SURVEY.md section 8(c): the reference has no CPU backend,
+so the cached CUDA_Accelerator instance is re-pointed at torch CPU calls before launch().
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+
+def shim_cpu_accelerator():
+    from internlm.accelerator import get_accelerator
+    from internlm.accelerator.abstract_accelerator import AcceleratorType
+
+    acc = get_accelerator()
+    cls = type(acc)
+
+    class _Stream:
+        def synchronize(self):
+            pass
+
+    cls.get_backend_name = lambda self: "cpu"
+    cls.get_accelerator_backend = lambda self: AcceleratorType.CPU
+    cls.is_available = lambda self: True
+    cls.current_device_name = lambda self: "cpu"
+    cls.device_name = lambda self, device_index=None: "cpu"
+    cls.set_device = lambda self, device_index: None
+    cls.get_device_id = lambda self: 0
+    cls.synchronize = lambda self, device_index=None: None
+    cls.empty_cache = lambda self: None
+    cls.device_count = lambda self: 1
+    cls.get_rng_state = lambda self, device_index=None: torch.get_rng_state()
+    cls.set_rng_state = lambda self, new_state, device_index=None: torch.set_rng_state(new_state)
+    cls.manual_seed = lambda self, seed: torch.manual_seed(seed)
+    cls.manual_seed_all = lambda self, seed: torch.manual_seed(seed)
+    cls.current_stream = lambda self, device_index=None: _Stream()
+    for n in ("memory_allocated", "max_memory_allocated", "memory_reserved", "max_memory_reserved", "memory_cached",
+              "max_memory_cached", "total_memory"):
+        setattr(cls, n, lambda self, device_index=None: 0)
+    cls.reset_peak_memory_stats = lambda self, device_index=None: None
+    acc._communication_backend_name = "gloo"
+    return acc
+
+
+# ------------------------------------------------------------------------------------------------ ops
+def gen_ops():
+    from internlm.model.modules.embedding import RotaryEmbedding, _torch_apply_rotary_func
+    from internlm.model.modules.multi_head_attention import CrossAttention
+    from internlm.model.ops.norm import manual_rms_norm
+    from internlm.model.utils import Silu
+    from internlm.solver.optimizer.utils import DynamicGradScaler, multi_tensor_l2norm_torch
+    from internlm.utils.common import get_megatron_flops
+
+    out, meta = {}, {}
+    g = torch.Generator().manual_seed(1234)
+
+    # K5
+    for tag, xdt, wdt in (("bf16", torch.bfloat16, torch.bfloat16), ("f32bf16", torch.float32, torch.bfloat16), ("f32", torch.float32, torch.float32)):
+        x = (torch.randn(6, 64, generator=g) * 2).to(xdt)
+        w = (1 + 0.1 * torch.randn(64, generator=g)).to(wdt)
+        y = manual_rms_norm(x, (64,), w, 1e-5)
+        out[f"rms_{tag}_x"], out[f"rms_{tag}_w"], out[f"rms_{tag}_y"] = x.float().numpy(), w.float().numpy(), y.float().numpy()
+        meta[f"rms_{tag}"] = {"x": str(xdt), "w": str(wdt), "y": str(y.dtype)}
+
+    # K2: tables + rotation
+    rot = RotaryEmbedding(64, base=10000, scale_base=0, device="cpu")
+    xq = torch.randn(1, 40, 2, 64, generator=g).to(torch.bfloat16)
+    rot._update_cos_sin_cache(xq, torch.arange(40))
+    out["rot_cos"], out["rot_sin"] = rot._cos_cached.float().numpy(), rot._sin_cached.float().numpy()
+    for conj in (False, True):
+        x1, x2 = xq[..., :32].clone(), xq[..., 32:].clone()
+        o1, o2 = torch.empty_like(x1), torch.empty_like(x2)
+        _torch_apply_rotary_func(x1, x2, rot._cos_cached[:40, None, :], rot._sin_cached[:40, None, :], o1, o2, conj)
+        out[f"rot_out1_conj{int(conj)}"], out[f"rot_out2_conj{int(conj)}"] = o1.float().numpy(), o2.float().numpy()
+    out["rot_x"] = xq.float().numpy()
+
+    # K1: CrossAttention (kv-packed, GQA 4:2, causal) in fp32 and bf16
+    q = torch.randn(2, 24, 4, 32, generator=g)
+    kv = torch.randn(2, 24, 2, 2, 32, generator=g)
+    ca = CrossAttention(causal=True)
+    out["attn_q"], out["attn_kv"] = q.numpy(), kv.numpy()
+    out["attn_out_f32"] = ca(q, kv).numpy()
+    out["attn_out_bf16"] = ca(q.to(torch.bfloat16), kv.to(torch.bfloat16)).float().numpy()
+    out["attn_out_f32_nocausal"] = CrossAttention(causal=False)(q, kv).numpy()
+
+    # K8
+    a = (torch.randn(5, 48, generator=g) * 2).to(torch.bfloat16)
+    b = torch.randn(5, 48, generator=g).to(torch.bfloat16)
+    out["silu_a"], out["silu_b"], out["silu_out"] = a.float().numpy(), b.float().numpy(), Silu(a, b).float().numpy()
+
+    # K4
+    logits = torch.randn(12, 100, generator=g) * 3
+    labels = torch.randint(0, 100, (12,), generator=g)
+    labels[3] = -100
+    out["ce_logits"], out["ce_labels"] = logits.numpy(), labels.numpy()
+    out["ce_loss"] = torch.nn.CrossEntropyLoss(reduction="mean")(logits, labels).reshape(1).numpy()
+    out["ce_loss_ls01"] = torch.nn.CrossEntropyLoss(reduction="mean", label_smoothing=0.1)(logits, labels).reshape(1).numpy()
+
+    # K6
+    ts = [torch.randn(n, generator=g).to(torch.bfloat16) for n in (7, 130, 1000)]
+    for i, t in enumerate(ts):
+        out[f"l2_t{i}"] = t.float().numpy()
+    out["l2_norm"] = multi_tensor_l2norm_torch(ts, False)[0].numpy()
+
+    # a17: scaler trace (initial 2**16, growth interval 3 to make it visible)
+    sc = DynamicGradScaler(initial_scale=2**16, growth_factor=2, backoff_factor=0.5, growth_interval=3, min_scale=1, max_scale=2**24, hysteresis=2)
+    seq = [0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1]
+    trace = []
+    for ov in seq:
+        sc.update(bool(ov))
+        trace.append([float(sc.scale.item()), sc._growth_step, sc._hysteresis_step])
+    meta["scaler_seq"], meta["scaler_trace"] = seq, trace
+
+    # a21
+    meta["flops_7b_internlm2_4096"] = get_megatron_flops(1.0, checkpoint=False, seq_len=4096, hidden_size=4096, num_layers=32, vocab_size=92544,
+                                                         global_batch_size=4, global_world_size=1, mlp_ratio=3.5)
+    meta["flops_ckpt"] = get_megatron_flops(2.0, checkpoint=True, seq_len=2048, hidden_size=4096, num_layers=32, vocab_size=103168,
+                                            global_batch_size=16, global_world_size=8, mlp_ratio=8 / 3)
+    # lr schedule traces (solver/schedulers/lr_scheduler.py:92-131 driven like core/engine.py:105-126)
+    from internlm.solver.schedulers import FineTuneCosineAnnealingWarmupLR
+
+    meta["lr_trace"] = {}
+    for key, (total, ratio, eta, init_steps) in {"t20_w0.2": (20, 0.2, 1e-5, 0), "t20_w0.01": (20, 0.01, 1e-5, 0), "t10_w0.3_i2": (10, 0.3, 0.0, 2)}.items():
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+        sch = FineTuneCosineAnnealingWarmupLR(opt, total_steps=total, init_steps=init_steps, warmup_ratio=ratio, eta_min=eta)
+        lrs = []
+        for _ in range(total):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        meta["lr_trace"][key] = {"total": total, "ratio": ratio, "eta_min": eta, "init_steps": init_steps, "base": 1e-4, "lrs": lrs}
+
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
+    with open(os.path.join(HERE, "ops.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("ops goldens written:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------------ training runs
+NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (build_dataloader.py:31-33); the harness
+#                     shrinks ONLY that count (host time/RAM), everything else is the unmodified pipeline.
+
+
+def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps):
+    return dict(
+        JOB_NAME="golden",
+        model_type="INTERNLM2_PUBLIC",
+        ckpt=dict(enable_save_ckpt=False, auto_resume=False),
+        data=dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=1, valid_micro_num=1, valid_every=0, pack_sample_into_one=False,
+                  total_steps=total_steps, skip_batches="", rampup_batch_size="", min_length=0, train_folder=None, valid_folder=None,
+                  empty_cache_and_diag_interval=10000, diag_outlier_ratio=1.1, use_packed_dataset=use_packed,
+                  fixed_random_dataset_seqlen=True, num_worker=0, type="tokenized"),
+        grad_scaler=dict(fp16=dict(initial_scale=2**16, min_scale=1, growth_interval=1000), growth_factor=2, backoff_factor=0.5,
+                         max_scale=2**24, hysteresis=2),
+        hybrid_zero_optimizer=dict(overlap_sync_grad=False, overlap_sync_param=False, reduce_bucket_size=512 * 1024 * 1024, clip_grad_norm=1.0),
+        loss=dict(label_smoothing=0),
+        adam=dict(lr=1e-3, adam_beta1=0.9, adam_beta2=0.95, adam_beta2_c=0, adam_eps=1e-8, weight_decay=0.01),
+        lr_scheduler=dict(total_steps=total_steps, init_steps=0, warmup_ratio=0.01, eta_min=1e-5, last_epoch=-1),
+        beta2_scheduler=dict(init_beta2=0.95, c=0, cur_iter=-1),
+        use_fp32_norm=False,
+        model=dict(checkpoint=False, num_chunks=1, num_attention_heads=heads, embed_split_hidden=True, vocab_size=vocab, embed_grad_scale=1,
+                   parallel_output=False, hidden_size=hidden, num_layers=layers, no_bias=True, mlp_ratio=3.5, apply_post_layer_norm=False,
+                   dtype=dtype, norm_type="rmsnorm", layer_norm_epsilon=1e-5, num_kv_attention_heads=kv_heads, use_flash_attn=False),
+        parallel=dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=1, interleaved_overlap=True),
+                      weight=dict(size=1, overlap=False, memory_pool=False)),
+        cudnn_deterministic=False, cudnn_benchmark=False,
+        monitor=dict(alert=dict(enable_feishu_alert=False, feishu_alert_address=None, light_monitor_address=None, alert_file_path="/tmp/alert.log"),
+                     tensorboard=dict(queue_max_length=10)),
+        enable_tb=False,
+    )
+
+
+def run_training(tag, dtype, cfg_kw, port):
+    """One process = one run (gpc is a singleton); called through `--run tag`."""
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    import internlm.data.build_dataloader as bdl
+    from internlm.core.context import global_context as gpc
+    from internlm.data.tokenized.dummy_dataset import RandomDataset
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.losses import FlashGPTLMLoss
+    from internlm.model.metrics import AccPerplex
+    from internlm.train import get_scheduler_hooks, initialize_model, initialize_optimizer, load_new_batch
+    from internlm.train.utils import create_param_groups  # noqa: F401
+    from internlm.utils.common import get_current_device
+    from internlm.core.context import ParallelMode
+    from internlm.core.trainer import TrainState
+
+    from oracle.model import formula_init  # closed-form weights shared with the oracle / HIP engine
+
+    bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
+
+    cfg = tiny_config(dtype, **cfg_kw)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    torch.set_num_threads(8)
+
+    model = initialize_model()
+    # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
+    inner = model.model
+    with torch.no_grad():
+        for name, p in inner.named_parameters():
+            p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+    criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
+    train_dl, dataset_types = bdl.build_train_loader_with_data_type()
+    train_state = TrainState(gpc.config, train_dl.batch_sampler)
+    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, None)
+    metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
+                        dataset_types=dataset_types)
+    trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
+                                                          lr_scheduler=lr_scheduler, beta2_scheduler=beta2_scheduler,
+                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, None))
+    trainer.train()
+    train_iter = iter(train_dl)
+    rec = {"config": {k: cfg_kw[k] for k in cfg_kw}, "dtype": dtype, "num_samples": NUM_SAMPLES, "steps": []}
+    batches = []
+    t_steps = []
+    for step in range(cfg["data"]["total_steps"]):
+        t0 = time.time()
+        batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
+        if step < 2:
+            batches.append({"input_ids": batch[0]["input_ids"].tolist(), "labels": batch[1].tolist(),
+                            "cu_seqlens": [c.tolist() for c in batch[0]["cu_seqlens"]] if "cu_seqlens" in batch[0] else None,
+                            "indexes": batch[0]["indexes"].tolist() if "indexes" in batch[0] else None})
+        trainer.zero_grad()
+        if batch[0].get("type_ids", None) is not None:
+            metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
+        _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        lr_used = optimizer.optim.param_groups[0]["lr"]
+        ok, norms = trainer.step()
+        t_steps.append(time.time() - t0)
+        rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+                             "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
+        print(tag, step, rec["steps"][-1], flush=True)
+    rec["sec_per_step"] = t_steps
+    rec["threads"] = torch.get_num_threads()
+    # a fingerprint of the trained weights (bf16 shadow params) for end-state parity
+    with torch.no_grad():
+        rec["param_fingerprint"] = {name: [float(p.float().sum()), float(p.float().abs().sum())] for name, p in inner.named_parameters()}
+    with open(os.path.join(HERE, f"train_{tag}.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    if tag.endswith("packed_probe"):
+        pass
+    return batches
+
+
+RUNS = {
+    # tag: (dtype, cfg)
+    "pin_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
+    "pin_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
+    "cfg0_fp32": ("torch.float32", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
+    "cfg0_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
+}
+
+
+def gen_data():
+    """First packed batches of the unmodified data pipeline (use_packed_dataset=True path, which is what the
+    flash/packed hot path consumes), shrunk sample count."""
+    shim_cpu_accelerator()
+    import internlm.data.build_dataloader as bdl
+    from internlm.data.tokenized.dummy_dataset import RandomDataset
+    from internlm.core.context import Config
+
+    res = {}
+    for seq_len, micro_bsz, micro_num, fixed in ((128, 1, 2, True), (64, 2, 3, False), (256, 1, 4, False)):
+        bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
+
+        class _G:  # the only gpc members the pipeline touches
+            config = None
+
+            @staticmethod
+            def get_local_rank(mode):
+                return 0
+
+            @staticmethod
+            def get_world_size(mode):
+                return 1
+
+            @staticmethod
+            def is_initialized(mode):
+                return False
+
+        data_cfg = Config(dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=micro_bsz, packed_length=seq_len * micro_bsz, pack_sample_into_one=False,
+                               rampup_batch_size="", train_folder=None, fixed_random_dataset_seqlen=fixed, type="tokenized", use_packed_dataset=True))
+        import internlm.data.tokenized.batch_sampler as bs
+        import internlm.data.tokenized.packed_dataset as pdm
+
+        old = (bdl.gpc, bs.gpc, pdm.gpc)
+        bdl.gpc = bs.gpc = pdm.gpc = _G
+        try:
+            ds, sampler, collate = bdl.get_tokenized_train_loader_items(data_cfg)
+            it = iter(sampler)
+            batches = []
+            for _ in range(3):
+                idx = next(it)
+                b, y = collate([ds[int(i)] for i in idx])
+                batches.append({"idx": [int(i) for i in idx], "input_ids": b["input_ids"].tolist(), "labels": y.tolist(),
+                                "cu_seqlens": [c.tolist() for c in b["cu_seqlens"]], "indexes": b["indexes"].tolist(),
+                                "type_ids": b["type_ids"].tolist()})
+            res[f"seq{seq_len}_mbsz{micro_bsz}_mnum{micro_num}_fixed{int(fixed)}"] = {"len_ds": len(ds), "batches": batches}
+        finally:
+            bdl.gpc, bs.gpc, pdm.gpc = old
+    with open(os.path.join(HERE, "data.json"), "w") as f:
+        json.dump({"num_samples": NUM_SAMPLES, "cases": res}, f)
+    print("data goldens written")
+
+
+if __name__ == "__main__":
+    import subprocess
+
+    if len(sys.argv) >= 3 and sys.argv[1] == "--run":
+        tag = sys.argv[2]
+        dtype, kw = RUNS[tag]
+        run_training(tag, dtype, kw, port=29700 + list(RUNS).index(tag))
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--data":
+        gen_data()
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ops":
+        shim_cpu_accelerator()
+        gen_ops()
+        sys.exit(0)
+    for mode in ("--ops", "--data"):
+        subprocess.check_call([sys.executable, __file__, mode])
+    for tag in RUNS:
+        subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -1,0 +1,121 @@
+"""CPU tests of the flat layout and of the ZeRO-1 exchange (gloo, world_size 2, real processes)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flat_layout_invariants():
+    from internevo_amd.config import internlm2_7b, tiny
+    from internevo_amd.layout import ALIGN, FlatLayout
+
+    for cfg, worlds in ((tiny().model, (1, 2, 8)), (internlm2_7b().model, (1, 8))):
+        for w in worlds:
+            L = FlatLayout(cfg, w)
+            assert len(L.buckets) == cfg.num_layers + 2
+            end = 0
+            for b in L.buckets:
+                assert b.start == end and b.start % ALIGN == 0 and b.size % (w * ALIGN) == 0 and b.used <= b.size
+                end = b.start + b.size
+            assert end == L.total
+            # parameters tile their bucket without overlap
+            for b in L.buckets:
+                o = b.start
+                for n in b.params:
+                    s = L.params[n]
+                    assert s.offset == o and s.offset % ALIGN == 0
+                    o += (s.numel + ALIGN - 1) // ALIGN * ALIGN
+            assert sum(s.numel for s in L.params.values()) == cfg.num_params()
+            # w1 / w3 adjacency (one [2F, h] GEMM operand)
+            a, c = L.params["layers.0.feed_forward.w1.weight"], L.params["layers.0.feed_forward.w3.weight"]
+            assert c.offset == a.offset + a.numel
+            assert L.local_numel() * w == L.total
+    assert internlm2_7b().model.num_params() == 7_737_708_544  # 7.74 B
+
+
+def test_reference_config_files_map(tmp_path):
+    from internevo_amd.config import from_reference_dict, load_reference_config
+
+    p = tmp_path / "cfg.py"
+    p.write_text(
+        "SEQ=2048\nmodel_type='INTERNLM2_PUBLIC'\n"
+        "data=dict(seq_len=SEQ, micro_num=4, micro_bsz=1, total_steps=20)\n"
+        "grad_scaler=dict(fp16=dict(initial_scale=2**16, min_scale=1, growth_interval=1000), growth_factor=2, backoff_factor=0.5, max_scale=2**24, hysteresis=2)\n"
+        "hybrid_zero_optimizer=dict(overlap_sync_grad=True, overlap_sync_param=False, reduce_bucket_size=512*1024*1024, clip_grad_norm=1.0)\n"
+        "loss=dict(label_smoothing=0)\nadam=dict(lr=1e-4, adam_beta1=0.9, adam_beta2=0.95, adam_beta2_c=0, adam_eps=1e-8, weight_decay=0.01)\n"
+        "lr_scheduler=dict(total_steps=20, init_steps=0, warmup_ratio=0.01, eta_min=1e-5, last_epoch=-1)\n"
+        "model=dict(checkpoint=False, num_attention_heads=32, vocab_size=92544, hidden_size=4096, num_layers=32, no_bias=True, mlp_ratio=3.5,\n"
+        "           dtype='torch.bfloat16', layer_norm_epsilon=1e-5, num_kv_attention_heads=8, use_flash_attn=True)\n"
+        "parallel=dict(zero1=dict(size=8), tensor=dict(size=1, mode='mtp'), pipeline=dict(size=1), weight=dict(size=1))\n"
+    )
+    cfg = load_reference_config(str(p), seq_len=4096)
+    assert cfg.model.ffn_dim == 14336 and cfg.model.qkv_dim == 6144 and cfg.train.seq_len == 4096 and cfg.train.clip_grad_norm == 1.0
+    bad = dict(model=dict(vocab_size=8, hidden_size=8, num_layers=1, num_attention_heads=1), data=dict(seq_len=8, micro_bsz=1, micro_num=1, total_steps=1),
+               parallel=dict(pipeline=dict(size=2)))
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(bad)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.config import tiny
+        from internevo_amd.layout import FlatLayout
+        from internevo_amd.zero import ZeroComm
+
+        mc = tiny(hidden=64, layers=2, heads=1, kv_heads=1, vocab=40).model
+        L = FlatLayout(mc, world)
+        comm = ZeroComm(L, None, world, rank)
+        gen = torch.Generator().manual_seed(100 + rank)
+        grads = torch.randn(L.total, generator=gen).to(torch.bfloat16)
+        all_grads = [torch.randn(L.total, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(world)]
+        mean = sum(g.float() for g in all_grads) / world
+        for b in reversed(range(len(L.buckets))):
+            comm.reduce_bucket_async(grads, b)
+        comm.wait_all()
+        ok = True
+        sq_local = torch.zeros(1)
+        for b in L.buckets:
+            s, n = b.shard(rank, world)
+            ok &= torch.allclose(grads[s : s + n].float(), mean[s : s + n], rtol=1e-2, atol=1e-2)
+            sq_local += grads[s : s + n].float().pow(2).sum()
+        comm.all_reduce_sum(sq_local)
+        # every rank holds the same global squared norm of the averaged gradient
+        ref_sq = mean.to(torch.bfloat16).float().pow(2).sum()
+        ok &= abs(float(sq_local) - float(ref_sq)) <= 2e-2 * float(ref_sq)
+        # parameter all-gather: each rank writes its shard id, afterwards everyone sees every shard
+        params = torch.zeros(L.total, dtype=torch.bfloat16)
+        for b in L.buckets:
+            s, n = b.shard(rank, world)
+            params[s : s + n] = rank + 1
+            comm.gather_bucket_async(params, b.index)
+        comm.wait_all()
+        for b in L.buckets:
+            for r in range(world):
+                s, n = b.shard(r, world)
+                ok &= bool((params[s : s + n] == r + 1).all())
+        q.put((rank, ok, float(sq_local)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_zero_exchange_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, 29811
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res), res
+    assert abs(res[0][2] - res[1][2]) < 1e-6 * abs(res[0][2])

@@ -114,7 +114,7 @@ def main():
     eo = torch.empty(T, H, device=dev, dtype=bf)
     rec("embedding_fwd", timeit(lambda: K.embedding_fwd(emb, ids, eo)), nbytes=T * H * 4)
     demb = torch.zeros(V, H, device=dev, dtype=bf)
-    pres = torch.empty(V, dtype=torch.int32, device=dev)
+    pres = torch.empty(V + 1 + T, dtype=torch.int32, device=dev)
     rec("embedding_bwd (30 distinct ids)", timeit(lambda: K.embedding_bwd(eo, ids, demb, True, pres), iters=5), nbytes=T * H * 2)
     del emb, demb
 
