@@ -105,6 +105,8 @@ int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, co
  *     bwd (in place when dlogits == logits, as inplace_backward=True):
  *       dlogits = (softmax - (1-ls)*onehot - ls/vocab) * gscale, gscale = *dloss * dloss_mul / *count.
  *     dloss and count are DEVICE scalars so the loss scale never round-trips through the host.
+ *     count == NULL selects per-row mode: dloss[rows] holds one upstream gradient per token
+ *     (gscale = dloss[row] * dloss_mul), which is what an autograd consumer of the per-token losses needs.
  * ---------------------------------------------------------------------------------------------- */
 int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows,
               float* lse, int64_t rows, int64_t vocab, int64_t ignore_index, float label_smoothing,

@@ -103,6 +103,11 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for the hot path."
         )
+    # torch ships its own libamdhip64.so; it must be the HIP runtime already resident in the process when our
+    # library is loaded, otherwise two runtimes coexist and torch's streams/pointers are foreign to our launches
+    # (observed on MI355X: hipErrorInvalid* from the first launch when the .so was loaded before `import torch`).
+    import torch  # noqa: F401
+
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the ROCm runtime being present

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/internevo_hip.h"
 
@@ -33,7 +34,9 @@ extern "C" void ie_set_error(const char* msg);
 static inline int ie_launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        ie_set_error(what);
+        char buf[240];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        ie_set_error(buf);
         return IE_ERR_LAUNCH;
     }
     return IE_OK;

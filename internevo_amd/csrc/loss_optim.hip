@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const void* __restrict__ logits,
     const int tid = threadIdx.x;
     const int64_t lab = labels[row];
     const bool valid = lab != ignore_index;
-    const float g = valid ? dloss[0] * dloss_mul / count[0] : 0.f;
+    // count == NULL: dloss holds one upstream gradient per row (reduction = 'none' consumers)
+    const float g = valid ? (count ? dloss[0] * dloss_mul / count[0] : dloss[row] * dloss_mul) : 0.f;
     const float l = lse[row];
     const float smooth = ls / (float)vocab;
     const float hot = 1.f - ls;
@@ -394,7 +395,7 @@ extern "C" int ie_ce_mean(const float* loss_rows, const int64_t* labels, int64_t
 extern "C" int ie_ce_bwd(const void* logits, void* dlogits, int dtype, int64_t ld, const int64_t* labels, const float* lse,
                          const float* dloss, float dloss_mul, const float* count, int64_t rows, int64_t vocab, int64_t ignore_index,
                          float label_smoothing, void* stream) {
-    IE_CHECK_ARG(logits && dlogits && labels && lse && dloss && count, "ie_ce_bwd: null pointer");
+    IE_CHECK_ARG(logits && dlogits && labels && lse && dloss, "ie_ce_bwd: null pointer");
     IE_CHECK_ARG(rows >= 0 && vocab > 0 && ld >= vocab, "ie_ce_bwd: bad shape");
     IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_ce_bwd: bad dtype");
     if (rows == 0) return IE_OK;
