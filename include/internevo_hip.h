@@ -197,6 +197,12 @@ int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
  * ---------------------------------------------------------------------------------------------- */
 int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                  void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream);
+/* Same product with an explicit block-tile shape (tuning / A-B benchmarking; ie_gemm_bf16 picks one itself):
+ * variant 0 = 128x128 (4 waves), 1 = 256x256 (8 waves), 2 = 256x128, 3 = 128x256 (register-staged);
+ * 4 = 256x256 LDS-DMA, 5 = 128x128 LDS-DMA (need K % 64 == 0); -1 = automatic. */
+int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb,
+                      int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
+                      void* stream);
 /* column sums of a [rows, cols] bf16 matrix (bias gradient of linear_bias_wgrad, has_bias=True) */
 int ie_colsum_bf16(const void* x, int64_t ld, void* out, int64_t rows, int64_t cols, void* stream);
 
@@ -220,6 +226,9 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
                       float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
                       const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
                       int d, float softmax_scale, int causal, void* stream);
+
+/* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
+int ie_tune_flash_dq_occupancy(int waves_per_simd);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

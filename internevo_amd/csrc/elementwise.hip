@@ -260,12 +260,29 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ dw, const int* __restrict__ ws, int64_t T, int64_t vocab,
                                                        int64_t dim, int accumulate) {
     if ((int)blockIdx.x >= ws[vocab]) return;
+    __shared__ unsigned long long masks[4];
     const int64_t v = ws[vocab + 1 + blockIdx.x];
     const int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int64_t t = 0; t < T; ++t) {
-        if (ids[t] != v) continue;  // block-uniform branch
-        if (c < dim) acc += bf2f(dout[t * dim + c]);
+    // 256 ids per pass: every thread tests one id, the 4 wave ballots go through LDS, then all threads walk the
+    // set bits IN TOKEN ORDER (deterministic sum) and add their column of the matching rows.
+    for (int64_t base = 0; base < T; base += 256) {
+        const int64_t t = base + threadIdx.x;
+        const bool hit = t < T && ids[t] == v;
+        const unsigned long long m = __ballot(hit);
+        __syncthreads();
+        if (lane == 0) masks[wave] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mm = masks[w];
+            while (mm) {
+                const int b = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                if (c < dim) acc += bf2f(dout[(base + w * 64 + b) * dim + c]);
+            }
+        }
     }
     if (c < dim) {
         float r = rbf(acc);

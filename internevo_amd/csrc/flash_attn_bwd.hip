@@ -1,16 +1,20 @@
 // K1 backward: varlen, causal / full, GQA flash attention for gfx950.  Deterministic (no atomics):
 //   1. flash_delta_k : delta[h][t] = sum_d dO * O
 //   2. flash_dq_k    : one block per 128 query rows, loops over K/V tiles, recomputes P, dQ += dS K
-//   3. flash_dkdv_k  : one block per 128 keys (one wave per 32 keys), loops over the q heads of the
+//   3. flash_dkdv_k  : one block per 64 keys (one wave per 32 keys), loops over the q heads of the
 //                      GQA group and their query tiles, recomputes P, dV += P^T dO, dK += dS^T Q
 // The recompute costs 7 instead of 5 tile products but keeps every output written by exactly one
 // workgroup in a fixed order, so the result is bit-reproducible run to run.
 //
-// Layout tricks are the forward's (flash_common.h): in the dQ kernel scores are formed transposed
-// (lane = query row), in the dK/dV kernel un-transposed (lane = key), so the accumulator registers
-// of S / dS are directly the k-slots of the next MFMA; the operands that need their contraction
-// index contiguous (K^T, Q^T, dO^T) come from transposed LDS images built at staging time.
+// Tiles arrive by LDS-DMA into double-buffered natural-layout images (flash_common.h); one image serves
+// both the row fragments (ds_read_b128) and the transposed fragments (ds_read_b64_tr_b16), so the dQ kernel
+// stages only K and V, the dK/dV kernel only Q and dO.  In the dQ kernel scores are formed transposed
+// (lane = query row), in the dK/dV kernel un-transposed (lane = key), so the accumulator registers of
+// S / dS are directly the k-slots of the next MFMA.  Tile loops are unrolled by the two pipeline stages:
+// every LDS address is a precomputed per-lane offset + an immediate.
 #include "flash_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -45,17 +49,15 @@ __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
-                                                  int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                  int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                  bf16_t* __restrict__ dq, int64_t dq_ts, const int32_t* __restrict__ cu, int64_t T,
-                                                  int hq, int hkv, float scale) {
+template <int D, bool CAUSAL, int MINW>
+__global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
+                                                        int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                        int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        bf16_t* __restrict__ dq, int64_t dq_ts, const int32_t* __restrict__ cu, int64_t T,
+                                                        int hq, int hkv, float scale) {
     using G = Geo<D>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * G::ROW_PITCH + D * G::T_PITCH];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = smem + 64 * G::ROW_PITCH;
-    unsigned char* Kt = smem + 2 * 64 * G::ROW_PITCH;
+    constexpr int STAGE = 2 * G::IMG_BYTES;  // K image, V image
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int seq = blockIdx.z;
     const int h = blockIdx.y;
@@ -65,10 +67,21 @@ __global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dou
     const int q0 = qt * 128;
     if (q0 >= len) return;
     const int hk = h / (hq / hkv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qw0 = q0 + wave * 32;
     const int my_q = qw0 + (lane & 31);
     const bool q_valid = my_q < len;
+
+    const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
+    const int ntiles = (kv_end + 63) / 64;
+    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    dma_tile<D, 4>(kbase, kv_ts, len, smem, wave, lane);
+    dma_tile<D, 4>(vbase, kv_ts, len, smem + G::IMG_BYTES, wave, lane);
+
+    FragOffs<D> fo;
+    fo.init(lane);
 
     s16x8 qf[G::KS], dof[G::KS];
     {
@@ -91,29 +104,19 @@ __global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dou
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) dqacc[db] = zero16();
 
-    const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
-    const int ntiles = (kv_end + 63) / 64;
-    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
-    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
-
-    RowStager<D, 64, 256> k_st, v_st;
-    TransStager<D, 256> kt_st;
-    k_st.load(kbase, kv_ts, len);
-    v_st.load(vbase, kv_ts, len);
-    kt_st.load(kbase, kv_ts, len);
-    k_st.store(Ks);
-    v_st.store(Vs);
-    kt_st.store(Kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](auto stage_c, int t) {
+        constexpr int S = decltype(stage_c)::value;
         const int kv0 = t * 64;
-        const bool more = t + 1 < ntiles;
-        if (more) {
+        const unsigned char* Ks = smem + S * STAGE;
+        const unsigned char* Vs = Ks + G::IMG_BYTES;
+        if (t + 1 < ntiles) {
+            unsigned char* nxt = smem + (1 - S) * STAGE;
             const int rem = len - (kv0 + 64);
-            k_st.load(kbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem);
-            v_st.load(vbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem);
-            kt_st.load(kbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem);
+            dma_tile<D, 4>(kbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt, wave, lane);
+            dma_tile<D, 4>(vbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt + G::IMG_BYTES, wave, lane);
         }
         const bool active = !CAUSAL || kv0 <= qw0 + 31;
         if (active) {
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dou
                 f32x16 s = zero16(), dp = zero16();
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, lane), qf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, 32 * c, ks, lane), dof[ks], dp, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, 32 * c, ks, fo), dof[ks], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[r] * sc2 - lse2);
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lse2));
                     if (need_mask) {
                         const int key = kv0 + 32 * c + creg_row(r, lane);
                         if (key >= len || (CAUSAL && key > my_q)) p = 0.f;
@@ -140,17 +143,17 @@ __global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dou
                     const s16x8 dsf = pack_frag(s, s2);
 #pragma unroll
                     for (int db = 0; db < G::DB; ++db)
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Kt, 32 * db, 2 * c + s2, lane), dsf, dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Ks, db, 2 * c + s2, fo), dsf, dqacc[db], 0, 0, 0);
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (more) {
-            k_st.store(Ks);
-            v_st.store(Vs);
-            kt_st.store(Kt);
-        }
-        __syncthreads();
+    };
+
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
     if (q_valid) {
@@ -168,35 +171,70 @@ __global__ __launch_bounds__(256) void flash_dq_k(const bf16_t* __restrict__ dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block = DKV_WAVES waves x 32 keys.  With causal masking the work of a key block falls linearly with its
+// position, and there are only (len/64) x hkv blocks, so (a) blocks are small (64 keys) to get >= 2 per CU and
+// (b) the block index is folded so that the two blocks dispatched far apart (the ones that share a CU under
+// round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.
+constexpr int DKV_WAVES = 2;
+
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
-                                                    int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                    int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
-                                                    const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale) {
+__global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
+                                                               int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                               int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
+                                                               const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale) {
     using G = Geo<D>;
-    constexpr int ROWIMG = 64 * G::ROW_PITCH;
-    constexpr int TIMG = D * G::T_PITCH;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWIMG + 2 * TIMG + 2 * 64 * 4];
-    unsigned char* Qs = smem;
-    unsigned char* dOs = smem + ROWIMG;
-    unsigned char* Qt = smem + 2 * ROWIMG;
-    unsigned char* dOt = smem + 2 * ROWIMG + TIMG;
-    float* lse_s = reinterpret_cast<float*>(smem + 2 * ROWIMG + 2 * TIMG);
-    float* dlt_s = lse_s + 64;
+    constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, lse2[64], delta[64] (+ pad to keep 1 KiB alignment)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int seq = blockIdx.z;
-    const int hk = blockIdx.y;
-    const int kb = blockIdx.x;
+    const int hk = blockIdx.x % hkv;
+    const int nkb = gridDim.x / hkv;
+    const int j = blockIdx.x / hkv;
+    const int first = (nkb + 1) / 2;
+    const int kb = j < first ? j : nkb - 1 - (j - first);
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
-    const int k0 = kb * 128;
+    const int k0 = kb * 32 * DKV_WAVES;
     if (k0 >= len) return;
     const int grp = hq / hkv;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kw0 = k0 + wave * 32;
     const int my_k = kw0 + (lane & 31);
     const bool k_valid = my_k < len;
+
+    const int nqt_all = (len + 63) / 64;
+    const int qt_start = CAUSAL ? (k0 / 64) : 0;
+    const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len
+    const int nit = grp * nqt;
+
+    // stage `it`: Q / dO images by DMA; lse (log2 domain) and delta through registers of threads 0..63
+    auto issue = [&](int it, unsigned char* stage, float& lse_r, float& dlt_r) {
+        const int h = hk * grp + it / nqt;
+        const int q0 = (qt_start + it % nqt) * 64;
+        const int rem = len - q0;
+        dma_tile<D, DKV_WAVES>(q + (int64_t)(tok0 + q0) * q_ts + (int64_t)h * D, q_ts, rem, stage, wave, lane);
+        dma_tile<D, DKV_WAVES>(dout + (int64_t)(tok0 + q0) * do_ts + (int64_t)h * D, do_ts, rem, stage + G::IMG_BYTES, wave, lane);
+        if (threadIdx.x < 64) {
+            const bool ok = (int)threadIdx.x < rem;
+            lse_r = ok ? lse[(int64_t)h * T + tok0 + q0 + threadIdx.x] * kLog2e : INFINITY;
+            dlt_r = ok ? delta[(int64_t)h * T + tok0 + q0 + threadIdx.x] : 0.f;
+        }
+    };
+    auto commit = [&](unsigned char* stage, float lse_r, float dlt_r) {
+        if (threadIdx.x < 64) {
+            reinterpret_cast<float*>(stage + 2 * G::IMG_BYTES)[threadIdx.x] = lse_r;
+            reinterpret_cast<float*>(stage + 2 * G::IMG_BYTES + 256)[threadIdx.x] = dlt_r;
+        }
+    };
+
+    float lse_r = 0.f, dlt_r = 0.f;
+    issue(0, smem, lse_r, dlt_r);
+    commit(smem, lse_r, dlt_r);
+
+    FragOffs<D> fo;
+    fo.init(lane);
 
     // K, V fragments of this wave's 32 keys (B operands: lane = key)
     s16x8 kf[G::KS], vf[G::KS];
@@ -216,48 +254,22 @@ __global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ d
     f32x16 dkacc[G::DB], dvacc[G::DB];
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
+    const int rl_lane = 4 * (lane >> 5);
 
-    const int nqt_all = (len + 63) / 64;
-    const int qt_start = CAUSAL ? (k0 / 64) : 0;
-    const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len
-    const int nit = grp * nqt;
-
-    RowStager<D, 64, 256> q_st, do_st;
-    TransStager<D, 256> qt_st, dot_st;
-    float lse_r = 0.f, dlt_r = 0.f;  // threads 0..63 stage lse/delta of the tile
-
-    auto issue = [&](int it) {
-        const int h = hk * grp + it / nqt;
-        const int q0 = (qt_start + it % nqt) * 64;
-        const int rem = len - q0;
-        const bf16_t* qb = q + (int64_t)(tok0 + q0) * q_ts + (int64_t)h * D;
-        const bf16_t* dob = dout + (int64_t)(tok0 + q0) * do_ts + (int64_t)h * D;
-        q_st.load(qb, q_ts, rem);
-        do_st.load(dob, do_ts, rem);
-        qt_st.load(qb, q_ts, rem);
-        dot_st.load(dob, do_ts, rem);
-        if (threadIdx.x < 64) {
-            const bool ok = (int)threadIdx.x < rem;
-            lse_r = ok ? lse[(int64_t)h * T + tok0 + q0 + threadIdx.x] * kLog2e : INFINITY;
-            dlt_r = ok ? delta[(int64_t)h * T + tok0 + q0 + threadIdx.x] : 0.f;
-        }
-    };
-    auto commit = [&]() {
-        q_st.store(Qs);
-        do_st.store(dOs);
-        qt_st.store(Qt);
-        dot_st.store(dOt);
-        if (threadIdx.x < 64) { lse_s[threadIdx.x] = lse_r; dlt_s[threadIdx.x] = dlt_r; }
-    };
-
-    issue(0);
-    commit();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int it = 0; it < nit; ++it) {
+    auto step = [&](auto stage_c, int it) {
+        constexpr int S = decltype(stage_c)::value;
         const int q0 = (qt_start + it % nqt) * 64;
+        const unsigned char* stage = smem + S * STAGE;
+        unsigned char* nxt = smem + (1 - S) * STAGE;
         const bool more = it + 1 < nit;
-        if (more) issue(it + 1);
+        if (more) issue(it + 1, nxt, lse_r, dlt_r);
+        const unsigned char* Qs = stage;
+        const unsigned char* dOs = stage + G::IMG_BYTES;
+        const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
+        const float* dlt_s = lse_s + 64;
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             const int qb0 = q0 + 32 * qs;  // first query row of this sub-block
@@ -266,14 +278,14 @@ __global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ d
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, 32 * qs, ks, lane), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, 32 * qs, ks, lane), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, 32 * qs, ks, fo), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, 32 * qs, ks, fo), vf[ks], dp, 0, 0, 0);
             }
             const bool need_mask = (CAUSAL && kw0 + 31 > qb0) || (kw0 + 32 > len);
             f32x16 p;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int rl = 32 * qs + 8 * g + 4 * (lane >> 5);  // tile-local row of regs 4g..4g+3
+                const int rl = 32 * qs + 8 * g + rl_lane;  // tile-local row of regs 4g..4g+3
                 const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rl);
                 const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + rl);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ d
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    float pv = __builtin_amdgcn_exp2f(s[r] * sc2 - lv[e]);  // lse2 = +inf for rows >= len -> 0
+                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));  // lse2 = +inf for rows >= len -> 0
                     if (need_mask) {
                         const int qrow = q0 + rl + e;
                         if (my_k >= len || (CAUSAL && my_k > qrow)) pv = 0.f;
@@ -296,14 +308,19 @@ __global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ d
                 const s16x8 dsf = pack_frag(s, s2);
 #pragma unroll
                 for (int db = 0; db < G::DB; ++db) {
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(dOt, 32 * db, 2 * qs + s2, lane), pf, dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Qt, 32 * db, 2 * qs + s2, lane), dsf, dkacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(dOs, db, 2 * qs + s2, fo), pf, dvacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Qs, db, 2 * qs + s2, fo), dsf, dkacc[db], 0, 0, 0);
                 }
             }
         }
+        if (more) commit(nxt, lse_r, dlt_r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (more) commit();
-        __syncthreads();
+    };
+
+    for (int it = 0; it < nit; it += 2) {
+        step(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
     if (k_valid) {
@@ -326,7 +343,16 @@ __global__ __launch_bounds__(256) void flash_dkdv_k(const bf16_t* __restrict__ d
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+int g_dq_minw = 2;  // waves/SIMD the dQ kernel is compiled for (2: 256 VGPRs with a small spill; 1: no spill, half the occupancy)
+
 }  // namespace
+
+// tuning hook (A/B benchmarking only): occupancy target of the dQ kernel, 1 or 2 waves per SIMD
+extern "C" int ie_tune_flash_dq_occupancy(int waves_per_simd) {
+    IE_CHECK_ARG(waves_per_simd == 1 || waves_per_simd == 2, "ie_tune_flash_dq_occupancy: 1 or 2");
+    g_dq_minw = waves_per_simd;
+    return IE_OK;
+}
 
 extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
                                  int64_t kv_ts, const void* out, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts,
@@ -351,15 +377,21 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     }
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq(nt128, (unsigned)hq, (unsigned)nseq);
-    dim3 gk(nt128, (unsigned)hkv, (unsigned)nseq);
+    const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
+    dim3 gk(nkb * (unsigned)hkv, 1, (unsigned)nseq);
 #define IE_L(DD, CA)                                                                                                               \
     do {                                                                                                                           \
-        hipLaunchKernelGGL((flash_dq_k<DD, CA>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,           \
-                           (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,        \
-                           softmax_scale);                                                                                          \
-        hipLaunchKernelGGL((flash_dkdv_k<DD, CA>), gk, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,         \
-                           (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T,   \
-                           hq, hkv, softmax_scale);                                                                                 \
+        if (g_dq_minw == 2)                                                                                                        \
+            hipLaunchKernelGGL((flash_dq_k<DD, CA, 2>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
+                               (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
+                               softmax_scale);                                                                                      \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((flash_dq_k<DD, CA, 1>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
+                               (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
+                               softmax_scale);                                                                                      \
+        hipLaunchKernelGGL((flash_dkdv_k<DD, CA>), gk, dim3(64 * DKV_WAVES), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q,    \
+                           q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts,            \
+                           cu_seqlens, T, hq, hkv, softmax_scale);                                                                  \
     } while (0)
     if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
     else          { if (causal) IE_L(64, true); else IE_L(64, false); }

@@ -1,120 +1,110 @@
 // Shared pieces of the flash-attention kernels (gfx950, wave64, v_mfma_f32_32x32x16_bf16).
 //
-// Fragment conventions used everywhere (pinned on hardware by ie_mfma_probe):
+// Fragment conventions (pinned on hardware by ie_mfma_probe):
 //   A operand: lane l holds A[i = l & 31][k = 8*(l >> 5) + 0..7]     (8 bf16, k contiguous)
 //   B operand: lane l holds B[k = 8*(l >> 5) + 0..7][j = l & 31]
 //   C/D      : lane l, reg r holds D[i = (r & 3) + 8*(r >> 2) + 4*(l >> 5)][j = l & 31]
 //
-// "Row" LDS images are [row][D] with a (2*D + 16)-byte pitch (conflict-free ds_read_b128 of 16 rows).
-// "Transposed" LDS images are [D][R] (R = 64 rows of the tile) with a (2*R + 8)-byte pitch; they are
-// built by an in-register 4x8 transpose at staging time and consumed with two ds_read_b64 per
-// fragment.  Because the contraction order inside an MFMA is free, the k-slot <-> row mapping of a
-// transposed fragment is chosen to equal the C/D register order of the producing MFMA:
-//   slot e (0..7) of k-step s  <->  row 16*s + 8*(e >> 2) + 4*(l >> 5) + (e & 3)
-// so score/probability accumulators feed the next MFMA without any cross-lane movement.
+// Every tile (K, V, Q, dO: 64 rows x D) is brought HBM -> LDS by the DMA path (global_load_lds_dwordx4,
+// 1 KiB per wave-instruction, lane-linear destination) in its NATURAL [row][D] layout; ONE image serves
+// both kinds of MFMA operand:
+//   * "row" fragments (the tile's rows are the MFMA i/j index, D is contracted): ds_read_b128,
+//   * "transposed" fragments (the tile's rows are CONTRACTED, e.g. V in P.V, K in dS.K, Q in dS^T.Q,
+//     dO in P^T.dO): two ds_read_b64_tr_b16 (hardware transposing load; lane i of a 16-lane group receives
+//     X[r0..r0+3][c0 + i] when lane p addresses row r0 + (p >> 2), columns c0 + 4*(p & 3)..+3 -- pinned by
+//     tools/probes/probe_lds.hip).
+// The 16-byte slot s of row r is stored at slot s ^ swz(r) (the DMA permutes the per-lane SOURCE address,
+// the reads apply the same XOR).  swz is a permutation of row bits chosen so that BOTH read kinds are
+// bank-conflict free: the 16 rows of a ds_read_b128 lane group land in 16 distinct slots of the 256-byte
+// bank row, and the 4 rows of a transposing read land in 4 distinct 64-byte blocks.
+// Because the contraction order inside an MFMA is free, the rows fetched by a transposed fragment are
+// chosen to equal the C/D register order of the producing MFMA:
+//   slot e (0..7) of 16-row step s  <->  row 16*s + 8*(e >> 2) + 4*(l >> 5) + (e & 3)
+// so score / probability accumulators feed the next MFMA without any cross-lane movement.
 #pragma once
 #include "ie_common.h"
 
 namespace fa {
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 template <int D> struct Geo {
-    static constexpr int ROW_PITCH = 2 * D + 16;   // bytes
-    static constexpr int T_PITCH = 2 * 64 + 8;     // bytes, 64-row transposed tile
-    static constexpr int KS = D / 16;              // k-steps over the head dim
-    static constexpr int DB = D / 32;              // 32-wide head-dim blocks
-    static constexpr int CHUNKS_PER_ROW = D / 8;   // 16-byte chunks per row
+    static constexpr int ROW_BYTES = 2 * D;           // 256 (D=128) or 128 (D=64)
+    static constexpr int IMG_BYTES = 64 * ROW_BYTES;  // one 64-row tile image
+    static constexpr int KS = D / 16;                 // k-steps over the head dim
+    static constexpr int DB = D / 32;                 // 32-wide head-dim blocks
+    static constexpr int SLOTS = D / 8;               // 16-byte slots per row
+    static constexpr int ROWS_PER_DMA = 64 / SLOTS;   // rows written by one wave-instruction (4 or 8)
 };
 
-__device__ __forceinline__ uint4 z4() { return make_uint4(0, 0, 0, 0); }
-
-// ---- stage ROWS x D rows (row-major, token stride ts elements) into a "row" LDS image ------------
-// src points at (first row, head, d = 0).  Rows >= valid_rows are zero-filled.
-template <int D, int ROWS, int NT>
-struct RowStager {
-    static constexpr int CPR = D / 8;
-    static constexpr int TOTAL = ROWS * CPR;
-    static constexpr int PER = (TOTAL + NT - 1) / NT;
-    uint4 r[PER];
-    __device__ __forceinline__ void load(const bf16_t* __restrict__ src, int64_t ts, int valid_rows) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int c = threadIdx.x + NT * q;
-            const int row = c / CPR, ch = c % CPR;
-            r[q] = (c < TOTAL && row < valid_rows) ? ld16(src + (int64_t)row * ts + ch * 8) : z4();
-        }
-    }
-    __device__ __forceinline__ void store(unsigned char* lds) const {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int c = threadIdx.x + NT * q;
-            const int row = c / CPR, ch = c % CPR;
-            if (c < TOTAL) st16(lds + row * (2 * D + 16) + ch * 16, r[q]);
-        }
-    }
-};
-
-// ---- stage 64 rows x D into a transposed LDS image [D][64] -----------------------------------------
-// task = (rg = group of 4 rows, 0..15 ; dc = 8-column chunk); rg is the fast index across lanes so a
-// 16-lane ds_write_b64 group writes one contiguous 128-byte image row.
-template <int D, int NT>
-struct TransStager {
-    static constexpr int TASKS = 16 * (D / 8);
-    static constexpr int PER = (TASKS + NT - 1) / NT;
-    uint4 r[PER][4];
-    __device__ __forceinline__ void load(const bf16_t* __restrict__ src, int64_t ts, int valid_rows) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int t = threadIdx.x + NT * q;
-            const int rg = t & 15, dc = t >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = rg * 4 + j;
-                r[q][j] = (t < TASKS && row < valid_rows) ? ld16(src + (int64_t)row * ts + dc * 8) : z4();
-            }
-        }
-    }
-    __device__ __forceinline__ void store(unsigned char* lds) const {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int t = threadIdx.x + NT * q;
-            const int rg = t & 15, dc = t >> 4;
-            if (t >= TASKS) continue;
-            unsigned char* base = lds + (dc * 8) * (2 * 64 + 8) + rg * 8;
-            const unsigned w0[4] = {r[q][0].x, r[q][0].y, r[q][0].z, r[q][0].w};
-            const unsigned w1[4] = {r[q][1].x, r[q][1].y, r[q][1].z, r[q][1].w};
-            const unsigned w2[4] = {r[q][2].x, r[q][2].y, r[q][2].z, r[q][2].w};
-            const unsigned w3[4] = {r[q][3].x, r[q][3].y, r[q][3].z, r[q][3].w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                uint2 lo, hi;
-                lo.x = (w0[p] & 0xffffu) | (w1[p] << 16);
-                lo.y = (w2[p] & 0xffffu) | (w3[p] << 16);
-                hi.x = (w0[p] >> 16) | (w1[p] & 0xffff0000u);
-                hi.y = (w2[p] >> 16) | (w3[p] & 0xffff0000u);
-                st8(base + (2 * p) * (2 * 64 + 8), lo);
-                st8(base + (2 * p + 1) * (2 * 64 + 8), hi);
-            }
-        }
-    }
-};
-
-// fragment of a "row" image: rows row0 + (l & 31), k-step ks
-template <int D>
-__device__ __forceinline__ s16x8 row_frag(const unsigned char* img, int row0, int ks, int lane) {
-    return *reinterpret_cast<const s16x8*>(img + (row0 + (lane & 31)) * (2 * D + 16) + ks * 32 + (lane >> 5) * 16);
+// slot permutation of row r (see header): D=128 (16 slots/row): ((r & 3) << 2) | ((r >> 2) & 3);
+//                                         D=64  ( 8 slots/row): (((r >> 1) & 1) << 2) | ((r >> 2) & 3)
+template <int D> __device__ __forceinline__ int swz(int r) {
+    return D == 128 ? (((r & 3) << 2) | ((r >> 2) & 3)) : ((((r >> 1) & 1) << 2) | ((r >> 2) & 3));
 }
 
-// fragment of a transposed image [D][64]: d = d0 + (l & 31); rows (k-slots) of 16-row step `step`
-__device__ __forceinline__ s16x8 trans_frag(const unsigned char* img, int d0, int step, int lane) {
-    const unsigned char* p = img + (d0 + (lane & 31)) * (2 * 64 + 8) + (step * 16 + 4 * (lane >> 5)) * 2;
-    const uint2 a = *reinterpret_cast<const uint2*>(p);
-    const uint2 b = *reinterpret_cast<const uint2*>(p + 16);
-    union { uint4 u; s16x8 s; } cv;
-    cv.u = make_uint4(a.x, a.y, b.x, b.y);
-    return cv.s;
+__device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// DMA one 64-row tile (rows row0.., token stride ts elements) into `img`.  4 waves share the tile.
+// Rows >= valid_rows re-read the last valid row (finite data; such rows are masked by the callers).
+template <int D, int NW>
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int64_t ts, int valid_rows, unsigned char* img, int wave, int lane) {
+    using G = Geo<D>;
+    constexpr int INSTRS = 64 / G::ROWS_PER_DMA;
+#pragma unroll
+    for (int q = 0; q < INSTRS / NW; ++q) {
+        const int g = wave + NW * q;
+        const int row = g * G::ROWS_PER_DMA + lane / G::SLOTS;
+        const int c = (lane % G::SLOTS) ^ swz<D>(row);
+        const int rr = min(row, valid_rows - 1);
+        dma16(src + (int64_t)rr * ts + c * 8, img + g * 1024);
+    }
+}
+
+// Per-lane byte offsets of the fragments inside ANY tile image, computed once per kernel: the XOR swizzle only
+// involves the low row bits, which do not depend on the 32-row block / 16-row step / image / pipeline stage, so
+// inside the tile loop every fragment read is `ds_read base_register offset:immediate` with zero address VALU.
+template <int D>
+struct FragOffs {
+    int row[Geo<D>::KS];    // "row" fragment of k-step ks (rows (l & 31) of a 32-row block)
+    int tr0[Geo<D>::DB];    // "transposed" fragment, first  ds_read_b64_tr_b16 (rows 4h + 0..3 of a 16-row step), d-block db
+    int tr1[Geo<D>::DB];    // second read (rows 8 + 4h + 0..3)
+    __device__ __forceinline__ void init(int lane) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < Geo<D>::KS; ++ks) row[ks] = r * (2 * D) + (((ks * 2 + h) ^ swz<D>(r)) << 4);
+        const int p = lane & 15, gq = lane >> 4;
+        const int r0 = 4 * h + (p >> 2), r1 = r0 + 8;
+#pragma unroll
+        for (int db = 0; db < Geo<D>::DB; ++db) {
+            const int col = 32 * db + 16 * (gq & 1) + 4 * (p & 3);
+            tr0[db] = r0 * (2 * D) + ((((col >> 3) ^ swz<D>(r0)) << 4) | ((col & 7) << 1));
+            tr1[db] = r1 * (2 * D) + ((((col >> 3) ^ swz<D>(r1)) << 4) | ((col & 7) << 1));
+        }
+    }
+};
+
+// "row" fragment: rows row0 + (l & 31) (row0 a multiple of 32), d = 16*ks + 8*(l >> 5) .. +7
+template <int D>
+__device__ __forceinline__ s16x8 row_frag(const unsigned char* img, int row0, int ks, const FragOffs<D>& fo) {
+    return *reinterpret_cast<const s16x8*>(img + row0 * (2 * D) + fo.row[ks]);
+}
+
+// "transposed" fragment: d = 32*db + (l & 31); contracted rows of 16-row step `step` in C/D register order
+template <int D>
+__device__ __forceinline__ s16x8 trans_frag(const unsigned char* img, int db, int step, const FragOffs<D>& fo) {
+    const unsigned char* base = img + step * 16 * (2 * D);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + fo.tr0[db]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + fo.tr1[db]));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
 }
 
 // pack accumulator regs [8*half .. 8*half+7] of a 32x32 C/D tile into a bf16 fragment
@@ -135,5 +125,7 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     return z;
 }
+
+__device__ __forceinline__ uint4 z4() { return make_uint4(0, 0, 0, 0); }
 
 }  // namespace fa

@@ -4,88 +4,129 @@
 //   fwd   y  = x W^T   (A [M][K], B [N][K])            a_kmajor=0 b_kmajor=0
 //   dgrad dx = dy W    (A [M][K], B stored [K][N])     a_kmajor=0 b_kmajor=1
 //   wgrad dW = dy^T x  (A stored [K][M], B [K][N])     a_kmajor=1 b_kmajor=1
-// Block tile 128x128x64, 4 wave64 (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
-// Staging is register-staged and double-buffered in LDS: the global loads of tile t+1 are issued
-// before the MFMAs of tile t and written to the other LDS buffer after them (one barrier per
-// k-tile).  The LDS image is always [row][k] with k contiguous and a 144-byte row pitch
-// (conflict-free ds_read_b128 for 16 consecutive rows: 144/4 = 36 banks apart).  Operands whose
-// contraction index is the slow one in memory (k-major) are transposed IN REGISTERS while they are
-// staged (4 k-rows x 8 columns per thread -> eight 8-byte LDS writes), so global loads stay
-// 16-byte coalesced in every variant and the MFMA side never changes.
-// The product is formed as D^T (B rows as the MFMA "A" operand) so every lane ends up with 4
-// consecutive output columns per accumulator quad; the epilogue goes through LDS and leaves as
-// 16-byte row-contiguous stores, optionally fused with the bf16 `grad += new` of autograd.
+// Block tile BM x BN x 64 with WAVES_M x WAVES_N wave64; each wave owns (BM/WAVES_M) x (BN/WAVES_N)
+// as 32x32 MFMA tiles.  Staging is register-staged and double-buffered in LDS: the global loads of
+// tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer in the MIDDLE
+// of them (so the ds_writes overlap the second half of the MFMAs; one barrier per k-tile).  The LDS
+// image is always [row][k] with k contiguous and a 144-byte row pitch (conflict-free ds_read_b128
+// for 16 consecutive rows: 144/4 = 36 banks apart).  Operands whose contraction index is the slow
+// one in memory (k-major) are transposed IN REGISTERS while they are staged (4 k-rows x 8 columns
+// per thread -> eight 8-byte LDS writes), so global loads stay 16-byte coalesced in every variant
+// and the MFMA side never changes.  The product is formed as D^T (B rows as the MFMA "A" operand) so
+// every lane ends up with 4 consecutive output columns per accumulator quad; the epilogue goes
+// through LDS and leaves as 16-byte row-contiguous stores, optionally fused with the bf16
+// `grad += new` of autograd.
+//
+// Tile shapes: 256x256 (8 waves, 128x64 per wave: 0.75 ds_read_b128 per MFMA, 147 KB LDS, 1 block/CU),
+// 256x128 / 128x256 (8 waves, 64x64 per wave) and 128x128 (4 waves, 2 blocks/CU); ie_gemm_bf16 picks
+// the shape that wastes the fewest CU-rounds for the problem (wave quantisation on 256 CUs).
 //
 // Roofline: MFMA-bound; 2*M*N*K flop, algorithmic bytes 2*(M*K + N*K + M*N).
 #include "ie_common.h"
 
+extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
+                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream);
+
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int PITCH = 144;                 // bytes per LDS row (64 bf16 + 16 B pad)
-constexpr int TILE_BYTES = BM * PITCH;     // 18432
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int CPITCH = 272;                // epilogue tile pitch in bytes (128 bf16 + 16 B pad)
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 73728 >= 128*272
+constexpr int BK = 64;
+constexpr int PITCH = 144;  // bytes per LDS row (64 bf16 + 16 B pad)
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0, 0, 0, 0); }
 
-// ---- operand with k contiguous: tile = 128 rows x 64 k --------------------------------------------
-__device__ __forceinline__ void gload_kcontig(const bf16_t* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int K,
-                                              uint4 (&r)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = threadIdx.x + 256 * q;
-        const int row = c >> 3, kc = c & 7;
-        const int gr = row0 + row, gk = k0 + kc * 8;
-        r[q] = (gr < nrows && gk < K) ? ld16(P + (int64_t)gr * ld + gk) : zero4();
-    }
-}
-__device__ __forceinline__ void swrite_kcontig(unsigned char* tile, const uint4 (&r)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = threadIdx.x + 256 * q;
-        const int row = c >> 3, kc = c & 7;
-        st16(tile + row * PITCH + kc * 16, r[q]);
-    }
-}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct Cfg {
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_BYTES = BM * PITCH, B_BYTES = BN * PITCH;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int CPITCH = BN * 2 + 16;
+    static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+    static_assert(BM * CPITCH <= SMEM_BYTES, "epilogue tile must fit in the staging buffers");
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+};
 
-// ---- operand stored [K][R] (k-major): tile = 64 k-rows x 128 columns -------------------------------
-// thread -> (h = 4-row half of an 8-row k group, kg = k group, mc = 8-column chunk)
-__device__ __forceinline__ void gload_kmajor(const bf16_t* __restrict__ P, int64_t ld, int col0, int ncols, int k0, int K,
-                                             uint4 (&r)[4]) {
-    const int h = threadIdx.x & 1, kg = (threadIdx.x >> 1) & 7, mc = threadIdx.x >> 4;
-    const int col = col0 + mc * 8;
+// ---- operand with k contiguous: tile = R rows x 64 k ------------------------------------------------
+template <int R, int NT>
+struct StageKC {
+    static constexpr int PER = R * 8 / NT;
+    uint4 r[PER];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int K) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + kg * 8 + 4 * h + j;
-        r[j] = (k < K && col < ncols) ? ld16(P + (int64_t)k * ld + col) : zero4();
+        for (int q = 0; q < PER; ++q) {
+            const int c = threadIdx.x + NT * q;
+            const int row = c >> 3, kc = c & 7;
+            const int gr = row0 + row, gk = k0 + kc * 8;
+            r[q] = (gr < nrows && gk < K) ? ld16(P + (int64_t)gr * ld + gk) : zero4();
+        }
     }
-}
-__device__ __forceinline__ void swrite_kmajor(unsigned char* tile, const uint4 (&r)[4]) {
-    const int h = threadIdx.x & 1, kg = (threadIdx.x >> 1) & 7, mc = threadIdx.x >> 4;
-    unsigned char* base = tile + (mc * 8) * PITCH + kg * 16 + h * 8;
-    const unsigned w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
-    const unsigned w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
-    const unsigned w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
-    const unsigned w3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+    __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint2 lo, hi;
-        lo.x = (w0[q] & 0xffffu) | (w1[q] << 16);
-        lo.y = (w2[q] & 0xffffu) | (w3[q] << 16);
-        hi.x = (w0[q] >> 16) | (w1[q] & 0xffff0000u);
-        hi.y = (w2[q] >> 16) | (w3[q] & 0xffff0000u);
-        st8(base + (2 * q) * PITCH, lo);
-        st8(base + (2 * q + 1) * PITCH, hi);
+        for (int q = 0; q < PER; ++q) {
+            const int c = threadIdx.x + NT * q;
+            const int row = c >> 3, kc = c & 7;
+            st16(tile + row * PITCH + kc * 16, r[q]);
+        }
     }
-}
+};
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
-                                                      int64_t ldb, bf16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                      int accumulate, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+// ---- operand stored [K][R] (k-major): tile = 64 k-rows x R columns ----------------------------------
+// task -> (h = 4-row half of an 8-row k group, kg = k group, mc = 8-column chunk); 2R tasks of 4 loads
+template <int R, int NT>
+struct StageKM {
+    static constexpr int TASKS = 2 * R;
+    static constexpr int PER = (TASKS + NT - 1) / NT;
+    uint4 r[PER][4];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ P, int64_t ld, int col0, int ncols, int k0, int K) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int t = threadIdx.x + NT * q;
+            const int h = t & 1, kg = (t >> 1) & 7, mc = t >> 4;
+            const int col = col0 + mc * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kg * 8 + 4 * h + j;
+                r[q][j] = (t < TASKS && k < K && col < ncols) ? ld16(P + (int64_t)k * ld + col) : zero4();
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile) const {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int t = threadIdx.x + NT * q;
+            if (t >= TASKS) continue;
+            const int h = t & 1, kg = (t >> 1) & 7, mc = t >> 4;
+            unsigned char* base = tile + (mc * 8) * PITCH + kg * 16 + h * 8;
+            const unsigned w0[4] = {r[q][0].x, r[q][0].y, r[q][0].z, r[q][0].w};
+            const unsigned w1[4] = {r[q][1].x, r[q][1].y, r[q][1].z, r[q][1].w};
+            const unsigned w2[4] = {r[q][2].x, r[q][2].y, r[q][2].z, r[q][2].w};
+            const unsigned w3[4] = {r[q][3].x, r[q][3].y, r[q][3].z, r[q][3].w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint2 lo, hi;
+                lo.x = (w0[p] & 0xffffu) | (w1[p] << 16);
+                lo.y = (w2[p] & 0xffffu) | (w3[p] << 16);
+                hi.x = (w0[p] >> 16) | (w1[p] & 0xffff0000u);
+                hi.y = (w2[p] >> 16) | (w3[p] & 0xffff0000u);
+                st8(base + (2 * p) * PITCH, lo);
+                st8(base + (2 * p + 1) * PITCH, hi);
+            }
+        }
+    }
+};
+
+template <bool KM, int R, int NT> struct StagerSel { using type = StageKC<R, NT>; };
+template <int R, int NT> struct StagerSel<true, R, NT> { using type = StageKM<R, NT>; };
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_k(const bf16_t* __restrict__ A, int64_t lda,
+                                                                      const bf16_t* __restrict__ B, int64_t ldb,
+                                                                      bf16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                                      int accumulate, int tiles_m, int tiles_n) {
+    using G = Cfg<BM, BN, WAVES_M, WAVES_N>;
+    constexpr int NT = G::NT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM_BYTES];
 
     // ---- block -> output tile: XCD-aware (block b runs on XCD b % 8; give each XCD a contiguous
     // run of tiles so neighbours share A/B panels in that XCD's L2), then grouped along M.
@@ -95,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_k(const bf16_t* __restrict__
         const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    constexpr int GM = 8;
+    constexpr int GM = (BM >= 256) ? 4 : 8;
     const int width = GM * tiles_n;
     const int group = id / width;
     const int first_m = group * GM;
@@ -105,23 +146,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_k(const bf16_t* __restrict__
     const int m0 = pm * BM, n0 = pn * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    f32x16 acc[2][2];
+    f32x16 acc[G::TM][G::TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < G::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rb[4];
+    typename StagerSel<A_KM, BM, NT>::type sa;
+    typename StagerSel<B_KM, BN, NT>::type sb;
     const int nk = (K + BK - 1) / BK;
 
-    if (A_KM) gload_kmajor(A, lda, m0, M, 0, K, ra); else gload_kcontig(A, lda, m0, M, 0, K, ra);
-    if (B_KM) gload_kmajor(B, ldb, n0, N, 0, K, rb); else gload_kcontig(B, ldb, n0, N, 0, K, rb);
-    if (A_KM) swrite_kmajor(smem, ra); else swrite_kcontig(smem, ra);
-    if (B_KM) swrite_kmajor(smem + TILE_BYTES, rb); else swrite_kcontig(smem + TILE_BYTES, rb);
+    sa.load(A, lda, m0, M, 0, K);
+    sb.load(B, ldb, n0, N, 0, K);
+    sa.store(smem);
+    sb.store(smem + G::A_BYTES);
     __syncthreads();
 
     const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 16;
@@ -129,56 +171,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_k(const bf16_t* __restrict__
         const bool more = kt + 1 < nk;
         if (more) {
             const int k0 = (kt + 1) * BK;
-            if (A_KM) gload_kmajor(A, lda, m0, M, k0, K, ra); else gload_kcontig(A, lda, m0, M, k0, K, ra);
-            if (B_KM) gload_kmajor(B, ldb, n0, N, k0, K, rb); else gload_kcontig(B, ldb, n0, N, k0, K, rb);
+            sa.load(A, lda, m0, M, k0, K);
+            sb.load(B, ldb, n0, N, k0, K);
         }
-        const unsigned char* At = smem + (kt & 1) * STAGE_BYTES + (wm * 64) * PITCH + frag_off;
-        const unsigned char* Bt = smem + (kt & 1) * STAGE_BYTES + TILE_BYTES + (wn * 64) * PITCH + frag_off;
+        const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES + (wm * G::WM) * PITCH + frag_off;
+        const unsigned char* Bt = smem + (kt & 1) * G::STAGE_BYTES + G::A_BYTES + (wn * G::WN) * PITCH + frag_off;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s16x8 af[2], bfr[2];
+            if (ks == 2 && more) {  // stage the next tile while the second half of this tile's MFMAs run
+                unsigned char* nxt = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
+                sa.store(nxt);
+                sb.store(nxt + G::A_BYTES);
+            }
+            s16x8 af[G::TM], bfr[G::TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const s16x8*>(At + i * 32 * PITCH + ks * 32);
+            for (int i = 0; i < G::TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(At + i * 32 * PITCH + ks * 32);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const s16x8*>(Bt + j * 32 * PITCH + ks * 32);
+            for (int j = 0; j < G::TN; ++j) bfr[j] = *reinterpret_cast<const s16x8*>(Bt + j * 32 * PITCH + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < G::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
-        }
-        if (more) {
-            unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            if (A_KM) swrite_kmajor(nxt, ra); else swrite_kcontig(nxt, ra);
-            if (B_KM) swrite_kmajor(nxt + TILE_BYTES, rb); else swrite_kcontig(nxt + TILE_BYTES, rb);
         }
         __syncthreads();
     }
 
     // ---- epilogue: accumulators (D^T layout: lane -> m, regs -> n) -> LDS [m][n] bf16 -> 16-byte stores
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = wm * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < G::TM; ++i) {
+        const int m = wm * G::WM + i * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < G::TN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = wn * G::WN + j * 32 + 8 * g + 4 * (lane >> 5);
                 uint2 v;
                 v.x = pack2bf(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]);
                 v.y = pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                st8(smem + m * CPITCH + n * 2, v);
+                st8(smem + m * G::CPITCH + n * 2, v);
             }
         }
     }
     __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per output row
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = threadIdx.x + 256 * q;
-        const int row = c >> 4, nc = c & 15;
+    for (int q = 0; q < BM * CPR / NT; ++q) {
+        const int c = threadIdx.x + NT * q;
+        const int row = c / CPR, nc = c % CPR;
         const int gm = m0 + row, gn = n0 + nc * 8;
         if (gm < M && gn < N) {
-            uint4 v = ld16(smem + row * CPITCH + nc * 16);
+            uint4 v = ld16(smem + row * G::CPITCH + nc * 16);
             bf16_t* dst = C + (int64_t)gm * ldc + gn;
             if (accumulate) {
                 float o[8], n[8];
@@ -204,10 +247,48 @@ __global__ __launch_bounds__(256) void colsum_bf16_k(const bf16_t* __restrict__ 
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-}  // namespace
+template <int BM, int BN, int WM_, int WN_>
+void launch_shape(int a_km, int b_km, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, bf16_t* C, int64_t ldc,
+                  int M, int N, int K, int accumulate) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    dim3 grid((unsigned)(tiles_m * tiles_n)), block(64 * WM_ * WN_);
+#define IE_L(AK, BKM) \
+    hipLaunchKernelGGL((gemm_bf16_k<BM, BN, WM_, WN_, AK, BKM>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, tiles_m, tiles_n)
+    if (a_km) { if (b_km) IE_L(true, true); else IE_L(true, false); }
+    else      { if (b_km) IE_L(false, true); else IE_L(false, false); }
+#undef IE_L
+}
 
-extern "C" int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
-                            int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+// CU-rounds a tile shape needs on 256 CUs (blocks_per_cu co-resident), weighted by a per-shape efficiency
+// prior (bigger tiles do more MFMA work per staged byte).  Smaller is better.
+inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu, double eff) {
+    const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int64_t slots = 256 * blocks_per_cu;
+    const int64_t rounds = (tiles + slots - 1) / slots;
+    return (double)rounds * slots * bm * bn / eff;  // ~ time: rounds x work per round / efficiency
+}
+
+int pick_variant(int64_t M, int64_t N, int64_t K) {
+    // priors from the round-1 micro-benchmarks (profiles/r01_gemm_tune*.json): relative MFMA efficiency per tile shape
+    if (K > 0 && K % 64 == 0 && M >= 8 && N >= 8) {  // LDS-DMA kernels: 256x256 unless wave quantisation on 256 CUs favours 128x128
+        const double d256 = shape_cost(M, N, 256, 256, 1, 1.18);
+        const double d128 = shape_cost(M, N, 128, 128, 2, 1.00);
+        return d256 <= d128 ? 4 : 5;
+    }
+    const double c0 = shape_cost(M, N, 128, 128, 2, 1.00);
+    const double c1 = shape_cost(M, N, 256, 256, 1, 1.30);
+    const double c2 = shape_cost(M, N, 256, 128, 1, 1.12);
+    const double c3 = shape_cost(M, N, 128, 256, 1, 1.12);
+    int v = 0;
+    double best = c0;
+    if (c1 < best) { best = c1; v = 1; }
+    if (c2 < best) { best = c2; v = 2; }
+    if (c3 < best) { best = c3; v = 3; }
+    return v;
+}
+
+int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
+                  int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
     IE_CHECK_ARG(A && B && C, "ie_gemm_bf16: null pointer");
     IE_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "ie_gemm_bf16: negative size");
     IE_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30), "ie_gemm_bf16: size too large");
@@ -216,17 +297,36 @@ extern "C" int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
+    IE_CHECK_ARG(variant >= -1 && variant <= 5, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-    dim3 grid((unsigned)(tiles_m * tiles_n));
+    if (variant < 0) variant = pick_variant(M, N, K);
+    if (variant >= 4) {  // LDS-DMA kernels (gemm_bf16_dma.hip): need whole 64-wide k-tiles and >= 8 valid rows/cols to clamp to
+        IE_CHECK_SUPPORTED(K > 0 && K % 64 == 0 && M >= 8 && N >= 8, "ie_gemm_bf16: the LDS-DMA variants need K % 64 == 0");
+        return ie_gemm_dma_launch(variant - 4, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
-#define IE_L(AK, BKM)                                                                                                         \
-    hipLaunchKernelGGL((gemm_bf16_k<AK, BKM>), grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, \
-                       (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n)
-    if (a_kmajor) { if (b_kmajor) IE_L(true, true); else IE_L(true, false); }
-    else          { if (b_kmajor) IE_L(false, true); else IE_L(false, false); }
-#undef IE_L
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* b = (const bf16_t*)B;
+    bf16_t* c = (bf16_t*)C;
+    switch (variant) {
+        case 0: launch_shape<128, 128, 2, 2>(a_kmajor, b_kmajor, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate); break;
+        case 1: launch_shape<256, 256, 2, 4>(a_kmajor, b_kmajor, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate); break;
+        case 2: launch_shape<256, 128, 4, 2>(a_kmajor, b_kmajor, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate); break;
+        default: launch_shape<128, 256, 2, 4>(a_kmajor, b_kmajor, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate); break;
+    }
     return ie_launch_status("ie_gemm_bf16 launch");
+}
+
+}  // namespace
+
+extern "C" int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
+                            int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+    return gemm_dispatch(-1, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
+}
+
+extern "C" int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
+                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+    return gemm_dispatch(variant, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
 }
 
 extern "C" int ie_colsum_bf16(const void* x, int64_t ld, void* out, int64_t rows, int64_t cols, void* stream) {

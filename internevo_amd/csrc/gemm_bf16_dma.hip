@@ -1,0 +1,242 @@
+// K3/K3b  bf16 GEMM, LDS-DMA variant: no staging registers and no ds_write at all.
+//
+// Same products / operand conventions as gemm_bf16.hip (fwd NT, dgrad NN, wgrad TN), for K % 64 == 0.
+// Every operand tile goes HBM -> LDS with `global_load_lds_dwordx4` (1 KiB per wave-instruction, the
+// destination is wave-uniform base + lane*16, pinned on hardware by tools/probes/probe_lds.hip), double
+// buffered, the next tile in flight under the current tile's MFMAs.  Because the DMA image is lane-linear,
+// bank-conflict avoidance is done by permuting the per-lane SOURCE address and applying the same involution
+// when fragments are read (guide section 5.4 rule 21):
+//   * k-contiguous operand: image [R][64] bf16, 128-B rows, 16-B chunk c of row r lives at slot
+//     c ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 rows distinct mod 16, one k-chunk) touches 16
+//     distinct 16-B slots of the 256-B bank row -> conflict-free without padding;
+//   * k-major operand ([K][R] in memory, the wgrad / dgrad case): image [64][R] bf16 in its NATURAL layout,
+//     64-B block b of k-row k lives at block b ^ (k & 3); fragments are read with the hardware transposing
+//     load ds_read_b64_tr_b16 (lane i of a 16-lane group receives X[k0..k0+3][m0+i] when lane p addresses
+//     row k0 + (p >> 2), columns m0 + 4*(p & 3)..+3 -- pinned by the same probe), two reads per fragment,
+//     conflict-free because the four k-rows of a read sit in four different 64-B blocks.
+// So the transposed products cost no VALU transpose, no LDS write bandwidth and no extra registers.
+// Block tile 256x256x64, 8 wave64 as 2(M) x 4(N), 128x64 per wave (8 accumulator tiles, 0.75 LDS reads/MFMA).
+#include "ie_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int BK = 64;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct DCfg {
+    static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr int NT = 64 * NW;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;  // both image kinds are R * 64 * 2 bytes
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int CPITCH = BN * 2 + 16;
+    static constexpr int SMEM_BYTES = (2 * STAGE_BYTES > BM * CPITCH) ? 2 * STAGE_BYTES : BM * CPITCH;
+};
+
+__device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Per-lane DMA source pointers of one operand, computed once and advanced by one k-tile per issue.
+//   k-contiguous operand (R rows x 64 k): one wave-instruction = 8 rows; lane -> (row, 16-B chunk) with the chunk
+//     index XOR-permuted by ((row >> 1) & 7); rows past the edge re-read the last row (their outputs are never stored).
+//   k-major operand stored [K][ncols] (64 k-rows x R columns): one wave-instruction = 1024 / (2R) k-rows; the 16-B slot
+//     index is XOR-permuted by ((k & 3) << 2), i.e. 64-B block b of k-row k goes to block b ^ (k & 3).
+template <bool KM, int R, int NW>
+struct DmaSrc {
+    static constexpr int LPR = R / 8;                      // KM: lanes (16-B slots) per k-row
+    static constexpr int RPI = 64 / LPR;                   // KM: k-rows per instruction
+    static constexpr int PERW = KM ? (64 / RPI) / NW : R / 8 / NW;
+    const bf16_t* p[PERW];
+    int64_t step;
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int wave, int lane) {
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) {
+            const int g = wave + NW * q;
+            if (KM) {
+                const int kr = g * RPI + lane / LPR;
+                const int cpos = (lane % LPR) ^ ((kr & 3) << 2);
+                const int col = min(r0 + cpos * 8, nr - 8);
+                p[q] = P + (int64_t)kr * ld + col;
+            } else {
+                const int row = 8 * g + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                const int gr = min(r0 + row, nr - 1);
+                p[q] = P + (int64_t)gr * ld + c * 8;
+            }
+        }
+        step = KM ? 64 * ld : 64;
+    }
+    __device__ __forceinline__ void issue(unsigned char* tile, int wave) {
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) {
+            dma16(p[q], tile + (wave + NW * q) * 1024);
+            p[q] += step;
+        }
+    }
+};
+
+// fragment (rows rbase + (lane & 31), k-step ks) of a k-contiguous image
+__device__ __forceinline__ s16x8 frag_kc(const unsigned char* tile, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 31);
+    const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const s16x8*>(tile + row * 128 + c * 16);
+}
+
+// fragment (columns mbase + (lane & 31), k-step ks) of a k-major image [64][R]
+template <int R>
+__device__ __forceinline__ s16x8 frag_km(const unsigned char* tile, int mbase, int ks, int lane) {
+    const int p = lane & 15, gq = lane >> 4;
+    const int mcol = mbase + 16 * (gq & 1) + 4 * (p & 3);
+    const int swz = (p >> 2) << 6;  // (kb & 3) << 6 with kb & 3 == p >> 2
+    const int kb0 = ks * 16 + 8 * (lane >> 5) + (p >> 2);
+    const unsigned char* a0 = tile + kb0 * (2 * R) + ((mcol * 2) ^ swz);
+    const unsigned char* a1 = a0 + 4 * (2 * R);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                                     int64_t ldb, bf16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                                     int accumulate, int tiles_m, int tiles_n) {
+    using G = DCfg<BM, BN, WAVES_M, WAVES_N>;
+    constexpr int NT = G::NT, NW = G::NW;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM_BYTES];
+
+    const int nblk = tiles_m * tiles_n;
+    int id;
+    {
+        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    constexpr int GM = 4;
+    const int width = GM * tiles_n;
+    const int group = id / width;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int pm = first_m + (id % width) % gsz;
+    const int pn = (id % width) / gsz;
+    const int m0 = pm * BM, n0 = pn * BN;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    DmaSrc<A_KM, BM, NW> sa;
+    DmaSrc<B_KM, BN, NW> sb;
+    sa.init(A, lda, m0, M, wave, lane);
+    sb.init(B, ldb, n0, N, wave, lane);
+    sa.issue(smem, wave);
+    sb.issue(smem + G::A_BYTES, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            unsigned char* nxt = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
+            sa.issue(nxt, wave);
+            sb.issue(nxt + G::A_BYTES, wave);
+        }
+        const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
+        const unsigned char* Bt = At + G::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s16x8 af[G::TM], bfr[G::TN];
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+                af[i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j)
+                bfr[j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed (this wave's part)
+        __syncthreads();
+    }
+
+    // ---- epilogue (as gemm_bf16.hip): D^T accumulators -> LDS [m][n] bf16 -> 16-byte row stores
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) {
+        const int m = wm * G::WM + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = wn * G::WN + j * 32 + 8 * g + 4 * (lane >> 5);
+                uint2 v;
+                v.x = pack2bf(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]);
+                v.y = pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                st8(smem + m * G::CPITCH + n * 2, v);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int q = 0; q < BM * CPR / NT; ++q) {
+        const int c = threadIdx.x + NT * q;
+        const int row = c / CPR, nc = c % CPR;
+        const int gm = m0 + row, gn = n0 + nc * 8;
+        if (gm < M && gn < N) {
+            uint4 v = ld16(smem + row * G::CPITCH + nc * 16);
+            bf16_t* dst = C + (int64_t)gm * ldc + gn;
+            if (accumulate) {
+                float o[8], n[8];
+                unpack8(ld16(dst), o);
+                unpack8(v, n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += n[e];
+                v = pack8(o);
+            }
+            st16(dst, v);
+        }
+    }
+}
+
+}  // namespace
+
+// called from gemm_bf16.hip's dispatcher; arguments already validated there (K % 64 == 0, N % 8 == 0, ...)
+extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
+                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* b = (const bf16_t*)B;
+    bf16_t* c = (bf16_t*)C;
+#define IE_SHAPE(BM_, BN_, WM_, WN_)                                                                                              \
+    do {                                                                                                                          \
+        const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (int)((N + BN_ - 1) / BN_);                                       \
+        dim3 grid((unsigned)(tiles_m * tiles_n)), block(64 * WM_ * WN_);                                                           \
+        if (a_kmajor) {                                                                                                           \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, true>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, false>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+        } else {                                                                                                                  \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, true>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, false>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+        }                                                                                                                         \
+    } while (0)
+    if (shape == 0) IE_SHAPE(256, 256, 2, 4);
+    else IE_SHAPE(128, 128, 2, 2);
+#undef IE_SHAPE
+    return ie_launch_status("ie_gemm_bf16 (dma) launch");
+}

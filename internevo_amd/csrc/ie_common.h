@@ -45,15 +45,16 @@ static inline int ie_launch_status(const char* what) {
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved; identical to torch's cast) -------------
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// gfx950 has a native RNE convert (v_cvt_pk_bf16_f32, two floats per instruction); hipcc selects it for the
+// __bf16 fptrunc, so the conversions are written as plain casts rather than integer bit tricks.
+typedef __attribute__((ext_vector_type(2))) float ie_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ie_bf16x2;
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const ie_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ie_bf16x2));
 }
 
 __device__ __forceinline__ float bflo(unsigned w) { return __uint_as_float(w << 16); }

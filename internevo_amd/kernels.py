@@ -282,7 +282,7 @@ def cast(src, dtype, out=None):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False):
+def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False, variant=-1):
     """C[M,N] = op(A) @ op(B)  (bf16 in, fp32 accumulate, bf16 out).
     a_kmajor=False: A is [M,K];  True: A is [K,M].   b_kmajor=False: B is [N,K];  True: B is [K,N]."""
     if A.dim() != 2 or B.dim() != 2 or A.stride(1) != 1 or B.stride(1) != 1:
@@ -305,8 +305,12 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False):
     prof = GEMM_PROFILER
     if prof is not None:
         prof.begin()
-    check(_L().ie_gemm_bf16(_p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
-                            int(accumulate), _stream()), "ie_gemm_bf16")
+    if variant < 0:
+        check(_L().ie_gemm_bf16(_p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(out), out.stride(0), M, N, K,
+                                int(accumulate), _stream()), "ie_gemm_bf16")
+    else:
+        check(_L().ie_gemm_bf16_tile(int(variant), _p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(out),
+                                     out.stride(0), M, N, K, int(accumulate), _stream()), "ie_gemm_bf16_tile")
     if prof is not None:
         prof.end(2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
     return out

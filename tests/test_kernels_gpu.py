@@ -308,7 +308,8 @@ def test_add_and_cast(dev):
 
 
 # ---------------------------------------------------------------------------------------------- K3
-GEMM_SHAPES = [(128, 128, 64), (256, 256, 256), (128, 384, 512), (200, 136, 72), (8, 8, 8), (1000, 1016, 200), (512, 1792, 512)]
+GEMM_SHAPES = [(128, 128, 64), (256, 256, 256), (128, 384, 512), (200, 136, 72), (8, 8, 8), (1000, 1016, 200), (512, 1792, 512),
+               (1000, 1016, 192), (8, 8, 64), (136, 264, 128), (520, 776, 320)]  # K % 64 == 0 -> LDS-DMA kernels, ragged M/N edges
 
 
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)

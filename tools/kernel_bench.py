@@ -152,6 +152,11 @@ def main():
     rec("flash_attn_bwd causal (algorithmic 2.5x fwd)",
         timeit(lambda: K.flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], o, lse_a, cu, T, None, True, dq, dkv[:, 0], dkv[:, 1], dws), iters=5),
         flops=2.5 * fl_fwd)
+    for occ in (1, 2):  # A/B of the dQ kernel's occupancy target (2 = default)
+        K._L().ie_tune_flash_dq_occupancy(occ)
+        rec(f"flash_attn_bwd causal, dQ kernel compiled for {occ} wave(s)/SIMD",
+            timeit(lambda: K.flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], o, lse_a, cu, T, None, True, dq, dkv[:, 0], dkv[:, 1], dws), iters=5),
+            flops=2.5 * fl_fwd)
     # packed: 8 sequences of 512
     cu8 = torch.arange(0, T + 1, 512, dtype=torch.int32, device=dev)
     rec("flash_attn_fwd causal packed 8x512", timeit(lambda: K.flash_attn_fwd(q, kv[:, 0], kv[:, 1], cu8, 512, None, True, out), iters=10),
