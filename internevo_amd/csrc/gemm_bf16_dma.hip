@@ -156,20 +156,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         }
         const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
         const unsigned char* Bt = At + G::A_BYTES;
+        // Software-pipelined over the 4 k-steps: the fragments of step ks+1 are requested BEFORE the MFMAs of step ks
+        // are issued (sched_barrier pins that order; hipcc otherwise reads, waits lgkmcnt(0), computes, reads ...),
+        // so the LDS latency of all but the first step of a tile hides under 8 MFMAs.
+        s16x8 af[2][G::TM], bfr[2][G::TN];
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i)
+            af[0][i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, 0, lane) : frag_kc(At, wm * G::WM + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+            bfr[0][j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, 0, lane) : frag_kc(Bt, wn * G::WN + j * 32, 0, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s16x8 af[G::TM], bfr[G::TN];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks < 3) {
 #pragma unroll
-            for (int i = 0; i < G::TM; ++i)
-                af[i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
+                for (int i = 0; i < G::TM; ++i)
+                    af[nxt][i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks + 1, lane) : frag_kc(At, wm * G::WM + i * 32, ks + 1, lane);
 #pragma unroll
-            for (int j = 0; j < G::TN; ++j)
-                bfr[j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
+                for (int j = 0; j < G::TN; ++j)
+                    bfr[nxt][j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks + 1, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks + 1, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < G::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed (this wave's part)
         __syncthreads();

@@ -11,7 +11,8 @@ all-reduce + broadcast (2x the necessary bytes, the owner needs only its shard) 
   all_gather_into_tensor      <- updated bf16 shards, in place in the flat params
 launched asynchronously per bucket (c10d runs them on its own HIP stream and orders them against
 the compute stream), waited only where the values are consumed.
-Works with any c10d backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU multi-process tests.
+Backends: "nccl" (= RCCL on ROCm) is the product path.  "gloo" exists for the multi-process tests
+(CPU tensors, or device tensors staged through the host): same bucket/shard arithmetic, synchronous.
 """
 import torch
 import torch.distributed as dist
@@ -43,10 +44,11 @@ class ZeroComm:
             work = dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             self.pending.append((work, None))
         else:
-            # gloo: no in-place aliasing guarantee and no AVG for reduce_scatter -> SUM into a temp, scale, copy
-            tmp = torch.empty_like(shard)
-            work = dist.reduce_scatter_tensor(tmp, full.clone(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((work, lambda: shard.copy_((tmp.float() / self.world).to(shard.dtype))))
+            # test path: gloo has no AVG / in-place reduce-scatter and no device tensors -> host staging, SUM, scale
+            src = full.detach().to("cpu", copy=True)
+            tmp = torch.empty(n, dtype=src.dtype)
+            dist.reduce_scatter_tensor(tmp, src, op=dist.ReduceOp.SUM, group=self.group)
+            shard.copy_((tmp.float() / self.world).to(shard.dtype))
 
     # ---- parameters: updated shard -> every rank ---------------------------------------------------
     def gather_bucket_async(self, params_flat, bucket_index):
@@ -60,9 +62,10 @@ class ZeroComm:
             work = dist.all_gather_into_tensor(full, shard, group=self.group, async_op=True)
             self.pending.append((work, None))
         else:
-            tmp = torch.empty_like(full)
-            work = dist.all_gather_into_tensor(tmp, shard.clone(), group=self.group, async_op=True)
-            self.pending.append((work, lambda: full.copy_(tmp)))
+            src = shard.detach().to("cpu", copy=True)
+            tmp = torch.empty(b.size, dtype=src.dtype)
+            dist.all_gather_into_tensor(tmp, src, group=self.group)
+            full.copy_(tmp)
 
     def wait_all(self):
         for work, fin in self.pending:
@@ -73,10 +76,20 @@ class ZeroComm:
 
     def all_reduce_sum(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                c = t.detach().to("cpu", copy=True)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(c)
         return t
 
     def broadcast_params(self, params_flat, src=0):
         """sync_model_param at init (internlm/utils/parallel.py:71-107): every DP rank starts from rank 0's weights."""
         if self.world > 1:
-            dist.broadcast(params_flat, src=src, group=self.group)
+            if self.backend == "nccl":
+                dist.broadcast(params_flat, src=src, group=self.group)
+            else:
+                c = params_flat.detach().to("cpu", copy=True)
+                dist.broadcast(c, src=src, group=self.group)
+                params_flat.copy_(c)

@@ -1,0 +1,96 @@
+"""Data-parallel (ZeRO-1) path of the HIP engine on real kernels with world_size 2.
+
+The GPU box has one MI355X and RCCL refuses two ranks on one device, so both ranks run on cuda:0 over the gloo
+backend (ZeroComm's gloo branch: reduce-scatter / all-gather through temporaries).  What is checked is the
+engine's DP logic around the kernels -- bucket sharding, reduce-scatter(AVG) of the flat grads, the all-reduced
+squared norm, AdamW on the local shards, all-gather of the bf16 shards: a 2-rank step over 2 x M micro-batches must
+equal a 1-rank step over the same 2M micro-batches (same averaged gradient, same global grad norm, same update).
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(micro_num):
+    from internevo_amd.config import tiny
+
+    return tiny(hidden=256, layers=2, heads=4, kv_heads=2, vocab=512, seq_len=128, micro_num=micro_num, lr=1e-3, total_steps=6)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        dev = torch.device("cuda:0")
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init)
+        loader = iter(SyntheticLoader(128, 1, 2, True, 4000, data_rank=rank, data_world_size=world))
+        out = []
+        for _ in range(2):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm)))
+        q.put((rank, out, eng.params.float().cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_equals_one_rank_step(dev):
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29833, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    # single rank, micro_num 4 == the union of both ranks' micro-batches (the sampler interleaves ranks)
+    eng = InternLM2Engine(_cfg(4), dev, init_fn=formula_init)
+    loader = iter(SyntheticLoader(128, 1, 4, True, 4000))
+    ref = []
+    for _ in range(2):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm)))
+    (r0, o0, p0), (r1, o1, p1) = res
+    assert torch.equal(p0, p1), "ranks disagree on the parameters after the all-gather"
+    for k in range(2):
+        mean_loss = 0.5 * (o0[k][0] + o1[k][0])
+        print(f"step {k}: dp2 loss {mean_loss:.5f} gn {o0[k][1]:.4f} | dp1(4 micro) loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        assert abs(mean_loss - ref[k][0]) <= 2e-3 * abs(ref[k][0])
+        assert abs(o0[k][1] - o1[k][1]) <= 1e-6 * o0[k][1], "ranks disagree on the global grad norm"
+        assert abs(o0[k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    ref_params = eng.params.float().cpu()
+    # layouts differ only by per-bucket padding (world 2 vs 1): compare parameter by parameter
+    from internevo_amd.layout import FlatLayout
+
+    L2, L1 = FlatLayout(_cfg(2).model, 2), eng.layout
+    worst = 0.0
+    for n, s in L1.params.items():
+        a = ref_params[s.offset : s.offset + s.numel]
+        s2 = L2.params[n]
+        b = p0[s2.offset : s2.offset + s2.numel]
+        worst = max(worst, float((a - b).abs().max()))
+    print("max |param diff| dp2 vs dp1:", worst)
+    assert worst <= 6e-3
