@@ -178,14 +178,27 @@ def main():
     if prof is not None:
         s = prof.summary()
         ach = s["flops"] / max(s["seconds"], 1e-12)
+        # HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, collected and
+        # corrected as MI355X_MICROARCH.md prescribes): measured ratio to the algorithmic bytes x this run's algorithmic bytes
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")) as f:
+                tj = json.load(f)
+            traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
+            traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
+                            "(profiles/r01_gemm_hbm_traffic.json; fabric-side L2 misses incl. Infinity-Cache hits: 8 XCD L2s each stream their own panels)")
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {
-            "kernel": "gemm_bf16_k (v_mfma_f32_32x32x16_bf16; fwd/dgrad/wgrad of every linear layer)",
+            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd/dgrad/wgrad of every linear layer)",
             "bound": "mfma",
             "achieved": ach / 1e12,
             "peak": MFMA_PEAK / 1e12,
             "unit": "TFLOP/s",
             "frac": ach / MFMA_PEAK,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
+            "algorithmic_bytes_per_launch": s["bytes"] / max(s["launches"], 1),
             "launches": s["launches"],
             "avg_launch_us": s["avg_us"],
             "algorithmic_flops_per_launch": s["flops"] / max(s["launches"], 1),

@@ -72,10 +72,11 @@ struct DmaSrc {
     }
     __device__ __forceinline__ void issue(unsigned char* tile, int wave) {
 #pragma unroll
-        for (int q = 0; q < PERW; ++q) {
-            dma16(p[q], tile + (wave + NW * q) * 1024);
-            p[q] += step;
-        }
+        for (int q = 0; q < PERW; ++q) issue_one(q, tile, wave);
+    }
+    __device__ __forceinline__ void issue_one(int q, unsigned char* tile, int wave) {
+        dma16(p[q], tile + (wave + NW * q) * 1024);
+        p[q] += step;
     }
 };
 
@@ -103,7 +104,10 @@ __device__ __forceinline__ s16x8 frag_km(const unsigned char* tile, int mbase, i
     return r;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM>
+// SPREAD = 0: the next tile's DMA instructions are all issued at the top of the k-tile; SPREAD = n > 0: they are
+// interleaved one by one with the MFMAs of the first n k-steps (a DMA issue costs ~60-180 cycles of issue time during
+// which this wave cannot feed the matrix pipe; spreading them lets the previous MFMAs cover that time).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int SPREAD>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, bf16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                                      int accumulate, int tiles_m, int tiles_n) {
@@ -148,11 +152,73 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    constexpr int NA = DmaSrc<A_KM, BM, NW>::PERW, NB = DmaSrc<B_KM, BN, NW>::PERW;
+    constexpr int DMA_STRIDE = SPREAD > 0 ? (SPREAD * G::TM * G::TN) / (NA + NB) : 1;  // MFMAs between two DMA issues
+    static_assert(SPREAD <= 0 || DMA_STRIDE >= 1, "more DMA slots than MFMAs in the spread window");
+    if constexpr (SPREAD < 0) {
+        // ---- role-split schedule (the "two waves per SIMD alternate compute and load segments" regime of
+        // MI355X_MICROARCH.md): every k-step is a LOAD phase (fragment ds_reads + a share of the next tile's DMA
+        // issues) and a COMPUTE phase (TM*TN MFMAs), each closed by a raw s_barrier.  The second half of the waves
+        // (which share SIMDs with the first half) runs ONE PHASE BEHIND (one extra barrier up front, one fewer at the
+        // end), so in every barrier interval one wave of each SIMD issues MFMAs while its partner issues LDS reads /
+        // DMAs: the matrix pipe no longer idles while both waves of a SIMD wait for the same LDS round trip.
+        // Hazards (placement-independent, by barrier counting): a wave drains its own ds_reads (lgkmcnt(0)) before the
+        // barrier that closes a LOAD phase, so when the leading group starts tile t (and issues DMA into the buffer of
+        // tile t-1) the lagging group -- then in the COMPUTE phase of step 3 of tile t-1 -- has no read of that
+        // buffer in flight; each wave waits for its own DMA of tile t+1 (vmcnt(0)) in step 3 before the barrier that
+        // precedes the first read of tile t+1 by anyone.
+        const bool lag = wave >= NW / 2;
+        constexpr int PER_PHASE = (NA + NB + 1) / 2;  // DMA issues per LOAD phase (steps 0 and 1 only: time to land)
+        if (lag) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            unsigned char* nbuf = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
+            const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
+            const unsigned char* Bt = At + G::A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // LOAD phase
+                s16x8 af[G::TM], bfr[G::TN];
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i)
+                    af[i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j)
+                    bfr[j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
+                if (ks < 2 && more) {
+#pragma unroll
+                    for (int s = ks * PER_PHASE; s < (ks + 1) * PER_PHASE && s < NA + NB; ++s) {
+                        if (s < NA) sa.issue_one(s, nbuf, wave);
+                        else sb.issue_one(s - NA, nbuf + G::A_BYTES, wave);
+                    }
+                }
+                if (ks == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // COMPUTE phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!lag) __builtin_amdgcn_s_barrier();
+        __syncthreads();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            unsigned char* nxt = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
-            sa.issue(nxt, wave);
-            sb.issue(nxt + G::A_BYTES, wave);
+        const bool more = kt + 1 < nk;
+        unsigned char* nbuf = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
+        if (SPREAD == 0 && more) {
+            sa.issue(nbuf, wave);
+            sb.issue(nbuf + G::A_BYTES, wave);
         }
         const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
         const unsigned char* Bt = At + G::A_BYTES;
@@ -181,8 +247,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-                for (int j = 0; j < G::TN; ++j)
+                for (int j = 0; j < G::TN; ++j) {
+                    if (SPREAD > 0 && ks < SPREAD) {
+                        const int mg = ks * G::TM * G::TN + i * G::TN + j;  // MFMA index inside the spread window
+                        if (mg % DMA_STRIDE == 0 && mg / DMA_STRIDE < NA + NB && more) {
+                            const int slot = mg / DMA_STRIDE;
+                            if (slot < NA) sa.issue_one(slot, nbuf, wave);
+                            else sb.issue_one(slot - NA, nbuf + G::A_BYTES, wave);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's DMA has landed (this wave's part)
@@ -237,20 +313,25 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
     bf16_t* c = (bf16_t*)C;
-#define IE_SHAPE(BM_, BN_, WM_, WN_)                                                                                              \
+#define IE_SHAPE(BM_, BN_, WM_, WN_, SP_)                                                                                            \
     do {                                                                                                                          \
         const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (int)((N + BN_ - 1) / BN_);                                       \
         dim3 grid((unsigned)(tiles_m * tiles_n)), block(64 * WM_ * WN_);                                                           \
         if (a_kmajor) {                                                                                                           \
-            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, true>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
-            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, false>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
         } else {                                                                                                                  \
-            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, true>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
-            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, false>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
         }                                                                                                                         \
     } while (0)
-    if (shape == 0) IE_SHAPE(256, 256, 2, 4);
-    else IE_SHAPE(128, 128, 2, 2);
+    if (shape == 0) IE_SHAPE(256, 256, 2, 4, 0);
+    else if (shape == 1) IE_SHAPE(128, 128, 2, 2, 0);
+    else if (shape == 2) IE_SHAPE(256, 256, 2, 4, 2);
+    else if (shape == 3) IE_SHAPE(256, 256, 2, 4, 4);
+    else if (shape == 4) IE_SHAPE(128, 128, 2, 2, 2);
+    else if (shape == 5) IE_SHAPE(256, 256, 2, 4, -1);
+    else IE_SHAPE(128, 128, 2, 2, -1);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
 }

@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
             eng.step()
             st = eng.read_state()
             out.append((float(loss), float(st.grad_norm)))
-        q.put((rank, out, eng.params.float().cpu()))
+        q.put((rank, out, eng.params.float().cpu().numpy()))  # numpy: pickled by value (a torch tensor would travel as an fd)
     finally:
         dist.destroy_process_group()
 
@@ -74,6 +74,7 @@ def test_two_rank_step_equals_one_rank_step(dev):
         eng.step()
         ref.append((float(loss), float(eng.read_state().grad_norm)))
     (r0, o0, p0), (r1, o1, p1) = res
+    p0, p1 = torch.from_numpy(p0), torch.from_numpy(p1)
     assert torch.equal(p0, p1), "ranks disagree on the parameters after the all-gather"
     for k in range(2):
         mean_loss = 0.5 * (o0[k][0] + o1[k][0])

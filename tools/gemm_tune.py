@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from internevo_amd import kernels as K  # noqa: E402
 
-VARIANTS = {0: "128x128", 1: "256x256", 4: "dma256x256", 5: "dma128x128"}
+VARIANTS = {5: "dma128", 6: "dma256_spread2", 8: "dma128_spread2", 9: "dma256_phased", 10: "dma128_phased"}
 
 
 def t_once(fn, iters):
