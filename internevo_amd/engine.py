@@ -37,7 +37,8 @@ BF16 = torch.bfloat16
 
 
 class InternLM2Engine:
-    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None):
+    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
+                 force_collectives=False):
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -48,7 +49,7 @@ class InternLM2Engine:
         K._L()  # fail loudly now if libinternevo_hip.so is missing
         self.layout = FlatLayout(mc, world_size)
         L = self.layout
-        self.comm = ZeroComm(L, process_group, world_size, rank)
+        self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives)
 
         # ---- flat parameter / gradient buffers + ZeRO-1 fp32 state of this rank's shards
         self.params = torch.zeros(L.total, dtype=BF16, device=device)
@@ -166,10 +167,12 @@ class InternLM2Engine:
         L, F, eps = mc.num_layers, mc.ffn_dim, mc.layer_norm_epsilon
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p = self.p
+        self.comm.wait_gather(0)          # parameters of bucket b were all-gathered asynchronously by the previous step()
         K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
         ffn_out = None
         for l in range(L):
             pre = f"layers.{l}."
+            self.comm.wait_gather(1 + l)
             if l == 0:
                 K.rmsnorm_fwd(self.a_x[0], p[pre + "attention_norm.weight"], eps, self.a_n1[0], self.a_rstd1[0])
             else:
@@ -183,6 +186,7 @@ class InternLM2Engine:
             K.linear_fwd(self.a_n2[l], w13, self.a_w13[l])
             K.swiglu_fwd(self.a_w13[l][:, :F], self.a_w13[l][:, F:], self.t_act)
             ffn_out = K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+        self.comm.wait_gather(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
         K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
@@ -283,7 +287,8 @@ class InternLM2Engine:
             K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
                          self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
             self.comm.gather_bucket_async(self.params, b.index)
-        self.comm.wait_all()
+        # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter
+        # exchange overlaps the next step's first layers; read_state()/named_parameters() drain them explicitly.
         # Engine.step steps the schedulers only after a successful update; success lives on the device, so the
         # host-side schedule advances optimistically and is corrected lazily when a skip is observed (read_state()).
         self.lr_sched.step()
@@ -292,6 +297,7 @@ class InternLM2Engine:
 
     def read_state(self):
         """Host copy of the step state (synchronises).  Also rewinds the host schedulers for skipped steps."""
+        self.comm.wait_all_gathers()
         st = K.step_state_read(self.state)
         self.lr_sched.set_successful_steps(st.adam_step)
         self.beta2_sched.set_successful_steps(st.adam_step)
@@ -299,9 +305,11 @@ class InternLM2Engine:
 
     # ------------------------------------------------------------------------------------------ utilities
     def named_parameters(self):
+        self.comm.wait_all_gathers()
         return self.p.items()
 
     def load_named_parameters(self, named):
+        self.comm.wait_all_gathers()
         for n, t in named.items():
             self.p[n].copy_(t.to(self.dev, BF16))
         self.sync_master_from_params()

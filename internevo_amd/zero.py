@@ -19,13 +19,17 @@ import torch.distributed as dist
 
 
 class ZeroComm:
-    def __init__(self, layout, group=None, world_size=1, rank=0):
+    def __init__(self, layout, group=None, world_size=1, rank=0, force_collectives=False):
+        """force_collectives: issue the collectives even on a 1-rank group (they are identities there) -- lets a single-GPU
+        test drive the exact RCCL call sequence of the multi-GPU path."""
         self.layout = layout
         self.group = group
         self.world = world_size
         self.rank = rank
         self.pending = []
-        if world_size > 1:
+        self.gathers = {}
+        self.active = world_size > 1 or force_collectives
+        if self.active:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for world_size > 1")
             self.backend = dist.get_backend(group)
@@ -34,7 +38,7 @@ class ZeroComm:
 
     # ---- gradients: bucket -> averaged shard on its owner ----------------------------------------
     def reduce_bucket_async(self, grads_flat, bucket_index):
-        if self.world == 1:
+        if not self.active:
             return
         b = self.layout.buckets[bucket_index]
         full = grads_flat[b.start : b.start + b.size]
@@ -52,7 +56,7 @@ class ZeroComm:
 
     # ---- parameters: updated shard -> every rank ---------------------------------------------------
     def gather_bucket_async(self, params_flat, bucket_index):
-        if self.world == 1:
+        if not self.active:
             return
         b = self.layout.buckets[bucket_index]
         full = params_flat[b.start : b.start + b.size]
@@ -60,12 +64,20 @@ class ZeroComm:
         shard = params_flat[s : s + n]
         if self.backend == "nccl":
             work = dist.all_gather_into_tensor(full, shard, group=self.group, async_op=True)
-            self.pending.append((work, None))
+            self.gathers[bucket_index] = work
         else:
             src = shard.detach().to("cpu", copy=True)
             tmp = torch.empty(b.size, dtype=src.dtype)
             dist.all_gather_into_tensor(tmp, src, group=self.group)
             full.copy_(tmp)
+
+    def wait_gather(self, bucket_index):
+        """Block the compute stream until the all-gather of this bucket's parameters (issued by the previous step) is
+        done -- called by the forward right before the first kernel that reads the bucket, so the parameter exchange
+        of step n overlaps the forward of step n+1 (the reference's overlap_sync_param idea, hybrid_zero_optim.py:831-834)."""
+        work = self.gathers.pop(bucket_index, None)
+        if work is not None:
+            work.wait()
 
     def wait_all(self):
         for work, fin in self.pending:
@@ -74,8 +86,12 @@ class ZeroComm:
                 fin()
         self.pending = []
 
+    def wait_all_gathers(self):
+        for b in list(self.gathers):
+            self.wait_gather(b)
+
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.active:
             if self.backend == "nccl":
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             else:
@@ -86,7 +102,7 @@ class ZeroComm:
 
     def broadcast_params(self, params_flat, src=0):
         """sync_model_param at init (internlm/utils/parallel.py:71-107): every DP rank starts from rank 0's weights."""
-        if self.world > 1:
+        if self.active:
             if self.backend == "nccl":
                 dist.broadcast(params_flat, src=src, group=self.group)
             else:

@@ -95,3 +95,49 @@ def test_two_rank_step_equals_one_rank_step(dev):
         worst = max(worst, float((a - b).abs().max()))
     print("max |param diff| dp2 vs dp1:", worst)
     assert worst <= 6e-3
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        out = {}
+        for force in (False, True):
+            eng = InternLM2Engine(_cfg(2), dev, None, 1, 0, init_fn=formula_init, force_collectives=force)
+            loader = iter(SyntheticLoader(128, 1, 2, True, 4000))
+            tr = []
+            for _ in range(3):
+                batch, labels = next(loader)
+                loss = eng.forward_backward(batch, labels)
+                eng.step()  # no read_state() in between: the next forward must wait for the gathers bucket by bucket
+                tr.append(loss.clone())
+            st = eng.read_state()
+            out[force] = ([float(x) for x in tr], float(st.grad_norm), eng.params.float().cpu().numpy())
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_call_sequence_on_one_rank_group(dev):
+    """The product exchange (in-place reduce_scatter_tensor(AVG) / all_gather_into_tensor per bucket, async, the gathers
+    waited bucket by bucket in the NEXT forward; all_reduce of the squared norm) driven through real RCCL on a 1-rank
+    communicator, where every collective is an identity: the step must be bit-identical to the collective-free one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29871, q))
+    p.start()
+    out = q.get(timeout=500)
+    p.join(60)
+    (l0, g0, p0), (l1, g1, p1) = out[False], out[True]
+    assert l0 == l1 and g0 == g1
+    assert (p0 == p1).all()
