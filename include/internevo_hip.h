@@ -113,6 +113,26 @@ int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, 
               void* stream);
 int ie_ce_mean(const float* loss_rows, const int64_t* labels, int64_t rows, int64_t ignore_index,
                float* loss_out, float* count_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Metric pass fused into K4.  Replaces the per-micro-batch work of AccPerplex.update and
+ * LossWithTypeId.update (internlm/model/metrics.py:108-199,281-310), which re-read the [T, vocab] logits three
+ * more times (max, argmax, exp-sum) plus one more CE forward, and torch_scatter.scatter(..., reduce="sum") (:92-96).
+ *   ie_ce_fwd_metric = ie_ce_fwd that also writes argmax_rows[rows] (int32, FIRST index of the row maximum) and
+ *     nll_rows[rows] (plain lse - logit[label]; 0 for ignored rows; independent of label_smoothing).
+ *   ie_metric_accumulate adds one micro-batch to device-resident accumulators (single block, fixed order):
+ *     facc[5] = {right, total, total_log_probs, loss, token_num} (fp32, the reference's accumulator dtypes),
+ *     ds_right / ds_tokens int64[ntypes], ds_loss / ds_token_num fp32[ntypes], indexed by type_ids[rows] (int64).
+ *     right counts label == argmax over ALL rows; total / total_log_probs / loss / token_num over labels != ignore.
+ *     ntypes == 0: the per-type pointers may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int ie_ce_fwd_metric(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows,
+                     float* lse, int32_t* argmax_rows, float* nll_rows, int64_t rows, int64_t vocab,
+                     int64_t ignore_index, float label_smoothing, void* stream);
+int ie_metric_accumulate(const float* nll_rows, const int32_t* argmax_rows, const int64_t* labels,
+                         const int64_t* type_ids, int64_t rows, int64_t ignore_index, int ntypes,
+                         float* facc, int64_t* ds_right, int64_t* ds_tokens, float* ds_loss,
+                         float* ds_token_num, void* stream);
 int ie_ce_bwd(const void* logits, void* dlogits, int dtype, int64_t ld, const int64_t* labels,
               const float* lse, const float* dloss, float dloss_mul, const float* count, int64_t rows,
               int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream);

@@ -72,6 +72,8 @@ SIGNATURES = {
     "ie_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, P]),
     "ie_ce_fwd": (I, [P, I, I64, P, P, P, I64, I64, I64, F, P]),
     "ie_ce_mean": (I, [P, P, I64, I64, P, P, P]),
+    "ie_ce_fwd_metric": (I, [P, I, I64, P, P, P, P, P, I64, I64, I64, F, P]),
+    "ie_metric_accumulate": (I, [P, P, P, P, I64, I64, I, P, P, P, P, P, P]),
     "ie_ce_bwd": (I, [P, P, I, I64, P, P, P, F, P, I64, I64, I64, F, P]),
     "ie_sumsq_max_partials": (I64, []),
     "ie_sumsq_partial": (I, [P, I, I64, P, I64, POINTER(c_int64), P]),

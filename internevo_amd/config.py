@@ -3,7 +3,7 @@
 `load_reference_config(path)` executes an InternEvo config file exactly like
 internlm/core/context/parallel_context.py:77-127 (Config.from_file: the .py is run and its module
 globals become the config) and maps the keys the training step needs onto `PathConfig`.
-Anything the path does not implement (pipeline parallel, MoE, checkpointing ...) is rejected loudly
+Anything the path does not implement (pipeline parallel, MoE ...) is rejected loudly
 instead of being ignored.
 """
 import dataclasses
@@ -25,6 +25,7 @@ class ModelConfig:
     rope_base: int = 10000
     adapt_hf: bool = True           # builder default (modeling_internlm2.py:1071); False = even/odd de-interleave before rotary (:425-427)
     multiple_of: int = 256          # modules/mlp.py:52
+    checkpoint: float = 0.0         # fraction of layers under activation checkpointing (launch.py:295-303; True -> 1, False -> 0)
     dtype: str = "torch.bfloat16"
     # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
     init_std: float = 0.02
@@ -46,6 +47,12 @@ class ModelConfig:
     def ffn_dim(self):
         f = int(self.hidden_size * self.mlp_ratio)
         return self.multiple_of * ((f + self.multiple_of - 1) // self.multiple_of)
+
+    @property
+    def checkpoint_layers(self):
+        """modeling_internlm2.py:857-861,910: layer lid is checkpointed iff lid < num_layers * checkpoint_fraction."""
+        lim = self.num_layers * float(self.checkpoint)
+        return sum(1 for lid in range(self.num_layers) if lid < lim)
 
     def num_params(self):
         h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size
@@ -113,8 +120,10 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {cfg.get('model_type')}")
     if m.get("num_experts", 1) > 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: MoE")
-    if m.get("checkpoint", False) not in (False, 0, 0.0):
-        raise NotImplementedError(f"{_UNSUPPORTED}: activation checkpointing (not needed with 288 GB HBM)")
+    ck = m.get("checkpoint", False)
+    ck = 1.0 if ck is True else 0.0 if ck is False else float(ck)
+    if not 0.0 <= ck <= 1.0:
+        raise ValueError(f'model.checkpoint: "{ck}" should >=0 and <=1')  # launch.py:300-303
     if not m.get("no_bias", True):
         raise NotImplementedError(f"{_UNSUPPORTED}: linear bias")
     if _parse_dtype(m.get("dtype", "torch.bfloat16")) != "torch.bfloat16":
@@ -123,7 +132,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], num_layers=m["num_layers"],
         num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
-        adapt_hf=m.get("adapt_hf", True),
+        adapt_hf=m.get("adapt_hf", True), checkpoint=ck,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]

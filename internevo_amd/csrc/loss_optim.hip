@@ -17,80 +17,120 @@ __host__ __device__ inline bool aligned16(const void* p) { return (((uintptr_t)p
 // block combine.  Mirrors flash-attn's xentropy forward / nn.CrossEntropyLoss on fp32 logits: the
 // bf16 -> fp32 cast of NaiveAMPModel (internlm/core/naive_amp.py:157-158) is exact, so reading bf16
 // logits directly gives the same numbers while halving the traffic.
-template <bool BF>
+// ARG = true additionally produces what the reference's metric pass (AccPerplex / LossWithTypeId,
+// internlm/model/metrics.py:108-199,281-310) re-reads the logits three more times for: the row argmax (first index
+// of the maximum) and the plain (un-smoothed) negative log-likelihood.
+template <bool BF, bool ARG>
 __global__ __launch_bounds__(256) void ce_fwd_k(const void* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
                                                 float* __restrict__ loss_rows, float* __restrict__ lse_out, int64_t vocab,
-                                                int64_t ignore_index, float ls, int vec_ok) {
+                                                int64_t ignore_index, float ls, int vec_ok, int32_t* __restrict__ argmax_rows,
+                                                float* __restrict__ nll_rows) {
     __shared__ float scratch[8];
+    __shared__ int iscratch[4];
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x;
     float m = -INFINITY, s = 0.f, sx = 0.f;
+    float bm = -INFINITY;   // ARG: running maximum with the index of its first occurrence
+    int bi = 0x7fffffff;
+    auto chunk = [&](const float* v, const int n, const int64_t base) {
+        float cm = v[0];
+        for (int e = 1; e < n; ++e) cm = fmaxf(cm, v[e]);
+        if (cm > m) { s *= __expf(m - cm); m = cm; }
+        for (int e = 0; e < n; ++e) { s += __expf(v[e] - m); sx += v[e]; }
+        if (ARG && cm > bm) {
+            bm = cm;
+            for (int e = n - 1; e >= 0; --e) if (v[e] == cm) bi = (int)(base + e);
+        }
+    };
     if (BF) {
         const bf16_t* x = (const bf16_t*)logits + row * ld;
-        if (vec_ok) {
-            const int64_t n8 = vocab / 8;
-            for (int64_t i = tid; i < n8; i += 256) {
-                float v[8];
-                unpack8(ld16(x + i * 8), v);
-                float cm = v[0];
-#pragma unroll
-                for (int e = 1; e < 8; ++e) cm = fmaxf(cm, v[e]);
-                if (cm > m) { s *= __expf(m - cm); m = cm; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s += __expf(v[e] - m); sx += v[e]; }
-            }
-            for (int64_t i = n8 * 8 + tid; i < vocab; i += 256) {
-                const float v = bf2f(x[i]);
-                if (v > m) { s *= __expf(m - v); m = v; }
-                s += __expf(v - m); sx += v;
-            }
-        } else {
-            for (int64_t i = tid; i < vocab; i += 256) {
-                const float v = bf2f(x[i]);
-                if (v > m) { s *= __expf(m - v); m = v; }
-                s += __expf(v - m); sx += v;
-            }
+        const int64_t n8 = vec_ok ? vocab / 8 : 0;
+        for (int64_t i = tid; i < n8; i += 256) {
+            float v[8];
+            unpack8(ld16(x + i * 8), v);
+            chunk(v, 8, i * 8);
+        }
+        for (int64_t i = n8 * 8 + tid; i < vocab; i += 256) {
+            const float v = bf2f(x[i]);
+            chunk(&v, 1, i);
         }
     } else {
         const float* x = (const float*)logits + row * ld;
-        if (vec_ok) {
-            const int64_t n4 = vocab / 4;
-            for (int64_t i = tid; i < n4; i += 256) {
-                const float4 q = *reinterpret_cast<const float4*>(x + i * 4);
-                const float v[4] = {q.x, q.y, q.z, q.w};
-                const float cm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                if (cm > m) { s *= __expf(m - cm); m = cm; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s += __expf(v[e] - m); sx += v[e]; }
-            }
-            for (int64_t i = n4 * 4 + tid; i < vocab; i += 256) {
-                const float v = x[i];
-                if (v > m) { s *= __expf(m - v); m = v; }
-                s += __expf(v - m); sx += v;
-            }
-        } else {
-            for (int64_t i = tid; i < vocab; i += 256) {
-                const float v = x[i];
-                if (v > m) { s *= __expf(m - v); m = v; }
-                s += __expf(v - m); sx += v;
-            }
+        const int64_t n4 = vec_ok ? vocab / 4 : 0;
+        for (int64_t i = tid; i < n4; i += 256) {
+            const float4 q = *reinterpret_cast<const float4*>(x + i * 4);
+            const float v[4] = {q.x, q.y, q.z, q.w};
+            chunk(v, 4, i * 4);
+        }
+        for (int64_t i = n4 * 4 + tid; i < vocab; i += 256) {
+            const float v = x[i];
+            chunk(&v, 1, i);
         }
     }
     const float mb = block_max<4>(m, scratch);
     const float contrib = (m == -INFINITY) ? 0.f : s * __expf(m - mb);
     const float sb = block_sum<4>(contrib, scratch);
     const float sxb = block_sum<4>(sx, scratch);
+    int arg = 0;
+    if (ARG) {
+        // first index holding the block maximum: min over the threads whose own maximum equals it
+        int cand = (bm == mb) ? bi : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) iscratch[tid >> 6] = cand;
+        __syncthreads();
+        arg = min(min(iscratch[0], iscratch[1]), min(iscratch[2], iscratch[3]));
+    }
     if (tid == 0) {
         const float lse = mb + logf(sb);
         lse_out[row] = lse;
         const int64_t lab = labels[row];
-        float loss = 0.f;
+        float loss = 0.f, nll = 0.f;
         if (lab != ignore_index && lab >= 0 && lab < vocab) {
             const float xl = BF ? bf2f(((const bf16_t*)logits)[row * ld + lab]) : ((const float*)logits)[row * ld + lab];
-            loss = lse - xl;
+            nll = lse - xl;
+            loss = nll;
             if (ls > 0.f) loss = (1.f - ls) * loss + ls * (lse - sxb / (float)vocab);
         }
         loss_rows[row] = loss;
+        if (ARG) { argmax_rows[row] = arg; nll_rows[row] = nll; }
+    }
+}
+
+// Metric accumulation (AccPerplex.update + LossWithTypeId.update, metrics.py:108-199,281-310) from the per-row outputs of
+// ce_fwd_k<.., true>: one block, fixed reduction order (deterministic).  facc = {right, total, total_log_probs, loss,
+// token_num}; per type: ds_right / ds_tokens (int64), ds_loss / ds_token_num (fp32).
+__global__ __launch_bounds__(1024) void metric_accumulate_k(const float* __restrict__ nll_rows, const int32_t* __restrict__ argmax_rows,
+                                                            const int64_t* __restrict__ labels, const int64_t* __restrict__ type_ids,
+                                                            int64_t rows, int64_t ignore_index, int ntypes, float* __restrict__ facc,
+                                                            int64_t* __restrict__ ds_right, int64_t* __restrict__ ds_tokens,
+                                                            float* __restrict__ ds_loss, float* __restrict__ ds_token_num) {
+    __shared__ double sh[3][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // t = -1: totals over all rows; t >= 0: rows of dataset type t
+    for (int t = -1; t < ntypes; ++t) {
+        double right = 0.0, tokens = 0.0, loss = 0.0;
+        for (int64_t i = threadIdx.x; i < rows; i += 1024) {
+            if (t >= 0 && type_ids[i] != t) continue;
+            const int64_t lab = labels[i];
+            // corrects = (label == argmax) -- no ignore mask needed, -100 is never an argmax (metrics.py:139-141,163)
+            if (lab == (int64_t)argmax_rows[i]) right += 1.0;
+            if (lab != ignore_index) { tokens += 1.0; loss += (double)nll_rows[i]; }
+        }
+        right = wave_sum_d(right); tokens = wave_sum_d(tokens); loss = wave_sum_d(loss);
+        __syncthreads();
+        if (lane == 0) { sh[0][w] = right; sh[1][w] = tokens; sh[2][w] = loss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r = 0.0, k = 0.0, l = 0.0;
+            for (int i = 0; i < 16; ++i) { r += sh[0][i]; k += sh[1][i]; l += sh[2][i]; }
+            if (t < 0) {
+                facc[0] += (float)r; facc[1] += (float)k; facc[2] += (float)l; facc[3] += (float)l; facc[4] += (float)k;
+            } else {
+                ds_right[t] += (int64_t)r; ds_tokens[t] += (int64_t)k; ds_loss[t] += (float)l; ds_token_num[t] += (float)k;
+            }
+        }
     }
 }
 
@@ -368,21 +408,59 @@ __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float
 
 }  // namespace
 
-extern "C" int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows, float* lse, int64_t rows,
-                         int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream) {
+static int ce_fwd_launch(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows, float* lse, int32_t* argmax_rows,
+                         float* nll_rows, int64_t rows, int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream,
+                         const char* what) {
     IE_CHECK_ARG(logits && labels && loss_rows && lse, "ie_ce_fwd: null pointer");
     IE_CHECK_ARG(rows >= 0 && vocab > 0 && ld >= vocab, "ie_ce_fwd: bad shape");
+    IE_CHECK_ARG(vocab < 0x7fffffff, "ie_ce_fwd: vocab too large");
     IE_CHECK_ARG(dtype == IE_BF16 || dtype == IE_F32, "ie_ce_fwd: bad dtype");
     if (rows == 0) return IE_OK;
     const int esz = dtype == IE_BF16 ? 2 : 4;
     const int vec_ok = aligned16(logits) && ((ld * esz) % 16 == 0);
-    if (dtype == IE_BF16)
-        hipLaunchKernelGGL((ce_fwd_k<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_rows, lse,
-                           vocab, ignore_index, label_smoothing, vec_ok);
-    else
-        hipLaunchKernelGGL((ce_fwd_k<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_rows, lse,
-                           vocab, ignore_index, label_smoothing, vec_ok);
-    return ie_launch_status("ie_ce_fwd launch");
+    const dim3 grid((unsigned)rows), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (argmax_rows) {
+        if (dtype == IE_BF16)
+            hipLaunchKernelGGL((ce_fwd_k<true, true>), grid, block, 0, st, logits, ld, labels, loss_rows, lse, vocab, ignore_index,
+                               label_smoothing, vec_ok, argmax_rows, nll_rows);
+        else
+            hipLaunchKernelGGL((ce_fwd_k<false, true>), grid, block, 0, st, logits, ld, labels, loss_rows, lse, vocab, ignore_index,
+                               label_smoothing, vec_ok, argmax_rows, nll_rows);
+    } else {
+        if (dtype == IE_BF16)
+            hipLaunchKernelGGL((ce_fwd_k<true, false>), grid, block, 0, st, logits, ld, labels, loss_rows, lse, vocab, ignore_index,
+                               label_smoothing, vec_ok, nullptr, nullptr);
+        else
+            hipLaunchKernelGGL((ce_fwd_k<false, false>), grid, block, 0, st, logits, ld, labels, loss_rows, lse, vocab, ignore_index,
+                               label_smoothing, vec_ok, nullptr, nullptr);
+    }
+    return ie_launch_status(what);
+}
+
+extern "C" int ie_ce_fwd(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows, float* lse, int64_t rows,
+                         int64_t vocab, int64_t ignore_index, float label_smoothing, void* stream) {
+    return ce_fwd_launch(logits, dtype, ld, labels, loss_rows, lse, nullptr, nullptr, rows, vocab, ignore_index, label_smoothing, stream,
+                         "ie_ce_fwd launch");
+}
+
+extern "C" int ie_ce_fwd_metric(const void* logits, int dtype, int64_t ld, const int64_t* labels, float* loss_rows, float* lse,
+                                int32_t* argmax_rows, float* nll_rows, int64_t rows, int64_t vocab, int64_t ignore_index,
+                                float label_smoothing, void* stream) {
+    IE_CHECK_ARG(argmax_rows && nll_rows, "ie_ce_fwd_metric: null pointer");
+    return ce_fwd_launch(logits, dtype, ld, labels, loss_rows, lse, argmax_rows, nll_rows, rows, vocab, ignore_index, label_smoothing,
+                         stream, "ie_ce_fwd_metric launch");
+}
+
+extern "C" int ie_metric_accumulate(const float* nll_rows, const int32_t* argmax_rows, const int64_t* labels, const int64_t* type_ids,
+                                    int64_t rows, int64_t ignore_index, int ntypes, float* facc, int64_t* ds_right, int64_t* ds_tokens,
+                                    float* ds_loss, float* ds_token_num, void* stream) {
+    IE_CHECK_ARG(nll_rows && argmax_rows && labels && facc && rows >= 0, "ie_metric_accumulate: bad argument");
+    IE_CHECK_ARG(ntypes >= 0 && ntypes <= 4096, "ie_metric_accumulate: bad ntypes");
+    IE_CHECK_ARG(ntypes == 0 || (type_ids && ds_right && ds_tokens && ds_loss && ds_token_num), "ie_metric_accumulate: per-type buffers missing");
+    hipLaunchKernelGGL(metric_accumulate_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_rows, argmax_rows, labels, type_ids, rows,
+                       ignore_index, ntypes, facc, ds_right, ds_tokens, ds_loss, ds_token_num);
+    return ie_launch_status("ie_metric_accumulate launch");
 }
 
 extern "C" int ie_ce_mean(const float* loss_rows, const int64_t* labels, int64_t rows, int64_t ignore_index, float* loss_out,

@@ -12,8 +12,8 @@ It is the host-side mirror of the reference's hot path:
 
 MI355X-first differences that do not change results beyond rounding order:
   * no autograd: the backward is an explicit reverse sweep over pre-allocated activation buffers
-    (288 GB HBM holds params + grads + fp32 state + all activations of a micro-batch, so nothing is
-    re-materialised and nothing is recomputed except the SwiGLU product);
+    (288 GB HBM holds params + grads + fp32 state + all activations of a micro-batch, so by default nothing
+    is recomputed except the SwiGLU product; `model.checkpoint` layers are replayed from their input);
   * parameters and gradients live in single flat bf16 buffers (layout.py); weight-gradient GEMMs
     accumulate straight into the flat gradient buffer (bf16 `+=`, as autograd's AccumulateGrad does);
   * the loss scale, overflow check, clip factor and Adam step counter live on the device
@@ -80,6 +80,7 @@ class InternLM2Engine:
         self.T = tc.packed_length
         self._alloc(self.T)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
+        self.metric = None  # optional internevo_amd.metrics.AccPerplex (attach_metric)
         self.step_count = 0
 
     # ------------------------------------------------------------------------------------------ setup
@@ -126,22 +127,28 @@ class InternLM2Engine:
         def e(*shape, dtype=BF16):
             return torch.empty(shape, dtype=dtype, device=dev)
 
-        # saved per layer
+        # saved per layer: the layer input always; everything else per activation SLOT -- a layer under activation
+        # checkpointing (model.checkpoint, modeling_internlm2.py:857-861,910: lid < num_layers * fraction) shares slot 0
+        # and is recomputed from its input in backward (solver/activation_checkpoint.py:40-172), the others own a slot
+        nck = mc.checkpoint_layers
+        self.slot = [0 if l < nck else l - nck + (1 if nck else 0) for l in range(L)]
+        S = (L - nck) + (1 if nck else 0)
         self.a_x = [e(T, h) for _ in range(L)]        # layer input (residual stream)
-        self.a_n1 = [e(T, h) for _ in range(L)]
-        self.a_rstd1 = [e(T, dtype=torch.float32) for _ in range(L)]
-        self.a_q = [e(T, hq, d) for _ in range(L)]
-        self.a_kv = [e(T, 2, hkv, d) for _ in range(L)]
-        self.a_ctx = [e(T, hq, d) for _ in range(L)]
-        self.a_lse = [e(hq, T, dtype=torch.float32) for _ in range(L)]
-        self.a_r2 = [e(T, h) for _ in range(L)]
-        self.a_n2 = [e(T, h) for _ in range(L)]
-        self.a_rstd2 = [e(T, dtype=torch.float32) for _ in range(L)]
-        self.a_w13 = [e(T, 2 * F) for _ in range(L)]
+        self.a_n1 = [e(T, h) for _ in range(S)]
+        self.a_rstd1 = [e(T, dtype=torch.float32) for _ in range(S)]
+        self.a_q = [e(T, hq, d) for _ in range(S)]
+        self.a_kv = [e(T, 2, hkv, d) for _ in range(S)]
+        self.a_ctx = [e(T, hq, d) for _ in range(S)]
+        self.a_lse = [e(hq, T, dtype=torch.float32) for _ in range(S)]
+        self.a_r2 = [e(T, h) for _ in range(S)]
+        self.a_n2 = [e(T, h) for _ in range(S)]
+        self.a_rstd2 = [e(T, dtype=torch.float32) for _ in range(S)]
+        self.a_w13 = [e(T, 2 * F) for _ in range(S)]
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
         # transient
         self.t_qkv = e(T, mc.qkv_dim)
         self.t_h0, self.t_h1, self.t_h2 = e(T, h), e(T, h), e(T, h)
+        self.t_h3 = e(T, h) if nck else None          # wo output of a recomputed layer (t_h0..2 carry gradients then)
         self.t_act = e(T, F)
         self.t_dact = e(T, F)
         self.t_dw13 = e(T, 2 * F)
@@ -162,34 +169,52 @@ class InternLM2Engine:
         F, h = self.mc.ffn_dim, self.mc.hidden_size
         return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
 
+    def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
+        """One PackedFlashLlamaLayer1D (modeling_internlm2.py:684-740) into activation slot slot[l].
+        recompute=False: the forward proper; the layer input a_x[l] = prev_ffn_out + previous layer's r2 is produced
+        here (fused with the attention norm) and the w2 output is returned.
+        recompute=True: the backward-time replay of a checkpointed layer from its saved input a_x[l]; same kernels on the
+        same values (bit-identical activations), minus the w2 GEMM whose output backward does not need."""
+        mc = self.mc
+        F, eps = mc.ffn_dim, mc.layer_norm_epsilon
+        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
+        p, s = self.p, self.slot[l]
+        pre = f"layers.{l}."
+        if l == 0 or recompute:
+            K.rmsnorm_fwd(self.a_x[l], p[pre + "attention_norm.weight"], eps, self.a_n1[s], self.a_rstd1[s])
+        else:
+            K.add_rmsnorm_fwd(prev_ffn_out, self.a_r2[self.slot[l - 1]], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[s], self.a_rstd1[s])
+        K.linear_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.t_qkv)
+        K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s])
+        K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, None, True, self.a_ctx[s], self.a_lse[s])
+        attn_out = self.t_h3 if recompute else self.t_h0
+        K.linear_fwd(self.a_ctx[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
+        K.add_rmsnorm_fwd(attn_out, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[s], self.a_n2[s], self.a_rstd2[s])
+        w13, _ = self._w13(l)
+        K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
+        if recompute:
+            return None
+        K.swiglu_fwd(self.a_w13[s][:, :F], self.a_w13[s][:, F:], self.t_act)
+        return K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+
     def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
         mc = self.mc
-        L, F, eps = mc.num_layers, mc.ffn_dim, mc.layer_norm_epsilon
-        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
+        L, eps = mc.num_layers, mc.layer_norm_epsilon
         p = self.p
         self.comm.wait_gather(0)          # parameters of bucket b were all-gathered asynchronously by the previous step()
         K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
         ffn_out = None
         for l in range(L):
-            pre = f"layers.{l}."
             self.comm.wait_gather(1 + l)
-            if l == 0:
-                K.rmsnorm_fwd(self.a_x[0], p[pre + "attention_norm.weight"], eps, self.a_n1[0], self.a_rstd1[0])
-            else:
-                K.add_rmsnorm_fwd(ffn_out, self.a_r2[l - 1], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[l], self.a_rstd1[l])
-            K.linear_fwd(self.a_n1[l], p[pre + "attention.wqkv.weight"], self.t_qkv)
-            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[l], self.a_kv[l])
-            K.flash_attn_fwd(self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], cu, max_seqlen, None, True, self.a_ctx[l], self.a_lse[l])
-            K.linear_fwd(self.a_ctx[l].view(self.T, -1), p[pre + "attention.wo.weight"], self.t_h0)
-            K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
-            w13, _ = self._w13(l)
-            K.linear_fwd(self.a_n2[l], w13, self.a_w13[l])
-            K.swiglu_fwd(self.a_w13[l][:, :F], self.a_w13[l][:, F:], self.t_act)
-            ffn_out = K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+            ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
         self.comm.wait_gather(L + 1)
-        K.add_rmsnorm_fwd(ffn_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
+        K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
-        K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+        if self.metric is None:
+            K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+        else:  # metric pass (SchedulerMetricHook.post_helper_func -> AccPerplex.update) fused into the same sweep over the logits
+            K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss, self.t_argmax, self.t_nll)
+            self.metric.update_fused(self.t_nll, self.t_argmax, labels)
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro):
         mc, tc = self.mc, self.tc
@@ -211,27 +236,30 @@ class InternLM2Engine:
         for l in range(L - 1, -1, -1):
             pre = f"layers.{l}."
             w13, gw13 = self._w13(l)
+            sl = self.slot[l]
+            if l < mc.checkpoint_layers:
+                self._layer_forward(l, None, cu, pos, max_seqlen, True)
             # feed-forward
             K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
-            K.swiglu_bwd(self.t_dact, self.a_w13[l][:, :F], self.a_w13[l][:, F:], self.t_dw13[:, :F], self.t_dw13[:, F:], self.t_act)
+            K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], self.t_dw13[:, :F], self.t_dw13[:, F:], self.t_act)
             K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], True)
             d_n2 = spare[0]
             K.linear_dgrad(self.t_dw13, w13, d_n2)
-            K.linear_wgrad(self.t_dw13, self.a_n2[l], gw13, True)
+            K.linear_wgrad(self.t_dw13, self.a_n2[sl], gw13, True)
             d_r2 = spare[1]
-            K.rmsnorm_bwd(d_n2, self.a_r2[l], p[pre + "ffn_norm.weight"], self.a_rstd2[l], d_out, g[pre + "ffn_norm.weight"], True, ws, d_r2)
+            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], True, ws, d_r2)
             # attention
             d_ctx = d_n2  # reuse
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
-            K.linear_wgrad(d_r2, self.a_ctx[l].view(T, -1), g[pre + "attention.wo.weight"], True)
-            K.flash_attn_bwd(d_ctx.view(T, -1, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu,
+            K.linear_wgrad(d_r2, self.a_ctx[sl].view(T, -1), g[pre + "attention.wo.weight"], True)
+            K.flash_attn_bwd(d_ctx.view(T, -1, d), self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
                              max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
             K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
             d_n1 = d_ctx
             K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
-            K.linear_wgrad(self.t_qkv, self.a_n1[l], g[pre + "attention.wqkv.weight"], True)
+            K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], True)
             d_x = d_out  # the old d_out buffer is free now
-            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[l], d_r2, g[pre + "attention_norm.weight"], True, ws, d_x)
+            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], True, ws, d_x)
             # rotate buffers: next d_out = d_x; spare = the two others
             spare = [d_n2, d_r2]
             d_out = d_x
@@ -240,6 +268,13 @@ class InternLM2Engine:
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], True, self.t_emb_ws)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, 0)
+
+    def attach_metric(self, metric):
+        """get_scheduler_hooks(metric, ...) of the reference (train/pipeline.py): the metric sees every micro-batch's logits."""
+        self.metric = metric
+        if metric is not None and not hasattr(self, "t_argmax"):
+            self.t_argmax = torch.empty(self.T, dtype=torch.int32, device=self.dev)
+            self.t_nll = torch.empty(self.T, dtype=torch.float32, device=self.dev)
 
     def zero_grad(self):
         self.grads.zero_()
@@ -256,6 +291,8 @@ class InternLM2Engine:
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
         lab_d = labels.to(self.dev, non_blocking=True)
         pos_d = batch["indexes"].to(self.dev, non_blocking=True)
+        if self.metric is not None and self.metric.ntypes:
+            self.metric.set_current_type_ids(batch["type_ids"])  # train.py:239-240
         for i in range(M):
             cu_h = batch["cu_seqlens"][i]
             max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())  # host-side: no `.item()` sync (modeling_internlm2.py:989 syncs here)

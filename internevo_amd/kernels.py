@@ -168,9 +168,10 @@ def swiglu_bwd(dout, a, b, da=None, db=None, act_out=None):
 
 
 # ------------------------------------------------------------------------------------------ CE
-def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=None, lse=None, out=None):
+def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=None, lse=None, out=None, argmax_rows=None, nll_rows=None):
     """logits [rows, V] (bf16|fp32, row stride arbitrary), labels int64 [rows] ->
-    (loss_rows fp32, lse fp32, loss_mean fp32[1], count fp32[1])."""
+    (loss_rows fp32, lse fp32, loss_mean fp32[1], count fp32[1]).
+    With argmax_rows (int32 [rows]) and nll_rows (fp32 [rows]) the metric variant of the kernel fills them too."""
     rows, V, ld = _rows_ld(logits)
     _contig(labels, "labels")
     dev = logits.device
@@ -181,10 +182,29 @@ def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=Non
     if out is None:
         out = torch.empty(2, dtype=torch.float32, device=dev)
     L = _L()
-    check(L.ie_ce_fwd(_p(logits), _dt(logits), ld, _p(labels), _p(loss_rows), _p(lse), rows, V, ignore_index, label_smoothing, _stream()),
-          "ie_ce_fwd")
+    if argmax_rows is not None:
+        assert argmax_rows.dtype == torch.int32 and nll_rows is not None and nll_rows.dtype == torch.float32
+        check(L.ie_ce_fwd_metric(_p(logits), _dt(logits), ld, _p(labels), _p(loss_rows), _p(lse), _p(argmax_rows), _p(nll_rows), rows, V,
+                                 ignore_index, label_smoothing, _stream()), "ie_ce_fwd_metric")
+    else:
+        check(L.ie_ce_fwd(_p(logits), _dt(logits), ld, _p(labels), _p(loss_rows), _p(lse), rows, V, ignore_index, label_smoothing, _stream()),
+              "ie_ce_fwd")
     check(L.ie_ce_mean(_p(loss_rows), _p(labels), rows, ignore_index, _p(out[0:1]), _p(out[1:2]), _stream()), "ie_ce_mean")
     return loss_rows, lse, out[0:1], out[1:2]
+
+
+def metric_accumulate(nll_rows, argmax_rows, labels, type_ids, facc, ds_right=None, ds_tokens=None, ds_loss=None, ds_token_num=None,
+                      ignore_index=-100):
+    """One micro-batch into the AccPerplex / LossWithTypeId accumulators (see include/internevo_hip.h)."""
+    ntypes = 0 if ds_right is None else ds_right.numel()
+    assert facc.dtype == torch.float32 and facc.numel() >= 5
+    if ntypes:
+        assert type_ids is not None and type_ids.dtype == torch.int64 and type_ids.numel() == labels.numel()
+        assert ds_right.dtype == torch.int64 and ds_tokens.dtype == torch.int64
+        _contig(type_ids, "type_ids")
+    check(_L().ie_metric_accumulate(_p(nll_rows), _p(argmax_rows), _p(labels), _p(type_ids) if ntypes else None, labels.numel(), ignore_index, ntypes,
+                                    _p(facc), _p(ds_right) if ntypes else None, _p(ds_tokens) if ntypes else None,
+                                    _p(ds_loss) if ntypes else None, _p(ds_token_num) if ntypes else None, _stream()), "ie_metric_accumulate")
 
 
 def ce_bwd(logits, labels, lse, dloss, count, dloss_mul=1.0, ignore_index=-100, label_smoothing=0.0, dlogits=None):

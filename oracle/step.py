@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import ops as O
-from .model import build_params, micro_loss
+from .model import build_params, forward_logits, micro_loss
 
 
 class OracleTrainer:
@@ -36,6 +36,7 @@ class OracleTrainer:
         self.adam_step = 0
         self.k = 0  # successful steps (drives the lr schedule)
         self.beta2_iter = 0
+        self.metric = None  # optional oracle.ops.AccPerplexOracle, fed every micro-batch's logits (SchedulerMetricHook)
 
     # lr exactly as the reference produces it: torch's scheduler objects driven the same way
     def _lr(self):
@@ -66,9 +67,15 @@ class OracleTrainer:
         for i in range(M):
             cu = batch["cu_seqlens"][i] if "cu_seqlens" in batch and batch["cu_seqlens"] is not None else None
             idx = batch["indexes"][i] if "indexes" in batch and batch["indexes"] is not None else None
-            loss = micro_loss(self.params, mc, batch["input_ids"][i], labels[i], idx, cu, tc.label_smoothing)
+            if self.metric is None:
+                loss = micro_loss(self.params, mc, batch["input_ids"][i], labels[i], idx, cu, tc.label_smoothing)
+            else:
+                logits = forward_logits(self.params, mc, batch["input_ids"][i], idx, cu)
+                loss = O.cross_entropy(logits, labels[i], tc.label_smoothing)
+                tid = batch["type_ids"][i] if batch.get("type_ids", None) is not None else None
+                self.metric.update(logits.detach().float(), labels[i], tid)
             loss = loss / M                       # `loss /= scale_loss` (no_pipeline_scheduler.py:146)
-            total += float(loss)
+            total += float(loss.detach())
             (self.scaler.scale * loss).backward()  # HybridZeroOptimizer.backward :592-594
         # compute_norm: sum of squared fp32-cast grads (norm_type 2), inf -> -1, nan -> -2
         sq = 0.0  # calc_lp (utils.py:207-212): `norm += grad_norm ** norm_type` accumulates an fp32 tensor

@@ -12,6 +12,8 @@ What it pins
                        get_megatron_flops) -> oracle/ops.py must reproduce them.
   data.json            first batches of RandomDataset -> PackedDatasetWithCut -> StaticBatchSampler ->
                        packed_collate_fn -> internevo_amd/data.py must reproduce them.
+  metrics.npz / .json  AccPerplex + LossWithTypeId accumulators and get_metric() dict on seeded logits / labels / type_ids
+                       -> oracle/ops.py:acc_perplex_update and the fused HIP metric pass must reproduce them.
   train_*.json         loss / grad-norm / loss-scale trajectories of the unmodified reference training
                        loop (internlm.core.trainer + HybridZeroOptimizer) on a tiny InternLM2, fp32 and
                        bf16, with weights set by the closed-form init of oracle/model.py:formula_init
@@ -257,7 +259,8 @@ def run_training(tag, dtype, cfg_kw, port):
         ok, norms = trainer.step()
         t_steps.append(time.time() - t0)
         rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
-                             "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
+                             "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used,
+                             "metric": metric.get_metric(reset=True)})  # train.py:264-275 reads the metric every step
         print(tag, step, rec["steps"][-1], flush=True)
     rec["sec_per_step"] = t_steps
     rec["threads"] = torch.get_num_threads()
@@ -269,6 +272,50 @@ def run_training(tag, dtype, cfg_kw, port):
     if tag.endswith("packed_probe"):
         pass
     return batches
+
+
+def gen_metrics(port=29790):
+    """AccPerplex + LossWithTypeId (internlm/model/metrics.py:56-310) run for real on seeded fp32 logits with three dataset
+    types, ignored labels and ties-free maxima: raw accumulators after each update + the get_metric() dict."""
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    from internlm.core.context import ParallelMode
+    from internlm.core.context import global_context as gpc
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.metrics import AccPerplex
+
+    cfg = tiny_config("torch.bfloat16", use_packed=False, seq_len=48, hidden=64, heads=2, kv_heads=2, vocab=160, layers=1, micro_num=3, total_steps=2)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    types = ["en", "cn", "code"]
+    metric = AccPerplex(device=torch.device("cpu"), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA), dataset_types=types)
+    gen = torch.Generator().manual_seed(77)
+    M, S, V = 3, 48, 160
+    # bf16-representable logits (the HIP path holds bf16 logits; the reference sees them cast to fp32, naive_amp.py:157)
+    logits = (torch.randn(M, S, V, generator=gen) * 3).to(torch.bfloat16).float()
+    labels = torch.randint(0, V, (M, S), generator=gen)
+    # make a good share of the predictions right, and mask some positions
+    am = logits.argmax(-1)
+    pick = torch.rand(M, S, generator=gen) < 0.4
+    labels = torch.where(pick, am, labels)
+    labels[torch.rand(M, S, generator=gen) < 0.15] = -100
+    type_ids = torch.randint(0, 3, (M, S), generator=gen)
+    type_ids[1] = torch.randint(0, 2, (S,), generator=gen)  # a micro-batch that never sees the last type (the zero-padding branch :150-154)
+    trace = []
+    metric.set_current_type_ids(type_ids)
+    for i in range(M):
+        metric(logits[i : i + 1], labels[i : i + 1])
+        trace.append({
+            "right": float(metric.right), "total": float(metric.total), "total_log_probs": float(metric.total_log_probs),
+            "ds_right": metric.ds_right.tolist(), "ds_tokens": metric.ds_tokens.tolist(),
+            "loss": float(metric.loss_with_type_id.loss), "token_num": float(metric.loss_with_type_id.token_num),
+            "ds_loss": metric.loss_with_type_id.ds_loss.tolist(), "ds_token_num": metric.loss_with_type_id.ds_token_num.tolist()})
+    res = metric.get_metric(reset=True)
+    after_reset = {"right": float(metric.right), "total": float(metric.total), "ds_tokens": metric.ds_tokens.tolist()}
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), logits=logits.numpy(), labels=labels.numpy(), type_ids=type_ids.numpy())
+    with open(os.path.join(HERE, "metrics.json"), "w") as f:
+        json.dump({"dataset_types": types, "trace": trace, "get_metric": res, "after_reset": after_reset}, f, indent=1)
+    print(res)
 
 
 RUNS = {
@@ -343,11 +390,14 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--data":
         gen_data()
         sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--metrics":
+        gen_metrics()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--ops":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data"):
+    for mode in ("--ops", "--data", "--metrics"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

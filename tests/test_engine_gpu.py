@@ -119,3 +119,30 @@ def test_engine_packed_varlen_batch_matches_oracle(dev):
         print(f"packed step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
         assert abs(float(loss) - ref["loss"]) <= 3e-3 * abs(ref["loss"])
         assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+
+
+@pytest.mark.parametrize("frac", [1.0, 0.5])
+def test_activation_checkpointing_is_bit_identical(dev, frac):
+    """model.checkpoint (solver/activation_checkpoint.py:40-172): the checkpointed layers keep only their input and are
+    replayed in backward -- same kernels on the same values, so losses, grad norms and trained weights must not move by a bit."""
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    out = []
+    for ck in (0.0, frac):
+        cfg = tiny(256, 4, 4, 2, 512, 256, 2, 1e-3, 6)
+        cfg.model.checkpoint = ck
+        eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+        assert eng.mc.checkpoint_layers == int(4 * ck)
+        loader = iter(SyntheticLoader(256, 1, 2, False, 4000))  # ragged packed samples
+        tr = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            tr.append((float(loss), float(eng.read_state().grad_norm)))
+        out.append((tr, eng.params.clone()))
+    assert out[0][0] == out[1][0], f"{out[0][0]} vs {out[1][0]}"
+    assert torch.equal(out[0][1], out[1][1])

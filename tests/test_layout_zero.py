@@ -119,3 +119,12 @@ def test_zero_exchange_gloo_world2():
         p.join(30)
     assert all(ok for _, ok, _ in res), res
     assert abs(res[0][2] - res[1][2]) < 1e-6 * abs(res[0][2])
+
+
+def test_checkpoint_fraction_maps_like_the_reference():
+    """launch.py:295-303 (True -> 1, False -> 0, else a fraction in [0,1]) and modeling_internlm2.py:857-861,910
+    (layer lid is checkpointed iff lid < num_layers * fraction)."""
+    from internevo_amd.config import ModelConfig
+
+    for L, frac, want in [(32, 0.0, 0), (32, 1.0, 32), (32, 0.5, 16), (5, 0.5, 3), (4, 0.3, 2), (2, True, 2), (2, False, 0)]:
+        assert ModelConfig(num_layers=L, checkpoint=float(frac)).checkpoint_layers == want
