@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
     args = ap.parse_args()
 
     from internevo_amd import kernels as K
@@ -90,6 +91,7 @@ def main():
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
 
+    K.LINEAR_FWD_VARIANT = args.fwd_variant
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -18,6 +18,8 @@
 // Block tile 256x256x64, 8 wave64 as 2(M) x 4(N), 128x64 per wave (8 accumulator tiles, 0.75 LDS reads/MFMA).
 #include "ie_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -52,7 +54,7 @@ struct DmaSrc {
     static constexpr int PERW = KM ? (64 / RPI) / NW : R / 8 / NW;
     const bf16_t* p[PERW];
     int64_t step;
-    __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int wave, int lane) {
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int /*K*/, int wave, int lane) {
 #pragma unroll
         for (int q = 0; q < PERW; ++q) {
             const int g = wave + NW * q;
@@ -77,6 +79,68 @@ struct DmaSrc {
     __device__ __forceinline__ void issue_one(int q, unsigned char* tile, int wave) {
         dma16(p[q], tile + (wave + NW * q) * 1024);
         p[q] += step;
+    }
+    // split form: the address VGPRs are not touched next to the load (the pointer bump of every slot is done in one place)
+    __device__ __forceinline__ void issue_keep(int q, unsigned char* tile, int wave) { dma16(p[q], tile + (wave + NW * q) * 1024); }
+    __device__ __forceinline__ void advance_all() {
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) p[q] += step;
+    }
+};
+
+// Buffer-addressed twin of DmaSrc (`buffer_load_dwordx4 ... offen lds`): ONE per-lane byte offset VGPR per operand, the
+// per-piece part of the address in an SGPR (wave-uniform: piece g = wave + NW*q covers whole rows), the k advance folded
+// into the descriptor base -- no per-piece address VGPRs to bump and no 64-bit per-lane addresses through the memory
+// front end.  The swizzle term of a piece depends on g only through g & 1 == wave & 1 (NW is even), so it is per-wave
+// constant.  Rows past the edge of the matrix fall outside num_records and read as zero (no clamping needed).
+template <bool KM, int R, int NW>
+struct BufSrc {
+    static constexpr int LPR = R / 8;
+    static constexpr int RPI = 64 / LPR;
+    static constexpr int PERW = KM ? (64 / RPI) / NW : R / 8 / NW;
+    static_assert(NW % 2 == 0 && (!KM || RPI == 2 || RPI % 4 == 0), "swizzle must be per-wave constant");
+    const bf16_t* base;   // tile origin at the current k-tile
+    uint32_t bytes_left;  // bytes from `base` to the end of the matrix
+    uint32_t step_bytes;
+    int voff;
+    int soff[PERW];
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int K, int wave, int lane) {
+        const int ldb = (int)ld * 2;
+        if (KM) {  // matrix [K][ld], tile columns r0..r0+R
+            const int kr_in = lane / LPR;                                   // k-row inside a piece
+            const int kr3 = (RPI == 2 ? 2 * (wave & 1) + kr_in : kr_in) & 3;  // (g * RPI + kr_in) & 3
+            const int cpos = (lane % LPR) ^ (kr3 << 2);
+            voff = kr_in * ldb + cpos * 16;
+            base = P + r0;
+            bytes_left = (uint32_t)((int64_t)K * ldb - (int64_t)r0 * 2);
+            step_bytes = 64u * (uint32_t)ldb;
+#pragma unroll
+            for (int q = 0; q < PERW; ++q) soff[q] = (wave + NW * q) * RPI * ldb;
+        } else {   // matrix [nr][ld], tile rows r0..r0+R
+            const int row_in = lane >> 3;
+            const int sw = (4 * (wave & 1) + (lane >> 4)) & 7;              // ((8 g + row_in) >> 1) & 7
+            voff = row_in * ldb + (((lane & 7) ^ sw) * 16);
+            base = P + (int64_t)r0 * ld;
+            bytes_left = (uint32_t)(((int64_t)nr - r0) * ldb);
+            step_bytes = 128u;
+#pragma unroll
+            for (int q = 0; q < PERW; ++q) soff[q] = 8 * (wave + NW * q) * ldb;
+        }
+    }
+    __device__ __forceinline__ void issue_keep(int q, unsigned char* tile, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type does not exist in the host pass
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_left, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave + NW * q) * 1024), 16, voff, soff[q], 0, 0);
+#endif
+    }
+    __device__ __forceinline__ void advance_all() {
+        base = (const bf16_t*)((const unsigned char*)base + step_bytes);
+        bytes_left -= step_bytes;
+    }
+    __device__ __forceinline__ void issue(unsigned char* tile, int wave) {
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) issue_keep(q, tile, wave);
+        advance_all();
     }
 };
 
@@ -143,10 +207,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = K / BK;
-    DmaSrc<A_KM, BM, NW> sa;
-    DmaSrc<B_KM, BN, NW> sb;
-    sa.init(A, lda, m0, M, wave, lane);
-    sb.init(B, ldb, n0, N, wave, lane);
+    constexpr bool USE_BUF = SPREAD == -2;
+    std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
+    std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
+    sa.init(A, lda, m0, M, K, wave, lane);
+    sb.init(B, ldb, n0, N, K, wave, lane);
     sa.issue(smem, wave);
     sb.issue(smem + G::A_BYTES, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -155,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     constexpr int NA = DmaSrc<A_KM, BM, NW>::PERW, NB = DmaSrc<B_KM, BN, NW>::PERW;
     constexpr int DMA_STRIDE = SPREAD > 0 ? (SPREAD * G::TM * G::TN) / (NA + NB) : 1;  // MFMAs between two DMA issues
     static_assert(SPREAD <= 0 || DMA_STRIDE >= 1, "more DMA slots than MFMAs in the spread window");
-    if constexpr (SPREAD < 0) {
+    if constexpr (SPREAD == -1) {
         // ---- role-split schedule (the "two waves per SIMD alternate compute and load segments" regime of
         // MI355X_MICROARCH.md): every k-step is a LOAD phase (fragment ds_reads + a share of the next tile's DMA
         // issues) and a COMPUTE phase (TM*TN MFMAs), each closed by a raw s_barrier.  The second half of the waves
@@ -211,6 +276,101 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
             }
         }
         if (!lag) __builtin_amdgcn_s_barrier();
+        __syncthreads();
+    } else if constexpr (SPREAD == -2) {
+        // ---- one wave per SIMD (4 waves, 128x128 per wave: 0.5 LDS reads per MFMA), software-pipelined ACROSS k-tiles.
+        // The single barrier of a k-tile sits between k-step 2 and k-step 3: by then every wave has requested all four
+        // fragment sets of tile t, so after it (a) the first fragments of tile t+1 are read while the MFMAs of step 3 of
+        // tile t run (no pipeline refill bubble at tile boundaries) and (b) the DMA of tile t+2 is issued into tile t's
+        // buffer, one instruction per MFMA of step 3, which gives it three more k-steps to land before the next barrier.
+        s16x8 af[2][G::TM], bfr[2][G::TN];
+        auto load_frags = [&](const unsigned char* At, int ks, int set) {
+            const unsigned char* Bt = At + G::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+                af[set][i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j)
+                bfr[set][j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
+        };
+        // DMA placement: the next k-step's fragment reads go under the first TM+TN MFMAs of a k-step (one each), the DMA
+        // pieces under the MFMAs after them (one each) -- never both in one MFMA gap: a gap hides ~5 single-issue
+        // instructions, and a DMA piece with its M0 update next to a ds_read and its wait already overflows it.
+        // Iteration t issues the first PER pieces of tile t+2 (into tile t's buffer, free after the barrier) under its
+        // step 3 and the remaining pieces of tile t+1 under its steps 0 and 1 (they have step 2 to land).
+        constexpr int NS = NA + NB, NM = G::TM * G::TN;
+        auto issue_slot = [&](int slot, unsigned char* tile) {
+            if (slot < NA) sa.issue_keep(slot, tile, wave);
+            else sb.issue_keep(slot - NA, tile + G::A_BYTES, wave);
+        };
+        auto run = [&](auto) {
+            constexpr int FIRST = G::TM + G::TN;        // MFMA positions before FIRST carry the fragment reads
+            constexpr int PER = (NS + 2) / 3;           // pieces under step 3; the rest split over steps 0 and 1
+            static_assert(PER <= NM - FIRST && NS - PER <= 2 * (NM - FIRST), "not enough DMA positions");
+            // piece issued at (window step kidx = 0 (k-step 3), 1 (k-step 0), 2 (k-step 1); MFMA position m), or -1
+            auto slot_at = [](int kidx, int m) constexpr -> int {
+                if (m < FIRST) return -1;
+                const int pos = m - FIRST;
+                if (kidx == 0) return pos < PER ? pos : -1;
+                const int rest = NS - PER, first = (rest + 1) / 2;  // step 0 takes `first`, step 1 the remainder
+                if (kidx == 1) return pos < first ? PER + pos : -1;
+                return pos < rest - first ? PER + first + pos : -1;
+            };
+            if (nk > 1) {
+#pragma unroll
+                for (int sl = 0; sl < PER; ++sl) issue_slot(sl, smem + G::STAGE_BYTES);
+            }
+            load_frags(smem, 0, 0);
+            // one k-tile; D01: tile t+1 exists (rest of its DMA under steps 0-1, its first fragments under step 3); D3: tile t+2 exists
+            auto tile = [&](int kt, auto d01, auto d3) {
+                constexpr bool D01 = decltype(d01)::value, D3 = decltype(d3)::value;
+                unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
+                unsigned char* Nt = smem + ((kt + 1) & 1) * G::STAGE_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int cur = ks & 1, nxt = cur ^ 1;
+                    // the next k-step's fragments are requested one per MFMA (positions 0 .. TM+TN-1), not as a burst
+                    const unsigned char* Ft = ks < 3 ? At : Nt;
+                    const int fks = ks < 3 ? ks + 1 : 0;
+                    const bool do_frags = ks < 3 || D01;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j) {
+                            const int m = i * G::TN + j;
+                            if (do_frags && m < G::TM + G::TN) {
+                                if (m < G::TM) af[nxt][m] = A_KM ? frag_km<BM>(Ft, wm * G::WM + m * 32, fks, lane) : frag_kc(Ft, wm * G::WM + m * 32, fks, lane);
+                                else bfr[nxt][m - G::TM] = B_KM ? frag_km<BN>(Ft + G::A_BYTES, wn * G::WN + (m - G::TM) * 32, fks, lane)
+                                                                : frag_kc(Ft + G::A_BYTES, wn * G::WN + (m - G::TM) * 32, fks, lane);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (ks != 2) {
+                                const int sl = slot_at(ks == 3 ? 0 : ks + 1, m);
+                                if (sl >= 0 && (ks == 3 ? D3 : D01)) {
+                                    issue_slot(sl, ks == 3 ? At : Nt);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 2) {
+                        sa.advance_all();  // every slot moves on one k-tile here: slots >= PER were used for tile t+1 (steps 0-1),
+                        sb.advance_all();  // slots < PER are next used for tile t+2 (step 3)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            for (int kt = 0; kt < nk - 2; ++kt) tile(kt, T_{}, T_{});
+            if (nk >= 2) tile(nk - 2, T_{}, F_{});
+            tile(nk - 1, F_{}, F_{});
+        };
+        run(0);
         __syncthreads();
     } else
     for (int kt = 0; kt < nk; ++kt) {
@@ -331,7 +491,8 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 3) IE_SHAPE(256, 256, 2, 4, 4);
     else if (shape == 4) IE_SHAPE(128, 128, 2, 2, 2);
     else if (shape == 5) IE_SHAPE(256, 256, 2, 4, -1);
-    else IE_SHAPE(128, 128, 2, 2, -1);
+    else if (shape == 6) IE_SHAPE(128, 128, 2, 2, -1);
+    else IE_SHAPE(256, 256, 2, 2, -2);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
 }

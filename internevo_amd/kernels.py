@@ -367,9 +367,12 @@ class KernelProfiler:
 GEMM_PROFILER = None
 
 
+LINEAR_FWD_VARIANT = -1  # tile variant forced on the forward product (A/B runs of bench.py --fwd-variant); -1 = the library's choice
+
+
 def linear_fwd(x, w, out=None):
     """y[T,N] = x[T,K] @ w[N,K]^T"""
-    return gemm(x, w, False, False, out)
+    return gemm(x, w, False, False, out, False, LINEAR_FWD_VARIANT)
 
 
 def linear_dgrad(dy, w, out=None):

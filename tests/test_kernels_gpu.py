@@ -322,6 +322,26 @@ def test_gemm_small(dev, M, N, Kd, akm, bkm):
     close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"gemm {M}x{N}x{Kd} akm={akm} bkm={bkm}")
 
 
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10, 11])
+def test_gemm_every_dma_tile_variant(dev, variant):
+    """Each LDS-DMA schedule (ie_gemm_bf16_tile) on ragged M/N edges, a single k-tile, two and many k-tiles, all four operand
+    layouts, a strided A view and accumulate -- the dispatcher only ever picks some of them for a given shape."""
+    for (M, N, Kd) in [(520, 392, 192), (264, 256, 64), (8, 520, 128), (304, 1000, 1024)]:
+        for akm, bkm in ((False, False), (False, True), (True, True), (True, False)):
+            Abig = bf(torch.randn((Kd, M + 8) if akm else (M, Kd + 64), generator=g(57)))
+            A = Abig[:, :M] if akm else Abig[:, :Kd]
+            B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(58)))
+            ref = (A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t())
+            C0 = bf(torch.randn(M, N, generator=g(59)))
+            Ad = Abig.to(dev)
+            Ad = Ad[:, :M] if akm else Ad[:, :Kd]
+            C = K().gemm(Ad, B.to(dev), akm, bkm, variant=variant)
+            close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"variant {variant} {M}x{N}x{Kd} akm={akm} bkm={bkm}")
+            Cd = C0.to(dev).clone()
+            K().gemm(Ad, B.to(dev), akm, bkm, out=Cd, accumulate=True, variant=variant)
+            close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, f"variant {variant} accumulate")
+
+
 def test_gemm_accumulate_and_strided(dev):
     M, N, Kd = 256, 384, 320
     Abig = bf(torch.randn(M, Kd + 64, generator=g(52)))

@@ -14,7 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from internevo_amd import kernels as K  # noqa: E402
 
-VARIANTS = {5: "dma128", 6: "dma256_spread2", 8: "dma128_spread2", 9: "dma256_phased", 10: "dma128_phased"}
+ALL_VARIANTS = {4: "dma256", 5: "dma128", 6: "dma256_spread2", 7: "dma256_spread4", 8: "dma128_spread2", 9: "dma256_phased", 10: "dma128_phased",
+                11: "buf256_w4"}
+VARIANTS = {v: ALL_VARIANTS[v] for v in (5, 8, 9, 10, 11)}
 
 
 def t_once(fn, iters):
@@ -31,11 +33,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--variants", default=None, help="comma list of tile variant ids (default: 5,6,8,9,10)")
+    ap.add_argument("--shapes", default=None, help="comma list out of wqkv,wo,w13,w2,head")
     args = ap.parse_args()
+    if args.variants:
+        VARIANTS.clear()
+        VARIANTS.update({int(v): ALL_VARIANTS[int(v)] for v in args.variants.split(",")})
     dev = torch.device("cuda:0")
     T, F, V = 4096, 14336, 92544
     bf = torch.bfloat16
     shapes = [("wqkv", 6144, 4096), ("wo", 4096, 4096), ("w13", 2 * F, 4096), ("w2", 4096, F), ("head", V, 4096)]
+    if args.shapes:
+        shapes = [x for x in shapes if x[0] in args.shapes.split(",")]
     out = []
     # correctness of every variant / kind on an awkward shape
     for v in VARIANTS:
