@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
+    ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
+                                                       "must divide --gpus; data parallel size = gpus / sp")
     args = ap.parse_args()
 
     from internevo_amd import kernels as K
@@ -106,13 +108,14 @@ def main():
 
     cfg = internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else tiny(seq_len=min(args.seq_len, 256))
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
+    cfg.train.sp_size = args.sp
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024)
     if world > 1:
         eng.comm.broadcast_params(eng.params)
         eng.sync_master_from_params()
     loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, 1_000_000 if args.config != "tiny" else 4000,
-                                  data_rank=rank, data_world_size=world))
+                                  data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
 
     def sync():
         if world > 1:
@@ -145,7 +148,7 @@ def main():
     st = eng.read_state()
     loss_val = float(loss)
 
-    tokens_step = tc.packed_length * tc.micro_num * world
+    tokens_step = tc.packed_length * tc.micro_num * world // args.sp
     sec_step = dt / args.steps
     total_tps = tokens_step / sec_step
     tgs = total_tps / world
@@ -167,7 +170,7 @@ def main():
         "data": "synthetic (reference RandomDataset/PackedDatasetWithCut shape, fixed_random_dataset_seqlen=True), random-init weights",
         "config": {"workload": f"configs/7B_internlm2.py (BASELINE.json configs[1]): InternLM2-7B, seq_len {tc.seq_len}, micro_bsz {tc.micro_bsz} x micro_num {tc.micro_num} per GPU, "
                                f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2" else "tiny InternLM2 (hidden 512, 2 layers)",
-                   "tokens_per_step": tokens_step, "parallelism": f"dp{world}"},
+                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // args.sp}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,

@@ -203,6 +203,15 @@ int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int* w
 
 /* elementwise helpers used around the path */
 int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* a18  Send-side layout of the Ulysses sequence<->head exchange.  Replaces the tensor_split + .contiguous() + torch.cat of
+ *      _SeqAllToAll (internlm/model/modules/multi_head_attention.py:27-53) around dist.all_to_all: bf16 [A][B][S][C] ->
+ *      [S][A][B][C] (inverse = 0) or back (inverse = 1); A = local tokens (or S*... see INTEGRATION.md), B = 1 for q / ctx,
+ *      2 for kv, S = sequence-parallel size, C = heads_per_rank * head_dim (multiple of 8).  The receive side of
+ *      all_to_all_single needs no copy: [S][A][B][C] is the gathered [S*A tokens][B][C] tensor.
+ *      ie_scale_bf16: x *= factor in place (the embed/head gradient re-scale of the ISP averaging rule). */
+int ie_seq_head_permute(const void* in, void* out, int64_t A, int B, int S, int64_t C, int inverse, void* stream);
+int ie_scale_bf16(void* x, int64_t n, float factor, void* stream);
 int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ SIGNATURES = {
     "ie_embedding_fwd": (I, [P, P, P, I64, I64, I64, P]),
     "ie_embedding_bwd": (I, [P, P, P, P, I64, I64, I64, I, P]),
     "ie_add_bf16": (I, [P, P, P, I64, P]),
+    "ie_seq_head_permute": (I, [P, P, I64, I, I, I64, I, P]),
+    "ie_scale_bf16": (I, [P, I64, F, P]),
     "ie_cast": (I, [P, I, P, I, I64, P]),
     "ie_gemm_bf16": (I, [P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),
     "ie_gemm_bf16_tile": (I, [I, P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),

@@ -89,6 +89,7 @@ class TrainConfig:
     clip_grad_norm: float = 1.0
     label_smoothing: float = 0.0
     zero1_size: int = -1
+    sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
 
     @property
     def packed_length(self):
@@ -114,8 +115,14 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     par = cfg.get("parallel", {})
     if par.get("pipeline", {}).get("size", 1) != 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallel size must be 1")
-    if par.get("tensor", {}).get("size", 1) != 1:
-        raise NotImplementedError(f"{_UNSUPPORTED}: tensor/sequence parallel size must be 1 (round 1)")
+    tensor = par.get("tensor", {})
+    tensor = tensor if isinstance(tensor, dict) else dict(size=tensor, mode="mtp")  # launch.py normalises an int the same way
+    sp_size = 1
+    if tensor.get("size", 1) != 1:
+        if tensor.get("mode", "mtp") != "isp":
+            raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {tensor.get('mode', 'mtp')!r} (only 'isp' sequence parallelism)")
+        sp_size = int(tensor["size"])
+        # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
     if cfg.get("model_type", "INTERNLM2_PUBLIC") not in ("INTERNLM2_PUBLIC",):
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {cfg.get('model_type')}")
     if m.get("num_experts", 1) > 1:
@@ -146,6 +153,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
+        sp_size=sp_size,
     )
     return PathConfig(model, train)
 

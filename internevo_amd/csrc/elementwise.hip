@@ -298,6 +298,32 @@ inline unsigned grid_for(int64_t n, int per_block = 256, int64_t cap = 1 << 20) 
     return (unsigned)g;
 }
 
+// ------------------------------------------------------------------------------------------ a18 Ulysses exchange layout
+// _SeqAllToAll (internlm/model/modules/multi_head_attention.py:27-53) splits the head dimension into `S` contiguous blocks,
+// sends block r to rank r and concatenates what it receives along the sequence.  With all_to_all_single the send buffer must
+// hold block r contiguously: [A tokens][B][S][C] -> [S][A][B][C] (q / ctx: B = 1, C = heads_per_rank * d; kv: B = 2).
+// The receive buffer [S][A][B][C] IS the gathered-sequence tensor [S*A tokens][B][C], so only the send side needs a copy;
+// the inverse direction (gathered heads back to [A][B][S][C]) is the same kernel with the index maps swapped.
+__global__ __launch_bounds__(256) void seq_head_permute_k(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t A, int B, int S,
+                                                          int64_t C8, int inverse, int64_t total) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // i indexes the [A][B][S][C8] side
+        const int64_t c = i % C8;
+        int64_t r = i / C8;
+        const int s = (int)(r % S);
+        r /= S;
+        const int b = (int)(r % B);
+        const int64_t a = r / B;
+        const int64_t j = (((int64_t)s * A + a) * B + b) * C8 + c;  // the [S][A][B][C8] side
+        if (inverse) out[i] = in[j];
+        else out[j] = in[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_bf16_k(bf16_t* __restrict__ x, int64_t n, float f) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = f2bf(bf2f(x[i]) * f);
+}
+
 }  // namespace
 
 extern "C" int ie_apply_rotary(const void* x1, const void* x2, const void* cos_, const void* sin_, void* out1, void* out2,
@@ -385,6 +411,23 @@ extern "C" int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int6
     hipLaunchKernelGGL(swiglu_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, lddo, (const bf16_t*)a, lda,
                        (const bf16_t*)b, ldb, (bf16_t*)da, ldda, (bf16_t*)db, lddb, (bf16_t*)act_out, ldact, rows, cols / 8);
     return ie_launch_status("ie_swiglu_bwd launch");
+}
+
+extern "C" int ie_seq_head_permute(const void* in, void* out, int64_t A, int B, int S, int64_t C, int inverse, void* stream) {
+    IE_CHECK_ARG(in && out && A >= 0 && B > 0 && S > 0 && C > 0, "ie_seq_head_permute: bad argument");
+    IE_CHECK_ARG(C % 8 == 0 && aligned16(in) && aligned16(out), "ie_seq_head_permute: C must be a multiple of 8 bf16 and pointers 16-byte aligned");
+    const int64_t total = A * B * S * (C / 8);
+    if (total == 0) return IE_OK;
+    hipLaunchKernelGGL(seq_head_permute_k, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, A,
+                       B, S, C / 8, inverse, total);
+    return ie_launch_status("ie_seq_head_permute launch");
+}
+
+extern "C" int ie_scale_bf16(void* x, int64_t n, float factor, void* stream) {
+    IE_CHECK_ARG(x && n >= 0, "ie_scale_bf16: bad argument");
+    if (n == 0) return IE_OK;
+    hipLaunchKernelGGL(scale_bf16_k, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n, factor);
+    return ie_launch_status("ie_scale_bf16 launch");
 }
 
 extern "C" int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {

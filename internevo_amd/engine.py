@@ -31,6 +31,7 @@ from ._lib import IeScalerConfig
 from .config import PathConfig
 from .layout import FlatLayout
 from .schedule import Beta2Scheduler, CosineWarmupLR
+from .seqpar import SeqParallel
 from .zero import ZeroComm
 
 BF16 = torch.bfloat16
@@ -38,7 +39,10 @@ BF16 = torch.bfloat16
 
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
-                 force_collectives=False):
+                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1):
+        """sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
+        emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
+        run (test hook: an sp = n run must then match it step for step)."""
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -50,6 +54,12 @@ class InternLM2Engine:
         self.layout = FlatLayout(mc, world_size)
         L = self.layout
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives)
+        sp_size = int(tc.sp_size if sp_size is None else sp_size)  # default: the config's parallel.tensor size (mode "isp")
+        self.sp = sp_size
+        self.seqpar = SeqParallel(sp_size, rank, world_size)
+        self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
+        if sp_size > 1 and (mc.num_kv_attention_heads % sp_size or tc.packed_length % sp_size):
+            raise ValueError("sequence parallel size must divide the kv head count and the packed length")
 
         # ---- flat parameter / gradient buffers + ZeRO-1 fp32 state of this rank's shards
         self.params = torch.zeros(L.total, dtype=BF16, device=device)
@@ -77,7 +87,8 @@ class InternLM2Engine:
         self._ensure_rotary(tc.seq_len)
 
         # ---- activation / workspace buffers for T tokens per micro-batch
-        self.T = tc.packed_length
+        self.Tg = tc.packed_length              # tokens of a micro-batch
+        self.T = tc.packed_length // sp_size    # tokens this rank owns (all of them without sequence parallelism)
         self._alloc(self.T)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
         self.metric = None  # optional internevo_amd.metrics.AccPerplex (attach_metric)
@@ -136,10 +147,14 @@ class InternLM2Engine:
         self.a_x = [e(T, h) for _ in range(L)]        # layer input (residual stream)
         self.a_n1 = [e(T, h) for _ in range(S)]
         self.a_rstd1 = [e(T, dtype=torch.float32) for _ in range(S)]
-        self.a_q = [e(T, hq, d) for _ in range(S)]
-        self.a_kv = [e(T, 2, hkv, d) for _ in range(S)]
-        self.a_ctx = [e(T, hq, d) for _ in range(S)]
-        self.a_lse = [e(hq, T, dtype=torch.float32) for _ in range(S)]
+        # attention works on ALL Tg tokens of the micro-batch with this rank's 1/sp of the heads (same element counts)
+        sp, Tg = self.sp, self.Tg
+        hql, hkvl = hq // sp, hkv // sp
+        self.a_q = [e(Tg, hql, d) for _ in range(S)]
+        self.a_kv = [e(Tg, 2, hkvl, d) for _ in range(S)]
+        self.a_ctx = [e(Tg, hql, d) for _ in range(S)]
+        self.a_lse = [e(hql, Tg, dtype=torch.float32) for _ in range(S)]
+        self.a_ctxl = [e(T, hq, d) for _ in range(S)] if sp > 1 else self.a_ctx   # context of the local tokens, all heads (wo input)
         self.a_r2 = [e(T, h) for _ in range(S)]
         self.a_n2 = [e(T, h) for _ in range(S)]
         self.a_rstd2 = [e(T, dtype=torch.float32) for _ in range(S)]
@@ -152,13 +167,18 @@ class InternLM2Engine:
         self.t_act = e(T, F)
         self.t_dact = e(T, F)
         self.t_dw13 = e(T, 2 * F)
-        self.t_dq = e(T, hq, d)
-        self.t_dkv = e(T, 2, hkv, d)
+        self.t_dq = e(Tg, hql, d)
+        self.t_dkv = e(Tg, 2, hkvl, d)
+        if sp > 1:  # local-token / all-head staging of the exchanges
+            self.t_ql, self.t_kvl = e(T, hq, d), e(T, 2, hkv, d)
+            self.t_xq, self.t_xkv = e(T, hq, d), e(T, 2, hkv, d)      # send / receive buffers
+            self.t_dctx_full = e(Tg, hql, d)
+            self.t_loss_red = e(2, dtype=torch.float32)
         self.t_logits = e(T, V)
         self.t_loss_rows = e(T, dtype=torch.float32)
         self.t_lse = e(T, dtype=torch.float32)
         self.t_loss = e(2, dtype=torch.float32)       # [mean loss of the micro-batch, valid-token count]
-        self.t_delta = e(hq * T, dtype=torch.float32)
+        self.t_delta = e(hql * Tg, dtype=torch.float32)
         self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
         self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
         self.scale_view = self.state[:4].view(torch.float32)  # IeStepState.loss_scale, read by the CE backward on device
@@ -185,10 +205,17 @@ class InternLM2Engine:
         else:
             K.add_rmsnorm_fwd(prev_ffn_out, self.a_r2[self.slot[l - 1]], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[s], self.a_rstd1[s])
         K.linear_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.t_qkv)
-        K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s])
+        if self.sp == 1:
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s])
+        else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl)
+            self.seqpar.scatter_heads_gather_seq(self.t_ql, 1, self.t_xq, self.a_q[s])
+            self.seqpar.scatter_heads_gather_seq(self.t_kvl, 2, self.t_xkv, self.a_kv[s])
         K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, None, True, self.a_ctx[s], self.a_lse[s])
+        if self.sp > 1:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
+            self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
-        K.linear_fwd(self.a_ctx[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
+        K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
         K.add_rmsnorm_fwd(attn_out, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[s], self.a_n2[s], self.a_rstd2[s])
         w13, _ = self._w13(l)
         K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
@@ -215,6 +242,16 @@ class InternLM2Engine:
         else:  # metric pass (SchedulerMetricHook.post_helper_func -> AccPerplex.update) fused into the same sweep over the logits
             K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss, self.t_argmax, self.t_nll)
             self.metric.update_fused(self.t_nll, self.t_argmax, labels)
+        if self.sp > 1:
+            # the loss is the mean over ALL tokens of the micro-batch (the reference gathers the sequence in front of the head,
+            # ops/linear.py:146-153 gather_dim=1): combine the local (sum, count) over the sequence group; the backward
+            # then divides by the global count
+            self.t_loss_red[0] = self.t_loss[0] * self.t_loss[1]
+            self.t_loss_red[1] = self.t_loss[1]
+            torch.nan_to_num_(self.t_loss_red[0:1], nan=0.0)  # a rank whose tokens are all ignored: 0/0 * 0
+            self.seqpar.all_reduce_sum(self.t_loss_red)
+            self.t_loss[1] = self.t_loss_red[1]
+            self.t_loss[0] = self.t_loss_red[0] / self.t_loss_red[1]
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro):
         mc, tc = self.mc, self.tc
@@ -251,10 +288,19 @@ class InternLM2Engine:
             # attention
             d_ctx = d_n2  # reuse
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
-            K.linear_wgrad(d_r2, self.a_ctx[sl].view(T, -1), g[pre + "attention.wo.weight"], True)
-            K.flash_attn_bwd(d_ctx.view(T, -1, d), self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
+            K.linear_wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], True)
+            if self.sp == 1:
+                d_ctx_full = d_ctx.view(T, -1, d)
+            else:  # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53)
+                d_ctx_full = self.seqpar.scatter_heads_gather_seq(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full)
+            K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
                              max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
-            K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
+            if self.sp == 1:
+                dq_l, dkv_l = self.t_dq, self.t_dkv
+            else:
+                dq_l = self.seqpar.scatter_seq_gather_heads(self.t_dq, 1, self.t_xq, self.t_ql)
+                dkv_l = self.seqpar.scatter_seq_gather_heads(self.t_dkv, 2, self.t_xkv, self.t_kvl)
+            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
             d_n1 = d_ctx
             K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
             K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], True)
@@ -285,7 +331,8 @@ class InternLM2Engine:
         (host tensors).  Returns the device scalar sum_i loss_i / micro_num."""
         tc = self.tc
         M = batch["input_ids"].shape[0]
-        assert M == tc.micro_num and batch["input_ids"].shape[1] == self.T
+        assert M == tc.micro_num and batch["input_ids"].shape[1] == self.Tg
+        lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T  # this rank's tokens of every micro-batch
         self.zero_grad()
         self.loss_acc.zero_()
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
@@ -298,9 +345,12 @@ class InternLM2Engine:
             max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())  # host-side: no `.item()` sync (modeling_internlm2.py:989 syncs here)
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
             cu = cu_h.to(self.dev, non_blocking=True)
-            self._forward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen)
+            ids_i, lab_i, pos_i = ids_d[i, lo:hi], lab_d[i, lo:hi], pos_d[i, lo:hi]
+            if self.metric is not None and self.metric.ntypes and self.sp > 1:
+                self.metric.type_ids_local = (lo, hi)
+            self._forward_micro(ids_i, lab_i, cu, pos_i, max_seqlen)
             self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
-            self._backward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen, i == M - 1)
+            self._backward_micro(ids_i, lab_i, cu, pos_i, max_seqlen, i == M - 1)
         return self.loss_acc
 
     # ------------------------------------------------------------------------------------------ optimizer
@@ -314,6 +364,8 @@ class InternLM2Engine:
         for b in L.buckets:
             s, n = b.shard(self.rank, self.world)
             shards.append(self.grads[s : s + n])
+        if self.isp_rule > 1:
+            self._apply_isp_grad_rule(shards)
         K.sumsq(shards, self.sumsq, False, self.sumsq_ws)
         self.comm.all_reduce_sum(self.sumsq)
         K.step_control(self.state, self.sumsq, self.scaler_cfg)
@@ -331,6 +383,31 @@ class InternLM2Engine:
         self.lr_sched.step()
         self.beta2_sched.step()
         self.step_count += 1
+
+    def _apply_isp_grad_rule(self, shards):
+        """The gradient averaging of the reference's ISP mode, as its code reads (sp = size of the sequence group):
+          * ISPLinear weights: reduce-scatter AVG over the weight group (model/utils.py:556) then all-reduce AVG over
+            WEIGHT_DATA (hybrid_zero_optim.py:98,169) = the mean over ALL ranks of per-rank gradients that each cover only
+            1/sp of a micro-batch's tokens -> 1/sp of the data-parallel mean gradient;
+          * norm weights (IS_REPLICA_ZERO_PARALLEL): AVG over the weight group (hybrid_zero_optim.py:318-324,
+            solver/optimizer/utils.py:119), then the same bucket all-reduce -> also 1/sp;
+          * embedding and head ("embed_head" group, train/utils.py:42-43, reduced over DATA): their gradients come from the
+            gathered sequence (ops/linear.py:146-153, modules/embedding.py:52-60), so they are the full mean gradient.
+        Here every rank's weight gradient covers its local tokens and the ZeRO reduce-scatter averages over all ranks, i.e.
+        everything arrives as 1/sp of the mean gradient: embedding and head are multiplied back by sp (exact in bf16).
+        With emulate_isp_grad_rule (no sequence parallelism) the gradients arrive as the full mean: divide all, then same."""
+        n_ = float(self.isp_rule)
+        L = self.layout
+        if self.sp == 1:
+            for sh in shards:
+                K.scale_bf16(sh, 1.0 / n_)
+        for name in ("tok_embeddings.weight", "output.weight"):
+            spec = L.params[name]
+            for b, sh in zip(L.buckets, shards):
+                s0, n0 = b.shard(self.rank, self.world)
+                a, z = max(s0, spec.offset), min(s0 + n0, spec.offset + spec.numel)
+                if a < z:
+                    K.scale_bf16(self.grads[a:z], n_)
 
     def read_state(self):
         """Host copy of the step state (synchronises).  Also rewinds the host schedulers for skipped steps."""

@@ -167,6 +167,21 @@ def swiglu_bwd(dout, a, b, da=None, db=None, act_out=None):
     return da, db
 
 
+# ------------------------------------------------------------------------------------------ Ulysses exchange layout
+def seq_head_permute(x, out, A, B, S, C, inverse=False):
+    """bf16 [A][B][S][C] -> [S][A][B][C] (or back): the send-side copy of the sequence<->head all-to-all."""
+    _contig(x, "x"); _contig(out, "out")
+    assert x.numel() == A * B * S * C == out.numel()
+    check(_L().ie_seq_head_permute(_p(x), _p(out), A, B, S, C, int(inverse), _stream()), "ie_seq_head_permute")
+    return out
+
+
+def scale_bf16(x, factor):
+    _contig(x, "x")
+    check(_L().ie_scale_bf16(_p(x), x.numel(), float(factor), _stream()), "ie_scale_bf16")
+    return x
+
+
 # ------------------------------------------------------------------------------------------ CE
 def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=None, lse=None, out=None, argmax_rows=None, nll_rows=None):
     """logits [rows, V] (bf16|fp32, row stride arbitrary), labels int64 [rows] ->

@@ -31,6 +31,7 @@ class AccPerplex:
         self.ds_loss, self.ds_token_num = self._f[6 : 6 + n], self._f[6 + n : 6 + 2 * n]
         self.ds_right, self.ds_tokens = self._i[0:n], self._i[n : 2 * n]
         self.type_ids = None
+        self.type_ids_local = None  # (lo, hi): this rank's token range of a micro-batch under sequence parallelism
         self.batch_shift = 0
 
     def set_current_type_ids(self, type_ids):
@@ -45,6 +46,8 @@ class AccPerplex:
             if self.type_ids is None:
                 raise RuntimeError("dataset_types given but set_current_type_ids() was not called for this batch")
             tid = self.type_ids[self.batch_shift].reshape(-1)
+            if self.type_ids_local is not None:
+                tid = tid[self.type_ids_local[0] : self.type_ids_local[1]].contiguous()
             self.batch_shift += 1
         if self.tokenizer is not None:  # bits per byte needs the decoded byte count (metrics.py:128-130), host work
             ids = (host_labels if host_labels is not None else labels.cpu()).reshape(1, -1).tolist()

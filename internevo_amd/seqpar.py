@@ -1,0 +1,81 @@
+"""Ulysses sequence parallelism of the attention and the data layout of the ISP mode (a19).
+
+Reference behaviour being matched (`tensor=dict(size=sp, mode="isp")`, configs/7B_isp_sft.py):
+  * every micro-batch is split contiguously along the packed sequence over the `tensor` group: rank j of the group owns
+    tokens [j*T/sp, (j+1)*T/sp) (Embedding1D splits dim 1, modules/embedding.py:52-60; `indexes` is split the same way,
+    modeling_internlm2.py:985-987); all token-wise work (norms, linears, SwiGLU, rotary) runs on the local tokens;
+  * attention needs the whole sequence: `DistributedAttention` (modules/multi_head_attention.py:56-135) exchanges
+    "my tokens, all heads" for "all tokens, my heads" with an all-to-all before the local attention (q: scatter heads /
+    gather sequence, packed kv likewise) and the inverse exchange on the context; backward is the mirrored exchange;
+  * ISPLinear (ops/linear.py:357-378, core/communication/isp.py) keeps 1/wp of every weight per rank, all-gathers it before
+    each use (forward and backward) and reduce-scatters the weight gradient with AVG over the weight group.
+
+MI355X redesign with the same results: 288 GB of HBM hold the whole bf16 model on every GPU, so the weights stay resident
+(they are already exchanged once per step by the ZeRO-1 all-gather) and the per-layer weight all-gather / reduce-scatter
+traffic of ISP (3x the parameter bytes per micro-batch) disappears; what remains of a19 is its gradient averaging RULE, which
+the engine reproduces (engine.py `_apply_isp_grad_rule`).  The exchange itself is ONE `all_to_all_single` per tensor over
+xGMI with a single packing copy on the send side (ie_seq_head_permute); the receive buffer already is the gathered tensor.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+class SeqParallel:
+    def __init__(self, sp_size, rank, world_size):
+        if world_size % sp_size != 0:
+            raise ValueError(f"world size {world_size} is not a multiple of the sequence-parallel size {sp_size}")
+        self.sp = sp_size
+        self.sp_rank = rank % sp_size
+        self.data_rank = rank // sp_size          # ranks of one sequence group read the same batch (data/build_dataloader.py:54-63)
+        self.data_world = world_size // sp_size
+        self.group = None
+        self.backend = None
+        if sp_size > 1:
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed must be initialised for sequence parallelism")
+            # consecutive ranks share a sequence (parallel_context.py: the tensor group is the innermost dimension);
+            # every rank has to take part in the creation of every group
+            for g in range(world_size // sp_size):
+                ranks = list(range(g * sp_size, (g + 1) * sp_size))
+                grp = dist.new_group(ranks)
+                if rank in ranks:
+                    self.group = grp
+            self.backend = dist.get_backend(self.group)
+
+    # ---- the exchange: send[r] (contiguous chunk r) -> rank r; recv[s] <- rank s -------------------------------------
+    def all_to_all(self, send, recv):
+        # flat views: chunk r of the send buffer is its r-th 1/sp, whatever shape the caller gives the tensors
+        if self.backend == "nccl":
+            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        else:  # gloo test path: CPU tensors only
+            s = send.detach().reshape(-1).to("cpu", copy=True)
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=self.group)
+            recv.view(-1).copy_(r)
+        return recv
+
+    def all_reduce_sum(self, t):
+        if self.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            c = t.detach().to("cpu", copy=True)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c)
+        return t
+
+    # ---- heads <-> sequence ------------------------------------------------------------------------------------------
+    def scatter_heads_gather_seq(self, x_local, B, pack_buf, out_full):
+        """x_local [Tl, (B,) heads, d] -> out_full [T, (B,) heads/sp, d] (q, kv, d_ctx: _SeqAllToAll scatter_idx = head dim)."""
+        Tl = x_local.shape[0]
+        C = x_local.numel() // (Tl * B * self.sp)
+        K.seq_head_permute(x_local, pack_buf, Tl, B, self.sp, C, inverse=False)
+        return self.all_to_all(pack_buf, out_full)
+
+    def scatter_seq_gather_heads(self, x_full, B, recv_buf, out_local):
+        """x_full [T, (B,) heads/sp, d] -> out_local [Tl, (B,) heads, d] (context, dq, dkv: the inverse exchange)."""
+        Tl = out_local.shape[0]
+        C = out_local.numel() // (Tl * B * self.sp)
+        self.all_to_all(x_full, recv_buf)
+        return K.seq_head_permute(recv_buf, out_local, Tl, B, self.sp, C, inverse=True)

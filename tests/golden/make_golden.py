@@ -170,7 +170,7 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 #                     shrinks ONLY that count (host time/RAM), everything else is the unmodified pipeline.
 
 
-def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps):
+def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1):
     return dict(
         JOB_NAME="golden",
         model_type="INTERNLM2_PUBLIC",
@@ -190,8 +190,8 @@ def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, laye
         model=dict(checkpoint=False, num_chunks=1, num_attention_heads=heads, embed_split_hidden=True, vocab_size=vocab, embed_grad_scale=1,
                    parallel_output=False, hidden_size=hidden, num_layers=layers, no_bias=True, mlp_ratio=3.5, apply_post_layer_norm=False,
                    dtype=dtype, norm_type="rmsnorm", layer_norm_epsilon=1e-5, num_kv_attention_heads=kv_heads, use_flash_attn=False),
-        parallel=dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=1, interleaved_overlap=True),
-                      weight=dict(size=1, overlap=False, memory_pool=False)),
+        parallel=dict(zero1=dict(size=-1), tensor=dict(size=sp, mode="isp" if sp > 1 else "mtp"), pipeline=dict(size=1, interleaved_overlap=True),
+                      weight=dict(size=wp, overlap=False, memory_pool=False)),
         cudnn_deterministic=False, cudnn_benchmark=False,
         monitor=dict(alert=dict(enable_feishu_alert=False, feishu_alert_address=None, light_monitor_address=None, alert_file_path="/tmp/alert.log"),
                      tensorboard=dict(queue_max_length=10)),
@@ -199,9 +199,72 @@ def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, laye
     )
 
 
-def run_training(tag, dtype, cfg_kw, port):
-    """One process = one run (gpc is a singleton); called through `--run tag`."""
+def _gloo_all_to_all(output_list, input_list, group=None, async_op=False):
+    """gloo has no list-form all_to_all (SURVEY.md 8c limit 2): same exchange through all_gather (harness only)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    stacked = torch.stack([t.contiguous() for t in input_list])
+    gathered = [torch.empty_like(stacked) for _ in range(world)]
+    dist.all_gather(gathered, stacked, group=group)
+    for src in range(world):
+        output_list[src].copy_(gathered[src][me])
+
+
+def _patch_gloo_flat_collectives():
+    """NCCL's all_gather_into_tensor / reduce_scatter_tensor treat both tensors as flat buffers (the reference relies on it:
+    model/utils.py:168-217 gathers along dim 1 of a [1, T, h] tensor); gloo insists on a dim-0 concatenation.  Harness only:
+    hand gloo flat views of the same buffers."""
+    import torch.distributed as dist
+
+    ag, rs = dist.all_gather_into_tensor, dist.reduce_scatter_tensor
+
+    def all_gather_into_tensor(output_tensor, input_tensor, group=None, async_op=False):
+        assert output_tensor.is_contiguous()
+        return ag(output_tensor.view(-1), input_tensor.contiguous().view(-1), group=group, async_op=async_op)
+
+    def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):  # noqa: A002
+        assert output.is_contiguous()
+        if op == dist.ReduceOp.AVG:  # gloo has no AVG reduce-scatter
+            w = rs(output.view(-1), input.contiguous().view(-1), op=dist.ReduceOp.SUM, group=group, async_op=False)
+            output.div_(dist.get_world_size(group))
+
+            class _Done:
+                def wait(self):
+                    return True
+
+            return _Done() if async_op else w
+        return rs(output.view(-1), input.contiguous().view(-1), op=op, group=group, async_op=async_op)
+
+    dist.all_gather_into_tensor = all_gather_into_tensor
+    dist.reduce_scatter_tensor = reduce_scatter_tensor
+
+
+def _full_param_slice(name, shard_shape, formula_init, rank_in_tp, tp, rank_in_wp, wp, full_shapes):
+    """The reference's ISP sharding of a parameter (embedding.py:40-50 hidden split over TENSOR; linear.py head = vocab
+    rows over TENSOR; every ISPLinear = output rows over WEIGHT, linear.py:357-378 / mlp.py:207-208)."""
+    full = formula_init(name, full_shapes[name])
+    if tuple(full.shape) == tuple(shard_shape):
+        return full
+    if name == "tok_embeddings.weight":
+        n = full.shape[1] // tp
+        return full[:, rank_in_tp * n : (rank_in_tp + 1) * n]
+    if name == "output.weight":
+        n = full.shape[0] // tp
+        return full[rank_in_tp * n : (rank_in_tp + 1) * n]
+    n = full.shape[0] // wp
+    return full[rank_in_wp * n : (rank_in_wp + 1) * n]
+
+
+def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
+    """One process = one run (gpc is a singleton); called through `--run tag` (one process per rank for the ISP runs)."""
     shim_cpu_accelerator()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_to_all = _gloo_all_to_all
+        _patch_gloo_flat_collectives()
     import internlm  # noqa: F401
     import internlm.data.build_dataloader as bdl
     from internlm.core.context import global_context as gpc
@@ -220,25 +283,39 @@ def run_training(tag, dtype, cfg_kw, port):
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
 
     cfg = tiny_config(dtype, **cfg_kw)
-    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
     torch.set_num_threads(8)
 
     model = initialize_model()
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
     inner = model.model
+    sp, wp = cfg_kw.get("sp", 1), cfg_kw.get("wp", 1)
+    if world > 1:
+        from internevo_amd.config import ModelConfig
+        from oracle.model import param_shapes
+
+        full_shapes = param_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
+                                               num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]))
+        tp_rank, wp_rank = gpc.get_local_rank(ParallelMode.TENSOR), gpc.get_local_rank(ParallelMode.WEIGHT)
     with torch.no_grad():
         for name, p in inner.named_parameters():
-            p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+            if world > 1:
+                p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, tp_rank, sp, wp_rank, wp, full_shapes).to(p.dtype))
+            else:
+                p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
     criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
     train_dl, dataset_types = bdl.build_train_loader_with_data_type()
     train_state = TrainState(gpc.config, train_dl.batch_sampler)
-    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, None)
+    from internlm.train import initialize_isp_communicator
+
+    isp_communicator = initialize_isp_communicator(model)  # train.py:108 (None unless tensor.mode == 'isp')
+    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, isp_communicator)
     metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
                         dataset_types=dataset_types)
     trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
                                                           lr_scheduler=lr_scheduler, beta2_scheduler=beta2_scheduler,
-                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, None))
+                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp_communicator))
     trainer.train()
     train_iter = iter(train_dl)
     rec = {"config": {k: cfg_kw[k] for k in cfg_kw}, "dtype": dtype, "num_samples": NUM_SAMPLES, "steps": []}
@@ -267,10 +344,9 @@ def run_training(tag, dtype, cfg_kw, port):
     # a fingerprint of the trained weights (bf16 shadow params) for end-state parity
     with torch.no_grad():
         rec["param_fingerprint"] = {name: [float(p.float().sum()), float(p.float().abs().sum())] for name, p in inner.named_parameters()}
-    with open(os.path.join(HERE, f"train_{tag}.json"), "w") as f:
+    rec["world"], rec["rank"] = world, rank
+    with open(os.path.join(HERE, f"train_{tag}.json" if world == 1 else f"train_{tag}_rank{rank}.json"), "w") as f:
         json.dump(rec, f, indent=1)
-    if tag.endswith("packed_probe"):
-        pass
     return batches
 
 
@@ -285,7 +361,7 @@ def gen_metrics(port=29790):
     from internlm.model.metrics import AccPerplex
 
     cfg = tiny_config("torch.bfloat16", use_packed=False, seq_len=48, hidden=64, heads=2, kv_heads=2, vocab=160, layers=1, micro_num=3, total_steps=2)
-    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
     types = ["en", "cn", "code"]
     metric = AccPerplex(device=torch.device("cpu"), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA), dataset_types=types)
@@ -324,6 +400,11 @@ RUNS = {
     "pin_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
     "cfg0_fp32": ("torch.float32", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
     "cfg0_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
+}
+# two-process runs of the reference's ISP mode (configs/7B_isp_sft.py shape: tensor=dict(size=sp, mode="isp"), weight=dict(size=wp))
+RUNS_MP = {
+    "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
+    "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
 }
 
 
@@ -382,6 +463,17 @@ def gen_data():
 if __name__ == "__main__":
     import subprocess
 
+    if len(sys.argv) >= 4 and sys.argv[1] == "--run-rank":
+        tag, rank = sys.argv[2], int(sys.argv[3])
+        dtype, kw, world = RUNS_MP[tag]
+        run_training(tag, dtype, kw, port=29750 + list(RUNS_MP).index(tag), rank=rank, world=world)
+        sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--run-mp":
+        tag = sys.argv[2]
+        world = RUNS_MP[tag][2]
+        procs = [subprocess.Popen([sys.executable, __file__, "--run-rank", tag, str(r)]) for r in range(world)]
+        rc = [p.wait() for p in procs]
+        sys.exit(max(rc))
     if len(sys.argv) >= 3 and sys.argv[1] == "--run":
         tag = sys.argv[2]
         dtype, kw = RUNS[tag]
@@ -401,3 +493,5 @@ if __name__ == "__main__":
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])
+    for tag in RUNS_MP:
+        subprocess.check_call([sys.executable, __file__, "--run-mp", tag])

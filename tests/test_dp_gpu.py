@@ -18,6 +18,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _collect(q, procs, n, timeout=500):
+    """n results from the worker queue, failing fast (not after the full timeout) when a worker has died."""
+    import queue
+    import time
+
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise RuntimeError(f"a worker exited with {[p.exitcode for p in procs]}") from None
+            if time.time() - t0 > timeout:
+                raise
+    return out
+
+
 def _cfg(micro_num):
     from internevo_amd.config import tiny
 
@@ -61,7 +78,7 @@ def test_two_rank_step_equals_one_rank_step(dev):
     procs = [ctx.Process(target=_worker, args=(r, 2, 29833, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
     for p in procs:
         p.join(60)
     # single rank, micro_num 4 == the union of both ranks' micro-batches (the sampler interleaves ranks)
@@ -136,8 +153,92 @@ def test_rccl_call_sequence_on_one_rank_group(dev):
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29871, q))
     p.start()
-    out = q.get(timeout=500)
+    out = _collect(q, [p], 1)[0]
     p.join(60)
     (l0, g0, p0), (l1, g1, p1) = out[False], out[True]
     assert l0 == l1 and g0 == g1
     assert (p0 == p1).all()
+
+
+def _sp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from internevo_amd.metrics import AccPerplex
+        from oracle.model import formula_init
+
+        dev = torch.device("cuda:0")
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, sp_size=2)
+        metric = AccPerplex(dev, None, ["en"], dp_world_size=world)
+        eng.attach_metric(metric)
+        # both ranks of the sequence group read the same batches; ragged packed samples so cu_seqlens matter
+        loader = iter(SyntheticLoader(128, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm), metric.get_metric(reset=True)))
+        q.put((rank, out, eng.params.float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sequence_parallel_step_equals_single_rank_step(dev):
+    """Ulysses / ISP sequence parallelism with sp = 2 on two ranks vs ONE rank running the same
+    micro-batches with the ISP gradient averaging rule emulated: splitting the tokens and exchanging heads for sequence must not
+    change the step -- same loss, same grad norm, same trained weights (bf16 summation-order noise only), same metric counts."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from oracle.model import formula_init
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_worker, args=(r, 2, 29843, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_cfg(2), dev, init_fn=formula_init, emulate_isp_grad_rule=2)
+    metric = AccPerplex(dev, None, ["en"])
+    eng.attach_metric(metric)
+    loader = iter(SyntheticLoader(128, 1, 2, False, 4000))
+    ref = []
+    for _ in range(3):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm), metric.get_metric(reset=True)))
+    (r0, o0, p0), (r1, o1, p1) = res
+    p0, p1 = torch.from_numpy(p0), torch.from_numpy(p1)
+    assert torch.equal(p0, p1), "ranks disagree on the parameters after the all-gather"
+    for k in range(3):
+        print(f"step {k}: sp2 loss {o0[k][0]:.5f} gn {o0[k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f} | acc {o0[k][2]['acc']} vs {ref[k][2]['acc']}")
+        assert o0[k][0] == o1[k][0], "both ranks of a sequence group must report the same (global) loss"
+        assert abs(o0[k][0] - ref[k][0]) <= 1e-3 * abs(ref[k][0])
+        assert abs(o0[k][1] - o1[k][1]) <= 1e-6 * o0[k][1]
+        assert abs(o0[k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+        assert o0[k][2]["tokens/en"] == ref[k][2]["tokens/en"], "every token is counted exactly once across the sequence group"
+        assert abs(o0[k][2]["acc"] - ref[k][2]["acc"]) <= 0.02
+        assert abs(o0[k][2]["loss_from_metric"] - ref[k][2]["loss_from_metric"]) <= 2e-3 * ref[k][2]["loss_from_metric"]
+    ref_params = eng.params.float().cpu()
+    from internevo_amd.layout import FlatLayout
+
+    L2, L1 = FlatLayout(_cfg(2).model, 2), eng.layout
+    worst = 0.0
+    for n, s in L1.params.items():
+        a = ref_params[s.offset : s.offset + s.numel]
+        s2 = L2.params[n]
+        b = p0[s2.offset : s2.offset + s2.numel]
+        worst = max(worst, float((a - b).abs().max()))
+    print("max |param diff| sp2 vs 1 rank:", worst)
+    assert worst <= 6e-3

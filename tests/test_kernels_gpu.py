@@ -410,3 +410,19 @@ def test_flash_attention_lse_and_big_scores(dev):
     s = torch.einsum("thd,shd->hts", q.float(), k) / math.sqrt(d)
     s = s.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
     close(lse, torch.logsumexp(s, -1), 1e-3, 1e-2, "flash lse")
+
+
+# ---------------------------------------------------------------------------------------------- a18
+@pytest.mark.parametrize("A,B,S,C", [(96, 1, 2, 256), (40, 2, 4, 128), (7, 2, 8, 64), (128, 1, 1, 512)])
+def test_seq_head_permute_matches_seq_all_to_all_layout(dev, A, B, S, C):
+    """[A tokens][B][S head blocks][C] -> [S][A][B][C] = what _SeqAllToAll's tensor_split(+contiguous) along the head dim hands
+    to all_to_all (multi_head_attention.py:41-45), and the inverse = torch.cat of the received chunks along the head dim."""
+    x = bf(torch.randn(A, B, S, C, generator=g(60)))
+    chunks = torch.stack([t.contiguous() for t in torch.tensor_split(x, S, dim=2)])  # [S][A][B][1][C]
+    want = chunks.reshape(S, A, B, C)
+    got = K().seq_head_permute(x.to(dev), torch.empty(S, A, B, C, dtype=torch.bfloat16, device=dev), A, B, S, C, inverse=False)
+    close(got, want, 0, 0, "pack (exact)")
+    back = K().seq_head_permute(got, torch.empty(A, B, S, C, dtype=torch.bfloat16, device=dev), A, B, S, C, inverse=True)
+    close(back, x, 0, 0, "unpack (exact)")
+    y = bf(torch.randn(1001, generator=g(61)))
+    close(K().scale_bf16(y.to(dev).clone(), 4.0), y * 4.0, 0, 0, "scale by a power of two (exact)")

@@ -59,6 +59,19 @@ def test_reference_config_files_map(tmp_path):
                parallel=dict(pipeline=dict(size=2)))
     with pytest.raises(NotImplementedError):
         from_reference_dict(bad)
+    # configs/7B_isp_sft.py: tensor=dict(size=2, mode="isp"), weight=dict(size=4, overlap=True, memory_pool=True)
+    import copy
+    import runpy
+
+    g = {k: v for k, v in runpy.run_path(str(p)).items() if not k.startswith("__")}
+    isp = copy.deepcopy(g)
+    isp["parallel"] = dict(zero1=dict(size=-1), tensor=dict(size=2, mode="isp"), pipeline=dict(size=1, interleaved_overlap=True),
+                           weight=dict(size=4, overlap=True, memory_pool=True))
+    assert from_reference_dict(isp).train.sp_size == 2
+    mtp = copy.deepcopy(g)
+    mtp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="mtp"), pipeline=dict(size=1))
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(mtp)
 
 
 def _worker(rank, world, port, q):
