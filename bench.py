@@ -195,7 +195,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out["roofline"] = {
-            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd/dgrad/wgrad of every linear layer)",
+            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd (4-wave buffer-DMA schedule) / dgrad / wgrad (8-wave phased schedule) of every linear layer)",
             "bound": "mfma",
             "achieved": ach / 1e12,
             "peak": MFMA_PEAK / 1e12,

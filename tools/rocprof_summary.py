@@ -27,8 +27,8 @@ def main():
     lines += ["", f"total GPU kernel time: {total / 1e3:.1f} ms over {sum(r[1] for r in rows)} launches"]
     try:
         pmc = c.execute(
-            "select k.name, p.counter_name, avg(p.counter_value), count(*) from counters_collection p join kernels k on p.dispatch_id = k.dispatch_id "
-            "group by k.name, p.counter_name order by k.name").fetchall()
+            "select kernel_name, counter_name, sum(value) / count(distinct dispatch_id), count(distinct dispatch_id) from counters_collection "
+            "group by kernel_name, counter_name order by kernel_name").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:
