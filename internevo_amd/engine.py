@@ -253,20 +253,23 @@ class InternLM2Engine:
             self.t_loss[1] = self.t_loss_red[1]
             self.t_loss[0] = self.t_loss_red[0] / self.t_loss_red[1]
 
-    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro):
+    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False):
         mc, tc = self.mc, self.tc
         L, F = mc.num_layers, mc.ffn_dim
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, g = self.p, self.g
         T = self.T
         ws = self.t_norm_ws
+        # the first micro-batch of a step WRITES the gradients, the others accumulate: no zero_grad pass over 15.5 GB and no read of
+        # the old value in the first weight-gradient epilogues (bucket padding is zero from allocation and never written)
+        acc = not first_micro
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
         K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         dlog = self.t_logits
         K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
-        K.linear_wgrad(dlog, self.a_nf, g["output.weight"], True)
+        K.linear_wgrad(dlog, self.a_nf, g["output.weight"], acc)
         d_out = self.t_h1
-        K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], True, ws, d_out)
+        K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
         spare = [self.t_h0, self.t_h2]
@@ -279,16 +282,16 @@ class InternLM2Engine:
             # feed-forward
             K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
             K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], self.t_dw13[:, :F], self.t_dw13[:, F:], self.t_act)
-            K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], True)
+            K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], acc)
             d_n2 = spare[0]
             K.linear_dgrad(self.t_dw13, w13, d_n2)
-            K.linear_wgrad(self.t_dw13, self.a_n2[sl], gw13, True)
+            K.linear_wgrad(self.t_dw13, self.a_n2[sl], gw13, acc)
             d_r2 = spare[1]
-            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], True, ws, d_r2)
+            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc, ws, d_r2)
             # attention
             d_ctx = d_n2  # reuse
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
-            K.linear_wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], True)
+            K.linear_wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], acc)
             if self.sp == 1:
                 d_ctx_full = d_ctx.view(T, -1, d)
             else:  # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53)
@@ -303,15 +306,15 @@ class InternLM2Engine:
             K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
             d_n1 = d_ctx
             K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
-            K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], True)
+            K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], acc)
             d_x = d_out  # the old d_out buffer is free now
-            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], True, ws, d_x)
+            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc, ws, d_x)
             # rotate buffers: next d_out = d_x; spare = the two others
             spare = [d_n2, d_r2]
             d_out = d_x
             if last_micro:
                 self.comm.reduce_bucket_async(self.grads, 1 + l)
-        K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], True, self.t_emb_ws)
+        K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, 0)
 
@@ -333,7 +336,6 @@ class InternLM2Engine:
         M = batch["input_ids"].shape[0]
         assert M == tc.micro_num and batch["input_ids"].shape[1] == self.Tg
         lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T  # this rank's tokens of every micro-batch
-        self.zero_grad()
         self.loss_acc.zero_()
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
         lab_d = labels.to(self.dev, non_blocking=True)
@@ -350,7 +352,7 @@ class InternLM2Engine:
                 self.metric.type_ids_local = (lo, hi)
             self._forward_micro(ids_i, lab_i, cu, pos_i, max_seqlen)
             self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
-            self._backward_micro(ids_i, lab_i, cu, pos_i, max_seqlen, i == M - 1)
+            self._backward_micro(ids_i, lab_i, cu, pos_i, max_seqlen, i == M - 1, i == 0)
         return self.loss_acc
 
     # ------------------------------------------------------------------------------------------ optimizer
