@@ -252,7 +252,10 @@ int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, const void* v,
                       void* out, int64_t o_ts, float* lse, const int32_t* cu_seqlens, int nseq,
                       int64_t T, int max_seqlen, int hq, int hkv, int d, float softmax_scale,
                       int causal, void* stream);
-/* delta [hq, T] fp32 workspace.  dq [T,hq,d] (stride dq_ts), dk/dv [T,hkv,d] (stride dkv_ts). */
+/* delta: fp32 workspace of ie_flash_attn_bwd_workspace(T, hq, hkv, d) floats (delta[hq, T] followed by the deterministic
+ * per-head-split partial dK / dV sums of the causal-balanced dK/dV kernel).  dq [T,hq,d] (stride dq_ts), dk/dv [T,hkv,d]
+ * (stride dkv_ts). */
+int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d);
 int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k,
                       const void* v, int64_t kv_ts, const void* out, int64_t o_ts, const float* lse,
                       float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
@@ -261,6 +264,8 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
 
 /* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
+/* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */
+int ie_tune_flash_dkdv_split(int split);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

@@ -177,12 +177,17 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.
 constexpr int DKV_WAVES = 2;
 
-template <int D, bool CAUSAL>
+// HS > 1 (causal balance): the q heads of a kv head are split over HS blocks (blockIdx.y), each writing fp32 partial dK / dV
+// to part[2][HS][T][hkv][D]; flash_dkdv_reduce_k sums them in a fixed order (deterministic, no atomics).  With all blocks
+// resident at once the kernel takes as long as its heaviest block (key block 0 sees every query tile: 2x the mean); HS x more,
+// HS x smaller blocks dispatched heavy-first let the light ones back-fill the tail.
+template <int D, bool CAUSAL, int HS>
 __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
                                                                int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
-                                                               const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale) {
+                                                               const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale,
+                                                               float* __restrict__ part) {
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, lse2[64], delta[64] (+ pad to keep 1 KiB alignment)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
@@ -192,12 +197,13 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int nkb = gridDim.x / hkv;
     const int j = blockIdx.x / hkv;
     const int first = (nkb + 1) / 2;
-    const int kb = j < first ? j : nkb - 1 - (j - first);
+    const int kb = HS > 1 ? j : (j < first ? j : nkb - 1 - (j - first));  // HS > 1: plain order = heavy blocks first
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     const int k0 = kb * 32 * DKV_WAVES;
     if (k0 >= len) return;
-    const int grp = hq / hkv;
+    const int grp = hq / hkv / HS;          // q heads handled by this block
+    const int h_first = hk * (hq / hkv) + (int)blockIdx.y * grp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kw0 = k0 + wave * 32;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 
     // stage `it`: Q / dO images by DMA; lse (log2 domain) and delta through registers of threads 0..63
     auto issue = [&](int it, unsigned char* stage, float& lse_r, float& dlt_r) {
-        const int h = hk * grp + it / nqt;
+        const int h = h_first + it / nqt;
         const int q0 = (qt_start + it % nqt) * 64;
         const int rem = len - q0;
         dma_tile<D, DKV_WAVES>(q + (int64_t)(tok0 + q0) * q_ts + (int64_t)h * D, q_ts, rem, stage, wave, lane);
@@ -270,17 +276,43 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         const unsigned char* dOs = stage + G::IMG_BYTES;
         const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
         const float* dlt_s = lse_s + 64;
+        // One wave per SIMD: nothing but this wave's own instruction stream can hide an LDS round trip, so every fragment is
+        // requested well before its MFMA -- the 16 row fragments of a sub-block in one burst (the second sub-block's under
+        // the first one's dV/dK MFMAs), the 16 transposed fragments BEFORE the softmax VALU block that they wait behind.
+        s16x8 qf[G::KS], dof[G::KS];
+        auto load_rows = [&](int qs) {
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                qf[ks] = row_frag<D>(Qs, 32 * qs, ks, fo);
+                dof[ks] = row_frag<D>(dOs, 32 * qs, ks, fo);
+            }
+        };
+        bool act[2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) act[qs] = (q0 + 32 * qs) < len && (!CAUSAL || q0 + 32 * qs + 31 >= kw0);
+        if (act[0]) load_rows(0);
+        else if (act[1]) load_rows(1);
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             const int qb0 = q0 + 32 * qs;  // first query row of this sub-block
-            const bool active = qb0 < len && (!CAUSAL || qb0 + 31 >= kw0);
-            if (!active) continue;
+            if (!act[qs]) continue;
             f32x16 s = zero16(), dp = zero16();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, 32 * qs, ks, fo), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, 32 * qs, ks, fo), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], dp, 0, 0, 0);
             }
+            // transposed fragments of this sub-block: requested now, consumed after the softmax block
+            s16x8 tdo[2][G::DB], tq[2][G::DB];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db) {
+                    tdo[s2][db] = trans_frag<D>(dOs, db, 2 * qs + s2, fo);
+                    tq[s2][db] = trans_frag<D>(Qs, db, 2 * qs + s2, fo);
+                }
+            __builtin_amdgcn_sched_barrier(0);
             const bool need_mask = (CAUSAL && kw0 + 31 > qb0) || (kw0 + 32 > len);
             f32x16 p;
 #pragma unroll
@@ -302,14 +334,17 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                     s[r] = pv * (dp[r] - dv4[e]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (qs == 0 && act[1]) load_rows(1);  // the next sub-block's row fragments land under the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const s16x8 pf = pack_frag(p, s2);
                 const s16x8 dsf = pack_frag(s, s2);
 #pragma unroll
                 for (int db = 0; db < G::DB; ++db) {
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(dOs, db, 2 * qs + s2, fo), pf, dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Qs, db, 2 * qs + s2, fo), dsf, dkacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[s2][db], pf, dvacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[s2][db], dsf, dkacc[db], 0, 0, 0);
                 }
             }
         }
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
-    if (k_valid) {
+    if (k_valid && HS == 1) {
         bf16_t* dkp = dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
         bf16_t* dvp = dv + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
 #pragma unroll
@@ -339,10 +374,56 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                 st8(dvp + 32 * db + 8 * g + 4 * (lane >> 5), b);
             }
     }
+    if (k_valid && HS > 1) {
+        const int64_t row = (((int64_t)blockIdx.y * T + tok0 + my_k) * hkv + hk) * D;
+        float* pk = part + row;
+        float* pv = part + (int64_t)HS * T * hkv * D + row;
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 32 * db + 8 * g + 4 * (lane >> 5);
+                *reinterpret_cast<float4*>(pk + c) = make_float4(dkacc[db][4 * g + 0], dkacc[db][4 * g + 1], dkacc[db][4 * g + 2], dkacc[db][4 * g + 3]);
+                *reinterpret_cast<float4*>(pv + c) = make_float4(dvacc[db][4 * g + 0], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
+            }
+    }
 }
+
+// dk = bf16(scale * sum_hs part_k), dv = bf16(sum_hs part_v); one thread per 4 consecutive d of a (token, kv head)
+template <int HS>
+__global__ __launch_bounds__(256) void flash_dkdv_reduce_k(const float* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                           int64_t dkv_ts, int64_t T, int hkv, int D, float scale,
+                                                           const int32_t* __restrict__ cu, int nseq) {
+    const int64_t n4 = T * hkv * (D / 4);
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % (D / 4));
+    const int64_t th = i / (D / 4);  // tok * hkv + hk
+    const int hk = (int)(th % hkv);
+    const int64_t tok = th / hkv;
+    if (tok >= cu[nseq]) return;  // tokens behind the last sequence were written by no block (and are left alone, as without the split)
+    const int64_t stride = T * hkv * (int64_t)D;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+#pragma unroll
+    for (int hs = 0; hs < HS; ++hs) {
+        const float4 x = *reinterpret_cast<const float4*>(part + hs * stride + th * D + c4 * 4);
+        const float4 y = *reinterpret_cast<const float4*>(part + (HS + hs) * stride + th * D + c4 * 4);
+        a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+    }
+    uint2 ka, vb;
+    ka.x = pack2bf(a.x * scale, a.y * scale);
+    ka.y = pack2bf(a.z * scale, a.w * scale);
+    vb.x = pack2bf(b.x, b.y);
+    vb.y = pack2bf(b.z, b.w);
+    st8(dk + tok * dkv_ts + (int64_t)hk * D + c4 * 4, ka);
+    st8(dv + tok * dkv_ts + (int64_t)hk * D + c4 * 4, vb);
+}
+
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+int g_dkdv_split = 0;  // 0 = automatic (see dkdv_split), else the forced head split of the dK/dV kernel
 int g_dq_minw = 2;  // waves/SIMD the dQ kernel is compiled for (2: 256 VGPRs with a small spill; 1: no spill, half the occupancy)
 
 }  // namespace
@@ -352,6 +433,26 @@ extern "C" int ie_tune_flash_dq_occupancy(int waves_per_simd) {
     IE_CHECK_ARG(waves_per_simd == 1 || waves_per_simd == 2, "ie_tune_flash_dq_occupancy: 1 or 2");
     g_dq_minw = waves_per_simd;
     return IE_OK;
+}
+
+// head split of the dK/dV kernel: causal attention only (the imbalance it removes is the causal one), as many ways as divides
+// the GQA group, up to 4
+static int dkdv_split(int hq, int hkv, int causal) {
+    const int grp = hq / hkv;
+    int hs = g_dkdv_split > 0 ? g_dkdv_split : (causal ? 4 : 1);
+    while (hs > 1 && grp % hs != 0) hs >>= 1;
+    return hs;
+}
+
+extern "C" int ie_tune_flash_dkdv_split(int split) {
+    IE_CHECK_ARG(split == 0 || split == 1 || split == 2 || split == 4, "ie_tune_flash_dkdv_split: 0 (auto), 1, 2 or 4");
+    g_dkdv_split = split;
+    return IE_OK;
+}
+
+extern "C" int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d) {
+    if (T < 0 || hq <= 0 || hkv <= 0 || d <= 0) return -1;
+    return (int64_t)hq * T + 2ll * 4 * T * hkv * d;  // delta + the largest set of dK/dV partials
 }
 
 extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
@@ -378,7 +479,26 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq(nt128, (unsigned)hq, (unsigned)nseq);
     const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
-    dim3 gk(nkb * (unsigned)hkv, 1, (unsigned)nseq);
+    const int hs = dkdv_split(hq, hkv, causal);
+    dim3 gk(nkb * (unsigned)hkv, (unsigned)hs, (unsigned)nseq);
+    float* part = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
+#define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
+    do {                                                                                                                           \
+        hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_>), gk, dim3(64 * DKV_WAVES), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, \
+                           q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts,            \
+                           cu_seqlens, T, hq, hkv, softmax_scale, part);                                                            \
+        if (HS_ > 1) {                                                                                                             \
+            const int64_t n4 = T * hkv * (DD / 4);                                                                                 \
+            hipLaunchKernelGGL((flash_dkdv_reduce_k<HS_>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, (bf16_t*)dk,   \
+                               (bf16_t*)dv, dkv_ts, T, hkv, DD, softmax_scale, cu_seqlens, nseq);                                   \
+        }                                                                                                                          \
+    } while (0)
+#define IE_DKDV(DD, CA)                                                                                                            \
+    do {                                                                                                                           \
+        if (hs == 4) IE_DKDV_HS(DD, CA, 4);                                                                                        \
+        else if (hs == 2) IE_DKDV_HS(DD, CA, 2);                                                                                   \
+        else IE_DKDV_HS(DD, CA, 1);                                                                                                \
+    } while (0)
 #define IE_L(DD, CA)                                                                                                               \
     do {                                                                                                                           \
         if (g_dq_minw == 2)                                                                                                        \
@@ -389,12 +509,12 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
             hipLaunchKernelGGL((flash_dq_k<DD, CA, 1>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
                                (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
                                softmax_scale);                                                                                      \
-        hipLaunchKernelGGL((flash_dkdv_k<DD, CA>), gk, dim3(64 * DKV_WAVES), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q,    \
-                           q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts,            \
-                           cu_seqlens, T, hq, hkv, softmax_scale);                                                                  \
+        IE_DKDV(DD, CA);                                                                                                           \
     } while (0)
     if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
     else          { if (causal) IE_L(64, true); else IE_L(64, false); }
 #undef IE_L
+#undef IE_DKDV
+#undef IE_DKDV_HS
     return ie_launch_status("ie_flash_attn_bwd launch");
 }

@@ -178,7 +178,7 @@ class InternLM2Engine:
         self.t_loss_rows = e(T, dtype=torch.float32)
         self.t_lse = e(T, dtype=torch.float32)
         self.t_loss = e(2, dtype=torch.float32)       # [mean loss of the micro-batch, valid-token count]
-        self.t_delta = e(hql * Tg, dtype=torch.float32)
+        self.t_delta = e(K._L().ie_flash_attn_bwd_workspace(Tg, hql, hkvl, d), dtype=torch.float32)
         self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
         self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
         self.scale_view = self.state[:4].view(torch.float32)  # IeStepState.loss_scale, read by the CE backward on device

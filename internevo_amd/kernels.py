@@ -449,8 +449,9 @@ def flash_attn_bwd(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scal
     if dk is None or dv is None:
         dkv = torch.empty((T, 2, hkv, d), dtype=q.dtype, device=q.device)
         dk, dv = dkv[:, 0], dkv[:, 1]
-    if delta_ws is None or delta_ws.numel() < hq * T:
-        delta_ws = torch.empty(hq * T, dtype=torch.float32, device=q.device)
+    need = _L().ie_flash_attn_bwd_workspace(T, hq, hkv, d)
+    if delta_ws is None or delta_ws.numel() < need:
+        delta_ws = torch.empty(need, dtype=torch.float32, device=q.device)
     kv_ts = _tok_stride(k, d)
     if _tok_stride(v, d) != kv_ts:
         raise ValueError("k and v must share the token stride")

@@ -426,3 +426,30 @@ def test_seq_head_permute_matches_seq_all_to_all_layout(dev, A, B, S, C):
     close(back, x, 0, 0, "unpack (exact)")
     y = bf(torch.randn(1001, generator=g(61)))
     close(K().scale_bf16(y.to(dev).clone(), 4.0), y * 4.0, 0, 0, "scale by a power of two (exact)")
+
+
+@pytest.mark.parametrize("split", [1, 2, 4])
+def test_flash_bwd_dkdv_head_split_and_trailing_tokens(dev, split):
+    """Every head split of the dK/dV kernel (deterministic fp32 partial sums) gives the same gradients; tokens behind the last
+    sequence of the packed buffer (cu_seqlens[-1] < T) are left untouched in dk / dv."""
+    k = K()
+    lens, hq, hkv, d = [70, 130], 8, 2, 128
+    T = sum(lens) + 24  # 24 padding tokens at the end, in no sequence
+    cu = torch.tensor([0, 70, 200], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(70)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(71)))
+    do = bf(torch.randn(T, hq, d, generator=g(72)))
+    q32, kv32 = q[:200].float().requires_grad_(True), kv[:200].float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, True)
+    (ref * do[:200].float()).sum().backward()
+    qd, kvd = q.to(dev), kv.to(dev)
+    out, lse = k.flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), 130, None, True)
+    dkv = torch.full((T, 2, hkv, d), 7.0, dtype=torch.bfloat16, device=dev)
+    try:
+        k._L().ie_tune_flash_dkdv_split(split)
+        dq, dk, dv = k.flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), 130, None, True, dk=dkv[:, 0], dv=dkv[:, 1])
+    finally:
+        k._L().ie_tune_flash_dkdv_split(0)
+    close(dk[:200], kv32.grad[:, 0], 2e-2, 3e-2, f"dk split {split}")
+    close(dv[:200], kv32.grad[:, 1], 2e-2, 3e-2, f"dv split {split}")
+    assert bool((dkv[200:] == 7.0).all()), "rows of tokens outside every sequence must not be written"
