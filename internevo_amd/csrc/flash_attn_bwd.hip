@@ -60,8 +60,11 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int seq = blockIdx.z;
-    const int h = blockIdx.y;
-    const int qt = gridDim.x - 1 - blockIdx.x;
+    // dispatch order = x fastest: ALL heads of the heaviest (last) query tile first, then the next tile ... -- a global
+    // longest-job-first order over the causal work (head-major order started the last heads' heavy tiles half-way through the
+    // kernel and left most SIMD slots idle in the tail); neighbouring blocks are the q heads of one kv head -> shared K/V in L2
+    const int h = blockIdx.x;
+    const int qt = gridDim.y - 1 - blockIdx.y;
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     const int q0 = qt * 128;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.
 constexpr int DKV_WAVES = 2;
 
-// HS > 1 (causal balance): the q heads of a kv head are split over HS blocks (blockIdx.y), each writing fp32 partial dK / dV
+// HS > 1 (causal balance): the q heads of a kv head are split over HS blocks, each writing fp32 partial dK / dV
 // to part[2][HS][T][hkv][D]; flash_dkdv_reduce_k sums them in a fixed order (deterministic, no atomics).  With all blocks
 // resident at once the kernel takes as long as its heaviest block (key block 0 sees every query tile: 2x the mean); HS x more,
 // HS x smaller blocks dispatched heavy-first let the light ones back-fill the tail.
@@ -193,9 +196,11 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int seq = blockIdx.z;
+    // x = (key block, head split, kv head), kv head fastest: every (split, head) of the heaviest key block is dispatched first
     const int hk = blockIdx.x % hkv;
-    const int nkb = gridDim.x / hkv;
-    const int j = blockIdx.x / hkv;
+    const int hsi = (blockIdx.x / hkv) % HS;
+    const int nkb = gridDim.x / (hkv * HS);
+    const int j = blockIdx.x / (hkv * HS);
     const int first = (nkb + 1) / 2;
     const int kb = HS > 1 ? j : (j < first ? j : nkb - 1 - (j - first));  // HS > 1: plain order = heavy blocks first
     const int tok0 = cu[seq];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int k0 = kb * 32 * DKV_WAVES;
     if (k0 >= len) return;
     const int grp = hq / hkv / HS;          // q heads handled by this block
-    const int h_first = hk * (hq / hkv) + (int)blockIdx.y * grp;
+    const int h_first = hk * (hq / hkv) + hsi * grp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kw0 = k0 + wave * 32;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             }
     }
     if (k_valid && HS > 1) {
-        const int64_t row = (((int64_t)blockIdx.y * T + tok0 + my_k) * hkv + hk) * D;
+        const int64_t row = (((int64_t)hsi * T + tok0 + my_k) * hkv + hk) * D;
         float* pk = part + row;
         float* pv = part + (int64_t)HS * T * hkv * D + row;
 #pragma unroll
@@ -435,12 +440,18 @@ extern "C" int ie_tune_flash_dq_occupancy(int waves_per_simd) {
     return IE_OK;
 }
 
-// head split of the dK/dV kernel: causal attention only (the imbalance it removes is the causal one), as many ways as divides
-// the GQA group, up to 4
-static int dkdv_split(int hq, int hkv, int causal) {
+// head split of the dK/dV kernel: causal attention only (the imbalance it removes is the causal one); the smallest split that
+// gives about four blocks per CU (256 CUs), as far as it divides the GQA group, at most 4
+static int dkdv_split(int hq, int hkv, int causal, int64_t blocks_unsplit) {
     const int grp = hq / hkv;
-    int hs = g_dkdv_split > 0 ? g_dkdv_split : (causal ? 4 : 1);
-    while (hs > 1 && grp % hs != 0) hs >>= 1;
+    int hs = 1;
+    if (g_dkdv_split > 0) {
+        hs = g_dkdv_split;
+        while (hs > 1 && grp % hs != 0) hs >>= 1;
+        return hs;
+    }
+    if (!causal) return 1;
+    while (hs < 4 && blocks_unsplit * hs < 1024 && grp % (hs * 2) == 0) hs *= 2;
     return hs;
 }
 
@@ -477,10 +488,10 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
             hipLaunchKernelGGL((flash_delta_k<64>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, delta, T, hq);
     }
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
-    dim3 gq(nt128, (unsigned)hq, (unsigned)nseq);
+    dim3 gq((unsigned)hq, nt128, (unsigned)nseq);
     const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
-    const int hs = dkdv_split(hq, hkv, causal);
-    dim3 gk(nkb * (unsigned)hkv, (unsigned)hs, (unsigned)nseq);
+    const int hs = dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
+    dim3 gk(nkb * (unsigned)hkv * (unsigned)hs, 1, (unsigned)nseq);
     float* part = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
 #define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
     do {                                                                                                                           \

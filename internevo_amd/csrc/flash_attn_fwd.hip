@@ -29,8 +29,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int seq = blockIdx.z;
-    const int h = blockIdx.y;
-    const int qt = gridDim.x - 1 - blockIdx.x;
+    // dispatch order = x fastest: ALL heads of the heaviest (last) query tile first, then the next tile ... -- a global
+    // longest-job-first order over the causal work (head-major order started the last heads' heavy tiles half-way through the
+    // kernel and left most SIMD slots idle in the tail); neighbouring blocks are the q heads of one kv head -> shared K/V in L2
+    const int h = blockIdx.x;
+    const int qt = gridDim.y - 1 - blockIdx.y;
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     const int q0 = qt * 128;
@@ -182,7 +185,7 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     IE_CHECK_SUPPORTED(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && q_ts % 8 == 0 && kv_ts % 8 == 0 && o_ts % 4 == 0,
                        "ie_flash_attn_fwd: pointers must be 16-byte aligned and token strides multiples of 8");
     if (nseq == 0 || T == 0 || max_seqlen == 0) return IE_OK;
-    dim3 grid((unsigned)((max_seqlen + 127) / 128), (unsigned)hq, (unsigned)nseq);
+    dim3 grid((unsigned)hq, (unsigned)((max_seqlen + 127) / 128), (unsigned)nseq);
     hipStream_t st = (hipStream_t)stream;
 #define IE_L(DD, CA)                                                                                                              \
     hipLaunchKernelGGL((flash_fwd_k<DD, CA>), grid, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
