@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
     // dispatch order = x fastest: ALL heads of the heaviest (last) query tile first, then the next tile ... -- a global
     // longest-job-first order over the causal work (head-major order started the last heads' heavy tiles half-way through the
     // kernel and left most SIMD slots idle in the tail); neighbouring blocks are the q heads of one kv head -> shared K/V in L2
-    const int h = blockIdx.x;
+    // consecutive workgroups go to consecutive XCDs: x -> head so that the q heads of one kv head (x = hk, hk + hkv, ...) share an XCD's L2
+    const int h = ((int)blockIdx.x % hkv) * (hq / hkv) + (int)blockIdx.x / hkv;
     const int qt = gridDim.y - 1 - blockIdx.y;
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
