@@ -141,3 +141,53 @@ def test_checkpoint_fraction_maps_like_the_reference():
 
     for L, frac, want in [(32, 0.0, 0), (32, 1.0, 32), (32, 0.5, 16), (5, 0.5, 3), (4, 0.3, 2), (2, True, 2), (2, False, 0)]:
         assert ModelConfig(num_layers=L, checkpoint=float(frac)).checkpoint_layers == want
+
+
+def _sp_exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.seqpar import SeqParallel
+
+        sp = SeqParallel(2, rank, world)  # world 4 = 2 data-parallel groups of 2 sequence ranks
+        Tl, H, d = 6, 4, 8
+        gen = torch.Generator().manual_seed(7 + sp.data_rank)     # both ranks of a sequence group derive the same full tensors
+        q_full_heads = torch.randn(2 * Tl, H, d, generator=gen)   # [T, H, d]: all tokens, all heads (ground truth)
+        kv_full_heads = torch.randn(2 * Tl, 2, H, d, generator=gen)
+        lo = sp.sp_rank * Tl
+        # what _SeqAllToAll computes (multi_head_attention.py:27-53): scatter heads, gather sequence
+        want_q = q_full_heads[:, sp.sp_rank * (H // 2) : (sp.sp_rank + 1) * (H // 2)]
+        want_kv = kv_full_heads[:, :, sp.sp_rank * (H // 2) : (sp.sp_rank + 1) * (H // 2)]
+        # CPU stand-in for ie_seq_head_permute: [A][B][S][C] -> [S][A][B][C]
+        def pack(x, B):
+            A = x.shape[0]
+            return x.reshape(A, B, 2, -1).permute(2, 0, 1, 3).contiguous()
+        got_q = sp.all_to_all(pack(q_full_heads[lo : lo + Tl], 1), torch.empty(2 * Tl, H // 2, d))
+        got_kv = sp.all_to_all(pack(kv_full_heads[lo : lo + Tl], 2), torch.empty(2 * Tl, 2, H // 2, d))
+        ok = torch.equal(got_q, want_q) and torch.equal(got_kv, want_kv)
+        # the inverse exchange brings "all tokens, my heads" back to "my tokens, all heads"
+        back = sp.all_to_all(got_q.contiguous(), torch.empty(2, Tl, 1, (H // 2) * d))
+        ctx_local = back.permute(1, 2, 0, 3).reshape(Tl, H, d)   # inverse permute [S][A][B][C] -> [A][B][S][C]
+        ok = ok and torch.equal(ctx_local, q_full_heads[lo : lo + Tl])
+        t = torch.tensor([float(rank + 1)])
+        sp.all_reduce_sum(t)  # sums over the sequence group only: ranks (0,1) -> 3, ranks (2,3) -> 7
+        ok = ok and float(t) == (3.0 if rank < 2 else 7.0) and (sp.data_rank, sp.data_world) == (rank // 2, 2)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_ulysses_exchange_gloo_world4():
+    """SeqParallel's groups (consecutive ranks share a sequence) and its flat all_to_all_single exchange reproduce
+    _SeqAllToAll's scatter-heads / gather-sequence result and its inverse, 2 sequence groups x 2 ranks over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_exchange_worker, args=(r, 4, 29861, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(4))
+    for p in procs:
+        p.join(30)
+    assert res == [(0, True), (1, True), (2, True), (3, True)], res
