@@ -146,3 +146,41 @@ def test_activation_checkpointing_is_bit_identical(dev, frac):
         out.append((tr, eng.params.clone()))
     assert out[0][0] == out[1][0], f"{out[0][0]} vs {out[1][0]}"
     assert torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.timeout(1500)
+def test_engine_7b_shaped_layer_full_size_matches_oracle(dev):
+    """BASELINE.json configs[1] at its FULL per-layer sizes (hidden 4096, 32/8 heads of 128, FFN 14336, vocab 92544, 4096 packed
+    tokens per micro-batch) with ONE transformer layer, so the CPU oracle finishes in under a minute: every kernel runs the code
+    path the 7B benchmark runs (256x256 GEMM tilings, flash attention at T = 4096 with several packed sequences, the 92544-wide
+    cross-entropy, the 218M / 379M-parameter AdamW buckets)."""
+    from internevo_amd.config import internlm2_7b
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+    from oracle.step import OracleTrainer
+
+    cfg = internlm2_7b(4096)
+    cfg.model.num_layers = 1
+    cfg.train.micro_num = 1
+    cfg.train.total_steps = 4
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    loader = iter(SyntheticLoader(4096, 1, 1, False, 4000))
+    for k in range(2):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        ref = ora.train_step(batch, labels)
+        print(f"7B-shaped layer, step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}  "
+              f"({len(batch['cu_seqlens'][0]) - 1} packed sequences)")
+        assert st.skip == 0
+        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])            # the north star's loss tolerance
+        assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+    worst = 0.0
+    for n, p in eng.named_parameters():
+        if n in ("layers.0.attention.wqkv.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
+            worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
+    print("max |param diff| after 2 steps:", worst)
+    assert worst <= 8e-3
