@@ -40,8 +40,10 @@ def _compile(src, force):
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
         return obj, False
     cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
+    if os.path.exists(obj):
+        os.remove(obj)  # a stale object must never survive a failed compile (the hipcc wrapper can exit 0 after "failed to execute")
     res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
+    if res.returncode != 0 or not os.path.exists(obj) or "error:" in res.stderr:
         raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")
     return obj, True
 

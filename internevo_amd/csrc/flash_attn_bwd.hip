@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     const int ntiles = (kv_end + 63) / 64;
     const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
     const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
-    dma_tile<D, 4>(kbase, kv_ts, len, smem, wave, lane);
-    dma_tile<D, 4>(vbase, kv_ts, len, smem + G::IMG_BYTES, wave, lane);
+    TileSrc<D, 4> ksrc, vsrc;
+    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
+    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
+    ksrc.issue(smem, 0, 0, wave);
+    vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
 
     FragOffs<D> fo;
     fo.init(lane);
@@ -118,9 +121,8 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
         const unsigned char* Vs = Ks + G::IMG_BYTES;
         if (t + 1 < ntiles) {
             unsigned char* nxt = smem + (1 - S) * STAGE;
-            const int rem = len - (kv0 + 64);
-            dma_tile<D, 4>(kbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt, wave, lane);
-            dma_tile<D, 4>(vbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt + G::IMG_BYTES, wave, lane);
+            ksrc.issue(nxt, kv0 + 64, 0, wave);
+            vsrc.issue(nxt + G::IMG_BYTES, kv0 + 64, 0, wave);
         }
         const bool active = !CAUSAL || kv0 <= qw0 + 31;
         if (active) {
@@ -133,14 +135,17 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, 32 * c, ks, fo), dof[ks], dp, 0, 0, 0);
                 }
+                if (need_mask) {  // wave-uniform; selects instead of per-element branches
+                    const int lim = CAUSAL ? min(len - 1, my_q) : len - 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lse2));
-                    if (need_mask) {
+                    for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + 32 * c + creg_row(r, lane);
-                        if (key >= len || (CAUSAL && key > my_q)) p = 0.f;
+                        const float p = key > lim ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lse2));
+                        s[r] = p * (dp[r] - dlt);
                     }
-                    s[r] = p * (dp[r] - dlt);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lse2)) * (dp[r] - dlt);
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -221,13 +226,16 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len
     const int nit = grp * nqt;
 
+    TileSrc<D, DKV_WAVES> qsrc, dosrc;
+    qsrc.init(q + (int64_t)tok0 * q_ts, q_ts, T - tok0, (int64_t)hq * D, wave, lane);
+    dosrc.init(dout + (int64_t)tok0 * do_ts, do_ts, T - tok0, (int64_t)hq * D, wave, lane);
     // stage `it`: Q / dO images by DMA; lse (log2 domain) and delta through registers of threads 0..63
     auto issue = [&](int it, unsigned char* stage, float& lse_r, float& dlt_r) {
         const int h = h_first + it / nqt;
         const int q0 = (qt_start + it % nqt) * 64;
         const int rem = len - q0;
-        dma_tile<D, DKV_WAVES>(q + (int64_t)(tok0 + q0) * q_ts + (int64_t)h * D, q_ts, rem, stage, wave, lane);
-        dma_tile<D, DKV_WAVES>(dout + (int64_t)(tok0 + q0) * do_ts + (int64_t)h * D, do_ts, rem, stage + G::IMG_BYTES, wave, lane);
+        qsrc.issue(stage, q0, h * D, wave);
+        dosrc.issue(stage + G::IMG_BYTES, q0, h * D, wave);
         if (threadIdx.x < 64) {
             const bool ok = (int)threadIdx.x < rem;
             lse_r = ok ? lse[(int64_t)h * T + tok0 + q0 + threadIdx.x] * kLog2e : INFINITY;
@@ -328,16 +336,24 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                 const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + rl);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
                 const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                if (need_mask) {  // wave-uniform; selects instead of per-element branches
+                    const int first_q = (my_k >= len) ? 0x7fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));  // lse2 = +inf for rows >= len -> 0
-                    if (need_mask) {
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
                         const int qrow = q0 + rl + e;
-                        if (my_k >= len || (CAUSAL && my_k > qrow)) pv = 0.f;
+                        const float pv = qrow < first_q ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));  // lse2 = +inf for rows >= len -> 0
+                        p[r] = pv;
+                        s[r] = pv * (dp[r] - dv4[e]);
                     }
-                    p[r] = pv;
-                    s[r] = pv * (dp[r] - dv4[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));
+                        p[r] = pv;
+                        s[r] = pv * (dp[r] - dv4[e]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -51,8 +51,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
     const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
     const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
 
-    dma_tile<D, 4>(kbase, kv_ts, len, smem, wave, lane);
-    dma_tile<D, 4>(vbase, kv_ts, len, smem + G::IMG_BYTES, wave, lane);
+    TileSrc<D, 4> ksrc, vsrc;
+    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
+    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
+    ksrc.issue(smem, 0, 0, wave);
+    vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
 
     FragOffs<D> fo;
     fo.init(lane);
@@ -85,9 +88,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
         const unsigned char* Vs = Ks + G::IMG_BYTES;
         if (t + 1 < ntiles) {
             unsigned char* nxt = smem + (1 - S) * STAGE;
-            const int rem = len - (kv0 + 64);
-            dma_tile<D, 4>(kbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt, wave, lane);
-            dma_tile<D, 4>(vbase + (int64_t)(kv0 + 64) * kv_ts, kv_ts, rem, nxt + G::IMG_BYTES, wave, lane);
+            ksrc.issue(nxt, kv0 + 64, 0, wave);
+            vsrc.issue(nxt + G::IMG_BYTES, kv0 + 64, 0, wave);
         }
         // wave-uniform: does this wave see any unmasked key in this tile?
         const bool active = !CAUSAL || kv0 <= qw0 + 31;
@@ -102,16 +104,20 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
             }
             const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > len);
             float mx = -INFINITY;
+            if (need_mask) {  // wave-uniform: only the diagonal / last tiles pay for the masks (selects, no per-element branches)
+                const int lim = CAUSAL ? min(len - 1, my_q) : len - 1;  // largest visible key of this lane's query
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 32 * c + creg_row(r, lane);
+                        sacc[c][r] = key > lim ? -INFINITY : sacc[c][r];
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (need_mask) {
-                        const int key = kv0 + 32 * c + creg_row(r, lane);
-                        if (key >= len || (CAUSAL && key > my_q)) sacc[c][r] = -INFINITY;
-                    }
-                    mx = fmaxf(mx, sacc[c][r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[c][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;

@@ -66,6 +66,45 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int64_t
     }
 }
 
+// Buffer-addressed twin of dma_tile for the kernels' inner loops: the per-lane part of a piece's source address is a byte
+// offset VGPR computed ONCE (voff[q]), the tile / head part goes into the scalar offset of `buffer_load_dwordx4 .. lds`,
+// so issuing a tile costs no vector ALU at all (dma_tile recomputes a clamped 64-bit address per piece per tile: ~6 VALU
+// incl. 64-bit multiplies).  No row clamping: rows behind the sequence are rows of the next sequence (finite, masked by the
+// callers like the clamped rows were) and rows behind the tensor read as zero (num_records).
+template <int D, int NW>
+struct TileSrc {
+    static constexpr int PERW = (64 / Geo<D>::ROWS_PER_DMA) / NW;
+    const bf16_t* base;
+    uint32_t bytes;
+    int ts2;          // token stride in bytes
+    int voff[PERW];
+    // `base` = first row any tile may start at; rows_to_end = rows from there to the end of the tensor, tail_elems = elements
+    // of the last row that belong to the tensor (head_dim for a single head, heads * head_dim when the head goes into `extra`)
+    __device__ __forceinline__ void init(const bf16_t* b, int64_t ts, int64_t rows_to_end, int64_t tail_elems, int wave, int lane) {
+        using G = Geo<D>;
+        base = b;
+        ts2 = (int)(ts * 2);
+        bytes = (uint32_t)(((rows_to_end - 1) * ts + tail_elems) * 2);
+#pragma unroll
+        for (int q = 0; q < PERW; ++q) {
+            const int g = wave + NW * q;
+            const int row = g * G::ROWS_PER_DMA + lane / G::SLOTS;
+            const int c = (lane % G::SLOTS) ^ swz<D>(row);
+            voff[q] = row * ts2 + c * 16;
+        }
+    }
+    // tile starting `row0` rows (+ `extra` elements, e.g. a head offset) behind base -> img
+    __device__ __forceinline__ void issue(unsigned char* img, int row0, int extra, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+        const int soff = row0 * ts2 + extra * 2;
+#pragma unroll
+        for (int q = 0; q < PERW; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, voff[q], soff, 0, 0);
+#endif
+    }
+};
+
 // Per-lane byte offsets of the fragments inside ANY tile image, computed once per kernel: the XOR swizzle only
 // involves the low row bits, which do not depend on the 32-row block / 16-row step / image / pipeline stage, so
 // inside the tile loop every fragment read is `ds_read base_register offset:immediate` with zero address VALU.

@@ -370,44 +370,31 @@ __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float
     const AdamConsts c = sc;
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * 256;
-    // 8 elements per thread and iteration: 16-byte loads on every stream (two per fp32 stream), all issued before the math;
-    // the state is touched once per step, so loads and stores are non-temporal (they would only evict the weights from L2 / MALL)
-    const int64_t n8 = vec_ok ? n / 8 : 0;
-    const int64_t n4 = n8 * 2;
-    for (int64_t i = tid; i < n8; i += nthreads) {
-        float gv[8];
+    const int64_t n4 = vec_ok ? n / 4 : 0;
+    for (int64_t i = tid; i < n4; i += nthreads) {
+        float gv[4];
         if (GBF) {
-            const uint4 q = __builtin_nontemporal_load(reinterpret_cast<const uint4*>((const bf16_t*)g + i * 8));
+            const uint2 q = ld8((const bf16_t*)g + i * 4);
             gv[0] = bflo(q.x); gv[1] = bfhi(q.x); gv[2] = bflo(q.y); gv[3] = bfhi(q.y);
-            gv[4] = bflo(q.z); gv[5] = bfhi(q.z); gv[6] = bflo(q.w); gv[7] = bfhi(q.w);
         } else {
-            const float4 q0 = __builtin_nontemporal_load(reinterpret_cast<const float4*>((const float*)g + i * 8));
-            const float4 q1 = __builtin_nontemporal_load(reinterpret_cast<const float4*>((const float*)g + i * 8 + 4));
-            gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
+            const float4 q = *reinterpret_cast<const float4*>((const float*)g + i * 4);
+            gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
         }
-        float4* P = reinterpret_cast<float4*>(p32 + i * 8);
-        float4* M = reinterpret_cast<float4*>(m + i * 8);
-        float4* V = reinterpret_cast<float4*>(v + i * 8);
-        float4 pp[2] = {__builtin_nontemporal_load(P), __builtin_nontemporal_load(P + 1)};
-        float4 mm[2] = {__builtin_nontemporal_load(M), __builtin_nontemporal_load(M + 1)};
-        float4 vv[2] = {__builtin_nontemporal_load(V), __builtin_nontemporal_load(V + 1)};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            adam_one(gv[4 * h + 0], pp[h].x, mm[h].x, vv[h].x, c);
-            adam_one(gv[4 * h + 1], pp[h].y, mm[h].y, vv[h].y, c);
-            adam_one(gv[4 * h + 2], pp[h].z, mm[h].z, vv[h].z, c);
-            adam_one(gv[4 * h + 3], pp[h].w, mm[h].w, vv[h].w, c);
-            __builtin_nontemporal_store(pp[h], P + h);
-            __builtin_nontemporal_store(mm[h], M + h);
-            __builtin_nontemporal_store(vv[h], V + h);
-        }
+        float4 pp = *reinterpret_cast<float4*>(p32 + i * 4);
+        float4 mm = *reinterpret_cast<float4*>(m + i * 4);
+        float4 vv = *reinterpret_cast<float4*>(v + i * 4);
+        adam_one(gv[0], pp.x, mm.x, vv.x, c);
+        adam_one(gv[1], pp.y, mm.y, vv.y, c);
+        adam_one(gv[2], pp.z, mm.z, vv.z, c);
+        adam_one(gv[3], pp.w, mm.w, vv.w, c);
+        *reinterpret_cast<float4*>(p32 + i * 4) = pp;
+        *reinterpret_cast<float4*>(m + i * 4) = mm;
+        *reinterpret_cast<float4*>(v + i * 4) = vv;
         if (p16) {
-            uint4 o;
-            o.x = pack2bf(pp[0].x, pp[0].y);
-            o.y = pack2bf(pp[0].z, pp[0].w);
-            o.z = pack2bf(pp[1].x, pp[1].y);
-            o.w = pack2bf(pp[1].z, pp[1].w);
-            st16(p16 + i * 8, o);  // the bf16 shadow IS re-read (all-gather, next forward): normal store
+            uint2 o;
+            o.x = pack2bf(pp.x, pp.y);
+            o.y = pack2bf(pp.z, pp.w);
+            st8(p16 + i * 4, o);
         }
     }
     for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) {
@@ -545,8 +532,9 @@ extern "C" int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, f
     IE_CHECK_ARG(g && p32 && m && v && state_dev && n >= 0, "ie_adamw_step: bad argument");
     IE_CHECK_ARG(g_dtype == IE_BF16 || g_dtype == IE_F32, "ie_adamw_step: bad dtype");
     if (n == 0) return IE_OK;
-    const int vec_ok = aligned16(p32) && aligned16(m) && aligned16(v) && aligned16(g) && (!p16 || aligned16(p16));
-    int64_t blocks = (n / 8 + 255) / 256;
+    const int vec_ok = aligned16(p32) && aligned16(m) && aligned16(v) && ((((uintptr_t)g) & (g_dtype == IE_BF16 ? 7u : 15u)) == 0) &&
+                       (!p16 || (((uintptr_t)p16) & 7u) == 0);
+    int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
     if (g_dtype == IE_BF16)
