@@ -271,11 +271,12 @@ inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu
 int pick_variant(int64_t M, int64_t N, int64_t K, bool any_kmajor) {
     // priors from the round-1 micro-benchmarks (profiles/r01_gemm_tile_tuning.json): relative MFMA efficiency per tile shape
     if (K > 0 && K % 64 == 0 && M >= 8 && N >= 8) {  // LDS-DMA kernels: 256x256 unless wave quantisation on 256 CUs favours 128x128
-        const double d256 = shape_cost(M, N, 256, 256, 1, 1.18);
+        const double d256 = shape_cost(M, N, 256, 256, 1, 1.36);  // measured: variants 11 / 13 vs the 128x128 kernels on 1.5-round shapes (wqkv)
         const double d128 = shape_cost(M, N, 128, 128, 2, 1.00);
         // 256x256: k-contiguous operands -> one wave per SIMD (128x128 per wave), buffer-addressed DMA, fragments pipelined
-        // across k-tiles; a k-major operand (two transposing reads per fragment) -> 8 waves, role-split load/compute phases
-        if (d256 <= d128) return any_kmajor ? 9 : 11;
+        // across k-tiles; a k-major operand (two transposing reads per fragment) -> 8 waves, role-split load/compute phases of
+        // two k-steps each, buffer-addressed DMA (+12 % dgrad, +7 % wgrad over one k-step per phase, profiles/)
+        if (d256 <= d128) return any_kmajor ? 13 : 11;
         return any_kmajor ? 5 : 8;    // 128x128: spreading helps the k-contiguous product only
     }
     const double c0 = shape_cost(M, N, 128, 128, 2, 1.00);
@@ -300,15 +301,15 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 12, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 13, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
-    const bool fits32 = (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
+    const bool fits32 = /* also needed by variant 13 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
     if (variant < 0) {
         variant = pick_variant(M, N, K, a_kmajor || b_kmajor);
-        if (variant == 11 && !fits32) variant = 9;
+        if ((variant == 11 || variant == 13) && !fits32) variant = 9;
     }
-    IE_CHECK_SUPPORTED(variant != 11 || fits32, "ie_gemm_bf16: tile variant 11 needs operands smaller than 4 GiB");
+    IE_CHECK_SUPPORTED((variant != 11 && variant != 13) || fits32, "ie_gemm_bf16: tile variants 11 and 13 need operands smaller than 4 GiB");
     if (variant >= 4) {  // LDS-DMA kernels (gemm_bf16_dma.hip): need whole 64-wide k-tiles and >= 8 valid rows/cols to clamp to
         IE_CHECK_SUPPORTED(K > 0 && K % 64 == 0 && M >= 8 && N >= 8, "ie_gemm_bf16: the LDS-DMA variants need K % 64 == 0");
         return ie_gemm_dma_launch(variant - 4, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = K / BK;
-    constexpr bool USE_BUF = SPREAD == -2;
+    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
     sa.init(A, lda, m0, M, K, wave, lane);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     constexpr int NA = DmaSrc<A_KM, BM, NW>::PERW, NB = DmaSrc<B_KM, BN, NW>::PERW;
     constexpr int DMA_STRIDE = SPREAD > 0 ? (SPREAD * G::TM * G::TN) / (NA + NB) : 1;  // MFMAs between two DMA issues
     static_assert(SPREAD <= 0 || DMA_STRIDE >= 1, "more DMA slots than MFMAs in the spread window");
-    if constexpr (SPREAD == -1) {
+    if constexpr (SPREAD == -1 || SPREAD == -11) {
         // ---- role-split schedule (the "two waves per SIMD alternate compute and load segments" regime of
         // MI355X_MICROARCH.md): every k-step is a LOAD phase (fragment ds_reads + a share of the next tile's DMA
         // issues) and a COMPUTE phase (TM*TN MFMAs), each closed by a raw s_barrier.  The second half of the waves
@@ -233,7 +233,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         // buffer in flight; each wave waits for its own DMA of tile t+1 (vmcnt(0)) in step 3 before the barrier that
         // precedes the first read of tile t+1 by anyone.
         const bool lag = wave >= NW / 2;
-        constexpr int PER_PHASE = (NA + NB + 1) / 2;  // DMA issues per LOAD phase (steps 0 and 1 only: time to land)
+        // KP k-steps per phase: KP = 1 -> 4 LOAD/COMPUTE pairs per k-tile; KP = 2 (SPREAD = -11) -> 2 pairs with twice the
+        // fragments and MFMAs each: the fixed cost of a phase (LDS round trip, drain, two barriers) is paid half as often
+        constexpr int KP = SPREAD == -11 ? 2 : 1;
+        constexpr int NPH = 4 / KP;
+        constexpr int DMA_PHASES = KP == 2 ? 1 : 2;                       // phases (from 0) that carry the next tile's DMA issues
+        constexpr int PER_PHASE = (NA + NB + DMA_PHASES - 1) / DMA_PHASES;
         if (lag) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
@@ -241,23 +246,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
             const unsigned char* At = smem + (kt & 1) * G::STAGE_BYTES;
             const unsigned char* Bt = At + G::A_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int kp = 0; kp < NPH; ++kp) {
                 // LOAD phase
-                s16x8 af[G::TM], bfr[G::TN];
+                s16x8 af[KP][G::TM], bfr[KP][G::TN];
 #pragma unroll
-                for (int i = 0; i < G::TM; ++i)
-                    af[i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
+                for (int u = 0; u < KP; ++u) {
+                    const int ks = kp * KP + u;
 #pragma unroll
-                for (int j = 0; j < G::TN; ++j)
-                    bfr[j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
-                if (ks < 2 && more) {
+                    for (int i = 0; i < G::TM; ++i)
+                        af[u][i] = A_KM ? frag_km<BM>(At, wm * G::WM + i * 32, ks, lane) : frag_kc(At, wm * G::WM + i * 32, ks, lane);
 #pragma unroll
-                    for (int s = ks * PER_PHASE; s < (ks + 1) * PER_PHASE && s < NA + NB; ++s) {
-                        if (s < NA) sa.issue_one(s, nbuf, wave);
-                        else sb.issue_one(s - NA, nbuf + G::A_BYTES, wave);
-                    }
+                    for (int j = 0; j < G::TN; ++j)
+                        bfr[u][j] = B_KM ? frag_km<BN>(Bt, wn * G::WN + j * 32, ks, lane) : frag_kc(Bt, wn * G::WN + j * 32, ks, lane);
                 }
-                if (ks == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (kp < DMA_PHASES && more) {
+#pragma unroll
+                    for (int s = kp * PER_PHASE; s < (kp + 1) * PER_PHASE && s < NA + NB; ++s) {
+                        if (s < NA) sa.issue_keep(s, nbuf, wave);
+                        else sb.issue_keep(s - NA, nbuf + G::A_BYTES, wave);
+                    }
+                    if (kp == DMA_PHASES - 1) { sa.advance_all(); sb.advance_all(); }
+                }
+                if (kp == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -265,10 +275,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                 // COMPUTE phase
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < G::TM; ++i)
+                for (int u = 0; u < KP; ++u)
 #pragma unroll
-                    for (int j = 0; j < G::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+                    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u][j], af[u][i], acc[i][j], 0, 0, 0);  // D[n][m]
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -493,7 +505,8 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 5) IE_SHAPE(256, 256, 2, 4, -1);
     else if (shape == 6) IE_SHAPE(128, 128, 2, 2, -1);
     else if (shape == 7) IE_SHAPE(256, 256, 2, 2, -2);
-    else IE_SHAPE(128, 256, 2, 4, -1);
+    else if (shape == 8) IE_SHAPE(128, 256, 2, 4, -1);
+    else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
 }
