@@ -91,6 +91,11 @@ class InternLM2Engine:
         self.T = tc.packed_length // sp_size    # tokens this rank owns (all of them without sequence parallelism)
         self._alloc(self.T)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
+        # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
+        # GEMMs are MFMA-bound, so bucket b+1's update overlaps the forward of layer b; per-bucket events order the two.
+        self.opt_stream = torch.cuda.Stream(device=device)
+        self._bucket_ready = [None] * len(self.layout.buckets)
+        self._opt_done = None
         self.metric = None  # optional internevo_amd.metrics.AccPerplex (attach_metric)
         self.step_count = 0
 
@@ -228,13 +233,13 @@ class InternLM2Engine:
         mc = self.mc
         L, eps = mc.num_layers, mc.layer_norm_epsilon
         p = self.p
-        self.comm.wait_gather(0)          # parameters of bucket b were all-gathered asynchronously by the previous step()
+        self._wait_bucket(0)              # bucket b's AdamW / all-gather of the previous step() may still be running on the optimizer stream
         K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
         ffn_out = None
         for l in range(L):
-            self.comm.wait_gather(1 + l)
+            self._wait_bucket(1 + l)
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
-        self.comm.wait_gather(L + 1)
+        self._wait_bucket(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
         if self.metric is None:
@@ -263,6 +268,8 @@ class InternLM2Engine:
         # the first micro-batch of a step WRITES the gradients, the others accumulate: no zero_grad pass over 15.5 GB and no read of
         # the old value in the first weight-gradient epilogues (bucket padding is zero from allocation and never written)
         acc = not first_micro
+        if first_micro:
+            self._wait_optimizer()  # the previous step's AdamW reads the gradients this backward is about to overwrite
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
         K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         dlog = self.t_logits
@@ -373,11 +380,20 @@ class InternLM2Engine:
         K.step_control(self.state, self.sumsq, self.scaler_cfg)
         lr = self.lr_sched.lr()
         beta2 = self.beta2_sched.beta2()
-        for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
-            s, n = b.shard(self.rank, self.world)
-            K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
-                         self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
-            self.comm.gather_bucket_async(self.params, b.index)
+        main = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.opt_stream):
+            self.opt_stream.wait_event(ev)  # gradients, norm and step control are final
+            for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
+                s, n = b.shard(self.rank, self.world)
+                K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
+                             self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
+                self.comm.gather_bucket_async(self.params, b.index)
+                done = torch.cuda.Event()
+                done.record(self.opt_stream)
+                self._bucket_ready[b.index] = done
+            self._opt_done = self._bucket_ready[L.buckets[-1].index]
         # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter
         # exchange overlaps the next step's first layers; read_state()/named_parameters() drain them explicitly.
         # Engine.step steps the schedulers only after a successful update; success lives on the device, so the
@@ -411,9 +427,29 @@ class InternLM2Engine:
                 if a < z:
                     K.scale_bf16(self.grads[a:z], n_)
 
+    def _wait_bucket(self, b):
+        """Order the current stream behind the optimizer-stream work on bucket b (AdamW, and its all-gather when world > 1)."""
+        ev = self._bucket_ready[b]
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self._bucket_ready[b] = None
+        self.comm.wait_gather(b)
+
+    def _wait_optimizer(self):
+        if self._opt_done is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._opt_done)
+            self._opt_done = None
+
+    def drain(self):
+        """Order the current stream behind everything the last step() left running (call before touching eng.params directly)."""
+        for b in range(len(self._bucket_ready)):
+            self._wait_bucket(b)
+        self._wait_optimizer()
+        self.comm.wait_all_gathers()
+
     def read_state(self):
         """Host copy of the step state (synchronises).  Also rewinds the host schedulers for skipped steps."""
-        self.comm.wait_all_gathers()
+        self.drain()
         st = K.step_state_read(self.state)
         self.lr_sched.set_successful_steps(st.adam_step)
         self.beta2_sched.set_successful_steps(st.adam_step)
@@ -421,11 +457,11 @@ class InternLM2Engine:
 
     # ------------------------------------------------------------------------------------------ utilities
     def named_parameters(self):
-        self.comm.wait_all_gathers()
+        self.drain()
         return self.p.items()
 
     def load_named_parameters(self, named):
-        self.comm.wait_all_gathers()
+        self.drain()
         for n, t in named.items():
             self.p[n].copy_(t.to(self.dev, BF16))
         self.sync_master_from_params()
