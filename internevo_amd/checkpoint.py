@@ -1,0 +1,187 @@
+"""InternEvo's on-disk checkpoint format, single model-parallel shard (tp = pp = 1, ZeRO world 1).
+
+Written / read so that a run can be handed over between the reference and this engine in both directions:
+
+    <folder>/model_tp0_pp0.pt                      torch.save(OrderedDict), keys "model.<param>" in module order, model dtype
+    <folder>/topo_tp0_pp0.json                     torch.save({}) (yes, a torch zip under a .json name)
+    <folder>/optimizer_tp0_pp0_zo0.pt              HybridZeroOptimizer.state_dict():
+        grad_scaler        {_scale (python float), _growth_step, _hysteresis_step}
+        base_optim_states  torch.optim.AdamW.state_dict() over ONE flat fp32 parameter per group:
+                           state {0: {step (0-d fp32), exp_avg [P], exp_avg_sq [P]}}, param_groups [default, fp32]
+        flat_fp32_weights  {0: fp32 [P]}  -- the master weights
+        zero_devide_optim_plan  as below
+    <folder>/gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt   zero_devide_optim_plan: [[["<i>_<shape>" ...]], [[]]]
+
+(internlm/checkpoint/components.py:199-283,377-410; solver/optimizer/hybrid_zero_optim.py:133-140,254-284,882-936.)
+The flat vectors hold the group's parameters in the ZeRO partition order of rank 0: the module-order parameter list stably
+sorted by numel, largest first (`_partition_param_list`).  `param_groups[*]["optimizer_mode"]` is the reference's ParallelMode
+enum, pickled by reference: it is written through a stand-in module of the same dotted name when `internlm` is not importable
+and read through a tolerant unpickler, so neither side needs the other installed.
+
+Everything here works on named host tensors; `InternLM2Engine.save_checkpoint / load_checkpoint` (engine.py) map them onto
+the flat device buffers.  Pinned by tests/golden/ckpt_ref/ (written by the real reference, tests/golden/make_golden.py --ckpt).
+"""
+import collections
+import enum
+import os
+import pickle
+import sys
+import types
+
+import torch
+
+_PM_MODULE = "internlm.core.context.process_group_initializer"
+
+
+def state_dict_order(model_cfg):
+    """Parameter names in the reference's module order (PackedFlashLlama1D.state_dict())."""
+    names = ["tok_embeddings.weight"]
+    for l in range(model_cfg.num_layers):
+        p = f"layers.{l}."
+        names += [p + "attention.wqkv.weight", p + "attention.wo.weight", p + "attention_norm.weight", p + "ffn_norm.weight",
+                  p + "feed_forward.w1.weight", p + "feed_forward.w2.weight", p + "feed_forward.w3.weight"]
+    return names + ["norm.weight", "output.weight"]
+
+
+def zero_flat_order(named_shapes):
+    """ZeRO rank-0 order of a parameter group on one rank: stable sort by numel, descending (hybrid_zero_optim.py:254-284)."""
+    def numel(shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return n
+
+    return sorted(named_shapes, key=lambda kv: numel(kv[1]), reverse=True)
+
+
+def _plan_names(ordered):
+    return [f"{i}_" + "_".join(str(d) for d in shape) for i, (_, shape) in enumerate(ordered)]
+
+
+class _RefEnumModule:
+    """Context: make `ParallelMode.ZERO1` picklable by reference under the reference's module path without the reference."""
+
+    def __enter__(self):
+        self.created = []
+        try:
+            import importlib
+
+            self.pm = importlib.import_module(_PM_MODULE).ParallelMode
+            return self.pm.ZERO1
+        except Exception:  # noqa: BLE001 - the reference is simply not installed
+            pass
+        parts = _PM_MODULE.split(".")
+        for i in range(1, len(parts) + 1):
+            name = ".".join(parts[:i])
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+                self.created.append(name)
+        mod = sys.modules[_PM_MODULE]
+        pm = enum.Enum("ParallelMode", {"ZERO1": "zero1"}, module=_PM_MODULE)
+        mod.ParallelMode = pm
+        return pm.ZERO1
+
+    def __exit__(self, *exc):
+        for name in reversed(self.created):
+            sys.modules.pop(name, None)
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith("internlm"):
+            try:
+                return super().find_class(module, name)
+            except Exception:  # noqa: BLE001 - reference not installed: a placeholder that remembers its constructor args
+                return type(name, (), {"__module__": module, "__init__": lambda self, *a, **k: setattr(self, "args", a),
+                                       "__repr__": lambda self: f"{name}{getattr(self, 'args', ())}"})
+        return super().find_class(module, name)
+
+
+_pickle_shim = types.ModuleType("internevo_amd_refpickle")
+_pickle_shim.Unpickler = _TolerantUnpickler
+_pickle_shim.load = lambda f, **kw: _TolerantUnpickler(f, **kw).load()
+_pickle_shim.__name__ = "pickle"
+
+
+def _load(path):
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_pickle_shim)
+
+
+def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16):
+    """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
+    hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr")."""
+    os.makedirs(folder, exist_ok=True)
+    order = state_dict_order(model_cfg)
+    sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
+    torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
+    torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
+    flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
+
+    def flat(named):
+        return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n, _ in flat_order])
+
+    plan = [[_plan_names(flat_order)], [[]]]
+    with _RefEnumModule() as zero1:
+        tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
+                    differentiable=False, fused=True, decoupled_weight_decay=True)
+        # key order as the reference's groups carry it (train/utils.py:create_param_groups + torch.optim.AdamW defaults)
+        g_default = dict(name="default", weight_decay=hyper["weight_decay"], optimizer_mode=zero1, **tail, dtype=param_dtype,
+                         initial_lr=hyper["initial_lr"], params=[0])
+        g_fp32 = dict(name="fp32", optimizer_mode=zero1, weight_decay=hyper["weight_decay"], **tail, dtype=None,
+                      initial_lr=hyper["initial_lr"], params=[])
+        states = {
+            "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]),
+                            "_hysteresis_step": int(scaler["hysteresis_step"])},
+            "base_optim_states": {
+                "state": {0: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg), "exp_avg_sq": flat(exp_avg_sq)}},
+                "param_groups": [g_default, g_fp32],
+            },
+            "flat_fp32_weights": {0: flat(master)},
+            "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
+        }
+        torch.save(states, os.path.join(folder, "optimizer_tp0_pp0_zo0.pt"))
+    torch.save(plan, os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt"))
+
+
+def load_checkpoint(folder, model_cfg):
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr).  Optimizer entries are None when
+    the folder holds model weights only."""
+    order = state_dict_order(model_cfg)
+    sd = torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False)
+    params = {}
+    for n in order:
+        key = "model." + n if "model." + n in sd else n
+        if key not in sd:
+            raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
+        params[n] = sd[key].detach()
+    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None)
+    opt_path = os.path.join(folder, "optimizer_tp0_pp0_zo0.pt")
+    if not os.path.exists(opt_path):
+        return out
+    st = _load(opt_path)
+    flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
+    plan_path = os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt")
+    if os.path.exists(plan_path):
+        plan = _load(plan_path)
+        if plan[0][0] != _plan_names(flat_order):
+            raise ValueError("zero_devide_optim_plan of the checkpoint does not match this model's single-rank partition order")
+
+    def unflat(vec):
+        named, o = {}, 0
+        for n, shape in flat_order:
+            k = 1
+            for d in shape:
+                k *= d
+            named[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
+            o += k
+        if o != vec.numel():
+            raise ValueError(f"flat optimizer vector holds {vec.numel()} elements, the model {o}")
+        return named
+
+    base = st["base_optim_states"]
+    s0 = base["state"][0]
+    gs = st["grad_scaler"]
+    out.update(master=unflat(st["flat_fp32_weights"][0]), exp_avg=unflat(s0["exp_avg"]), exp_avg_sq=unflat(s0["exp_avg_sq"]),
+               adam_step=int(float(s0["step"])), lr=float(base["param_groups"][0]["lr"]),
+               scaler=dict(scale=float(gs["_scale"]), growth_step=int(gs["_growth_step"]), hysteresis_step=int(gs["_hysteresis_step"])))
+    return out

@@ -460,6 +460,57 @@ class InternLM2Engine:
         self.drain()
         return self.p.items()
 
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def _named_shard_views(self, flat_local):
+        """name -> view of this rank's fp32 state for a parameter (world 1: the whole parameter)."""
+        L = self.layout
+        out = {}
+        for b, lo in zip(L.buckets, L.local_offsets()):
+            for n in b.params:
+                s = L.params[n]
+                out[n] = flat_local[lo + (s.offset - b.start) : lo + (s.offset - b.start) + s.numel].view(s.shape)
+        return out
+
+    def save_checkpoint(self, folder):
+        """InternEvo's checkpoint files (checkpoint.py; model weights + hybrid-ZeRO optimizer state), single-rank layout."""
+        from . import checkpoint as C
+
+        if self.world != 1:
+            raise NotImplementedError("checkpoints are written in the single-rank layout (tp = pp = 1, ZeRO world 1) in this round")
+        st = self.read_state()  # drains the optimizer stream
+        tc = self.tc
+        cpu = lambda d: {n: t.detach().to("cpu") for n, t in d.items()}  # noqa: E731
+        C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
+                          cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step,
+                          dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step), self.lr_sched.lr(),
+                          dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr))
+
+    def load_checkpoint(self, folder):
+        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint)."""
+        from . import checkpoint as C
+        from ._lib import IeStepState
+
+        ck = C.load_checkpoint(folder, self.mc)
+        self.drain()
+        for n, t in ck["params"].items():
+            self.p[n].copy_(t.to(self.dev, BF16))
+        if ck["master"] is None:
+            self.sync_master_from_params()
+            return
+        if self.world != 1:
+            raise NotImplementedError("optimizer state is read in the single-rank layout (ZeRO world 1) in this round")
+        for views, key in ((self._named_shard_views(self.master), "master"), (self._named_shard_views(self.exp_avg), "exp_avg"),
+                           (self._named_shard_views(self.exp_avg_sq), "exp_avg_sq")):
+            for n, v in views.items():
+                v.copy_(ck[key][n].to(self.dev))
+        st = K.step_state_read(self.state)
+        st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
+        st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0
+        self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.dev))
+        self.lr_sched.set_successful_steps(ck["adam_step"])
+        self.beta2_sched.set_successful_steps(ck["adam_step"])
+        self.step_count = ck["adam_step"]
+
     def load_named_parameters(self, named):
         self.drain()
         for n, t in named.items():

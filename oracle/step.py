@@ -38,6 +38,28 @@ class OracleTrainer:
         self.beta2_iter = 0
         self.metric = None  # optional oracle.ops.AccPerplexOracle, fed every micro-batch's logits (SchedulerMetricHook)
 
+    # ---- checkpoint hand-over (internevo_amd/checkpoint.py dict form; load_checkpoint / save_checkpoint of the reference format)
+    def load_state(self, ck):
+        with torch.no_grad():
+            for n in self.names:
+                self.params[n].copy_(ck["params"][n].to(self.params[n].dtype))
+                if ck["master"] is not None:
+                    self.master[n].copy_(ck["master"][n])
+                    self.m[n].copy_(ck["exp_avg"][n])
+                    self.v[n].copy_(ck["exp_avg_sq"][n])
+                else:
+                    self.master[n].copy_(self.params[n].float())
+        if ck["adam_step"] is not None:
+            self.adam_step = self.k = self.beta2_iter = int(ck["adam_step"])  # no skipped step so far: successful == total
+            sc = ck["scaler"]
+            self.scaler.scale, self.scaler.growth_step, self.scaler.hysteresis_step = float(sc["scale"]), int(sc["growth_step"]), int(sc["hysteresis_step"])
+
+    def export_state(self):
+        return dict(params={n: self.params[n].detach().clone() for n in self.names}, master={n: t.clone() for n, t in self.master.items()},
+                    exp_avg={n: t.clone() for n, t in self.m.items()}, exp_avg_sq={n: t.clone() for n, t in self.v.items()},
+                    adam_step=self.adam_step, lr=self._lr(),
+                    scaler=dict(scale=self.scaler.scale, growth_step=self.scaler.growth_step, hysteresis_step=self.scaler.hysteresis_step))
+
     # lr exactly as the reference produces it: torch's scheduler objects driven the same way
     def _lr(self):
         tc = self.tc

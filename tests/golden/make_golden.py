@@ -394,6 +394,188 @@ def gen_metrics(port=29790):
     print(res)
 
 
+def gen_checkpoint(port=29795):
+    """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
+    reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
+    training 2 more steps and record that trajectory: a loader for this format must resume exactly there."""
+    import shutil
+
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    import internlm.data.build_dataloader as bdl
+    from internlm.checkpoint.components import save_model_checkpoint, save_optimizer_checkpoint
+    from internlm.core.context import ParallelMode
+    from internlm.core.context import global_context as gpc
+    from internlm.core.trainer import TrainState
+    from internlm.data.tokenized.dummy_dataset import RandomDataset
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.losses import FlashGPTLMLoss
+    from internlm.model.metrics import AccPerplex
+    from internlm.train import get_scheduler_hooks, initialize_isp_communicator, initialize_model, initialize_optimizer, load_new_batch
+    from internlm.utils.common import get_current_device
+    from internlm.utils.storage_manager import init_storage_manager
+
+    from oracle.model import formula_init
+
+    kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
+    bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
+    cfg = tiny_config("torch.bfloat16", **kw)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    torch.set_num_threads(8)
+    model = initialize_model()
+    with torch.no_grad():
+        for name, p in model.model.named_parameters():
+            p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+    criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
+    train_dl, dataset_types = bdl.build_train_loader_with_data_type()
+    train_state = TrainState(gpc.config, train_dl.batch_sampler)
+    isp = initialize_isp_communicator(model)
+    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, isp)
+    metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
+                        dataset_types=dataset_types)
+    trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
+                                                          lr_scheduler=lr_scheduler, beta2_scheduler=beta2_scheduler,
+                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
+    trainer.train()
+    train_iter = iter(train_dl)
+    folder = os.path.join(HERE, "ckpt_ref")
+    shutil.rmtree(folder, ignore_errors=True)
+    os.makedirs(folder)
+    init_storage_manager(True, None, False)
+    # get_model_topology (checkpoint/utils.py:50-69) imports flash_attn's VocabParallelEmbedding only to isinstance-test the
+    # modules (none is one): give it a stand-in class, harness only
+    import types
+
+    fa = types.ModuleType("flash_attn"); fam = types.ModuleType("flash_attn.modules"); fae = types.ModuleType("flash_attn.modules.embedding")
+    fae.VocabParallelEmbedding = type("VocabParallelEmbedding", (), {})
+    sys.modules.setdefault("flash_attn", fa); sys.modules.setdefault("flash_attn.modules", fam); sys.modules.setdefault("flash_attn.modules.embedding", fae)
+    rec = {"config": kw, "num_samples": NUM_SAMPLES, "saved_after_step": 2, "steps": []}
+    for step in range(4):
+        batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
+        trainer.zero_grad()
+        if batch[0].get("type_ids", None) is not None:
+            metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
+        _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        lr_used = optimizer.optim.param_groups[0]["lr"]
+        ok, norms = trainer.step()
+        rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+                             "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
+        print("ckpt", step, rec["steps"][-1], flush=True)
+        if step == 1:
+            save_model_checkpoint("local:" + folder, model)
+            save_optimizer_checkpoint(optimizer, "local:" + folder)
+            sd = model.state_dict()
+            rec["model_keys"] = [[k, str(v.dtype), list(v.shape)] for k, v in sd.items()]
+            osd = optimizer.state_dict()
+            rec["optimizer_top_keys"] = list(osd.keys())
+            rec["grad_scaler"] = {k: (float(v) if torch.is_tensor(v) else v) for k, v in osd["grad_scaler"].items()}
+            rec["base_param_groups"] = [{k: (v if not torch.is_tensor(v) else float(v)) for k, v in g.items() if k != "params"} | {"n_params": len(g["params"])}
+                                        for g in osd["base_optim_states"]["param_groups"]]
+            rec["base_state"] = {str(i): {k: ([str(t.dtype), list(t.shape)] if torch.is_tensor(t) and t.dim() else float(t)) for k, t in st.items()}
+                                 for i, st in osd["base_optim_states"]["state"].items()}
+            rec["flat_fp32_weights"] = {str(g): [str(t.dtype), list(t.shape)] for g, t in osd["flat_fp32_weights"].items()}
+            rec["zero_devide_optim_plan"] = osd["zero_devide_optim_plan"]
+            groups = optimizer._fp16_param_groups
+            groups = groups.items() if isinstance(groups, dict) else enumerate(groups)
+            rec["param_group_order"] = {str(gid): [name for p in pg for name, q in model.model.named_parameters() if q is p] for gid, pg in groups}
+    rec["files"] = sorted(os.listdir(folder))
+    with open(os.path.join(HERE, "ckpt.json"), "w") as f:
+        json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
+    print(rec["files"])
+
+
+def gen_checkpoint_load(port=29796):
+    """The other direction: the CPU oracle trains 2 steps and writes a checkpoint with internevo_amd/checkpoint.py; the REAL
+    reference loads it with load_model_checkpoint / load_optimizer_checkpoint (checkpoint/components.py:95-197,285-375) and trains
+    2 more steps.  tests/golden/ckpt_load.json = that trajectory (the oracle must reproduce it when it simply keeps training)."""
+    import shutil
+    import tempfile
+    import types
+
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    import internlm.data.build_dataloader as bdl
+    from internlm.checkpoint.components import load_model_checkpoint, load_optimizer_checkpoint
+    from internlm.core.context import ParallelMode
+    from internlm.core.context import global_context as gpc
+    from internlm.core.trainer import TrainState
+    from internlm.data.tokenized.dummy_dataset import RandomDataset
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.losses import FlashGPTLMLoss
+    from internlm.model.metrics import AccPerplex
+    from internlm.train import get_scheduler_hooks, initialize_isp_communicator, initialize_model, initialize_optimizer, load_new_batch
+    from internlm.utils.common import get_current_device
+    from internlm.utils.storage_manager import init_storage_manager
+
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
+    # 1) the oracle trains two steps and saves in the reference format
+    pcfg = tiny(kw["hidden"], kw["layers"], kw["heads"], kw["kv_heads"], kw["vocab"], kw["seq_len"], kw["micro_num"], 1e-3, kw["total_steps"])
+    ora = OracleTrainer(pcfg, torch.bfloat16)
+    oloader = iter(SyntheticLoader(kw["seq_len"], 1, kw["micro_num"], True, NUM_SAMPLES))
+    osteps = [ora.train_step(*next(oloader)) for _ in range(2)]
+    folder = tempfile.mkdtemp(prefix="ie_ckpt_")
+    st = ora.export_state()
+    C.save_checkpoint(folder, pcfg.model, st["params"], st["master"], st["exp_avg"], st["exp_avg_sq"], st["adam_step"], st["scaler"], st["lr"],
+                      dict(weight_decay=pcfg.train.weight_decay, betas=(pcfg.train.adam_beta1, pcfg.train.adam_beta2), eps=pcfg.train.adam_eps,
+                           initial_lr=pcfg.train.lr))
+    # 2) the reference loads it and keeps training
+    bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
+    cfg = tiny_config("torch.bfloat16", **kw)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    torch.set_num_threads(8)
+    model = initialize_model()
+    criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
+    train_dl, dataset_types = bdl.build_train_loader_with_data_type()
+    train_state = TrainState(gpc.config, train_dl.batch_sampler)
+    isp = initialize_isp_communicator(model)
+    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, isp)
+    init_storage_manager(True, None, False)
+    fa = types.ModuleType("flash_attn"); fam = types.ModuleType("flash_attn.modules"); fae = types.ModuleType("flash_attn.modules.embedding")
+    fae.VocabParallelEmbedding = type("VocabParallelEmbedding", (), {})
+    sys.modules.setdefault("flash_attn", fa); sys.modules.setdefault("flash_attn.modules", fam); sys.modules.setdefault("flash_attn.modules.embedding", fae)
+    # torch >= 2.6 defaults torch.load to weights_only=True, which rejects the reference's own optimizer files (they pickle its
+    # ParallelMode enum): allow-list it, as a maintainer running this torch would have to (harness only)
+    from internlm.core.context.process_group_initializer import ParallelMode as _PM
+
+    torch.serialization.add_safe_globals([_PM])
+    load_model_checkpoint("local:" + folder, model)
+    load_optimizer_checkpoint("local:" + folder, optimizer)
+    for _ in range(2):  # scheduler / sampler state files (schedulder.pt, sampler.pt, context.pt) are not part of this slice
+        lr_scheduler.step()
+        beta2_scheduler.step()
+    metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
+                        dataset_types=dataset_types)
+    trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
+                                                          lr_scheduler=lr_scheduler, beta2_scheduler=beta2_scheduler,
+                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
+    trainer.train()
+    train_iter = iter(train_dl)
+    rec = {"config": kw, "num_samples": NUM_SAMPLES, "oracle_steps_before_save": osteps, "reference_steps_after_load": []}
+    for step in range(4):
+        batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
+        if step < 2:
+            continue  # consumed by the run that wrote the checkpoint
+        trainer.zero_grad()
+        if batch[0].get("type_ids", None) is not None:
+            metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
+        _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        lr_used = optimizer.optim.param_groups[0]["lr"]
+        ok, norms = trainer.step()
+        rec["reference_steps_after_load"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+                                                  "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
+        print("ckpt-load", step, rec["reference_steps_after_load"][-1], flush=True)
+    shutil.rmtree(folder, ignore_errors=True)
+    with open(os.path.join(HERE, "ckpt_load.json"), "w") as f:
+        json.dump(rec, f, indent=1, default=str)
+
+
 RUNS = {
     # tag: (dtype, cfg)
     "pin_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
@@ -482,6 +664,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--data":
         gen_data()
         sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-load":
+        gen_checkpoint_load()
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt":
+        gen_checkpoint()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--metrics":
         gen_metrics()
         sys.exit(0)
@@ -489,7 +677,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--metrics"):
+    for mode in ("--ops", "--data", "--metrics", "--ckpt", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])
