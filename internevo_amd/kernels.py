@@ -24,11 +24,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_EMPTY_ANCHOR = {}
+
+
 def _p(t):
     if t is None:
         return ctypes.c_void_p(0)
     if not t.is_cuda:
         raise ValueError("internevo_amd kernels need HIP device tensors (no CPU fallback)")
+    if t.numel() == 0:
+        # torch hands out a NULL data pointer for empty tensors; the C ABI wants non-NULL pointers whatever the extent, so an
+        # empty tensor is represented by a small live allocation of its device (never dereferenced: the extent is zero)
+        a = _EMPTY_ANCHOR.get(t.device)
+        if a is None:
+            a = _EMPTY_ANCHOR[t.device] = torch.zeros(64, dtype=torch.uint8, device=t.device)
+        return ctypes.c_void_p(a.data_ptr())
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -337,6 +347,10 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False, varia
         accumulate = False
     if out.shape != (M, N) or out.stride(1) != 1:
         raise ValueError("gemm: bad output")
+    if K == 0 or M == 0 or N == 0:  # empty contraction: the product is zero
+        if not accumulate:
+            out.zero_()
+        return out
     prof = GEMM_PROFILER
     if prof is not None:
         prof.begin()

@@ -453,3 +453,52 @@ def test_flash_bwd_dkdv_head_split_and_trailing_tokens(dev, split):
     close(dk[:200], kv32.grad[:, 0], 2e-2, 3e-2, f"dk split {split}")
     close(dv[:200], kv32.grad[:, 1], 2e-2, 3e-2, f"dv split {split}")
     assert bool((dkv[200:] == 7.0).all()), "rows of tokens outside every sequence must not be written"
+
+
+# ---------------------------------------------------------------------------------------------- edge cases of the C ABI
+def test_empty_inputs_are_no_ops(dev):
+    """Zero rows / zero tokens / zero-sized products: every entry point returns success without launching (the reference's torch
+    ops accept empty tensors too)."""
+    k = K()
+    e = lambda *s, dt=torch.bfloat16: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+    w = torch.ones(64, dtype=torch.bfloat16, device=dev)
+    y, rstd = k.rmsnorm_fwd(e(0, 64), w, 1e-5)
+    assert y.shape == (0, 64) and rstd.numel() == 0
+    assert k.swiglu_fwd(e(0, 128), e(0, 128)).shape == (0, 128)
+    assert k.gemm(e(0, 64), e(16, 64)).shape == (0, 16)
+    C0 = torch.full((8, 16), 3.0, dtype=torch.bfloat16, device=dev)
+    assert bool((k.gemm(e(8, 0), e(16, 0), out=C0.clone(), accumulate=True) == 3.0).all()), "K = 0 with accumulate leaves C alone"
+    assert k.sumsq(e(0)).item() == 0.0
+    cu = torch.zeros(1, dtype=torch.int32, device=dev)
+    out, lse = k.flash_attn_fwd(e(0, 4, 64), e(0, 2, 64), e(0, 2, 64), cu, 0, None, True)
+    assert out.shape == (0, 4, 64)
+    loss_rows, lse2, mean, cnt = k.ce_fwd(e(0, 32), torch.empty(0, dtype=torch.int64, device=dev))
+    assert loss_rows.numel() == 0
+    k.embedding_fwd(e(10, 64), torch.empty(0, dtype=torch.int64, device=dev), e(0, 64))
+
+
+def test_bad_arguments_raise_not_crash(dev):
+    """Error convention of the boundary (include/internevo_hip.h): a negative code + ie_last_error(), surfaced as InternEvoHipError
+    -- never a device fault -- for unsupported head dims, misaligned views, mismatched contractions."""
+    from internevo_amd._lib import InternEvoHipError
+
+    k = K()
+    e = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+    cu = torch.tensor([0, 16], dtype=torch.int32, device=dev)
+    with pytest.raises(InternEvoHipError):
+        k.flash_attn_fwd(e(16, 2, 32), e(16, 2, 32), e(16, 2, 32), cu, 16, None, True)  # head dim 32
+    with pytest.raises(ValueError):
+        k.gemm(e(8, 64), e(8, 32))  # contraction mismatch
+    with pytest.raises(InternEvoHipError):
+        k.gemm(e(8, 72)[:, 4:68], e(8, 64))  # A view starts 8 bytes off a 16-byte boundary
+    with pytest.raises(InternEvoHipError):
+        k.gemm(e(64, 64), e(64, 64), variant=99)
+    with pytest.raises(ValueError):
+        k.rmsnorm_fwd(torch.zeros(4, 64), torch.ones(64), 1e-5)  # host tensors: no CPU fallback
+
+
+def test_flash_attention_many_short_and_one_long_sequence(dev):
+    """Packed batch with sequences of length 1, lengths that are not multiples of any tile, and one sequence longer than all the
+    others together (max_seqlen >> mean): varlen indexing, early exits of empty tiles, the longest-job-first dispatch."""
+    _attn_case(dev, [1, 1, 63, 2, 65, 1, 700, 3, 129, 1], 8, 2, 128, True, 90)
+    _attn_case(dev, [5, 1000, 7], 4, 4, 64, True, 91)
