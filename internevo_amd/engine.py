@@ -491,14 +491,14 @@ class InternLM2Engine:
         from ._lib import IeStepState
 
         ck = C.load_checkpoint(folder, self.mc)
+        if ck["master"] is not None and self.world != 1:  # refuse before touching anything
+            raise NotImplementedError("optimizer state is read in the single-rank layout (ZeRO world 1) in this round")
         self.drain()
         for n, t in ck["params"].items():
             self.p[n].copy_(t.to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return
-        if self.world != 1:
-            raise NotImplementedError("optimizer state is read in the single-rank layout (ZeRO world 1) in this round")
         for views, key in ((self._named_shard_views(self.master), "master"), (self._named_shard_views(self.exp_avg), "exp_avg"),
                            (self._named_shard_views(self.exp_avg_sq), "exp_avg_sq")):
             for n, v in views.items():
