@@ -502,3 +502,46 @@ def test_flash_attention_many_short_and_one_long_sequence(dev):
     others together (max_seqlen >> mean): varlen indexing, early exits of empty tiles, the longest-job-first dispatch."""
     _attn_case(dev, [1, 1, 63, 2, 65, 1, 700, 3, 129, 1], 8, 2, 128, True, 90)
     _attn_case(dev, [5, 1000, 7], 4, 4, 64, True, 91)
+
+
+@pytest.mark.timeout(600)
+def test_flash_attention_seq32768_properties(dev):
+    """BASELINE.json configs[3] (7B_isp_sft: seq 32768, SP = 8): the per-rank attention problem after the Ulysses exchange is
+    32768 tokens x 4 q heads x 1 kv head.  Too large for a dense oracle, so size-independent properties:
+      * V == 1  =>  every output element is exactly 1 (rows of P sum to one), dV column sums equal dO sums;
+      * causality: the first 4096 rows equal the result on the truncated sequence (prefix property), bit for bit;
+      * the last 256 query rows against a blocked fp32 reference (S = q_blk K^T is only 256 x 32768);
+      * backward: dQ / dK / dV of the truncated problem equal the corresponding slices when dO is zero behind token 4096."""
+    k = K()
+    T, hq, hkv, d = 32768, 4, 1, 128
+    q = bf(torch.randn(T, hq, d, generator=g(100)) * 0.5).to(dev)
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(101)) * 0.5).to(dev)
+    cu = torch.tensor([0, T], dtype=torch.int32, device=dev)
+    out, lse = k.flash_attn_fwd(q, kv[:, 0], kv[:, 1], cu, T, None, True)
+    # prefix property
+    P = 4096
+    cu_p = torch.tensor([0, P], dtype=torch.int32, device=dev)
+    out_p, lse_p = k.flash_attn_fwd(q[:P].contiguous(), kv[:P, 0], kv[:P, 1], cu_p, P, None, True)
+    assert torch.equal(out[:P], out_p) and torch.equal(lse[:, :P], lse_p)
+    # V == 1
+    kv1 = kv.clone()
+    kv1[:, 1] = 1.0
+    out1, _ = k.flash_attn_fwd(q, kv1[:, 0], kv1[:, 1], cu, T, None, True)
+    assert float((out1.float() - 1.0).abs().max()) <= 8e-3
+    # last 256 rows vs blocked fp32 reference
+    qb = q[-256:].float()                                   # [256, hq, d]
+    kf, vf = kv[:, 0, 0].float(), kv[:, 1, 0].float()       # [T, d]
+    s = torch.einsum("qhd,td->hqt", qb, kf) / math.sqrt(d)
+    rows = torch.arange(T - 256, T, device=dev)[:, None]
+    s = s.masked_fill(torch.arange(T, device=dev)[None, :] > rows, float("-inf"))
+    ref = torch.einsum("hqt,td->qhd", torch.softmax(s, -1), vf)
+    close(out[-256:], ref.cpu(), 1.6e-2, 1e-2, "last 256 rows at T = 32768")
+    # backward prefix property
+    do = torch.zeros(T, hq, d, dtype=torch.bfloat16, device=dev)
+    do[:P] = bf(torch.randn(P, hq, d, generator=g(102))).to(dev)
+    dq, dk, dv = k.flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], out, lse, cu, T, None, True)
+    dq_p, dk_p, dv_p = k.flash_attn_bwd(do[:P].contiguous(), q[:P].contiguous(), kv[:P, 0], kv[:P, 1], out_p, lse_p, cu_p, P, None, True)
+    assert torch.equal(dq[:P], dq_p) and float(dq[P:].float().abs().max()) == 0.0
+    close(dk[:P], dk_p.cpu(), 1e-2, 1e-2, "dK prefix (the head split of the long problem may differ: fp32 partial order)")
+    close(dv[:P], dv_p.cpu(), 1e-2, 1e-2, "dV prefix")
+    assert float(dk[P:].float().abs().max()) == 0.0 and float(dv[P:].float().abs().max()) == 0.0
