@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
+    ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
+                                                                  "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
+    ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
                                                        "must divide --gpus; data parallel size = gpus / sp")
     args = ap.parse_args()
@@ -109,6 +112,9 @@ def main():
     cfg = internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else tiny(seq_len=min(args.seq_len, 256))
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
     cfg.train.sp_size = args.sp
+    cfg.model.checkpoint = args.checkpoint
+    if args.micro_num:
+        cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024)
     if world > 1:
@@ -153,10 +159,11 @@ def main():
     total_tps = tokens_step / sec_step
     tgs = total_tps / world
     # reference metric (train/pipeline.py:500-556 + utils/common.py:208-238)
-    ref_flops_tok = (3 * ((8 + mc.mlp_ratio * 1.5 * 4) * mc.hidden_size**2 + 4 * tc.seq_len * mc.hidden_size) * mc.num_layers
+    fac = 4 if mc.checkpoint_layers else 3  # get_megatron_flops counts the recomputed forward (utils/common.py:224-226)
+    ref_flops_tok = (fac * ((8 + mc.mlp_ratio * 1.5 * 4) * mc.hidden_size**2 + 4 * tc.seq_len * mc.hidden_size) * mc.num_layers
                      + 6 * mc.hidden_size * mc.vocab_size)
     out = {
-        "metric": "tokens_per_second (TGS x n_gpus), InternLM2-7B bf16 seq4096 training step" if args.config == "7B_internlm2" else "tokens_per_second (tiny plumbing config)",
+        "metric": f"tokens_per_second (TGS x n_gpus), InternLM2-7B bf16 seq{tc.seq_len} training step" if args.config == "7B_internlm2" else "tokens_per_second (tiny plumbing config)",
         "value": total_tps,
         "unit": "tokens/s",
         "n_gpus": world,
