@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="7B_internlm2", choices=["7B_internlm2", "tiny"])
+    ap.add_argument("--config", default="7B_internlm2", choices=["7B_internlm2", "7B_llama2", "tiny"])
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -92,7 +92,7 @@ def main():
     args = ap.parse_args()
 
     from internevo_amd import kernels as K
-    from internevo_amd.config import internlm2_7b, tiny
+    from internevo_amd.config import internlm2_7b, llama2_7b, tiny
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
 
@@ -109,7 +109,8 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
-    cfg = internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else tiny(seq_len=min(args.seq_len, 256))
+    cfg = (internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else llama2_7b(args.seq_len) if args.config == "7B_llama2"
+           else tiny(seq_len=min(args.seq_len, 256)))
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
     cfg.train.sp_size = args.sp
     cfg.model.checkpoint = args.checkpoint
@@ -163,7 +164,9 @@ def main():
     ref_flops_tok = (fac * ((8 + mc.mlp_ratio * 1.5 * 4) * mc.hidden_size**2 + 4 * tc.seq_len * mc.hidden_size) * mc.num_layers
                      + 6 * mc.hidden_size * mc.vocab_size)
     out = {
-        "metric": f"tokens_per_second (TGS x n_gpus), InternLM2-7B bf16 seq{tc.seq_len} training step" if args.config == "7B_internlm2" else "tokens_per_second (tiny plumbing config)",
+        "metric": (f"tokens_per_second (TGS x n_gpus), InternLM2-7B bf16 seq{tc.seq_len} training step" if args.config == "7B_internlm2"
+                   else f"tokens_per_second (TGS x n_gpus), LLaMA2-7B (configs/7B_llama2.py) bf16 seq{tc.seq_len} training step" if args.config == "7B_llama2"
+                   else "tokens_per_second (tiny plumbing config)"),
         "value": total_tps,
         "unit": "tokens/s",
         "n_gpus": world,
@@ -176,7 +179,9 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (reference RandomDataset/PackedDatasetWithCut shape, fixed_random_dataset_seqlen=True), random-init weights",
         "config": {"workload": f"configs/7B_internlm2.py (BASELINE.json configs[1]): InternLM2-7B, seq_len {tc.seq_len}, micro_bsz {tc.micro_bsz} x micro_num {tc.micro_num} per GPU, "
-                               f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2" else "tiny InternLM2 (hidden 512, 2 layers)",
+                               f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2"
+                               else "configs/7B_llama2.py (BASELINE.json configs[2]'s model, tensor size 1 as shipped): LLaMA2-7B, vocab 32000" if args.config == "7B_llama2"
+                               else "tiny InternLM2 (hidden 512, 2 layers)",
                    "tokens_per_step": tokens_step, "parallelism": f"dp{world // args.sp}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,

@@ -36,9 +36,11 @@ _PM_MODULE = "internlm.core.context.process_group_initializer"
 def state_dict_order(model_cfg):
     """Parameter names in the reference's module order (PackedFlashLlama1D.state_dict())."""
     names = ["tok_embeddings.weight"]
+    llama = getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2"  # modeling_llama.py: wq, wk, wv instead of wqkv
     for l in range(model_cfg.num_layers):
         p = f"layers.{l}."
-        names += [p + "attention.wqkv.weight", p + "attention.wo.weight", p + "attention_norm.weight", p + "ffn_norm.weight",
+        names += ([p + "attention.wq.weight", p + "attention.wk.weight", p + "attention.wv.weight"] if llama else [p + "attention.wqkv.weight"])
+        names += [p + "attention.wo.weight", p + "attention_norm.weight", p + "ffn_norm.weight",
                   p + "feed_forward.w1.weight", p + "feed_forward.w2.weight", p + "feed_forward.w3.weight"]
     return names + ["norm.weight", "output.weight"]
 

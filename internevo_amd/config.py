@@ -23,6 +23,7 @@ class ModelConfig:
     mlp_ratio: float = 3.5
     layer_norm_epsilon: float = 1e-5
     rope_base: int = 10000
+    model_type: str = "INTERNLM2_PUBLIC"  # or "LLAMA2" (modeling_llama.py): separate wq / wk / wv instead of the GQA-interleaved wqkv
     adapt_hf: bool = True           # builder default (modeling_internlm2.py:1071); False = even/odd de-interleave before rotary (:425-427)
     multiple_of: int = 256          # modules/mlp.py:52
     checkpoint: float = 0.0         # fraction of layers under activation checkpointing (launch.py:295-303; True -> 1, False -> 0)
@@ -123,8 +124,9 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
             raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {tensor.get('mode', 'mtp')!r} (only 'isp' sequence parallelism)")
         sp_size = int(tensor["size"])
         # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
-    if cfg.get("model_type", "INTERNLM2_PUBLIC") not in ("INTERNLM2_PUBLIC",):
-        raise NotImplementedError(f"{_UNSUPPORTED}: model_type {cfg.get('model_type')}")
+    model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
+    if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2"):
+        raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")
     if m.get("num_experts", 1) > 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: MoE")
     ck = m.get("checkpoint", False)
@@ -139,7 +141,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], num_layers=m["num_layers"],
         num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
-        adapt_hf=m.get("adapt_hf", True), checkpoint=ck,
+        # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
+        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]
@@ -170,9 +173,15 @@ def internlm2_7b(seq_len=4096) -> PathConfig:
     return PathConfig(ModelConfig(), TrainConfig(seq_len=seq_len))
 
 
-def tiny(hidden=512, layers=2, heads=8, kv_heads=2, vocab=1024, seq_len=256, micro_num=2, lr=1e-3, total_steps=5) -> PathConfig:
+def llama2_7b(seq_len=4096) -> PathConfig:
+    """configs/7B_llama2.py (BASELINE.json configs[2]'s model; the shipped file has tensor size 1): LLAMA2, vocab 32000, GQA 32/8."""
+    return PathConfig(ModelConfig(vocab_size=32000, model_type="LLAMA2", adapt_hf=False), TrainConfig(seq_len=seq_len))
+
+
+def tiny(hidden=512, layers=2, heads=8, kv_heads=2, vocab=1024, seq_len=256, micro_num=2, lr=1e-3, total_steps=5, model_type="INTERNLM2_PUBLIC") -> PathConfig:
     """BASELINE.json configs[0]: the CPU-runnable plumbing case (SURVEY.md section 8d "tiny config")."""
     return PathConfig(
-        ModelConfig(vocab_size=vocab, hidden_size=hidden, num_layers=layers, num_attention_heads=heads, num_kv_attention_heads=kv_heads),
+        ModelConfig(vocab_size=vocab, hidden_size=hidden, num_layers=layers, num_attention_heads=heads, num_kv_attention_heads=kv_heads,
+                    model_type=model_type, adapt_hf=model_type != "LLAMA2"),
         TrainConfig(seq_len=seq_len, micro_bsz=1, micro_num=micro_num, total_steps=total_steps, lr=lr, fixed_random_dataset_seqlen=True),
     )

@@ -104,8 +104,7 @@ class InternLM2Engine:
         """modeling_internlm2.py:646-672 + :890-893,:955-961: normal(0.02); wo / w2 scaled by 1/sqrt(2*(layer+1)); norms = 1."""
         mc = self.mc
         if init_fn is not None:
-            for n, s in self.layout.params.items():
-                self.p[n].copy_(init_fn(n, s.shape).to(self.dev, BF16))
+            self.load_named_parameters({n: init_fn(n, shape) for n, shape in self.reference_param_shapes().items()}, sync_master=False)
             return
         gen = torch.Generator(device=self.dev).manual_seed(seed + self.rank * 0)  # same weights on every DP rank
         for n, s in self.layout.params.items():
@@ -442,9 +441,10 @@ class InternLM2Engine:
 
     def drain(self):
         """Order the current stream behind everything the last step() left running (call before touching eng.params directly)."""
-        for b in range(len(self._bucket_ready)):
+        for b in range(len(getattr(self, "_bucket_ready", ()))):  # (also called while the constructor is still loading the weights)
             self._wait_bucket(b)
-        self._wait_optimizer()
+        if getattr(self, "_opt_done", None) is not None:
+            self._wait_optimizer()
         self.comm.wait_all_gathers()
 
     def read_state(self):
@@ -456,9 +456,65 @@ class InternLM2Engine:
         return st
 
     # ------------------------------------------------------------------------------------------ utilities
+    # LLAMA2 (modeling_llama.py:126-148) keeps wq / wk / wv as separate parameters; the kernels work on one projection in
+    # InternLM2's layout [kv group][q_per_kv q heads, k, v][head_dim] (same product, rows permuted), so the engine stores that and
+    # converts at the naming boundary (named_parameters, load_named_parameters, checkpoints).
+    def _is_llama(self):
+        return getattr(self.mc, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2"
+
+    def _split_wqkv(self, t):
+        mc = self.mc
+        v = t.reshape(mc.num_kv_attention_heads, mc.q_per_kv + 2, mc.head_dim, t.shape[-1])
+        qpk = mc.q_per_kv
+        return (v[:, :qpk].reshape(-1, t.shape[-1]), v[:, qpk].reshape(-1, t.shape[-1]), v[:, qpk + 1].reshape(-1, t.shape[-1]))
+
+    def _fuse_wqkv(self, wq, wk, wv):
+        mc = self.mc
+        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
+        return torch.cat([wq.reshape(hkv, qpk, d, -1), wk.reshape(hkv, 1, d, -1), wv.reshape(hkv, 1, d, -1)], dim=1).reshape(mc.qkv_dim, -1)
+
+    def _to_reference_names(self, named):
+        """engine names -> the reference's parameter names (a copy for the LLAMA2 projections, the same tensors otherwise)."""
+        if not self._is_llama():
+            return dict(named)
+        out = {}
+        for n, t in named.items():
+            if n.endswith("attention.wqkv.weight"):
+                pre = n[: -len("wqkv.weight")]
+                out[pre + "wq.weight"], out[pre + "wk.weight"], out[pre + "wv.weight"] = self._split_wqkv(t)
+            else:
+                out[n] = t
+        return out
+
+    def _from_reference_names(self, named):
+        if not self._is_llama():
+            return dict(named)
+        out = {n: t for n, t in named.items() if not n.endswith(("attention.wq.weight", "attention.wk.weight", "attention.wv.weight"))}
+        for l in range(self.mc.num_layers):
+            pre = f"layers.{l}.attention."
+            if pre + "wq.weight" in named:
+                out[pre + "wqkv.weight"] = self._fuse_wqkv(named[pre + "wq.weight"], named[pre + "wk.weight"], named[pre + "wv.weight"])
+        return out
+
+    def reference_param_shapes(self):
+        shapes = {n: s.shape for n, s in self.layout.params.items()}
+        if self._is_llama():
+            mc, out = self.mc, {}
+            for n, shp in shapes.items():
+                if n.endswith("attention.wqkv.weight"):
+                    pre = n[: -len("wqkv.weight")]
+                    out[pre + "wq.weight"] = (mc.num_attention_heads * mc.head_dim, shp[1])
+                    out[pre + "wk.weight"] = (mc.num_kv_attention_heads * mc.head_dim, shp[1])
+                    out[pre + "wv.weight"] = (mc.num_kv_attention_heads * mc.head_dim, shp[1])
+                else:
+                    out[n] = shp
+            return out
+        return shapes
+
     def named_parameters(self):
+        """(reference name, bf16 tensor) pairs -- views of the flat buffer, except LLAMA2's wq / wk / wv (copies)."""
         self.drain()
-        return self.p.items()
+        return self._to_reference_names(self.p).items()
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def _named_shard_views(self, flat_local):
@@ -479,7 +535,7 @@ class InternLM2Engine:
             raise NotImplementedError("checkpoints are written in the single-rank layout (tp = pp = 1, ZeRO world 1) in this round")
         st = self.read_state()  # drains the optimizer stream
         tc = self.tc
-        cpu = lambda d: {n: t.detach().to("cpu") for n, t in d.items()}  # noqa: E731
+        cpu = lambda d: {n: t.detach().to("cpu") for n, t in self._to_reference_names(d).items()}  # noqa: E731
         C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
                           cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step,
                           dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step), self.lr_sched.lr(),
@@ -494,15 +550,16 @@ class InternLM2Engine:
         if ck["master"] is not None and self.world != 1:  # refuse before touching anything
             raise NotImplementedError("optimizer state is read in the single-rank layout (ZeRO world 1) in this round")
         self.drain()
-        for n, t in ck["params"].items():
+        for n, t in self._from_reference_names(ck["params"]).items():
             self.p[n].copy_(t.to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return
         for views, key in ((self._named_shard_views(self.master), "master"), (self._named_shard_views(self.exp_avg), "exp_avg"),
                            (self._named_shard_views(self.exp_avg_sq), "exp_avg_sq")):
+            src = self._from_reference_names(ck[key])
             for n, v in views.items():
-                v.copy_(ck[key][n].to(self.dev))
+                v.copy_(src[n].to(self.dev))
         st = K.step_state_read(self.state)
         st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
         st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0
@@ -511,8 +568,9 @@ class InternLM2Engine:
         self.beta2_sched.set_successful_steps(ck["adam_step"])
         self.step_count = ck["adam_step"]
 
-    def load_named_parameters(self, named):
+    def load_named_parameters(self, named, sync_master=True):
         self.drain()
-        for n, t in named.items():
+        for n, t in self._from_reference_names(named).items():
             self.p[n].copy_(t.to(self.dev, BF16))
-        self.sync_master_from_params()
+        if sync_master:
+            self.sync_master_from_params()

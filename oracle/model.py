@@ -40,7 +40,12 @@ def param_shapes(mc):
     out = {"tok_embeddings.weight": (v, h)}
     for l in range(mc.num_layers):
         p = f"layers.{l}."
-        out[p + "attention.wqkv.weight"] = (mc.qkv_dim, h)
+        if getattr(mc, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2":  # modeling_llama.py:126-148: three separate projections
+            out[p + "attention.wq.weight"] = (mc.num_attention_heads * mc.head_dim, h)
+            out[p + "attention.wk.weight"] = (mc.num_kv_attention_heads * mc.head_dim, h)
+            out[p + "attention.wv.weight"] = (mc.num_kv_attention_heads * mc.head_dim, h)
+        else:
+            out[p + "attention.wqkv.weight"] = (mc.qkv_dim, h)
         out[p + "attention.wo.weight"] = (h, h)
         out[p + "feed_forward.w1.weight"] = (f, h)
         out[p + "feed_forward.w3.weight"] = (f, h)
@@ -72,7 +77,15 @@ def forward_logits(params, mc, input_ids, indexes=None, cu_seqlens=None):
         pre = f"layers.{l}."
         residual = h
         x = O.rms_norm(residual.to(p[pre + "attention_norm.weight"].dtype), p[pre + "attention_norm.weight"], mc.layer_norm_epsilon)
-        qkv = F.linear(x, p[pre + "attention.wqkv.weight"])
+        if getattr(mc, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2":
+            # modeling_llama.py:412-426: q, k, v projected separately, heads contiguous; q head j attends kv head j // q_per_kv.
+            # Arranged as InternLM2's [kv group][q_per_kv q heads, k, v] the rest of the path is shared.
+            qh = F.linear(x, p[pre + "attention.wq.weight"]).reshape(S, hkv, qpk, d)
+            kh = F.linear(x, p[pre + "attention.wk.weight"]).reshape(S, hkv, 1, d)
+            vh = F.linear(x, p[pre + "attention.wv.weight"]).reshape(S, hkv, 1, d)
+            qkv = torch.cat([qh, kh, vh], dim=2).reshape(S, -1)
+        else:
+            qkv = F.linear(x, p[pre + "attention.wqkv.weight"])
         q, kv = O.qkv_split_rotary(qkv, cos, sin, indexes, hkv, qpk, d, interleaved=not mc.adapt_hf)
         ctx = O.attention_varlen(q, kv, cu_seqlens, causal=True)
         attn_out = F.linear(ctx.reshape(S, -1), p[pre + "attention.wo.weight"])

@@ -170,10 +170,10 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 #                     shrinks ONLY that count (host time/RAM), everything else is the unmodified pipeline.
 
 
-def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1):
+def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC"):
     return dict(
         JOB_NAME="golden",
-        model_type="INTERNLM2_PUBLIC",
+        model_type=model_type,
         ckpt=dict(enable_save_ckpt=False, auto_resume=False),
         data=dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=1, valid_micro_num=1, valid_every=0, pack_sample_into_one=False,
                   total_steps=total_steps, skip_batches="", rampup_batch_size="", min_length=0, train_folder=None, valid_folder=None,
@@ -582,6 +582,9 @@ RUNS = {
     "pin_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
     "cfg0_fp32": ("torch.float32", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
     "cfg0_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
+    # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
+    "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
+    "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
 }
 # two-process runs of the reference's ISP mode (configs/7B_isp_sft.py shape: tensor=dict(size=sp, mode="isp"), weight=dict(size=wp))
 RUNS_MP = {

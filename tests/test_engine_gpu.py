@@ -23,7 +23,8 @@ def _run(dev, gold, steps, with_oracle=True):
     from oracle.step import OracleTrainer
 
     c = gold["config"]
-    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"],
+               model_type=c.get("model_type", "INTERNLM2_PUBLIC"))
     eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
     ora = OracleTrainer(cfg, torch.bfloat16) if with_oracle else None
     loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
@@ -38,7 +39,7 @@ def _run(dev, gold, steps, with_oracle=True):
     return rows, eng, ora
 
 
-@pytest.mark.parametrize("tag", ["pin_bf16", "cfg0_bf16"])
+@pytest.mark.parametrize("tag", ["pin_bf16", "cfg0_bf16", "llama_bf16"])  # llama_bf16: model_type LLAMA2 (BASELINE configs[2]'s family)
 def test_engine_matches_reference_trajectory(dev, tag):
     gold = json.load(open(os.path.join(G, f"train_{tag}.json")))
     steps = len(gold["steps"])

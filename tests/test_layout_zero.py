@@ -191,3 +191,16 @@ def test_ulysses_exchange_gloo_world4():
     for p in procs:
         p.join(30)
     assert res == [(0, True), (1, True), (2, True), (3, True)], res
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference tree is only mounted in the build container")
+def test_shipped_reference_configs_map():
+    """The reference's own config files for the covered model families load through load_reference_config unchanged."""
+    from internevo_amd.config import load_reference_config
+
+    a = load_reference_config("/root/reference/configs/7B_internlm2.py", seq_len=4096)
+    assert (a.model.model_type, a.model.vocab_size, a.model.num_kv_attention_heads, a.train.micro_num, a.model.adapt_hf) == ("INTERNLM2_PUBLIC", 92544, 8, 4, True)
+    b = load_reference_config("/root/reference/configs/7B_llama2.py")
+    assert (b.model.model_type, b.model.vocab_size, b.model.num_kv_attention_heads, b.model.adapt_hf, b.train.sp_size) == ("LLAMA2", 32000, 8, False, 1)
+    c = load_reference_config("/root/reference/configs/7B_isp_sft.py")
+    assert c.train.sp_size == 2
