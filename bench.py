@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
                                                                   "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
     ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Megatron 'mtp') group size, parallel.tensor=dict(size=tp, mode='mtp'); "
+                                                       "must divide --gpus; data parallel size = gpus / tp")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
                                                        "must divide --gpus; data parallel size = gpus / sp")
     args = ap.parse_args()
@@ -113,13 +115,14 @@ def main():
            else tiny(seq_len=min(args.seq_len, 256)))
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
     cfg.train.sp_size = args.sp
+    cfg.train.tp_size = args.tp
     cfg.model.checkpoint = args.checkpoint
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024)
     if world > 1:
-        eng.comm.broadcast_params(eng.params)
+        eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()
     loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, 1_000_000 if args.config != "tiny" else 4000,
                                   data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
@@ -155,7 +158,7 @@ def main():
     st = eng.read_state()
     loss_val = float(loss)
 
-    tokens_step = tc.packed_length * tc.micro_num * world // args.sp
+    tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp)
     sec_step = dt / args.steps
     total_tps = tokens_step / sec_step
     tgs = total_tps / world
@@ -182,7 +185,7 @@ def main():
                                f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2"
                                else "configs/7B_llama2.py (BASELINE.json configs[2]'s model, tensor size 1 as shipped): LLaMA2-7B, vocab 32000" if args.config == "7B_llama2"
                                else "tiny InternLM2 (hidden 512, 2 layers)",
-                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // args.sp}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "")},
+                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,

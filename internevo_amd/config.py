@@ -28,13 +28,16 @@ class ModelConfig:
     multiple_of: int = 256          # modules/mlp.py:52
     checkpoint: float = 0.0         # fraction of layers under activation checkpointing (launch.py:295-303; True -> 1, False -> 0)
     dtype: str = "torch.bfloat16"
+    # explicit per-rank sizes of a tensor-parallel shard (engine-internal: ModelConfig.tp_shard); None = derived from the above
+    head_dim_override: Optional[int] = None
+    ffn_dim_override: Optional[int] = None
     # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
     init_std: float = 0.02
     use_scaled_init: bool = True
 
     @property
     def head_dim(self):
-        return self.hidden_size // self.num_attention_heads
+        return self.head_dim_override or self.hidden_size // self.num_attention_heads
 
     @property
     def q_per_kv(self):
@@ -46,6 +49,8 @@ class ModelConfig:
 
     @property
     def ffn_dim(self):
+        if self.ffn_dim_override:
+            return self.ffn_dim_override
         f = int(self.hidden_size * self.mlp_ratio)
         return self.multiple_of * ((f + self.multiple_of - 1) // self.multiple_of)
 
@@ -54,6 +59,16 @@ class ModelConfig:
         """modeling_internlm2.py:857-861,910: layer lid is checkpointed iff lid < num_layers * checkpoint_fraction."""
         lim = self.num_layers * float(self.checkpoint)
         return sum(1 for lid in range(self.num_layers) if lid < lim)
+
+    def tp_shard(self, tp):
+        """The model one rank of a tensor-parallel group of size tp holds (Megatron "mtp" split, model/ops/linear.py:205-337):
+        1/tp of the attention heads (whole kv groups) and 1/tp of the FFN width; hidden size, vocabulary and norms are whole."""
+        if tp == 1:
+            return self
+        if self.num_kv_attention_heads % tp or self.ffn_dim % tp:
+            raise ValueError(f"tensor parallel size {tp} must divide the kv head count and the FFN width")
+        return dataclasses.replace(self, num_attention_heads=self.num_attention_heads // tp, num_kv_attention_heads=self.num_kv_attention_heads // tp,
+                                   head_dim_override=self.head_dim, ffn_dim_override=self.ffn_dim // tp)
 
     def num_params(self):
         h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size
@@ -91,6 +106,7 @@ class TrainConfig:
     label_smoothing: float = 0.0
     zero1_size: int = -1
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
+    tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
 
     @property
     def packed_length(self):
@@ -118,11 +134,15 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallel size must be 1")
     tensor = par.get("tensor", {})
     tensor = tensor if isinstance(tensor, dict) else dict(size=tensor, mode="mtp")  # launch.py normalises an int the same way
-    sp_size = 1
+    sp_size = tp_size = 1
     if tensor.get("size", 1) != 1:
-        if tensor.get("mode", "mtp") != "isp":
-            raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {tensor.get('mode', 'mtp')!r} (only 'isp' sequence parallelism)")
-        sp_size = int(tensor["size"])
+        mode = tensor.get("mode", "mtp")
+        if mode == "isp":
+            sp_size = int(tensor["size"])
+        elif mode == "mtp":
+            tp_size = int(tensor["size"])
+        else:
+            raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'isp')")
         # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
     model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
     if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2"):
@@ -156,7 +176,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size,
+        sp_size=sp_size, tp_size=tp_size,
     )
     return PathConfig(model, train)
 

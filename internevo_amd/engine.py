@@ -32,6 +32,7 @@ from .config import PathConfig
 from .layout import FlatLayout
 from .schedule import Beta2Scheduler, CosineWarmupLR
 from .seqpar import SeqParallel
+from .tensorpar import TensorParallel
 from .zero import ZeroComm
 
 BF16 = torch.bfloat16
@@ -39,7 +40,7 @@ BF16 = torch.bfloat16
 
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
-                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1):
+                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None):
         """sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step)."""
@@ -51,12 +52,24 @@ class InternLM2Engine:
         if mc.head_dim not in (64, 128):
             raise NotImplementedError("head dim must be 64 or 128")
         K._L()  # fail loudly now if libinternevo_hip.so is missing
-        self.layout = FlatLayout(mc, world_size)
+        tp_size = int(tc.tp_size if tp_size is None else tp_size)  # default: the config's parallel.tensor size (mode "mtp")
+        sp_size = int(tc.sp_size if sp_size is None else sp_size)  # default: the config's parallel.tensor size (mode "isp")
+        if tp_size > 1 and sp_size > 1:
+            raise NotImplementedError("tensor parallelism and sequence parallelism are alternatives (parallel.tensor has ONE mode)")
+        self.tpar = TensorParallel(tp_size, rank, world_size)
+        self.tp = tp_size
+        self.lmc = mc.tp_shard(tp_size)   # what this rank holds / computes of every layer: 1/tp of the heads and of the FFN width
+        if tp_size > 1:
+            # data parallelism and ZeRO-1 run over the ranks that hold the same shard
+            process_group, world_size, rank = self.tpar.dp_group, self.tpar.dp_world, self.tpar.dp_rank
+            self.world, self.rank = world_size, rank
+        self.layout = FlatLayout(self.lmc, world_size)
         L = self.layout
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives)
-        sp_size = int(tc.sp_size if sp_size is None else sp_size)  # default: the config's parallel.tensor size (mode "isp")
         self.sp = sp_size
         self.seqpar = SeqParallel(sp_size, rank, world_size)
+        if tp_size > 1:  # every rank of a tensor group reads the same batches
+            self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
         self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
         if sp_size > 1 and (mc.num_kv_attention_heads % sp_size or tc.packed_length % sp_size):
             raise ValueError("sequence parallel size must divide the kv head count and the packed length")
@@ -135,7 +148,7 @@ class InternLM2Engine:
         self._rot_len = seqlen
 
     def _alloc(self, T):
-        mc, dev = self.mc, self.dev
+        mc, dev = self.lmc, self.dev   # per-rank sizes (1/tp of the heads and of the FFN width under tensor parallelism)
         h, F, V, L = mc.hidden_size, mc.ffn_dim, mc.vocab_size, mc.num_layers
         hq, hkv, d = mc.num_attention_heads, mc.num_kv_attention_heads, mc.head_dim
 
@@ -190,7 +203,7 @@ class InternLM2Engine:
     # ------------------------------------------------------------------------------------------ forward / backward
     def _w13(self, l):
         s = self.layout.params[f"layers.{l}.feed_forward.w1.weight"]
-        F, h = self.mc.ffn_dim, self.mc.hidden_size
+        F, h = self.lmc.ffn_dim, self.lmc.hidden_size
         return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
 
     def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
@@ -199,7 +212,7 @@ class InternLM2Engine:
         here (fused with the attention norm) and the w2 output is returned.
         recompute=True: the backward-time replay of a checkpointed layer from its saved input a_x[l]; same kernels on the
         same values (bit-identical activations), minus the w2 GEMM whose output backward does not need."""
-        mc = self.mc
+        mc = self.lmc
         F, eps = mc.ffn_dim, mc.layer_norm_epsilon
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, s = self.p, self.slot[l]
@@ -220,13 +233,15 @@ class InternLM2Engine:
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
         K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
+        self.tpar.all_reduce_sum(attn_out)   # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism)
         K.add_rmsnorm_fwd(attn_out, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[s], self.a_n2[s], self.a_rstd2[s])
         w13, _ = self._w13(l)
         K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
         if recompute:
             return None
         K.swiglu_fwd(self.a_w13[s][:, :F], self.a_w13[s][:, F:], self.t_act)
-        return K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+        K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
+        return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
 
     def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
         mc = self.mc
@@ -258,7 +273,7 @@ class InternLM2Engine:
             self.t_loss[0] = self.t_loss_red[0] / self.t_loss_red[1]
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False):
-        mc, tc = self.mc, self.tc
+        mc, tc = self.lmc, self.tc
         L, F = mc.num_layers, mc.ffn_dim
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, g = self.p, self.g
@@ -291,11 +306,12 @@ class InternLM2Engine:
             K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], acc)
             d_n2 = spare[0]
             K.linear_dgrad(self.t_dw13, w13, d_n2)
+            self.tpar.all_reduce_sum(d_n2)   # input gradient of the column-parallel w1 | w3
             K.linear_wgrad(self.t_dw13, self.a_n2[sl], gw13, acc)
             d_r2 = spare[1]
             K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc, ws, d_r2)
             # attention
-            d_ctx = d_n2  # reuse
+            d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
             K.linear_wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], acc)
             if self.sp == 1:
@@ -310,8 +326,9 @@ class InternLM2Engine:
                 dq_l = self.seqpar.scatter_seq_gather_heads(self.t_dq, 1, self.t_xq, self.t_ql)
                 dkv_l = self.seqpar.scatter_seq_gather_heads(self.t_dkv, 2, self.t_xkv, self.t_kvl)
             K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
-            d_n1 = d_ctx
+            d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
+            self.tpar.all_reduce_sum(d_n1)   # input gradient of the column-parallel wqkv
             K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], acc)
             d_x = d_out  # the old d_out buffer is free now
             K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc, ws, d_x)
@@ -375,7 +392,16 @@ class InternLM2Engine:
         if self.isp_rule > 1:
             self._apply_isp_grad_rule(shards)
         K.sumsq(shards, self.sumsq, False, self.sumsq_ws)
+        if self.tp > 1:
+            # compute_norm (solver/optimizer/utils.py:265-378) counts a parameter that is replicated over the tensor group (norm
+            # weights; here also embedding and head) on ONE rank only: every rank of the group subtracts (1 - 1/tp) of its
+            # (identical) contribution, then the squared norm is summed over the data-parallel AND the tensor group
+            rep = self._replicated_grad_slices(shards)
+            if rep:
+                rs = K.sumsq(rep)
+                self.sumsq.sub_(rs * (1.0 - 1.0 / self.tp))
         self.comm.all_reduce_sum(self.sumsq)
+        self.tpar.all_reduce_sum(self.sumsq)
         K.step_control(self.state, self.sumsq, self.scaler_cfg)
         lr = self.lr_sched.lr()
         beta2 = self.beta2_sched.beta2()
@@ -400,6 +426,20 @@ class InternLM2Engine:
         self.lr_sched.step()
         self.beta2_sched.step()
         self.step_count += 1
+
+    def _replicated_grad_slices(self, shards):
+        """Views of this rank's ZeRO gradient shards that belong to parameters held whole by every rank of the tensor group."""
+        L = self.layout
+        out = []
+        for spec in L.params.values():
+            if spec.kind not in ("embed", "norm", "head"):
+                continue
+            b = L.buckets[spec.bucket]
+            s0, n0 = b.shard(self.rank, self.world)
+            a, z = max(s0, spec.offset), min(s0 + n0, spec.offset + spec.numel)
+            if a < z:
+                out.append(self.grads[a:z])
+        return out
 
     def _apply_isp_grad_rule(self, shards):
         """The gradient averaging of the reference's ISP mode, as its code reads (sp = size of the sequence group):
@@ -464,14 +504,15 @@ class InternLM2Engine:
 
     def _split_wqkv(self, t):
         mc = self.mc
-        v = t.reshape(mc.num_kv_attention_heads, mc.q_per_kv + 2, mc.head_dim, t.shape[-1])
         qpk = mc.q_per_kv
+        v = t.reshape(-1, qpk + 2, mc.head_dim, t.shape[-1])  # [kv groups (all, or this rank's under tensor parallelism)][q.., k, v][d][h]
         return (v[:, :qpk].reshape(-1, t.shape[-1]), v[:, qpk].reshape(-1, t.shape[-1]), v[:, qpk + 1].reshape(-1, t.shape[-1]))
 
     def _fuse_wqkv(self, wq, wk, wv):
         mc = self.mc
-        hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
-        return torch.cat([wq.reshape(hkv, qpk, d, -1), wk.reshape(hkv, 1, d, -1), wv.reshape(hkv, 1, d, -1)], dim=1).reshape(mc.qkv_dim, -1)
+        qpk, d = mc.q_per_kv, mc.head_dim
+        hkv = wk.shape[0] // d
+        return torch.cat([wq.reshape(hkv, qpk, d, -1), wk.reshape(hkv, 1, d, -1), wv.reshape(hkv, 1, d, -1)], dim=1).reshape(hkv * (qpk + 2) * d, -1)
 
     def _to_reference_names(self, named):
         """engine names -> the reference's parameter names (a copy for the LLAMA2 projections, the same tensors otherwise)."""
@@ -497,7 +538,8 @@ class InternLM2Engine:
         return out
 
     def reference_param_shapes(self):
-        shapes = {n: s.shape for n, s in self.layout.params.items()}
+        """Shapes of the FULL (un-sharded) parameters under the reference's names."""
+        shapes = {n: s.shape for n, s in FlatLayout(self.mc, 1).params.items()}
         if self._is_llama():
             mc, out = self.mc, {}
             for n, shp in shapes.items():
@@ -569,8 +611,9 @@ class InternLM2Engine:
         self.step_count = ck["adam_step"]
 
     def load_named_parameters(self, named, sync_master=True):
+        """named: the reference's FULL parameter tensors by name; under tensor parallelism every rank keeps its shard."""
         self.drain()
         for n, t in self._from_reference_names(named).items():
-            self.p[n].copy_(t.to(self.dev, BF16))
+            self.p[n].copy_(self.tpar.shard(self.layout.params[n].kind, t).to(self.dev, BF16))
         if sync_master:
             self.sync_master_from_params()

@@ -87,7 +87,7 @@ class FlatLayout:
             p = f"layers.{l}."
             add(cur, p + "attention_norm.weight", (h,), "norm", l)
             add(cur, p + "attention.wqkv.weight", (c.qkv_dim, h), "wqkv", l)
-            add(cur, p + "attention.wo.weight", (h, h), "wo", l)
+            add(cur, p + "attention.wo.weight", (h, c.num_attention_heads * c.head_dim), "wo", l)  # = (h, h) unless tensor-parallel
             add(cur, p + "ffn_norm.weight", (h,), "norm", l)
             add(cur, p + "feed_forward.w1.weight", (f, h), "w1", l)   # w1 and w3 adjacent: one [2F, h] GEMM operand
             add(cur, p + "feed_forward.w3.weight", (f, h), "w3", l)

@@ -1,0 +1,74 @@
+"""Megatron-style tensor parallelism of the transformer layers ("mtp", parallel.tensor = dict(size=tp, mode="mtp")).
+
+Reference behaviour being matched (model/ops/linear.py:205-337, model/utils.py:228-346, modeling_internlm2.py:86-189,
+modules/mlp.py:100-140): wqkv / w1 / w3 are column-parallel (each rank owns the output rows of its 1/tp of the kv groups / FFN
+units), wo / w2 are row-parallel (each rank owns the matching input columns); the row-parallel outputs are partial sums over
+the tensor group and are all-reduced (4 x 33.5 MB per layer and micro-batch: two in forward, two in
+backward for the input gradients of the column-parallel layers).  Norm weights are replicated.
+
+Every rank of a tensor group reads the same micro-batches; data parallelism (and the ZeRO-1 sharding) runs over the ranks that
+hold the same shard (rank % tp).  MI355X note: the embedding and the output head are kept whole on every rank here (the
+reference splits them along hidden / vocabulary): 288 GB make the 1.5 GB of duplicated weights irrelevant, the logits of a
+micro-batch are computed redundantly (3.1 of ~1800 GFLOP per rank and micro-batch at tp = 2) and the vocabulary-parallel
+cross-entropy with its three extra all-reduces per micro-batch disappears; losses and gradients are the same numbers.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TensorParallel:
+    def __init__(self, tp_size, rank, world_size):
+        if world_size % tp_size != 0:
+            raise ValueError(f"world size {world_size} is not a multiple of the tensor-parallel size {tp_size}")
+        self.tp = tp_size
+        self.tp_rank = rank % tp_size
+        self.dp_rank = rank // tp_size
+        self.dp_world = world_size // tp_size
+        self.group = None      # the tensor group this rank belongs to
+        self.dp_group = None   # ranks holding the same shard (gradient averaging / ZeRO-1)
+        self.backend = None
+        if tp_size > 1:
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed must be initialised for tensor parallelism")
+            for g in range(world_size // tp_size):  # consecutive ranks form a tensor group (parallel_context.py: innermost dimension)
+                ranks = list(range(g * tp_size, (g + 1) * tp_size))
+                grp = dist.new_group(ranks)
+                if rank in ranks:
+                    self.group = grp
+            for t in range(tp_size):
+                ranks = list(range(t, world_size, tp_size))
+                grp = dist.new_group(ranks)
+                if rank in ranks:
+                    self.dp_group = grp
+            self.backend = dist.get_backend(self.group)
+
+    def all_reduce_sum(self, t):
+        """In-place sum over the tensor group (the `g` operator of a row-parallel output / a column-parallel input gradient)."""
+        if self.tp == 1:
+            return t
+        if self.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo test path: through the host
+            c = t.detach().to("cpu", copy=True)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c)
+        return t
+
+    # ---- shard <-> full parameter ------------------------------------------------------------------------------------
+    def shard(self, kind, full):
+        """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
+        if self.tp == 1 or kind in ("embed", "norm", "head"):
+            return full
+        r, tp = self.tp_rank, self.tp
+        if kind in ("wqkv", "w1", "w3"):      # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups)
+            n = full.shape[0] // tp
+            return full[r * n : (r + 1) * n]
+        n = full.shape[1] // tp               # row-parallel (wo, w2): input columns
+        return full[:, r * n : (r + 1) * n]
+
+    @staticmethod
+    def unshard(kind, parts):
+        """Inverse of shard() given every rank's part in rank order."""
+        if kind in ("embed", "norm", "head") or len(parts) == 1:
+            return parts[0]
+        return torch.cat(parts, dim=0 if kind in ("wqkv", "w1", "w3") else 1)

@@ -103,6 +103,8 @@ class ZeroComm:
     def broadcast_params(self, params_flat, src=0):
         """sync_model_param at init (internlm/utils/parallel.py:71-107): every DP rank starts from rank 0's weights."""
         if self.active:
+            if self.group is not None:
+                src = dist.get_global_rank(self.group, src)  # `src` counts inside the data-parallel group
             if self.backend == "nccl":
                 dist.broadcast(params_flat, src=src, group=self.group)
             else:

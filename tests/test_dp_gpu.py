@@ -242,3 +242,73 @@ def test_sequence_parallel_step_equals_single_rank_step(dev):
         worst = max(worst, float((a - b).abs().max()))
     print("max |param diff| sp2 vs 1 rank:", worst)
     assert worst <= 6e-3
+
+
+def _tp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        dev = torch.device("cuda:0")
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, tp_size=2)
+        loader = iter(SyntheticLoader(128, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm)))
+        shards = {n: (eng.layout.params[n].kind, p.float().cpu().numpy()) for n, p in eng.p.items()}
+        q.put((rank, out, shards))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_tensor_parallel_step_equals_single_rank_step(dev):
+    """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
+    same micro-batches: same loss, same grad norm (replicated parameters counted once), and the two ranks' parameter shards
+    concatenate to the single-rank parameters (bf16 summation-order noise only)."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.tensorpar import TensorParallel
+    from oracle.model import formula_init
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_cfg(2), dev, init_fn=formula_init)
+    loader = iter(SyntheticLoader(128, 1, 2, False, 4000))
+    ref = []
+    for _ in range(3):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm)))
+    (r0, o0, s0), (r1, o1, s1) = res
+    for k in range(3):
+        print(f"step {k}: tp2 loss {o0[k][0]:.5f} gn {o0[k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        assert o0[k] == o1[k], "both ranks of a tensor group compute the same loss and the same global grad norm"
+        assert abs(o0[k][0] - ref[k][0]) <= 1e-3 * abs(ref[k][0])
+        assert abs(o0[k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    worst = 0.0
+    for n, p in eng.p.items():
+        kind = s0[n][0]
+        full = TensorParallel.unshard(kind, [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
+        if kind in ("embed", "norm", "head"):
+            assert (s0[n][1] == s1[n][1]).all(), f"replicated parameter {n} diverged between the ranks of the tensor group"
+        worst = max(worst, float((full - p.float().cpu()).abs().max()))
+    print("max |param diff| tp2 vs 1 rank:", worst)
+    assert worst <= 6e-3

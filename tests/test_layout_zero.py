@@ -70,8 +70,19 @@ def test_reference_config_files_map(tmp_path):
     assert from_reference_dict(isp).train.sp_size == 2
     mtp = copy.deepcopy(g)
     mtp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="mtp"), pipeline=dict(size=1))
+    assert from_reference_dict(mtp).train.tp_size == 2 and from_reference_dict(mtp).train.sp_size == 1
+    msp = copy.deepcopy(g)
+    msp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="msp"), pipeline=dict(size=1))
     with pytest.raises(NotImplementedError):
-        from_reference_dict(mtp)
+        from_reference_dict(msp)
+    from internevo_amd.config import ModelConfig
+    from internevo_amd.layout import FlatLayout
+
+    half = ModelConfig().tp_shard(2)
+    assert (half.num_attention_heads, half.num_kv_attention_heads, half.head_dim, half.ffn_dim, half.qkv_dim) == (16, 4, 128, 7168, 3072)
+    L = FlatLayout(half, 4)
+    assert L.params["layers.0.attention.wo.weight"].shape == (4096, 2048) and L.params["layers.0.feed_forward.w2.weight"].shape == (4096, 7168)
+    assert L.params["layers.0.attention.wqkv.weight"].shape == (3072, 4096) and L.params["tok_embeddings.weight"].shape == (92544, 4096)
 
 
 def _worker(rank, world, port, q):
