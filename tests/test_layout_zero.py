@@ -215,3 +215,44 @@ def test_shipped_reference_configs_map():
     assert (b.model.model_type, b.model.vocab_size, b.model.num_kv_attention_heads, b.model.adapt_hf, b.train.sp_size) == ("LLAMA2", 32000, 8, False, 1)
     c = load_reference_config("/root/reference/configs/7B_isp_sft.py")
     assert c.train.sp_size == 2
+
+
+def _tp_group_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.tensorpar import TensorParallel
+
+        tp = TensorParallel(2, rank, world)  # ranks (0,1), (2,3) are tensor groups; (0,2), (1,3) hold the same shard
+        t = torch.tensor([float(rank + 1)])
+        tp.all_reduce_sum(t)
+        ok = float(t) == (3.0 if rank < 2 else 7.0)
+        d = torch.tensor([float(rank + 1)])
+        dist.all_reduce(d, group=tp.dp_group)
+        ok = ok and float(d) == (4.0 if rank % 2 == 0 else 6.0) and (tp.tp_rank, tp.dp_rank, tp.dp_world) == (rank % 2, rank // 2, 2)
+        full = {"wqkv": torch.arange(24.0).reshape(6, 4), "wo": torch.arange(16.0).reshape(4, 4), "w2": torch.arange(32.0).reshape(4, 8),
+                "norm": torch.arange(4.0), "embed": torch.arange(12.0).reshape(3, 4)}
+        for kind, w in full.items():
+            mine = tp.shard(kind, w)
+            parts = [TensorParallel(1, 0, 1).shard(kind, w)] if kind in ("norm", "embed") else None
+            other = type("O", (), {"tp": 2, "tp_rank": 1 - tp.tp_rank})()
+            theirs = TensorParallel.shard(other, kind, w)
+            both = [mine, theirs] if tp.tp_rank == 0 else [theirs, mine]
+            ok = ok and torch.equal(TensorParallel.unshard(kind, parts or both), w)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_tensor_parallel_groups_and_shards_gloo_world4():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_group_worker, args=(r, 4, 29867, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(4))
+    for p in procs:
+        p.join(30)
+    assert res == [(0, True), (1, True), (2, True), (3, True)], res
