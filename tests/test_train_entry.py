@@ -1,0 +1,76 @@
+"""train.py (the reference's entry point on the HIP engine) and the per-step log of internevo_amd/trainlog.py."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+CFG = """
+model_type = "INTERNLM2_PUBLIC"
+data = dict(seq_len=128, micro_num=2, micro_bsz=1, total_steps={steps}, train_folder=None, fixed_random_dataset_seqlen=True)
+grad_scaler = dict(fp16=dict(initial_scale=2**16, min_scale=1, growth_interval=1000), growth_factor=2, backoff_factor=0.5, max_scale=2**24, hysteresis=2)
+hybrid_zero_optimizer = dict(overlap_sync_grad=True, overlap_sync_param=False, reduce_bucket_size=512 * 1024 * 1024, clip_grad_norm=1.0)
+loss = dict(label_smoothing=0)
+adam = dict(lr=1e-3, adam_beta1=0.9, adam_beta2=0.95, adam_beta2_c=0, adam_eps=1e-8, weight_decay=0.01)
+lr_scheduler = dict(total_steps={steps}, init_steps=0, warmup_ratio=0.01, eta_min=1e-5, last_epoch=-1)
+model = dict(checkpoint=False, num_attention_heads=4, vocab_size=512, hidden_size=256, num_layers=2, no_bias=True, mlp_ratio=3.5,
+             dtype="torch.bfloat16", layer_norm_epsilon=1e-5, num_kv_attention_heads=2, use_flash_attn=True)
+parallel = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=1), weight=dict(size=1))
+ckpt = dict(enable_save_ckpt={save}, save_ckpt_folder="local:{folder}", checkpoint_every=2, load_ckpt_info=dict(path="local:{load}", content=("all",), ckpt_type="internevo"))
+"""
+
+
+def test_megatron_flops_and_tgs_windows_match_reference_golden():
+    """get_megatron_flops against the value the REAL reference function returned (tests/golden/ops.json) and the TGS windows against a
+    hand-rolled replay of pipeline.py:511-545."""
+    import json
+
+    from internevo_amd.trainlog import TgsStatistic, get_megatron_flops, line
+
+    ops = json.load(open(os.path.join(G, "ops.json")))
+    got = get_megatron_flops(1.0, checkpoint=False, seq_len=4096, hidden_size=4096, num_layers=32, vocab_size=92544, global_batch_size=4,
+                             global_world_size=1, mlp_ratio=3.5)
+    assert abs(got - ops["flops_7b_internlm2_4096"]) <= 1e-9 * got
+    got = get_megatron_flops(2.0, checkpoint=True, seq_len=2048, hidden_size=4096, num_layers=32, vocab_size=103168, global_batch_size=16,
+                             global_world_size=8, mlp_ratio=8 / 3)
+    assert abs(got - ops["flops_ckpt"]) <= 1e-9 * got
+    t = TgsStatistic()
+    toks, times = [16384.0] * 12, [0.5 + 0.01 * i for i in range(12)]
+    for i, (a, b) in enumerate(zip(toks, times)):
+        w = t.update(a, b)
+        assert w["tgs/last_tgs_1"] == round(a / b, 2)
+        assert w["tgs/tgs_all"] == round(sum(toks[: i + 1]) / sum(times[: i + 1]), 2)
+        assert w["tgs/tgs_avg"] == round(sum(round(x / y, 2) for x, y in zip(toks[: i + 1], times[: i + 1])) / (i + 1), 2)
+    assert w["tgs/last_tgs_10"] == round(sum(toks[:10]) / sum(times[:10]), 2) and w["tgs/last_tgs_50"] == 0
+    assert line({"a": 1, "b": {"x": 2.0}}) == "a=1 b={'x': 2.0} "
+
+
+@pytest.mark.gpu
+def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
+    """python train.py --config <an InternEvo config file> --launcher torch: 4 steps with a checkpoint every 2, then a second
+    run resumed from the step-2 checkpoint must reproduce steps 2 and 3 exactly (same loss, grad norm, metric)."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    folder = str(tmp_path / "ckpts")
+    cfg1 = tmp_path / "cfg1.py"
+    cfg1.write_text(CFG.format(steps=4, save=True, folder=folder, load=str(tmp_path / "none")))
+    lines = []
+    run1 = train.main(["--config", str(cfg1), "--launcher", "torch"], log=lines.append)
+    assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"]
+    keys = list(run1[0])
+    assert keys[:13] == ["tflops", "step", "loss", "tgs (tokens/gpu/second)", "tgs/last_tgs_1", "tgs/tgs_all", "tgs/tgs_avg", "tgs/tgs_SMA",
+                         "tgs/last_tgs_10", "tgs/last_tgs_50", "lr", "loss_scale", "grad_norm"], "the reference's key order (pipeline.py:556-570)"
+    assert keys[13:23] == ["micro_num", "num_consumed_tokens", "inf_nan_skip_batches", "num_samples_in_batch", "largest_length", "largest_batch",
+                           "smallest_batch", "adam_beta2", "fwd_bwd_time", "acc"]
+    assert run1[3]["num_consumed_tokens"] == 4 * 2 * 128 and run1[0]["loss"] > run1[3]["loss"]
+    assert any(l.startswith("tflops=") for l in lines)
+    cfg2 = tmp_path / "cfg2.py"
+    cfg2.write_text(CFG.format(steps=4, save=False, folder=folder, load=os.path.join(folder, "2")))
+    run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run2] == [2, 3]
+    for a, b in zip(run1[2:], run2):
+        assert (a["loss"], a["grad_norm"], a["acc"], a["perplexity"], a["lr"]) == (b["loss"], b["grad_norm"], b["acc"], b["perplexity"], b["lr"])

@@ -1,0 +1,122 @@
+"""Training entry of the MI355X path, same invocation as the reference's train.py:
+
+    python train.py --config configs/7B_internlm2.py --launcher torch
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 train.py --config ... --launcher torch
+
+It reads an unmodified InternEvo config file (internevo_amd/config.py), runs the hot loop of the reference's train.py:196-306 on the
+HIP engine -- load batch, forward / backward over the micro-batches, optimizer step, metric, one log line per step with the
+reference's keys (internevo_amd/trainlog.py), checkpoints in the reference's format every `ckpt.checkpoint_every` steps -- and
+resumes from `ckpt.load_ckpt_info` / `ckpt.load_ckpt_folder`.  Out of scope here (control plane): real tokenized
+datasets (`data.train_folder` must be None = the reference's RandomDataset), validation, tensorboard, alerts, remote storage.
+"""
+import argparse
+import os
+import runpy
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True, help="path to an InternEvo config file")
+    ap.add_argument("--launcher", type=str, default="torch", choices=["torch"], help="torch (torchrun env vars; a single process without them)")
+    ap.add_argument("--port", type=int, default=8888)  # accepted for command-line compatibility (the rendezvous comes from the environment)
+    ap.add_argument("--seed", type=int, default=1024)
+    ap.add_argument("--profiling", action="store_true")
+    return ap.parse_args(argv)
+
+
+def _local(path):
+    if path is None:
+        return None
+    if ":" in path:
+        backend, p = path.split(":", 1)
+        if backend != "local":
+            raise NotImplementedError(f"checkpoint backend {backend!r}: only local: folders")
+        return p
+    return path
+
+
+def main(argv=None, log=print):
+    args = parse_args(argv)
+    from internevo_amd.config import from_reference_dict
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from internevo_amd.trainlog import TgsStatistic, get_megatron_flops, line, step_infos
+
+    raw = {k: v for k, v in runpy.run_path(args.config).items() if not k.startswith("__")}
+    cfg = from_reference_dict(raw)
+    tc, mc = cfg.train, cfg.model
+    if raw.get("data", {}).get("train_folder", None) is not None:
+        raise NotImplementedError("only the reference's synthetic RandomDataset (data.train_folder = None) is wired in")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL
+    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
+    ck = raw.get("ckpt", {}) or {}
+    load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
+    first_step = 0
+    if load_folder and os.path.isdir(load_folder):
+        eng.load_checkpoint(load_folder)
+        first_step = eng.step_count
+        log(f"load_ckpt_folder: {load_folder} (resuming at step {first_step})")
+    elif world > 1:
+        eng.comm.broadcast_params(eng.params)  # sync_model_param (utils/parallel.py:71-107)
+        eng.sync_master_from_params()
+    dp_world = eng.seqpar.data_world
+    metric = AccPerplex(dev, eng.tpar.dp_group, ["en", "cn", "code"], dp_world_size=dp_world)  # the dummy dataset's type list
+    eng.attach_metric(metric)
+    loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
+                                  data_rank=eng.seqpar.data_rank, data_world_size=dp_world))
+    for _ in range(first_step):
+        next(loader)  # the sampler position is part of the run state
+    flops = lambda t: get_megatron_flops(t, checkpoint=bool(mc.checkpoint_layers), seq_len=tc.seq_len, hidden_size=mc.hidden_size,  # noqa: E731
+                                         num_layers=mc.num_layers, vocab_size=mc.vocab_size, global_batch_size=tc.micro_bsz * tc.micro_num * dp_world,
+                                         global_world_size=world, mlp_ratio=mc.mlp_ratio)
+    tgs = TgsStatistic()
+    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    every = int(ck.get("checkpoint_every", 0) or 0)
+    consumed, skipped_seen, out = 0, 0, []
+    for step in range(first_step, tc.total_steps):
+        start = time.time()
+        batch, labels = next(loader)
+        t0 = time.time()
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()                       # the reference syncs here too (loss.item(), the norm and the scaler)
+        fwd_bwd_time = time.time() - t0
+        success = st.skip == 0
+        if success:
+            consumed += labels.nelement() * dp_world
+        else:
+            log(f"Warning: skip parameter update at step {step}.")
+        m = metric.get_metric()
+        tk_per_gpu = round(labels.nelement() * dp_world / world, 4)
+        infos = step_infos(tflops=flops(time.time() - start), step=step, loss=float(loss), tk_per_gpu=tk_per_gpu, start_time=start, tgs=tgs,
+                           lr=eng.lr_sched.lr(),  # read after the scheduler stepped, like optimizer.param_groups[0]["lr"] (pipeline.py:494)
+                           loss_scale=st.loss_scale, grad_norm={"0_default": st.grad_norm}, batch=batch, labels=labels,
+                           num_consumed_tokens=consumed, inf_nan_skip_batches=st.skipped_total, adam_beta2=eng.beta2_sched.beta2(),
+                           fwd_bwd_time=fwd_bwd_time, metric=m)
+        out.append(infos)
+        if rank % 8 == 0 and success:
+            log(line(infos))
+        if save_folder and every and (step + 1) % every == 0 and world == 1:
+            eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))
+            log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
+    if world > 1:
+        torch.distributed.barrier()
+    return out
+
+
+if __name__ == "__main__":
+    main()
