@@ -262,6 +262,8 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
                       const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
                       int d, float softmax_scale, int causal, void* stream);
 
+/* Tuning hook: tile rows per group of the LDS-DMA GEMMs' XCD-aware tile order (0 = default 4). */
+int ie_tune_gemm_group(int tile_rows_per_group);
 /* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
 /* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    constexpr int GM = 4;
+    const int GM = (accumulate >> 8) ? (accumulate >> 8) : 4;  // tile rows per group (bits 8.. of the flag word: ie_tune_gemm_group)
+    accumulate &= 1;
     const int width = GM * tiles_n;
     const int group = id / width;
     const int first_m = group * GM;
@@ -479,12 +480,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 }  // namespace
 
 // called from gemm_bf16.hip's dispatcher; arguments already validated there (K % 64 == 0, N % 8 == 0, ...)
+static int g_gemm_group = 0;  // 0 = the kernel's default (4 tile rows per group)
+extern "C" int ie_tune_gemm_group(int gm) {
+    if (gm < 0 || gm > 64) return IE_ERR_INVALID;
+    g_gemm_group = gm;
+    return IE_OK;
+}
+
 extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
                                   int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
     bf16_t* c = (bf16_t*)C;
+    accumulate = (accumulate ? 1 : 0) | (g_gemm_group << 8);
 #define IE_SHAPE(BM_, BN_, WM_, WN_, SP_)                                                                                            \
     do {                                                                                                                          \
         const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (int)((N + BN_ - 1) / BN_);                                       \
