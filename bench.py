@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
+    ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B only: ie_tune_gemm_tail_split mode (library default when omitted)")
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
                                                                   "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
     ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
@@ -99,6 +100,8 @@ def main():
     from internevo_amd.engine import InternLM2Engine
 
     K.LINEAR_FWD_VARIANT = args.fwd_variant
+    if args.gemm_tail_split is not None:
+        assert K._L().ie_tune_gemm_tail_split(args.gemm_tail_split) == 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

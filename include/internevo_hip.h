@@ -231,7 +231,9 @@ int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_
  * 4 = 256x256 LDS-DMA, 5 = 128x128 LDS-DMA, 6 / 7 = 256x256 LDS-DMA with the DMA issue spread over 2 / 4 k-steps,
  * 8 = 128x128 LDS-DMA spread over 2 k-steps, 9 / 10 = 256x256 / 128x128 LDS-DMA with role-split load/compute
  * phases, 11 = 256x256 with one wave per SIMD (4 waves, 128x128 each), buffer-addressed LDS-DMA and fragments
- * pipelined across k-tiles (operands must each span < 4 GiB), 12 = 128x256 phased, 13 = 256x256 phased with two k-steps per phase and buffer-addressed DMA (operands < 4 GiB); all LDS-DMA variants need K % 64 == 0; -1 = automatic. */
+ * pipelined across k-tiles (operands must each span < 4 GiB), 12 = 128x256 phased, 13 = 256x256 phased with two k-steps per phase and buffer-addressed DMA (operands < 4 GiB), 14 = 128x256 likewise; all LDS-DMA
+ * variants need K % 64 == 0; -1 = automatic (which can also cut a half-empty last round of 256x256 tiles off into a second launch
+ * of 128x256 tiles, see ie_tune_gemm_tail_split). */
 int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb,
                       int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
                       void* stream);
@@ -264,6 +266,9 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
 
 /* Tuning hook: tile rows per group of the LDS-DMA GEMMs' XCD-aware tile order (0 = default 4). */
 int ie_tune_gemm_group(int tile_rows_per_group);
+/* Tuning hook: the automatic GEMM's tail split (0 = off [default: neutral inside the training step], 1 = on: remainder tiles by
+ * variant 14 when an operand is k-major, else 12; 2 / 3 = always 14 / 12). */
+int ie_tune_gemm_tail_split(int mode);
 /* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
 /* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */

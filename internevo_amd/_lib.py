@@ -94,6 +94,7 @@ SIGNATURES = {
     "ie_flash_attn_bwd": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, I64, P, P, I64, P, I, I64, I, I, I, I, F, I, P]),
     "ie_tune_flash_dq_occupancy": (I, [I]),
     "ie_tune_gemm_group": (I, [I]),
+    "ie_tune_gemm_tail_split": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
     "ie_flash_attn_bwd_workspace": (I64, [I64, I, I, I]),
     "ie_mfma_probe": (I, [P, P, P, P]),

@@ -515,6 +515,7 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 6) IE_SHAPE(128, 128, 2, 2, -1);
     else if (shape == 7) IE_SHAPE(256, 256, 2, 2, -2);
     else if (shape == 8) IE_SHAPE(128, 256, 2, 4, -1);
+    else if (shape == 10) IE_SHAPE(128, 256, 2, 4, -11);
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");

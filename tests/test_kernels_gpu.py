@@ -322,7 +322,7 @@ def test_gemm_small(dev, M, N, Kd, akm, bkm):
     close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"gemm {M}x{N}x{Kd} akm={akm} bkm={bkm}")
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_gemm_every_dma_tile_variant(dev, variant):
     """Each LDS-DMA schedule (ie_gemm_bf16_tile) on ragged M/N edges, a single k-tile, two and many k-tiles, all four operand
     layouts, a strided A view and accumulate -- the dispatcher only ever picks some of them for a given shape."""
@@ -340,6 +340,36 @@ def test_gemm_every_dma_tile_variant(dev, variant):
             Cd = C0.to(dev).clone()
             K().gemm(Ad, B.to(dev), akm, bkm, out=Cd, accumulate=True, variant=variant)
             close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, f"variant {variant} accumulate")
+
+
+@pytest.mark.parametrize("M,N", [(4096, 6144), (6144, 4096), (4096, 14336)])
+def test_gemm_tail_split_is_bit_identical(dev, M, N):
+    """With ie_tune_gemm_tail_split on, the automatic GEMM cuts a half-empty last round of 256x256 tiles off into a launch of 128x256 tiles (wqkv: cut along N for
+    fwd, along M for wgrad; w2 dgrad / wgrad: along N): same k order per element, so the result must not change by one bit, for
+    every operand layout, with and without accumulate, on strided operands."""
+    from internevo_amd._lib import load as lib
+    Kd = 256
+    try:
+        for akm, bkm in ((False, False), (False, True), (True, True)):
+            Abig = bf(torch.randn((Kd, M + 64) if akm else (M, Kd + 64), generator=g(60))).to(dev)
+            A = Abig[:, :M] if akm else Abig[:, :Kd]
+            B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(61))).to(dev)
+            C0 = bf(torch.randn(M, N, generator=g(62))).to(dev)
+            outs = {}
+            for mode in (0, 1, 2, 3):
+                assert lib().ie_tune_gemm_tail_split(mode) == 0
+                plain = K().gemm(A, B, akm, bkm)
+                acc = C0.clone()
+                K().gemm(A, B, akm, bkm, out=acc, accumulate=True)
+                outs[mode] = (plain, acc)
+            ref = (A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t())
+            close(outs[0][0], ref, 8e-3, 2e-3 * math.sqrt(Kd), "tail split off")
+            for mode in (1, 2, 3):
+                assert torch.equal(outs[mode][0], outs[0][0]), f"mode {mode} akm={akm} bkm={bkm}"
+                assert torch.equal(outs[mode][1], outs[0][1]), f"mode {mode} accumulate akm={akm} bkm={bkm}"
+    finally:
+        lib().ie_tune_gemm_tail_split(0)
+    assert lib().ie_tune_gemm_tail_split(4) != 0
 
 
 def test_gemm_accumulate_and_strided(dev):

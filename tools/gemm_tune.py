@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from internevo_amd import kernels as K  # noqa: E402
 
 ALL_VARIANTS = {4: "dma256", 5: "dma128", 6: "dma256_spread2", 7: "dma256_spread4", 8: "dma128_spread2", 9: "dma256_phased", 10: "dma128_phased",
-                11: "buf256_w4", 12: "dma128x256_phased", 13: "buf256_phased2"}
+                11: "buf256_w4", 12: "dma128x256_phased", 13: "buf256_phased2", 14: "buf128x256_phased2"}
 VARIANTS = {v: ALL_VARIANTS[v] for v in (5, 8, 9, 10, 11)}
 
 
