@@ -15,7 +15,7 @@ q = torch.randn(T, HQ, D, device=dev).to(bf)
 kv = torch.randn(T, 2, HKV, D, device=dev).to(bf)
 do = torch.randn(T, HQ, D, device=dev).to(bf)
 cu = torch.tensor([0, T], dtype=torch.int32, device=dev)
-for _ in range(3):
+for _ in range(10):
     o, lse = K.flash_attn_fwd(q, kv[:, 0], kv[:, 1], cu, T, None, True)
     K.flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], o, lse, cu, T, None, True)
 if "--gemm" in sys.argv:
