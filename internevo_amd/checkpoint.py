@@ -1,4 +1,4 @@
-"""InternEvo's on-disk checkpoint format, single model-parallel shard (tp = pp = 1, ZeRO world 1).
+"""InternEvo's on-disk checkpoint format, single model-parallel shard (tp = pp = 1), any ZeRO-1 world.
 
 Written / read so that a run can be handed over between the reference and this engine in both directions:
 
@@ -13,8 +13,11 @@ Written / read so that a run can be handed over between the reference and this e
     <folder>/gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt   zero_devide_optim_plan: [[["<i>_<shape>" ...]], [[]]]
 
 (internlm/checkpoint/components.py:199-283,377-410; solver/optimizer/hybrid_zero_optim.py:133-140,254-284,882-936.)
-The flat vectors hold the group's parameters in the ZeRO partition order of rank 0: the module-order parameter list stably
-sorted by numel, largest first (`_partition_param_list`).  `param_groups[*]["optimizer_mode"]` is the reference's ParallelMode
+The flat vectors hold the group's parameters in the ZeRO partition order: the module-order parameter list stably sorted by
+numel, largest first, each parameter handed WHOLE to the rank that holds the fewest elements so far (`_partition_param_list`);
+ZeRO world W gives W optimizer files `optimizer_tp0_pp0_zo{r}.pt` and W plan files `gpus-{W}_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt`,
+every one carrying the plan of ALL ranks.  (This engine shards each bucket into contiguous slices instead; engine.py re-cuts
+the state on the way in and out, so a checkpoint can also be loaded into a different data-parallel size.)  `param_groups[*]["optimizer_mode"]` is the reference's ParallelMode
 enum, pickled by reference: it is written through a stand-in module of the same dotted name when `internlm` is not importable
 and read through a tolerant unpickler, so neither side needs the other installed.
 
@@ -56,8 +59,29 @@ def zero_flat_order(named_shapes):
     return sorted(named_shapes, key=lambda kv: numel(kv[1]), reverse=True)
 
 
-def _plan_names(ordered):
-    return [f"{i}_" + "_".join(str(d) for d in shape) for i, (_, shape) in enumerate(ordered)]
+def zero_partition(ordered, zero_world):
+    """ordered: zero_flat_order(...) output.  -> per rank the list of indices into `ordered` (greedy: next-largest parameter to
+    the rank with the fewest elements, first such rank on ties; hybrid_zero_optim.py:254-284)."""
+    per_rank = [[] for _ in range(zero_world)]
+    numel = [0] * zero_world
+    for i, (_, shape) in enumerate(ordered):
+        k = 1
+        for d in shape:
+            k *= d
+        r = numel.index(min(numel))
+        per_rank[r].append(i)
+        numel[r] += k
+    return per_rank
+
+
+def _plan_ids(ordered, indices):
+    return [f"{i}_" + "_".join(str(d) for d in ordered[i][1]) for i in indices]
+
+
+def zero_rank_names(shapes, zero_world):
+    """Reference parameter names owned by each ZeRO rank, in flat order.  shapes: dict name -> shape in module order."""
+    ordered = zero_flat_order([(n, tuple(shp)) for n, shp in shapes.items()])
+    return [[ordered[i][0] for i in idx] for idx in zero_partition(ordered, zero_world)]
 
 
 class _RefEnumModule:
@@ -109,45 +133,66 @@ def _load(path):
     return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_pickle_shim)
 
 
-def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16):
+def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16,
+                    zero_world=1, zero_ranks=None, write_model=True, shapes=None):
     """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
-    hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr")."""
+    hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr").
+    zero_world > 1: one optimizer + plan file per rank in `zero_ranks` (default: all); the state dicts then only need the
+    parameters those ranks own (zero_rank_names).  write_model=False skips the model / topology files (the reference writes them
+    from data-parallel rank 0 only) and `params` may then be None if `shapes` (name -> shape, module order) is given."""
     os.makedirs(folder, exist_ok=True)
     order = state_dict_order(model_cfg)
-    sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
-    torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
-    torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
-    flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
+    if write_model:
+        sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
+        torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
+        torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
+    if shapes is None:
+        shapes = {n: tuple(params[n].shape) for n in order}
+    flat_order = zero_flat_order([(n, tuple(shapes[n])) for n in order])
+    partition = zero_partition(flat_order, zero_world)
+    plan = [[_plan_ids(flat_order, idx) for idx in partition], [[] for _ in range(zero_world)]]
 
-    def flat(named):
-        return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n, _ in flat_order])
-
-    plan = [[_plan_names(flat_order)], [[]]]
     with _RefEnumModule() as zero1:
         tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
                     differentiable=False, fused=True, decoupled_weight_decay=True)
-        # key order as the reference's groups carry it (train/utils.py:create_param_groups + torch.optim.AdamW defaults)
-        g_default = dict(name="default", weight_decay=hyper["weight_decay"], optimizer_mode=zero1, **tail, dtype=param_dtype,
-                         initial_lr=hyper["initial_lr"], params=[0])
-        g_fp32 = dict(name="fp32", optimizer_mode=zero1, weight_decay=hyper["weight_decay"], **tail, dtype=None,
-                      initial_lr=hyper["initial_lr"], params=[])
-        states = {
-            "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]),
-                            "_hysteresis_step": int(scaler["hysteresis_step"])},
-            "base_optim_states": {
-                "state": {0: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg), "exp_avg_sq": flat(exp_avg_sq)}},
-                "param_groups": [g_default, g_fp32],
-            },
-            "flat_fp32_weights": {0: flat(master)},
-            "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
-        }
-        torch.save(states, os.path.join(folder, "optimizer_tp0_pp0_zo0.pt"))
-    torch.save(plan, os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt"))
+        for r in (range(zero_world) if zero_ranks is None else zero_ranks):
+            names = [flat_order[i][0] for i in partition[r]]
+
+            def flat(named):
+                return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n in names])
+
+            # key order as the reference's groups carry it (train/utils.py:create_param_groups + torch.optim.AdamW defaults)
+            g_default = dict(name="default", weight_decay=hyper["weight_decay"], optimizer_mode=zero1, **tail, dtype=param_dtype,
+                             initial_lr=hyper["initial_lr"], params=[0])
+            g_fp32 = dict(name="fp32", optimizer_mode=zero1, weight_decay=hyper["weight_decay"], **tail, dtype=None,
+                          initial_lr=hyper["initial_lr"], params=[])
+            states = {
+                "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]),
+                                "_hysteresis_step": int(scaler["hysteresis_step"])},
+                "base_optim_states": {
+                    "state": {0: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg), "exp_avg_sq": flat(exp_avg_sq)}},
+                    "param_groups": [g_default, g_fp32],
+                },
+                "flat_fp32_weights": {0: flat(master)},
+                "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
+            }
+            torch.save(states, os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt"))
+            torch.save(plan, os.path.join(folder, f"gpus-{zero_world}_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt"))
 
 
-def load_checkpoint(folder, model_cfg):
-    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr).  Optimizer entries are None when
-    the folder holds model weights only."""
+def saved_zero_world(folder):
+    """Number of ZeRO-1 optimizer shards in the folder (components.py:294-306 counts them the same way); 0 = weights only."""
+    n = 0
+    for fn in os.listdir(folder):
+        if fn.startswith("optimizer_tp0_pp0_zo") and fn.endswith(".pt"):
+            n = max(n, int(fn[len("optimizer_tp0_pp0_zo"):-3]) + 1)
+    return n
+
+
+def load_checkpoint(folder, model_cfg, want=None):
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr, zero_world).  Optimizer entries are
+    None when the folder holds model weights only.  All optimizer shards in the folder are read and merged (whatever ZeRO world
+    wrote them); `want` (a set of names) limits the optimizer tensors kept in memory to those parameters."""
     order = state_dict_order(model_cfg)
     sd = torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False)
     params = {}
@@ -156,34 +201,50 @@ def load_checkpoint(folder, model_cfg):
         if key not in sd:
             raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
         params[n] = sd[key].detach()
-    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None)
-    opt_path = os.path.join(folder, "optimizer_tp0_pp0_zo0.pt")
-    if not os.path.exists(opt_path):
+    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
+    zero_world = saved_zero_world(folder)
+    if zero_world == 0:
         return out
-    st = _load(opt_path)
     flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
-    plan_path = os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt")
-    if os.path.exists(plan_path):
-        plan = _load(plan_path)
-        if plan[0][0] != _plan_names(flat_order):
-            raise ValueError("zero_devide_optim_plan of the checkpoint does not match this model's single-rank partition order")
+    partition = zero_partition(flat_order, zero_world)
+    plan_ids = [_plan_ids(flat_order, idx) for idx in partition]
+    merged = dict(master={}, exp_avg={}, exp_avg_sq={})
+    head = None
+    for r in range(zero_world):
+        opt_path = os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt")
+        if not os.path.exists(opt_path):
+            raise FileNotFoundError(f"{opt_path}: the folder holds shards up to zo{zero_world - 1} but not this one")
+        st = _load(opt_path)
+        plan_path = os.path.join(folder, f"gpus-{zero_world}_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt")
+        plan = _load(plan_path) if os.path.exists(plan_path) else st.get("zero_devide_optim_plan")
+        if plan is not None and list(plan[0]) != plan_ids:
+            raise ValueError(f"zero_devide_optim_plan of the checkpoint does not match this model's partition over {zero_world} ranks")
 
-    def unflat(vec):
-        named, o = {}, 0
-        for n, shape in flat_order:
-            k = 1
-            for d in shape:
-                k *= d
-            named[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
-            o += k
-        if o != vec.numel():
-            raise ValueError(f"flat optimizer vector holds {vec.numel()} elements, the model {o}")
-        return named
+        def unflat(vec, into):
+            o = 0
+            for i in partition[r]:
+                n, shape = flat_order[i]
+                k = 1
+                for d in shape:
+                    k *= d
+                if want is None or n in want:
+                    into[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
+                o += k
+            if o != vec.numel():
+                raise ValueError(f"flat optimizer vector of zo{r} holds {vec.numel()} elements, this model's partition {o}")
 
-    base = st["base_optim_states"]
-    s0 = base["state"][0]
-    gs = st["grad_scaler"]
-    out.update(master=unflat(st["flat_fp32_weights"][0]), exp_avg=unflat(s0["exp_avg"]), exp_avg_sq=unflat(s0["exp_avg_sq"]),
-               adam_step=int(float(s0["step"])), lr=float(base["param_groups"][0]["lr"]),
-               scaler=dict(scale=float(gs["_scale"]), growth_step=int(gs["_growth_step"]), hysteresis_step=int(gs["_hysteresis_step"])))
+        base = st["base_optim_states"]
+        s0 = base["state"][0]
+        unflat(st["flat_fp32_weights"][0], merged["master"])
+        unflat(s0["exp_avg"], merged["exp_avg"])
+        unflat(s0["exp_avg_sq"], merged["exp_avg_sq"])
+        gs = st["grad_scaler"]
+        this = dict(adam_step=int(float(s0["step"])), lr=float(base["param_groups"][0]["lr"]),
+                    scaler=dict(scale=float(gs["_scale"]), growth_step=int(gs["_growth_step"]), hysteresis_step=int(gs["_hysteresis_step"])))
+        if head is None:
+            head = this
+        elif this != head:
+            raise ValueError(f"optimizer shard zo{r} disagrees with zo0 on the step / scaler / lr: {this} vs {head}")
+        del st
+    out.update(merged, zero_world=zero_world, **head)
     return out

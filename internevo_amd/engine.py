@@ -569,39 +569,87 @@ class InternLM2Engine:
                 out[n] = flat_local[lo + (s.offset - b.start) : lo + (s.offset - b.start) + s.numel].view(s.shape)
         return out
 
+    def _engine_name(self, ref_name):
+        """the reference's parameter name -> the engine parameter that holds it (LLAMA2: wq / wk / wv live in the fused wqkv)."""
+        if self._is_llama() and ref_name.endswith(("attention.wq.weight", "attention.wk.weight", "attention.wv.weight")):
+            return ref_name[: -len("wq.weight")] + "wqkv.weight"
+        return ref_name
+
+    def _shard_pieces(self):
+        """[(name, start inside the parameter, length, offset inside this rank's fp32 state)]: what this rank's contiguous bucket
+        slices hold of every parameter (world 1: every parameter whole)."""
+        L = self.layout
+        out = []
+        for b, lo in zip(L.buckets, L.local_offsets()):
+            ss = b.size // self.world
+            s0 = b.start + self.rank * ss
+            for n in b.params:
+                spec = L.params[n]
+                a, e = max(spec.offset, s0), min(spec.offset + spec.numel, s0 + ss)
+                if a < e:
+                    out.append((n, a - spec.offset, e - a, lo + (a - s0)))
+        return out
+
+    def _checkpoint_guard(self):
+        if self.tp != 1 or self.sp != 1:
+            raise NotImplementedError("checkpoints cover tp = pp = 1 without sequence parallelism in this round (any data-parallel size)")
+
     def save_checkpoint(self, folder):
-        """InternEvo's checkpoint files (checkpoint.py; model weights + hybrid-ZeRO optimizer state), single-rank layout."""
+        """InternEvo's checkpoint files (checkpoint.py): model weights from data-parallel rank 0, one hybrid-ZeRO optimizer shard
+        + partition plan per rank, in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284).  Collective."""
         from . import checkpoint as C
 
-        if self.world != 1:
-            raise NotImplementedError("checkpoints are written in the single-rank layout (tp = pp = 1, ZeRO world 1) in this round")
+        self._checkpoint_guard()
         st = self.read_state()  # drains the optimizer stream
-        tc = self.tc
+        tc, L, W, r = self.tc, self.layout, self.world, self.rank
+        hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
+        scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
         cpu = lambda d: {n: t.detach().to("cpu") for n, t in self._to_reference_names(d).items()}  # noqa: E731
-        C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
-                          cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step,
-                          dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step), self.lr_sched.lr(),
-                          dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr))
+        if W == 1:
+            C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
+                              cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper)
+            return
+        ref_shapes = self.reference_param_shapes()
+        shapes = {n: tuple(ref_shapes[n]) for n in C.state_dict_order(self.mc)}
+        mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole)
+        need = {self._engine_name(n) for n in mine}
+        state = {}
+        for key, flat in (("master", self.master), ("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            named = {}
+            for bi, (b, lo) in enumerate(zip(L.buckets, L.local_offsets())):  # every rank walks every bucket: the gather is collective
+                full = self.comm.gather_full_bucket(flat, lo, bi)
+                for n in b.params:
+                    if n in need:
+                        spec = L.params[n]
+                        named[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape).to("cpu", copy=True)
+                del full
+            ref_named = self._to_reference_names(named)
+            state[key] = {n: ref_named[n] for n in mine}
+        C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
+                          scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes)
+        self.comm.barrier()  # the folder is complete when any rank returns
 
     def load_checkpoint(self, folder):
-        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint)."""
+        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world: the
+        whole-parameter shards are merged and re-cut into this engine's bucket slices)."""
         from . import checkpoint as C
-        from ._lib import IeStepState
 
-        ck = C.load_checkpoint(folder, self.mc)
-        if ck["master"] is not None and self.world != 1:  # refuse before touching anything
-            raise NotImplementedError("optimizer state is read in the single-rank layout (ZeRO world 1) in this round")
+        self._checkpoint_guard()
+        pieces = self._shard_pieces()
+        want = set()
+        for n in {p[0] for p in pieces}:
+            want.update(self._to_reference_names({n: self.p[n]}).keys())
+        ck = C.load_checkpoint(folder, self.mc, want=want)
         self.drain()
         for n, t in self._from_reference_names(ck["params"]).items():
             self.p[n].copy_(t.to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return
-        for views, key in ((self._named_shard_views(self.master), "master"), (self._named_shard_views(self.exp_avg), "exp_avg"),
-                           (self._named_shard_views(self.exp_avg_sq), "exp_avg_sq")):
+        for flat, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
             src = self._from_reference_names(ck[key])
-            for n, v in views.items():
-                v.copy_(src[n].to(self.dev))
+            for n, a, k, lo in pieces:
+                flat[lo : lo + k].copy_(src[n].reshape(-1)[a : a + k].to(self.dev))
         st = K.step_state_read(self.state)
         st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
         st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0

@@ -71,6 +71,27 @@ class ZeroComm:
             dist.all_gather_into_tensor(tmp, src, group=self.group)
             full.copy_(tmp)
 
+    def gather_full_bucket(self, local_flat, local_offset, bucket_index):
+        """Checkpointing only (synchronous): this rank's slice of a bucket of optimizer state -> the whole bucket on every rank.
+        Returns a device tensor on the RCCL path, a host tensor on the gloo test path."""
+        b = self.layout.buckets[bucket_index]
+        n = b.size // self.world
+        shard = local_flat[local_offset : local_offset + n]
+        if not self.active or self.world == 1:
+            return shard
+        if self.backend == "nccl":
+            full = torch.empty(b.size, dtype=shard.dtype, device=shard.device)
+            dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
+            return full
+        src = shard.detach().to("cpu", copy=True)
+        tmp = torch.empty(b.size, dtype=src.dtype)
+        dist.all_gather_into_tensor(tmp, src, group=self.group)
+        return tmp
+
+    def barrier(self):
+        if self.active and self.world > 1:
+            dist.barrier(group=self.group)
+
     def wait_gather(self, bucket_index):
         """Block the compute stream until the all-gather of this bucket's parameters (issued by the previous step) is
         done -- called by the forward right before the first kernel that reads the bucket, so the parameter exchange

@@ -394,13 +394,17 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795):
+def gen_checkpoint(port=29795, rank=0, world=1):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
-    training 2 more steps and record that trajectory: a loader for this format must resume exactly there."""
+    training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
+    world = 2 (`--ckpt-mp`, one process per rank over gloo): data parallel 2 = ZeRO-1 world 2 -> ckpt_ref_dp2/ with one optimizer
+    shard and one partition-plan file per rank (hybrid_zero_optim.py:254-284)."""
     import shutil
 
     shim_cpu_accelerator()
+    if world > 1:
+        _patch_gloo_flat_collectives()
     import internlm  # noqa: F401
     import internlm.data.build_dataloader as bdl
     from internlm.checkpoint.components import save_model_checkpoint, save_optimizer_checkpoint
@@ -420,7 +424,7 @@ def gen_checkpoint(port=29795):
     kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
-    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
     torch.set_num_threads(8)
     model = initialize_model()
@@ -439,9 +443,14 @@ def gen_checkpoint(port=29795):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref")
-    shutil.rmtree(folder, ignore_errors=True)
-    os.makedirs(folder)
+    folder = os.path.join(HERE, "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}")
+    if rank == 0:
+        shutil.rmtree(folder, ignore_errors=True)
+        os.makedirs(folder)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
     init_storage_manager(True, None, False)
     # get_model_topology (checkpoint/utils.py:50-69) imports flash_attn's VocabParallelEmbedding only to isinstance-test the
     # modules (none is one): give it a stand-in class, harness only
@@ -450,7 +459,7 @@ def gen_checkpoint(port=29795):
     fa = types.ModuleType("flash_attn"); fam = types.ModuleType("flash_attn.modules"); fae = types.ModuleType("flash_attn.modules.embedding")
     fae.VocabParallelEmbedding = type("VocabParallelEmbedding", (), {})
     sys.modules.setdefault("flash_attn", fa); sys.modules.setdefault("flash_attn.modules", fam); sys.modules.setdefault("flash_attn.modules.embedding", fae)
-    rec = {"config": kw, "num_samples": NUM_SAMPLES, "saved_after_step": 2, "steps": []}
+    rec = {"config": kw, "num_samples": NUM_SAMPLES, "saved_after_step": 2, "steps": [], "world": world}
     for step in range(4):
         batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
         trainer.zero_grad()
@@ -479,8 +488,14 @@ def gen_checkpoint(port=29795):
             groups = optimizer._fp16_param_groups
             groups = groups.items() if isinstance(groups, dict) else enumerate(groups)
             rec["param_group_order"] = {str(gid): [name for p in pg for name, q in model.model.named_parameters() if q is p] for gid, pg in groups}
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        if rank != 0:
+            return
     rec["files"] = sorted(os.listdir(folder))
-    with open(os.path.join(HERE, "ckpt.json"), "w") as f:
+    with open(os.path.join(HERE, "ckpt.json" if world == 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
 
@@ -673,6 +688,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt":
         gen_checkpoint()
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-rank":
+        gen_checkpoint(port=29797, rank=int(sys.argv[2]), world=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-mp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--metrics":
         gen_metrics()
         sys.exit(0)
@@ -680,7 +701,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--metrics", "--ckpt", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--metrics", "--ckpt", "--ckpt-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -117,6 +117,121 @@ def test_reference_resumes_from_our_checkpoint():
         assert g["loss_scale"] == w["loss_scale"] and w["ok"]
 
 
+REF2 = os.path.join(G, "ckpt_ref_dp2")
+
+
+def _cmp_optimizer_files(C, a_path, b_path):
+    ra, rb = C._load(a_path), C._load(b_path)
+    assert list(ra) == list(rb)
+    assert ra["zero_devide_optim_plan"] == rb["zero_devide_optim_plan"] and ra["grad_scaler"] == rb["grad_scaler"]
+    assert torch.equal(ra["flat_fp32_weights"][0], rb["flat_fp32_weights"][0])
+    sa, sb = ra["base_optim_states"]["state"][0], rb["base_optim_states"]["state"][0]
+    assert float(sa["step"]) == float(sb["step"]) and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    for ga, gb in zip(ra["base_optim_states"]["param_groups"], rb["base_optim_states"]["param_groups"]):
+        assert list(ga) == list(gb) and all(ga[k] == gb[k] for k in ga if k != "optimizer_mode")
+
+
+def test_two_rank_zero_partition_matches_the_reference():
+    """tests/golden/ckpt_ref_dp2/: the real reference on 2 data-parallel ranks (gloo), ZeRO-1 world 2 (make_golden.py --ckpt-mp).
+    The greedy whole-parameter partition restated in checkpoint.zero_partition must reproduce its plan, and load -> save
+    (all ranks, or one rank at a time the way the engine's ranks write) its files tensor for tensor."""
+    from internevo_amd import checkpoint as C
+
+    gold = json.load(open(os.path.join(G, "ckpt_dp2.json")))
+    cfg = _cfg()
+    assert C.saved_zero_world(REF2) == 2 and C.saved_zero_world(REF) == 1
+    ck = C.load_checkpoint(REF2, cfg.model)
+    assert ck["zero_world"] == 2 and ck["adam_step"] == 2
+    shapes = {n: tuple(ck["params"][n].shape) for n in C.state_dict_order(cfg.model)}
+    order = C.zero_flat_order(list(shapes.items()))
+    part = C.zero_partition(order, 2)
+    assert [C._plan_ids(order, idx) for idx in part] == gold["zero_devide_optim_plan"][0]
+    assert sorted(i for idx in part for i in idx) == list(range(len(order)))
+    for n, p in ck["params"].items():  # the merged shards cover every parameter; masters round to the saved bf16 weights
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), p), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as out:
+        C.save_checkpoint(out, cfg.model, ck["params"], ck["master"], ck["exp_avg"], ck["exp_avg_sq"], ck["adam_step"], ck["scaler"], ck["lr"],
+                          hyper, zero_world=2)
+        assert sorted(os.listdir(out)) == gold["files"]
+        for r in (0, 1):
+            _cmp_optimizer_files(C, os.path.join(REF2, f"optimizer_tp0_pp0_zo{r}.pt"), os.path.join(out, f"optimizer_tp0_pp0_zo{r}.pt"))
+            fn = f"gpus-2_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt"
+            assert C._load(os.path.join(REF2, fn)) == C._load(os.path.join(out, fn))
+    with tempfile.TemporaryDirectory() as out:  # rank by rank, each rank holding only the parameters it owns
+        names = C.zero_rank_names(shapes, 2)
+        for r in (1, 0):
+            own = lambda d: {n: d[n] for n in names[r]}  # noqa: E731
+            C.save_checkpoint(out, cfg.model, ck["params"] if r == 0 else None, own(ck["master"]), own(ck["exp_avg"]), own(ck["exp_avg_sq"]),
+                              ck["adam_step"], ck["scaler"], ck["lr"], hyper, zero_world=2, zero_ranks=[r], write_model=(r == 0), shapes=shapes)
+        assert sorted(os.listdir(out)) == gold["files"]
+        for r in (0, 1):
+            _cmp_optimizer_files(C, os.path.join(REF2, f"optimizer_tp0_pp0_zo{r}.pt"), os.path.join(out, f"optimizer_tp0_pp0_zo{r}.pt"))
+        a = torch.load(os.path.join(REF2, "model_tp0_pp0.pt"), weights_only=False)
+        b = torch.load(os.path.join(out, "model_tp0_pp0.pt"), weights_only=False)
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    # `want` keeps only the asked-for optimizer tensors; a missing shard or a foreign plan is refused
+    some = set(names[1][:2])
+    part_ck = C.load_checkpoint(REF2, cfg.model, want=some)
+    assert set(part_ck["master"]) == some == set(part_ck["exp_avg"])
+    import shutil
+
+    with tempfile.TemporaryDirectory() as out:
+        shutil.copytree(REF2, out, dirs_exist_ok=True)
+        os.remove(os.path.join(out, "optimizer_tp0_pp0_zo0.pt"))
+        with pytest.raises(FileNotFoundError):
+            C.load_checkpoint(out, cfg.model)
+
+
+def test_zero_partition_properties():
+    """Greedy whole-parameter partition on the 7B shapes: every parameter on exactly one rank, loads within one largest parameter
+    of each other, world 1 = the flat order itself."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import internlm2_7b
+    from internevo_amd.layout import FlatLayout
+
+    mc = internlm2_7b().model
+    shapes = {n: s.shape for n, s in FlatLayout(mc, 1).params.items()}
+    order = C.zero_flat_order([(n, shapes[n]) for n in C.state_dict_order(mc)])
+    numel = lambda shp: int(torch.Size(shp).numel())  # noqa: E731
+    assert C.zero_partition(order, 1) == [list(range(len(order)))]
+    for w in (2, 8, 64):
+        part = C.zero_partition(order, w)
+        assert sorted(i for idx in part for i in idx) == list(range(len(order)))
+        loads = [sum(numel(order[i][1]) for i in idx) for idx in part]
+        assert max(loads) - min(loads) <= numel(order[0][1])
+        assert all(idx == sorted(idx) for idx in part)  # flat order inside a rank = sorted order
+
+
+def test_oracle_resumes_from_the_two_rank_reference_checkpoint():
+    """The 2 steps the 2-rank reference trained after saving: global batch = 2 ranks x micro_num micro-batches; the oracle runs
+    them as one rank with twice the micro-batches (same averaged gradient up to summation order)."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    gold = json.load(open(os.path.join(G, "ckpt_dp2.json")))
+    cfg = _cfg()
+    c = gold["config"]
+    cfg.train.micro_num = 2 * c["micro_num"]
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(C.load_checkpoint(REF2, cfg.model))
+    loaders = [iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=r, data_world_size=2)) for r in (0, 1)]
+    for _ in range(gold["saved_after_step"]):
+        [next(l) for l in loaders]
+    for w in gold["steps"][gold["saved_after_step"]:]:
+        parts = [next(l) for l in loaders]
+        batch = {k: (sum((p[0][k] for p in parts), []) if isinstance(parts[0][0][k], list) else torch.cat([p[0][k] for p in parts]))
+                 for k in parts[0][0]}
+        labels = torch.cat([p[1] for p in parts])
+        g = tr.train_step(batch, labels)
+        # the reference logs rank 0's LOCAL loss; the grad norm is global
+        assert abs(g["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * w["grad_norm"]["0_default"], (g["grad_norm"], w["grad_norm"])
+        assert abs(g["lr"] - w["lr"]) <= 1e-9 * w["lr"] and g["loss_scale"] == w["loss_scale"]
+
+
 @pytest.mark.gpu
 def test_engine_resumes_from_reference_checkpoint_and_round_trips(dev, tmp_path):
     """The HIP engine loads the reference's checkpoint and reproduces the 2 steps the reference trained after saving; a checkpoint

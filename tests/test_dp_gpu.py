@@ -114,6 +114,91 @@ def test_two_rank_step_equals_one_rank_step(dev):
     assert worst <= 6e-3
 
 
+def _ckpt_worker(rank, world, port, q, folder):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        dev = torch.device("cuda:0")
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init)
+        loader = iter(SyntheticLoader(128, 1, 2, True, 4000, data_rank=rank, data_world_size=world))
+        for _ in range(2):
+            batch, labels = next(loader)
+            eng.forward_backward(batch, labels)
+            eng.step()
+        eng.save_checkpoint(folder)  # collective; returns after a barrier
+        fresh = InternLM2Engine(_cfg(2), dev, None, world, rank)  # random init: everything must come from the files
+        fresh.load_checkpoint(folder)
+        same = all(torch.equal(a, b) for a, b in ((eng.master, fresh.master), (eng.exp_avg, fresh.exp_avg), (eng.exp_avg_sq, fresh.exp_avg_sq)))
+        same = same and all(torch.equal(eng.p[n], fresh.p[n]) for n in eng.p)
+        batch, labels = next(loader)
+        out = []
+        for e in (eng, fresh):
+            loss = e.forward_backward(batch, labels)
+            e.step()
+            st = e.read_state()
+            out.append((float(loss), float(st.grad_norm), float(st.loss_scale), int(st.adam_step)))
+        same_after = torch.equal(eng.params, fresh.params) and torch.equal(eng.master, fresh.master)
+        q.put((rank, bool(same), bool(same_after), out, eng.params.float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_checkpoint_round_trip_and_reshard(dev, tmp_path):
+    """2 data-parallel ranks save InternEvo's checkpoint files (one whole-parameter ZeRO shard per rank, the reference's greedy
+    partition), fresh engines load them: state bit-identical, the next step bit-identical.  The same folder loaded into ONE rank
+    (shards merged and re-cut) continues with the same step up to summation order."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.layout import FlatLayout
+
+    folder = str(tmp_path / "ck")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, 29841, q, folder)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    assert sorted(os.listdir(folder)) == ["gpus-2_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "gpus-2_wp-0_tp-0_dp-1_pp-0_zo-1.pt", "model_tp0_pp0.pt",
+                                          "optimizer_tp0_pp0_zo0.pt", "optimizer_tp0_pp0_zo1.pt", "topo_tp0_pp0.json"]
+    for rank, same, same_after, out, _ in res:
+        assert same, f"rank {rank}: reloaded state differs from the saved engine's"
+        assert same_after and out[0] == out[1], f"rank {rank}: the step after the reload differs: {out}"
+        assert out[0][3] == 3
+    cfg1 = _cfg(4)
+    ck = C.load_checkpoint(folder, cfg1.model)
+    assert ck["zero_world"] == 2 and ck["adam_step"] == 2 and set(ck["master"]) == set(ck["params"])
+    one = InternLM2Engine(cfg1, dev)
+    one.load_checkpoint(folder)
+    loader = iter(SyntheticLoader(128, 1, 4, True, 4000))
+    for _ in range(2):
+        next(loader)
+    batch, labels = next(loader)
+    loss = one.forward_backward(batch, labels)
+    one.step()
+    st = one.read_state()
+    mean_loss = 0.5 * (res[0][3][0][0] + res[1][3][0][0])
+    print(f"step 3: dp2 loss {mean_loss:.5f} gn {res[0][3][0][1]:.4f} | re-sharded dp1 loss {float(loss):.5f} gn {float(st.grad_norm):.4f}")
+    assert abs(float(loss) - mean_loss) <= 2e-3 * abs(mean_loss) and abs(float(st.grad_norm) - res[0][3][0][1]) <= 2e-2 * res[0][3][0][1]
+    assert int(st.adam_step) == 3
+    p2 = torch.from_numpy(res[0][4])
+    L2, L1 = FlatLayout(_cfg(2).model, 2), one.layout
+    ref_params = one.params.float().cpu()
+    worst = max(float((ref_params[s.offset : s.offset + s.numel] - p2[L2.params[n].offset : L2.params[n].offset + s.numel]).abs().max())
+                for n, s in L1.params.items())
+    assert worst <= 6e-3, worst
+
+
 def _rccl_worker(port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

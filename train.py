@@ -110,9 +110,10 @@ def main(argv=None, log=print):
         out.append(infos)
         if rank % 8 == 0 and success:
             log(line(infos))
-        if save_folder and every and (step + 1) % every == 0 and world == 1:
-            eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))
-            log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
+        if save_folder and every and (step + 1) % every == 0 and eng.tp == 1 and eng.sp == 1:
+            eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))  # collective: every data-parallel rank writes its ZeRO shard
+            if rank == 0:
+                log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
     if world > 1:
         torch.distributed.barrier()
     return out
