@@ -12,6 +12,9 @@ Written / read so that a run can be handed over between the reference and this e
         zero_devide_optim_plan  as below
     <folder>/gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt   zero_devide_optim_plan: [[["<i>_<shape>" ...]], [[]]]
 
+    <folder>/schedulder.pt (sic), sampler.pt, context.pt   the run state written by rank 0 (checkpoint_manager.py:608-618):
+        the LR scheduler's state_dict, the batch sampler's (generator state, position, this epoch's order), TrainState's counters
+
 (internlm/checkpoint/components.py:199-283,377-410; solver/optimizer/hybrid_zero_optim.py:133-140,254-284,882-936.)
 The flat vectors hold the group's parameters in the ZeRO partition order: the module-order parameter list stably sorted by
 numel, largest first, each parameter handed WHOLE to the rank that holds the fewest elements so far (`_partition_param_list`);
@@ -247,4 +250,29 @@ def load_checkpoint(folder, model_cfg, want=None):
             raise ValueError(f"optimizer shard zo{r} disagrees with zo0 on the step / scaler / lr: {this} vs {head}")
         del st
     out.update(merged, zero_world=zero_world, **head)
+    return out
+
+
+def save_run_state(folder, scheduler_state, sampler_state, batch_count, num_consumed_samples_in_epoch, num_consumed_tokens,
+                   inf_nan_skip_batches, step_count, tensorboard_folder=None):
+    """schedulder.pt / sampler.pt / context.pt as CheckpointManager.save_checkpoint writes them from the logging rank
+    (checkpoint_manager.py:608-618).  scheduler_state: schedule.CosineWarmupLR.state_dict(); sampler_state:
+    data.StaticBatchSampler.state_dict(); the rest are TrainState's counters (core/trainer.py:123-135): batch_count = index of the
+    last batch run, step_count = successful optimizer steps."""
+    os.makedirs(folder, exist_ok=True)
+    torch.save(scheduler_state, os.path.join(folder, "schedulder.pt"))
+    if sampler_state is not None:
+        torch.save(sampler_state, os.path.join(folder, "sampler.pt"))
+    torch.save({"batch_count": int(batch_count), "num_consumed_samples_in_epoch": int(num_consumed_samples_in_epoch),
+                "num_consumed_tokens": int(num_consumed_tokens), "inf_nan_skip_batches": int(inf_nan_skip_batches),
+                "step_count": int(step_count), "tensorboard_folder": tensorboard_folder}, os.path.join(folder, "context.pt"))
+
+
+def load_run_state(folder):
+    """-> dict(scheduler, sampler, context), each None when its file is absent.  A resumed run starts at batch
+    context["batch_count"] + 1 (TrainState.load_state_dict, core/trainer.py:114-117)."""
+    out = {}
+    for key, fn in (("scheduler", "schedulder.pt"), ("sampler", "sampler.pt"), ("context", "context.pt")):
+        path = os.path.join(folder, fn)
+        out[key] = torch.load(path, map_location="cpu", weights_only=False) if os.path.exists(path) else None
     return out

@@ -131,11 +131,13 @@ class PackedDatasetWithCut:
 
 
 class StaticBatchSampler:
-    """batch_sampler.py:110-247 without batch-size ramp-up (rampup_batch_size="" in every config of the path)."""
+    """batch_sampler.py:110-247 without batch-size ramp-up (rampup_batch_size="" in every config of the path), including its
+    state_dict / load_state_dict (:249-272): the content of a checkpoint's `sampler.pt`."""
 
     def __init__(self, num_samples, batch_size, seed=1024, data_rank=0, data_world_size=1):
         self.num_samples = num_samples
         self.batch_size = batch_size
+        self.seed, self.epoch = seed, 0
         self.rng = np.random.RandomState(seed)
         self.data_rank, self.data_world_size = data_rank, data_world_size
         self.batch_count = 0
@@ -143,6 +145,7 @@ class StaticBatchSampler:
 
     def _get_indices(self):
         indices = np.arange(self.num_samples)
+        self.rng_state = self.rng.get_state()  # the generator BEFORE this epoch's shuffle: enough to regenerate `indices`
         self.rng.shuffle(indices)
         n = self.num_samples // (self.batch_size * self.data_world_size) * self.batch_size * self.data_world_size
         self.indices = indices[:n]
@@ -158,6 +161,20 @@ class StaticBatchSampler:
                 self.batch_count += 1
                 yield batch
             self._get_indices()
+
+    def state_dict(self):
+        return {"batch_size": self.batch_size, "raw_rampup_batch_size": "", "rng_state": self.rng_state, "epoch": self.epoch,
+                "seed": self.seed, "data_world_size": self.data_world_size, "num_consumed_samples_in_epoch": self.consumed,
+                "batch_count": self.batch_count, "indices": self.indices}
+
+    def load_state_dict(self, states):
+        for name, mine in (("data_world_size", self.data_world_size), ("raw_rampup_batch_size", ""), ("seed", self.seed)):
+            assert states[name] == mine, (name, states[name], mine)  # should not change (batch_sampler.py:265-266)
+        self.rng.set_state(states["rng_state"])
+        self._get_indices()  # regenerate this epoch's order from the saved generator state
+        self.epoch = states["epoch"]
+        self.batch_count = states["batch_count"]
+        self.consumed = states["num_consumed_samples_in_epoch"]
 
 
 def packed_collate(items, packed_length):

@@ -45,6 +45,36 @@ class CosineWarmupLR:
     def set_successful_steps(self, k):
         self.k = k
 
+    def state_dict(self, n_groups=2):
+        """The reference scheduler's state_dict() after self.k steps -- the content of a checkpoint's `schedulder.pt`
+        (lr_scheduler.py:28-37: the wrapper's __dict__ plus the after-scheduler's; n_groups = the optimizer's parameter groups,
+        "default" and "fp32").  While warming up the wrapper counts the steps, from the hand-over on only the CosineAnnealingLR
+        does.  Pinned by tests/golden/sched_state.json (the real class, torch 2.10 key set)."""
+        k, w = self.k, self.warmup_epochs
+        base = [self.base_lr] * n_groups
+        now = [self.lr_at(k)] * n_groups
+        return {
+            "_init_steps": self.init_steps, "_warmup_steps": self.warmup_steps, "warmup_epochs": w, "finished": k >= w,
+            "base_lrs": list(base), "last_epoch": min(k, w), "_step_count": 1 + min(k, w), "_is_initial": False,
+            "_get_lr_called_within_step": False, "_last_lr": list(now), "after_scheduler_type": "CosineAnnealingLR",
+            "after_scheduler_dict": {"T_max": self.t_max, "eta_min": self.eta_min, "base_lrs": list(base), "last_epoch": max(0, k - w),
+                                     "_step_count": 1 + max(0, k - w), "_is_initial": False,
+                                     "_get_lr_called_within_step": k == w,  # set by hand on the hand-over step (:124), reset by its next step()
+                                     "_last_lr": list(now if k > w else base)},
+        }
+
+    def load_state_dict(self, state):
+        """Position from a `schedulder.pt`: steps taken = the wrapper's count + the after-scheduler's.  (The reference's
+        load_scheduler additionally overwrites the wrapper's last_epoch with step_count + 1, components.py:446 -- inside the
+        warm-up that moves a resumed reference run one step ahead of an uninterrupted one; not mirrored.)"""
+        for key, mine in (("_init_steps", self.init_steps), ("_warmup_steps", self.warmup_steps)):
+            if key in state and state[key] != mine:
+                raise ValueError(f"scheduler checkpoint has {key} = {state[key]}, the config gives {mine}")
+        after = state.get("after_scheduler_dict", {})
+        if "T_max" in after and after["T_max"] != self.t_max:
+            raise ValueError(f"scheduler checkpoint has T_max = {after['T_max']}, the config gives {self.t_max}")
+        self.k = int(state["last_epoch"]) + int(after.get("last_epoch", 0))
+
 
 class Beta2Scheduler:
     def __init__(self, init_beta2, c=0.0):

@@ -462,18 +462,37 @@ def gen_checkpoint(port=29795, rank=0, world=1):
     rec = {"config": kw, "num_samples": NUM_SAMPLES, "saved_after_step": 2, "steps": [], "world": world}
     for step in range(4):
         batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
+        # the run-state bookkeeping of the reference's loop (train.py:205-207,250-253; train/pipeline.py:489)
+        train_state.batch_count = step
+        train_state.num_consumed_samples_in_epoch += len(batch[1])
         trainer.zero_grad()
         if batch[0].get("type_ids", None) is not None:
             metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
         _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
         lr_used = optimizer.optim.param_groups[0]["lr"]
         ok, norms = trainer.step()
+        if ok:
+            train_state.step_count += 1
+        else:
+            train_state.inf_nan_skip_batches += 1
+        train_state.num_consumed_tokens += batch[1].nelement() * gpc.get_world_size(ParallelMode.DATA)
         rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
                              "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
             save_model_checkpoint("local:" + folder, model)
             save_optimizer_checkpoint(optimizer, "local:" + folder)
+            if world == 1:
+                # the remaining files of CheckpointManager.save_checkpoint (checkpoint_manager.py:608-618), written the same way
+                from internlm.utils.storage_manager import llm_save
+
+                llm_save(os.path.join("local:" + folder, "schedulder.pt"), saved_obj=lr_scheduler.state_dict())
+                llm_save(os.path.join("local:" + folder, "sampler.pt"), saved_obj=train_state.batch_sampler.state_dict())
+                llm_save(os.path.join("local:" + folder, "context.pt"), saved_obj=train_state.state_dict())
+                rec["scheduler_state"] = json.loads(json.dumps(lr_scheduler.state_dict(), default=str))
+                rec["context_state"] = train_state.state_dict()
+                ss = train_state.batch_sampler.state_dict()
+                rec["sampler_state"] = {k: (v if isinstance(v, (int, float, str, type(None))) else str(type(v))) for k, v in ss.items()}
             sd = model.state_dict()
             rec["model_keys"] = [[k, str(v.dtype), list(v.shape)] for k, v in sd.items()]
             osd = optimizer.state_dict()
@@ -532,13 +551,21 @@ def gen_checkpoint_load(port=29796):
     # 1) the oracle trains two steps and saves in the reference format
     pcfg = tiny(kw["hidden"], kw["layers"], kw["heads"], kw["kv_heads"], kw["vocab"], kw["seq_len"], kw["micro_num"], 1e-3, kw["total_steps"])
     ora = OracleTrainer(pcfg, torch.bfloat16)
-    oloader = iter(SyntheticLoader(kw["seq_len"], 1, kw["micro_num"], True, NUM_SAMPLES))
+    oloader_obj = SyntheticLoader(kw["seq_len"], 1, kw["micro_num"], True, NUM_SAMPLES)
+    oloader = iter(oloader_obj)
     osteps = [ora.train_step(*next(oloader)) for _ in range(2)]
     folder = tempfile.mkdtemp(prefix="ie_ckpt_")
     st = ora.export_state()
     C.save_checkpoint(folder, pcfg.model, st["params"], st["master"], st["exp_avg"], st["exp_avg_sq"], st["adam_step"], st["scaler"], st["lr"],
                       dict(weight_decay=pcfg.train.weight_decay, betas=(pcfg.train.adam_beta1, pcfg.train.adam_beta2), eps=pcfg.train.adam_eps,
                            initial_lr=pcfg.train.lr))
+    # ... and the run state of the logging rank (schedulder.pt / sampler.pt / context.pt), from this repo's scheduler and sampler
+    from internevo_amd.schedule import CosineWarmupLR
+
+    sched = CosineWarmupLR(pcfg.train.lr, kw["total_steps"], 0.01, 1e-5)
+    sched.set_successful_steps(2)
+    C.save_run_state(folder, sched.state_dict(), oloader_obj.sampler.state_dict(), batch_count=1, num_consumed_samples_in_epoch=oloader_obj.sampler.consumed,
+                     num_consumed_tokens=2 * kw["micro_num"] * kw["seq_len"], inf_nan_skip_batches=0, step_count=2)
     # 2) the reference loads it and keeps training
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
@@ -560,11 +587,21 @@ def gen_checkpoint_load(port=29796):
     from internlm.core.context.process_group_initializer import ParallelMode as _PM
 
     torch.serialization.add_safe_globals([_PM])
+    # ... and its sampler files hold numpy arrays / generator state, which weights_only=True rejects as well: restore the
+    # pre-2.6 default for the reference's llm_load (harness only)
+    _torch_load = torch.load
+    torch.load = lambda *a, **k: _torch_load(*a, **{**k, "weights_only": k.get("weights_only") or False})
+    # the resume sequence of try_load_internevo_ckpt (checkpoint_manager.py:83-124), with the reference's own loaders
+    from internlm.checkpoint.components import load_context, load_sampler, load_scheduler
+
     load_model_checkpoint("local:" + folder, model)
+    load_context("local:" + folder, train_state)
     load_optimizer_checkpoint("local:" + folder, optimizer)
-    for _ in range(2):  # scheduler / sampler state files (schedulder.pt, sampler.pt, context.pt) are not part of this slice
-        lr_scheduler.step()
-        beta2_scheduler.step()
+    load_scheduler("local:" + folder, lr_scheduler, optimizer, train_state)
+    load_sampler("local:" + folder, train_dl.batch_sampler)
+    train_state.init_batch_sampler(train_dl.batch_sampler)
+    for _ in range(2):
+        beta2_scheduler.step()  # c = 0: constant; kept in step for tidiness
     metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
                         dataset_types=dataset_types)
     trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
@@ -572,11 +609,11 @@ def gen_checkpoint_load(port=29796):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    rec = {"config": kw, "num_samples": NUM_SAMPLES, "oracle_steps_before_save": osteps, "reference_steps_after_load": []}
-    for step in range(4):
+    rec = {"config": kw, "num_samples": NUM_SAMPLES, "oracle_steps_before_save": osteps, "reference_steps_after_load": [],
+           "resumed_train_state": json.loads(str(train_state)), "resumed_from_batch": train_state.batch_count}
+    assert train_state.batch_count == 2 and train_state.step_count == 2
+    for step in range(train_state.batch_count, 4):  # the sampler file put the loader after the two batches already consumed
         batch, train_iter = load_new_batch(train_dl=train_dl, train_iter=train_iter, train_state=train_state)
-        if step < 2:
-            continue  # consumed by the run that wrote the checkpoint
         trainer.zero_grad()
         if batch[0].get("type_ids", None) is not None:
             metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
@@ -606,6 +643,30 @@ RUNS_MP = {
     "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
 }
+
+
+def gen_sched_state():
+    """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
+    wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
+    Pins schedule.CosineWarmupLR.state_dict (the content of a checkpoint's schedulder.pt)."""
+    sys.path.insert(0, REF)
+    from internlm.solver.schedulers.lr_scheduler import FineTuneCosineAnnealingWarmupLR
+
+    out = {"torch": torch.__version__, "cases": []}
+    for total, ratio, init_steps, eta_min in ((50, 0.1, 0, 1e-5), (6, 0.01, 0, 1e-5), (40, 0.1, 3, 0.0)):
+        ps = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))]
+        opt = torch.optim.AdamW([{"params": [ps[0]]}, {"params": [ps[1]]}], lr=1e-3)
+        sch = FineTuneCosineAnnealingWarmupLR(opt, total_steps=total, init_steps=init_steps, warmup_ratio=ratio, eta_min=eta_min)
+        states = []
+        for n in range(0, 12):
+            states.append({"n": n, "lr": opt.param_groups[0]["lr"], "state": json.loads(json.dumps(sch.state_dict()))})
+            opt.step()
+            sch.step()
+        out["cases"].append({"total_steps": total, "warmup_ratio": ratio, "init_steps": init_steps, "eta_min": eta_min, "base_lr": 1e-3,
+                             "states": states})
+    with open(os.path.join(HERE, "sched_state.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("sched_state.json", len(out["cases"]))
 
 
 def gen_data():
@@ -694,6 +755,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-mp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 2 and sys.argv[1] == "--sched":
+        gen_sched_state()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--metrics":
         gen_metrics()
         sys.exit(0)
@@ -701,7 +765,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--metrics", "--ckpt", "--ckpt-mp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--metrics", "--sched", "--ckpt", "--ckpt-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

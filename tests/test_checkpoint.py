@@ -34,6 +34,66 @@ def test_reference_checkpoint_loads_and_structure_matches():
         assert ck["exp_avg"][n].shape == p.shape and float(ck["exp_avg_sq"][n].min()) >= 0.0
 
 
+def _same_tree(a, b, path=""):
+    """dict / list trees with the same keys in the same order; floats to 1e-12 relative, everything else exactly."""
+    assert type(a) is type(b) or (isinstance(a, (int, float)) and isinstance(b, (int, float)) and not isinstance(a, bool) and not isinstance(b, bool)), (path, a, b)
+    if isinstance(a, dict):
+        assert list(a) == list(b), (path, list(a), list(b))
+        for k in a:
+            _same_tree(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same_tree(x, y, f"{path}[{i}]")
+    elif isinstance(a, float) or isinstance(b, float):
+        assert abs(a - b) <= 1e-12 * max(abs(a), abs(b)), (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+def test_scheduler_state_dict_matches_the_reference_class():
+    """tests/golden/sched_state.json: state_dict() of the real FineTuneCosineAnnealingWarmupLR after n = 0..11 steps, with and
+    without warm-up and init steps.  CosineWarmupLR.state_dict restates it in closed form; load_state_dict finds n back."""
+    from internevo_amd.schedule import CosineWarmupLR
+
+    gold = json.load(open(os.path.join(G, "sched_state.json")))
+    for case in gold["cases"]:
+        for st in case["states"]:
+            if st["n"] > case["total_steps"]:
+                continue  # past the end of training torch's recursive cosine leaves the closed form; no run gets there
+            s = CosineWarmupLR(case["base_lr"], case["total_steps"], case["warmup_ratio"], case["eta_min"], case["init_steps"])
+            s.set_successful_steps(st["n"])
+            assert abs(s.lr() - st["lr"]) <= 1e-12 * max(st["lr"], 1e-30)
+            _same_tree(s.state_dict(), st["state"], f"total={case['total_steps']} n={st['n']}")
+            t = CosineWarmupLR(case["base_lr"], case["total_steps"], case["warmup_ratio"], case["eta_min"], case["init_steps"])
+            t.load_state_dict(st["state"])
+            assert t.k == st["n"]
+    bad = CosineWarmupLR(1e-3, 60, 0.1, 1e-5)
+    with pytest.raises(ValueError):
+        bad.load_state_dict(gold["cases"][0]["states"][3]["state"])
+
+
+def test_sampler_resumes_from_the_reference_sampler_file():
+    """sampler.pt written by the real reference after 2 batches: loading it puts a fresh sampler where an uninterrupted one is."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.data import SyntheticLoader
+
+    gold = json.load(open(os.path.join(G, "ckpt.json")))
+    c = gold["config"]
+    rs = C.load_run_state(REF)
+    assert rs["context"]["step_count"] == 2 and rs["context"]["batch_count"] == 1 and rs["scheduler"]["after_scheduler_dict"]["last_epoch"] == 2
+    straight = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(straight)
+    resumed = SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"])
+    resumed.sampler.load_state_dict(rs["sampler"])
+    it = iter(resumed)
+    for _ in range(3):
+        (a, la), (b, lb) = next(straight), next(it)
+        assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(la, lb)
+    assert C.load_run_state(REF2) == dict(scheduler=None, sampler=None, context=None)  # the dp-2 fixture holds model + optimizer only
+
+
 def test_saved_files_equal_the_reference_files(tmp_path):
     """load(reference files) -> save -> the same file set, the same keys / dtypes / shapes / values, tensor for tensor."""
     from internevo_amd import checkpoint as C
@@ -44,7 +104,33 @@ def test_saved_files_equal_the_reference_files(tmp_path):
     out = str(tmp_path / "ck")
     C.save_checkpoint(out, cfg.model, ck["params"], ck["master"], ck["exp_avg"], ck["exp_avg_sq"], ck["adam_step"], ck["scaler"], ck["lr"],
                       dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3))
+    # ... and the run state the logging rank adds (checkpoint_manager.py:608-618): scheduler, sampler, TrainState counters
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.schedule import CosineWarmupLR
+
+    c = gold["config"]
+    loader = SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"])
+    it = iter(loader)
+    for _ in range(gold["saved_after_step"]):
+        _, labels = next(it)
+    sched = CosineWarmupLR(1e-3, c["total_steps"], 0.01, 1e-5)
+    sched.set_successful_steps(gold["saved_after_step"])
+    C.save_run_state(out, sched.state_dict(), loader.sampler.state_dict(), batch_count=gold["saved_after_step"] - 1,
+                     num_consumed_samples_in_epoch=gold["saved_after_step"] * labels.shape[0],
+                     num_consumed_tokens=gold["saved_after_step"] * labels.nelement(), inf_nan_skip_batches=0, step_count=gold["saved_after_step"])
     assert sorted(os.listdir(out)) == gold["files"]
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    assert ld(out, "context.pt") == ld(REF, "context.pt") == gold["context_state"]
+    _same_tree(ld(out, "schedulder.pt"), ld(REF, "schedulder.pt"))
+    sa, sb = ld(REF, "sampler.pt"), ld(out, "sampler.pt")
+    assert list(sa) == list(sb)
+    for k in sa:
+        if k == "rng_state":
+            assert sa[k][0] == sb[k][0] and (sa[k][1] == sb[k][1]).all() and tuple(sa[k][2:]) == tuple(sb[k][2:])
+        elif k == "indices":
+            assert sa[k].dtype == sb[k].dtype and (sa[k] == sb[k]).all()
+        else:
+            assert sa[k] == sb[k], k
     a = torch.load(os.path.join(REF, "model_tp0_pp0.pt"), weights_only=False)
     b = torch.load(os.path.join(out, "model_tp0_pp0.pt"), weights_only=False)
     assert list(a) == list(b) and all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a)
@@ -94,24 +180,27 @@ def test_oracle_resumes_from_the_reference_checkpoint():
 
 
 def test_reference_resumes_from_our_checkpoint():
-    """tests/golden/ckpt_load.json: the oracle trained 2 steps, save_checkpoint() wrote the files, the REAL reference loaded them
-    with its own load_model_checkpoint / load_optimizer_checkpoint and trained 2 more steps (make_golden.py --ckpt-load).  The
-    oracle, simply continuing, must land on the same losses and grad norms (given the learning rates the resumed reference used:
-    its scheduler files are not part of this slice, the harness re-stepped a fresh scheduler)."""
+    """tests/golden/ckpt_load.json: the oracle trained 2 steps, save_checkpoint() + save_run_state() wrote the files, the REAL
+    reference resumed from them with its own loaders in its own order (load_model_checkpoint, load_context,
+    load_optimizer_checkpoint, load_scheduler, load_sampler; make_golden.py --ckpt-load) and trained 2 more steps.  The oracle,
+    simply continuing, must land on the same losses, grad norms AND learning rates, on the same batches."""
     from internevo_amd.data import SyntheticLoader
     from oracle.step import OracleTrainer
 
     gold = json.load(open(os.path.join(G, "ckpt_load.json")))
     cfg = _cfg()
     c = gold["config"]
+    assert gold["resumed_from_batch"] == 2
+    assert gold["resumed_train_state"] == dict(batch_count=2, inf_nan_skip_batches=0, num_consumed_samples_in_epoch=4,
+                                               num_consumed_tokens=2 * c["micro_num"] * c["seq_len"], step_count=2)
     tr = OracleTrainer(cfg, torch.bfloat16)
     loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
     for w in gold["oracle_steps_before_save"]:
         g = tr.train_step(*next(loader))
         assert g["loss"] == w["loss"] and g["grad_norm"] == w["grad_norm"], "the oracle itself is deterministic"
     for w in gold["reference_steps_after_load"]:
-        tr._lr = lambda lr=w["lr"]: lr
         g = tr.train_step(*next(loader))
+        assert abs(g["lr"] - w["lr"]) <= 1e-12 * w["lr"], "the reference's scheduler, restored from our schedulder.pt, is where ours is"
         assert abs(g["loss"] - w["loss"]) <= 2e-3 * abs(w["loss"]), (g["loss"], w["loss"])
         assert abs(g["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * w["grad_norm"]["0_default"]
         assert g["loss_scale"] == w["loss_scale"] and w["ok"]

@@ -74,3 +74,13 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
     assert [r["step"] for r in run2] == [2, 3]
     for a, b in zip(run1[2:], run2):
         assert (a["loss"], a["grad_norm"], a["acc"], a["perplexity"], a["lr"]) == (b["loss"], b["grad_norm"], b["acc"], b["perplexity"], b["lr"])
+        assert a["num_consumed_tokens"] == b["num_consumed_tokens"], "context.pt carries the token count across the restart"
+    # the folder is a complete InternEvo checkpoint: model, optimizer shard + plan, and the logging rank's run state
+    from internevo_amd import checkpoint as C
+
+    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["context.pt", "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt",
+                                                             "optimizer_tp0_pp0_zo0.pt", "sampler.pt", "schedulder.pt", "topo_tp0_pp0.json"]
+    rs = C.load_run_state(os.path.join(folder, "2"))
+    assert rs["context"] == dict(batch_count=1, num_consumed_samples_in_epoch=4, num_consumed_tokens=2 * 2 * 128, inf_nan_skip_batches=0,
+                                 step_count=2, tensorboard_folder=None)
+    assert rs["sampler"]["batch_count"] == 2 and rs["scheduler"]["after_scheduler_dict"]["last_epoch"] == 2

@@ -65,28 +65,42 @@ def main(argv=None, log=print):
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
     ck = raw.get("ckpt", {}) or {}
     load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
-    first_step = 0
+    first_step, run_state = 0, None
     if load_folder and os.path.isdir(load_folder):
+        from internevo_amd.checkpoint import load_run_state
+
         eng.load_checkpoint(load_folder)
-        first_step = eng.step_count
-        log(f"load_ckpt_folder: {load_folder} (resuming at step {first_step})")
+        run_state = load_run_state(load_folder)  # schedulder.pt / sampler.pt / context.pt when the folder has them
+        ctx = run_state["context"]
+        # TrainState.load_state_dict (core/trainer.py:114-117): the loop restarts one batch after the last one run
+        first_step = ctx["batch_count"] + 1 if ctx else eng.step_count
+        if run_state["scheduler"] is not None:
+            eng.lr_sched.load_state_dict(run_state["scheduler"])
+        log(f"load_ckpt_folder: {load_folder} (resuming at batch {first_step}, step_count {eng.step_count})")
     elif world > 1:
         eng.comm.broadcast_params(eng.params)  # sync_model_param (utils/parallel.py:71-107)
         eng.sync_master_from_params()
     dp_world = eng.seqpar.data_world
     metric = AccPerplex(dev, eng.tpar.dp_group, ["en", "cn", "code"], dp_world_size=dp_world)  # the dummy dataset's type list
     eng.attach_metric(metric)
-    loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
-                                  data_rank=eng.seqpar.data_rank, data_world_size=dp_world))
-    for _ in range(first_step):
-        next(loader)  # the sampler position is part of the run state
+    loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
+                                 data_rank=eng.seqpar.data_rank, data_world_size=dp_world)
+    loader = iter(loader_obj)
+    if run_state and run_state["sampler"] is not None:
+        loader_obj.sampler.load_state_dict(run_state["sampler"])  # generator state + position: the same batches as an uninterrupted run
+    else:
+        for _ in range(first_step):
+            next(loader)  # no sampler file: replay the position
     flops = lambda t: get_megatron_flops(t, checkpoint=bool(mc.checkpoint_layers), seq_len=tc.seq_len, hidden_size=mc.hidden_size,  # noqa: E731
                                          num_layers=mc.num_layers, vocab_size=mc.vocab_size, global_batch_size=tc.micro_bsz * tc.micro_num * dp_world,
                                          global_world_size=world, mlp_ratio=mc.mlp_ratio)
     tgs = TgsStatistic()
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
     every = int(ck.get("checkpoint_every", 0) or 0)
-    consumed, skipped_seen, out = 0, 0, []
+    ctx = run_state["context"] if run_state else None
+    consumed = ctx["num_consumed_tokens"] if ctx else 0
+    skipped_before = ctx["inf_nan_skip_batches"] if ctx else 0
+    out = []
     for step in range(first_step, tc.total_steps):
         start = time.time()
         batch, labels = next(loader)
@@ -105,7 +119,7 @@ def main(argv=None, log=print):
         infos = step_infos(tflops=flops(time.time() - start), step=step, loss=float(loss), tk_per_gpu=tk_per_gpu, start_time=start, tgs=tgs,
                            lr=eng.lr_sched.lr(),  # read after the scheduler stepped, like optimizer.param_groups[0]["lr"] (pipeline.py:494)
                            loss_scale=st.loss_scale, grad_norm={"0_default": st.grad_norm}, batch=batch, labels=labels,
-                           num_consumed_tokens=consumed, inf_nan_skip_batches=st.skipped_total, adam_beta2=eng.beta2_sched.beta2(),
+                           num_consumed_tokens=consumed, inf_nan_skip_batches=skipped_before + st.skipped_total, adam_beta2=eng.beta2_sched.beta2(),
                            fwd_bwd_time=fwd_bwd_time, metric=m)
         out.append(infos)
         if rank % 8 == 0 and success:
@@ -113,6 +127,11 @@ def main(argv=None, log=print):
         if save_folder and every and (step + 1) % every == 0 and eng.tp == 1 and eng.sp == 1:
             eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))  # collective: every data-parallel rank writes its ZeRO shard
             if rank == 0:
+                from internevo_amd.checkpoint import save_run_state
+
+                save_run_state(os.path.join(save_folder, str(step + 1)), eng.lr_sched.state_dict(), loader_obj.sampler.state_dict(), batch_count=step,
+                               num_consumed_samples_in_epoch=loader_obj.sampler.consumed, num_consumed_tokens=consumed,
+                               inf_nan_skip_batches=skipped_before + st.skipped_total, step_count=st.adam_step)
                 log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
     if world > 1:
         torch.distributed.barrier()
