@@ -4,15 +4,21 @@ Same observable batches as InternEvo's
   RandomDataset            internlm/data/tokenized/dummy_dataset.py:8-49
   PackedDatasetWithCut     internlm/data/tokenized/packed_dataset.py:204-331 (build_pack)
   StaticBatchSampler       internlm/data/tokenized/batch_sampler.py:110-247
+  JsonlDataset             internlm/data/tokenized/single_dataset.py:18-117   (`data.train_folder`: tokenized .bin + .meta files)
+  get_packed_dataset_without_short_length   internlm/data/tokenized/packed_dataset.py:393-480
   packed_collate_fn        internlm/data/tokenized/collaters.py:7-58
 but built for a 288 GB-HBM node with modest host RAM: samples are generated on demand from the
 pre-drawn (n, r) arrays instead of materialising a million Python lists (the reference needs
 13-21 GB RSS and 2-5 minutes per rank at seq 4096), and a batch is assembled
-straight into int64 numpy buffers.  tests/test_data.py pins the first batches against fixtures
+straight into int64 numpy buffers.  tests/test_oracle_golden.py pins the first batches against fixtures
 produced by the real reference pipeline (tests/golden/data.json).
 """
 import bisect
 import itertools
+import json
+import mmap
+import os
+import re
 
 import numpy as np
 import torch
@@ -58,6 +64,49 @@ class RandomDataset:
     def token_at(self, index, pos):
         n, r = int(self.max_num[index]), int(self._r[index])
         return n if pos == 0 else (r if pos == 1 else (pos - 2) % n)
+
+
+class JsonlDataset:
+    """single_dataset.py:18-117: one .bin file = one JSON document per line ({"tokens": [...]}), `<file>.meta` = np.save of
+    [n_docs, k] with the byte offset of each line first and its token count last; documents shorter than min_length are dropped.
+    Same access surface as RandomDataset (lengths / tokens / token_at) so PackedDatasetWithCut packs either."""
+
+    def __init__(self, path, type_id=0, min_length=50):
+        self.path = os.path.realpath(path)
+        meta_path = self.path + ".meta"
+        assert os.path.exists(meta_path), f"The cache file:{meta_path} is not found for file:{path}"
+        with open(meta_path, "rb") as f:
+            meta = np.load(f)
+        self.offsets, self.lengths = meta[:, 0], meta[:, -1]
+        self.type_id = type_id
+        self.old_length = len(self.offsets)
+        if min_length > 0:
+            keep = self.lengths >= min_length
+            self.offsets, self.lengths = self.offsets[keep], self.lengths[keep]
+        self._mm, self._last = None, (-1, None)
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def _doc(self, index):
+        if self._last[0] != index:
+            if self._mm is None:
+                with open(self.path, "rb") as f:
+                    self._mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            self._mm.seek(int(self.offsets[index]))
+            line = self._mm.readline().decode("utf-8")
+            try:
+                toks = json.loads(line)["tokens"]
+            except Exception as err:  # noqa: BLE001
+                raise ValueError(f"Error while loading JSONL line in file {self.path} at byte {int(self.offsets[index])}: {err}") from err
+            self._last = (index, np.asarray(toks, dtype=np.int64))
+        return self._last[1]
+
+    def tokens(self, index, start=0, stop=None):
+        return self._doc(index)[start:stop]
+
+    def token_at(self, index, pos):
+        return int(self._doc(index)[pos])
 
 
 class PackedDatasetWithCut:
@@ -126,8 +175,54 @@ class PackedDatasetWithCut:
             "labels": np.concatenate(labs),
             "cu_seqlens": np.array(cu, dtype=np.int32),
             "indexes": np.concatenate(idxs) if idxs else np.zeros(0, dtype=np.int64),
-            "type_ids": np.zeros(self.packed_length, dtype=np.int64),
+            "type_ids": np.full(self.packed_length, getattr(self.dataset, "type_id", 0), dtype=np.int64),  # one type per file
         }
+
+
+class ConcatPacked:
+    """torch.utils.data.ConcatDataset over the per-file packed datasets."""
+
+    def __init__(self, datasets):
+        self.datasets = list(datasets)
+        self.cum = list(itertools.accumulate(len(d) for d in self.datasets))
+
+    def __len__(self):
+        return self.cum[-1] if self.cum else 0
+
+    def __getitem__(self, i):
+        k = bisect.bisect_right(self.cum, i)
+        return self.datasets[k][i - (self.cum[k - 1] if k else 0)]
+
+
+def dataset_type_ids_map(folder):
+    """data/utils.py:11-14: the sub-folders of train_folder, sorted, are the dataset types ("en", "cn", ...) of the metric."""
+    return {key: idx for idx, key in enumerate(sorted(os.listdir(folder)))}
+
+
+def build_folder_dataset(folder, max_length_per_sample, packed_length, min_length=0, min_length_dict=None):
+    """packed_dataset.py:393-480 (pack_sample_into_one=False): every .bin under `folder`, walked top-down with sorted directory
+    and file names, becomes a JsonlDataset -> PackedDatasetWithCut; files left empty by the length filter are skipped."""
+    assert os.path.exists(folder), f"{folder} does not exist."
+    type_map = dataset_type_ids_map(folder)
+    packed = []
+    for root, dirs, files in os.walk(folder, followlinks=True):
+        dirs.sort()
+        for fn in sorted(files):
+            if not fn.endswith(".bin"):
+                continue
+            fp = os.path.join(root, fn)
+            ml = min_length
+            if min_length_dict is not None:
+                hits = [k for k in min_length_dict if k in fp]
+                assert len(hits) < 2, f"The file name `{fp}` matched the following resample keys:{hits}"
+                ml = min_length_dict[hits[0]] if hits else ml
+            match = [idx for key, idx in type_map.items() if re.search(rf"/[z_]*{key}/", fp)]  # data/utils.py:17-25
+            assert len(match) == 1, f"{fp}, match_idxes should be 1, but got {match} from {type_map}"
+            ds = JsonlDataset(fp, match[0], min_length=ml)
+            if len(ds) == 0:
+                continue
+            packed.append(PackedDatasetWithCut(ds, max_length_per_sample, packed_length))
+    return ConcatPacked(packed)
 
 
 class StaticBatchSampler:
@@ -188,6 +283,20 @@ def packed_collate(items, packed_length):
         "indexes": torch.from_numpy(np.stack([b["indexes"] for b in items])),
         "type_ids": torch.from_numpy(np.stack([b["type_ids"] for b in items])),
     }, torch.from_numpy(ys)
+
+
+class FolderLoader:
+    """build_dataloader.py:26-66 for data.train_folder = <tokenized folder>: the same sampler and collate over the packed files."""
+
+    def __init__(self, folder, seq_len, micro_bsz, micro_num, min_length=0, min_length_dict=None, data_rank=0, data_world_size=1, seed=1024):
+        self.packed_length = seq_len * micro_bsz
+        self.ds = build_folder_dataset(folder, seq_len, self.packed_length, min_length, min_length_dict)
+        self.dataset_types = list(dataset_type_ids_map(folder).keys())
+        self.sampler = StaticBatchSampler(len(self.ds), micro_num, seed, data_rank, data_world_size)
+
+    def __iter__(self):
+        for idx in self.sampler:
+            yield packed_collate([self.ds[int(i)] for i in idx], self.packed_length)
 
 
 class SyntheticLoader:

@@ -721,6 +721,86 @@ def gen_data():
     print("data goldens written")
 
 
+def gen_data_folder():
+    """The unmodified train_folder pipeline (get_packed_dataset_without_short_length -> JsonlDataset -> PackedDatasetWithCut ->
+    ConcatDataset, StaticBatchSampler, packed_collate_fn; build_dataloader.py:26-66) over the deterministic folder of
+    folder_fixture.py -> data_folder.json: first batches, per-file pack counts, the dataset types."""
+    import tempfile
+
+    shim_cpu_accelerator()
+    import internlm.data.build_dataloader as bdl
+    import internlm.data.tokenized.batch_sampler as bs
+    import internlm.data.tokenized.packed_dataset as pdm
+    from internlm.core.context import Config
+
+    sys.path.insert(0, HERE)
+    from folder_fixture import write_folder
+
+    root = tempfile.mkdtemp(prefix="ie_folder_")
+    write_folder(root)
+    res = {}
+    for seq_len, micro_bsz, micro_num, min_length, mld in ((64, 2, 3, 5, None), (128, 1, 2, 0, None), (32, 2, 2, 10, {"en/c": 60})):
+
+        class _G:  # the only gpc members the pipeline touches
+            config = None
+
+            @staticmethod
+            def get_local_rank(mode):
+                return 0
+
+            @staticmethod
+            def get_world_size(mode):
+                return 1
+
+            @staticmethod
+            def is_initialized(mode):
+                return False
+
+            @staticmethod
+            def get_global_rank():
+                return 0
+
+            @staticmethod
+            def is_rank_for_log():
+                return False
+
+        class _D:  # torch.distributed as this single process sees it
+            @staticmethod
+            def broadcast_object_list(objs, src=0):
+                return None
+
+            @staticmethod
+            def get_rank():
+                return 0
+
+        data_cfg = Config(dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=micro_bsz, packed_length=seq_len * micro_bsz, pack_sample_into_one=False,
+                               rampup_batch_size="", train_folder=root, type="tokenized", use_packed_dataset=True, min_length=min_length,
+                               min_length_dict=mld))
+        old = (bdl.gpc, bs.gpc, pdm.gpc, pdm.dist, bdl.dist)
+        bdl.gpc = bs.gpc = pdm.gpc = _G
+        pdm.dist = bdl.dist = _D
+        try:
+            ds, sampler, collate = bdl.get_tokenized_train_loader_items(data_cfg)
+            it = iter(sampler)
+            batches = []
+            for _ in range(4):
+                idx = next(it)
+                b, y = collate([ds[int(i)] for i in idx])
+                batches.append({"idx": [int(i) for i in idx], "input_ids": b["input_ids"].tolist(), "labels": y.tolist(),
+                                "cu_seqlens": [c.tolist() for c in b["cu_seqlens"]], "indexes": b["indexes"].tolist(),
+                                "type_ids": b["type_ids"].tolist()})
+            res[f"seq{seq_len}_mbsz{micro_bsz}_mnum{micro_num}_min{min_length}" + ("_dict" if mld else "")] = {
+                "seq_len": seq_len, "micro_bsz": micro_bsz, "micro_num": micro_num, "min_length": min_length, "min_length_dict": mld,
+                "len_ds": len(ds), "len_files": [len(d) for d in ds.datasets], "batches": batches,
+                "files": [os.path.relpath(str(d.dataset.resolved_path), os.path.realpath(root)) for d in ds.datasets],
+                "dataset_types": list(bdl.get_dataset_type_ids_map(root).keys())}
+        finally:
+            bdl.gpc, bs.gpc, pdm.gpc, pdm.dist, bdl.dist = old
+    with open(os.path.join(HERE, "data_folder.json"), "w") as f:
+        json.dump({"cases": res}, f)
+    print("data_folder goldens written", {k: v["len_files"] for k, v in res.items()})
+
+
 if __name__ == "__main__":
     import subprocess
 
@@ -739,6 +819,9 @@ if __name__ == "__main__":
         tag = sys.argv[2]
         dtype, kw = RUNS[tag]
         run_training(tag, dtype, kw, port=29700 + list(RUNS).index(tag))
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--data-folder":
+        gen_data_folder()
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--data":
         gen_data()
@@ -765,7 +848,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--metrics", "--sched", "--ckpt", "--ckpt-mp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--ckpt", "--ckpt-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -84,3 +84,36 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
     assert rs["context"] == dict(batch_count=1, num_consumed_samples_in_epoch=4, num_consumed_tokens=2 * 2 * 128, inf_nan_skip_batches=0,
                                  step_count=2, tensorboard_folder=None)
     assert rs["sampler"]["batch_count"] == 2 and rs["scheduler"]["after_scheduler_dict"]["last_epoch"] == 2
+
+
+@pytest.mark.gpu
+def test_train_entry_on_a_tokenized_folder(dev, tmp_path):
+    """data.train_folder = a folder of tokenized .bin / .meta files (tests/golden/folder_fixture.py): the loader's packs (pinned
+    against the real pipeline in test_tokenized_folder_pipeline_matches_reference) drive the HIP engine; the metric splits by the
+    folder's dataset types; the per-type token counts add up to the tokens with a label."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, G)
+    import train
+    from folder_fixture import write_folder
+
+    root = str(tmp_path / "data")
+    write_folder(root)
+    cfg = tmp_path / "cfg.py"
+    text = CFG.format(steps=3, save=False, folder=str(tmp_path / "ck"), load=str(tmp_path / "none"))
+    text = text.replace("seq_len=128, micro_num=2, micro_bsz=1,", "seq_len=64, micro_num=3, micro_bsz=2, min_length=5,").replace(
+        "train_folder=None", f"train_folder={root!r}")
+    cfg.write_text(text)
+    lines = []
+    run = train.main(["--config", str(cfg), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run] == [0, 1, 2]
+    for r in run:
+        assert r["loss"] == r["loss"] and r["loss"] < 7.0 and r["grad_norm"]["0_default"] > 0
+        assert {"acc/cn", "acc/en", "tokens/cn", "tokens/en", "loss/cn", "loss/en"} <= set(r)
+        assert r["tokens/cn"] + r["tokens/en"] > 0 and r["tokens/cn"] + r["tokens/en"] <= 3 * 128
+    assert run[2]["num_consumed_tokens"] == 3 * 3 * 128
+    # the same batches as the loader alone yields
+    from internevo_amd.data import FolderLoader
+
+    it = iter(FolderLoader(root, 64, 2, 3, 5))
+    _, labels = next(it)
+    assert run[0]["tokens/cn"] + run[0]["tokens/en"] == int((labels > 0).sum()) or run[0]["tokens/cn"] + run[0]["tokens/en"] == int((labels != -100).sum())

@@ -53,8 +53,10 @@ def main(argv=None, log=print):
     raw = {k: v for k, v in runpy.run_path(args.config).items() if not k.startswith("__")}
     cfg = from_reference_dict(raw)
     tc, mc = cfg.train, cfg.model
-    if raw.get("data", {}).get("train_folder", None) is not None:
-        raise NotImplementedError("only the reference's synthetic RandomDataset (data.train_folder = None) is wired in")
+    data_raw = raw.get("data", {}) or {}
+    train_folder = _local(data_raw.get("train_folder", None))
+    if data_raw.get("pack_sample_into_one", False):
+        raise NotImplementedError("data.pack_sample_into_one = True (PackedDatasetWithoutCuSeqlen) is not on the packed flash path")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,10 +83,18 @@ def main(argv=None, log=print):
         eng.comm.broadcast_params(eng.params)  # sync_model_param (utils/parallel.py:71-107)
         eng.sync_master_from_params()
     dp_world = eng.seqpar.data_world
-    metric = AccPerplex(dev, eng.tpar.dp_group, ["en", "cn", "code"], dp_world_size=dp_world)  # the dummy dataset's type list
+    if train_folder:  # tokenized .bin / .meta files (build_dataloader.py:41-50); the metric's types are its sub-folders
+        from internevo_amd.data import FolderLoader
+
+        loader_obj = FolderLoader(train_folder, tc.seq_len, tc.micro_bsz, tc.micro_num, data_raw.get("min_length", 0), data_raw.get("min_length_dict", None),
+                                  data_rank=eng.seqpar.data_rank, data_world_size=dp_world, seed=data_raw.get("seed", 1024))
+        dataset_types = loader_obj.dataset_types
+    else:
+        loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
+                                     data_rank=eng.seqpar.data_rank, data_world_size=dp_world)
+        dataset_types = ["en", "cn", "code"]  # the dummy dataset's type list (build_dataloader.py:93)
+    metric = AccPerplex(dev, eng.tpar.dp_group, dataset_types, dp_world_size=dp_world)
     eng.attach_metric(metric)
-    loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
-                                 data_rank=eng.seqpar.data_rank, data_world_size=dp_world)
     loader = iter(loader_obj)
     if run_state and run_state["sampler"] is not None:
         loader_obj.sampler.load_state_dict(run_state["sampler"])  # generator state + position: the same batches as an uninterrupted run
