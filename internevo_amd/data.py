@@ -6,6 +6,7 @@ Same observable batches as InternEvo's
   StaticBatchSampler       internlm/data/tokenized/batch_sampler.py:110-247
   JsonlDataset             internlm/data/tokenized/single_dataset.py:18-117   (`data.train_folder`: tokenized .bin + .meta files)
   get_packed_dataset_without_short_length   internlm/data/tokenized/packed_dataset.py:393-480
+  validation loaders       internlm/data/build_dataloader.py:67-157 + DataParallelSampler (batch_sampler.py:20-93) + jsonl_ds_collate_fn
   packed_collate_fn        internlm/data/tokenized/collaters.py:7-58
 but built for a 288 GB-HBM node with modest host RAM: samples are generated on demand from the
 pre-drawn (n, r) arrays instead of materialising a million Python lists (the reference needs
@@ -313,3 +314,70 @@ class SyntheticLoader:
     def __iter__(self):
         for idx in self.sampler:
             yield packed_collate([self.ds[int(i)] for i in idx], self.packed_length)
+
+
+def jsonl_collate(items, max_length_per_sample):
+    """collaters.py:58-88 (validation): truncate to seq_len, tokens -> abs(), labels = shifted tokens with non-positive ids and the
+    padding ignored (-100), both zero- / -100-padded to exactly seq_len."""
+    xs = torch.zeros(len(items), max_length_per_sample, dtype=torch.int64)
+    ys = torch.full((len(items), max_length_per_sample), -100, dtype=torch.int64)
+    for r, toks in enumerate(items):
+        t = torch.as_tensor(np.asarray(toks[:max_length_per_sample], dtype=np.int64))
+        xs[r, : len(t)] = t.abs()
+        lab = torch.where(t > 0, t, torch.full_like(t, -100))
+        ys[r, : len(t) - 1] = lab[1:]
+    return {"input_ids": xs}, ys
+
+
+class _DocConcat:
+    """ConcatDataset of JsonlDatasets as get_dataset_dict builds it (documents, not packs)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.cum = list(itertools.accumulate(len(d) for d in parts))
+
+    def __len__(self):
+        return self.cum[-1] if self.cum else 0
+
+    def tokens(self, i):
+        k = bisect.bisect_right(self.cum, i)
+        return self.parts[k].tokens(i - (self.cum[k - 1] if k else 0))
+
+
+def valid_datasets(seq_len, fixed_seqlen, data_world_size, valid_folder=None):
+    """build_dataloader.py:67-83: no valid_folder -> {"val": RandomDataset(500 samples per data-parallel rank)}; a folder -> one
+    entry per directory that holds .bin files (tokenized/dataset.py:10-56: sorted walk, every .bin, min_length 50)."""
+    if not valid_folder:
+        return {"val": RandomDataset(num_samples=data_world_size * 500, max_len=seq_len, fixed_seqlen=fixed_seqlen)}
+    assert os.path.exists(valid_folder), f"folder `{valid_folder}` not exists"
+    out = {}
+    for root, dirs, files in os.walk(valid_folder, followlinks=True):
+        dirs.sort()
+        parts = [JsonlDataset(os.path.join(root, fn)) for fn in sorted(files) if fn.endswith(".bin")]
+        if parts:
+            out[os.path.basename(root)] = _DocConcat(parts)
+    return out
+
+
+class ValidLoader:
+    """One validation set as build_valid_loader_with_data_type iterates it: DataParallelSampler(shuffle=False, drop_last=True)
+    -> this rank's documents rank, rank + world, ...; DataLoader(batch_size, drop_last=True); jsonl_ds_collate_fn.
+    batch_size = min(valid_micro_num * micro_bsz, len // world) rounded down to whole micro-batches; 0 = the set is skipped."""
+
+    def __init__(self, dataset, seq_len, micro_bsz, valid_micro_num, data_rank=0, data_world_size=1):
+        self.ds, self.seq_len = dataset, seq_len
+        n, w = len(dataset), data_world_size
+        self.batch_size = min(valid_micro_num * micro_bsz, n // w) // micro_bsz * micro_bsz
+        if w > 1:  # the sampler only exists under data parallelism (get_dpsampler_dataloader)
+            per_rank = -((n - w) // -w) if n % w else n // w  # drop_last: ceil((n - w) / w)
+            self.indices = list(range(n))[: per_rank * w][data_rank : per_rank * w : w]
+        else:
+            self.indices = list(range(n))
+
+    def __len__(self):
+        return len(self.indices) // self.batch_size if self.batch_size else 0
+
+    def __iter__(self):
+        bs = self.batch_size
+        for b in range(len(self)):
+            yield jsonl_collate([self.ds.tokens(i) for i in self.indices[b * bs : (b + 1) * bs]], self.seq_len)

@@ -378,6 +378,34 @@ class InternLM2Engine:
             self._backward_micro(ids_i, lab_i, cu, pos_i, max_seqlen, i == M - 1, i == 0)
         return self.loss_acc
 
+    def forward_only(self, input_ids, labels, metric=None):
+        """One evaluation batch = NonPipelineScheduler.forward_backward_step(forward_only=True) as evaluate_on_val_dls drives it
+        (eval/evaluation.py:45-147, data_process_func = None): input_ids / labels [B, seq_len] host tensors, every row one
+        (zero-padded) sequence, B a multiple of micro_bsz; micro-batches of micro_bsz rows run the training forward (same kernels,
+        nothing saved for a backward that matters, gradients untouched).  `metric`: an AccPerplex that sees these logits instead
+        of the training metric.  Returns the device scalar mean over micro-batches of the mean token loss."""
+        tc = self.tc
+        B, S = input_ids.shape
+        if S != tc.seq_len or B % tc.micro_bsz:
+            raise ValueError(f"evaluation batch {tuple(input_ids.shape)}: rows must be seq_len = {tc.seq_len} long, their number a multiple of micro_bsz = {tc.micro_bsz}")
+        M = B // tc.micro_bsz
+        lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T
+        ids_d = input_ids.reshape(M, -1).to(self.dev, non_blocking=True)
+        lab_d = labels.reshape(M, -1).to(self.dev, non_blocking=True)
+        pos_d = torch.arange(S, dtype=torch.int64).repeat(tc.micro_bsz).to(self.dev, non_blocking=True)
+        cu = (torch.arange(tc.micro_bsz + 1, dtype=torch.int32) * S).to(self.dev, non_blocking=True)
+        self._ensure_rotary(S)
+        out = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        train_metric = self.metric
+        self.attach_metric(metric)  # allocates the argmax / nll rows on first use
+        try:
+            for i in range(M):
+                self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S)
+                out.add_(self.t_loss[0:1], alpha=1.0 / M)
+        finally:
+            self.metric = train_metric
+        return out
+
     # ------------------------------------------------------------------------------------------ optimizer
     def step(self):
         """HybridZeroOptimizer.step + Engine.step (engine.py:105-126): norm, scaler, clip, AdamW, param sync,

@@ -79,6 +79,25 @@ class OracleTrainer:
             return tc.adam_beta2
         return max(tc.adam_beta2, 1 - (1 / self.beta2_iter**tc.adam_beta2_c))
 
+    def eval_batch(self, input_ids, labels, metric=None):
+        """forward_only=True step of the evaluation loop (eval/evaluation.py:84-108): rows are whole sequences, micro-batches of
+        micro_bsz rows, loss = mean over micro-batches; `metric` (an AccPerplexOracle) sees the logits."""
+        tc, mc = self.tc, self.mc
+        B, S = input_ids.shape
+        M = B // tc.micro_bsz
+        total = 0.0
+        with torch.no_grad():
+            for i in range(M):
+                ids = input_ids[i * tc.micro_bsz : (i + 1) * tc.micro_bsz].reshape(-1)
+                lab = labels[i * tc.micro_bsz : (i + 1) * tc.micro_bsz].reshape(-1)
+                cu = torch.arange(tc.micro_bsz + 1, dtype=torch.int32) * S
+                idx = torch.arange(S, dtype=torch.int64).repeat(tc.micro_bsz)
+                logits = forward_logits(self.params, mc, ids, idx, cu)
+                total += float(O.cross_entropy(logits, lab, tc.label_smoothing)) / M
+                if metric is not None:
+                    metric.update(logits.float(), lab, None)
+        return total
+
     def train_step(self, batch, labels):
         """batch['input_ids'] [micro_num, T]; returns dict(loss, grad_norm, ok, loss_scale)."""
         tc, mc = self.tc, self.mc

@@ -645,6 +645,98 @@ RUNS_MP = {
 }
 
 
+def gen_eval(port=29798):
+    """evaluate_on_val_dls (eval/evaluation.py:45-147) of the real reference on its default validation set (RandomDataset, 500
+    samples, valid_folder=None; unpadded lengths so that rows carry zero padding) -- once on the closed-form initial weights,
+    once on the weights of tests/golden/ckpt_ref/ (its own checkpoint after two training steps) -> eval.json.  Pins data.ValidLoader + engine.forward_only / oracle eval_batch."""
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    import internlm.data.build_dataloader as bdl
+    from internlm.core.context import ParallelMode
+    from internlm.core.context import global_context as gpc
+    from internlm.core.trainer import TrainState
+    from internlm.data.tokenized.dummy_dataset import RandomDataset
+    from internlm.eval.evaluation import evaluate_on_val_dls
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.losses import FlashGPTLMLoss
+    from internlm.model.metrics import AccPerplex
+    from internlm.train import get_scheduler_hooks, initialize_isp_communicator, initialize_model, initialize_optimizer, load_new_batch
+    from internlm.utils.common import get_current_device
+
+    from oracle.model import formula_init
+
+    kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)
+    bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(
+        num_samples=NUM_SAMPLES if num_samples > 100000 else num_samples, max_len=max_len, fixed_seqlen=fixed_seqlen)
+    cfg = tiny_config("torch.bfloat16", **kw)
+    cfg["data"]["fixed_random_dataset_seqlen"] = False
+    cfg["data"]["valid_micro_num"] = 2
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    torch.set_num_threads(8)
+    model = initialize_model()
+    with torch.no_grad():
+        for name, p in model.model.named_parameters():
+            p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+    criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
+    train_dl, dataset_types = bdl.build_train_loader_with_data_type()
+    val_dls = bdl.build_valid_loader_with_data_type()
+    train_state = TrainState(gpc.config, train_dl.batch_sampler)
+    isp = initialize_isp_communicator(model)
+    optimizer, beta2_scheduler, lr_scheduler = initialize_optimizer(model, isp)
+    metric = AccPerplex(device=get_current_device(), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA),
+                        dataset_types=dataset_types)
+    trainer, train_dl, _, _ = internlm.initialize_trainer(model=model, optimizer=optimizer, criterion=criterion, train_dataloader=train_dl,
+                                                          lr_scheduler=lr_scheduler, beta2_scheduler=beta2_scheduler,
+                                                          scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
+    trainer.train()
+
+    class _Writer:
+        def __init__(self):
+            self.scalars = {}
+
+        def add_scalar(self, key, value, step):
+            self.scalars[key] = float(value)
+
+    class _Logger:
+        lines = []
+
+        def info(self, msg, *a, **k):
+            self.lines.append(str(msg))
+
+    rec = {"config": kw, "num_samples": NUM_SAMPLES, "valid_micro_num": 2, "evals": [],
+           "val_sets": {name: {"batches": len(dl), "batch_size": dl.batch_size} for name, dl in val_dls.items()}}
+    first = next(iter(val_dls["val"]))
+    rec["first_batch"] = {"input_ids": first[0]["input_ids"].tolist(), "labels": first[1].tolist()}
+
+    # this torch refuses the reference's rotary autograd.Function under inference_mode ("Inference tensors cannot be saved for
+    # backward", modules/embedding.py:376): run its evaluation under no_grad instead -- same arithmetic (harness only)
+    torch.inference_mode = torch.no_grad
+
+    def run_eval(step):
+        w, lg = _Writer(), _Logger()
+        evaluate_on_val_dls(trainer, val_dls, w, lg, step)
+        rec["evals"].append({"step": step, "scalars": w.scalars, "line": lg.lines[-1]})
+        print("eval", step, w.scalars, flush=True)
+
+    run_eval(0)
+    # second point: the weights of tests/golden/ckpt_ref/ (the reference's own checkpoint after two training steps, --ckpt)
+    import types
+
+    from internlm.checkpoint.components import load_model_checkpoint
+    from internlm.utils.storage_manager import init_storage_manager
+
+    init_storage_manager(True, None, False)
+    fa = types.ModuleType("flash_attn"); fam = types.ModuleType("flash_attn.modules"); fae = types.ModuleType("flash_attn.modules.embedding")
+    fae.VocabParallelEmbedding = type("VocabParallelEmbedding", (), {})
+    sys.modules.setdefault("flash_attn", fa); sys.modules.setdefault("flash_attn.modules", fam); sys.modules.setdefault("flash_attn.modules.embedding", fae)
+    load_model_checkpoint("local:" + os.path.join(HERE, "ckpt_ref"), model)
+    run_eval(2)
+    with open(os.path.join(HERE, "eval.json"), "w") as f:
+        json.dump(rec, f)
+    print("eval.json written")
+
+
 def gen_sched_state():
     """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
     wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
@@ -838,6 +930,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-mp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 2 and sys.argv[1] == "--eval":
+        gen_eval()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--sched":
         gen_sched_state()
         sys.exit(0)
@@ -848,7 +943,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--ckpt", "--ckpt-mp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--ckpt", "--ckpt-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -122,6 +122,60 @@ def test_engine_packed_varlen_batch_matches_oracle(dev):
         assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
 
 
+def test_forward_only_evaluation_matches_oracle_and_reference(dev):
+    """engine.forward_only (the evaluation pass, eval/evaluation.py:45-147) on the reference's default validation batches (zero-padded
+    rows, 2 micro-batches per batch): loss and the AccPerplex it feeds vs the oracle batch by batch, then the whole validation set
+    vs what the REAL reference's evaluate_on_val_dls reported (tests/golden/eval.json) -- on the closed-form weights and on the
+    weights of the reference's own step-2 checkpoint.  Training state must come out untouched."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader, ValidLoader, valid_datasets
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from oracle.model import formula_init
+    from oracle.ops import AccPerplexOracle
+    from oracle.step import OracleTrainer
+
+    gold = json.load(open(os.path.join(G, "eval.json")))
+    c = gold["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    vl = ValidLoader(valid_datasets(c["seq_len"], False, 1)["val"], c["seq_len"], 1, gold["valid_micro_num"])
+    # a training step first: evaluation must neither read nor disturb gradients / optimizer state
+    batch, labels = next(iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"])))
+    eng.forward_backward(batch, labels)
+    grads_before = eng.grads.clone()
+    m_hip, m_ora = AccPerplex(dev, None, None), AccPerplexOracle([])
+    for k, (b, y) in enumerate(vl):
+        if k == 6:
+            break
+        got = float(eng.forward_only(b["input_ids"], y, m_hip))
+        want = ora.eval_batch(b["input_ids"], y, m_ora)
+        assert abs(got - want) <= 2e-3 * abs(want), (k, got, want)
+    a, b_ = m_hip.get_metric(), m_ora.get_metric()
+    assert abs(a["acc"] - b_["acc"]) <= 5e-3 and abs(a["perplexity"] - b_["perplexity"]) <= 1e-2 * b_["perplexity"], (a, b_)
+    assert torch.equal(eng.grads, grads_before) and eng.metric is None
+    eng.step()
+    with pytest.raises(ValueError):
+        eng.forward_only(torch.zeros(2, c["seq_len"] + 1, dtype=torch.int64), torch.zeros(2, c["seq_len"] + 1, dtype=torch.int64))
+    # the whole validation set against the reference's report
+    fresh = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    for ev in gold["evals"]:
+        if ev["step"] == 2:
+            fresh.load_checkpoint(os.path.join(G, "ckpt_ref"))
+        metric = AccPerplex(dev, None, None)
+        total, n = torch.zeros(1, device=dev), 0
+        for b, y in vl:
+            total += fresh.forward_only(b["input_ids"], y, metric)
+            n += 1
+        res, want = metric.get_metric(), ev["scalars"]
+        loss = float(total) / (n + 1e-6)
+        print(f"eval at step {ev['step']}: HIP loss {loss:.5f} acc {res['acc']} plex {res['perplexity']} | reference {want}")
+        assert abs(loss - want["val/val_loss"]) <= 2e-3 * want["val/val_loss"]
+        assert abs(res["acc"] - want["val/val_acc"]) <= 5e-3 and abs(res["perplexity"] - want["val/val_plex"]) <= 1e-2 * want["val/val_plex"]
+
+
 @pytest.mark.parametrize("frac", [1.0, 0.5])
 def test_activation_checkpointing_is_bit_identical(dev, frac):
     """model.checkpoint (solver/activation_checkpoint.py:40-172): the checkpointed layers keep only their input and are

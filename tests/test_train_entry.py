@@ -117,3 +117,26 @@ def test_train_entry_on_a_tokenized_folder(dev, tmp_path):
     it = iter(FolderLoader(root, 64, 2, 3, 5))
     _, labels = next(it)
     assert run[0]["tokens/cn"] + run[0]["tokens/en"] == int((labels > 0).sum()) or run[0]["tokens/cn"] + run[0]["tokens/en"] == int((labels != -100).sum())
+
+
+@pytest.mark.gpu
+def test_train_entry_validates_every_n_steps(dev, tmp_path):
+    """data.valid_every = 2: after successful steps 2 and 4 the loop runs evaluate_on_val_dls over the default validation set and
+    prints the reference's line; the numbers are those of a direct forward_only sweep."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    cfg = tmp_path / "cfg.py"
+    text = CFG.format(steps=4, save=False, folder=str(tmp_path / "ck"), load=str(tmp_path / "none"))
+    cfg.write_text(text.replace("train_folder=None,", "train_folder=None, valid_every=2, valid_micro_num=4, valid_folder=None,"))
+    lines = []
+    run = train.main(["--config", str(cfg), "--launcher", "torch"], log=lines.append)
+    val = [l for l in lines if l.startswith("Validation on val: ")]
+    assert len(val) == 2 and val[0].startswith("Validation on val: step=2 val/val_loss=") and " val/val_acc=" in val[0] and " val/val_plex=" in val[0]
+    assert "val/val_loss" not in run[0] and "val/val_loss" in run[1] and "val/val_loss" in run[3]
+    assert run[3]["val/val_loss"] < run[1]["val/val_loss"] < 6.3 and 0.0 <= run[3]["val/val_acc"] <= 1.0
+    # training is unaffected by the interleaved evaluation: same losses as the run without it
+    cfg2 = tmp_path / "cfg2.py"
+    cfg2.write_text(text)
+    run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
+    assert [r["loss"] for r in run] == [r["loss"] for r in run2] and [r["grad_norm"] for r in run] == [r["grad_norm"] for r in run2]

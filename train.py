@@ -42,6 +42,30 @@ def _local(path):
     return path
 
 
+def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
+    """eval/evaluation.py:45-147: a forward-only pass over every validation set with a fresh AccPerplex (no dataset types); the
+    logging rank reports its own mean batch loss (divided by batches + 1e-6, as the reference does) and the all-reduced accuracy /
+    perplexity."""
+    from internevo_amd.metrics import AccPerplex
+
+    infos_all = {}
+    metric = AccPerplex(dev, eng.tpar.dp_group, None, dp_world_size=eng.seqpar.data_world)
+    for name, vl in val_loaders.items():
+        if len(vl) == 0:
+            log(f"Validation dataset: {name} is empty")
+            continue
+        total = torch.zeros(1, dtype=torch.float32, device=dev)
+        n = 0
+        for batch, labels in vl:
+            total += eng.forward_only(batch["input_ids"], labels, metric)
+            n += 1
+        res = metric.get_metric()  # all-reduces over the data-parallel group and resets
+        infos = {"step": step_count, f"val/{name}_loss": float(total) / (n + 1e-6), f"val/{name}_acc": res["acc"], f"val/{name}_plex": res["perplexity"]}
+        log(f"Validation on {name}: " + " ".join(f"{k}={v}" for k, v in infos.items()))
+        infos_all.update(infos)
+    return infos_all
+
+
 def main(argv=None, log=print):
     args = parse_args(argv)
     from internevo_amd.config import from_reference_dict
@@ -105,6 +129,18 @@ def main(argv=None, log=print):
                                          num_layers=mc.num_layers, vocab_size=mc.vocab_size, global_batch_size=tc.micro_bsz * tc.micro_num * dp_world,
                                          global_world_size=world, mlp_ratio=mc.mlp_ratio)
     tgs = TgsStatistic()
+    # validation sets (build_dataloader.py:67-157): the default 500-document RandomDataset per data-parallel rank, or valid_folder
+    valid_every = int(data_raw.get("valid_every", 0) or 0)
+    val_loaders = {}
+    if valid_every > 0:
+        from internevo_amd.data import ValidLoader, valid_datasets
+
+        for name, ds in valid_datasets(tc.seq_len, tc.fixed_random_dataset_seqlen, dp_world, _local(data_raw.get("valid_folder", None))).items():
+            vl = ValidLoader(ds, tc.seq_len, tc.micro_bsz, int(data_raw.get("valid_micro_num", 1)), eng.seqpar.data_rank, dp_world)
+            if vl.batch_size == 0:
+                log(f"skip validate {name}.")
+                continue
+            val_loaders[name] = vl
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
     every = int(ck.get("checkpoint_every", 0) or 0)
     ctx = run_state["context"] if run_state else None
@@ -134,6 +170,8 @@ def main(argv=None, log=print):
         out.append(infos)
         if rank % 8 == 0 and success:
             log(line(infos))
+        if val_loaders and st.adam_step % valid_every == 0:  # train.py:279-288: keyed on the count of successful steps
+            out[-1].update(evaluate_on_val_dls(eng, val_loaders, st.adam_step, dev, log if rank == 0 else (lambda m: None)))
         if save_folder and every and (step + 1) % every == 0 and eng.tp == 1 and eng.sp == 1:
             eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))  # collective: every data-parallel rank writes its ZeRO shard
             if rank == 0:
