@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
+    ap.add_argument("--no-batch-wgrad", action="store_true", help="A/B only: one weight-gradient GEMM per micro-batch (engine batch_wgrad=False)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B only: ie_tune_gemm_tail_split mode (library default when omitted)")
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
                                                                   "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
@@ -123,7 +124,7 @@ def main():
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
-    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024)
+    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None)
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()

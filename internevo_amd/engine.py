@@ -40,7 +40,7 @@ BF16 = torch.bfloat16
 
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
-                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None):
+                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None):
         """sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step)."""
@@ -103,6 +103,7 @@ class InternLM2Engine:
         self.Tg = tc.packed_length              # tokens of a micro-batch
         self.T = tc.packed_length // sp_size    # tokens this rank owns (all of them without sequence parallelism)
         self._alloc(self.T)
+        self.batch_wgrad = self._alloc_wgrad_stage(batch_wgrad)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
         # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
         # GEMMs are MFMA-bound, so bucket b+1's update overlaps the forward of layer b; per-bucket events order the two.
@@ -200,6 +201,59 @@ class InternLM2Engine:
         self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
         self.scale_view = self.state[:4].view(torch.float32)  # IeStepState.loss_scale, read by the CE backward on device
 
+    def _alloc_wgrad_stage(self, want):
+        """Batched weight gradients.  The reference (autograd) runs one weight-gradient GEMM per linear per micro-batch and adds
+        it into the bf16 .grad; with micro_num micro-batches that is micro_num GEMMs of contraction length T each.  On 288 GB there
+        is room to keep every linear's (dY, X) pair of ALL micro-batches of a step (7B, seq 4096, micro_num 4: 76 GB) and run ONE
+        GEMM per linear with contraction length micro_num * T in the last micro-batch's backward: the tile prologue / epilogue and
+        the bf16 read-modify-write of dW are paid once (+6 ... +14 % on the weight-gradient GEMMs, tools/wgrad_batch_probe.py),
+        the sum over micro-batches is carried in the fp32 accumulators (rounded to bf16 once instead of micro_num times), and
+        the gradient reduce-scatter of a bucket still starts right after its last weight gradient.  No copies: the producing
+        kernels write straight into the micro-batch's rows of the [micro_num * T, cols] staging tensors.
+        want: None = on when micro_num > 1, no activation checkpointing and the memory is there; True / False = forced."""
+        tc, mc = self.tc, self.lmc
+        M, T, L = tc.micro_num, self.T, mc.num_layers
+        h, F, V = mc.hidden_size, mc.ffn_dim, mc.vocab_size
+        ctx_cols = mc.num_attention_heads * mc.head_dim
+        cols = L * (3 * h + ctx_cols + 3 * F + mc.qkv_dim) + h + V  # n1, n2, d_out, d_r2 | ctx | act, dw13 | dqkv ; nf, logits
+        need = 2 * M * T * cols
+        possible = M > 1 and mc.checkpoint_layers == 0
+        if want is None:
+            free = torch.cuda.mem_get_info(self.dev)[0] if self.dev.type == "cuda" else 0
+            want = possible and need + (16 << 30) < free
+        elif want and not possible:
+            raise ValueError("batch_wgrad needs micro_num > 1 and no activation checkpointing")
+        if not want:
+            return False
+
+        def big(c):
+            return torch.empty(M * T, c, dtype=BF16, device=self.dev)
+
+        self.st_n1, self.st_n2 = [big(h) for _ in range(L)], [big(h) for _ in range(L)]
+        self.st_ctx = [big(ctx_cols) for _ in range(L)]
+        self.st_act, self.st_dw13 = [big(F) for _ in range(L)], [big(2 * F) for _ in range(L)]
+        self.st_dqkv = [big(mc.qkv_dim) for _ in range(L)]
+        self.st_dout, self.st_dr2 = [big(h) for _ in range(L)], [big(h) for _ in range(L)]
+        self.st_nf, self.st_logits = big(h), big(V)
+        self.batch_wgrad = True
+        self._bind_micro(0)  # also releases the single-micro-batch buffers these replace
+        return True
+
+    def _bind_micro(self, i):
+        """Point the forward's saved linear inputs at micro-batch i's rows of the weight-gradient staging tensors."""
+        if not getattr(self, "batch_wgrad", False):
+            return
+        T, mc = self.T, self.lmc
+        r = slice(i * T, (i + 1) * T)
+        self._mrows = r
+        self.a_n1 = [t[r] for t in self.st_n1]
+        self.a_n2 = [t[r] for t in self.st_n2]
+        ctx = [t[r].view(T, mc.num_attention_heads, mc.head_dim) for t in self.st_ctx]
+        self.a_ctxl = ctx
+        if self.sp == 1:
+            self.a_ctx = ctx  # without sequence parallelism the attention output IS the wo input
+        self.a_nf, self.t_logits = self.st_nf[r], self.st_logits[r]
+
     # ------------------------------------------------------------------------------------------ forward / backward
     def _w13(self, l):
         s = self.layout.params[f"layers.{l}.feed_forward.w1.weight"]
@@ -287,9 +341,18 @@ class InternLM2Engine:
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
         K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         dlog = self.t_logits
+        bw = self.batch_wgrad
+        r = self._mrows if bw else None
+
+        def wgrad(dy, x, gw, dy_all, x_all):
+            if not bw:
+                K.linear_wgrad(dy, x, gw, acc)
+            elif last_micro:  # every micro-batch's rows are in place: one GEMM over micro_num * T tokens
+                K.linear_wgrad(dy_all, x_all, gw, False)
+
         K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
-        K.linear_wgrad(dlog, self.a_nf, g["output.weight"], acc)
-        d_out = self.t_h1
+        wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
+        d_out = self.st_dout[L - 1][r] if bw else self.t_h1
         K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
@@ -301,19 +364,20 @@ class InternLM2Engine:
             if l < mc.checkpoint_layers:
                 self._layer_forward(l, None, cu, pos, max_seqlen, True)
             # feed-forward
+            t_act, t_dw13, t_qkv = (self.st_act[l][r], self.st_dw13[l][r], self.st_dqkv[l][r]) if bw else (self.t_act, self.t_dw13, self.t_qkv)
             K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
-            K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], self.t_dw13[:, :F], self.t_dw13[:, F:], self.t_act)
-            K.linear_wgrad(d_out, self.t_act, g[pre + "feed_forward.w2.weight"], acc)
+            K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], t_dw13[:, :F], t_dw13[:, F:], t_act)
+            wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None)
             d_n2 = spare[0]
-            K.linear_dgrad(self.t_dw13, w13, d_n2)
+            K.linear_dgrad(t_dw13, w13, d_n2)
             self.tpar.all_reduce_sum(d_n2)   # input gradient of the column-parallel w1 | w3
-            K.linear_wgrad(self.t_dw13, self.a_n2[sl], gw13, acc)
-            d_r2 = spare[1]
+            wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None)
+            d_r2 = self.st_dr2[l][r] if bw else spare[1]
             K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc, ws, d_r2)
             # attention
             d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
-            K.linear_wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], acc)
+            wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None)
             if self.sp == 1:
                 d_ctx_full = d_ctx.view(T, -1, d)
             else:  # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53)
@@ -325,15 +389,19 @@ class InternLM2Engine:
             else:
                 dq_l = self.seqpar.scatter_seq_gather_heads(self.t_dq, 1, self.t_xq, self.t_ql)
                 dkv_l = self.seqpar.scatter_seq_gather_heads(self.t_dkv, 2, self.t_xkv, self.t_kvl)
-            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_qkv)
+            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
-            K.linear_dgrad(self.t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
+            K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
             self.tpar.all_reduce_sum(d_n1)   # input gradient of the column-parallel wqkv
-            K.linear_wgrad(self.t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], acc)
-            d_x = d_out  # the old d_out buffer is free now
+            wgrad(t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], self.st_dqkv[l] if bw else None, self.st_n1[l] if bw else None)
+            if bw:    # the layer below reads its output gradient from its own staging rows (it is the dY of that layer's w2)
+                d_x = self.st_dout[l - 1][r] if l > 0 else self.t_h1
+            else:
+                d_x = d_out  # the old d_out buffer is free now
             K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc, ws, d_x)
             # rotate buffers: next d_out = d_x; spare = the two others
-            spare = [d_n2, d_r2]
+            if not bw:
+                spare = [d_n2, d_r2]
             d_out = d_x
             if last_micro:
                 self.comm.reduce_bucket_async(self.grads, 1 + l)
@@ -371,6 +439,7 @@ class InternLM2Engine:
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
             cu = cu_h.to(self.dev, non_blocking=True)
             ids_i, lab_i, pos_i = ids_d[i, lo:hi], lab_d[i, lo:hi], pos_d[i, lo:hi]
+            self._bind_micro(i)
             if self.metric is not None and self.metric.ntypes and self.sp > 1:
                 self.metric.type_ids_local = (lo, hi)
             self._forward_micro(ids_i, lab_i, cu, pos_i, max_seqlen)
@@ -398,6 +467,7 @@ class InternLM2Engine:
         out = torch.zeros(1, dtype=torch.float32, device=self.dev)
         train_metric = self.metric
         self.attach_metric(metric)  # allocates the argmax / nll rows on first use
+        self._bind_micro(0)
         try:
             for i in range(M):
                 self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S)

@@ -189,7 +189,7 @@ def test_activation_checkpointing_is_bit_identical(dev, frac):
     for ck in (0.0, frac):
         cfg = tiny(256, 4, 4, 2, 512, 256, 2, 1e-3, 6)
         cfg.model.checkpoint = ck
-        eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+        eng = InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=False)  # per-micro-batch weight gradients on both sides
         assert eng.mc.checkpoint_layers == int(4 * ck)
         loader = iter(SyntheticLoader(256, 1, 2, False, 4000))  # ragged packed samples
         tr = []
@@ -201,6 +201,50 @@ def test_activation_checkpointing_is_bit_identical(dev, frac):
         out.append((tr, eng.params.clone()))
     assert out[0][0] == out[1][0], f"{out[0][0]} vs {out[1][0]}"
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_batched_weight_gradients_match_per_micro_batch_accumulation(dev):
+    """batch_wgrad: ONE weight-gradient GEMM per linear over all micro-batches of a step (fp32 sum, one bf16 rounding) against the
+    reference-order accumulation (one GEMM per micro-batch added into the bf16 gradient): same trajectory within bf16 rounding of
+    the gradient, both on the oracle; ragged packed rows, 4 micro-batches; on by default when it applies."""
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+    from oracle.step import OracleTrainer
+
+    cfg = tiny(256, 3, 4, 2, 512, 128, 4, 1e-3, 6)
+    cfg.train.micro_bsz = 2
+    cfg.train.fixed_random_dataset_seqlen = False
+    engs = [InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=flag) for flag in (True, False)]
+    assert engs[0].batch_wgrad and not engs[1].batch_wgrad and InternLM2Engine(cfg, dev, init_fn=formula_init).batch_wgrad
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    loader = iter(SyntheticLoader(128, 2, 4, False, 4000))
+    for k in range(3):
+        batch, labels = next(loader)
+        rows = []
+        for e in engs:
+            loss = e.forward_backward(batch, labels)
+            if k == 0:
+                grads = e.grads.float().clone()
+                rows.append(grads)
+            e.step()
+            st = e.read_state()
+            rows.append((float(loss), float(st.grad_norm)))
+        ref = ora.train_step(batch, labels)
+        if k == 0:
+            ga, (la, na), gb, (lb, nb) = rows
+            rel = float((ga - gb).norm() / gb.norm())
+            print(f"gradient: batched vs per-micro-batch relative difference {rel:.2e}")
+            assert rel < 4e-3
+        else:
+            (la, na), (lb, nb) = rows
+        print(f"step {k}: batched {la:.5f}/{na:.4f}  per-micro {lb:.5f}/{nb:.4f}  oracle {ref['loss']:.5f}/{ref['grad_norm']:.4f}")
+        for l_, n_ in ((la, na), (lb, nb)):
+            assert abs(l_ - ref["loss"]) <= 3e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+    with pytest.raises(ValueError):
+        cfg.model.checkpoint = 1.0
+        InternLM2Engine(cfg, dev, batch_wgrad=True)
 
 
 @pytest.mark.timeout(1500)
