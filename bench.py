@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
+    ap.add_argument("--merge-micro", type=int, default=None, help="A/B only: 1 = run the micro-batches of a step as one merged pass, 0 = sequentially")
     ap.add_argument("--no-batch-wgrad", action="store_true", help="A/B only: one weight-gradient GEMM per micro-batch (engine batch_wgrad=False)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B only: ie_tune_gemm_tail_split mode (library default when omitted)")
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
@@ -124,7 +125,8 @@ def main():
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
-    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None)
+    eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None,
+                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro))
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()

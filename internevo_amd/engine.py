@@ -40,7 +40,7 @@ BF16 = torch.bfloat16
 
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
-                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None):
+                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None):
         """sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step)."""
@@ -100,9 +100,28 @@ class InternLM2Engine:
         self._ensure_rotary(tc.seq_len)
 
         # ---- activation / workspace buffers for T tokens per micro-batch
-        self.Tg = tc.packed_length              # tokens of a micro-batch
-        self.T = tc.packed_length // sp_size    # tokens this rank owns (all of them without sequence parallelism)
+        # merge_micro: run the micro_num micro-batches of a step as ONE pass over micro_num * packed_length tokens (see forward_backward)
+        can_merge = tc.micro_num > 1 and sp_size == 1 and mc.checkpoint_layers == 0
+        if merge_micro and not can_merge:
+            raise ValueError("merge_micro needs micro_num > 1, no sequence parallelism and no activation checkpointing")
+        if merge_micro is None and batch_wgrad:
+            merge_micro = False  # an explicit request for the staged per-micro-batch path
+        if merge_micro is None:
+            # automatic: on when the activations of micro_num micro-batches fit next to the weights and the optimizer state.  Decided
+            # from static sizes and the device's TOTAL memory, so every rank of a job takes the same decision (the tensor-parallel
+            # all-reduces of the two modes differ in number and size)
+            lm = self.lmc
+            per_token = 2 * (lm.num_layers * (6 * lm.hidden_size + 2 * lm.num_kv_attention_heads * lm.head_dim + 2 * lm.ffn_dim)
+                             + lm.vocab_size + 12 * lm.hidden_size + 6 * lm.ffn_dim + 2 * lm.qkv_dim) + 64
+            fixed = 4 * L.total + 12 * L.local_numel()
+            total = torch.cuda.get_device_properties(device).total_memory if device.type == "cuda" else 0
+            merge_micro = can_merge and fixed + per_token * tc.packed_length * tc.micro_num + (24 << 30) < 0.92 * total
+        self.mm = tc.micro_num if merge_micro else 1       # micro-batches per pass
+        self.n_pass = tc.micro_num // self.mm               # passes (gradient-accumulation steps) per optimizer step
+        self.Tg = tc.packed_length * self.mm    # tokens of a pass
+        self.T = self.Tg // sp_size             # tokens this rank owns (all of them without sequence parallelism)
         self._alloc(self.T)
+        self.t_loss_seg = torch.empty(self.mm, 2, dtype=torch.float32, device=device)  # per micro-batch [mean loss, valid tokens]
         self.batch_wgrad = self._alloc_wgrad_stage(batch_wgrad)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
         # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
@@ -212,7 +231,7 @@ class InternLM2Engine:
         kernels write straight into the micro-batch's rows of the [micro_num * T, cols] staging tensors.
         want: None = on when micro_num > 1, no activation checkpointing and the memory is there; True / False = forced."""
         tc, mc = self.tc, self.lmc
-        M, T, L = tc.micro_num, self.T, mc.num_layers
+        M, T, L = self.n_pass, self.T, mc.num_layers
         h, F, V = mc.hidden_size, mc.ffn_dim, mc.vocab_size
         ctx_cols = mc.num_attention_heads * mc.head_dim
         cols = L * (3 * h + ctx_cols + 3 * F + mc.qkv_dim) + h + V  # n1, n2, d_out, d_r2 | ctx | act, dw13 | dqkv ; nf, logits
@@ -297,7 +316,7 @@ class InternLM2Engine:
         K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
         return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
 
-    def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
+    def _forward_micro(self, ids, labels, cu, pos, max_seqlen, nseg=None):
         mc = self.mc
         L, eps = mc.num_layers, mc.layer_norm_epsilon
         p = self.p
@@ -310,7 +329,19 @@ class InternLM2Engine:
         self._wait_bucket(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
-        if self.metric is None:
+        if self.mm > 1:
+            # merged pass: the loss (and the metric) stay per micro-batch -- each has its own valid-token count (loss = mean over
+            # micro-batches of the mean token loss, no_pipeline_scheduler.py:146)
+            P = self.T // self.mm
+            for i in range(self.mm if nseg is None else nseg):
+                r = slice(i * P, (i + 1) * P)
+                if self.metric is None:
+                    K.ce_fwd(self.t_logits[r], labels[r], -100, self.tc.label_smoothing, self.t_loss_rows[r], self.t_lse[r], self.t_loss_seg[i])
+                else:
+                    K.ce_fwd(self.t_logits[r], labels[r], -100, self.tc.label_smoothing, self.t_loss_rows[r], self.t_lse[r], self.t_loss_seg[i],
+                             self.t_argmax[r], self.t_nll[r])
+                    self.metric.update_fused(self.t_nll[r], self.t_argmax[r], labels[r])
+        elif self.metric is None:
             K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
         else:  # metric pass (SchedulerMetricHook.post_helper_func -> AccPerplex.update) fused into the same sweep over the logits
             K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss, self.t_argmax, self.t_nll)
@@ -339,7 +370,13 @@ class InternLM2Engine:
         if first_micro:
             self._wait_optimizer()  # the previous step's AdamW reads the gradients this backward is about to overwrite
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
-        K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+        if self.mm > 1:
+            P = T // self.mm
+            for i in range(self.mm):
+                r = slice(i * P, (i + 1) * P)
+                K.ce_bwd(self.t_logits[r], labels[r], self.t_lse[r], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+        else:
+            K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         dlog = self.t_logits
         bw = self.batch_wgrad
         r = self._mrows if bw else None
@@ -425,7 +462,9 @@ class InternLM2Engine:
         (host tensors).  Returns the device scalar sum_i loss_i / micro_num."""
         tc = self.tc
         M = batch["input_ids"].shape[0]
-        assert M == tc.micro_num and batch["input_ids"].shape[1] == self.Tg
+        assert M == tc.micro_num and batch["input_ids"].shape[1] * self.mm == self.Tg
+        if self.mm > 1:
+            return self._forward_backward_merged(batch, labels)
         lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T  # this rank's tokens of every micro-batch
         self.loss_acc.zero_()
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
@@ -457,24 +496,59 @@ class InternLM2Engine:
         B, S = input_ids.shape
         if S != tc.seq_len or B % tc.micro_bsz:
             raise ValueError(f"evaluation batch {tuple(input_ids.shape)}: rows must be seq_len = {tc.seq_len} long, their number a multiple of micro_bsz = {tc.micro_bsz}")
-        M = B // tc.micro_bsz
+        M = B // tc.micro_bsz                      # micro-batches of the evaluation batch
+        rows = tc.micro_bsz * self.mm              # rows of one pass (a merge_micro engine takes several micro-batches at once)
+        npass = -(-B // rows)
+        if npass * rows != B:                      # pad with empty rows: no label, so neither the loss nor the metric sees them
+            pad = npass * rows - B
+            input_ids = torch.cat([input_ids, input_ids.new_zeros(pad, S)])
+            labels = torch.cat([labels, labels.new_full((pad, S), -100)])
         lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T
-        ids_d = input_ids.reshape(M, -1).to(self.dev, non_blocking=True)
-        lab_d = labels.reshape(M, -1).to(self.dev, non_blocking=True)
-        pos_d = torch.arange(S, dtype=torch.int64).repeat(tc.micro_bsz).to(self.dev, non_blocking=True)
-        cu = (torch.arange(tc.micro_bsz + 1, dtype=torch.int32) * S).to(self.dev, non_blocking=True)
+        ids_d = input_ids.reshape(npass, -1).to(self.dev, non_blocking=True)
+        lab_d = labels.reshape(npass, -1).to(self.dev, non_blocking=True)
+        pos_d = torch.arange(S, dtype=torch.int64).repeat(rows).to(self.dev, non_blocking=True)
+        cu = (torch.arange(rows + 1, dtype=torch.int32) * S).to(self.dev, non_blocking=True)
         self._ensure_rotary(S)
         out = torch.zeros(1, dtype=torch.float32, device=self.dev)
         train_metric = self.metric
         self.attach_metric(metric)  # allocates the argmax / nll rows on first use
         self._bind_micro(0)
         try:
-            for i in range(M):
-                self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S)
-                out.add_(self.t_loss[0:1], alpha=1.0 / M)
+            for i in range(npass):
+                if self.mm > 1:
+                    nseg = min(self.mm, M - i * self.mm)   # real micro-batches of this pass
+                    self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S, nseg)
+                    out.add_(self.t_loss_seg[:nseg, 0].sum(dim=0, keepdim=True), alpha=1.0 / M)
+                else:
+                    self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S)
+                    out.add_(self.t_loss[0:1], alpha=1.0 / M)
         finally:
             self.metric = train_metric
         return out
+
+    def _forward_backward_merged(self, batch, labels):
+        """merge_micro: the micro_num micro-batches of a step as ONE varlen pass over micro_num * packed_length tokens.  The
+        micro-batches are independent until their gradients are summed, so stacking their tokens changes nothing but the shapes:
+        every GEMM sees micro_num x the rows (whole rounds of 256x256 tiles on 256 CUs where 4096 tokens left 1.5 or 3.5, weights
+        streamed once per step instead of micro_num times), the weight gradient contracts over all tokens at once, attention walks
+        the concatenated cu_seqlens, the cross-entropy is normalised per micro-batch.  Gradients are summed in fp32 and rounded to
+        bf16 once (as with batch_wgrad)."""
+        tc, M, P = self.tc, self.mm, self.tc.packed_length
+        ids_d = batch["input_ids"].reshape(-1).to(self.dev, non_blocking=True)
+        lab_d = labels.reshape(-1).to(self.dev, non_blocking=True)
+        pos_d = batch["indexes"].reshape(-1).to(self.dev, non_blocking=True)
+        cus = batch["cu_seqlens"]
+        cu_h = torch.cat([cus[0].to(torch.int32)] + [cus[i][1:].to(torch.int32) + i * P for i in range(1, M)])
+        max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())
+        self._ensure_rotary(int(batch["indexes"].max()) + 1)
+        if self.metric is not None and self.metric.ntypes:
+            self.metric.set_current_type_ids(batch["type_ids"])
+        cu = cu_h.to(self.dev, non_blocking=True)
+        self._forward_micro(ids_d, lab_d, cu, pos_d, max_seqlen)
+        torch.sum(self.t_loss_seg[:, 0:1], dim=0, out=self.loss_acc)
+        self.loss_acc.mul_(1.0 / M)
+        self._backward_micro(ids_d, lab_d, cu, pos_d, max_seqlen, True, True)
+        return self.loss_acc
 
     # ------------------------------------------------------------------------------------------ optimizer
     def step(self):

@@ -189,7 +189,7 @@ def test_activation_checkpointing_is_bit_identical(dev, frac):
     for ck in (0.0, frac):
         cfg = tiny(256, 4, 4, 2, 512, 256, 2, 1e-3, 6)
         cfg.model.checkpoint = ck
-        eng = InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=False)  # per-micro-batch weight gradients on both sides
+        eng = InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=False, merge_micro=False)  # sequential micro-batches, per-micro-batch weight gradients on both sides
         assert eng.mc.checkpoint_layers == int(4 * ck)
         loader = iter(SyntheticLoader(256, 1, 2, False, 4000))  # ragged packed samples
         tr = []
@@ -216,8 +216,8 @@ def test_batched_weight_gradients_match_per_micro_batch_accumulation(dev):
     cfg = tiny(256, 3, 4, 2, 512, 128, 4, 1e-3, 6)
     cfg.train.micro_bsz = 2
     cfg.train.fixed_random_dataset_seqlen = False
-    engs = [InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=flag) for flag in (True, False)]
-    assert engs[0].batch_wgrad and not engs[1].batch_wgrad and InternLM2Engine(cfg, dev, init_fn=formula_init).batch_wgrad
+    engs = [InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=flag, merge_micro=False) for flag in (True, False)]
+    assert engs[0].batch_wgrad and not engs[1].batch_wgrad and InternLM2Engine(cfg, dev, init_fn=formula_init, merge_micro=False).batch_wgrad
     ora = OracleTrainer(cfg, torch.bfloat16)
     loader = iter(SyntheticLoader(128, 2, 4, False, 4000))
     for k in range(3):
@@ -245,6 +245,73 @@ def test_batched_weight_gradients_match_per_micro_batch_accumulation(dev):
     with pytest.raises(ValueError):
         cfg.model.checkpoint = 1.0
         InternLM2Engine(cfg, dev, batch_wgrad=True)
+
+
+def test_merged_micro_batches_match_sequential_accumulation(dev):
+    """merge_micro: the micro-batches of a step as one varlen pass (concatenated cu_seqlens, per-micro-batch cross-entropy
+    normalisation and metric) against the sequential gradient accumulation and the oracle: ragged packed rows with different
+    valid-token counts per micro-batch, dataset-type metric on; then the evaluation pass on the merged engine with a batch that
+    needs padding (3 micro-batches into a 4-micro-batch pass)."""
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader, ValidLoader, valid_datasets
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from oracle.model import formula_init
+    from oracle.step import OracleTrainer
+
+    cfg = tiny(256, 3, 4, 2, 512, 128, 4, 1e-3, 6)
+    cfg.train.micro_bsz = 2
+    cfg.train.fixed_random_dataset_seqlen = False
+    merged = InternLM2Engine(cfg, dev, init_fn=formula_init, merge_micro=True)
+    seq = InternLM2Engine(cfg, dev, init_fn=formula_init, batch_wgrad=False, merge_micro=False)
+    assert merged.mm == 4 and merged.T == 4 * 256 and not merged.batch_wgrad and seq.mm == 1
+    assert InternLM2Engine(cfg, dev).mm == 4, "on by default when the memory is there"
+    ms = [AccPerplex(dev, None, ["en", "cn", "code"]) for _ in range(2)]
+    merged.attach_metric(ms[0])
+    seq.attach_metric(ms[1])
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    loader = iter(SyntheticLoader(128, 2, 4, False, 4000))
+    for k in range(3):
+        batch, labels = next(loader)
+        batch["type_ids"] = (torch.arange(4 * 256).reshape(4, 256) // 100) % 3  # a dataset type per token, different per micro-batch
+        assert len({int((labels[i] != -100).sum()) for i in range(4)}) > 1, "micro-batches with different valid-token counts"
+        rows = []
+        for e in (merged, seq):
+            loss = e.forward_backward(batch, labels)
+            g = e.grads.float().clone() if k == 0 else None
+            e.step()
+            st = e.read_state()
+            rows.append((float(loss), float(st.grad_norm), g))
+        ref = ora.train_step(batch, labels)
+        (la, na, ga), (lb, nb, gb) = rows
+        if k == 0:
+            ga2 = torch.cat([ga[s_.offset : s_.offset + s_.numel] for s_ in merged.layout.params.values()])
+            gb2 = torch.cat([gb[s_.offset : s_.offset + s_.numel] for s_ in seq.layout.params.values()])
+            rel = float((ga2 - gb2).norm() / gb2.norm())
+            print(f"gradient: merged vs sequential relative difference {rel:.2e}")
+            assert rel < 4e-3
+        print(f"step {k}: merged {la:.5f}/{na:.4f}  sequential {lb:.5f}/{nb:.4f}  oracle {ref['loss']:.5f}/{ref['grad_norm']:.4f}")
+        assert abs(la - lb) <= 1e-4 * abs(lb) or k > 0
+        for l_, n_ in ((la, na), (lb, nb)):
+            assert abs(l_ - ref["loss"]) <= 3e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+        ma, mb = ms[0].get_metric(), ms[1].get_metric()
+        for key in mb:
+            assert abs(ma[key] - mb[key]) <= 2e-2 * max(abs(mb[key]), 1.0), (key, ma[key], mb[key])
+        assert ma["tokens/en"] == mb["tokens/en"] and ma["tokens/code"] == mb["tokens/code"]
+    # evaluation on the merged engine: 6 rows = 3 micro-batches of 2 rows -> one padded pass
+    vl = ValidLoader(valid_datasets(128, False, 1)["val"], 128, 2, 3)
+    b, y = next(iter(vl))
+    assert b["input_ids"].shape[0] == 6
+    m_hip = AccPerplex(dev, None, None)
+    got = float(merged.forward_only(b["input_ids"], y, m_hip))
+    want_seq = float(seq.forward_only(b["input_ids"], y, AccPerplex(dev, None, None)))
+    print(f"eval: merged {got:.5f}  sequential {want_seq:.5f}")
+    assert abs(got - want_seq) <= 2e-3 * abs(want_seq)
+    a = m_hip.get_metric()
+    assert 0.0 <= a["acc"] <= 1.0 and a["perplexity"] > 1.0
+    with pytest.raises(ValueError):
+        cfg.model.checkpoint = 1.0
+        InternLM2Engine(cfg, dev, merge_micro=True)
 
 
 @pytest.mark.timeout(1500)
