@@ -191,6 +191,8 @@ def main():
                                f"ZeRO-1 over dp{world}, AdamW + dynamic loss scale + grad clip 1.0" if args.config == "7B_internlm2"
                                else "configs/7B_llama2.py (BASELINE.json configs[2]'s model, tensor size 1 as shipped): LLaMA2-7B, vocab 32000" if args.config == "7B_llama2"
                                else "tiny InternLM2 (hidden 512, 2 layers)",
+                   "micro_batch_execution": ("merged: the micro_num micro-batches of a step run as one varlen pass" if eng.mm > 1 else
+                                             "sequential gradient accumulation" + (", weight gradients batched over the micro-batches" if eng.batch_wgrad else "")),
                    "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
