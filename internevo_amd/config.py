@@ -7,7 +7,6 @@ Anything the path does not implement (pipeline parallel, MoE ...) is rejected lo
 instead of being ignored.
 """
 import dataclasses
-import math
 import runpy
 from typing import Optional
 

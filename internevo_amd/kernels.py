@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import IE_BF16, IE_F32, IeScalerConfig, IeStepState, InternEvoHipError, check
+from ._lib import IE_BF16, IE_F32, IeScalerConfig, IeStepState, InternEvoHipError, check  # noqa: F401  (InternEvoHipError re-exported for callers)
 
 _DT = {torch.bfloat16: IE_BF16, torch.float32: IE_F32}
 
