@@ -140,3 +140,30 @@ def test_train_entry_validates_every_n_steps(dev, tmp_path):
     cfg2.write_text(text)
     run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
     assert [r["loss"] for r in run] == [r["loss"] for r in run2] and [r["grad_norm"] for r in run] == [r["grad_norm"] for r in run2]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_line_contract(dev):
+    """`python bench.py` prints ONE JSON line with the driver's keys, the roofline object of the dominant kernel and the CPU baseline
+    (here on the tiny plumbing config so that it takes seconds; the driver runs the default = configs[1], InternLM2-7B)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1"], capture_output=True,
+                         text=True, timeout=500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "tokens/s" and d["dtype"] == "bf16" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["tokens_per_step"]) <= 1e-6 * d["config"]["tokens_per_step"]
+    r = d["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["launches"] > 0
+    c = d["cpu_baseline"]
+    assert set(c) >= {"value", "unit", "cores", "kind", "sample"} and c["kind"] == "port" and c["unit"] == "tokens/s" and c["value"] > 0 and c["cores"] >= 1
