@@ -19,6 +19,17 @@ What it pins
                        bf16, with weights set by the closed-form init of oracle/model.py:formula_init
                        -> oracle/model.py + oracle/step.py must reproduce them.
 
+  ckpt_ref/ + ckpt.json        (--ckpt)  model / optimizer / plan / topo / schedulder / sampler / context files written by the reference's own
+                       writers after 2 steps of a tiny bf16 run, and the 2 steps it trained afterwards
+  ckpt_ref_dp2/ + ckpt_dp2.json (--ckpt-mp)  the same on 2 data-parallel ranks (gloo): one ZeRO-1 optimizer shard + plan per rank
+  ckpt_load.json       (--ckpt-load)  the other direction: the oracle trains, internevo_amd/checkpoint.py writes, the REAL reference resumes
+                       with its own loaders (model, context, optimizer, scheduler, sampler) and keeps training
+  sched_state.json     (--sched)  state_dict() of the real FineTuneCosineAnnealingWarmupLR after n steps
+  data_folder.json     (--data-folder)  first batches of the tokenized train_folder pipeline over folder_fixture.py's deterministic folder
+  eval.json            (--eval)  evaluate_on_val_dls of the reference on its default validation set, on two sets of weights
+  train_isp2_*.json    (--run-mp isp2_*)  2-process ISP runs (kept for the record: the reference's unpacked CPU path bypasses
+                       DistributedAttention)
+
 The CPU accelerator shim is the one described in SURVEY.md section 8(c): the reference has no CPU backend,
 so the cached CUDA_Accelerator instance is re-pointed at torch CPU calls before launch().
 """
