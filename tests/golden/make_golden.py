@@ -27,8 +27,8 @@ What it pins
   sched_state.json     (--sched)  state_dict() of the real FineTuneCosineAnnealingWarmupLR after n steps
   data_folder.json     (--data-folder)  first batches of the tokenized train_folder pipeline over folder_fixture.py's deterministic folder
   eval.json            (--eval)  evaluate_on_val_dls of the reference on its default validation set, on two sets of weights
-  train_isp2_*.json    (--run-mp isp2_*)  2-process ISP runs (kept for the record: the reference's unpacked CPU path bypasses
-                       DistributedAttention)
+  (--run-mp isp2_*)    2-process ISP runs of the reference; their output is NOT committed: the reference's unpacked CPU path bypasses
+                       DistributedAttention, so they pin nothing about the sequence-parallel exchange (scope row a19)
 
 The CPU accelerator shim is the one described in SURVEY.md section 8(c): the reference has no CPU backend,
 so the cached CUDA_Accelerator instance is re-pointed at torch CPU calls before launch().
