@@ -180,6 +180,52 @@ class PackedDatasetWithCut:
         }
 
 
+class PackedDatasetWithoutCuSeqlen:
+    """packed_dataset.py:70-202 (`data.pack_sample_into_one = True`): the shuffled documents are laid end to end and cut into packs
+    of packed_length tokens; a pack is presented as packed_length / seq_len sequences of exactly seq_len tokens (cu_seqlens at
+    multiples of seq_len, positions restarting with them) whatever the document boundaries are; a document piece's last label
+    is -100 even when the document continues in the next pack."""
+
+    def __init__(self, dataset, max_length_per_sample=2048, packed_length=4096):
+        assert packed_length % max_length_per_sample == 0
+        self.dataset = dataset
+        self.max_length_per_sample, self.packed_length = max_length_per_sample, packed_length
+        self.bsz = packed_length // max_length_per_sample
+        self.lengths = dataset.lengths
+        rng = np.random.RandomState(DEFAULT_SEED)
+        self.indices = np.arange(len(self.lengths))
+        rng.shuffle(self.indices)
+        self.cum_lens = np.cumsum(self.lengths[self.indices])
+        self.num_tokens = int(self.lengths.sum())
+
+    def __len__(self):
+        return self.num_tokens // self.packed_length
+
+    def _find_offset(self, offset):
+        idx = int(np.searchsorted(self.cum_lens, offset, side="right"))
+        return (idx, offset) if idx == 0 else (idx, int(offset - self.cum_lens[idx - 1]))
+
+    def __getitem__(self, item):
+        s_idx, s_len = self._find_offset(item * self.packed_length)
+        e_idx, e_len = self._find_offset((item + 1) * self.packed_length)
+        pieces = []
+        if s_idx == e_idx:
+            pieces.append(self.dataset.tokens(int(self.indices[s_idx]), s_len, e_len))
+        else:
+            pieces.append(self.dataset.tokens(int(self.indices[s_idx]), s_len))
+            pieces += [self.dataset.tokens(int(self.indices[i])) for i in range(s_idx + 1, e_idx)]
+            if e_len:
+                pieces.append(self.dataset.tokens(int(self.indices[e_idx]), 0, e_len))
+        S = self.max_length_per_sample
+        return {
+            "tokens": np.concatenate(pieces),
+            "labels": np.concatenate([np.concatenate([p[1:], np.array([-100], dtype=np.int64)]) for p in pieces]),
+            "cu_seqlens": np.arange(self.bsz + 1, dtype=np.int32) * S,
+            "indexes": np.tile(np.arange(S, dtype=np.int64), self.bsz),
+            "type_ids": np.full(self.packed_length, getattr(self.dataset, "type_id", 0), dtype=np.int64),
+        }
+
+
 class ConcatPacked:
     """torch.utils.data.ConcatDataset over the per-file packed datasets."""
 
@@ -200,9 +246,10 @@ def dataset_type_ids_map(folder):
     return {key: idx for idx, key in enumerate(sorted(os.listdir(folder)))}
 
 
-def build_folder_dataset(folder, max_length_per_sample, packed_length, min_length=0, min_length_dict=None):
-    """packed_dataset.py:393-480 (pack_sample_into_one=False): every .bin under `folder`, walked top-down with sorted directory
-    and file names, becomes a JsonlDataset -> PackedDatasetWithCut; files left empty by the length filter are skipped."""
+def build_folder_dataset(folder, max_length_per_sample, packed_length, min_length=0, min_length_dict=None, pack_sample_into_one=False):
+    """packed_dataset.py:393-480: every .bin under `folder`, walked top-down with sorted directory
+    and file names, becomes a JsonlDataset -> PackedDatasetWithCut (PackedDatasetWithoutCuSeqlen with pack_sample_into_one); files left empty by the
+    length filter are skipped."""
     assert os.path.exists(folder), f"{folder} does not exist."
     type_map = dataset_type_ids_map(folder)
     packed = []
@@ -222,7 +269,7 @@ def build_folder_dataset(folder, max_length_per_sample, packed_length, min_lengt
             ds = JsonlDataset(fp, match[0], min_length=ml)
             if len(ds) == 0:
                 continue
-            packed.append(PackedDatasetWithCut(ds, max_length_per_sample, packed_length))
+            packed.append((PackedDatasetWithoutCuSeqlen if pack_sample_into_one else PackedDatasetWithCut)(ds, max_length_per_sample, packed_length))
     return ConcatPacked(packed)
 
 
@@ -289,9 +336,10 @@ def packed_collate(items, packed_length):
 class FolderLoader:
     """build_dataloader.py:26-66 for data.train_folder = <tokenized folder>: the same sampler and collate over the packed files."""
 
-    def __init__(self, folder, seq_len, micro_bsz, micro_num, min_length=0, min_length_dict=None, data_rank=0, data_world_size=1, seed=1024):
+    def __init__(self, folder, seq_len, micro_bsz, micro_num, min_length=0, min_length_dict=None, data_rank=0, data_world_size=1, seed=1024,
+                 pack_sample_into_one=False):
         self.packed_length = seq_len * micro_bsz
-        self.ds = build_folder_dataset(folder, seq_len, self.packed_length, min_length, min_length_dict)
+        self.ds = build_folder_dataset(folder, seq_len, self.packed_length, min_length, min_length_dict, pack_sample_into_one)
         self.dataset_types = list(dataset_type_ids_map(folder).keys())
         self.sampler = StaticBatchSampler(len(self.ds), micro_num, seed, data_rank, data_world_size)
 

@@ -842,7 +842,8 @@ def gen_data_folder():
     root = tempfile.mkdtemp(prefix="ie_folder_")
     write_folder(root)
     res = {}
-    for seq_len, micro_bsz, micro_num, min_length, mld in ((64, 2, 3, 5, None), (128, 1, 2, 0, None), (32, 2, 2, 10, {"en/c": 60})):
+    for seq_len, micro_bsz, micro_num, min_length, mld, into_one in ((64, 2, 3, 5, None, False), (128, 1, 2, 0, None, False),
+                                                                     (32, 2, 2, 10, {"en/c": 60}, False), (32, 4, 2, 5, None, True)):
 
         class _G:  # the only gpc members the pipeline touches
             config = None
@@ -876,7 +877,7 @@ def gen_data_folder():
             def get_rank():
                 return 0
 
-        data_cfg = Config(dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=micro_bsz, packed_length=seq_len * micro_bsz, pack_sample_into_one=False,
+        data_cfg = Config(dict(seq_len=seq_len, micro_num=micro_num, micro_bsz=micro_bsz, packed_length=seq_len * micro_bsz, pack_sample_into_one=into_one,
                                rampup_batch_size="", train_folder=root, type="tokenized", use_packed_dataset=True, min_length=min_length,
                                min_length_dict=mld))
         old = (bdl.gpc, bs.gpc, pdm.gpc, pdm.dist, bdl.dist)
@@ -892,8 +893,8 @@ def gen_data_folder():
                 batches.append({"idx": [int(i) for i in idx], "input_ids": b["input_ids"].tolist(), "labels": y.tolist(),
                                 "cu_seqlens": [c.tolist() for c in b["cu_seqlens"]], "indexes": b["indexes"].tolist(),
                                 "type_ids": b["type_ids"].tolist()})
-            res[f"seq{seq_len}_mbsz{micro_bsz}_mnum{micro_num}_min{min_length}" + ("_dict" if mld else "")] = {
-                "seq_len": seq_len, "micro_bsz": micro_bsz, "micro_num": micro_num, "min_length": min_length, "min_length_dict": mld,
+            res[f"seq{seq_len}_mbsz{micro_bsz}_mnum{micro_num}_min{min_length}" + ("_dict" if mld else "") + ("_intoone" if into_one else "")] = {
+                "pack_sample_into_one": into_one, "seq_len": seq_len, "micro_bsz": micro_bsz, "micro_num": micro_num, "min_length": min_length, "min_length_dict": mld,
                 "len_ds": len(ds), "len_files": [len(d) for d in ds.datasets], "batches": batches,
                 "files": [os.path.relpath(str(d.dataset.resolved_path), os.path.realpath(root)) for d in ds.datasets],
                 "dataset_types": list(bdl.get_dataset_type_ids_map(root).keys())}

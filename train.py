@@ -79,8 +79,9 @@ def main(argv=None, log=print):
     tc, mc = cfg.train, cfg.model
     data_raw = raw.get("data", {}) or {}
     train_folder = _local(data_raw.get("train_folder", None))
-    if data_raw.get("pack_sample_into_one", False):
-        raise NotImplementedError("data.pack_sample_into_one = True (PackedDatasetWithoutCuSeqlen) is not on the packed flash path")
+    into_one = bool(data_raw.get("pack_sample_into_one", False))
+    if into_one and not train_folder:
+        raise NotImplementedError("data.pack_sample_into_one needs a tokenized train_folder (the reference's RandomDataset has no type_id for it)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,7 +112,7 @@ def main(argv=None, log=print):
         from internevo_amd.data import FolderLoader
 
         loader_obj = FolderLoader(train_folder, tc.seq_len, tc.micro_bsz, tc.micro_num, data_raw.get("min_length", 0), data_raw.get("min_length_dict", None),
-                                  data_rank=eng.seqpar.data_rank, data_world_size=dp_world, seed=data_raw.get("seed", 1024))
+                                  data_rank=eng.seqpar.data_rank, data_world_size=dp_world, seed=data_raw.get("seed", 1024), pack_sample_into_one=into_one)
         dataset_types = loader_obj.dataset_types
     else:
         loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
