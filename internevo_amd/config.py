@@ -154,6 +154,27 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise ValueError(f'model.checkpoint: "{ck}" should >=0 and <=1')  # launch.py:300-303
     if not m.get("no_bias", True):
         raise NotImplementedError(f"{_UNSUPPORTED}: linear bias")
+    # settings that change the arithmetic of the step: refuse them instead of training something else than the config describes
+    if cfg.get("use_fp32_norm", False):
+        raise NotImplementedError(f"{_UNSUPPORTED}: use_fp32_norm (the norms run on bf16 activations with fp32 statistics)")
+    if m.get("norm_type", "rmsnorm") != "rmsnorm":
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.norm_type {m.get('norm_type')!r} (rmsnorm only)")
+    if m.get("apply_post_layer_norm", False):
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.apply_post_layer_norm")
+    if m.get("embed_grad_scale", 1) != 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.embed_grad_scale != 1")
+    if m.get("num_chunks", 1) != 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.num_chunks != 1 (interleaved pipeline stages)")
+    for key in ("drop_rate", "attn_drop_rate", "dropout"):
+        if m.get(key, 0):
+            raise NotImplementedError(f"{_UNSUPPORTED}: model.{key} > 0 (the path trains without dropout)")
+    if m.get("multiple_of", 256) != 256:
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.multiple_of != 256")
+    if d.get("rampup_batch_size", "") or d.get("skip_batches", ""):
+        raise NotImplementedError(f"{_UNSUPPORTED}: data.rampup_batch_size / data.skip_batches")
+    zero1 = par.get("zero1", {})
+    if isinstance(zero1, dict) and zero1.get("fsdp", False):
+        raise NotImplementedError(f"{_UNSUPPORTED}: parallel.zero1.fsdp")
     if _parse_dtype(m.get("dtype", "torch.bfloat16")) != "torch.bfloat16":
         raise NotImplementedError(f"{_UNSUPPORTED}: the HIP path computes in bf16")
     model = ModelConfig(

@@ -75,6 +75,18 @@ def test_reference_config_files_map(tmp_path):
     msp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="msp"), pipeline=dict(size=1))
     with pytest.raises(NotImplementedError):
         from_reference_dict(msp)
+    # settings that would change the arithmetic are refused, not silently ignored
+    for path, value in ((("use_fp32_norm",), True), (("model", "norm_type"), "layernorm"), (("model", "apply_post_layer_norm"), True),
+                        (("model", "embed_grad_scale"), 0.1), (("model", "num_chunks"), 2), (("model", "attn_drop_rate"), 0.1),
+                        (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"), (("data", "skip_batches"), "1-3"),
+                        (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False)):
+        c = copy.deepcopy(g)
+        node = c
+        for k in path[:-1]:
+            node = node[k]
+        node[path[-1]] = value
+        with pytest.raises(NotImplementedError):
+            from_reference_dict(c)
     from internevo_amd.config import ModelConfig
     from internevo_amd.layout import FlatLayout
 
