@@ -77,8 +77,8 @@ def cpu_baseline(cfg, budget_note=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="7B_internlm2", choices=["7B_internlm2", "7B_llama2", "tiny"])
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
