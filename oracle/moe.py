@@ -1,0 +1,109 @@
+"""CPU oracle of the GShard MoE layer's routing arithmetic -- TEST INFRASTRUCTURE ONLY, prepared ahead
+of the HIP path (no product code imports it; round 1 ships no MoE kernels).
+
+Restates internlm/model/moe/gshard_layer.py in INDEX form -- what a gather / scatter implementation works with -- instead of the
+reference's one-hot masks and O(S*E*C*M) einsums:
+
+    top2gating   :217-285   softmax over experts, first expert = argmax of the gates, second = argmax of (logits + Gumbel noise) with
+                            the first masked out, slot of a token in its expert's capacity buffer = its rank among the tokens that
+                            chose the expert (second choices queue behind ALL first choices of that expert), tokens whose slot is
+                            past the capacity are dropped, the two gate values are renormalised over what survived, the auxiliary
+                            loss l_aux = mean_e(mean_s gates * mean_s first-choice mask) * E^2 uses the masks BEFORE the drop.
+    _capacity    :113-122   ceil(S / E * capacity_factor [* 2 for top-2]) clamped from below by min_capacity.
+    dispatch     :446-448   dispatched[e, c] = the token that holds slot c of expert e (zeros where nobody does).
+    combine      :482-486   out[s] = sum over the token's surviving choices of gate weight * expert_output[e, slot].
+
+The Gumbel noise of the second choice comes from the device RNG in the reference (:233-238): callers pass it in, so that oracle,
+reference (patched `gumbel_rsample`) and a future kernel see the same numbers.  Pinned by tests/golden/moe.npz
+(tests/golden/make_golden.py --moe runs the real top2gating and the reference's dispatch / combine einsums)."""
+import math
+
+import torch
+
+
+def capacity(num_tokens, num_experts, capacity_factor, min_capacity):
+    """gshard_layer.py:113-122 (torch: a float32 division, then ceil)."""
+    c = int(torch.ceil(torch.tensor(num_tokens / num_experts) * torch.tensor(capacity_factor)).to(torch.int64))
+    return max(c, int(min_capacity))
+
+
+def top2gating(logits, capacity_factor, min_capacity, noise):
+    """logits, noise: fp32 [S, E].  -> dict with
+        l_aux (fp32 scalar), capacity (int), exp_counts int64 [E] (first choices per expert, before the drop),
+        expert int64 [2, S], slot int64 [2, S] (-1 = dropped), weight fp32 [2, S] (0 when dropped)."""
+    logits = logits.float()
+    S, E = logits.shape
+    gates = torch.softmax(logits, dim=1)
+    cap = capacity(S, E, capacity_factor * 2, min_capacity)
+    e1 = torch.argmax(gates, dim=1)
+    masked = (logits + noise).clone()
+    masked[torch.arange(S), e1] = torch.finfo(logits.dtype).min
+    e2 = torch.argmax(masked, dim=1)
+    # rank of a token among the tokens that picked the same expert, in token order
+    first_counts = torch.bincount(e1, minlength=E)
+    pos1 = torch.empty(S, dtype=torch.int64)
+    pos2 = torch.empty(S, dtype=torch.int64)
+    seen1 = [0] * E
+    seen2 = [0] * E
+    for s in range(S):
+        a, b = int(e1[s]), int(e2[s])
+        pos1[s] = seen1[a]
+        seen1[a] += 1
+        pos2[s] = seen2[b] + int(first_counts[b])
+        seen2[b] += 1
+    me = gates.mean(dim=0)
+    ce = torch.nn.functional.one_hot(e1, E).to(logits.dtype).mean(dim=0)
+    l_aux = torch.mean(me * ce) * E * E
+    keep1, keep2 = pos1 < cap, pos2 < cap
+    g1 = torch.where(keep1, gates[torch.arange(S), e1], torch.zeros(S))
+    g2 = torch.where(keep2, gates[torch.arange(S), e2], torch.zeros(S))
+    denom = torch.clamp(g1 + g2, min=torch.finfo(logits.dtype).eps)
+    return dict(l_aux=l_aux, capacity=cap, exp_counts=first_counts,
+                expert=torch.stack([e1, e2]), slot=torch.stack([torch.where(keep1, pos1, torch.full_like(pos1, -1)),
+                                                                torch.where(keep2, pos2, torch.full_like(pos2, -1))]),
+                weight=torch.stack([g1 / denom, g2 / denom]))
+
+
+def combine_weights_dense(r, num_experts):
+    """The reference's [S, E, C] combine_weights tensor from the index form (for comparison only)."""
+    S = r["expert"].shape[1]
+    out = torch.zeros(S, num_experts, r["capacity"])
+    for k in range(2):
+        for s in range(S):
+            c = int(r["slot"][k, s])
+            if c >= 0:
+                out[s, int(r["expert"][k, s]), c] += r["weight"][k, s]
+    return out
+
+
+def dispatch(x, r, num_experts):
+    """[S, M] tokens -> [E, C, M] expert buffers (gshard_layer.py:446-448 `sec,sm->ecm` with the boolean dispatch mask).
+    The mask is combine_weights != 0: a surviving choice whose renormalised weight is exactly 0 is NOT dispatched."""
+    out = torch.zeros(num_experts, r["capacity"], x.shape[1], dtype=x.dtype)
+    for k in range(2):
+        for s in range(x.shape[0]):
+            c = int(r["slot"][k, s])
+            if c >= 0 and float(r["weight"][k, s]) != 0.0:
+                out[int(r["expert"][k, s]), c] += x[s]
+    return out
+
+
+def combine(expert_out, r):
+    """[E, C, M] expert outputs -> [S, M] (gshard_layer.py:482-486 `sec,ecm->sm`, weights cast to the activation dtype)."""
+    S = r["expert"].shape[1]
+    out = torch.zeros(S, expert_out.shape[2], dtype=torch.float32)
+    for k in range(2):
+        for s in range(S):
+            c = int(r["slot"][k, s])
+            if c >= 0:
+                w = r["weight"][k, s].to(expert_out.dtype).float()
+                out[s] += w * expert_out[int(r["expert"][k, s]), c].float()
+    return out.to(expert_out.dtype)
+
+
+def gumbel_noise(shape, seed):
+    """Deterministic stand-in for torch.distributions.Gumbel(0, 1).rsample (gshard_layer.py:63-70), same construction:
+    -log(-log(u)) with u uniform on the open interval."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(shape, generator=g).clamp_(min=torch.finfo(torch.float32).tiny, max=1.0 - math.ulp(1.0) / 2)
+    return -torch.log(-torch.log(u))

@@ -26,6 +26,8 @@ What it pins
                        with its own loaders (model, context, optimizer, scheduler, sampler) and keeps training
   sched_state.json     (--sched)  state_dict() of the real FineTuneCosineAnnealingWarmupLR after n steps
   data_folder.json     (--data-folder)  first batches of the tokenized train_folder pipeline over folder_fixture.py's deterministic folder
+  moe.npz / moe.json   (--moe)  the reference's top2gating + dispatch / combine einsums with injected Gumbel noise -> oracle/moe.py (groundwork
+                       for SURVEY 8f rank 2; no product code yet)
   eval.json            (--eval)  evaluate_on_val_dls of the reference on its default validation set, on two sets of weights
   (--run-mp isp2_*)    2-process ISP runs of the reference; their output is NOT committed: the reference's unpacked CPU path bypasses
                        DistributedAttention, so they pin nothing about the sequence-parallel exchange (scope row a19)
@@ -748,6 +750,47 @@ def gen_eval(port=29798):
     print("eval.json written")
 
 
+def gen_moe():
+    """The reference's own top2gating (gshard_layer.py:217-285) and its dispatch / combine einsums (:446-448, :482-486) on seeded
+    logits with the Gumbel noise injected (gumbel_rsample patched to return oracle.moe.gumbel_noise) -> moe.npz / moe.json.
+    Cases: balanced, a capacity that drops tokens, min_capacity binding, ties between experts, a single hot expert."""
+    shim_cpu_accelerator()
+    import internlm.model.moe.gshard_layer as gl
+
+    from oracle.moe import gumbel_noise
+
+    arrays, meta = {}, []
+    g = torch.Generator().manual_seed(11)
+    cases = [("balanced", 64, 4, 1.0, 4, 1.0), ("drops", 96, 8, 0.5, 2, 3.0), ("min_capacity", 24, 8, 1.0, 16, 1.0),
+             ("hot_expert", 80, 4, 1.0, 4, 0.0), ("ties", 40, 4, 1.25, 4, None)]
+    for k, (name, S, E, cf, mincap, spread) in enumerate(cases):
+        if spread is None:  # exact ties: logits drawn from a 3-value set
+            logits = torch.randint(0, 3, (S, E), generator=g).float()
+        elif spread == 0.0:  # everybody's first choice is expert 1
+            logits = torch.randn(S, E, generator=g) * 0.1
+            logits[:, 1] += 5.0
+        else:
+            logits = torch.randn(S, E, generator=g) * spread
+        noise = gumbel_noise((S, E), 100 + k)
+        gl.gumbel_rsample = lambda shape, device, _n=noise: _n
+        l_aux, cw, dm, counts = gl.top2gating(logits.clone(), cf, mincap)
+        M = 16
+        x = torch.randn(S, M, generator=g)
+        disp = gl.einsum("sec,sm->ecm", dm.type_as(x), x)
+        expert_out = torch.tanh(disp) * (1.0 + torch.arange(E, dtype=torch.float32).reshape(E, 1, 1))  # a different "expert" per e
+        comb = gl.einsum("sec,ecm->sm", cw.type_as(x), expert_out)
+        for key, t in (("logits", logits), ("noise", noise), ("combine_weights", cw), ("x", x), ("dispatched", disp), ("expert_out", expert_out),
+                       ("combined", comb)):
+            arrays[f"{name}.{key}"] = t.numpy()
+        arrays[f"{name}.exp_counts"] = counts.numpy()
+        meta.append(dict(name=name, S=S, E=E, capacity_factor=cf, min_capacity=mincap, l_aux=float(l_aux), capacity=int(cw.shape[2]),
+                         dropped=int(2 * S - int(dm.sum()))))
+        print("moe", meta[-1], flush=True)
+    np.savez_compressed(os.path.join(HERE, "moe.npz"), **arrays)
+    with open(os.path.join(HERE, "moe.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_sched_state():
     """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
     wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
@@ -942,6 +985,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-mp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 2 and sys.argv[1] == "--moe":
+        gen_moe()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--eval":
         gen_eval()
         sys.exit(0)
@@ -955,7 +1001,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--ckpt", "--ckpt-mp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--ckpt", "--ckpt-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])
