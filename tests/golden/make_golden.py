@@ -183,7 +183,7 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 #                     shrinks ONLY that count (host time/RAM), everything else is the unmodified pipeline.
 
 
-def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC"):
+def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1):
     return dict(
         JOB_NAME="golden",
         model_type=model_type,
@@ -203,7 +203,7 @@ def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, laye
         model=dict(checkpoint=False, num_chunks=1, num_attention_heads=heads, embed_split_hidden=True, vocab_size=vocab, embed_grad_scale=1,
                    parallel_output=False, hidden_size=hidden, num_layers=layers, no_bias=True, mlp_ratio=3.5, apply_post_layer_norm=False,
                    dtype=dtype, norm_type="rmsnorm", layer_norm_epsilon=1e-5, num_kv_attention_heads=kv_heads, use_flash_attn=False),
-        parallel=dict(zero1=dict(size=-1), tensor=dict(size=sp, mode="isp" if sp > 1 else "mtp"), pipeline=dict(size=1, interleaved_overlap=True),
+        parallel=dict(zero1=dict(size=-1), tensor=dict(size=sp if sp > 1 else tp, mode="isp" if sp > 1 else "mtp"), pipeline=dict(size=1, interleaved_overlap=True),
                       weight=dict(size=wp, overlap=False, memory_pool=False)),
         cudnn_deterministic=False, cudnn_benchmark=False,
         monitor=dict(alert=dict(enable_feishu_alert=False, feishu_alert_address=None, light_monitor_address=None, alert_file_path="/tmp/alert.log"),
@@ -311,9 +311,30 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
         full_shapes = param_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
                                                num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]))
         tp_rank, wp_rank = gpc.get_local_rank(ParallelMode.TENSOR), gpc.get_local_rank(ParallelMode.WEIGHT)
+    tp = cfg_kw.get("tp", 1)
     with torch.no_grad():
         for name, p in inner.named_parameters():
-            if world > 1:
+            if world > 1 and tp > 1:
+                # Megatron tensor parallelism: the layer weights cut by THIS REPO's rule (internevo_amd/tensorpar.py:shard -- the run
+                # reproducing the single-rank trajectory is what pins it); embedding over the hidden dim (embed_split_hidden) and
+                # head over the vocabulary as the reference's modules hold them
+                from internevo_amd.layout import FlatLayout
+                from internevo_amd.tensorpar import TensorParallel
+
+                full = formula_init(name, full_shapes[name])
+                if name == "tok_embeddings.weight":
+                    part = full[:, tp_rank * (full.shape[1] // tp) : (tp_rank + 1) * (full.shape[1] // tp)]
+                elif name == "output.weight":
+                    part = full[tp_rank * (full.shape[0] // tp) : (tp_rank + 1) * (full.shape[0] // tp)]
+                else:
+                    kind = FlatLayout(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
+                                                  num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]), 1).params[name].kind
+                    t = TensorParallel.__new__(TensorParallel)
+                    t.tp, t.tp_rank = tp, tp_rank
+                    part = t.shard(kind, full)
+                assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
+                p.copy_(part.to(p.dtype))
+            elif world > 1:
                 p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, tp_rank, sp, wp_rank, wp, full_shapes).to(p.dtype))
             else:
                 p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
@@ -653,6 +674,9 @@ RUNS = {
 }
 # two-process runs of the reference's ISP mode (configs/7B_isp_sft.py shape: tensor=dict(size=sp, mode="isp"), weight=dict(size=wp))
 RUNS_MP = {
+    # two-process Megatron tensor parallelism (parallel.tensor = dict(size=2, mode="mtp")), same model / data as pin_*: must retrace them
+    "tp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2), 2),
+    "tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2), 2),
     "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
 }
