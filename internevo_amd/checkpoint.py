@@ -62,6 +62,34 @@ def zero_flat_order(named_shapes):
     return sorted(named_shapes, key=lambda kv: numel(kv[1]), reverse=True)
 
 
+def tp_split_dim(name):
+    """The dimension along which the reference's Megatron tensor parallelism cuts a parameter (None = replicated): embedding over
+    the hidden dim (embed_split_hidden), head and the column-parallel wqkv (wq / wk / wv) / w1 / w3 over output rows, the
+    row-parallel wo / w2 over input columns; norms whole.  The layer rules are internevo_amd/tensorpar.py:shard's, pinned on a real
+    2-rank mtp run (tests/golden/train_tp2_*.json) and on its checkpoint files (tests/golden/ckpt_ref_tp2/)."""
+    if name == "tok_embeddings.weight":
+        return 1
+    if name == "output.weight" or name.endswith(("attention.wqkv.weight", "attention.wq.weight", "attention.wk.weight", "attention.wv.weight",
+                                                 "feed_forward.w1.weight", "feed_forward.w3.weight")):
+        return 0
+    if name.endswith(("attention.wo.weight", "feed_forward.w2.weight")):
+        return 1
+    return None
+
+
+def tp_shard(name, full, tp_rank, tp_world):
+    d = tp_split_dim(name)
+    if tp_world == 1 or d is None:
+        return full
+    n = full.shape[d] // tp_world
+    return full.narrow(d, tp_rank * n, n)
+
+
+def tp_unshard(name, parts):
+    d = tp_split_dim(name)
+    return parts[0] if len(parts) == 1 or d is None else torch.cat(list(parts), dim=d)
+
+
 def zero_partition(ordered, zero_world):
     """ordered: zero_flat_order(...) output.  -> per rank the list of indices into `ordered` (greedy: next-largest parameter to
     the rank with the fewest elements, first such rank on ties; hybrid_zero_optim.py:254-284)."""
@@ -137,18 +165,20 @@ def _load(path):
 
 
 def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16,
-                    zero_world=1, zero_ranks=None, write_model=True, shapes=None):
+                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0):
     """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
     hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr").
     zero_world > 1: one optimizer + plan file per rank in `zero_ranks` (default: all); the state dicts then only need the
     parameters those ranks own (zero_rank_names).  write_model=False skips the model / topology files (the reference writes them
-    from data-parallel rank 0 only) and `params` may then be None if `shapes` (name -> shape, module order) is given."""
+    from data-parallel rank 0 only) and `params` may then be None if `shapes` (name -> shape, module order) is given.
+    tp_world > 1: the tensors are tensor-parallel rank `tp_rank`'s LOCAL parts (tp_shard); the files carry that rank in their names
+    and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself."""
     os.makedirs(folder, exist_ok=True)
     order = state_dict_order(model_cfg)
     if write_model:
         sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
-        torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
-        torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
+        torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp0.pt"))
+        torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_pp0.json"))
     if shapes is None:
         shapes = {n: tuple(params[n].shape) for n in order}
     flat_order = zero_flat_order([(n, tuple(shapes[n])) for n in order])
@@ -179,25 +209,31 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
                 "flat_fp32_weights": {0: flat(master)},
                 "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
             }
-            torch.save(states, os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt"))
-            torch.save(plan, os.path.join(folder, f"gpus-{zero_world}_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt"))
+            torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp0_zo{r}.pt"))
+            torch.save(plan, os.path.join(folder, f"gpus-{zero_world * tp_world}_wp-0_tp-{tp_rank}_dp-{r}_pp-0_zo-{r}.pt"))
 
 
-def saved_zero_world(folder):
-    """Number of ZeRO-1 optimizer shards in the folder (components.py:294-306 counts them the same way); 0 = weights only."""
-    n = 0
+def saved_zero_world(folder, tp_rank=0):
+    """Number of ZeRO-1 optimizer shards of a tensor rank in the folder (components.py:294-306 counts them the same way); 0 = weights only."""
+    n, pre = 0, f"optimizer_tp{tp_rank}_pp0_zo"
     for fn in os.listdir(folder):
-        if fn.startswith("optimizer_tp0_pp0_zo") and fn.endswith(".pt"):
-            n = max(n, int(fn[len("optimizer_tp0_pp0_zo"):-3]) + 1)
+        if fn.startswith(pre) and fn.endswith(".pt"):
+            n = max(n, int(fn[len(pre):-3]) + 1)
     return n
 
 
-def load_checkpoint(folder, model_cfg, want=None):
-    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr, zero_world).  Optimizer entries are
-    None when the folder holds model weights only.  All optimizer shards in the folder are read and merged (whatever ZeRO world
-    wrote them); `want` (a set of names) limits the optimizer tensors kept in memory to those parameters."""
+def saved_tp_world(folder):
+    n = 0
+    for fn in os.listdir(folder):
+        if fn.startswith("model_tp") and fn.endswith("_pp0.pt"):
+            n = max(n, int(fn[len("model_tp"):-len("_pp0.pt")]) + 1)
+    return n
+
+
+def _load_tp_rank(folder, model_cfg, t, tp_world, want):
+    """One tensor rank's files -> its LOCAL named tensors (all its ZeRO shards merged)."""
     order = state_dict_order(model_cfg)
-    sd = torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False)
+    sd = torch.load(os.path.join(folder, f"model_tp{t}_pp0.pt"), map_location="cpu", weights_only=False)
     params = {}
     for n in order:
         key = "model." + n if "model." + n in sd else n
@@ -205,7 +241,7 @@ def load_checkpoint(folder, model_cfg, want=None):
             raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
         params[n] = sd[key].detach()
     out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
-    zero_world = saved_zero_world(folder)
+    zero_world = saved_zero_world(folder, t)
     if zero_world == 0:
         return out
     flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
@@ -214,11 +250,11 @@ def load_checkpoint(folder, model_cfg, want=None):
     merged = dict(master={}, exp_avg={}, exp_avg_sq={})
     head = None
     for r in range(zero_world):
-        opt_path = os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt")
+        opt_path = os.path.join(folder, f"optimizer_tp{t}_pp0_zo{r}.pt")
         if not os.path.exists(opt_path):
             raise FileNotFoundError(f"{opt_path}: the folder holds shards up to zo{zero_world - 1} but not this one")
         st = _load(opt_path)
-        plan_path = os.path.join(folder, f"gpus-{zero_world}_wp-0_tp-0_dp-{r}_pp-0_zo-{r}.pt")
+        plan_path = os.path.join(folder, f"gpus-{zero_world * tp_world}_wp-0_tp-{t}_dp-{r}_pp-0_zo-{r}.pt")
         plan = _load(plan_path) if os.path.exists(plan_path) else st.get("zero_devide_optim_plan")
         if plan is not None and list(plan[0]) != plan_ids:
             raise ValueError(f"zero_devide_optim_plan of the checkpoint does not match this model's partition over {zero_world} ranks")
@@ -234,7 +270,7 @@ def load_checkpoint(folder, model_cfg, want=None):
                     into[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
                 o += k
             if o != vec.numel():
-                raise ValueError(f"flat optimizer vector of zo{r} holds {vec.numel()} elements, this model's partition {o}")
+                raise ValueError(f"flat optimizer vector of tp{t} zo{r} holds {vec.numel()} elements, this model's partition {o}")
 
         base = st["base_optim_states"]
         s0 = base["state"][0]
@@ -247,9 +283,30 @@ def load_checkpoint(folder, model_cfg, want=None):
         if head is None:
             head = this
         elif this != head:
-            raise ValueError(f"optimizer shard zo{r} disagrees with zo0 on the step / scaler / lr: {this} vs {head}")
+            raise ValueError(f"optimizer shard tp{t} zo{r} disagrees with zo0 on the step / scaler / lr: {this} vs {head}")
         del st
     out.update(merged, zero_world=zero_world, **head)
+    return out
+
+
+def load_checkpoint(folder, model_cfg, want=None):
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, FULL tensors), adam_step, scaler, lr, zero_world, tp_world).
+    Optimizer entries are None when the folder holds model weights only.  Every shard in the folder is read and merged -- whatever
+    ZeRO world and tensor-parallel size wrote them; `want` (a set of names) limits the optimizer tensors kept in memory."""
+    tp_world = saved_tp_world(folder)
+    if tp_world == 0:
+        raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")
+    ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want) for t in range(tp_world)]
+    out = dict(ranks[0], tp_world=tp_world)
+    if tp_world == 1:
+        return out
+    for t, r in enumerate(ranks[1:], 1):
+        same = ("adam_step", "lr", "scaler", "zero_world")
+        if {k: r[k] for k in same} != {k: ranks[0][k] for k in same}:
+            raise ValueError(f"tensor rank {t} disagrees with rank 0 on the step / scaler / lr / ZeRO world")
+    for key in ("params", "master", "exp_avg", "exp_avg_sq"):
+        if ranks[0][key] is not None:
+            out[key] = {n: tp_unshard(n, [r[key][n] for r in ranks]) for n in ranks[0][key]}
     return out
 
 

@@ -763,26 +763,45 @@ class InternLM2Engine:
         return out
 
     def _checkpoint_guard(self):
-        if self.tp != 1 or self.sp != 1:
-            raise NotImplementedError("checkpoints cover tp = pp = 1 without sequence parallelism in this round (any data-parallel size)")
+        if self.sp != 1:
+            raise NotImplementedError("checkpoints cover pp = 1 without sequence parallelism in this round (any data-parallel and tensor-parallel size)")
+
+    def _local_reference_named(self, named):
+        """engine-named tensors of this rank -> the reference's names AND the reference's tensor-parallel cut: the layer weights are
+        already this tensor rank's part (same rule, tensorpar.py); embedding and head, which this engine keeps whole on every rank,
+        are cut the way the reference's modules hold them (hidden columns / vocabulary rows, checkpoint.tp_shard)."""
+        from . import checkpoint as C
+
+        out = self._to_reference_names(named)
+        if self.tp > 1:
+            for n in ("tok_embeddings.weight", "output.weight"):
+                if n in out:
+                    out[n] = C.tp_shard(n, out[n], self.tpar.tp_rank, self.tp)
+        return out
 
     def save_checkpoint(self, folder):
-        """InternEvo's checkpoint files (checkpoint.py): model weights from data-parallel rank 0, one hybrid-ZeRO optimizer shard
-        + partition plan per rank, in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284).  Collective."""
+        """InternEvo's checkpoint files (checkpoint.py): per tensor rank the model weights (written by its data-parallel rank 0) and
+        one hybrid-ZeRO optimizer shard + partition plan per data-parallel rank, in the reference's whole-parameter partition
+        (hybrid_zero_optim.py:254-284).  Collective."""
         from . import checkpoint as C
 
         self._checkpoint_guard()
         st = self.read_state()  # drains the optimizer stream
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
+        tp, t = self.tp, self.tpar.tp_rank
         hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
         scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
-        cpu = lambda d: {n: t.detach().to("cpu") for n, t in self._to_reference_names(d).items()}  # noqa: E731
+        cpu = lambda d: {n: x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
         if W == 1:
             C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
-                              cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper)
+                              cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t)
+            self.tpar.barrier()
             return
-        ref_shapes = self.reference_param_shapes()
-        shapes = {n: tuple(ref_shapes[n]) for n in C.state_dict_order(self.mc)}
+        shapes = {}
+        for n, shp in self.reference_param_shapes().items():  # FULL shapes -> this tensor rank's local shapes
+            d = C.tp_split_dim(n)
+            shapes[n] = tuple(x // tp if (tp > 1 and i == d) else x for i, x in enumerate(shp))
+        shapes = {n: shapes[n] for n in C.state_dict_order(self.mc)}
         mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole)
         need = {self._engine_name(n) for n in mine}
         state = {}
@@ -795,15 +814,17 @@ class InternLM2Engine:
                         spec = L.params[n]
                         named[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape).to("cpu", copy=True)
                 del full
-            ref_named = self._to_reference_names(named)
+            ref_named = self._local_reference_named(named)
             state[key] = {n: ref_named[n] for n in mine}
         C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
-                          scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes)
+                          scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t)
         self.comm.barrier()  # the folder is complete when any rank returns
+        self.tpar.barrier()
 
     def load_checkpoint(self, folder):
-        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world: the
-        whole-parameter shards are merged and re-cut into this engine's bucket slices)."""
+        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world and ANY
+        tensor-parallel size: the shards are merged into full tensors and re-cut into this engine's tensor-parallel parts and
+        bucket slices)."""
         from . import checkpoint as C
 
         self._checkpoint_guard()
@@ -813,15 +834,16 @@ class InternLM2Engine:
             want.update(self._to_reference_names({n: self.p[n]}).keys())
         ck = C.load_checkpoint(folder, self.mc, want=want)
         self.drain()
-        for n, t in self._from_reference_names(ck["params"]).items():
-            self.p[n].copy_(t.to(self.dev, BF16))
+        kind = lambda n: self.layout.params[n].kind  # noqa: E731
+        for n, full in self._from_reference_names(ck["params"]).items():
+            self.p[n].copy_(self.tpar.shard(kind(n), full).to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return
         for flat, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
-            src = self._from_reference_names(ck[key])
+            src = {n: self.tpar.shard(kind(n), full).reshape(-1) for n, full in self._from_reference_names(ck[key]).items()}
             for n, a, k, lo in pieces:
-                flat[lo : lo + k].copy_(src[n].reshape(-1)[a : a + k].to(self.dev))
+                flat[lo : lo + k].copy_(src[n][a : a + k].to(self.dev))
         st = K.step_state_read(self.state)
         st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
         st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0

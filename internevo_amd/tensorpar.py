@@ -55,6 +55,10 @@ class TensorParallel:
         return t
 
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
+    def barrier(self):
+        if self.tp > 1:
+            dist.barrier(group=self.group)
+
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
         if self.tp == 1 or kind in ("embed", "norm", "head"):

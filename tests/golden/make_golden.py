@@ -270,6 +270,25 @@ def _full_param_slice(name, shard_shape, formula_init, rank_in_tp, tp, rank_in_w
     return full[rank_in_wp * n : (rank_in_wp + 1) * n]
 
 
+def _mtp_part(name, full, tp_rank, tp, cfg_kw):
+    """A rank's part of a full parameter under Megatron tensor parallelism: the layer weights cut by THIS REPO's rule
+    (internevo_amd/tensorpar.py:shard -- the run reproducing the single-rank trajectory is what pins it); embedding over the hidden
+    dim (embed_split_hidden) and head over the vocabulary, as the reference's modules hold them."""
+    from internevo_amd.config import ModelConfig
+    from internevo_amd.layout import FlatLayout
+    from internevo_amd.tensorpar import TensorParallel
+
+    if name == "tok_embeddings.weight":
+        return full[:, tp_rank * (full.shape[1] // tp) : (tp_rank + 1) * (full.shape[1] // tp)]
+    if name == "output.weight":
+        return full[tp_rank * (full.shape[0] // tp) : (tp_rank + 1) * (full.shape[0] // tp)]
+    kind = FlatLayout(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
+                                  num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]), 1).params[name].kind
+    t = TensorParallel.__new__(TensorParallel)
+    t.tp, t.tp_rank = tp, tp_rank
+    return t.shard(kind, full)
+
+
 def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     """One process = one run (gpc is a singleton); called through `--run tag` (one process per rank for the ISP runs)."""
     shim_cpu_accelerator()
@@ -315,23 +334,7 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     with torch.no_grad():
         for name, p in inner.named_parameters():
             if world > 1 and tp > 1:
-                # Megatron tensor parallelism: the layer weights cut by THIS REPO's rule (internevo_amd/tensorpar.py:shard -- the run
-                # reproducing the single-rank trajectory is what pins it); embedding over the hidden dim (embed_split_hidden) and
-                # head over the vocabulary as the reference's modules hold them
-                from internevo_amd.layout import FlatLayout
-                from internevo_amd.tensorpar import TensorParallel
-
-                full = formula_init(name, full_shapes[name])
-                if name == "tok_embeddings.weight":
-                    part = full[:, tp_rank * (full.shape[1] // tp) : (tp_rank + 1) * (full.shape[1] // tp)]
-                elif name == "output.weight":
-                    part = full[tp_rank * (full.shape[0] // tp) : (tp_rank + 1) * (full.shape[0] // tp)]
-                else:
-                    kind = FlatLayout(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
-                                                  num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]), 1).params[name].kind
-                    t = TensorParallel.__new__(TensorParallel)
-                    t.tp, t.tp_rank = tp, tp_rank
-                    part = t.shard(kind, full)
+                part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw)
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
             elif world > 1:
@@ -428,7 +431,7 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
@@ -456,6 +459,8 @@ def gen_checkpoint(port=29795, rank=0, world=1):
     from oracle.model import formula_init
 
     kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
+    if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
+        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=1, tp=tp)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
@@ -463,8 +468,20 @@ def gen_checkpoint(port=29795, rank=0, world=1):
     torch.set_num_threads(8)
     model = initialize_model()
     with torch.no_grad():
+        if tp > 1:
+            from internevo_amd.config import ModelConfig
+            from oracle.model import param_shapes
+
+            full_shapes = param_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"],
+                                                   num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"]))
+            tp_rank = gpc.get_local_rank(ParallelMode.TENSOR)
         for name, p in model.model.named_parameters():
-            p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+            if tp > 1:
+                part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw)
+                assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
+                p.copy_(part.to(p.dtype))
+            else:
+                p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
     criterion = FlashGPTLMLoss(parallel_output=False, label_smoothing=0)
     train_dl, dataset_types = bdl.build_train_loader_with_data_type()
     train_state = TrainState(gpc.config, train_dl.batch_sampler)
@@ -477,7 +494,7 @@ def gen_checkpoint(port=29795, rank=0, world=1):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -548,7 +565,7 @@ def gen_checkpoint(port=29795, rank=0, world=1):
         if rank != 0:
             return
     rec["files"] = sorted(os.listdir(folder))
-    with open(os.path.join(HERE, "ckpt.json" if world == 1 else f"ckpt_dp{world}.json"), "w") as f:
+    with open(os.path.join(HERE, "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
 
@@ -1006,6 +1023,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-rank":
         gen_checkpoint(port=29797, rank=int(sys.argv[2]), world=2)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-tp-rank":
+        gen_checkpoint(port=29799, rank=int(sys.argv[2]), world=2, tp=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-tp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-tp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-mp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
@@ -1025,7 +1048,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--ckpt", "--ckpt-mp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--ckpt", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -321,6 +321,76 @@ def test_oracle_resumes_from_the_two_rank_reference_checkpoint():
         assert abs(g["lr"] - w["lr"]) <= 1e-9 * w["lr"] and g["loss_scale"] == w["loss_scale"]
 
 
+REFTP = os.path.join(G, "ckpt_ref_tp2")
+
+
+def test_tensor_parallel_checkpoint_shards_match_the_reference():
+    """tests/golden/ckpt_ref_tp2/: the real reference on 2 Megatron tensor-parallel ranks (make_golden.py --ckpt-tp), its weights
+    the tp_shard parts of the closed-form full tensors.  load_checkpoint merges the two ranks' files back into the FULL tensors
+    (= the closed-form init moved by two optimizer steps: every parameter whole, replicated norms equal on both ranks); cutting the
+    merged state again and saving reproduces the reference's files tensor for tensor."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+
+    gold = json.load(open(os.path.join(G, "ckpt_tp2.json")))
+    c = gold["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    assert C.saved_tp_world(REFTP) == 2 and C.saved_tp_world(REF) == 1 and C.saved_zero_world(REFTP, 1) == 1
+    ck = C.load_checkpoint(REFTP, cfg.model)
+    assert ck["tp_world"] == 2 and ck["zero_world"] == 1 and ck["adam_step"] == 2
+    from oracle.model import param_shapes
+
+    full = param_shapes(cfg.model)
+    for n in C.state_dict_order(cfg.model):
+        assert tuple(ck["params"][n].shape) == tuple(full[n]), n
+        assert tuple(ck["master"][n].shape) == tuple(full[n]) and torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    # the two ranks' copies of a replicated parameter agree; the sharded ones really differ
+    a, b = (C._load_tp_rank(REFTP, cfg.model, t, 2, None) for t in (0, 1))
+    assert torch.equal(a["params"]["norm.weight"], b["params"]["norm.weight"]) and torch.equal(a["master"]["norm.weight"], b["master"]["norm.weight"])
+    assert not torch.equal(a["params"]["layers.0.attention.wo.weight"], b["params"]["layers.0.attention.wo.weight"])
+    assert [C.tp_split_dim(n) for n in ("tok_embeddings.weight", "output.weight", "layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight",
+                                        "layers.0.feed_forward.w1.weight", "layers.0.feed_forward.w2.weight", "layers.0.ffn_norm.weight")] == [1, 0, 0, 1, 0, 1, None]
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as out:
+        for t in (0, 1):
+            cut = lambda d: {n: C.tp_shard(n, v, t, 2).contiguous() for n, v in d.items()}  # noqa: E731
+            C.save_checkpoint(out, cfg.model, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"],
+                              ck["scaler"], ck["lr"], hyper, tp_world=2, tp_rank=t)
+        assert sorted(os.listdir(out)) == gold["files"]
+        for t in (0, 1):
+            _cmp_optimizer_files(C, os.path.join(REFTP, f"optimizer_tp{t}_pp0_zo0.pt"), os.path.join(out, f"optimizer_tp{t}_pp0_zo0.pt"))
+            x = torch.load(os.path.join(REFTP, f"model_tp{t}_pp0.pt"), weights_only=False)
+            y = torch.load(os.path.join(out, f"model_tp{t}_pp0.pt"), weights_only=False)
+            assert list(x) == list(y) and all(x[k].shape == y[k].shape and torch.equal(x[k], y[k]) for k in x)
+            fn = f"gpus-2_wp-0_tp-{t}_dp-0_pp-0_zo-0.pt"
+            assert C._load(os.path.join(REFTP, fn)) == C._load(os.path.join(out, fn))
+
+
+def test_oracle_resumes_from_the_tensor_parallel_reference_checkpoint():
+    """The merged full tensors ARE the model: the single-rank oracle resumed from the 2-tensor-rank reference checkpoint reproduces
+    the 2 steps the tensor-parallel reference trained after saving."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    gold = json.load(open(os.path.join(G, "ckpt_tp2.json")))
+    c = gold["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(C.load_checkpoint(REFTP, cfg.model))
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for w in gold["steps"][gold["saved_after_step"]:]:
+        g = tr.train_step(*next(loader))
+        assert abs(g["loss"] - w["loss"]) <= 2e-3 * abs(w["loss"]), (g["loss"], w["loss"])
+        assert abs(g["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * w["grad_norm"]["0_default"]
+        assert abs(g["lr"] - w["lr"]) <= 1e-9 * w["lr"] and g["loss_scale"] == w["loss_scale"]
+
+
 @pytest.mark.gpu
 def test_engine_resumes_from_reference_checkpoint_and_round_trips(dev, tmp_path):
     """The HIP engine loads the reference's checkpoint and reproduces the 2 steps the reference trained after saving; a checkpoint

@@ -329,7 +329,7 @@ def test_sequence_parallel_step_equals_single_rank_step(dev):
     assert worst <= 6e-3
 
 
-def _tp_worker(rank, world, port, q):
+def _tp_worker(rank, world, port, q, folder=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -351,13 +351,27 @@ def _tp_worker(rank, world, port, q):
             st = eng.read_state()
             out.append((float(loss), float(st.grad_norm)))
         shards = {n: (eng.layout.params[n].kind, p.float().cpu().numpy()) for n, p in eng.p.items()}
-        q.put((rank, out, shards))
+        ck = None
+        if folder is not None:  # checkpoint round trip on the tensor-parallel ranks: one model + optimizer + plan file per tensor rank
+            eng.save_checkpoint(folder)
+            fresh = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2)
+            fresh.load_checkpoint(folder)
+            same = all(torch.equal(a, b) for a, b in ((eng.master, fresh.master), (eng.exp_avg, fresh.exp_avg), (eng.exp_avg_sq, fresh.exp_avg_sq)))
+            same = same and all(torch.equal(eng.p[n], fresh.p[n]) for n in eng.p)
+            batch, labels = next(loader)
+            nxt = []
+            for e in (eng, fresh):
+                loss = e.forward_backward(batch, labels)
+                e.step()
+                nxt.append((float(loss), float(e.read_state().grad_norm)))
+            ck = (bool(same), nxt, bool(torch.equal(eng.params, fresh.params)))
+        q.put((rank, out, shards, ck))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_tensor_parallel_step_equals_single_rank_step(dev):
+def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
     same micro-batches: same loss, same grad norm (replicated parameters counted once), and the two ranks' parameter shards
     concatenate to the single-rank parameters (bf16 summation-order noise only)."""
@@ -368,7 +382,8 @@ def test_tensor_parallel_step_equals_single_rank_step(dev):
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853, q)) for r in range(2)]
+    folder = str(tmp_path / "ck_tp2")
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853, q, folder)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
@@ -382,7 +397,7 @@ def test_tensor_parallel_step_equals_single_rank_step(dev):
         loss = eng.forward_backward(batch, labels)
         eng.step()
         ref.append((float(loss), float(eng.read_state().grad_norm)))
-    (r0, o0, s0), (r1, o1, s1) = res
+    (r0, o0, s0, c0), (r1, o1, s1, c1) = res
     for k in range(3):
         print(f"step {k}: tp2 loss {o0[k][0]:.5f} gn {o0[k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
         assert o0[k] == o1[k], "both ranks of a tensor group compute the same loss and the same global grad norm"
@@ -397,3 +412,24 @@ def test_tensor_parallel_step_equals_single_rank_step(dev):
         worst = max(worst, float((full - p.float().cpu()).abs().max()))
     print("max |param diff| tp2 vs 1 rank:", worst)
     assert worst <= 6e-3
+    # the checkpoint the two tensor ranks wrote (the reference's file set: model / optimizer / plan / topo per tensor rank) ...
+    assert sorted(os.listdir(folder)) == ["gpus-2_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "gpus-2_wp-0_tp-1_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "model_tp1_pp0.pt",
+                                          "optimizer_tp0_pp0_zo0.pt", "optimizer_tp1_pp0_zo0.pt", "topo_tp0_pp0.json", "topo_tp1_pp0.json"]
+    for c in (c0, c1):
+        same, nxt, same_after = c
+        assert same and same_after and nxt[0] == nxt[1], "a fresh tensor-parallel engine resumes bit-identically from it"
+    # ... merged and re-cut for ONE rank: exactly the concatenation of the two ranks' parts, and it keeps training
+    from internevo_amd import checkpoint as C
+
+    one = InternLM2Engine(_cfg(2), dev)
+    one.load_checkpoint(folder)
+    for n, p in one.p.items():
+        full = TensorParallel.unshard(s0[n][0], [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
+        assert torch.equal(p.float().cpu(), full), n
+    assert C.load_checkpoint(folder, _cfg(2).model)["tp_world"] == 2
+    for _ in range(3):
+        next(loader)
+    batch, labels = next(iter(SyntheticLoader(128, 1, 2, False, 4000)))  # any batch: the step must simply run on the loaded state
+    loss = one.forward_backward(batch, labels)
+    one.step()
+    assert int(one.read_state().adam_step) == 4 and float(loss) < 6.5
