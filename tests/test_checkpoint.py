@@ -391,6 +391,49 @@ def test_oracle_resumes_from_the_tensor_parallel_reference_checkpoint():
         assert abs(g["lr"] - w["lr"]) <= 1e-9 * w["lr"] and g["loss_scale"] == w["loss_scale"]
 
 
+@pytest.mark.parametrize("tp,zw", [(1, 3), (2, 2), (4, 1), (4, 3)])
+def test_checkpoint_layouts_round_trip(tmp_path, tp, zw):
+    """Any (tensor-parallel, ZeRO) layout written rank by rank -- every rank passing only what it owns -- merges back into the same
+    full tensors; the flat vectors of a rank hold its parameters in the partition order with nothing lost or duplicated."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from oracle.model import param_shapes
+
+    cfg = tiny(128, 2, 4, 4, 256, 32, 2, 1e-3, 4)
+    order = C.state_dict_order(cfg.model)
+    full_shapes = param_shapes(cfg.model)
+    g = torch.Generator().manual_seed(tp * 10 + zw)
+    full = {k: {n: torch.randn(full_shapes[n], generator=g) for n in order} for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+    full["params"] = {n: v.to(torch.bfloat16) for n, v in full["params"].items()}
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    scaler = dict(scale=1024.0, growth_step=7, hysteresis_step=1)
+    out = str(tmp_path / "ck")
+    total = 0
+    for t in range(tp):
+        local = {k: {n: C.tp_shard(n, v, t, tp).contiguous() for n, v in d.items()} for k, d in full.items()}
+        shapes = {n: tuple(local["params"][n].shape) for n in order}
+        owners = C.zero_rank_names(shapes, zw)
+        assert sorted(n for names in owners for n in names) == sorted(order)
+        for r in range(zw):
+            own = lambda d: {n: d[n] for n in owners[r]}  # noqa: E731
+            C.save_checkpoint(out, cfg.model, local["params"] if r == 0 else None, own(local["master"]), own(local["exp_avg"]), own(local["exp_avg_sq"]),
+                              5, scaler, 3e-4, hyper, zero_world=zw, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t)
+            st = C._load(os.path.join(out, f"optimizer_tp{t}_pp0_zo{r}.pt"))
+            total += st["flat_fp32_weights"][0].numel()
+            assert os.path.exists(os.path.join(out, f"gpus-{tp * zw}_wp-0_tp-{t}_dp-{r}_pp-0_zo-{r}.pt"))
+    replicated = sum(int(torch.Size(full_shapes[n]).numel()) for n in order if C.tp_split_dim(n) is None)  # norms live on every tensor rank
+    assert total == sum(int(torch.Size(s_).numel()) for s_ in full_shapes.values()) + (tp - 1) * replicated, "every local element in exactly one flat vector"
+    ck = C.load_checkpoint(out, cfg.model)
+    assert (ck["tp_world"], ck["zero_world"], ck["adam_step"], ck["lr"], ck["scaler"]) == (tp, zw, 5, 3e-4, scaler)
+    for k in ("params", "master", "exp_avg", "exp_avg_sq"):
+        assert list(ck[k]) == order or set(ck[k]) == set(order)
+        for n in order:
+            assert torch.equal(ck[k][n], full[k][n]), (k, n)
+    some = {order[1], order[-1]}
+    part = C.load_checkpoint(out, cfg.model, want=some)
+    assert set(part["master"]) == some and all(torch.equal(part["exp_avg"][n], full["exp_avg"][n]) for n in some)
+
+
 @pytest.mark.gpu
 def test_engine_resumes_from_reference_checkpoint_and_round_trips(dev, tmp_path):
     """The HIP engine loads the reference's checkpoint and reproduces the 2 steps the reference trained after saving; a checkpoint
