@@ -15,6 +15,12 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libinternevo_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
+# per-source additions.  The flash kernels place their vector-ALU work by hand in the shadow of single MFMAs; SLP-packed f32
+# arithmetic (v_pk_add_f32 / v_pk_mul_f32) costs more issue time there than the two scalar instructions it replaces
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+EXTRA_FLAGS = {"flash_attn_fwd.hip": ["-fno-slp-vectorize"], "flash_attn_bwd.hip": ["-fno-slp-vectorize"]}
+KBENCH_SRC = os.path.join(HERE, "..", "tools", "kbench", "kbench.cpp")
+KBENCH_BIN = os.path.join(HERE, "..", "tools", "kbench", "kbench")
 
 
 def _hipcc():
@@ -39,7 +45,7 @@ def _compile(src, force):
     spath = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _headers_mtime()):
         return obj, False
-    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", spath, "-o", obj]
     if os.path.exists(obj):
         os.remove(obj)  # a stale object must never survive a failed compile (the hipcc wrapper can exit 0 after "failed to execute")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -65,5 +71,20 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_kbench(verbose=True):
+    """tools/kbench: the torch-free A/B harness (development tool; dlopen()s the library)."""
+    if os.path.exists(KBENCH_BIN) and os.path.getmtime(KBENCH_BIN) > os.path.getmtime(KBENCH_SRC):
+        return KBENCH_BIN
+    cmd = [_hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", KBENCH_SRC, "-o", KBENCH_BIN, "-ldl"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(KBENCH_BIN):
+        raise RuntimeError(f"kbench build failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(f"[internevo_amd.build] {KBENCH_BIN}")
+    return KBENCH_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--kbench" in sys.argv:
+        build_kbench()

@@ -184,13 +184,12 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // position, and there are only (len/64) x hkv blocks, so (a) blocks are small (64 keys) to get >= 2 per CU and
 // (b) the block index is folded so that the two blocks dispatched far apart (the ones that share a CU under
 // round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.
-constexpr int DKV_WAVES = 2;
 
 // HS > 1 (causal balance): the q heads of a kv head are split over HS blocks, each writing fp32 partial dK / dV
 // to part[2][HS][T][hkv][D]; flash_dkdv_reduce_k sums them in a fixed order (deterministic, no atomics).  With all blocks
 // resident at once the kernel takes as long as its heaviest block (key block 0 sees every query tile: 2x the mean); HS x more,
 // HS x smaller blocks dispatched heavy-first let the light ones back-fill the tail.
-template <int D, bool CAUSAL, int HS>
+template <int D, bool CAUSAL, int HS, int DKV_WAVES>
 __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
                                                                int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -446,6 +445,7 @@ __global__ __launch_bounds__(256) void flash_dkdv_reduce_k(const float* __restri
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 int g_dkdv_split = 0;  // 0 = automatic (see dkdv_split), else the forced head split of the dK/dV kernel
+int g_dkdv_waves = 2;  // waves (x 32 keys) per dK/dV block
 int g_dq_minw = 2;  // waves/SIMD the dQ kernel is compiled for (2: 256 VGPRs with a small spill; 1: no spill, half the occupancy)
 
 }  // namespace
@@ -506,15 +506,19 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     }
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq((unsigned)hq, nt128, (unsigned)nseq);
+    const int DKV_WAVES = g_dkdv_waves;
     const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
     const int hs = dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
     dim3 gk(nkb * (unsigned)hkv * (unsigned)hs, 1, (unsigned)nseq);
     float* part = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
+#define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
+    hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
+                       softmax_scale, part)
 #define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
     do {                                                                                                                           \
-        hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_>), gk, dim3(64 * DKV_WAVES), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, \
-                           q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts,            \
-                           cu_seqlens, T, hq, hkv, softmax_scale, part);                                                            \
+        if (DKV_WAVES == 4) IE_DKDV_W(DD, CA, HS_, 4);                                                                             \
+        else IE_DKDV_W(DD, CA, HS_, 2);                                                                                            \
         if (HS_ > 1) {                                                                                                             \
             const int64_t n4 = T * hkv * (DD / 4);                                                                                 \
             hipLaunchKernelGGL((flash_dkdv_reduce_k<HS_>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, (bf16_t*)dk,   \
@@ -544,5 +548,13 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
 #undef IE_L
 #undef IE_DKDV
 #undef IE_DKDV_HS
+#undef IE_DKDV_W
     return ie_launch_status("ie_flash_attn_bwd launch");
+}
+
+// tuning hook (A/B benchmarking only): bits 0-1: 0 = 2 waves x 32 keys per dK/dV block, 1 = 4 waves
+extern "C" int ie_tune_flash_bwd_variant(int variant) {
+    IE_CHECK_ARG(variant >= 0 && variant <= 1, "ie_tune_flash_bwd_variant: 0 or 1");
+    g_dkdv_waves = (variant & 1) ? 4 : 2;
+    return IE_OK;
 }

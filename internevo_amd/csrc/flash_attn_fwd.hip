@@ -178,6 +178,362 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
     }
 }
 
+
+
+// ---- MFMAs with an explicit register file for every operand (one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
+// hipcc allocates every MFMA accumulator of a > 256-register kernel in the accumulation file and then copies whatever the vector
+// ALU touches back and forth (v_accvgpr_read / _write: > 1000 of them in this kernel); with the operand files spelled out the
+// scores S (vector-ALU food) stay in arch VGPRs, O and the Q fragments (MFMA-only) live in the accumulation file.  The asm
+// statements are opaque to the hazard recognizer, so the wait states the ISA asks for are written here:
+//   * VALU-written VGPR -> MFMA A/B operand: 2 states.  The only VALU-written operands are the packed P fragments, written in
+//     phase 1 and read in phase 2 with at least 12 MFMAs in between (K / V fragments come from LDS, Q from the accumulation file);
+//   * MFMA result -> any non-accumulate reader: 12 states for an 8-pass MFMA: mfma_settle() before the vector ALU (or the epilogue)
+//     looks at accumulators right behind their last MFMA; inside the tile loop >= 16 other MFMAs separate writer and reader.
+// (b_acc is a read-write operand although the MFMA only reads it: that pins the Q fragment in ONE accumulation register tuple
+// for the whole kernel; as a plain input hipcc copies it into a fresh tuple in front of every statement)
+__device__ __forceinline__ void mfma_s_first(f32x16& d, const s16x8& a, s16x8& b_acc) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(b_acc) : "v"(a));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const s16x8& a, s16x8& b_acc) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(d), "+a"(b_acc) : "v"(a));
+}
+__device__ __forceinline__ void mfma_o(f32x16& d_acc, const s16x8& a, const s16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d_acc) : "v"(a), "v"(b));
+}
+// vector-ALU instructions that must stay where they are written (a volatile asm statement keeps its place among the MFMA
+// statements; hipcc would hoist all 64 scale-and-subtracts of a phase to its top, outside any MFMA shadow) and that hipcc would
+// otherwise wrap in canonicalising v_max (fmaxf on values it cannot prove quiet).  Plain VALU -> VALU dependencies are interlocked.
+__device__ __forceinline__ float fma_pinned(float a, float b, float c) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void max3_pinned(float& m, float a, float b) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+    asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void mfma_settle_acc(f32x16& a, f32x16& b) { asm volatile("s_nop 15" : "+a"(a), "+a"(b)); }
+// acc *= f, element-wise, with the accumulator staying in the accumulation file (a vector-ALU use of it in HIP source would make
+// hipcc keep it in arch VGPRs and copy all of it into the accumulation file in front of every MFMA statement)
+__device__ __forceinline__ void acc_scale(f32x16& acc, float f) {
+    asm volatile("s_nop 15" : "+a"(acc));  // the last MFMA into acc has retired
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float e = acc[r], t;
+        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1" : "+a"(e), "=&v"(t) : "v"(f));
+        acc[r] = e;
+    }
+    asm volatile("s_nop 3" : "+a"(acc));  // accumulation-file write -> MFMA source
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 forward, one wave per SIMD: block = 4 wave64 = 256 query rows, each wave owns 64 rows (two 32-row blocks X = 0, 1)
+// and the whole 512-entry register file of its SIMD.  Every K fragment read from LDS feeds TWO MFMAs (both row blocks)
+// and so does every V^T fragment: half the LDS bytes per MFMA of the 32-rows-per-wave kernel above, which is what that
+// kernel waits for (one wave per SIMD cannot hide an LDS round trip behind a partner wave).
+// The tile loop is software-pipelined over two phases of 8*KS/2.. MFMAs each so that the matrix pipe and the vector ALU
+// always have independent work in the same basic block:
+//   phase 1 of tile t:  S(t+1) = K(t+1) Q^T  (MFMA)   beside   finish-softmax(t): p = exp2(S(t) - m), row sums, bf16 pack
+//   phase 2 of tile t:  O += V(t)^T P(t)     (MFMA)   beside   start-softmax(t+1): row maxima of S(t+1), new m, alpha
+// (the O rescale by alpha(t), when some row maximum moved by more than the deferral threshold, opens phase 1).
+// S is double-buffered in registers (the loop is unrolled by two, which also makes every LDS stage address an immediate).
+// K(t+2) and V(t+1) are requested by LDS-DMA at the top of tile t: each has a whole tile of MFMAs to land; one barrier per tile.
+__device__ unsigned long long g_dbg[8];  // ABL & 32: per-phase cycle totals of wave 0 of every block (diagnostic builds only)
+
+template <int D, bool CAUSAL, int THR, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out,
+                                                        int64_t o_ts, float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T,
+                                                        int hq, int hkv, float scale) {
+    using G = Geo<D>;
+    constexpr int IMG = G::IMG_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * IMG];  // K stage 0, K stage 1, V stage 0, V stage 1
+
+    const int seq = blockIdx.z;
+    const int h = ((int)blockIdx.x % hkv) * (hq / hkv) + (int)blockIdx.x / hkv;  // the q heads of one kv head share an XCD's L2
+    const int qt = gridDim.y - 1 - blockIdx.y;                                    // heaviest (last) query tiles first
+    const int tok0 = cu[seq];
+    const int len = cu[seq + 1] - tok0;
+    const int q0 = qt * 256;
+    if (q0 >= len) return;
+    const int hk = h / (hq / hkv);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qw0 = q0 + wave * 64;
+    int my_q[2];
+    bool q_valid[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        my_q[X] = qw0 + 32 * X + (lane & 31);
+        q_valid[X] = my_q[X] < len;
+    }
+    const int kv_end = CAUSAL ? min(len, q0 + 256) : len;
+    const int nt = (kv_end + 63) / 64;                                                    // tiles the block streams
+    const int ntw = qw0 >= len ? 0 : (CAUSAL ? min(nt, qw0 / 64 + 1) : nt);               // tiles this wave computes on
+
+    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    TileSrc<D, 4> ksrc, vsrc;
+    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
+    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
+    unsigned char* Kst = smem;
+    unsigned char* Vst = smem + 2 * IMG;
+    ksrc.issue(Kst, 0, 0, wave);
+    if (nt > 1) ksrc.issue(Kst + IMG, 64, 0, wave);
+    vsrc.issue(Vst, 0, 0, wave);
+
+    FragOffs<D> fo;
+    fo.init(lane);
+
+    s16x8 qf[2][G::KS];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const bf16_t* qp = q + (int64_t)(tok0 + my_q[X]) * q_ts + (int64_t)h * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            union { uint4 u; s16x8 s; } cv;
+            cv.u = q_valid[X] ? ld16(qp + ks * 16) : z4();
+            qf[X][ks] = cv.s;
+        }
+    }
+
+    f32x16 oacc[2][G::DB];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) oacc[X][db] = zero16();
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f}, moff[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+    bool resc[2] = {false, false};
+    const float sc2 = scale * kLog2e;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 pf[2][2][2];  // P fragments [X][c][s2]: 8 bf16 = keys 32c + 16*s2-step in C/D register order
+
+    // other half of the row: lane ^ 32 (v_permlane32_swap: vector-ALU latency; __shfl_xor would be a ds_bpermute round trip that
+    // a lone wave on its SIMD cannot hide)
+    auto xhalf_max = [&](float v) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    auto xhalf_sum = [&](float v) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+    // masks of tile t (wave-uniform decision: diagonal / last tiles only); selects, no per-element branches
+    auto apply_mask = [&](f32x16 (&s)[2][2], int t) {
+        const int kv0 = t * 64;
+        if (!((CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > len))) return;
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int lim = CAUSAL ? min(len - 1, my_q[X]) : len - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * c + creg_row(r, lane);
+                    s[X][c][r] = key > lim ? -INFINITY : s[X][c][r];
+                }
+        }
+    };
+    // start-softmax given the in-lane maxima of a tile's scores: row maxima, deferral decision, alpha, exponent offset
+    auto sm_start = [&](float (&mx)[2]) {
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const float m = xhalf_max(mx[X]);
+            const float m_new = fmaxf(m_run[X], m);
+            // deferred rescale: keep the old reference maximum while no row of the wave moved by more than THR (log2 units):
+            // p <= 2^THR then, exact in fp32 / same relative precision in bf16; THR = 0 rescales whenever any maximum moved
+            const bool keep = __all((m_new - m_run[X]) * sc2 <= (float)THR);
+            const float m_sel = keep ? m_run[X] : m_new;
+            const float m_use = (m_sel == -INFINITY) ? 0.f : m_sel;
+            alpha[X] = keep ? 1.f : __builtin_amdgcn_exp2f((m_run[X] - m_use) * sc2);  // m_run = -inf -> 0
+            resc[X] = !keep;
+            moff[X] = m_use * sc2;
+            m_run[X] = m_sel;
+            l_run[X] *= alpha[X];
+        }
+    };
+
+    // ---- prologue: S(0), start-softmax(0)
+    f32x16 sA[2][2], sB[2][2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntw > 0) {
+        float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const s16x8 kfr = row_frag<D>(Kst, 32 * c, ks, fo);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    if (ks == 0) mfma_s_first(sA[X][c], kfr, qf[X][ks]);
+                    else mfma_s(sA[X][c], kfr, qf[X][ks]);
+                }
+            }
+        mfma_settle(sA[0][0], sA[0][1], sA[1][0], sA[1][1]);
+        apply_mask(sA, 0);
+#pragma unroll
+        for (int X = 0; X < 2; ++X)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[X] = fmaxf(mx[X], sA[X][c][r]);
+        sm_start(mx);
+    }
+
+    constexpr int NM = 4 * G::KS;   // MFMAs of a phase (= 8 * DB)
+    constexpr int EPC = 64 / NM;    // score elements per lane handled beside one MFMA (2 for D = 128, 4 for D = 64)
+    static_assert(8 * G::DB == NM && EPC >= 2, "phase geometry");
+
+    long long dbg[5] = {0, 0, 0, 0, 0};
+    // tile t with its scores in `sc`; the scores of tile t+1 go to `sn`.  PAR = t & 1 selects the LDS stages.
+    auto tile = [&](auto par_c, int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool DBG = (ABL & 32) != 0;
+        long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+        if (DBG) T0 = __builtin_amdgcn_s_memtime();
+        // every wave's DMA pieces of K(t+1) and V(t) have landed; every wave is done with K(t) and V(t-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (DBG) T1 = __builtin_amdgcn_s_memtime();
+        if (!(ABL & 16)) {
+            if (t + 2 < nt) ksrc.issue(Kst + PAR * IMG, (t + 2) * 64, 0, wave);
+            if (t + 1 < nt) vsrc.issue(Vst + (1 - PAR) * IMG, (t + 1) * 64, 0, wave);
+        }
+        if (t >= ntw) return;
+        if (DBG) T2 = __builtin_amdgcn_s_memtime();
+        const unsigned char* Kn = Kst + (1 - PAR) * IMG;
+        const unsigned char* Vc = Vst + PAR * IMG;
+        const bool has_next = t + 1 < ntw;   // this wave also works on tile t + 1
+
+        // ---- phase 1
+#pragma unroll
+        for (int X = 0; X < 2; ++X)
+            if (resc[X]) {
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db) acc_scale(oacc[X][db], alpha[X]);
+            }
+        float rs[2] = {0.f, 0.f};
+        const float nmoff[2] = {-moff[0], -moff[1]};
+        auto fin_chunk = [&](int i) {  // elements [i*EPC, (i+1)*EPC) of the 64 scores a lane holds: X = e/32, c = (e/16)&1, r = e&15
+            if (ABL & 1) return;  // (ablation build: timing only)
+#pragma unroll
+            for (int u = 0; u < EPC; u += 2) {
+                const int e = i * EPC + u, X = e >> 5, c = (e >> 4) & 1, r = e & 15;
+                const float p0 = __builtin_amdgcn_exp2f(fma_pinned(sc[X][c][r], sc2, nmoff[X]));
+                const float p1 = __builtin_amdgcn_exp2f(fma_pinned(sc[X][c][r + 1], sc2, nmoff[X]));
+                rs[X] += p0;  // (two dependent adds: the second exp's result is not read by the instruction right behind it)
+                rs[X] += p1;
+                pf[X][c][r >> 3][(r & 7) >> 1] = pack2bf(p0, p1);
+            }
+        };
+        // Fragments are requested PF MFMA pairs ahead of their use (a lone wave per SIMD sees the whole LDS round trip; the asm
+        // statements pin the order of the LDS reads), across the phase boundary too: the first V^T fragments of phase 2 are
+        // requested under the last pairs of phase 1.  The vector-ALU chunks run SK ahead of the MFMAs so that the first K
+        // fragments' round trip (they cannot be requested before the barrier) has cover.
+        constexpr int PF = 3, SK = 2, NK = 2 * G::KS, NV = 4 * G::DB;
+        s16x8 kq[NK], vq[NV];
+        auto load_v = [&](int j) { if (!(ABL & 4)) vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
+        if (ABL & 4) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) vq[j] = qf[0][0];
+#pragma unroll
+            for (int j = 0; j < NK; ++j) kq[j] = qf[0][1];
+        }
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) if (!(ABL & 4)) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo);
+#pragma unroll
+            for (int i = 0; i < SK; ++i) fin_chunk(i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                const int c = j / G::KS, ks = j % G::KS;
+                if (j + PF < NK) { if (!(ABL & 4)) kq[j + PF] = row_frag<D>(Kn, 32 * ((j + PF) / G::KS), (j + PF) % G::KS, fo); }
+                else load_v(j + PF - NK);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    if (!(ABL & 8)) {
+                        if (ks == 0) mfma_s_first(sn[X][c], kq[j], qf[X][ks]);
+                        else mfma_s(sn[X][c], kq[j], qf[X][ks]);
+                    }
+                    if (j * 2 + X + SK < NM) fin_chunk(j * 2 + X + SK);
+                    __builtin_amdgcn_sched_barrier(0);  // this chunk's vector ALU work stays in the shadow of this MFMA
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) load_v(j);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) fin_chunk(i);
+        }
+#pragma unroll
+        for (int X = 0; X < 2; ++X) l_run[X] += xhalf_sum(rs[X]);
+
+        // ---- phase 2: the in-lane maxima of S(t+1) beside the first half of the MFMAs (4 scores per MFMA), the rest of
+        // start-softmax(t+1) -- a short dependent chain -- in the middle, with MFMAs still queued behind it.  On a wave's last tile
+        // the maxima are taken over stale registers and dropped: the per-MFMA chunks carry no branches.
+        if (DBG) T3 = __builtin_amdgcn_s_memtime();
+        if (has_next) apply_mask(sn, t + 1);
+        float mx[2] = {-INFINITY, -INFINITY};
+        auto max_chunk = [&](int i) {  // 2 * EPC scores
+            if (ABL & 2) return;
+#pragma unroll
+            for (int u = 0; u < 2 * EPC; u += 2) {
+                const int e = i * 2 * EPC + u, X = e >> 5, c = (e >> 4) & 1, r = e & 15;
+                max3_pinned(mx[X], sn[X][c][r], sn[X][c][r + 1]);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = j / (2 * G::DB), s2 = (j / G::DB) & 1, db = j % G::DB;
+            if (j + PF < NV) load_v(j + PF);
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                if (!(ABL & 8)) mfma_o(oacc[X][db], vq[j], __builtin_bit_cast(s16x8, pf[X][c][s2]));
+                if (j * 2 + X < NM / 2) max_chunk(j * 2 + X);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j == NV / 2 - 1 && has_next) sm_start(mx);
+        }
+        if (DBG) {
+            T4 = __builtin_amdgcn_s_memtime();
+            dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3; dbg[4] += 1;
+        }
+    };
+
+    for (int t = 0; t < nt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t, sA, sB);
+        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1, sB, sA);
+    }
+
+    if ((ABL & 32) && threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_dbg[i], (unsigned long long)dbg[i]);
+    }
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int db = 0; db < G::DB; db += 2) mfma_settle_acc(oacc[X][db], oacc[X][db + 1]);
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+        if (q_valid[X]) {
+            const float inv = l_run[X] > 0.f ? 1.f / l_run[X] : 0.f;
+            bf16_t* op = out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D;
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack2bf(oacc[X][db][4 * g + 0] * inv, oacc[X][db][4 * g + 1] * inv);
+                    w.y = pack2bf(oacc[X][db][4 * g + 2] * inv, oacc[X][db][4 * g + 3] * inv);
+                    st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
+                }
+            if (lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_run[X] > 0.f) ? m_run[X] * scale + logf(l_run[X]) : -INFINITY;
+        }
+}
+
+int g_fwd_variant = 0;  // 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: THR = 4
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace
@@ -192,8 +548,32 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     IE_CHECK_SUPPORTED(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && q_ts % 8 == 0 && kv_ts % 8 == 0 && o_ts % 4 == 0,
                        "ie_flash_attn_fwd: pointers must be 16-byte aligned and token strides multiples of 8");
     if (nseq == 0 || T == 0 || max_seqlen == 0) return IE_OK;
-    dim3 grid((unsigned)hq, (unsigned)((max_seqlen + 127) / 128), (unsigned)nseq);
     hipStream_t st = (hipStream_t)stream;
+    if (g_fwd_variant >= 16) {  // ablation builds (timing experiments, wrong results): variant = 16 + mask
+        dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
+        IE_CHECK_SUPPORTED(d == 128 && causal, "ablation variants: d = 128, causal");
+#define IE_ABL(M)                                                                                                                  \
+    case M:                                                                                                                        \
+        hipLaunchKernelGGL((flash_fwd64_k<128, true, 4, M>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k,     \
+                           (const bf16_t*)v, kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale);               \
+        break;
+        switch (g_fwd_variant - 16) { IE_ABL(1) IE_ABL(2) IE_ABL(3) IE_ABL(4) IE_ABL(7) IE_ABL(8) IE_ABL(11) IE_ABL(12) IE_ABL(16) IE_ABL(15) IE_ABL(32) default: break; }
+#undef IE_ABL
+        return ie_launch_status("ie_flash_attn_fwd launch");
+    }
+    if (g_fwd_variant > 0) {
+        dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
+#define IE_L64(DD, CA, TH)                                                                                                           \
+    hipLaunchKernelGGL((flash_fwd64_k<DD, CA, TH>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, \
+                       kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
+#define IE_L64T(DD, CA) do { if (g_fwd_variant == 1) IE_L64(DD, CA, 0); else IE_L64(DD, CA, 4); } while (0)
+        if (d == 128) { if (causal) IE_L64T(128, true); else IE_L64T(128, false); }
+        else          { if (causal) IE_L64T(64, true); else IE_L64T(64, false); }
+#undef IE_L64T
+#undef IE_L64
+        return ie_launch_status("ie_flash_attn_fwd launch");
+    }
+    dim3 grid((unsigned)hq, (unsigned)((max_seqlen + 127) / 128), (unsigned)nseq);
 #define IE_L(DD, CA)                                                                                                              \
     hipLaunchKernelGGL((flash_fwd_k<DD, CA>), grid, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
                        (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
@@ -201,4 +581,20 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     else          { if (causal) IE_L(64, true); else IE_L(64, false); }
 #undef IE_L
     return ie_launch_status("ie_flash_attn_fwd launch");
+}
+
+// tuning hook (A/B benchmarking only): kernel variant of the forward
+extern "C" int ie_tune_flash_fwd_variant(int variant) {
+    IE_CHECK_ARG(variant >= 0 && variant <= 64, "ie_tune_flash_fwd_variant: 0, 1, 2 (or 16 + ablation mask)");
+    g_fwd_variant = variant;
+    return IE_OK;
+}
+
+// diagnostic: read and clear the per-phase cycle totals of the instrumented forward build (variant 16 + 32)
+extern "C" int ie_debug_read_counters(unsigned long long* host_out, int n) {
+    IE_CHECK_ARG(host_out && n > 0 && n <= 8, "ie_debug_read_counters: n in 1..8");
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), n * sizeof(unsigned long long)) != hipSuccess) return IE_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return IE_ERR_LAUNCH;
+    return IE_OK;
 }
