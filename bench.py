@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Megatron 'mtp') group size, parallel.tensor=dict(size=tp, mode='mtp'); "
                                                        "must divide --gpus; data parallel size = gpus / tp")
+    ap.add_argument("--zero", type=int, default=None, help="parallel.zero1.size: ranks that share one copy of the sharded optimizer state "
+                                                            "(hybrid ZeRO when smaller than the data-parallel size; default: the whole data-parallel group)")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
                                                        "must divide --gpus; data parallel size = gpus / sp")
     args = ap.parse_args()
@@ -126,7 +128,7 @@ def main():
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None,
-                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro))
+                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero)
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()
@@ -163,6 +165,14 @@ def main():
         dt = float(t)
     st = eng.read_state()
     loss_val = float(loss)
+    # what every rank sees of the communicator (rank 0 prints it: a job that silently ran as N independent 1-rank jobs would show here)
+    comm_info = {"backend": "none (single process)", "rccl_world_size_per_rank": [1]}
+    if world > 1:
+        seen = torch.zeros(world, dtype=torch.int64, device=dev)
+        seen[rank] = torch.distributed.get_world_size()
+        torch.distributed.all_reduce(seen)   # SUM of one-hot rows: entry r = the world size rank r reports
+        comm_info = {"backend": torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
+    comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
 
     tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp)
     sec_step = dt / args.steps
@@ -202,6 +212,7 @@ def main():
         "grad_norm_last_step": st.grad_norm,
         "loss_scale": st.loss_scale,
         "skipped_steps": st.skipped_total,
+        "comm": comm_info,
     }
     if prof is not None:
         s = prof.summary()

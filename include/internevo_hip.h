@@ -276,8 +276,6 @@ int ie_tune_flash_dkdv_split(int split);
 /* Tuning hooks (A/B benchmarking, tools/kbench): kernel variant of the attention forward / backward (0 = default). */
 int ie_tune_flash_fwd_variant(int variant);
 int ie_tune_flash_bwd_variant(int variant);
-/* Diagnostic (instrumented kbench builds only): read and clear the per-phase cycle counters of the attention forward. */
-int ie_debug_read_counters(unsigned long long* host_out, int n);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

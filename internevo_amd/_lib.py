@@ -98,7 +98,6 @@ SIGNATURES = {
     "ie_tune_flash_dkdv_split": (I, [I]),
     "ie_tune_flash_fwd_variant": (I, [I]),
     "ie_tune_flash_bwd_variant": (I, [I]),
-    "ie_debug_read_counters": (I, [P, I]),
     "ie_flash_attn_bwd_workspace": (I64, [I64, I, I, I]),
     "ie_mfma_probe": (I, [P, P, P, P]),
 }

@@ -213,6 +213,26 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
             torch.save(plan, os.path.join(folder, f"gpus-{zero_world * tp_world}_wp-0_tp-{tp_rank}_dp-{r}_pp-0_zo-{r}.pt"))
 
 
+def remove_stale_shards(folder, zero_world, tp_world):
+    """Before a save into an existing folder: drop the shard / plan / topology files of an earlier save by a LARGER layout.  The
+    loaders infer the saved layout from the highest file index present (saved_zero_world / saved_tp_world, as the reference's
+    components.py:294-306 does), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would be merged as if
+    they belonged to it.  Called by ONE rank, before anyone writes."""
+    if not os.path.isdir(folder):
+        return
+    import re
+
+    for fn in os.listdir(folder):
+        m = re.fullmatch(r"optimizer_tp(\d+)_pp0_zo(\d+)\.pt", fn)
+        stale = bool(m) and (int(m.group(1)) >= tp_world or int(m.group(2)) >= zero_world)
+        m = re.fullmatch(r"(?:model_tp(\d+)_pp0\.pt|topo_tp(\d+)_pp0\.json)", fn)
+        stale = stale or (bool(m) and int(m.group(1) or m.group(2)) >= tp_world)
+        m = re.fullmatch(r"gpus-(\d+)_wp-0_tp-(\d+)_dp-(\d+)_pp-0_zo-(\d+)\.pt", fn)
+        stale = stale or (bool(m) and (int(m.group(1)) != zero_world * tp_world or int(m.group(2)) >= tp_world or int(m.group(4)) >= zero_world))
+        if stale:
+            os.remove(os.path.join(folder, fn))
+
+
 def saved_zero_world(folder, tp_rank=0):
     """Number of ZeRO-1 optimizer shards of a tensor rank in the folder (components.py:294-306 counts them the same way); 0 = weights only."""
     n, pre = 0, f"optimizer_tp{tp_rank}_pp0_zo"

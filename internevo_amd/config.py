@@ -170,6 +170,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
             raise NotImplementedError(f"{_UNSUPPORTED}: model.{key} > 0 (the path trains without dropout)")
     if m.get("multiple_of", 256) != 256:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.multiple_of != 256")
+    if not d.get("use_packed_dataset", True):
+        raise NotImplementedError(f"{_UNSUPPORTED}: data.use_packed_dataset=False (the loaders build PackedDatasetWithCut batches only)")
     if d.get("rampup_batch_size", "") or d.get("skip_batches", ""):
         raise NotImplementedError(f"{_UNSUPPORTED}: data.rampup_batch_size / data.skip_batches")
     zero1 = par.get("zero1", {})

@@ -180,39 +180,6 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
 
 
 
-// ---- MFMAs with an explicit register file for every operand (one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
-// hipcc allocates every MFMA accumulator of a > 256-register kernel in the accumulation file and then copies whatever the vector
-// ALU touches back and forth (v_accvgpr_read / _write: > 1000 of them in this kernel); with the operand files spelled out the
-// scores S (vector-ALU food) stay in arch VGPRs, O and the Q fragments (MFMA-only) live in the accumulation file.  The asm
-// statements are opaque to the hazard recognizer, so the wait states the ISA asks for are written here:
-//   * VALU-written VGPR -> MFMA A/B operand: 2 states.  The only VALU-written operands are the packed P fragments, written in
-//     phase 1 and read in phase 2 with at least 12 MFMAs in between (K / V fragments come from LDS, Q from the accumulation file);
-//   * MFMA result -> any non-accumulate reader: 12 states for an 8-pass MFMA: mfma_settle() before the vector ALU (or the epilogue)
-//     looks at accumulators right behind their last MFMA; inside the tile loop >= 16 other MFMAs separate writer and reader.
-// (b_acc is a read-write operand although the MFMA only reads it: that pins the Q fragment in ONE accumulation register tuple
-// for the whole kernel; as a plain input hipcc copies it into a fresh tuple in front of every statement)
-__device__ __forceinline__ void mfma_s_first(f32x16& d, const s16x8& a, s16x8& b_acc) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(b_acc) : "v"(a));
-}
-__device__ __forceinline__ void mfma_s(f32x16& d, const s16x8& a, s16x8& b_acc) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(d), "+a"(b_acc) : "v"(a));
-}
-__device__ __forceinline__ void mfma_o(f32x16& d_acc, const s16x8& a, const s16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d_acc) : "v"(a), "v"(b));
-}
-// vector-ALU instructions that must stay where they are written (a volatile asm statement keeps its place among the MFMA
-// statements; hipcc would hoist all 64 scale-and-subtracts of a phase to its top, outside any MFMA shadow) and that hipcc would
-// otherwise wrap in canonicalising v_max (fmaxf on values it cannot prove quiet).  Plain VALU -> VALU dependencies are interlocked.
-__device__ __forceinline__ float fma_pinned(float a, float b, float c) {
-    float r;
-    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ void max3_pinned(float& m, float a, float b) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
-    asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-__device__ __forceinline__ void mfma_settle_acc(f32x16& a, f32x16& b) { asm volatile("s_nop 15" : "+a"(a), "+a"(b)); }
 // acc *= f, element-wise, with the accumulator staying in the accumulation file (a vector-ALU use of it in HIP source would make
 // hipcc keep it in arch VGPRs and copy all of it into the accumulation file in front of every MFMA statement)
 __device__ __forceinline__ void acc_scale(f32x16& acc, float f) {
@@ -238,9 +205,7 @@ __device__ __forceinline__ void acc_scale(f32x16& acc, float f) {
 // (the O rescale by alpha(t), when some row maximum moved by more than the deferral threshold, opens phase 1).
 // S is double-buffered in registers (the loop is unrolled by two, which also makes every LDS stage address an immediate).
 // K(t+2) and V(t+1) are requested by LDS-DMA at the top of tile t: each has a whole tile of MFMAs to land; one barrier per tile.
-__device__ unsigned long long g_dbg[8];  // ABL & 32: per-phase cycle totals of wave 0 of every block (diagnostic builds only)
-
-template <int D, bool CAUSAL, int THR, int ABL = 0>
+template <int D, bool CAUSAL, int THR>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out,
                                                         int64_t o_ts, float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T,
@@ -385,23 +350,15 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
     constexpr int EPC = 64 / NM;    // score elements per lane handled beside one MFMA (2 for D = 128, 4 for D = 64)
     static_assert(8 * G::DB == NM && EPC >= 2, "phase geometry");
 
-    long long dbg[5] = {0, 0, 0, 0, 0};
     // tile t with its scores in `sc`; the scores of tile t+1 go to `sn`.  PAR = t & 1 selects the LDS stages.
     auto tile = [&](auto par_c, int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
         constexpr int PAR = decltype(par_c)::value;
-        constexpr bool DBG = (ABL & 32) != 0;
-        long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
-        if (DBG) T0 = __builtin_amdgcn_s_memtime();
         // every wave's DMA pieces of K(t+1) and V(t) have landed; every wave is done with K(t) and V(t-1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (DBG) T1 = __builtin_amdgcn_s_memtime();
-        if (!(ABL & 16)) {
-            if (t + 2 < nt) ksrc.issue(Kst + PAR * IMG, (t + 2) * 64, 0, wave);
-            if (t + 1 < nt) vsrc.issue(Vst + (1 - PAR) * IMG, (t + 1) * 64, 0, wave);
-        }
+        if (t + 2 < nt) ksrc.issue(Kst + PAR * IMG, (t + 2) * 64, 0, wave);
+        if (t + 1 < nt) vsrc.issue(Vst + (1 - PAR) * IMG, (t + 1) * 64, 0, wave);
         if (t >= ntw) return;
-        if (DBG) T2 = __builtin_amdgcn_s_memtime();
         const unsigned char* Kn = Kst + (1 - PAR) * IMG;
         const unsigned char* Vc = Vst + PAR * IMG;
         const bool has_next = t + 1 < ntw;   // this wave also works on tile t + 1
@@ -416,7 +373,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         float rs[2] = {0.f, 0.f};
         const float nmoff[2] = {-moff[0], -moff[1]};
         auto fin_chunk = [&](int i) {  // elements [i*EPC, (i+1)*EPC) of the 64 scores a lane holds: X = e/32, c = (e/16)&1, r = e&15
-            if (ABL & 1) return;  // (ablation build: timing only)
 #pragma unroll
             for (int u = 0; u < EPC; u += 2) {
                 const int e = i * EPC + u, X = e >> 5, c = (e >> 4) & 1, r = e & 15;
@@ -433,30 +389,22 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         // fragments' round trip (they cannot be requested before the barrier) has cover.
         constexpr int PF = 3, SK = 2, NK = 2 * G::KS, NV = 4 * G::DB;
         s16x8 kq[NK], vq[NV];
-        auto load_v = [&](int j) { if (!(ABL & 4)) vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
-        if (ABL & 4) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) vq[j] = qf[0][0];
-#pragma unroll
-            for (int j = 0; j < NK; ++j) kq[j] = qf[0][1];
-        }
+        auto load_v = [&](int j) { vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < PF; ++j) if (!(ABL & 4)) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo);
+            for (int j = 0; j < PF; ++j) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo);
 #pragma unroll
             for (int i = 0; i < SK; ++i) fin_chunk(i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NK; ++j) {
                 const int c = j / G::KS, ks = j % G::KS;
-                if (j + PF < NK) { if (!(ABL & 4)) kq[j + PF] = row_frag<D>(Kn, 32 * ((j + PF) / G::KS), (j + PF) % G::KS, fo); }
+                if (j + PF < NK) kq[j + PF] = row_frag<D>(Kn, 32 * ((j + PF) / G::KS), (j + PF) % G::KS, fo);
                 else load_v(j + PF - NK);
 #pragma unroll
                 for (int X = 0; X < 2; ++X) {
-                    if (!(ABL & 8)) {
-                        if (ks == 0) mfma_s_first(sn[X][c], kq[j], qf[X][ks]);
-                        else mfma_s(sn[X][c], kq[j], qf[X][ks]);
-                    }
+                    if (ks == 0) mfma_s_first(sn[X][c], kq[j], qf[X][ks]);
+                    else mfma_s(sn[X][c], kq[j], qf[X][ks]);
                     if (j * 2 + X + SK < NM) fin_chunk(j * 2 + X + SK);
                     __builtin_amdgcn_sched_barrier(0);  // this chunk's vector ALU work stays in the shadow of this MFMA
                 }
@@ -473,11 +421,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         // ---- phase 2: the in-lane maxima of S(t+1) beside the first half of the MFMAs (4 scores per MFMA), the rest of
         // start-softmax(t+1) -- a short dependent chain -- in the middle, with MFMAs still queued behind it.  On a wave's last tile
         // the maxima are taken over stale registers and dropped: the per-MFMA chunks carry no branches.
-        if (DBG) T3 = __builtin_amdgcn_s_memtime();
         if (has_next) apply_mask(sn, t + 1);
         float mx[2] = {-INFINITY, -INFINITY};
         auto max_chunk = [&](int i) {  // 2 * EPC scores
-            if (ABL & 2) return;
 #pragma unroll
             for (int u = 0; u < 2 * EPC; u += 2) {
                 const int e = i * 2 * EPC + u, X = e >> 5, c = (e >> 4) & 1, r = e & 15;
@@ -490,15 +436,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
             if (j + PF < NV) load_v(j + PF);
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
-                if (!(ABL & 8)) mfma_o(oacc[X][db], vq[j], __builtin_bit_cast(s16x8, pf[X][c][s2]));
+                mfma_o(oacc[X][db], vq[j], __builtin_bit_cast(s16x8, pf[X][c][s2]));
                 if (j * 2 + X < NM / 2) max_chunk(j * 2 + X);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (j == NV / 2 - 1 && has_next) sm_start(mx);
-        }
-        if (DBG) {
-            T4 = __builtin_amdgcn_s_memtime();
-            dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3; dbg[4] += 1;
         }
     };
 
@@ -507,9 +449,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1, sB, sA);
     }
 
-    if ((ABL & 32) && threadIdx.x == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_dbg[i], (unsigned long long)dbg[i]);
-    }
 #pragma unroll
     for (int X = 0; X < 2; ++X)
 #pragma unroll
@@ -532,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         }
 }
 
-int g_fwd_variant = 0;  // 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: THR = 4
+int g_fwd_variant = -1;  // -1: automatic; 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: 64 rows per wave, THR = 4
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -549,24 +488,16 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
                        "ie_flash_attn_fwd: pointers must be 16-byte aligned and token strides multiples of 8");
     if (nseq == 0 || T == 0 || max_seqlen == 0) return IE_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (g_fwd_variant >= 16) {  // ablation builds (timing experiments, wrong results): variant = 16 + mask
-        dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
-        IE_CHECK_SUPPORTED(d == 128 && causal, "ablation variants: d = 128, causal");
-#define IE_ABL(M)                                                                                                                  \
-    case M:                                                                                                                        \
-        hipLaunchKernelGGL((flash_fwd64_k<128, true, 4, M>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k,     \
-                           (const bf16_t*)v, kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale);               \
-        break;
-        switch (g_fwd_variant - 16) { IE_ABL(1) IE_ABL(2) IE_ABL(3) IE_ABL(4) IE_ABL(7) IE_ABL(8) IE_ABL(11) IE_ABL(12) IE_ABL(16) IE_ABL(15) IE_ABL(32) default: break; }
-#undef IE_ABL
-        return ie_launch_status("ie_flash_attn_fwd launch");
-    }
-    if (g_fwd_variant > 0) {
+    // automatic: 64 rows per wave (deferred rescale) for long sequences of head dim 128, where it measures 4-5 % faster in same-box
+    // A/B runs (4 x 4096 causal: 679 vs 713 us, full attention 4 x 2048: 337 vs 351 us; profiles/r02_flash_attention.md); ragged packs
+    // of short sequences leave too many of its 256-row blocks half empty (8 x <= 3000: 360 vs 336 us)
+    const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? 2 : 0);
+    if (fwd_variant > 0) {
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_L64(DD, CA, TH)                                                                                                           \
     hipLaunchKernelGGL((flash_fwd64_k<DD, CA, TH>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, \
                        kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
-#define IE_L64T(DD, CA) do { if (g_fwd_variant == 1) IE_L64(DD, CA, 0); else IE_L64(DD, CA, 4); } while (0)
+#define IE_L64T(DD, CA) do { if (fwd_variant == 1) IE_L64(DD, CA, 0); else IE_L64(DD, CA, 4); } while (0)
         if (d == 128) { if (causal) IE_L64T(128, true); else IE_L64T(128, false); }
         else          { if (causal) IE_L64T(64, true); else IE_L64T(64, false); }
 #undef IE_L64T
@@ -585,16 +516,8 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
 
 // tuning hook (A/B benchmarking only): kernel variant of the forward
 extern "C" int ie_tune_flash_fwd_variant(int variant) {
-    IE_CHECK_ARG(variant >= 0 && variant <= 64, "ie_tune_flash_fwd_variant: 0, 1, 2 (or 16 + ablation mask)");
+    IE_CHECK_ARG(variant >= -1 && variant <= 2, "ie_tune_flash_fwd_variant: -1 (automatic), 0, 1 or 2");
     g_fwd_variant = variant;
     return IE_OK;
 }
 
-// diagnostic: read and clear the per-phase cycle totals of the instrumented forward build (variant 16 + 32)
-extern "C" int ie_debug_read_counters(unsigned long long* host_out, int n) {
-    IE_CHECK_ARG(host_out && n > 0 && n <= 8, "ie_debug_read_counters: n in 1..8");
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), n * sizeof(unsigned long long)) != hipSuccess) return IE_ERR_LAUNCH;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)) != hipSuccess) return IE_ERR_LAUNCH;
-    return IE_OK;
-}

@@ -197,4 +197,38 @@ __device__ __forceinline__ f32x16 zero16() {
 
 __device__ __forceinline__ uint4 z4() { return make_uint4(0, 0, 0, 0); }
 
+// ---- MFMAs with an explicit register file for every operand (kernels with one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
+// hipcc allocates every MFMA accumulator of a > 256-register kernel in the accumulation file and then copies whatever the vector
+// ALU touches back and forth (v_accvgpr_read / _write: > 1000 of them in this kernel); with the operand files spelled out the
+// scores S (vector-ALU food) stay in arch VGPRs, O and the Q fragments (MFMA-only) live in the accumulation file.  The asm
+// statements are opaque to the hazard recognizer, so the wait states the ISA asks for are written here:
+//   * VALU-written VGPR -> MFMA A/B operand: 2 states.  The only VALU-written operands are the packed P fragments, written in
+//     phase 1 and read in phase 2 with at least 12 MFMAs in between (K / V fragments come from LDS, Q from the accumulation file);
+//   * MFMA result -> any non-accumulate reader: 12 states for an 8-pass MFMA: mfma_settle() before the vector ALU (or the epilogue)
+//     looks at accumulators right behind their last MFMA; inside the tile loop >= 16 other MFMAs separate writer and reader.
+// (b_acc is a read-write operand although the MFMA only reads it: that pins the Q fragment in ONE accumulation register tuple
+// for the whole kernel; as a plain input hipcc copies it into a fresh tuple in front of every statement)
+__device__ __forceinline__ void mfma_s_first(f32x16& d, const s16x8& a, s16x8& b_acc) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(b_acc) : "v"(a));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const s16x8& a, s16x8& b_acc) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(d), "+a"(b_acc) : "v"(a));
+}
+__device__ __forceinline__ void mfma_o(f32x16& d_acc, const s16x8& a, const s16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d_acc) : "v"(a), "v"(b));
+}
+// vector-ALU instructions that must stay where they are written (a volatile asm statement keeps its place among the MFMA
+// statements; hipcc would hoist all 64 scale-and-subtracts of a phase to its top, outside any MFMA shadow) and that hipcc would
+// otherwise wrap in canonicalising v_max (fmaxf on values it cannot prove quiet).  Plain VALU -> VALU dependencies are interlocked.
+__device__ __forceinline__ float fma_pinned(float a, float b, float c) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void max3_pinned(float& m, float a, float b) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+    asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void mfma_settle_acc(f32x16& a, f32x16& b) { asm volatile("s_nop 15" : "+a"(a), "+a"(b)); }
+
 }  // namespace fa

@@ -40,8 +40,11 @@ BF16 = torch.bfloat16
 
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
-                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None):
-        """sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
+                 force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
+                 zero_size=None):
+        """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
+        consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
+        sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step)."""
         self.cfg = cfg
@@ -63,9 +66,17 @@ class InternLM2Engine:
             # data parallelism and ZeRO-1 run over the ranks that hold the same shard
             process_group, world_size, rank = self.tpar.dp_group, self.tpar.dp_world, self.tpar.dp_rank
             self.world, self.rank = world_size, rank
-        self.layout = FlatLayout(self.lmc, world_size)
+        # data-parallel group (dp_world ranks) -> ZeRO shards: `self.world` / `self.rank` count the SHARDS of the optimizer state
+        # (= the data-parallel group unless parallel.zero1.size asks for hybrid ZeRO)
+        self.dp_world, self.dp_rank = world_size, rank
+        zs = tc.zero1_size if zero_size is None else zero_size
+        zs = world_size if (zs is None or zs <= 0 or zs >= world_size) else int(zs)
+        if world_size % zs:
+            raise ValueError(f"parallel.zero1.size = {zs} must divide the data-parallel size {world_size}")
+        self.world, self.rank = zs, rank % zs
+        self.layout = FlatLayout(self.lmc, zs)
         L = self.layout
-        self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives)
+        self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs)
         self.sp = sp_size
         self.seqpar = SeqParallel(sp_size, rank, world_size)
         if tp_size > 1:  # every rank of a tensor group reads the same batches
@@ -139,16 +150,20 @@ class InternLM2Engine:
         if init_fn is not None:
             self.load_named_parameters({n: init_fn(n, shape) for n, shape in self.reference_param_shapes().items()}, sync_master=False)
             return
-        gen = torch.Generator(device=self.dev).manual_seed(seed + self.rank * 0)  # same weights on every DP rank
-        for n, s in self.layout.params.items():
-            if s.kind == "norm":
+        # The FULL (un-sharded) tensors are drawn from one generator in the order of the single-rank layout and every tensor rank
+        # keeps its cut (tensorpar.shard): all data-parallel ranks start equal, the shards of a tensor group are DIFFERENT pieces
+        # of the same full model (the reference seeds TENSOR mode with seed + tp_rank for the same purpose,
+        # parallel_context.py:639-641), and a tp = n run starts from exactly the weights of the tp = 1 run with the same seed.
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        for n, full in FlatLayout(mc, 1).params.items():
+            if full.kind == "norm":
                 self.p[n].fill_(1.0)
                 continue
             std = mc.init_std
-            if mc.use_scaled_init and s.kind in ("wo", "w2"):
-                std = mc.init_std / math.sqrt(2.0 * (s.layer + 1))
-            w = torch.empty(s.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
-            self.p[n].copy_(w)
+            if mc.use_scaled_init and full.kind in ("wo", "w2"):
+                std = mc.init_std / math.sqrt(2.0 * (full.layer + 1))
+            w = torch.empty(full.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
+            self.p[n].copy_(self.tpar.shard(full.kind, w))
 
     def sync_master_from_params(self):
         """fp32 master copy of this rank's shards (hybrid_zero_optim.py:214-233)."""
@@ -299,8 +314,10 @@ class InternLM2Engine:
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s])
         else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl)
-            self.seqpar.scatter_heads_gather_seq(self.t_ql, 1, self.t_xq, self.a_q[s])
-            self.seqpar.scatter_heads_gather_seq(self.t_kvl, 2, self.t_xkv, self.a_kv[s])
+            xq = self.seqpar.scatter_heads_gather_seq_async(self.t_ql, 1, self.t_xq, self.a_q[s])     # q's exchange runs under kv's packing copy
+            xkv = self.seqpar.scatter_heads_gather_seq_async(self.t_kvl, 2, self.t_xkv, self.a_kv[s])  # and the two exchanges beside each other
+            xq.wait()
+            xkv.wait()
         K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, None, True, self.a_ctx[s], self.a_lse[s])
         if self.sp > 1:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
@@ -407,30 +424,32 @@ class InternLM2Engine:
             wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None)
             d_n2 = spare[0]
             K.linear_dgrad(t_dw13, w13, d_n2)
-            self.tpar.all_reduce_sum(d_n2)   # input gradient of the column-parallel w1 | w3
-            wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None)
+            ar = self.tpar.all_reduce_sum_async(d_n2)   # input gradient of the column-parallel w1 | w3: summed over the tensor group ...
+            wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None)   # ... under this GEMM
+            ar.wait()
             d_r2 = self.st_dr2[l][r] if bw else spare[1]
             K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc, ws, d_r2)
             # attention
             d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
+            # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53); d_ctx travels under wo's weight gradient
+            xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if self.sp > 1 else None
             wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None)
-            if self.sp == 1:
-                d_ctx_full = d_ctx.view(T, -1, d)
-            else:  # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53)
-                d_ctx_full = self.seqpar.scatter_heads_gather_seq(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full)
+            d_ctx_full = d_ctx.view(T, -1, d) if self.sp == 1 else xc.wait()
             K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
                              max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
             if self.sp == 1:
                 dq_l, dkv_l = self.t_dq, self.t_dkv
             else:
-                dq_l = self.seqpar.scatter_seq_gather_heads(self.t_dq, 1, self.t_xq, self.t_ql)
-                dkv_l = self.seqpar.scatter_seq_gather_heads(self.t_dkv, 2, self.t_xkv, self.t_kvl)
+                xq = self.seqpar.scatter_seq_gather_heads_async(self.t_dq, 1, self.t_xq, self.t_ql)
+                xkv = self.seqpar.scatter_seq_gather_heads_async(self.t_dkv, 2, self.t_xkv, self.t_kvl)   # both in flight; dq unpacks under dkv's
+                dq_l, dkv_l = xq.wait(), xkv.wait()
             K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
-            self.tpar.all_reduce_sum(d_n1)   # input gradient of the column-parallel wqkv
+            ar = self.tpar.all_reduce_sum_async(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient
             wgrad(t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], self.st_dqkv[l] if bw else None, self.st_n1[l] if bw else None)
+            ar.wait()
             if bw:    # the layer below reads its output gradient from its own staging rows (it is the dY of that layer's w2)
                 d_x = self.st_dout[l - 1][r] if l > 0 else self.t_h1
             else:
@@ -571,7 +590,9 @@ class InternLM2Engine:
             rep = self._replicated_grad_slices(shards)
             if rep:
                 rs = K.sumsq(rep)
-                self.sumsq.sub_(rs * (1.0 - 1.0 / self.tp))
+                # inf - inf would turn an overflow (inf: the scaler must back off) into NaN (which it treats differently):
+                # an overflowing replicated gradient leaves the total at inf
+                self.sumsq.sub_(torch.where(torch.isfinite(rs), rs * (1.0 - 1.0 / self.tp), torch.zeros_like(rs)))
         self.comm.all_reduce_sum(self.sumsq)
         self.tpar.all_reduce_sum(self.sumsq)
         K.step_control(self.state, self.sumsq, self.scaler_cfg)
@@ -789,12 +810,18 @@ class InternLM2Engine:
         st = self.read_state()  # drains the optimizer stream
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
         tp, t = self.tp, self.tpar.tp_rank
+        if self.dp_rank == 0 and t == 0:   # shards of an earlier, larger layout in the same folder would be merged into this save by any loader
+            C.remove_stale_shards(folder, W, tp)
+        self.comm.barrier()
+        self.tpar.barrier()
         hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
         scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
         cpu = lambda d: {n: x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
         if W == 1:
-            C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
-                              cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t)
+            if self.dp_rank == 0:
+                C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
+                                  cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t)
+            self.comm.barrier()
             self.tpar.barrier()
             return
         shapes = {}
@@ -816,8 +843,9 @@ class InternLM2Engine:
                 del full
             ref_named = self._local_reference_named(named)
             state[key] = {n: ref_named[n] for n in mine}
-        C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
-                          scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t)
+        if self.comm.replica == 0:   # hybrid ZeRO: every zero group holds the same shards, the first one writes them
+            C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
+                              scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t)
         self.comm.barrier()  # the folder is complete when any rank returns
         self.tpar.barrier()
 

@@ -45,15 +45,21 @@ class SeqParallel:
             self.backend = dist.get_backend(self.group)
 
     # ---- the exchange: send[r] (contiguous chunk r) -> rank r; recv[s] <- rank s -------------------------------------
-    def all_to_all(self, send, recv):
+    def all_to_all_async(self, send, recv):
+        """Start the exchange; returns a handle whose .wait() orders the current stream behind it.  On RCCL it runs on c10d's
+        stream (after the work already queued on the current stream), so kernels launched before .wait() overlap it -- the engine
+        puts the neighbouring weight-gradient GEMM / the other tensor's packing copy there.  (gloo test path: done on return.)"""
         # flat views: chunk r of the send buffer is its r-th 1/sp, whatever shape the caller gives the tensors
         if self.backend == "nccl":
-            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
-        else:  # gloo test path: CPU tensors only
-            s = send.detach().reshape(-1).to("cpu", copy=True)
-            r = torch.empty_like(s)
-            dist.all_to_all_single(r, s, group=self.group)
-            recv.view(-1).copy_(r)
+            return dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
+        s = send.detach().reshape(-1).to("cpu", copy=True)   # CPU tensors only
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        recv.view(-1).copy_(r)
+        return _DONE
+
+    def all_to_all(self, send, recv):
+        self.all_to_all_async(send, recv).wait()
         return recv
 
     def all_reduce_sum(self, t):
@@ -66,16 +72,47 @@ class SeqParallel:
         return t
 
     # ---- heads <-> sequence ------------------------------------------------------------------------------------------
-    def scatter_heads_gather_seq(self, x_local, B, pack_buf, out_full):
-        """x_local [Tl, (B,) heads, d] -> out_full [T, (B,) heads/sp, d] (q, kv, d_ctx: _SeqAllToAll scatter_idx = head dim)."""
+    def scatter_heads_gather_seq_async(self, x_local, B, pack_buf, out_full):
+        """x_local [Tl, (B,) heads, d] -> out_full [T, (B,) heads/sp, d] (q, kv, d_ctx: _SeqAllToAll scatter_idx = head dim).
+        Returns a handle; out_full is valid after .wait()."""
         Tl = x_local.shape[0]
         C = x_local.numel() // (Tl * B * self.sp)
         K.seq_head_permute(x_local, pack_buf, Tl, B, self.sp, C, inverse=False)
-        return self.all_to_all(pack_buf, out_full)
+        return _Exchange(self.all_to_all_async(pack_buf, out_full), out_full)
 
-    def scatter_seq_gather_heads(self, x_full, B, recv_buf, out_local):
-        """x_full [T, (B,) heads/sp, d] -> out_local [Tl, (B,) heads, d] (context, dq, dkv: the inverse exchange)."""
+    def scatter_heads_gather_seq(self, x_local, B, pack_buf, out_full):
+        return self.scatter_heads_gather_seq_async(x_local, B, pack_buf, out_full).wait()
+
+    def scatter_seq_gather_heads_async(self, x_full, B, recv_buf, out_local):
+        """x_full [T, (B,) heads/sp, d] -> out_local [Tl, (B,) heads, d] (context, dq, dkv: the inverse exchange).
+        Returns a handle; .wait() orders the stream behind the exchange and unpacks into out_local."""
         Tl = out_local.shape[0]
         C = out_local.numel() // (Tl * B * self.sp)
-        self.all_to_all(x_full, recv_buf)
-        return K.seq_head_permute(recv_buf, out_local, Tl, B, self.sp, C, inverse=True)
+        sp = self.sp
+        return _Exchange(self.all_to_all_async(x_full, recv_buf), out_local,
+                         lambda: K.seq_head_permute(recv_buf, out_local, Tl, B, sp, C, inverse=True))
+
+    def scatter_seq_gather_heads(self, x_full, B, recv_buf, out_local):
+        return self.scatter_seq_gather_heads_async(x_full, B, recv_buf, out_local).wait()
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+_DONE = _Done()
+
+
+class _Exchange:
+    """An exchange in flight: wait() orders the current stream behind it, runs the unpacking copy if there is one, returns the result."""
+
+    def __init__(self, work, out, after=None):
+        self.work, self.out, self.after = work, out, after
+
+    def wait(self):
+        self.work.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+        return self.out

@@ -16,6 +16,14 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+_DONE = _Done()
+
+
 class TensorParallel:
     def __init__(self, tp_size, rank, world_size):
         if world_size % tp_size != 0:
@@ -53,6 +61,19 @@ class TensorParallel:
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(c)
         return t
+
+    def all_reduce_sum_async(self, t):
+        """Start the in-place sum and return a handle; `.wait()` orders the CURRENT stream behind it.  On RCCL the collective runs
+        on c10d's own HIP stream (which first waits for the work already queued on the current stream, i.e. for the GEMM that
+        produced `t`), so kernels launched between this call and `.wait()` overlap it: the engine puts the weight-gradient GEMM of
+        the same layer there, as the reference does with its column-parallel backward (model/utils.py:329-345: all_reduce(grad_input,
+        async_op=True) -> wgrad -> handle.wait()).  On the gloo test path the sum is already complete when this returns."""
+        if self.tp == 1:
+            return _DONE
+        if self.backend == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.all_reduce_sum(t)
+        return _DONE
 
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def barrier(self):

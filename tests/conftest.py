@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ranks(n): GPUs a multi-rank test needs for its RCCL (nccl backend) variant")
 
 
 @pytest.fixture(scope="session")

@@ -44,6 +44,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("IE_GOLDEN_OUT", HERE)   # where --ops / --metrics / --moe / --sched write (tests regenerate into a scratch folder and diff)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, REF)
@@ -172,8 +173,8 @@ def gen_ops():
             sch.step()
         meta["lr_trace"][key] = {"total": total, "ratio": ratio, "eta_min": eta, "init_steps": init_steps, "base": 1e-4, "lrs": lrs}
 
-    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
-    with open(os.path.join(HERE, "ops.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    with open(os.path.join(OUT, "ops.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("ops goldens written:", len(out), "arrays")
 
@@ -398,7 +399,7 @@ def gen_metrics(port=29790):
     from internlm.model.metrics import AccPerplex
 
     cfg = tiny_config("torch.bfloat16", use_packed=False, seq_len=48, hidden=64, heads=2, kv_heads=2, vocab=160, layers=1, micro_num=3, total_steps=2)
-    launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
     args_sanity_check()
     types = ["en", "cn", "code"]
     metric = AccPerplex(device=torch.device("cpu"), tp_pg=gpc.get_group(ParallelMode.TENSOR), dp_pg=gpc.get_group(ParallelMode.DATA), dataset_types=types)
@@ -425,8 +426,8 @@ def gen_metrics(port=29790):
             "ds_loss": metric.loss_with_type_id.ds_loss.tolist(), "ds_token_num": metric.loss_with_type_id.ds_token_num.tolist()})
     res = metric.get_metric(reset=True)
     after_reset = {"right": float(metric.right), "total": float(metric.total), "ds_tokens": metric.ds_tokens.tolist()}
-    np.savez_compressed(os.path.join(HERE, "metrics.npz"), logits=logits.numpy(), labels=labels.numpy(), type_ids=type_ids.numpy())
-    with open(os.path.join(HERE, "metrics.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), logits=logits.numpy(), labels=labels.numpy(), type_ids=type_ids.numpy())
+    with open(os.path.join(OUT, "metrics.json"), "w") as f:
         json.dump({"dataset_types": types, "trace": trace, "get_metric": res, "after_reset": after_reset}, f, indent=1)
     print(res)
 
@@ -827,8 +828,8 @@ def gen_moe():
         meta.append(dict(name=name, S=S, E=E, capacity_factor=cf, min_capacity=mincap, l_aux=float(l_aux), capacity=int(cw.shape[2]),
                          dropped=int(2 * S - int(dm.sum()))))
         print("moe", meta[-1], flush=True)
-    np.savez_compressed(os.path.join(HERE, "moe.npz"), **arrays)
-    with open(os.path.join(HERE, "moe.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "moe.npz"), **arrays)
+    with open(os.path.join(OUT, "moe.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
 
@@ -851,7 +852,7 @@ def gen_sched_state():
             sch.step()
         out["cases"].append({"total_steps": total, "warmup_ratio": ratio, "init_steps": init_steps, "eta_min": eta_min, "base_lr": 1e-3,
                              "states": states})
-    with open(os.path.join(HERE, "sched_state.json"), "w") as f:
+    with open(os.path.join(OUT, "sched_state.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("sched_state.json", len(out["cases"]))
 

@@ -475,3 +475,21 @@ def test_engine_resumes_from_reference_checkpoint_and_round_trips(dev, tmp_path)
         eng2.step()
         tr2.append((loss, eng2.read_state().grad_norm))
     assert tr == tr2 and torch.equal(eng.params, eng2.params), "a restored engine continues bit-identically"
+
+
+def test_stale_shards_of_a_larger_layout_are_removed_before_a_save(tmp_path):
+    """Re-saving into a folder that still holds the shards of an earlier, larger layout: the loaders infer the layout from the highest
+    file index present, so those files have to go before the new save is written (engine.save_checkpoint calls this on one rank)."""
+    from internevo_amd import checkpoint as C
+
+    names = ["model_tp0_pp0.pt", "model_tp1_pp0.pt", "topo_tp0_pp0.json", "topo_tp1_pp0.json"]
+    names += [f"optimizer_tp{t}_pp0_zo{z}.pt" for t in range(2) for z in range(4)]
+    names += [f"gpus-8_wp-0_tp-{t}_dp-{z}_pp-0_zo-{z}.pt" for t in range(2) for z in range(4)]
+    names += ["context.pt", "sampler.pt", "schedulder.pt"]
+    for n in names:
+        (tmp_path / n).write_bytes(b"x")
+    C.remove_stale_shards(str(tmp_path), zero_world=2, tp_world=1)
+    left = sorted(os.listdir(tmp_path))
+    assert left == sorted(["model_tp0_pp0.pt", "topo_tp0_pp0.json", "optimizer_tp0_pp0_zo0.pt", "optimizer_tp0_pp0_zo1.pt",
+                           "context.pt", "sampler.pt", "schedulder.pt"]), left   # the gpus-8 plans name another world size: all gone
+    assert C.saved_zero_world(str(tmp_path)) == 2 and C.saved_tp_world(str(tmp_path)) == 1

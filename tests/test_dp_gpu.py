@@ -35,6 +35,33 @@ def _collect(q, procs, n, timeout=500):
     return out
 
 
+def _init_dist(rank, world, port):
+    """Process group + device of a worker.  IE_TEST_BACKEND = "gloo" (default; what a 1-GPU box can run: every rank on cuda:0,
+    collectives staged through the host) or "nccl" (= RCCL over xGMI, one GPU per rank: the product path, exercised whenever the
+    box has enough GPUs)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    backend = os.environ.get("IE_TEST_BACKEND", "gloo")
+    dev = torch.device(f"cuda:{rank}" if backend == "nccl" else "cuda:0")
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dev
+
+
+@pytest.fixture(params=["gloo", "nccl"])
+def backend(request, monkeypatch):
+    need = getattr(request.node.get_closest_marker("ranks"), "args", (2,))[0]
+    if request.param == "nccl" and torch.cuda.device_count() < need:
+        pytest.skip(f"RCCL run needs {need} GPUs (one rank per GPU); this box has {torch.cuda.device_count()}")
+    monkeypatch.setenv("IE_TEST_BACKEND", request.param)
+    return request.param
+
+
 def _cfg(micro_num):
     from internevo_amd.config import tiny
 
@@ -42,18 +69,16 @@ def _cfg(micro_num):
 
 
 def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init_dist(rank, world, port)
     try:
         from internevo_amd.data import SyntheticLoader
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        dev = torch.device("cuda:0")
-        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init)
+        zero = int(os.environ.get("IE_TEST_ZERO", "0")) or None
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, zero_size=zero)
         loader = iter(SyntheticLoader(128, 1, 2, True, 4000, data_rank=rank, data_world_size=world))
         out = []
         for _ in range(2):
@@ -68,7 +93,7 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_step_equals_one_rank_step(dev):
+def test_two_rank_step_equals_one_rank_step(dev, backend):
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
@@ -114,19 +139,67 @@ def test_two_rank_step_equals_one_rank_step(dev):
     assert worst <= 6e-3
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.ranks(4)
+def test_hybrid_zero_step_equals_one_rank_step(dev, backend, monkeypatch):
+    """parallel.zero1.size = 2 on 4 data-parallel ranks (hybrid ZeRO: optimizer state sharded inside groups of two consecutive ranks,
+    replicated across the two groups; gradients reduce-scattered inside the group and all-reduced across the replicas): the step
+    equals one rank over the union of the micro-batches, all four ranks end with the same parameters, and each rank holds half of
+    every bucket's fp32 state."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    monkeypatch.setenv("IE_TEST_ZERO", "2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 4, 29843, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 4), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_cfg(8), dev, init_fn=formula_init)
+    loader = iter(SyntheticLoader(128, 1, 8, True, 4000))
+    ref = []
+    for _ in range(2):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm)))
+    params = [torch.from_numpy(r[2]) for r in res]
+    for p_ in params[1:]:
+        assert torch.equal(params[0], p_), "ranks disagree on the parameters after the all-gather inside their zero groups"
+    for k in range(2):
+        mean_loss = sum(r[1][k][0] for r in res) / 4
+        print(f"step {k}: dp4/zero2 loss {mean_loss:.5f} gn {res[0][1][k][1]:.4f} | 1 rank (8 micro) loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        assert abs(mean_loss - ref[k][0]) <= 2e-3 * abs(ref[k][0])
+        for r in res[1:]:
+            assert abs(r[1][k][1] - res[0][1][k][1]) <= 1e-6 * res[0][1][k][1], "ranks disagree on the global grad norm"
+        assert abs(res[0][1][k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    from internevo_amd.layout import FlatLayout
+
+    L2, L1 = FlatLayout(_cfg(2).model, 2), eng.layout   # two shards per bucket, whatever the data-parallel size
+    ref_params = eng.params.float().cpu()
+    worst = 0.0
+    for n, sp in L1.params.items():
+        s2 = L2.params[n]
+        worst = max(worst, float((ref_params[sp.offset : sp.offset + sp.numel] - params[0][s2.offset : s2.offset + s2.numel]).abs().max()))
+    print("max |param diff| dp4/zero2 vs 1 rank:", worst)
+    assert worst <= 6e-3
+
+
 def _ckpt_worker(rank, world, port, q, folder):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init_dist(rank, world, port)
     try:
         from internevo_amd.data import SyntheticLoader
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        dev = torch.device("cuda:0")
-        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init)
+        zero = int(os.environ.get("IE_TEST_ZERO", "0")) or None
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, zero_size=zero)
         loader = iter(SyntheticLoader(128, 1, 2, True, 4000, data_rank=rank, data_world_size=world))
         for _ in range(2):
             batch, labels = next(loader)
@@ -151,7 +224,7 @@ def _ckpt_worker(rank, world, port, q, folder):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_checkpoint_round_trip_and_reshard(dev, tmp_path):
+def test_two_rank_checkpoint_round_trip_and_reshard(dev, tmp_path, backend):
     """2 data-parallel ranks save InternEvo's checkpoint files (one whole-parameter ZeRO shard per rank, the reference's greedy
     partition), fresh engines load them: state bit-identical, the next step bit-identical.  The same folder loaded into ONE rank
     (shards merged and re-cut) continues with the same step up to summation order."""
@@ -246,18 +319,15 @@ def test_rccl_call_sequence_on_one_rank_group(dev):
 
 
 def _sp_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init_dist(rank, world, port)
     try:
         from internevo_amd.data import SyntheticLoader
         from internevo_amd.engine import InternLM2Engine
         from internevo_amd.metrics import AccPerplex
         from oracle.model import formula_init
 
-        dev = torch.device("cuda:0")
         eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, sp_size=2)
         metric = AccPerplex(dev, None, ["en"], dp_world_size=world)
         eng.attach_metric(metric)
@@ -276,7 +346,7 @@ def _sp_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_sequence_parallel_step_equals_single_rank_step(dev):
+def test_sequence_parallel_step_equals_single_rank_step(dev, backend):
     """Ulysses / ISP sequence parallelism with sp = 2 on two ranks vs ONE rank running the same
     micro-batches with the ISP gradient averaging rule emulated: splitting the tokens and exchanging heads for sequence must not
     change the step -- same loss, same grad norm, same trained weights (bf16 summation-order noise only), same metric counts."""
@@ -330,17 +400,14 @@ def test_sequence_parallel_step_equals_single_rank_step(dev):
 
 
 def _tp_worker(rank, world, port, q, folder=None):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init_dist(rank, world, port)
     try:
         from internevo_amd.data import SyntheticLoader
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        dev = torch.device("cuda:0")
         eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, tp_size=2)
         loader = iter(SyntheticLoader(128, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
@@ -365,13 +432,16 @@ def _tp_worker(rank, world, port, q, folder=None):
                 e.step()
                 nxt.append((float(loss), float(e.read_state().grad_norm)))
             ck = (bool(same), nxt, bool(torch.equal(eng.params, fresh.params)))
-        q.put((rank, out, shards, ck))
+        # the DEFAULT initialisation (what train.py uses): every tensor rank must hold its own cut of one full model
+        dflt = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, seed=77)
+        init_shards = {n: p.float().cpu().numpy() for n, p in dflt.p.items()}
+        q.put((rank, out, shards, ck, init_shards))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path):
+def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
     same micro-batches: same loss, same grad norm (replicated parameters counted once), and the two ranks' parameter shards
     concatenate to the single-rank parameters (bf16 summation-order noise only)."""
@@ -397,7 +467,16 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path):
         loss = eng.forward_backward(batch, labels)
         eng.step()
         ref.append((float(loss), float(eng.read_state().grad_norm)))
-    (r0, o0, s0, c0), (r1, o1, s1, c1) = res
+    (r0, o0, s0, c0, i0), (r1, o1, s1, c1, i1) = res
+    # default init: the shards of a tensor group are different pieces of the full model a single rank draws from the same seed
+    # (equal shards would receive equal gradients forever: half the heads and FFN units of the model would be duplicates)
+    one_init = InternLM2Engine(_cfg(2), dev, seed=77)
+    for n, p in one_init.p.items():
+        kind = s0[n][0]
+        full = TensorParallel.unshard(kind, [torch.from_numpy(i0[n]), torch.from_numpy(i1[n])])
+        assert torch.equal(full, p.float().cpu()), f"default init of {n}: the tensor ranks' cuts do not concatenate to the single-rank tensor"
+        if kind not in ("embed", "norm", "head"):
+            assert not (i0[n] == i1[n]).all(), f"default init of {n}: both tensor ranks hold the same shard"
     for k in range(3):
         print(f"step {k}: tp2 loss {o0[k][0]:.5f} gn {o0[k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
         assert o0[k] == o1[k], "both ranks of a tensor group compute the same loss and the same global grad norm"

@@ -48,14 +48,21 @@ def test_engine_matches_reference_trajectory(dev, tag):
     for k, ((loss, gn, ls, skip, ref), w) in enumerate(zip(rows, gold["steps"])):
         report.append(f"step {k}: HIP loss {loss:.5f} gn {gn:.4f} | oracle {ref['loss']:.5f} {ref['grad_norm']:.4f} | reference {w['loss']:.5f} {w['grad_norm']['0_default']:.4f}")
     print("\n".join(report))
+    # tolerance of the north star: loss within 1e-3 relative of the reference's CPU run (bf16, same batches); grad norm within 2e-2
+    # (the norm is a bf16-gradient statistic: rounding order moves it more than the loss)
+    LOSS_RTOL, NORM_RTOL = 1e-3, 2e-2
+    worst_loss = max(max(abs(r[0] - w["loss"]) / abs(w["loss"]), abs(r[0] - r[4]["loss"]) / abs(r[4]["loss"])) for r, w in zip(rows, gold["steps"]))
+    worst_norm = max(max(abs(r[1] - w["grad_norm"]["0_default"]) / w["grad_norm"]["0_default"], abs(r[1] - r[4]["grad_norm"]) / r[4]["grad_norm"])
+                     for r, w in zip(rows, gold["steps"]))
+    print(f"[parity {tag}] max relative loss deviation {worst_loss:.2e} (bound {LOSS_RTOL:g}), grad norm {worst_norm:.2e} (bound {NORM_RTOL:g})")
     for k, ((loss, gn, ls, skip, ref), w) in enumerate(zip(rows, gold["steps"])):
         assert skip == 0 and ls == w["loss_scale"]
         # vs the real reference's CPU run
-        assert abs(loss - w["loss"]) <= 3e-3 * abs(w["loss"]), f"step {k}: loss {loss} vs reference {w['loss']}"
-        assert abs(gn - w["grad_norm"]["0_default"]) <= 2e-2 * w["grad_norm"]["0_default"], f"step {k}: grad norm {gn} vs {w['grad_norm']['0_default']}"
+        assert abs(loss - w["loss"]) <= LOSS_RTOL * abs(w["loss"]), f"step {k}: loss {loss} vs reference {w['loss']}"
+        assert abs(gn - w["grad_norm"]["0_default"]) <= NORM_RTOL * w["grad_norm"]["0_default"], f"step {k}: grad norm {gn} vs {w['grad_norm']['0_default']}"
         # vs the oracle on identical inputs
-        assert abs(loss - ref["loss"]) <= 3e-3 * abs(ref["loss"])
-        assert abs(gn - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+        assert abs(loss - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+        assert abs(gn - ref["grad_norm"]) <= NORM_RTOL * ref["grad_norm"]
     # end state: trained bf16 weights agree with the oracle's
     worst = 0.0
     for n, p in eng.named_parameters():
@@ -117,8 +124,9 @@ def test_engine_packed_varlen_batch_matches_oracle(dev):
         eng.step()
         st = eng.read_state()
         ref = ora.train_step(batch, labels)
-        print(f"packed step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
-        assert abs(float(loss) - ref["loss"]) <= 3e-3 * abs(ref["loss"])
+        print(f"packed step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}  "
+              f"(relative loss deviation {abs(float(loss) - ref['loss']) / abs(ref['loss']):.2e}, bound 1e-3)")
+        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])
         assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
 
 
@@ -241,7 +249,7 @@ def test_batched_weight_gradients_match_per_micro_batch_accumulation(dev):
             (la, na), (lb, nb) = rows
         print(f"step {k}: batched {la:.5f}/{na:.4f}  per-micro {lb:.5f}/{nb:.4f}  oracle {ref['loss']:.5f}/{ref['grad_norm']:.4f}")
         for l_, n_ in ((la, na), (lb, nb)):
-            assert abs(l_ - ref["loss"]) <= 3e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+            assert abs(l_ - ref["loss"]) <= 1e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
     with pytest.raises(ValueError):
         cfg.model.checkpoint = 1.0
         InternLM2Engine(cfg, dev, batch_wgrad=True)
@@ -293,7 +301,7 @@ def test_merged_micro_batches_match_sequential_accumulation(dev):
         print(f"step {k}: merged {la:.5f}/{na:.4f}  sequential {lb:.5f}/{nb:.4f}  oracle {ref['loss']:.5f}/{ref['grad_norm']:.4f}")
         assert abs(la - lb) <= 1e-4 * abs(lb) or k > 0
         for l_, n_ in ((la, na), (lb, nb)):
-            assert abs(l_ - ref["loss"]) <= 3e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+            assert abs(l_ - ref["loss"]) <= 1e-3 * abs(ref["loss"]) and abs(n_ - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
         ma, mb = ms[0].get_metric(), ms[1].get_metric()
         for key in mb:
             assert abs(ma[key] - mb[key]) <= 2e-2 * max(abs(mb[key]), 1.0), (key, ma[key], mb[key])

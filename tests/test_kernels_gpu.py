@@ -442,6 +442,44 @@ def test_flash_attention_lse_and_big_scores(dev):
     close(lse, torch.logsumexp(s, -1), 1e-3, 1e-2, "flash lse")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("lens,hq,hkv,d,causal", [
+    ([300, 700, 257], 4, 2, 128, True),    # ragged: 256-row blocks with idle waves, a tail block of one row
+    ([1, 129, 64, 512], 4, 1, 64, True),
+    ([333, 90], 2, 2, 128, False),
+    ([1024], 8, 2, 128, True),
+])
+def test_flash_forward_64_rows_per_wave(dev, variant, lens, hq, hkv, d, causal):
+    """The one-wave-per-SIMD forward (flash_fwd64_k; picked automatically for long head-dim-128 sequences) against the oracle, with
+    the exact rescale (variant 1) and the deferred rescale (variant 2), including a late spiky key that forces the rescale branch
+    of the deferred form (guide section 5.4 rule 26) and the log-sum-exp the backward consumes."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(80)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(81)))
+    kv[T - 40, 0] *= 12.0   # raw score far above everything before it: the running maximum jumps past any deferral threshold
+    do = bf(torch.randn(T, hq, d, generator=g(82)))
+    q32, kv32 = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, causal)
+    (ref * do.float()).sum().backward()
+    qd, kvd = q.to(dev), kv.to(dev)
+    try:
+        assert L.ie_tune_flash_fwd_variant(variant) == 0
+        out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), None, causal)
+    finally:
+        L.ie_tune_flash_fwd_variant(-1)
+    close(out, ref, 1.6e-2, 2e-2, f"flash fwd64 variant {variant} lens={lens}")
+    # the saved log-sum-exp must serve the backward: gradients through the variant's (out, lse)
+    dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
+    # (the spiky key makes gradients of magnitude ~10: absolute tolerance relative to the largest reference entry)
+    close(dq, q32.grad, 2e-2, 1e-2 * float(q32.grad.abs().max()), "flash dq from fwd64 lse")
+    close(dk, kv32.grad[:, 0], 2e-2, 1e-2 * float(kv32.grad[:, 0].abs().max()), "flash dk from fwd64 lse")
+    close(dv, kv32.grad[:, 1], 2e-2, 1e-2 * float(kv32.grad[:, 1].abs().max()), "flash dv from fwd64 lse")
+
+
 # ---------------------------------------------------------------------------------------------- a18
 @pytest.mark.parametrize("A,B,S,C", [(96, 1, 2, 256), (40, 2, 4, 128), (7, 2, 8, 64), (128, 1, 1, 512)])
 def test_seq_head_permute_matches_seq_all_to_all_layout(dev, A, B, S, C):

@@ -79,7 +79,8 @@ def test_reference_config_files_map(tmp_path):
     for path, value in ((("use_fp32_norm",), True), (("model", "norm_type"), "layernorm"), (("model", "apply_post_layer_norm"), True),
                         (("model", "embed_grad_scale"), 0.1), (("model", "num_chunks"), 2), (("model", "attn_drop_rate"), 0.1),
                         (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"), (("data", "skip_batches"), "1-3"),
-                        (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False)):
+                        (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False),
+                        (("data", "use_packed_dataset"), False)):
         c = copy.deepcopy(g)
         node = c
         for k in path[:-1]:
@@ -97,7 +98,7 @@ def test_reference_config_files_map(tmp_path):
     assert L.params["layers.0.attention.wqkv.weight"].shape == (3072, 4096) and L.params["tok_embeddings.weight"].shape == (92544, 4096)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, zero=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -107,12 +108,15 @@ def _worker(rank, world, port, q):
         from internevo_amd.zero import ZeroComm
 
         mc = tiny(hidden=64, layers=2, heads=1, kv_heads=1, vocab=40).model
-        L = FlatLayout(mc, world)
-        comm = ZeroComm(L, None, world, rank)
-        gen = torch.Generator().manual_seed(100 + rank)
+        z = zero or world          # shards per bucket: the whole data-parallel group, or parallel.zero1.size (hybrid ZeRO)
+        L = FlatLayout(mc, z)
+        comm = ZeroComm(L, None, world, rank, zero_size=zero)
+        assert (comm.world, comm.rank, comm.replica) == (z, rank % z, rank // z)
+        dp_rank, dp_world, rank, world = rank, world, comm.rank, comm.world   # below: shard index / shard count
+        gen = torch.Generator().manual_seed(100 + dp_rank)
         grads = torch.randn(L.total, generator=gen).to(torch.bfloat16)
-        all_grads = [torch.randn(L.total, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(world)]
-        mean = sum(g.float() for g in all_grads) / world
+        all_grads = [torch.randn(L.total, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(dp_world)]
+        mean = sum(g.float() for g in all_grads) / dp_world   # the average over the WHOLE data-parallel group, one or two hops
         for b in reversed(range(len(L.buckets))):
             comm.reduce_bucket_async(grads, b)
         comm.wait_all()
@@ -137,9 +141,26 @@ def _worker(rank, world, port, q):
             for r in range(world):
                 s, n = b.shard(r, world)
                 ok &= bool((params[s : s + n] == r + 1).all())
-        q.put((rank, ok, float(sq_local)))
+        q.put((dp_rank, ok, float(sq_local)))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_hybrid_zero_exchange_gloo_world4_zero2():
+    """parallel.zero1.size = 2 on four data-parallel ranks: two shards per bucket, reduce-scatter inside the zero group + all-reduce
+    across the replicas = the average over all four ranks; the all-gather stays inside the zero group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 4, 29817
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res), res
+    assert all(abs(r[2] - res[0][2]) < 1e-6 * abs(res[0][2]) for r in res)
 
 
 @pytest.mark.timeout(180)

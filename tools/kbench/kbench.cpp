@@ -254,20 +254,13 @@ static int run_fwd(const Args& a) {
         HIP_OK(hipDeviceSynchronize());
         const Diff dO = diff_bf16(to_host(out, no), ref_o), dL = diff_f32(to_host(lse, nl), ref_l);
         const double us = time_us(call, a.iters);
-        if (v == 48) {  // instrumented build: per-phase cycles of wave 0 of every block, summed over all launches since the last read
-            typedef int (*dbg_t)(unsigned long long*, int);
-            unsigned long long c[5];
-            IE_OKAY(sym<dbg_t>("ie_debug_read_counters")(c, 5));
-            printf("{\"debug\": \"fwd64 cycles per wave-tile\", \"wait_barrier\": %.0f, \"dma_issue\": %.0f, \"phase1\": %.0f, \"phase2\": %.0f, \"tiles\": %llu}\n",
-                   (double)c[0] / c[4], (double)c[1] / c[4], (double)c[2] / c[4], (double)c[3] / c[4], c[4]);
-        }
         printf("{\"bench\": \"flash_fwd\", \"variant\": %d, \"T\": %lld, \"seqs\": %d, \"ragged\": %d, \"hq\": %d, \"hkv\": %d, \"d\": %d, \"causal\": %d, "
                "\"us\": %.1f, \"tflops\": %.1f, \"o_max_abs_diff\": %.3g, \"o_rms_rel\": %.3g, \"o_nonfinite\": %zu, \"lse_max_abs_diff\": %.3g}\n",
                v, (long long)P.T, a.seqs, a.ragged, a.hq, a.hkv, a.d, a.causal, us, P.flops_fwd / us * 1e-6, dO.max_abs,
                sqrt(dO.sum_sq / (dO.ref_sq + 1e-30)), dO.bad, dL.max_abs);
         fflush(stdout);
     }
-    IE_OKAY(tune(0));
+    IE_OKAY(tune(-1));
     return 0;
 }
 

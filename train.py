@@ -6,8 +6,9 @@
 It reads an unmodified InternEvo config file (internevo_amd/config.py), runs the hot loop of the reference's train.py:196-306 on the
 HIP engine -- load batch, forward / backward over the micro-batches, optimizer step, metric, one log line per step with the
 reference's keys (internevo_amd/trainlog.py), checkpoints in the reference's format every `ckpt.checkpoint_every` steps -- and
-resumes from `ckpt.load_ckpt_info` / `ckpt.load_ckpt_folder`.  Out of scope here (control plane): real tokenized
-datasets (`data.train_folder` must be None = the reference's RandomDataset), validation, tensorboard, alerts, remote storage.
+resumes from `ckpt.load_ckpt_info` / `ckpt.load_ckpt_folder` (any data-parallel and tensor-parallel layout).  `data.train_folder` /
+`data.valid_folder` may name tokenized `.bin` folders (internevo_amd/data.py); None = the reference's RandomDataset.  Out of scope
+(control plane): tensorboard, alerts, remote storage backends.
 """
 import argparse
 import os
@@ -143,6 +144,10 @@ def main(argv=None, log=print):
                 continue
             val_loaders[name] = vl
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    if save_folder and eng.sp > 1:
+        # say so at start-up instead of silently writing nothing every checkpoint_every steps
+        raise NotImplementedError("ckpt.enable_save_ckpt with sequence parallelism (parallel.tensor mode 'isp'): checkpoints cover tensor sizes "
+                                  "of mode 'mtp' and any data-parallel size; set enable_save_ckpt=False for an isp run")
     every = int(ck.get("checkpoint_every", 0) or 0)
     ctx = run_state["context"] if run_state else None
     consumed = ctx["num_consumed_tokens"] if ctx else 0
@@ -173,7 +178,7 @@ def main(argv=None, log=print):
             log(line(infos))
         if val_loaders and st.adam_step % valid_every == 0:  # train.py:279-288: keyed on the count of successful steps
             out[-1].update(evaluate_on_val_dls(eng, val_loaders, st.adam_step, dev, log if rank == 0 else (lambda m: None)))
-        if save_folder and every and (step + 1) % every == 0 and eng.tp == 1 and eng.sp == 1:
+        if save_folder and every and (step + 1) % every == 0 and eng.sp == 1:  # (sp > 1 with saving enabled is refused at start-up)
             eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))  # collective: every data-parallel rank writes its ZeRO shard
             if rank == 0:
                 from internevo_amd.checkpoint import save_run_state
