@@ -246,6 +246,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg)
+            # the reference's OWN CPU path (unmodified trainer, torch CPU kernels) was timed once in the build container -- /root/reference
+            # does not exist on the GPU box -- on the 7B shape cut to 2 layers: quoted beside the port's figure
+            with open(os.path.join(ROOT, "profiles", "r02_reference_cpu_path.json")) as f:
+                rj = json.load(f)
+            out["cpu_baseline"]["reference_path_build_container"] = {
+                "kind": "reference", "value": rj["tokens_per_second"], "unit": "tokens/s (7B-shaped model cut to 2 layers, bf16, seq 4096)",
+                "cores": rj["threads"], "sec_per_4096_token_step": rj["sec_per_step_timed"], "source": "profiles/r02_reference_cpu_path.json"}
         except Exception as e:  # the baseline must never take the measurement down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
     if rank == 0:

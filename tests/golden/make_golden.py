@@ -318,7 +318,7 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     cfg = tiny_config(dtype, **cfg_kw)
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("IE_THREADS", "8")))
 
     model = initialize_model()
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
@@ -383,7 +383,20 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     with torch.no_grad():
         rec["param_fingerprint"] = {name: [float(p.float().sum()), float(p.float().abs().sum())] for name, p in inner.named_parameters()}
     rec["world"], rec["rank"] = world, rank
-    with open(os.path.join(HERE, f"train_{tag}.json" if world == 1 else f"train_{tag}_rank{rank}.json"), "w") as f:
+    if tag in RUNS_TIMING:  # a timing record, not a parity fixture: profiles/, with what the numbers mean
+        c = cfg_kw
+        tokens = c["seq_len"] * c["micro_num"]
+        timed = t_steps[1:]  # the first step pays the allocations
+        rec.pop("param_fingerprint")
+        rec.update(what="the UNMODIFIED reference training step (internlm.core.trainer: NonPipelineScheduler + HybridZeroOptimizer, torch CPU kernels "
+                        "through the harness-side accelerator shim of tests/golden/make_golden.py) on a 7B-shaped model cut to "
+                        f"{c['layers']} layers, {dtype}, seq {c['seq_len']}, micro_bsz 1 x micro_num {c['micro_num']}; timed in the build container",
+                   host_cores=os.cpu_count(), tokens_per_step=tokens, sec_per_step_timed=sum(timed) / len(timed),
+                   tokens_per_second=tokens / (sum(timed) / len(timed)))
+        out_path = os.path.join(ROOT, "profiles", "r02_reference_cpu_path.json")
+    else:
+        out_path = os.path.join(HERE, f"train_{tag}.json" if world == 1 else f"train_{tag}_rank{rank}.json")
+    with open(out_path, "w") as f:
         json.dump(rec, f, indent=1)
     return batches
 
@@ -689,6 +702,11 @@ RUNS = {
     # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
     "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
     "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
+}
+# BASELINE.md section 3 / SURVEY.md 8d: the reference's own CPU path on the 7B shape (2 layers), for the number bench.py quotes beside
+# the port's (`python make_golden.py --run cpu7b_2layer`; ~15 GB of host memory, minutes per step; not part of the fixture regeneration)
+RUNS_TIMING = {
+    "cpu7b_2layer": ("torch.bfloat16", dict(use_packed=False, seq_len=4096, hidden=4096, heads=32, kv_heads=8, vocab=92544, layers=2, micro_num=1, total_steps=3)),
 }
 # two-process runs of the reference's ISP mode (configs/7B_isp_sft.py shape: tensor=dict(size=sp, mode="isp"), weight=dict(size=wp))
 RUNS_MP = {
@@ -1006,8 +1024,8 @@ if __name__ == "__main__":
         sys.exit(max(rc))
     if len(sys.argv) >= 3 and sys.argv[1] == "--run":
         tag = sys.argv[2]
-        dtype, kw = RUNS[tag]
-        run_training(tag, dtype, kw, port=29700 + list(RUNS).index(tag))
+        dtype, kw = RUNS[tag] if tag in RUNS else RUNS_TIMING[tag]
+        run_training(tag, dtype, kw, port=29700 + (list(RUNS).index(tag) if tag in RUNS else 90))
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--data-folder":
         gen_data_folder()
