@@ -264,6 +264,41 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
                       const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
                       int d, float softmax_scale, int causal, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K6  GShard mixture-of-experts layer, top-2 gating, in index form (csrc/moe.hip).
+ *     Replaces the routing arithmetic of internlm/model/moe/gshard_layer.py: top2gating (:217-285), the `sec,sm->ecm`
+ *     dispatch (:446-448) and `sec,ecm->sm` combine (:482-486) einsums and their autograd; the expert FeedForward
+ *     modules (modules/mlp.py:82-86) run on ie_gemm_bf16 / ie_swiglu_* over the [E*C, M] buffers.
+ *     S tokens, M hidden, E experts (2..16), C = capacity; x bf16 [S, M]; wg fp32 [E, M] (the gate is an fp32 module);
+ *     expert [2, S] int32 (first / second choice); row [2, S] int32 = e*C + slot or -1 (dropped); weight [2, S] fp32
+ *     (renormalised; consumers round it to bf16 like NaiveAMP does); token_of [E*C] int32 = 2*token + choice or -1.
+ * ---------------------------------------------------------------------------------------------- */
+/* Gumbel(0,1) noise of the second choice (gshard_layer.py:63-70,233): counter-based, reproducible from (seed, offset). */
+int ie_moe_gumbel_noise(float* out, int64_t n, uint32_t seed, uint64_t offset, void* stream);
+/* logits = float(x) wg^T, gates = softmax(logits), expert[0] = argmax(gates), expert[1] = argmax(logits + noise) without the first
+ * (noise [S, E] fp32 or NULL). */
+int ie_moe_gate_fwd(const void* x, int64_t x_ld, const float* wg, const float* noise, int64_t S, int M, int E,
+                    float* logits, float* gates, int32_t* expert, void* stream);
+/* slots in token order, capacity drop, renormalised weights, l_aux (1 float, rounded to bf16), exp_counts [E]. */
+int ie_moe_route(const float* gates, const int32_t* expert, int64_t S, int E, int capacity, int32_t* row, float* weight,
+                 int32_t* token_of, float* l_aux, int32_t* exp_counts, void* stream);
+int ie_moe_dispatch(const void* x, int64_t x_ld, const int32_t* token_of, int64_t rows, int M, void* expert_in, void* stream);
+int ie_moe_combine_fwd(const void* expert_out, const int32_t* row, const float* weight, int64_t S, int M, void* out,
+                       int64_t out_ld, void* stream);
+/* d_expert_out [rows, M] and d_weight [2, S] (bf16-rounded values, zero where nothing was dispatched). */
+int ie_moe_combine_bwd(const void* dout, int64_t d_ld, const void* expert_out, const int32_t* token_of, const float* weight,
+                       int64_t rows, int64_t S, int M, void* d_expert_out, float* d_weight, void* stream);
+/* dx [S, M] = sum of the token's dispatched d_expert_in rows (overwrites dx). */
+int ie_moe_dispatch_bwd(const void* d_expert_in, const int32_t* row, const int32_t* token_of, int64_t S, int M, void* dx,
+                        int64_t dx_ld, void* stream);
+/* gate backward: d_weight (+ d l_aux = aux_factor * *loss_scale_dev, loss_scale_dev may be NULL = 1) -> d_logits [S, E];
+ * dx += bf16(d_logits wg); d_wg (= or +=) d_logits^T float(x).  workspace: ie_moe_dwg_workspace(M, E) floats. */
+int64_t ie_moe_dwg_workspace(int M, int E);
+int ie_moe_gate_bwd(const void* x, int64_t x_ld, const float* wg, const float* gates, const int32_t* expert, const int32_t* row,
+                    const float* d_weight, const int32_t* exp_counts, const float* loss_scale_dev, float aux_factor, int64_t S,
+                    int M, int E, float* d_logits, void* dx, int64_t dx_ld, float* d_wg, int accumulate_d_wg, float* workspace,
+                    void* stream);
+
 /* Tuning hook: tile rows per group of the LDS-DMA GEMMs' XCD-aware tile order (0 = default 4). */
 int ie_tune_gemm_group(int tile_rows_per_group);
 /* Tuning hook: the automatic GEMM's tail split (0 = off [default: neutral inside the training step], 1 = on: remainder tiles by

@@ -96,6 +96,15 @@ SIGNATURES = {
     "ie_tune_gemm_group": (I, [I]),
     "ie_tune_gemm_tail_split": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
+    "ie_moe_gumbel_noise": (I, [P, I64, ctypes.c_uint32, ctypes.c_uint64, P]),
+    "ie_moe_gate_fwd": (I, [P, I64, P, P, I64, I, I, P, P, P, P]),
+    "ie_moe_route": (I, [P, P, I64, I, I, P, P, P, P, P, P]),
+    "ie_moe_dispatch": (I, [P, I64, P, I64, I, P, P]),
+    "ie_moe_combine_fwd": (I, [P, P, P, I64, I, P, I64, P]),
+    "ie_moe_combine_bwd": (I, [P, I64, P, P, P, I64, I64, I, P, P, P]),
+    "ie_moe_dispatch_bwd": (I, [P, P, P, I64, I, P, I64, P]),
+    "ie_moe_dwg_workspace": (I64, [I, I]),
+    "ie_moe_gate_bwd": (I, [P, I64, P, P, P, P, P, P, P, F, I64, I, I, P, P, I64, P, I, P, P]),
     "ie_tune_flash_fwd_variant": (I, [I]),
     "ie_tune_flash_bwd_variant": (I, [I]),
     "ie_flash_attn_bwd_workspace": (I64, [I64, I, I, I]),

@@ -107,3 +107,66 @@ def gumbel_noise(shape, seed):
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(shape, generator=g).clamp_(min=torch.finfo(torch.float32).tiny, max=1.0 - math.ulp(1.0) / 2)
     return -torch.log(-torch.log(u))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The whole GShard MoE layer, forward AND backward (through torch autograd over the index form), with the reference's dtypes:
+#   gate      TopKGate.wg is an fp32 module behind NaiveAMP's hooks (naive_amp.py:160-206): its input is cast to fp32, its outputs
+#             (combine weights, l_aux) are cast back to the model dtype -- the combine weights reach the einsums rounded to bf16, and
+#             their gradient comes back as a bf16 tensor;
+#   dispatch  `sec,sm->ecm` with the boolean mask (taken from the fp32 weights) in bf16: a copy of the token row (or zeros);
+#   experts   FeedForward (modules/mlp.py:82-86): w2(silu(w1 x) * w3 x), bf16 linears;
+#   combine   `sec,ecm->sm` in bf16 (fp32 accumulation of the two surviving terms, one rounding).
+# Pinned by tests/golden/moe_layer.npz = the REAL GShardMOELayer run forward and backward on CPU (make_golden.py --moe-layer).
+class _RoundGradBf16(torch.autograd.Function):
+    """identity whose gradient is rounded to bf16 (a bf16 tensor's gradient is a bf16 tensor)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
+    """x bf16 [S, M] (requires_grad for the backward), wg fp32 [E, M], w1 / w3 bf16 [E, F, M], w2 bf16 [E, M, F], noise fp32 [S, E].
+    -> (out bf16 [S, M], l_aux bf16 scalar, routing dict).  Differentiable w.r.t. x, wg, w1, w3, w2."""
+    S, M = x.shape
+    E = wg.shape[0]
+    logits = x.float() @ wg.float().t()
+    with torch.no_grad():
+        r = top2gating(logits.detach(), capacity_factor, min_capacity, noise)
+    gates = torch.softmax(logits, dim=1)
+    ar = torch.arange(S)
+    keep = r["slot"] >= 0
+    g1 = torch.where(keep[0], gates[ar, r["expert"][0]], torch.zeros(S))
+    g2 = torch.where(keep[1], gates[ar, r["expert"][1]], torch.zeros(S))
+    denom = torch.clamp(g1 + g2, min=torch.finfo(torch.float32).eps)
+    w = torch.stack([g1 / denom, g2 / denom])                       # fp32 [2, S]
+    me = gates.mean(dim=0)
+    ce = torch.nn.functional.one_hot(r["expert"][0], E).float().mean(dim=0)
+    l_aux = (torch.mean(me * ce) * E * E).to(torch.bfloat16)
+    wb = _RoundGradBf16.apply(w).to(torch.bfloat16)                 # what the einsums see
+    C = r["capacity"]
+    # dispatch: row e*C + c <- token (mask from the fp32 weights)
+    sent = keep & (w.detach() != 0)
+    row = r["expert"] * C + torch.clamp(r["slot"], min=0)           # [2, S]
+    buf = torch.zeros(E * C, M, dtype=torch.float32)
+    for k in range(2):
+        idx = torch.nonzero(sent[k]).squeeze(1)
+        buf = buf.index_add(0, row[k][idx], x[idx].float())          # unique rows: a copy (index_add keeps it differentiable)
+    ein = buf.to(torch.bfloat16).reshape(E, C, M)
+    outs = []
+    for e in range(E):
+        h1 = torch.nn.functional.linear(ein[e], w1[e])
+        h3 = torch.nn.functional.linear(ein[e], w3[e])
+        outs.append(torch.nn.functional.linear(torch.nn.functional.silu(h1) * h3, w2[e]))
+    eo = torch.stack(outs).reshape(E * C, M)
+    acc = torch.zeros(S, M, dtype=torch.float32)
+    for k in range(2):
+        rows = _RoundGradBf16.apply(eo[row[k]].float())
+        acc = acc + torch.where(keep[k], wb[k].float(), torch.zeros(S))[:, None] * rows * keep[k][:, None]
+    r["row"], r["sent"] = row, sent
+    return acc.to(torch.bfloat16), l_aux, r

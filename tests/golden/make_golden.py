@@ -851,6 +851,70 @@ def gen_moe():
         json.dump(meta, f, indent=1)
 
 
+def gen_moe_layer(port=29789):
+    """The REAL GShardMOELayer (gshard_layer.py:360-498: TopKGate in fp32 behind NaiveAMP's fp32-module hooks, naive_amp.py:160-206, whose
+    outputs -- combine weights, l_aux -- come back rounded to bf16; experts = FeedForward SwiGLU modules, moe/experts.py) run forward
+    and backward on CPU in bf16 with the Gumbel noise injected -> moe_layer.npz: inputs, weights, output, l_aux and every gradient.
+    Pins oracle.moe.MoELayerOracle and, through it, the HIP MoE path (forward, backward, auxiliary loss)."""
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    import internlm.model.moe.gshard_layer as gl
+    from internlm.core.context import ParallelMode
+    from internlm.core.context import global_context as gpc
+    from internlm.core.naive_amp import NaiveAMPModel, set_fp32_attr_to_module
+    from internlm.initialize.launch import args_sanity_check, launch
+
+    from oracle.moe import gumbel_noise
+
+    cfg = tiny_config("torch.bfloat16", use_packed=False, seq_len=64, hidden=64, heads=2, kv_heads=2, vocab=160, layers=1, micro_num=1, total_steps=2)
+    cfg["model_type"] = "INTERNLM_MoE"
+    cfg["model"].update(num_experts=4, moe_use_residual=False, moe_type="GShard")
+    cfg["model"].pop("num_kv_attention_heads", None)
+    cfg["moe"] = dict(top_k=2, capacity_factor=1.0, eval_capacity_factor=1.0, min_capacity=4, noisy_gate_policy=None, drop_tokens=True, use_rts=True)
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    arrays, meta = {}, []
+    g = torch.Generator().manual_seed(23)
+    bits = lambda t: t.detach().to(torch.bfloat16).view(torch.int16).numpy()  # noqa: E731  (bf16 tensors stored as their bit patterns)
+    for k, (name, S, E, cf, mincap, hot) in enumerate([("balanced", 64, 4, 1.0, 4, 0.0), ("drops", 96, 8, 0.5, 2, 0.0), ("hot", 80, 4, 1.0, 4, 3.0)]):
+        M = 64
+        moe_kw = dict(cfg["moe"], capacity_factor=cf, min_capacity=mincap)
+        layer = gl.GShardMOELayer(hidden_size=M, num_experts=E, ep_group=gpc.get_group(ParallelMode.EXPERT), ep_size=1, device=torch.device("cpu"),
+                                  dtype=torch.bfloat16, **moe_kw)
+        set_fp32_attr_to_module(layer.gate)
+        with torch.no_grad():
+            for n, prm in layer.named_parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 if "wg" in n else 0.15))
+            if hot:
+                layer.gate.wg.weight[1] += hot * torch.randn(M, generator=g).sign() / 8   # most tokens want expert 1: its queue overflows
+        amp = NaiveAMPModel(layer, output_to_fp32=False, dtype=torch.bfloat16)
+        amp.train()
+        x = (torch.randn(1, S, M, generator=g)).to(torch.bfloat16).requires_grad_(True)
+        dy = torch.randn(1, S, M, generator=g).to(torch.bfloat16)
+        noise = gumbel_noise((S, E), 300 + k)
+        gl.gumbel_rsample = lambda shape, device, _n=noise: _n
+        out = amp(x, None)
+        l_aux = layer.l_aux
+        coeff = 0.01
+        loss = (out.float() * dy.float()).sum() + coeff * l_aux.float()
+        loss.backward()
+        F_ = layer.experts.wrapped_experts[0].w1.weight.shape[0]
+        arrays[f"{name}.x"], arrays[f"{name}.dy"], arrays[f"{name}.noise"] = bits(x), bits(dy), noise.numpy()
+        arrays[f"{name}.out"], arrays[f"{name}.dx"] = bits(out), bits(x.grad)
+        arrays[f"{name}.wg"], arrays[f"{name}.d_wg"] = layer.gate.wg.weight.detach().numpy(), layer.gate.wg.weight.grad.numpy()
+        for e, ex in enumerate(layer.experts.wrapped_experts):
+            for wn in ("w1", "w2", "w3"):
+                w = getattr(ex, wn).weight
+                arrays[f"{name}.e{e}.{wn}"], arrays[f"{name}.e{e}.d_{wn}"] = bits(w), bits(w.grad)
+        meta.append(dict(name=name, S=S, E=E, M=M, F=int(F_), capacity_factor=cf, min_capacity=mincap, l_aux=float(l_aux), l_aux_dtype=str(l_aux.dtype),
+                         aux_coeff=coeff, exp_counts=[int(c) for c in layer.exp_counts.tolist()], gate_dtype=str(layer.gate.wg.weight.dtype),
+                         out_dtype=str(out.dtype)))
+        print("moe_layer", meta[-1], flush=True)
+    np.savez_compressed(os.path.join(OUT, "moe_layer.npz"), **arrays)
+    with open(os.path.join(OUT, "moe_layer.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_sched_state():
     """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
     wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
@@ -1054,6 +1118,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--moe":
         gen_moe()
         sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--moe-layer":
+        gen_moe_layer()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--eval":
         gen_eval()
         sys.exit(0)
@@ -1067,7 +1134,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--ckpt", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])
