@@ -33,6 +33,11 @@ class ModelConfig:
     # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
     init_std: float = 0.02
     use_scaled_init: bool = True
+    # model_type "INTERNLM_MoE" (modeling_moe.py, configs/7B_MoE4_sft.py): InternLM-1 block (MHA with biases, no GQA) + GShard top-2 MoE
+    num_experts: int = 1
+    moe_capacity_factor: float = 1.0     # moe = dict(capacity_factor, min_capacity, ...)
+    moe_min_capacity: int = 4
+    moe_loss_coeff: float = 1.0          # loss.moe_loss_coeff (launch.py:433-434 default)
 
     @property
     def head_dim(self):
@@ -144,15 +149,35 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
             raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'isp')")
         # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
     model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
-    if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2"):
+    if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE"):
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")
-    if m.get("num_experts", 1) > 1:
-        raise NotImplementedError(f"{_UNSUPPORTED}: MoE")
+    moe_kw = {}
+    if model_type == "INTERNLM_MoE":
+        # configs/7B_MoE4_sft.py: GShard top-2 MoE in every block (internevo_amd/moe_engine.py)
+        moe = cfg.get("moe", {}) or {}
+        if m.get("num_experts", 1) <= 1:
+            raise NotImplementedError(f"{_UNSUPPORTED}: model_type INTERNLM_MoE with num_experts <= 1 (the dense InternLM-1 model)")
+        if m.get("moe_type", "GShard") != "GShard":
+            raise NotImplementedError(f"{_UNSUPPORTED}: model.moe_type {m.get('moe_type')!r} (GShard only)")
+        if m.get("moe_use_residual", False):
+            raise NotImplementedError(f"{_UNSUPPORTED}: model.moe_use_residual")
+        if moe.get("top_k", 1) != 2:
+            raise NotImplementedError(f"{_UNSUPPORTED}: moe.top_k = {moe.get('top_k', 1)} (top-2 gating only)")
+        if not moe.get("drop_tokens", True) or moe.get("noisy_gate_policy", None) not in (None, "None"):
+            raise NotImplementedError(f"{_UNSUPPORTED}: moe.drop_tokens=False / moe.noisy_gate_policy")
+        if sp_size > 1 or tp_size > 1:
+            raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with tensor / sequence parallelism (data and expert parallelism only)")
+        if not m.get("use_swiglu", True) or m.get("residual_in_fp32", False):
+            raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with use_swiglu=False / residual_in_fp32")
+        moe_kw = dict(num_experts=int(m["num_experts"]), moe_capacity_factor=float(moe.get("capacity_factor", 1.0)),
+                      moe_min_capacity=int(moe.get("min_capacity", 4)), moe_loss_coeff=float(cfg.get("loss", {}).get("moe_loss_coeff", 1.0)))
+    elif m.get("num_experts", 1) > 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: num_experts > 1 outside model_type INTERNLM_MoE")
     ck = m.get("checkpoint", False)
     ck = 1.0 if ck is True else 0.0 if ck is False else float(ck)
     if not 0.0 <= ck <= 1.0:
         raise ValueError(f'model.checkpoint: "{ck}" should >=0 and <=1')  # launch.py:300-303
-    if not m.get("no_bias", True):
+    if not m.get("no_bias", True) and model_type != "INTERNLM_MoE":   # (the InternLM-1 block of INTERNLM_MoE always has attention biases)
         raise NotImplementedError(f"{_UNSUPPORTED}: linear bias")
     # settings that change the arithmetic of the step: refuse them instead of training something else than the config describes
     if cfg.get("use_fp32_norm", False):
@@ -184,7 +209,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
         # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
-        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
+        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type, **moe_kw,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]

@@ -34,6 +34,17 @@ def formula_init(name, shape):
     return torch.from_numpy(w.astype(np.float32)).to(torch.bfloat16).float()
 
 
+def moe_formula_init(name, shape):
+    """formula_init for the INTERNLM_MoE family (modeling_moe.py): linear biases and the fp32 gate weight are small normal numbers
+    instead of the 1 + N(0, 0.05) that formula_init gives every 1-D tensor (a norm gain)."""
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    if name.endswith(".bias"):
+        return torch.from_numpy((0.02 * rs.standard_normal(shape)).astype(np.float32)).to(torch.bfloat16).float()
+    if name.endswith("gate.wg.weight"):
+        return torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32)).to(torch.bfloat16).float()
+    return formula_init(name, shape)
+
+
 def param_shapes(mc):
     """name -> shape, in the reference's naming (PackedFlashLlama1D.named_parameters())."""
     h, f, v = mc.hidden_size, mc.ffn_dim, mc.vocab_size

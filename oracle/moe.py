@@ -118,23 +118,25 @@ def gumbel_noise(shape, seed):
 #   experts   FeedForward (modules/mlp.py:82-86): w2(silu(w1 x) * w3 x), bf16 linears;
 #   combine   `sec,ecm->sm` in bf16 (fp32 accumulation of the two surviving terms, one rounding).
 # Pinned by tests/golden/moe_layer.npz = the REAL GShardMOELayer run forward and backward on CPU (make_golden.py --moe-layer).
-class _RoundGradBf16(torch.autograd.Function):
-    """identity whose gradient is rounded to bf16 (a bf16 tensor's gradient is a bf16 tensor)"""
+class _RoundGrad(torch.autograd.Function):
+    """identity whose gradient is rounded to the model dtype (a bf16 tensor's gradient is a bf16 tensor)"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dt):
+        ctx.dt = dt
         return x
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(ctx.dt).to(g.dtype), None
 
 
 def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
-    """x bf16 [S, M] (requires_grad for the backward), wg fp32 [E, M], w1 / w3 bf16 [E, F, M], w2 bf16 [E, M, F], noise fp32 [S, E].
-    -> (out bf16 [S, M], l_aux bf16 scalar, routing dict).  Differentiable w.r.t. x, wg, w1, w3, w2."""
+    """x [S, M] in the model dtype (bf16; fp32 for the fp32 runs), wg fp32 [E, M], w1 / w3 [E, F, M], w2 [E, M, F] in the model dtype,
+    noise fp32 [S, E].  -> (out [S, M], l_aux scalar, both in the model dtype; routing dict).  Differentiable w.r.t. x, wg, w1, w3, w2."""
     S, M = x.shape
     E = wg.shape[0]
+    dt = x.dtype
     logits = x.float() @ wg.float().t()
     with torch.no_grad():
         r = top2gating(logits.detach(), capacity_factor, min_capacity, noise)
@@ -147,8 +149,8 @@ def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
     w = torch.stack([g1 / denom, g2 / denom])                       # fp32 [2, S]
     me = gates.mean(dim=0)
     ce = torch.nn.functional.one_hot(r["expert"][0], E).float().mean(dim=0)
-    l_aux = (torch.mean(me * ce) * E * E).to(torch.bfloat16)
-    wb = _RoundGradBf16.apply(w).to(torch.bfloat16)                 # what the einsums see
+    l_aux = (torch.mean(me * ce) * E * E).to(dt)
+    wb = _RoundGrad.apply(w, dt).to(dt)                             # what the einsums see
     C = r["capacity"]
     # dispatch: row e*C + c <- token (mask from the fp32 weights)
     sent = keep & (w.detach() != 0)
@@ -157,7 +159,7 @@ def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
     for k in range(2):
         idx = torch.nonzero(sent[k]).squeeze(1)
         buf = buf.index_add(0, row[k][idx], x[idx].float())          # unique rows: a copy (index_add keeps it differentiable)
-    ein = buf.to(torch.bfloat16).reshape(E, C, M)
+    ein = buf.to(dt).reshape(E, C, M)
     outs = []
     for e in range(E):
         h1 = torch.nn.functional.linear(ein[e], w1[e])
@@ -166,7 +168,7 @@ def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
     eo = torch.stack(outs).reshape(E * C, M)
     acc = torch.zeros(S, M, dtype=torch.float32)
     for k in range(2):
-        rows = _RoundGradBf16.apply(eo[row[k]].float())
+        rows = _RoundGrad.apply(eo[row[k]].float(), dt)
         acc = acc + torch.where(keep[k], wb[k].float(), torch.zeros(S))[:, None] * rows * keep[k][:, None]
     r["row"], r["sent"] = row, sent
-    return acc.to(torch.bfloat16), l_aux, r
+    return acc.to(dt), l_aux, r

@@ -184,7 +184,21 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 #                     shrinks ONLY that count (host time/RAM), everything else is the unmodified pipeline.
 
 
-def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1):
+def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1,
+                num_experts=1, capacity_factor=1.0):
+    cfg = _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp, wp, model_type, tp)
+    if model_type == "INTERNLM_MoE":   # configs/7B_MoE4_sft.py: the InternLM-1 block (MHA with biases) + a GShard MoE in place of every MLP
+        m = cfg["model"]
+        for k in ("num_kv_attention_heads", "no_bias"):
+            m.pop(k, None)
+        m.update(num_experts=num_experts, moe_use_residual=False, moe_type="GShard", mlp_ratio=4 / 3)
+        cfg["moe"] = dict(top_k=2, capacity_factor=capacity_factor, eval_capacity_factor=1.0, min_capacity=4, noisy_gate_policy=None, drop_tokens=True,
+                          use_rts=True)
+        cfg["loss"] = dict(label_smoothing=0, moe_loss_coeff=0.1)
+    return cfg
+
+
+def _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1):
     return dict(
         JOB_NAME="golden",
         model_type=model_type,
@@ -312,6 +326,18 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     from internlm.core.trainer import TrainState
 
     from oracle.model import formula_init  # closed-form weights shared with the oracle / HIP engine
+    if cfg_kw.get("model_type") == "INTERNLM_MoE":
+        import internlm.model.moe.gshard_layer as gl
+        from oracle.model import moe_formula_init as formula_init  # noqa: F811
+        from oracle.moe import gumbel_noise
+
+        calls = [0]
+
+        def _noise(shape, device):  # the k-th gating call of the run (layer-major inside a micro-batch) gets gumbel_noise(seed = 5000 + k)
+            calls[0] += 1
+            return gumbel_noise(tuple(shape), 5000 + calls[0] - 1)
+
+        gl.gumbel_rsample = _noise
 
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
 
@@ -369,11 +395,13 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
         trainer.zero_grad()
         if batch[0].get("type_ids", None) is not None:
             metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
-        _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        res = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        loss, moe_loss = res[2], (res[3] if len(res) > 3 else None)   # MoE models: (outputs, labels, loss, moe_loss), no_pipeline_scheduler.py:237
         lr_used = optimizer.optim.param_groups[0]["lr"]
         ok, norms = trainer.step()
         t_steps.append(time.time() - t0)
-        rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+        rec["steps"].append({"loss": float(loss.item()), **({"moe_loss": float(moe_loss)} if moe_loss is not None else {}),
+                             "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
                              "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used,
                              "metric": metric.get_metric(reset=True)})  # train.py:264-275 reads the metric every step
         print(tag, step, rec["steps"][-1], flush=True)
@@ -699,6 +727,11 @@ RUNS = {
     "pin_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6)),
     "cfg0_fp32": ("torch.float32", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
     "cfg0_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=256, hidden=512, heads=8, kv_heads=2, vocab=1024, layers=2, micro_num=2, total_steps=5)),
+    # BASELINE.json configs[4]'s model family (configs/7B_MoE4_sft.py: model_type INTERNLM_MoE, GShard top-2 MoE in every block)
+    "moe_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                       model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0)),
+    "moe_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                        model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0)),
     # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
     "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
     "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
