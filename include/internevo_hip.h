@@ -264,6 +264,18 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
                       const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
                       int d, float softmax_scale, int causal, void* stream);
 
+/* y[rows, cols] += bias[cols] in place (bf16): the attention biases of the InternLM-1 block (multi_head_attention.py:371-408). */
+int ie_bias_add_bf16(void* y, int64_t ld, const void* bias, int64_t rows, int64_t cols, void* stream);
+/* HybridZeroOptimizer._step with several parameter groups (MoE models: default / fp32 / moe, train/utils.py:25-80): one overflow check and one
+ * scaler update over all groups, but every group unscaled and clipped by its OWN norm (hybrid_zero_optim.py:760-779,863-876).
+ * sumsq_dev [ngroups]; group_inv_scale_dev / group_norm_dev [ngroups] are outputs (norms already divided by the loss scale). */
+int ie_step_control_groups(IeStepState* state_dev, const float* sumsq_dev, int ngroups, const IeScalerConfig* cfg_host,
+                           float* group_inv_scale_dev, float* group_norm_dev, void* stream);
+/* ie_adamw_step with the gradient factor of a parameter group (one float on the device) instead of the state's. */
+int ie_adamw_step_group(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n,
+                        const IeStepState* state_dev, const float* inv_scale_group_dev, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K6  GShard mixture-of-experts layer, top-2 gating, in index form (csrc/moe.hip).
  *     Replaces the routing arithmetic of internlm/model/moe/gshard_layer.py: top2gating (:217-285), the `sec,sm->ecm`

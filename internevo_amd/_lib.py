@@ -96,6 +96,9 @@ SIGNATURES = {
     "ie_tune_gemm_group": (I, [I]),
     "ie_tune_gemm_tail_split": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
+    "ie_bias_add_bf16": (I, [P, I64, P, I64, I64, P]),
+    "ie_step_control_groups": (I, [P, P, I, POINTER(IeScalerConfig), P, P, P]),
+    "ie_adamw_step_group": (I, [P, I, P, P, P, P, I64, P, P, Dbl, Dbl, Dbl, Dbl, Dbl, P]),
     "ie_moe_gumbel_noise": (I, [P, I64, ctypes.c_uint32, ctypes.c_uint64, P]),
     "ie_moe_gate_fwd": (I, [P, I64, P, P, I64, I, I, P, P, P, P]),
     "ie_moe_route": (I, [P, P, I64, I, I, P, P, P, P, P, P]),

@@ -476,3 +476,31 @@ extern "C" int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dwei
                        (bf16_t*)dweight, ws, T, vocab, dim, accumulate);
     return ie_launch_status("ie_embedding_bwd launch");
 }
+
+// ---- y[r, :] += bias  (bf16, in place): the bias of the InternLM-1 attention linears (multi_head_attention.py:371-408, model_type INTERNLM_MoE).
+// HBM-bound: 4 bytes per element.
+namespace {
+__global__ __launch_bounds__(256) void bias_add_k(bf16_t* __restrict__ y, int64_t ld, const bf16_t* __restrict__ bias, int64_t rows, int cols) {
+    const int c8 = cols / 8;
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= rows * c8) return;
+    const int64_t r = i / c8;
+    const int c = (int)(i % c8) * 8;
+    float a[8], b[8];
+    unpack8(ld16(y + r * ld + c), a);
+    unpack8(ld16(bias + c), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    st16(y + r * ld + c, pack8(a));
+}
+}  // namespace
+
+extern "C" int ie_bias_add_bf16(void* y, int64_t ld, const void* bias, int64_t rows, int64_t cols, void* stream) {
+    IE_CHECK_ARG(y && bias && rows >= 0 && cols >= 0 && ld >= cols, "ie_bias_add_bf16: bad argument");
+    IE_CHECK_SUPPORTED(cols % 8 == 0 && ld % 8 == 0 && (((uintptr_t)y) & 15u) == 0 && (((uintptr_t)bias) & 15u) == 0,
+                       "ie_bias_add_bf16: columns / leading dimension multiples of 8, 16-byte aligned pointers");
+    if (rows == 0 || cols == 0) return IE_OK;
+    const int64_t n = rows * (cols / 8);
+    hipLaunchKernelGGL(bias_add_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)y, ld, (const bf16_t*)bias, rows, (int)cols);
+    return ie_launch_status("ie_bias_add_bf16 launch");
+}

@@ -323,6 +323,65 @@ __global__ void step_control_k(IeStepState* s, const float* __restrict__ sumsq, 
     s->grad_norm = (float)(norm / (double)scale_backup);
 }
 
+// Several optimizer parameter groups (the MoE models: default / fp32 gates / experts, train/utils.py:25-80): the overflow check and the
+// scaler see all of them, but every group is unscaled and clipped by its OWN norm (hybrid_zero_optim.py:760-779,863-876).
+__global__ void step_control_groups_k(IeStepState* s, const float* __restrict__ sumsq, int ng, IeScalerConfig cfg, float* __restrict__ inv_out,
+                                      float* __restrict__ norm_out) {
+    bool found_inf = false, found_nan = false;
+    double total = 0.0;
+    for (int g = 0; g < ng; ++g) {
+        found_inf |= isinf(sumsq[g]);
+        found_nan |= isnan(sumsq[g]);
+        total += (double)sumsq[g];
+    }
+    const float scale_backup = s->loss_scale;
+    s->loss_scale_used = scale_backup;
+    if (cfg.dynamic) {
+        if (found_inf) {
+            s->hysteresis_step += 1;
+            s->growth_step = 0;
+            if (s->hysteresis_step >= cfg.hysteresis) {
+                float ns = s->loss_scale * cfg.backoff_factor;
+                if (cfg.min_scale > 0.f) ns = fmaxf(ns, cfg.min_scale);
+                s->loss_scale = ns;
+            }
+        } else {
+            s->growth_step += 1;
+            if (s->growth_step == cfg.growth_interval) {
+                s->growth_step = 0;
+                s->hysteresis_step = 0;
+                float ns = s->loss_scale * cfg.growth_factor;
+                if (cfg.max_scale > 0.f) ns = fminf(ns, cfg.max_scale);
+                s->loss_scale = ns;
+            }
+        }
+    }
+    s->found_inf = found_inf ? 1 : 0;
+    s->found_nan = found_nan ? 1 : 0;
+    if (found_inf || found_nan) {
+        s->skip = 1;
+        s->skipped_total += 1;
+        s->inv_scale = 0.f;
+        s->grad_norm = found_inf ? -1.f : -2.f;
+        for (int g = 0; g < ng; ++g) { inv_out[g] = 0.f; norm_out[g] = s->grad_norm; }
+        return;
+    }
+    s->skip = 0;
+    s->adam_step += 1;
+    for (int g = 0; g < ng; ++g) {
+        const double norm = sqrt((double)sumsq[g]);
+        double combined = (double)scale_backup;
+        if (cfg.dynamic && cfg.clip_grad_norm > 0.f) {
+            const double clip = (norm / (double)scale_backup + 1e-6) / (double)cfg.clip_grad_norm;
+            if (clip > 1.0) combined = clip * (double)scale_backup;
+        }
+        inv_out[g] = cfg.dynamic ? (float)(1.0 / combined) : 1.f;
+        norm_out[g] = (float)(norm / (double)scale_backup);
+    }
+    s->inv_scale = inv_out[0];
+    s->grad_norm = (float)(sqrt(total) / (double)scale_backup);
+}
+
 // ------------------------------------------------------------------------------------------ AdamW
 struct AdamConsts {
     float decay;      // 1 - lr*wd
@@ -348,7 +407,7 @@ template <bool GBF>
 __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float* __restrict__ p32, float* __restrict__ m,
                                                float* __restrict__ v, bf16_t* __restrict__ p16, int64_t n,
                                                const IeStepState* __restrict__ state, double lr, double beta1, double beta2,
-                                               float eps, double wd, int vec_ok) {
+                                               float eps, double wd, int vec_ok, const float* __restrict__ inv_scale_group) {
     __shared__ AdamConsts sc;
     __shared__ int skip;
     if (threadIdx.x == 0) {
@@ -363,7 +422,7 @@ __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float
         sc.step_size = (float)(lr / bc1);
         sc.bc2_sqrt = (float)sqrt(bc2);
         sc.eps = eps;
-        sc.inv_scale = state->inv_scale;
+        sc.inv_scale = inv_scale_group ? inv_scale_group[0] : state->inv_scale;   // a parameter group clipped by its own norm
     }
     __syncthreads();
     if (skip) return;
@@ -526,9 +585,35 @@ extern "C" int ie_step_control(IeStepState* state_dev, const float* sumsq_dev, c
     return ie_launch_status("ie_step_control launch");
 }
 
+extern "C" int ie_step_control_groups(IeStepState* state_dev, const float* sumsq_dev, int ngroups, const IeScalerConfig* cfg_host,
+                                      float* group_inv_scale_dev, float* group_norm_dev, void* stream) {
+    IE_CHECK_ARG(state_dev && sumsq_dev && cfg_host && group_inv_scale_dev && group_norm_dev && ngroups >= 1 && ngroups <= 16,
+                 "ie_step_control_groups: bad argument");
+    IE_CHECK_ARG(cfg_host->growth_factor > 1.f && cfg_host->backoff_factor > 0.f && cfg_host->backoff_factor < 1.f && cfg_host->hysteresis >= 0,
+                 "ie_step_control_groups: bad scaler config");
+    hipLaunchKernelGGL(step_control_groups_k, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, sumsq_dev, ngroups, *cfg_host, group_inv_scale_dev,
+                       group_norm_dev);
+    return ie_launch_status("ie_step_control_groups launch");
+}
+
+static int adamw_launch(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n, const IeStepState* state_dev,
+                        const float* inv_scale_group, double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
+extern "C" int ie_adamw_step_group(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n, const IeStepState* state_dev,
+                                   const float* inv_scale_group_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                   void* stream) {
+    IE_CHECK_ARG(inv_scale_group_dev, "ie_adamw_step_group: null group scale");
+    return adamw_launch(g, g_dtype, p32, m, v, p16, n, state_dev, inv_scale_group_dev, lr, beta1, beta2, eps, weight_decay, stream);
+}
+
 extern "C" int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n,
                              const IeStepState* state_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
                              void* stream) {
+    return adamw_launch(g, g_dtype, p32, m, v, p16, n, state_dev, nullptr, lr, beta1, beta2, eps, weight_decay, stream);
+}
+
+static int adamw_launch(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n, const IeStepState* state_dev,
+                        const float* inv_scale_group, double lr, double beta1, double beta2, double eps, double weight_decay, void* stream) {
     IE_CHECK_ARG(g && p32 && m && v && state_dev && n >= 0, "ie_adamw_step: bad argument");
     IE_CHECK_ARG(g_dtype == IE_BF16 || g_dtype == IE_F32, "ie_adamw_step: bad dtype");
     if (n == 0) return IE_OK;
@@ -539,9 +624,9 @@ extern "C" int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, f
     if (blocks < 1) blocks = 1;
     if (g_dtype == IE_BF16)
         hipLaunchKernelGGL((adamw_k<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n,
-                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok);
+                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok, inv_scale_group);
     else
         hipLaunchKernelGGL((adamw_k<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n,
-                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok);
+                           state_dev, lr, beta1, beta2, (float)eps, weight_decay, vec_ok, inv_scale_group);
     return ie_launch_status("ie_adamw_step launch");
 }

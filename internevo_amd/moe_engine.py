@@ -1,0 +1,364 @@
+"""Training-step engine of the INTERNLM_MoE model family (BASELINE configs[4], configs/7B_MoE4_sft.py) on the HIP kernels.
+
+Host-side mirror of
+  PackedFlashInternLm1D / PackedFlashBaseLayer1D     internlm/model/modeling_moe.py:33-444 (norm1 -> MHA -> residual -> norm2 -> MoE -> residual)
+  MHA (InternLM-1: packed Wqkv "(three h d)" + bias, NeoX rotary, out_proj + bias)     modules/multi_head_attention.py:298-478
+  MoE / GShardMOELayer                                internevo_amd/moe.py (csrc/moe.hip)
+  the moe loss                                        core/scheduler/no_pipeline_scheduler.py:120-145
+  the optimizer's parameter groups default / fp32 / moe, one norm and one clipping factor each
+                                                      train/utils.py:25-80, solver/optimizer/hybrid_zero_optim.py:760-779,863-876
+Same construction as engine.InternLM2Engine (explicit backward over pre-allocated buffers, flat bf16 parameters / gradients, device-
+resident loss scale and step control, no host synchronisation inside a step); the scope of this engine is the single-rank and the
+data-parallel step (gradients averaged by all-reduce over the data-parallel group, optimizer state replicated -- `parallel.zero1.size = 1`
+semantics; the experts are local, expert parallel size 1).  Tensor / sequence parallelism, checkpoints and merged micro-batches are the
+dense engine's and are refused here (config.py).
+Weights: Wqkv is kept in the [head][q, k, v][d] row order of the shared rotary / attention kernels and converted at the naming boundary
+(`named_parameters` / `load_named_parameters`), exactly like LLAMA2's wq / wk / wv in the dense engine.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from ._lib import IeScalerConfig, check
+from .config import PathConfig
+from .moe import MoELayer
+from .schedule import Beta2Scheduler, CosineWarmupLR
+
+BF16 = torch.bfloat16
+GROUPS = ("0_default", "1_fp32", "2_moe_ep_size_1")
+
+
+def ffn_dim(mc):
+    f = int(mc.hidden_size * mc.mlp_ratio)
+    return mc.multiple_of * ((f + mc.multiple_of - 1) // mc.multiple_of)
+
+
+def group_of(name):
+    if name.endswith("gate.wg.weight"):
+        return 1
+    return 2 if ".experts." in name else 0
+
+
+class MoEEngine:
+    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, seed=1024, init_fn=None, noise_fn=None):
+        """noise_fn(call_index, S, E) -> fp32 [S, E] device tensor: test hook that injects the Gumbel noise of the call-th gating call of the
+        run (layer-major inside a micro-batch); None = generated on the device from (seed, layer, call)."""
+        self.cfg, self.mc, self.tc = cfg, cfg.model, cfg.train
+        mc, tc = self.mc, self.tc
+        if mc.model_type != "INTERNLM_MoE" or mc.num_experts < 2:
+            raise ValueError("MoEEngine runs model_type INTERNLM_MoE with num_experts > 1")
+        if mc.num_kv_attention_heads != mc.num_attention_heads:
+            raise NotImplementedError("the InternLM-1 block has no grouped-query attention")
+        K._L()
+        self.dev, self.world, self.rank, self.group = device, world_size, rank, process_group
+        if world_size > 1 and not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised for world_size > 1")
+        self.backend = dist.get_backend(process_group) if world_size > 1 else None
+        self.noise_fn, self.calls = noise_fn, 0
+        self.keep_routes = None   # set to [] to record (expert choices, gate logits) of every micro-batch and layer
+        h, F, V, L, E = mc.hidden_size, ffn_dim(mc), mc.vocab_size, mc.num_layers, mc.num_experts
+        self.F = F
+        H, d = mc.num_attention_heads, mc.head_dim
+        if d not in (64, 128):
+            raise NotImplementedError("head dim must be 64 or 128")
+        # ---- parameters: one flat bf16 buffer (+ gradients), one flat fp32 buffer for the gates (fp32 modules)
+        specs = [("embedding.weight", (V, h))]
+        for l in range(L):
+            p = f"blocks.{l}."
+            specs += [(p + "norm1.weight", (h,)), (p + "mixer.Wqkv.weight", (3 * h, h)), (p + "mixer.Wqkv.bias", (3 * h,)),
+                      (p + "mixer.out_proj.weight", (h, h)), (p + "mixer.out_proj.bias", (h,)), (p + "norm2.weight", (h,)),
+                      (p + "mlp.w13", (E, 2 * F, h)), (p + "mlp.w2", (E, h, F))]   # experts: w1 | w3 fused per expert, all experts of a layer adjacent
+        specs += [("norm.weight", (h,)), ("head.weight", (V, h))]
+        off, self.spec = 0, {}
+        for n, shp in specs:
+            numel = math.prod(shp)
+            self.spec[n] = (off, shp)
+            off += (numel + 7) // 8 * 8
+        self.params = torch.zeros(off, dtype=BF16, device=device)
+        self.grads = torch.zeros(off, dtype=BF16, device=device)
+        self.p = {n: self.params[o : o + math.prod(s)].view(s) for n, (o, s) in self.spec.items()}
+        self.g = {n: self.grads[o : o + math.prod(s)].view(s) for n, (o, s) in self.spec.items()}
+        self.wg = torch.zeros(L, E, h, dtype=torch.float32, device=device)       # blocks.{l}.mlp.moe_layer.gate.wg.weight
+        self.d_wg = torch.zeros_like(self.wg)
+        self.master = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.master), torch.zeros_like(self.master)
+        self.wg_m, self.wg_v = torch.zeros_like(self.wg), torch.zeros_like(self.wg)
+        # slices of the flat buffer by optimizer group (contiguous runs: experts of a layer vs everything else)
+        self.runs = {0: [], 2: []}
+        for n, (o, s) in self.spec.items():
+            g = 2 if n.endswith(("mlp.w13", "mlp.w2")) else 0
+            numel = (math.prod(s) + 7) // 8 * 8
+            if self.runs[g] and self.runs[g][-1][1] == o:   # adjacent parameters of one group: one launch
+                self.runs[g][-1] = (self.runs[g][-1][0], o + numel)
+            else:
+                self.runs[g].append((o, o + numel))
+        self._init_params(seed, init_fn)
+        self.master.copy_(self.params)
+        # ---- step state
+        self.state = K.step_state_new(device, tc.initial_scale)
+        self.scaler_cfg = IeScalerConfig(tc.growth_factor, tc.backoff_factor, tc.min_scale, tc.max_scale, tc.growth_interval, tc.hysteresis, tc.clip_grad_norm, 1)
+        self.lr_sched = CosineWarmupLR(tc.lr, tc.total_steps, tc.warmup_ratio, tc.eta_min, tc.init_steps)
+        self.beta2_sched = Beta2Scheduler(tc.adam_beta2, tc.adam_beta2_c)
+        self.sumsq = torch.zeros(3, dtype=torch.float32, device=device)
+        self.group_inv = torch.zeros(3, dtype=torch.float32, device=device)
+        self.group_norm = torch.zeros(3, dtype=torch.float32, device=device)
+        self.scale_view = self.state[:4].view(torch.float32)
+        # ---- rotary tables, activations
+        inv_freq = 1.0 / (mc.rope_base ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        freqs = torch.outer(torch.arange(tc.seq_len, dtype=torch.float32), inv_freq)
+        self.cos, self.sin = torch.cos(freqs).to(BF16).to(device), torch.sin(freqs).to(BF16).to(device)
+        T = self.T = tc.packed_length
+
+        def e(*shape, dtype=BF16):
+            return torch.empty(shape, dtype=dtype, device=device)
+
+        self.a_x = [e(T, h) for _ in range(L)]
+        self.a_n1, self.a_rstd1 = [e(T, h) for _ in range(L)], [e(T, dtype=torch.float32) for _ in range(L)]
+        self.a_q, self.a_kv, self.a_ctx = [e(T, H, d) for _ in range(L)], [e(T, 2, H, d) for _ in range(L)], [e(T, H, d) for _ in range(L)]
+        self.a_lse = [e(H, T, dtype=torch.float32) for _ in range(L)]
+        self.a_r2, self.a_n2, self.a_rstd2 = [e(T, h) for _ in range(L)], [e(T, h) for _ in range(L)], [e(T, dtype=torch.float32) for _ in range(L)]
+        self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed, layer_index=l) for l in range(L)]
+        self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
+        self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * h), e(T, h), e(T, h), e(T, h)
+        self.t_dq, self.t_dkv = e(T, H, d), e(T, 2, H, d)
+        self.t_logits, self.t_loss_rows, self.t_lse, self.t_loss = e(T, V), e(T, dtype=torch.float32), e(T, dtype=torch.float32), e(2, dtype=torch.float32)
+        self.t_delta = e(K._L().ie_flash_attn_bwd_workspace(T, H, H, d), dtype=torch.float32)
+        self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
+        self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
+        self.t_bias3, self.t_bias1 = e(3 * h), e(h)
+        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        self.moe_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        self.step_count = 0
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def reference_param_shapes(self):
+        mc, out = self.mc, {}
+        h, F, V, E = mc.hidden_size, self.F, mc.vocab_size, mc.num_experts
+        out["embedding.weight"] = (V, h)
+        for l in range(mc.num_layers):
+            p = f"blocks.{l}."
+            out[p + "mixer.Wqkv.weight"], out[p + "mixer.Wqkv.bias"] = (3 * h, h), (3 * h,)
+            out[p + "mixer.out_proj.weight"], out[p + "mixer.out_proj.bias"] = (h, h), (h,)
+            out[p + "norm1.weight"], out[p + "norm2.weight"] = (h,), (h,)
+            out[p + "mlp.moe_layer.gate.wg.weight"] = (E, h)
+            for e_ in range(E):
+                q = p + f"mlp.moe_layer.experts.wrapped_experts.{e_}."
+                out[q + "w1.weight"], out[q + "w2.weight"], out[q + "w3.weight"] = (F, h), (h, F), (F, h)
+        out["norm.weight"], out["head.weight"] = (h,), (V, h)
+        return out
+
+    def _qkv_to_engine(self, t):
+        """reference "(three h d)" rows -> [h][three][d] rows (weights [3h, h] or biases [3h])"""
+        H, d = self.mc.num_attention_heads, self.mc.head_dim
+        return t.reshape(3, H, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
+
+    def _qkv_to_reference(self, t):
+        H, d = self.mc.num_attention_heads, self.mc.head_dim
+        return t.reshape(H, 3, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
+
+    def load_named_parameters(self, named, sync_master=True):
+        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters())."""
+        F = self.F
+        for n, t in named.items():
+            t = t.to(self.dev)
+            if n.endswith("gate.wg.weight"):
+                self.wg[int(n.split(".")[1])].copy_(t.float())
+            elif ".experts." in n:
+                parts = n.split(".")
+                l, e_, w = int(parts[1]), int(parts[6]), parts[7]
+                if w == "w2":
+                    self.p[f"blocks.{l}.mlp.w2"][e_].copy_(t)
+                else:
+                    self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
+            elif "mixer.Wqkv" in n:
+                self.p[n].copy_(self._qkv_to_engine(t))
+            else:
+                self.p[n].copy_(t)
+        if sync_master:
+            self.master.copy_(self.params)
+
+    def named_parameters(self):
+        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors)."""
+        F, out = self.F, {}
+        for n, shp in self.reference_param_shapes().items():
+            if n.endswith("gate.wg.weight"):
+                out[n] = self.wg[int(n.split(".")[1])]
+            elif ".experts." in n:
+                parts = n.split(".")
+                l, e_, w = int(parts[1]), int(parts[6]), parts[7]
+                out[n] = self.p[f"blocks.{l}.mlp.w2"][e_] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
+            elif "mixer.Wqkv" in n:
+                out[n] = self._qkv_to_reference(self.p[n])
+            else:
+                out[n] = self.p[n]
+        return out.items()
+
+    def _init_params(self, seed, init_fn):
+        """modeling_moe.py:170-198: normal(0.006) Wqkv / w1 / w3, normal(0.0015) (scaled by 1/sqrt(2(l+1)) with use_scaled_init) out_proj / w2,
+        zero biases, unit norms; embedding / head normal(0.0052) (:364-366,:413-415)."""
+        if init_fn is not None:
+            self.load_named_parameters({n: init_fn(n, s) for n, s in self.reference_param_shapes().items()}, sync_master=False)
+            return
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        named = {}
+        for n, s in self.reference_param_shapes().items():
+            l = int(n.split(".")[1]) if n.startswith("blocks.") else 0
+            if n.endswith("bias"):
+                t = torch.zeros(s, device=self.dev)
+            elif len(s) == 1:
+                t = torch.ones(s, device=self.dev)
+            else:
+                std = 0.0052 if n in ("embedding.weight", "head.weight") else 0.006
+                if n.endswith(("out_proj.weight", "w2.weight")):
+                    std = 0.006 / math.sqrt(2.0 * (l + 1)) if self.mc.use_scaled_init else 0.0015
+                t = torch.empty(s, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
+            named[n] = t
+        self.load_named_parameters(named, sync_master=False)
+
+    # ------------------------------------------------------------------------------------------ forward / backward of one micro-batch
+    def _bias_add(self, y, b):
+        check(K._L().ie_bias_add_bf16(K._p(y), y.stride(0), K._p(b), y.shape[0], y.shape[1], K._stream()), "ie_bias_add_bf16")
+
+    def _noise(self, S, E):
+        n = None if self.noise_fn is None else self.noise_fn(self.calls, S, E)
+        self.calls += 1
+        return n
+
+    def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
+        mc, p = self.mc, self.p
+        L, eps, H, d = mc.num_layers, mc.layer_norm_epsilon, mc.num_attention_heads, mc.head_dim
+        K.embedding_fwd(p["embedding.weight"], ids, self.a_x[0])
+        moe_out = None
+        self.l_aux = []
+        for l in range(L):
+            pre = f"blocks.{l}."
+            if l == 0:
+                K.rmsnorm_fwd(self.a_x[0], p[pre + "norm1.weight"], eps, self.a_n1[0], self.a_rstd1[0])
+            else:
+                K.add_rmsnorm_fwd(moe_out, self.a_r2[l - 1], p[pre + "norm1.weight"], eps, self.a_x[l], self.a_n1[l], self.a_rstd1[l])
+            K.linear_fwd(self.a_n1[l], p[pre + "mixer.Wqkv.weight"], self.t_qkv)
+            self._bias_add(self.t_qkv, p[pre + "mixer.Wqkv.bias"])
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, H, 1, d, False, self.a_q[l], self.a_kv[l])
+            K.flash_attn_fwd(self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], cu, max_seqlen, None, True, self.a_ctx[l], self.a_lse[l])
+            K.linear_fwd(self.a_ctx[l].view(self.T, -1), p[pre + "mixer.out_proj.weight"], self.t_h0)
+            self._bias_add(self.t_h0, p[pre + "mixer.out_proj.bias"])
+            K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "norm2.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
+            moe_out = self.t_h1
+            self.l_aux.append(self.moe[l].forward(self.a_n2[l], self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], moe_out, noise=self._noise(self.T, mc.num_experts)).clone())
+        K.add_rmsnorm_fwd(moe_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
+        K.linear_fwd(self.a_nf, p["head.weight"], self.t_logits)
+        K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+
+    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, acc, inv_m):
+        mc, tc, p, g = self.mc, self.tc, self.p, self.g
+        L, H, d, T = mc.num_layers, mc.num_attention_heads, mc.head_dim, self.T
+        ws = self.t_norm_ws
+        K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], inv_m, -100, tc.label_smoothing)
+        K.linear_dgrad(self.t_logits, p["head.weight"], self.t_h0)
+        K.linear_wgrad(self.t_logits, self.a_nf, g["head.weight"], acc)
+        d_h = self.t_h1
+        K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_h)
+        spare = [self.t_h0, self.t_h2]
+        for l in range(L - 1, -1, -1):
+            pre = f"blocks.{l}."
+            d_n2 = spare[0]
+            self.moe[l].backward(d_h, self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], d_n2, self.d_wg[l], g[pre + "mlp.w13"], g[pre + "mlp.w2"],
+                                 accumulate=acc, loss_scale_dev=self.scale_view, aux_factor=mc.moe_loss_coeff * inv_m)
+            d_r2 = spare[1]
+            K.rmsnorm_bwd(d_n2, self.a_r2[l], p[pre + "norm2.weight"], self.a_rstd2[l], d_h, g[pre + "norm2.weight"], acc, ws, d_r2)
+            self._bias_grad(d_r2, g[pre + "mixer.out_proj.bias"], self.t_bias1, acc)
+            d_ctx = d_n2
+            K.linear_dgrad(d_r2, p[pre + "mixer.out_proj.weight"], d_ctx)
+            K.linear_wgrad(d_r2, self.a_ctx[l].view(T, -1), g[pre + "mixer.out_proj.weight"], acc)
+            K.flash_attn_bwd(d_ctx.view(T, H, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu, max_seqlen, None, True,
+                             self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+            K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, H, 1, d, False, self.t_qkv)
+            self._bias_grad(self.t_qkv, g[pre + "mixer.Wqkv.bias"], self.t_bias3, acc)
+            d_n1 = d_n2
+            K.linear_dgrad(self.t_qkv, p[pre + "mixer.Wqkv.weight"], d_n1)
+            K.linear_wgrad(self.t_qkv, self.a_n1[l], g[pre + "mixer.Wqkv.weight"], acc)
+            d_x = d_h
+            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "norm1.weight"], self.a_rstd1[l], d_r2, g[pre + "norm1.weight"], acc, ws, d_x)
+            spare = [d_n2, d_r2]
+            d_h = d_x
+        K.embedding_bwd(d_h, ids, g["embedding.weight"], acc, self.t_emb_ws)
+
+    def _bias_grad(self, dy, gb, tmp, acc):
+        if acc:
+            K.colsum(dy, tmp)
+            K.add_bf16(gb, tmp, gb)
+        else:
+            K.colsum(dy, gb)
+
+    def forward_backward(self, batch, labels):
+        """One NonPipelineScheduler.forward_backward_step.  Returns (loss incl. the moe loss, moe loss) as device scalars."""
+        tc, mc = self.tc, self.mc
+        M = batch["input_ids"].shape[0]
+        assert M == tc.micro_num and batch["input_ids"].shape[1] == self.T
+        self.loss_acc.zero_()
+        self.moe_acc.zero_()
+        ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
+        lab_d = labels.to(self.dev, non_blocking=True)
+        pos_d = batch["indexes"].to(self.dev, non_blocking=True)
+        for i in range(M):
+            cu_h = batch["cu_seqlens"][i]
+            max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())
+            cu = cu_h.to(self.dev, non_blocking=True)
+            self._forward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen)
+            if self.keep_routes is not None:   # diagnostics / parity tests: the discrete decisions of this micro-batch, layer by layer
+                self.keep_routes.append([(m.expert.clone(), m.logits.clone()) for m in self.moe])
+            # moe loss: sum of the layers' l_aux (model-dtype scalars) * coeff / micro_num, in the model dtype (no_pipeline_scheduler.py:134-145)
+            s = self.l_aux[0].to(BF16)
+            for la in self.l_aux[1:]:
+                s = s + la.to(BF16)
+            moe = ((s * mc.moe_loss_coeff) / M).float()
+            self.moe_acc.add_(moe)
+            self.loss_acc.add_(self.t_loss[0:1] / M + moe)
+            self._backward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen, i > 0, 1.0 / M)
+        return self.loss_acc, self.moe_acc
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    def _all_reduce_avg(self, t):
+        if self.world == 1:
+            return
+        if self.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:  # gloo test path
+            c = t.detach().float().to("cpu")
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_((c / self.world).to(t.dtype))
+
+    def step(self):
+        """HybridZeroOptimizer.step with the three parameter groups; stream-ordered, no host sync."""
+        tc = self.tc
+        self._all_reduce_avg(self.grads)      # data parallel: every rank keeps the whole (replicated) optimizer state
+        self._all_reduce_avg(self.d_wg)
+        K.sumsq([self.grads[a:b] for a, b in self.runs[0]], self.sumsq[0:1])
+        K.sumsq(self.d_wg, self.sumsq[1:2])
+        K.sumsq([self.grads[a:b] for a, b in self.runs[2]], self.sumsq[2:3])
+        check(K._L().ie_step_control_groups(K._p(self.state), K._p(self.sumsq), 3, self.scaler_cfg, K._p(self.group_inv), K._p(self.group_norm), K._stream()),
+              "ie_step_control_groups")
+        lr, beta2 = self.lr_sched.lr(), self.beta2_sched.beta2()
+        L_ = K._L()
+
+        def adam(gr, p32, m, v, p16, group):
+            check(L_.ie_adamw_step_group(K._p(gr), K._dt(gr), K._p(p32), K._p(m), K._p(v), K._p(p16), p32.numel(), K._p(self.state),
+                                         K._p(self.group_inv[group : group + 1]), lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay, K._stream()),
+                  "ie_adamw_step_group")
+
+        for grp in (0, 2):
+            for a, b in self.runs[grp]:
+                adam(self.grads[a:b], self.master[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.params[a:b], grp)
+        adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
+        self.lr_sched.step()
+        self.beta2_sched.step()
+        self.step_count += 1
+
+    def read_state(self):
+        st = K.step_state_read(self.state)
+        self.lr_sched.set_successful_steps(st.adam_step)
+        self.beta2_sched.set_successful_steps(st.adam_step)
+        st.group_norms = dict(zip(GROUPS, (float(x) for x in self.group_norm.cpu())))
+        return st

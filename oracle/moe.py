@@ -27,7 +27,7 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity):
     return max(c, int(min_capacity))
 
 
-def top2gating(logits, capacity_factor, min_capacity, noise):
+def top2gating(logits, capacity_factor, min_capacity, noise, force_expert=None):
     """logits, noise: fp32 [S, E].  -> dict with
         l_aux (fp32 scalar), capacity (int), exp_counts int64 [E] (first choices per expert, before the drop),
         expert int64 [2, S], slot int64 [2, S] (-1 = dropped), weight fp32 [2, S] (0 when dropped)."""
@@ -39,6 +39,11 @@ def top2gating(logits, capacity_factor, min_capacity, noise):
     masked = (logits + noise).clone()
     masked[torch.arange(S), e1] = torch.finfo(logits.dtype).min
     e2 = torch.argmax(masked, dim=1)
+    if force_expert is not None:
+        # teacher-forced routing (tests only): take the two choices from somewhere else -- the HIP engine's -- so that everything
+        # DOWNSTREAM of the discrete decision can be compared tightly; the decision itself flips between machines for tokens whose two
+        # best (noisy) logits are within bf16 rounding noise, and is compared separately
+        e1, e2 = force_expert[0].clone(), force_expert[1].clone()
     # rank of a token among the tokens that picked the same expert, in token order
     first_counts = torch.bincount(e1, minlength=E)
     pos1 = torch.empty(S, dtype=torch.int64)
@@ -131,7 +136,7 @@ class _RoundGrad(torch.autograd.Function):
         return g.to(ctx.dt).to(g.dtype), None
 
 
-def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
+def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity, force_expert=None):
     """x [S, M] in the model dtype (bf16; fp32 for the fp32 runs), wg fp32 [E, M], w1 / w3 [E, F, M], w2 [E, M, F] in the model dtype,
     noise fp32 [S, E].  -> (out [S, M], l_aux scalar, both in the model dtype; routing dict).  Differentiable w.r.t. x, wg, w1, w3, w2."""
     S, M = x.shape
@@ -139,7 +144,8 @@ def moe_layer(x, wg, w1, w3, w2, noise, capacity_factor, min_capacity):
     dt = x.dtype
     logits = x.float() @ wg.float().t()
     with torch.no_grad():
-        r = top2gating(logits.detach(), capacity_factor, min_capacity, noise)
+        r = top2gating(logits.detach(), capacity_factor, min_capacity, noise, force_expert)
+        r["logits"], r["noisy"] = logits.detach().clone(), (logits.detach() + noise)
     gates = torch.softmax(logits, dim=1)
     ar = torch.arange(S)
     keep = r["slot"] >= 0

@@ -55,7 +55,7 @@ def group_of(name):
     return "0_default"
 
 
-def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=None):
+def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=None, routes=None, forced=None):
     """input_ids [S] (one packed row / one micro-batch).  noise_fn(layer) -> fp32 [S, E] Gumbel noise of that layer's gate.
     Returns (fp32 logits [S, V], [l_aux per layer])."""
     p = params
@@ -85,8 +85,11 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
         w1 = torch.stack([p[ex + f"{e}.w1.weight"] for e in range(E)])
         w3 = torch.stack([p[ex + f"{e}.w3.weight"] for e in range(E)])
         w2 = torch.stack([p[ex + f"{e}.w2.weight"] for e in range(E)])
-        y, l_aux, _ = MO.moe_layer(x, p[pre + "mlp.moe_layer.gate.wg.weight"], w1, w3, w2, noise_fn(l), mc.moe_capacity_factor, mc.moe_min_capacity)
+        y, l_aux, route = MO.moe_layer(x, p[pre + "mlp.moe_layer.gate.wg.weight"], w1, w3, w2, noise_fn(l), mc.moe_capacity_factor, mc.moe_min_capacity,
+                                       None if forced is None else forced[l])
         l_auxes.append(l_aux)
+        if routes is not None:   # (diagnostics: which expert / slot every token got in this layer)
+            routes.append(route)
         h = y + residual
     x = O.rms_norm(h.float(), p["norm.weight"], mc.layer_norm_epsilon)
     return F.linear(x, p["head.weight"]).float(), l_auxes
@@ -121,7 +124,15 @@ class OracleMoETrainer(OracleTrainer):
 
         return fn
 
-    def train_step(self, batch, labels):
+    def train_step(self, batch, labels, forced=None):
+        total, moe_total = self.backward(batch, labels, forced)
+        return self.update(total, moe_total)
+
+    def backward(self, batch, labels, forced=None):
+        """forward + (loss-scaled) backward over the micro-batches; gradients accumulate in params[n].grad.  -> (loss, moe loss).
+        forced[i][l] = int64 [2, S] expert choices to use in micro-batch i, layer l (teacher-forced routing, see oracle.moe.top2gating);
+        self.routes[i][l] keeps what was routed."""
+        self.routes = []
         tc, mc = self.tc, self.mc
         for p in self.params.values():
             p.grad = None
@@ -131,7 +142,8 @@ class OracleMoETrainer(OracleTrainer):
             cu = batch["cu_seqlens"][i] if batch.get("cu_seqlens") is not None else None
             idx = batch["indexes"][i] if batch.get("indexes") is not None else None
             S = batch["input_ids"][i].shape[0]
-            logits, l_auxes = forward_logits(self.params, mc, batch["input_ids"][i], self._noise(S), idx, cu)
+            self.routes.append([])
+            logits, l_auxes = forward_logits(self.params, mc, batch["input_ids"][i], self._noise(S), idx, cu, self.routes[-1], None if forced is None else forced[i])
             loss = O.cross_entropy(logits, labels[i], tc.label_smoothing)
             moe_loss = sum(l_auxes) * mc.moe_loss_coeff        # model-dtype tensors (the gate's outputs are cast back to it)
             moe_loss = moe_loss / M
@@ -139,6 +151,11 @@ class OracleMoETrainer(OracleTrainer):
             total += float(loss.detach())
             moe_total += float(moe_loss.detach())
             (self.scaler.scale * loss).backward()
+        return total, moe_total
+
+    def update(self, total=0.0, moe_total=0.0):
+        """HybridZeroOptimizer.step on the accumulated gradients: group norms, overflow check, scaler, per-group clip, AdamW."""
+        tc = self.tc
         groups = {"0_default": [], "1_fp32": [], "2_moe_ep_size_1": []}
         for n in self.names:
             groups[group_of(n)].append(n)

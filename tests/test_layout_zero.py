@@ -248,6 +248,13 @@ def test_shipped_reference_configs_map():
     assert (b.model.model_type, b.model.vocab_size, b.model.num_kv_attention_heads, b.model.adapt_hf, b.train.sp_size) == ("LLAMA2", 32000, 8, False, 1)
     c = load_reference_config("/root/reference/configs/7B_isp_sft.py")
     assert c.train.sp_size == 2
+    # BASELINE configs[4]: model_type INTERNLM_MoE, 4 experts, top-2 (moe_engine.MoEEngine)
+    d = load_reference_config("/root/reference/configs/7B_MoE4_sft.py")
+    assert (d.model.model_type, d.model.num_experts, d.model.num_kv_attention_heads, d.model.moe_capacity_factor, d.model.moe_min_capacity,
+            d.model.moe_loss_coeff) == ("INTERNLM_MoE", 4, 32, 1.0, 4, 0.1)
+    from internevo_amd.moe_engine import ffn_dim
+
+    assert ffn_dim(d.model) == 5632   # int(4096 * 4/3) rounded up to a multiple of 256 (modules/mlp.py:52)
 
 
 def _tp_group_worker(rank, world, port, q):

@@ -67,6 +67,43 @@ def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
     return infos_all
 
 
+def _train_moe(cfg, raw, dev, world, rank, args, log):
+    """The hot loop for model_type INTERNLM_MoE (configs/7B_MoE4_sft.py) on internevo_amd.moe_engine.MoEEngine: synthetic RandomDataset batches,
+    forward / backward with the moe loss, the three-group optimizer step, one log line per step with the reference's loss / moe_loss /
+    per-group grad_norm keys (train/pipeline.py:494-530).  Checkpoints, validation and tokenized folders are the dense engine's: refused."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.moe_engine import MoEEngine
+
+    data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
+    if ck.get("enable_save_ckpt", False) or data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0:
+        raise NotImplementedError("INTERNLM_MoE runs: set ckpt.enable_save_ckpt=False, data.train_folder=None and data.valid_every=0 "
+                                  "(checkpoints / validation / tokenized folders are implemented for the dense model families)")
+    tc = cfg.train
+    eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
+    if world > 1:   # sync_model_param (utils/parallel.py:71-107)
+        torch.distributed.broadcast(eng.params, src=0)
+        torch.distributed.broadcast(eng.wg, src=0)
+        eng.master.copy_(eng.params)
+    loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world))
+    out = []
+    for step in range(tc.total_steps):
+        start = time.time()
+        batch, labels = next(loader)
+        loss, moe_loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        infos = dict(step=step, loss=float(loss), moe_loss=float(moe_loss), grad_norm=dict(st.group_norms), loss_scale=st.loss_scale, lr=eng.lr_sched.lr(),
+                     tgs=round(labels.nelement() / (time.time() - start), 2), inf_nan_skip_batches=st.skipped_total)
+        out.append(infos)
+        if rank % 8 == 0:
+            if st.skip:
+                log(f"Warning: skip parameter update at step {step}.")
+            log(" ".join(f"{k}={v}" for k, v in infos.items()))
+    if world > 1:
+        torch.distributed.barrier()
+    return out
+
+
 def main(argv=None, log=print):
     args = parse_args(argv)
     from internevo_amd.config import from_reference_dict
@@ -90,6 +127,8 @@ def main(argv=None, log=print):
     dev = torch.device("cuda", local_rank)
     if world > 1 and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL
+    if mc.model_type == "INTERNLM_MoE":
+        return _train_moe(cfg, raw, dev, world, rank, args, log)
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
     ck = raw.get("ckpt", {}) or {}
     load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
