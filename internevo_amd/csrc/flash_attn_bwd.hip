@@ -309,20 +309,12 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         for (int qs = 0; qs < 2; ++qs) {
             const int qb0 = q0 + 32 * qs;  // first query row of this sub-block
             if (!act[qs]) continue;
-            // explicit register files (flash_common.h): S / dP in arch VGPRs (the vector ALU reads them), dK / dV and the resident
-            // K / V fragments in the accumulation file -- hipcc otherwise keeps every accumulator of this > 256-register kernel
-            // there and moves S / dP back and forth (4.4 v_accvgpr moves per MFMA in the round-1 build)
-            f32x16 s, dp;
+            f32x16 s = zero16(), dp = zero16();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                if (ks == 0) {
-                    mfma_s_first(s, qf[ks], kf[ks]);
-                    mfma_s_first(dp, dof[ks], vf[ks]);
-                } else {
-                    mfma_s(s, qf[ks], kf[ks]);
-                    mfma_s(dp, dof[ks], vf[ks]);
-                }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], dp, 0, 0, 0);
             }
             // transposed fragments of this sub-block: requested now, consumed after the softmax block
             s16x8 tdo[2][G::DB], tq[2][G::DB];
@@ -334,7 +326,6 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                     tq[s2][db] = trans_frag<D>(Qs, db, 2 * qs + s2, fo);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 11" : "+v"(s), "+v"(dp));  // MFMA result -> vector ALU: 12 wait states behind the last MFMA
             const bool need_mask = (CAUSAL && kw0 + 31 > qb0) || (kw0 + 32 > len);
             f32x16 p;
 #pragma unroll
@@ -373,8 +364,8 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                 const s16x8 dsf = pack_frag(s, s2);
 #pragma unroll
                 for (int db = 0; db < G::DB; ++db) {
-                    mfma_o(dvacc[db], tdo[s2][db], pf);
-                    mfma_o(dkacc[db], tq[s2][db], dsf);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[s2][db], pf, dvacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[s2][db], dsf, dkacc[db], 0, 0, 0);
                 }
             }
         }
@@ -388,8 +379,6 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
-#pragma unroll
-    for (int db = 0; db < G::DB; ++db) mfma_settle_acc(dkacc[db], dvacc[db]);
     if (k_valid && HS == 1) {
         bf16_t* dkp = dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
         bf16_t* dvp = dv + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;

@@ -93,44 +93,19 @@ struct TileSrc {
             voff[q] = row * ts2 + c * 16;
         }
     }
-    // tile starting `row0` rows (+ `extra` elements, e.g. a head offset) behind base -> img.
-    // The transfers are issued from inline asm ON PURPOSE: hipcc tracks an LDS-DMA it knows about as a pending LDS write on the
-    // vm counter, and because `ds_read_b64_tr_b16` carries no address information for its alias analysis it puts `s_waitcnt vmcnt(0)`
-    // in front of the first transposing read after any DMA issue -- the tile requested for the NEXT iteration was drained before the
-    // current tile's P.V / dS.K products could start (every kernel of this family waited a full memory round trip per tile).  An asm
-    // transfer is invisible to that bookkeeping; the kernels wait for their tiles themselves (`s_waitcnt vmcnt(0)` + barrier before the
-    // first read of a stage -- the only ordering LDS-DMA data has anyway, MI355X_MICROARCH.md "Two waves per SIMD" item 7).
-    // M0 (LDS destination base) is compiler-reserved: saved and restored inside the statement; SALU write of M0 -> LDS-DMA needs one
-    // wait state (s_nop 0).
+    // (Measured in round 2: hipcc puts `s_waitcnt vmcnt(0)` in front of the first `ds_read_b64_tr_b16` after a DMA issue it knows about -- the
+    // transposing read carries no address for its alias analysis -- so the tile requested for the next iteration is drained before the
+    // current tile's P.V / dS.K products.  Issuing the transfers from inline asm removes that wait, and changes nothing: the tiles are
+    // L2-resident and land within the tile's first product anyway, while the asm form costs 3-4 % on the two-waves-per-SIMD kernels
+    // (M0 save / restore, no scheduling around it).  Kept as the builtin; profiles/r02_flash_attention.md.)
+    // tile starting `row0` rows (+ `extra` elements, e.g. a head offset) behind base -> img
     __device__ __forceinline__ void issue(unsigned char* img, int row0, int extra, int wave) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-        const uint64_t b = (uint64_t)base;
-        u32x4_t rsrc;
-        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
-        rsrc[2] = __builtin_amdgcn_readfirstlane(bytes);
-        rsrc[3] = 0x00020000u;
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(row0 * ts2 + extra * 2);
-        const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)img + wave * 1024);
-        // one statement per tile: M0 saved / restored once, s_mov + s_nop + load per piece
-        static_assert(PERW == 2 || PERW == 4 || PERW == 8, "pieces per wave");
-        const unsigned step = (unsigned)(NW * 1024);
-        unsigned keep;
-#define IE_PIECE(vo) "s_nop 0\n\tbuffer_load_dwordx4 " vo ", %2, %3 offen lds\n\ts_add_u32 m0, m0, %4\n\t"
-        if constexpr (PERW == 2) {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" IE_PIECE("%5") IE_PIECE("%6") "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(lds0), "s"(rsrc), "s"(soff), "s"(step), "v"(voff[0]), "v"(voff[1]) : "memory");
-        } else if constexpr (PERW == 4) {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" IE_PIECE("%5") IE_PIECE("%6") IE_PIECE("%7") IE_PIECE("%8") "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(lds0), "s"(rsrc), "s"(soff), "s"(step), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]) : "memory");
-        } else {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" IE_PIECE("%5") IE_PIECE("%6") IE_PIECE("%7") IE_PIECE("%8") IE_PIECE("%9")
-                         IE_PIECE("%10") IE_PIECE("%11") IE_PIECE("%12") "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(lds0), "s"(rsrc), "s"(soff), "s"(step), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]),
-                           "v"(voff[5]), "v"(voff[6]), "v"(voff[7]) : "memory");
-        }
-#undef IE_PIECE
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+        const int soff = row0 * ts2 + extra * 2;
+#pragma unroll
+        for (int q = 0; q < PERW; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, voff[q], soff, 0, 0);
 #endif
     }
 };
