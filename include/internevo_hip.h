@@ -231,8 +231,10 @@ int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_
  * 4 = 256x256 LDS-DMA, 5 = 128x128 LDS-DMA, 6 / 7 = 256x256 LDS-DMA with the DMA issue spread over 2 / 4 k-steps,
  * 8 = 128x128 LDS-DMA spread over 2 k-steps, 9 / 10 = 256x256 / 128x128 LDS-DMA with role-split load/compute
  * phases, 11 = 256x256 with one wave per SIMD (4 waves, 128x128 each), buffer-addressed LDS-DMA and fragments
- * pipelined across k-tiles (operands must each span < 4 GiB), 12 = 128x256 phased, 13 = 256x256 phased with two k-steps per phase and buffer-addressed DMA (operands < 4 GiB), 14 = 128x256 likewise; all LDS-DMA
- * variants need K % 64 == 0; -1 = automatic (which can also cut a half-empty last round of 256x256 tiles off into a second launch
+ * pipelined across k-tiles (operands must each span < 4 GiB), 12 = 128x256 phased, 13 = 256x256 phased with two k-steps per phase and buffer-addressed DMA (operands < 4 GiB), 14 = 128x256 likewise,
+ * 15 / 16 / 17 = 256x256 on four 32-deep LDS stages (k32 ring, counted vmcnt): 15 phased 8 waves, 16 one wave per SIMD, 17 = 16 with
+ * the DMA pieces of an entry split over both k-steps (operands < 4 GiB);
+ * all LDS-DMA variants need K % 64 == 0; -1 = automatic (which can also cut a half-empty last round of 256x256 tiles off into a second launch
  * of 128x256 tiles, see ie_tune_gemm_tail_split). */
 int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb,
                       int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,

@@ -268,7 +268,8 @@ inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu
     return (double)rounds * slots * bm * bn / eff;  // ~ time: rounds x work per round / efficiency
 }
 
-int pick_variant(int64_t M, int64_t N, int64_t K, bool any_kmajor) {
+int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {
+    const bool any_kmajor = a_kmajor || b_kmajor;
     // priors from the round-1 micro-benchmarks (profiles/r01_gemm_tile_tuning.json): relative MFMA efficiency per tile shape
     if (K > 0 && K % 64 == 0 && M >= 8 && N >= 8) {  // LDS-DMA kernels: 256x256 unless wave quantisation on 256 CUs favours 128x128
         const double d256 = shape_cost(M, N, 256, 256, 1, 1.36);  // measured: variants 11 / 13 vs the 128x128 kernels on 1.5-round shapes (wqkv)
@@ -276,7 +277,12 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool any_kmajor) {
         // 256x256: k-contiguous operands -> one wave per SIMD (128x128 per wave), buffer-addressed DMA, fragments pipelined
         // across k-tiles; a k-major operand (two transposing reads per fragment) -> 8 waves, role-split load/compute phases of
         // two k-steps each, buffer-addressed DMA (+12 % dgrad, +7 % wgrad over one k-step per phase, profiles/)
-        if (d256 <= d128) return any_kmajor ? 13 : 11;
+        // a k-major operand (dgrad, wgrad) -> the k32 ring variants (four 32-deep LDS stages, counted vmcnt, asm transposing reads:
+        // two to three entries of DMA stay in flight, where the two-stage kernels drained the DMA before every LOAD phase):
+        // round-2 same-box A/B at 16 384 tokens (profiles/r02_gemm_ring_ab.jsonl): dgrad +4 ... +11 % with the 8-wave phased ring (15),
+        // wgrad +7 ... +10 % with the one-wave-per-SIMD ring (16), +2 ... +4 % more with its DMA pieces split over both k-steps (17).  The forward product (both operands k-contiguous) stays on 11: its
+        // ring version reads 64-byte row segments instead of whole 128-byte lines and measured 1 ... 12 % slower.
+        if (d256 <= d128) return !any_kmajor ? 11 : (a_kmajor && b_kmajor) ? 17 : 15;
         return any_kmajor ? 5 : 8;    // 128x128: spreading helps the k-contiguous product only
     }
     const double c0 = shape_cost(M, N, 128, 128, 2, 1.00);
@@ -324,14 +330,14 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 14, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 17, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
     if (variant < 0) {
-        variant = pick_variant(M, N, K, a_kmajor || b_kmajor);
-        if ((variant == 11 || variant == 13) && !fits32) variant = 9;
-        const TailSplit ts = (g_tail_split && (variant == 11 || variant == 13)) ? tail_split(M, N) : TailSplit{false, false, 0};
+        variant = pick_variant(M, N, K, a_kmajor != 0, b_kmajor != 0);
+        if ((variant == 11 || variant == 13 || variant >= 15) && !fits32) variant = 9;
+        const TailSplit ts = (g_tail_split && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
             const int tail_variant = g_tail_split == 2 ? 14 : g_tail_split == 3 ? 12 : ((a_kmajor || b_kmajor) ? 14 : 12);
             const char* a = (const char*)A;
@@ -349,7 +355,7 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                                  M - ts.cut, N, K, accumulate, stream);
         }
     }
-    IE_CHECK_SUPPORTED((variant != 11 && variant != 13 && variant != 14) || fits32, "ie_gemm_bf16: tile variants 11, 13 and 14 need operands smaller than 4 GiB");
+    IE_CHECK_SUPPORTED((variant != 11 && variant < 13) || fits32, "ie_gemm_bf16: tile variants 11 and 13..17 need operands smaller than 4 GiB");
     if (variant >= 4) {  // LDS-DMA kernels (gemm_bf16_dma.hip): need whole 64-wide k-tiles and >= 8 valid rows/cols to clamp to
         IE_CHECK_SUPPORTED(K > 0 && K % 64 == 0 && M >= 8 && N >= 8, "ie_gemm_bf16: the LDS-DMA variants need K % 64 == 0");
         return ie_gemm_dma_launch(variant - 4, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);

@@ -168,6 +168,85 @@ __device__ __forceinline__ s16x8 frag_km(const unsigned char* tile, int mbase, i
     return r;
 }
 
+// ---- k32 ring staging (SPREAD -21 / -22).  The LDS holds FOUR stages of 32 k each instead of two of 64: a stage is free as soon as
+// every wave holds its fragments in registers, so the DMA of entry u+3 (8-wave phased schedule) / u+4 (one wave per SIMD) is
+// issued two to three whole entries before its first read, and the landing wait is a COUNTED `s_waitcnt vmcnt(n)` that leaves the
+// younger entries in flight.  With two 64-deep stages the last pieces of a tile were issued about one k-step (~0.3 us) before a
+// `vmcnt(0)`, i.e. inside the L2 / Infinity-Cache latency: the wave parked at that wait for a fifth of its time (SQ_WAIT_ANY
+// 22 % against 5 % for hipBLASLt's loop, which keeps two tiles in flight the same way -- profiles/r01_gemm_ablation.md).
+//   k-contiguous operand: stage image [R][32] bf16 (64-B rows); 16-B chunk c of row r sits at slot c ^ ((r >> 2) & 3) (16 rows x
+//     one chunk = 16 distinct 16-B slots of a 256-B bank row); a 1-KiB piece = 16 rows, 4 lanes per row;
+//   k-major operand: stage image [32][R] in natural layout, 64-B block b of k-row k at block b ^ (k & 3) exactly as above.
+template <bool KM, int R, int NW>
+struct RingSrc {
+    static constexpr int LPR = R / 8;                      // KM: 16-B slots per k-row
+    static constexpr int RPI = 64 / LPR;                   // KM: k-rows per piece
+    static constexpr int PERW = R / 16 / NW;               // pieces per wave and stage (a stage image is R * 64 bytes)
+    static_assert(PERW >= 1 && NW % 2 == 0 && (!KM || RPI == 2 || RPI % 4 == 0), "piece mapping");
+    const bf16_t* base;
+    uint32_t bytes_left, step_bytes;
+    int voff;
+    int soff[PERW];
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int K, int wave, int lane) {
+        const int ldb = (int)ld * 2;
+        if (KM) {
+            const int kr_in = lane / LPR;
+            const int kr3 = (RPI == 2 ? 2 * (wave & 1) + kr_in : kr_in) & 3;
+            voff = kr_in * ldb + (((lane % LPR) ^ (kr3 << 2)) * 16);
+            base = P + r0;
+            bytes_left = (uint32_t)((int64_t)K * ldb - (int64_t)r0 * 2);
+            step_bytes = 32u * (uint32_t)ldb;
+#pragma unroll
+            for (int q = 0; q < PERW; ++q) soff[q] = (wave + NW * q) * RPI * ldb;
+        } else {
+            const int row_in = lane >> 2;
+            voff = row_in * ldb + (((lane & 3) ^ ((row_in >> 2) & 3)) * 16);
+            base = P + (int64_t)r0 * ld;
+            bytes_left = (uint32_t)(((int64_t)nr - r0) * ldb);
+            step_bytes = 64u;
+#pragma unroll
+            for (int q = 0; q < PERW; ++q) soff[q] = 16 * (wave + NW * q) * ldb;
+        }
+    }
+    __device__ __forceinline__ void issue_keep(int q, unsigned char* img, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_left, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, voff, soff[q], 0, 0);
+#endif
+    }
+    __device__ __forceinline__ void advance() {
+        base = (const bf16_t*)((const unsigned char*)base + step_bytes);
+        bytes_left -= step_bytes;
+    }
+};
+
+// fragment (rows rbase + (lane & 31), k-step ks of 2) of a k-contiguous k32 stage image
+__device__ __forceinline__ s16x8 frag_kc32(const unsigned char* img, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 31);
+    const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const s16x8*>(img + row * 64 + c * 16);
+}
+
+// frag_km with the two transposing reads as inline asm.  hipcc treats the ds_read_tr builtin as a read of any memory and puts
+// `s_waitcnt vmcnt(0)` in front of the first one after an LDS-DMA issue, which would drain the ring entries that are meant to
+// stay in flight.  The asm form carries no memory dependence; the caller waits `lgkmcnt(0)` itself before the first use.
+template <int R>
+__device__ __forceinline__ s16x8 frag_km_nowait(const unsigned char* tile, int mbase, int ks, int lane) {
+    const int p = lane & 15, gq = lane >> 4;
+    const int mcol = mbase + 16 * (gq & 1) + 4 * (p & 3);
+    const int swz = (p >> 2) << 6;
+    const int kb0 = ks * 16 + 8 * (lane >> 5) + (p >> 2);
+    const unsigned char* a0 = tile + kb0 * (2 * R) + ((mcol * 2) ^ swz);
+    const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a0;
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(l0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(l0), "n"(4 * 2 * R));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
 // SPREAD = 0: the next tile's DMA instructions are all issued at the top of the k-tile; SPREAD = n > 0: they are
 // interleaved one by one with the MFMAs of the first n k-steps (a DMA issue costs ~60-180 cycles of issue time during
 // which this wave cannot feed the matrix pipe; spreading them lets the previous MFMAs cover that time).
@@ -207,20 +286,192 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23;
     const int nk = K / BK;
     constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
-    sa.init(A, lda, m0, M, K, wave, lane);
-    sb.init(B, ldb, n0, N, K, wave, lane);
-    sa.issue(smem, wave);
-    sb.issue(smem + G::A_BYTES, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (!RING) {
+        sa.init(A, lda, m0, M, K, wave, lane);
+        sb.init(B, ldb, n0, N, K, wave, lane);
+        sa.issue(smem, wave);
+        sb.issue(smem + G::A_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     constexpr int NA = DmaSrc<A_KM, BM, NW>::PERW, NB = DmaSrc<B_KM, BN, NW>::PERW;
     constexpr int DMA_STRIDE = SPREAD > 0 ? (SPREAD * G::TM * G::TN) / (NA + NB) : 1;  // MFMAs between two DMA issues
     static_assert(SPREAD <= 0 || DMA_STRIDE >= 1, "more DMA slots than MFMAs in the spread window");
+    if constexpr (SPREAD == -21 || SPREAD == -22 || SPREAD == -23) {
+        using RA = RingSrc<A_KM, BM, NW>;
+        using RB = RingSrc<B_KM, BN, NW>;
+        constexpr int AB = BM * 64, ST = (BM + BN) * 64;     // bytes of A's stage image, of one stage
+        static_assert(4 * ST <= G::SMEM_BYTES, "four k32 stages");
+        constexpr int PPW = RA::PERW + RB::PERW;              // DMA pieces per wave and entry
+        RA ra;
+        RB rb;
+        ra.init(A, lda, m0, M, K, wave, lane);
+        rb.init(B, ldb, n0, N, K, wave, lane);
+        const int nk = K / 32;
+        auto issue_piece = [&](int sl, unsigned char* st) {
+            if (sl < RA::PERW) ra.issue_keep(sl, st, wave);
+            else rb.issue_keep(sl - RA::PERW, st + AB, wave);
+        };
+        auto issue_entry = [&](int e) {
+            unsigned char* st = smem + (e & 3) * ST;
+#pragma unroll
+            for (int sl = 0; sl < PPW; ++sl) issue_piece(sl, st);
+            ra.advance();
+            rb.advance();
+        };
+        auto fragA = [&](const unsigned char* st, int i, int ks) {
+            return A_KM ? frag_km_nowait<BM>(st, wm * G::WM + i * 32, ks, lane) : frag_kc32(st, wm * G::WM + i * 32, ks, lane);
+        };
+        auto fragB = [&](const unsigned char* st, int j, int ks) {
+            return B_KM ? frag_km_nowait<BN>(st + AB, wn * G::WN + j * 32, ks, lane) : frag_kc32(st + AB, wn * G::WN + j * 32, ks, lane);
+        };
+        if constexpr (SPREAD == -21) {
+            // ---- 8 waves, role-split LOAD / COMPUTE phases as SPREAD -11; one phase pair = one ring entry (two k-steps).
+            // LOAD(u) reads entry u's fragments, issues entry u+3 into the stage of entry u-1 (the lagging group, then in
+            // COMPUTE(u-1), drained its reads of that stage before the barrier that closed its LOAD(u-1)) and waits until this
+            // wave's pieces of entry u+1 have landed: everything but the 2 * PPW youngest pieces.
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (e < nk) issue_entry(e);
+            if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool lag = wave >= NW / 2;
+            if (lag) __builtin_amdgcn_s_barrier();
+            auto entry = [&](int u, auto more_) {
+                constexpr bool MORE = decltype(more_)::value;   // entry u+3 exists
+                const unsigned char* st = smem + (u & 3) * ST;
+                s16x8 af[2][G::TM], bfr[2][G::TN];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i) af[ks][i] = fragA(st, i, ks);
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j) bfr[ks][j] = fragB(st, j, ks);
+                }
+                if constexpr (MORE) {
+                    issue_entry(u + 3);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int u = 0;
+            for (; u + 3 < nk; ++u) entry(u, std::true_type{});
+            for (; u < nk; ++u) entry(u, std::false_type{});
+            if (!lag) __builtin_amdgcn_s_barrier();
+            __syncthreads();
+        } else {
+            // ---- one wave per SIMD (4 waves, 128x128 per wave), fragments software-pipelined across entries.  Entry u: k-step 0
+            // runs on fragment set 0 while set 1 (entry u, k-step 1) is requested one read per MFMA gap; then the entry's single
+            // barrier (every wave now holds all of entry u in registers, and this wave's pieces of entry u+1 have landed:
+            // vmcnt leaves entries u+2, u+3 in flight); k-step 1 runs on set 1 while set 0 of entry u+1 is requested (gaps
+            // 0..7) and the pieces of entry u+4 are issued into the stage just freed (gaps 8..15).
+            static_assert(G::TM * G::TN >= G::TM + G::TN + PPW, "not enough MFMA gaps for the DMA pieces");
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nk) issue_entry(e);
+            if (nk >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // (not __syncthreads: its fence would drain the three entries left in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            s16x8 af[2][G::TM], bfr[2][G::TN];
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) af[0][i] = fragA(smem, i, 0);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) bfr[0][j] = fragB(smem, j, 0);
+            // SPLIT (-23): the pieces of an entry are issued half under k-step 1 of entry u (entry u+4, into the stage freed by
+            // barrier(u)) and half under k-step 0 of entry u+1 (still entry u+4 = its u+3, before barrier(u+1)) instead of all eight
+            // in consecutive gaps.  FAST = steady state (1 <= u, u+4 < nk): every condition is compile-time true; the first and the
+            // last four entries run the same body with run-time flags.
+            constexpr bool SPLIT = SPREAD == -23;
+            constexpr int H = SPLIT ? PPW / 2 : PPW;       // pieces issued under k-step 1
+            constexpr int G0 = G::TM + G::TN;              // first MFMA gap that carries a DMA piece
+            auto entry = [&](int u, auto fast_) {
+                constexpr bool FAST = decltype(fast_)::value;
+                const bool more1 = FAST || u + 1 < nk, more4 = FAST || u + 4 < nk, more3b = FAST || (u >= 1 && u + 3 < nk);
+                unsigned char* st = smem + (u & 3) * ST;
+                unsigned char* s3 = smem + ((u + 3) & 3) * ST;
+                const unsigned char* nx = smem + ((u + 1) & 3) * ST;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int cur = ks, nxt = ks ^ 1;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j) {
+                            const int m = i * G::TN + j;
+                            // the MFMA first, then this gap's read / DMA piece: the compiler's wait for the operands of the MFMA
+                            // must not cover the read issued in the same gap
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (m < G0 && (ks == 0 || more1)) {
+                                const unsigned char* ft = ks == 0 ? st : nx;
+                                if (m < G::TM) af[nxt][m] = fragA(ft, m, nxt);
+                                else bfr[nxt][m - G::TM] = fragB(ft, m - G::TM, nxt);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (ks == 1 && m >= G0 && m - G0 < H && more4) {
+                                issue_piece(m - G0, st);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (SPLIT && ks == 0 && m >= G0 && m - G0 < PPW - H && more3b) {
+                                issue_piece(H + m - G0, s3);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 0) {
+                        if (SPLIT && more3b) {
+                            ra.advance();
+                            rb.advance();
+                        }
+                        // this wave's pieces of entry u+1 have landed: everything but the entries after it that are in flight
+                        if (FAST || u + 3 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+                        else if (u + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        if (!SPLIT && more4) {
+                            ra.advance();
+                            rb.advance();
+                        }
+                        if (A_KM || B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (frag_km_nowait: set 0 of entry u+1)
+                    }
+                }
+            };
+            int u = 0;
+            entry(u++, std::false_type{});
+            for (; u + 4 < nk; ++u) entry(u, std::true_type{});
+            for (; u < nk; ++u) entry(u, std::false_type{});
+            __syncthreads();
+        }
+    } else
     if constexpr (SPREAD == -1 || SPREAD == -11) {
         // ---- role-split schedule (the "two waves per SIMD alternate compute and load segments" regime of
         // MI355X_MICROARCH.md): every k-step is a LOAD phase (fragment ds_reads + a share of the next tile's DMA
@@ -352,6 +603,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 #pragma unroll
                         for (int j = 0; j < G::TN; ++j) {
                             const int m = i * G::TN + j;
+                            // the MFMA first, then this gap's read / DMA piece: with the read first, the compiler's wait for the MFMA's
+                            // operands at the loop head (lgkmcnt(0), it cannot count across the back edge) also covered the read just
+                            // issued -- one exposed LDS round trip per k-tile
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                            __builtin_amdgcn_sched_barrier(0);
                             if (do_frags && m < G::TM + G::TN) {
                                 if (m < G::TM) af[nxt][m] = A_KM ? frag_km<BM>(Ft, wm * G::WM + m * 32, fks, lane) : frag_kc(Ft, wm * G::WM + m * 32, fks, lane);
                                 else bfr[nxt][m - G::TM] = B_KM ? frag_km<BN>(Ft + G::A_BYTES, wn * G::WN + (m - G::TM) * 32, fks, lane)
@@ -365,7 +621,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                                     __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);  // D[n][m]
                         }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 2) {
@@ -516,6 +771,9 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 7) IE_SHAPE(256, 256, 2, 2, -2);
     else if (shape == 8) IE_SHAPE(128, 256, 2, 4, -1);
     else if (shape == 10) IE_SHAPE(128, 256, 2, 4, -11);
+    else if (shape == 11) IE_SHAPE(256, 256, 2, 4, -21);
+    else if (shape == 12) IE_SHAPE(256, 256, 2, 2, -22);
+    else if (shape == 13) IE_SHAPE(256, 256, 2, 2, -23);
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
