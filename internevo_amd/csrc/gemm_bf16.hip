@@ -330,7 +330,7 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 17, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 18, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);

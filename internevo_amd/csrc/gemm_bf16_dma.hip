@@ -18,6 +18,7 @@
 // Block tile 256x256x64, 8 wave64 as 2(M) x 4(N), 128x64 per wave (8 accumulator tiles, 0.75 LDS reads/MFMA).
 #include "ie_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int GM = (accumulate >> 8) ? (accumulate >> 8) : 4;  // tile rows per group (bits 8.. of the flag word: ie_tune_gemm_group)
+    const int abl = (accumulate >> 4) & 15;                     // timing ablations (IE_GEMM_ABLATE, results are then wrong)
     accumulate &= 1;
     const int width = GM * tiles_n;
     const int group = id / width;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 
     constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23;
     const int nk = K / BK;
-    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -11;
+    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
     if constexpr (!RING) {
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         }
         if (!lag) __builtin_amdgcn_s_barrier();
         __syncthreads();
-    } else if constexpr (SPREAD == -2) {
+    } else if constexpr (SPREAD == -2 || SPREAD == -3) {
         // ---- one wave per SIMD (4 waves, 128x128 per wave: 0.5 LDS reads per MFMA), software-pipelined ACROSS k-tiles.
         // The single barrier of a k-tile sits between k-step 2 and k-step 3: by then every wave has requested all four
         // fragment sets of tile t, so after it (a) the first fragments of tile t+1 are read while the MFMAs of step 3 of
@@ -569,14 +571,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         };
         auto run = [&](auto) {
             constexpr int FIRST = G::TM + G::TN;        // MFMA positions before FIRST carry the fragment reads
-            constexpr int PER = (NS + 2) / 3;           // pieces under step 3; the rest split over steps 0 and 1
+            constexpr bool EARLY = SPREAD == -3;        // all pieces under steps 3 and 0: the last one has two k-steps to land, not one
+            constexpr int PER = EARLY ? NS / 2 : (NS + 2) / 3;   // pieces under step 3; the rest split over steps 0 and 1
             static_assert(PER <= NM - FIRST && NS - PER <= 2 * (NM - FIRST), "not enough DMA positions");
             // piece issued at (window step kidx = 0 (k-step 3), 1 (k-step 0), 2 (k-step 1); MFMA position m), or -1
             auto slot_at = [](int kidx, int m) constexpr -> int {
                 if (m < FIRST) return -1;
                 const int pos = m - FIRST;
                 if (kidx == 0) return pos < PER ? pos : -1;
-                const int rest = NS - PER, first = (rest + 1) / 2;  // step 0 takes `first`, step 1 the remainder
+                const int rest = NS - PER, first = EARLY ? rest : (rest + 1) / 2;  // step 0 takes `first`, step 1 the remainder
                 if (kidx == 1) return pos < first ? PER + pos : -1;
                 return pos < rest - first ? PER + first + pos : -1;
             };
@@ -626,7 +629,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                     if (ks == 2) {
                         sa.advance_all();  // every slot moves on one k-tile here: slots >= PER were used for tile t+1 (steps 0-1),
                         sb.advance_all();  // slots < PER are next used for tile t+2 (step 3)
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        if (abl & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        if (!(abl & 1)) __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (abl & 4) {
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -748,7 +755,8 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
     bf16_t* c = (bf16_t*)C;
-    accumulate = (accumulate ? 1 : 0) | (g_gemm_group << 8);
+    static const int ablate = getenv("IE_GEMM_ABLATE") ? atoi(getenv("IE_GEMM_ABLATE")) & 15 : 0;
+    accumulate = (accumulate ? 1 : 0) | (ablate << 4) | (g_gemm_group << 8);
 #define IE_SHAPE(BM_, BN_, WM_, WN_, SP_)                                                                                            \
     do {                                                                                                                          \
         const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (int)((N + BN_ - 1) / BN_);                                       \
@@ -774,6 +782,7 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 11) IE_SHAPE(256, 256, 2, 4, -21);
     else if (shape == 12) IE_SHAPE(256, 256, 2, 2, -22);
     else if (shape == 13) IE_SHAPE(256, 256, 2, 2, -23);
+    else if (shape == 14) IE_SHAPE(256, 256, 2, 2, -3);
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
