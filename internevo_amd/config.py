@@ -30,6 +30,7 @@ class ModelConfig:
     # explicit per-rank sizes of a tensor-parallel shard (engine-internal: ModelConfig.tp_shard); None = derived from the above
     head_dim_override: Optional[int] = None
     ffn_dim_override: Optional[int] = None
+    head_vocab_override: Optional[int] = None   # tensor parallelism: vocabulary rows of the head on this rank
     # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
     init_std: float = 0.02
     use_scaled_init: bool = True
@@ -64,15 +65,25 @@ class ModelConfig:
         lim = self.num_layers * float(self.checkpoint)
         return sum(1 for lid in range(self.num_layers) if lid < lim)
 
-    def tp_shard(self, tp):
+    @property
+    def head_vocab(self):
+        """Rows of the output head THIS rank holds: the whole vocabulary, or 1/tp of it under the vocabulary-parallel head."""
+        return self.head_vocab_override or self.vocab_size
+
+    def tp_shard(self, tp, vocab_parallel=True):
         """The model one rank of a tensor-parallel group of size tp holds (Megatron "mtp" split, model/ops/linear.py:205-337):
-        1/tp of the attention heads (whole kv groups) and 1/tp of the FFN width; hidden size, vocabulary and norms are whole."""
+        1/tp of the attention heads (whole kv groups), 1/tp of the FFN width and -- vocab_parallel, the reference's
+        `parallel_output=True` head (ops/linear.py:124-153) -- 1/tp of the head's vocabulary rows; hidden size, norms and the
+        embedding are whole."""
         if tp == 1:
             return self
         if self.num_kv_attention_heads % tp or self.ffn_dim % tp:
             raise ValueError(f"tensor parallel size {tp} must divide the kv head count and the FFN width")
+        if vocab_parallel and self.vocab_size % tp:
+            raise ValueError(f"tensor parallel size {tp} must divide the vocabulary size {self.vocab_size}")
         return dataclasses.replace(self, num_attention_heads=self.num_attention_heads // tp, num_kv_attention_heads=self.num_kv_attention_heads // tp,
-                                   head_dim_override=self.head_dim, ffn_dim_override=self.ffn_dim // tp)
+                                   head_dim_override=self.head_dim, ffn_dim_override=self.ffn_dim // tp,
+                                   head_vocab_override=self.vocab_size // tp if vocab_parallel else None)
 
     def num_params(self):
         h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size

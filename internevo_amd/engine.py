@@ -41,12 +41,14 @@ BF16 = torch.bfloat16
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None):
+                 zero_size=None, vocab_parallel=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
-        run (test hook: an sp = n run must then match it step for step)."""
+        run (test hook: an sp = n run must then match it step for step).
+        vocab_parallel (tensor parallelism only; default on): every tensor rank holds 1/tp of the head's vocabulary rows and the loss is
+        computed vocabulary-parallel (tensorpar.py); False = the whole head on every rank."""
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -59,9 +61,13 @@ class InternLM2Engine:
         sp_size = int(tc.sp_size if sp_size is None else sp_size)  # default: the config's parallel.tensor size (mode "isp")
         if tp_size > 1 and sp_size > 1:
             raise NotImplementedError("tensor parallelism and sequence parallelism are alternatives (parallel.tensor has ONE mode)")
-        self.tpar = TensorParallel(tp_size, rank, world_size)
+        self.tpar = TensorParallel(tp_size, rank, world_size, vocab_parallel=True if vocab_parallel is None else vocab_parallel)
         self.tp = tp_size
-        self.lmc = mc.tp_shard(tp_size)   # what this rank holds / computes of every layer: 1/tp of the heads and of the FFN width
+        self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
+        if self.vp and tc.label_smoothing > 0:
+            raise NotImplementedError("label smoothing with the vocabulary-parallel head (its uniform term needs one more reduction): "
+                                      "run with vocab_parallel=False")
+        self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
         if tp_size > 1:
             # data parallelism and ZeRO-1 run over the ranks that hold the same shard
             process_group, world_size, rank = self.tpar.dp_group, self.tpar.dp_world, self.tpar.dp_rank
@@ -123,7 +129,7 @@ class InternLM2Engine:
             # all-reduces of the two modes differ in number and size)
             lm = self.lmc
             per_token = 2 * (lm.num_layers * (6 * lm.hidden_size + 2 * lm.num_kv_attention_heads * lm.head_dim + 2 * lm.ffn_dim)
-                             + lm.vocab_size + 12 * lm.hidden_size + 6 * lm.ffn_dim + 2 * lm.qkv_dim) + 64
+                             + lm.head_vocab + 12 * lm.hidden_size + 6 * lm.ffn_dim + 2 * lm.qkv_dim) + 64
             fixed = 4 * L.total + 12 * L.local_numel()
             total = torch.cuda.get_device_properties(device).total_memory if device.type == "cuda" else 0
             merge_micro = can_merge and fixed + per_token * tc.packed_length * tc.micro_num + (24 << 30) < 0.92 * total
@@ -226,7 +232,9 @@ class InternLM2Engine:
             self.t_xq, self.t_xkv = e(T, hq, d), e(T, 2, hkv, d)      # send / receive buffers
             self.t_dctx_full = e(Tg, hql, d)
             self.t_loss_red = e(2, dtype=torch.float32)
-        self.t_logits = e(T, V)
+        self.t_logits = e(T, mc.head_vocab)
+        if self.vp:
+            self.t_lab_local = e(T, dtype=torch.int64)   # labels in this rank's vocabulary range (-1: valid, owned by another rank)
         self.t_loss_rows = e(T, dtype=torch.float32)
         self.t_lse = e(T, dtype=torch.float32)
         self.t_loss = e(2, dtype=torch.float32)       # [mean loss of the micro-batch, valid-token count]
@@ -249,6 +257,7 @@ class InternLM2Engine:
         M, T, L = self.n_pass, self.T, mc.num_layers
         h, F, V = mc.hidden_size, mc.ffn_dim, mc.vocab_size
         ctx_cols = mc.num_attention_heads * mc.head_dim
+        V = mc.head_vocab
         cols = L * (3 * h + ctx_cols + 3 * F + mc.qkv_dim) + h + V  # n1, n2, d_out, d_r2 | ctx | act, dw13 | dqkv ; nf, logits
         need = 2 * M * T * cols
         possible = M > 1 and mc.checkpoint_layers == 0
@@ -345,24 +354,15 @@ class InternLM2Engine:
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
         self._wait_bucket(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
-        K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)
+        K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
         if self.mm > 1:
             # merged pass: the loss (and the metric) stay per micro-batch -- each has its own valid-token count (loss = mean over
             # micro-batches of the mean token loss, no_pipeline_scheduler.py:146)
             P = self.T // self.mm
             for i in range(self.mm if nseg is None else nseg):
-                r = slice(i * P, (i + 1) * P)
-                if self.metric is None:
-                    K.ce_fwd(self.t_logits[r], labels[r], -100, self.tc.label_smoothing, self.t_loss_rows[r], self.t_lse[r], self.t_loss_seg[i])
-                else:
-                    K.ce_fwd(self.t_logits[r], labels[r], -100, self.tc.label_smoothing, self.t_loss_rows[r], self.t_lse[r], self.t_loss_seg[i],
-                             self.t_argmax[r], self.t_nll[r])
-                    self.metric.update_fused(self.t_nll[r], self.t_argmax[r], labels[r])
-        elif self.metric is None:
-            K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
-        else:  # metric pass (SchedulerMetricHook.post_helper_func -> AccPerplex.update) fused into the same sweep over the logits
-            K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss, self.t_argmax, self.t_nll)
-            self.metric.update_fused(self.t_nll, self.t_argmax, labels)
+                self._cross_entropy(slice(i * P, (i + 1) * P), labels, self.t_loss_seg[i])
+        else:
+            self._cross_entropy(slice(0, self.T), labels, self.t_loss)
         if self.sp > 1:
             # the loss is the mean over ALL tokens of the micro-batch (the reference gathers the sequence in front of the head,
             # ops/linear.py:146-153 gather_dim=1): combine the local (sum, count) over the sequence group; the backward
@@ -373,6 +373,45 @@ class InternLM2Engine:
             self.seqpar.all_reduce_sum(self.t_loss_red)
             self.t_loss[1] = self.t_loss_red[1]
             self.t_loss[0] = self.t_loss_red[0] / self.t_loss_red[1]
+
+    def _cross_entropy(self, r, labels, out):
+        """Loss of the token rows `r` of the current pass: out[0] = mean over the valid tokens, out[1] = their count; with a metric
+        attached (SchedulerMetricHook.post_helper_func -> AccPerplex.update) the arg-max / NLL pass is fused into the same sweep over
+        the logits.  Vocabulary-parallel head: the same kernels run on this rank's [rows, V / tp] columns with the labels mapped into
+        its range (-1 = valid but owned by another rank: no target term here), then ONE all-gather of (local log-sum-exp, local
+        target logit) per token over the tensor group gives the global log-sum-exp (kept in t_lse for the backward) and the loss."""
+        logits, lab, rows, lse = self.t_logits[r], labels[r], self.t_loss_rows[r], self.t_lse[r]
+        metric = self.metric is not None
+        if not self.vp:
+            if metric:
+                K.ce_fwd(logits, lab, -100, self.tc.label_smoothing, rows, lse, out, self.t_argmax[r], self.t_nll[r])
+                self.metric.update_fused(self.t_nll[r], self.t_argmax[r], lab)
+            else:
+                K.ce_fwd(logits, lab, -100, self.tc.label_smoothing, rows, lse, out)
+            return
+        Vl = self.lmc.head_vocab
+        v0 = self.tpar.tp_rank * Vl
+        ll = self.t_lab_local[r]
+        here = (lab >= v0) & (lab < v0 + Vl)
+        ll.copy_(torch.where(lab == -100, lab, torch.where(here, lab - v0, torch.full_like(lab, -1))))
+        if metric:
+            K.ce_fwd(logits, ll, -100, 0.0, rows, lse, out, self.t_argmax[r], self.t_nll[r])
+        else:
+            K.ce_fwd(logits, ll, -100, 0.0, rows, lse, out)
+        # rows = local lse - logit[label] where the label is here, else 0  ->  the target logit this rank contributes
+        stats = self.tpar.all_gather(torch.stack([lse, torch.where(here, lse - rows, torch.zeros_like(rows))]))   # [tp, 2, rows]
+        lse.copy_(torch.logsumexp(stats[:, 0], dim=0))
+        rows.copy_(torch.where(lab != -100, lse - stats[:, 1].sum(dim=0), torch.zeros_like(rows)))
+        K.ce_mean(rows, lab, -100, out)
+        if metric:
+            # first index of the row maximum over the whole vocabulary: the largest local maximum, the lowest rank on ties
+            am = self.t_argmax[r]
+            top = logits.gather(1, am.long().unsqueeze(1)).squeeze(1).float()
+            cand = self.tpar.all_gather(torch.stack([top, (am + v0).float()]))                                     # [tp, 2, rows]
+            win = cand[:, 0].max(dim=0).indices
+            am.copy_(cand[:, 1].gather(0, win.unsqueeze(0)).squeeze(0).to(torch.int32))
+            self.t_nll[r].copy_(rows)
+            self.metric.update_fused(self.t_nll[r], am, lab)
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False):
         mc, tc = self.lmc, self.tc
@@ -387,13 +426,16 @@ class InternLM2Engine:
         if first_micro:
             self._wait_optimizer()  # the previous step's AdamW reads the gradients this backward is about to overwrite
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
+        # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
+        # forward: a label owned by another rank is valid without a one-hot term here)
+        lab_b = self.t_lab_local if self.vp else labels
         if self.mm > 1:
             P = T // self.mm
             for i in range(self.mm):
                 r = slice(i * P, (i + 1) * P)
-                K.ce_bwd(self.t_logits[r], labels[r], self.t_lse[r], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+                K.ce_bwd(self.t_logits[r], lab_b[r], self.t_lse[r], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         else:
-            K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+            K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
         dlog = self.t_logits
         bw = self.batch_wgrad
         r = self._mrows if bw else None
@@ -405,7 +447,10 @@ class InternLM2Engine:
                 K.linear_wgrad(dy_all, x_all, gw, False)
 
         K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
+        ar = self.tpar.all_reduce_sum_async(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
         wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
+        if ar is not None:
+            ar.wait()
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
         K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
         if last_micro:
@@ -625,7 +670,7 @@ class InternLM2Engine:
         L = self.layout
         out = []
         for spec in L.params.values():
-            if spec.kind not in ("embed", "norm", "head"):
+            if spec.kind not in ("embed", "norm", "head") or (spec.kind == "head" and self.vp):
                 continue
             b = L.buckets[spec.bucket]
             s0, n0 = b.shard(self.rank, self.world)
@@ -795,7 +840,7 @@ class InternLM2Engine:
 
         out = self._to_reference_names(named)
         if self.tp > 1:
-            for n in ("tok_embeddings.weight", "output.weight"):
+            for n in ("tok_embeddings.weight",) if self.vp else ("tok_embeddings.weight", "output.weight"):
                 if n in out:
                     out[n] = C.tp_shard(n, out[n], self.tpar.tp_rank, self.tp)
         return out

@@ -218,6 +218,12 @@ def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=Non
     return loss_rows, lse, out[0:1], out[1:2]
 
 
+def ce_mean(loss_rows, labels, ignore_index, out):
+    """out[0] = mean of loss_rows over the rows whose label is not ignore_index, out[1] = their count (fixed-order reduction)."""
+    check(_L().ie_ce_mean(_p(loss_rows), _p(labels), labels.numel(), ignore_index, _p(out[0:1]), _p(out[1:2]), _stream()), "ie_ce_mean")
+    return out
+
+
 def metric_accumulate(nll_rows, argmax_rows, labels, type_ids, facc, ds_right=None, ds_tokens=None, ds_loss=None, ds_token_num=None,
                       ignore_index=-100):
     """One micro-batch into the AccPerplex / LossWithTypeId accumulators (see include/internevo_hip.h)."""

@@ -95,7 +95,7 @@ class FlatLayout:
             close_bucket(cur)
         cur = open_bucket()
         add(cur, "norm.weight", (h,), "norm")
-        add(cur, "output.weight", (v, h), "head")
+        add(cur, "output.weight", (c.head_vocab, h), "head")   # all vocabulary rows, or this tensor rank's 1/tp of them
         close_bucket(cur)
         self.total = off
 

@@ -117,39 +117,78 @@ class FlashCrossAttention(nn.Module):
         return out.reshape(B, Sq, *out.shape[1:])
 
 
+def _group_all_gather(t, group):
+    """[world, *t.shape]: every rank's `t` over `group` (per-token statistics of the vocabulary-parallel loss: small)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    else:  # gloo (tests): through the host
+        c = t.detach().to("cpu", copy=True).contiguous()
+        parts = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(parts, c, group=group)
+        out.copy_(torch.stack(parts))
+    return out
+
+
 class _CEFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, smoothing, ignore_index, inplace_backward):
-        loss_rows, lse, _, _ = K.ce_fwd(logits, labels, ignore_index, smoothing)
-        ctx.save_for_backward(logits, labels, lse)
+    def forward(ctx, logits, labels, smoothing, ignore_index, inplace_backward, group=None):
+        if group is None:
+            loss_rows, lse, _, _ = K.ce_fwd(logits, labels, ignore_index, smoothing)
+            own = labels
+        else:
+            # vocabulary-parallel (flash-attn's SoftmaxCrossEntropyLossFn with a process group, reached from losses/ce_loss.py:26-36 when
+            # parallel_output=True): `logits` are this rank's [rows, V / world] columns.  The fused kernel runs on them with the
+            # labels mapped into the local range (-1: valid, owned by another rank), then ONE all-gather of (local log-sum-exp, local
+            # target logit) per row gives the global log-sum-exp and the loss
+            import torch.distributed as dist
+
+            Vl, r = logits.shape[-1], dist.get_rank(group)
+            here = (labels >= r * Vl) & (labels < (r + 1) * Vl)
+            own = torch.where(labels == ignore_index, labels, torch.where(here, labels - r * Vl, torch.full_like(labels, -1)))
+            if ignore_index == -1:
+                raise NotImplementedError("vocabulary-parallel cross entropy uses -1 internally: ignore_index must differ")
+            loss_rows, lse, _, _ = K.ce_fwd(logits, own, ignore_index, 0.0)
+            stats = _group_all_gather(torch.stack([lse, torch.where(here, lse - loss_rows, torch.zeros_like(loss_rows))]), group)
+            lse = torch.logsumexp(stats[:, 0], dim=0)
+            loss_rows = torch.where(labels != ignore_index, lse - stats[:, 1].sum(dim=0), torch.zeros_like(lse))
+        ctx.save_for_backward(logits, own, lse)
         ctx.smoothing, ctx.ignore_index, ctx.inplace = smoothing, ignore_index, inplace_backward
         ctx.mark_non_differentiable(lse)
         return loss_rows
 
     @staticmethod
     def backward(ctx, dloss_rows):
-        # per-row upstream grads (ie_ce_bwd per-row mode): dlogits[r] = (softmax - onehot) * dloss_rows[r]
+        # per-row upstream grads (ie_ce_bwd per-row mode): dlogits[r] = (softmax - onehot) * dloss_rows[r]; vocabulary-parallel: the
+        # softmax uses the GLOBAL log-sum-exp, the one-hot term exists on the owning rank only
         logits, labels, lse = ctx.saved_tensors
         dlogits = logits if ctx.inplace else torch.empty_like(logits)
         K.ce_bwd(logits, labels, lse, dloss_rows.contiguous().float(), None, 1.0, ctx.ignore_index, ctx.smoothing, dlogits)
-        return dlogits, None, None, None, None
+        return dlogits, None, None, None, None, None
 
 
 class CrossEntropyLoss(nn.Module):
     """flash_attn.losses.cross_entropy.CrossEntropyLoss(ignore_index, reduction, label_smoothing, inplace_backward,
-    process_group) as constructed at internlm/model/losses/ce_loss.py:31-36."""
+    process_group) as constructed at internlm/model/losses/ce_loss.py:31-36.  process_group of more than one rank: `input` holds this
+    rank's vocabulary columns (rank r of the group owns [r V/world, (r+1) V/world)), `target` the global labels."""
 
     def __init__(self, ignore_index=-100, reduction="mean", label_smoothing=0.0, inplace_backward=False, process_group=None):
         super().__init__()
         if reduction not in ("mean", "none"):
             raise NotImplementedError("Only support reduction = 'mean' or 'none'")
+        self.group = None
         if process_group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
-            raise NotImplementedError("vocab-parallel cross entropy (tensor parallel > 1) is outside the round-1 hot path")
+            if label_smoothing > 0:
+                raise NotImplementedError("label smoothing with the vocabulary-parallel cross entropy (its uniform term needs one more reduction)")
+            self.group = process_group
         self.ignore_index, self.reduction, self.label_smoothing, self.inplace_backward = ignore_index, reduction, label_smoothing, inplace_backward
 
     def forward(self, input, target):
         assert input.is_cuda and target.is_cuda
-        loss = _CEFunc.apply(input, target, self.label_smoothing, self.ignore_index, self.inplace_backward)
+        loss = _CEFunc.apply(input, target, self.label_smoothing, self.ignore_index, self.inplace_backward, self.group)
         if self.reduction == "mean":
             return loss.sum() / (target != self.ignore_index).sum()
         return loss

@@ -7,10 +7,17 @@ the tensor group and are all-reduced (4 x 33.5 MB per l
 backward for the input gradients of the column-parallel layers).  Norm weights are replicated.
 
 Every rank of a tensor group reads the same micro-batches; data parallelism (and the ZeRO-1 sharding) runs over the ranks that
-hold the same shard (rank % tp).  MI355X note: the embedding and the output head are kept whole on every rank here (the
-reference splits them along hidden / vocabulary): 288 GB make the 1.5 GB of duplicated weights irrelevant, the logits of a
-micro-batch are computed redundantly (3.1 of ~1800 GFLOP per rank and micro-batch at tp = 2) and the vocabulary-parallel
-cross-entropy with its three extra all-reduces per micro-batch disappears; losses and gradients are the same numbers.
+hold the same shard (rank % tp).
+
+Output head and loss (`vocab_parallel`, default; the reference's `parallel_output=True`: ScaleColumnParallelLinear without
+gather_output, ops/linear.py:124-153, + flash-attn's vocabulary-parallel CrossEntropyLoss, losses/ce_loss.py:26-36): every rank holds
+V/tp rows of the head and computes [T, V/tp] logits; the cross-entropy runs on the local columns with the EXISTING fused kernels
+(labels another rank owns become "valid, not here"), and ONE all-gather of two floats per token (local log-sum-exp, local target
+logit) replaces flash-attn's three all-reduces (max, sum-exp, target); the backward uses the global log-sum-exp, and the head's
+input gradient is summed over the group under its weight gradient.  `vocab_parallel=False` keeps the whole head on every rank
+(logits computed redundantly).  The embedding is kept whole on every rank in both modes (the reference splits its hidden
+dimension and all-gathers the activations, modules/embedding.py:52-60): 0.76 GB of 288, no exchange; losses and gradients are
+the same numbers.
 """
 import torch
 import torch.distributed as dist
@@ -25,10 +32,11 @@ _DONE = _Done()
 
 
 class TensorParallel:
-    def __init__(self, tp_size, rank, world_size):
+    def __init__(self, tp_size, rank, world_size, vocab_parallel=True):
         if world_size % tp_size != 0:
             raise ValueError(f"world size {world_size} is not a multiple of the tensor-parallel size {tp_size}")
         self.tp = tp_size
+        self.vocab_parallel = bool(vocab_parallel) and tp_size > 1
         self.tp_rank = rank % tp_size
         self.dp_rank = rank // tp_size
         self.dp_world = world_size // tp_size
@@ -75,6 +83,20 @@ class TensorParallel:
         self.all_reduce_sum(t)
         return _DONE
 
+    def all_gather(self, t):
+        """[tp, *t.shape] tensor with every rank's `t` (rank order).  Small per-token statistics only (vocabulary-parallel loss)."""
+        if self.tp == 1:
+            return t.unsqueeze(0)
+        out = torch.empty((self.tp,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        else:  # gloo test path: through the host
+            c = t.detach().to("cpu", copy=True).contiguous()
+            parts = [torch.empty_like(c) for _ in range(self.tp)]
+            dist.all_gather(parts, c, group=self.group)
+            out.copy_(torch.stack(parts))
+        return out
+
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def barrier(self):
         if self.tp > 1:
@@ -82,18 +104,18 @@ class TensorParallel:
 
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
-        if self.tp == 1 or kind in ("embed", "norm", "head"):
+        if self.tp == 1 or kind in ("embed", "norm") or (kind == "head" and not self.vocab_parallel):
             return full
         r, tp = self.tp_rank, self.tp
-        if kind in ("wqkv", "w1", "w3"):      # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups)
+        if kind in ("wqkv", "w1", "w3", "head"):  # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups; head: vocabulary rows)
             n = full.shape[0] // tp
             return full[r * n : (r + 1) * n]
         n = full.shape[1] // tp               # row-parallel (wo, w2): input columns
         return full[:, r * n : (r + 1) * n]
 
     @staticmethod
-    def unshard(kind, parts):
+    def unshard(kind, parts, vocab_parallel=True):
         """Inverse of shard() given every rank's part in rank order."""
-        if kind in ("embed", "norm", "head") or len(parts) == 1:
+        if kind in ("embed", "norm") or (kind == "head" and not vocab_parallel) or len(parts) == 1:
             return parts[0]
-        return torch.cat(parts, dim=0 if kind in ("wqkv", "w1", "w3") else 1)
+        return torch.cat(parts, dim=0 if kind in ("wqkv", "w1", "w3", "head") else 1)

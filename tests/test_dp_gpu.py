@@ -399,7 +399,7 @@ def test_sequence_parallel_step_equals_single_rank_step(dev, backend):
     assert worst <= 6e-3
 
 
-def _tp_worker(rank, world, port, q, folder=None):
+def _tp_worker(rank, world, port, q, folder=None, vp=True):
     import torch.distributed as dist
 
     dev = _init_dist(rank, world, port)
@@ -408,7 +408,12 @@ def _tp_worker(rank, world, port, q, folder=None):
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, tp_size=2)
+        from internevo_amd.metrics import AccPerplex
+
+        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, tp_size=2, vocab_parallel=vp)
+        assert eng.p["output.weight"].shape[0] == (_cfg(2).model.vocab_size // 2 if vp else _cfg(2).model.vocab_size)
+        metric = AccPerplex(dev, None, None)
+        eng.attach_metric(metric)
         loader = iter(SyntheticLoader(128, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
         for _ in range(3):
@@ -417,11 +422,12 @@ def _tp_worker(rank, world, port, q, folder=None):
             eng.step()
             st = eng.read_state()
             out.append((float(loss), float(st.grad_norm)))
+        out.append(metric.get_metric())
         shards = {n: (eng.layout.params[n].kind, p.float().cpu().numpy()) for n, p in eng.p.items()}
         ck = None
         if folder is not None:  # checkpoint round trip on the tensor-parallel ranks: one model + optimizer + plan file per tensor rank
             eng.save_checkpoint(folder)
-            fresh = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2)
+            fresh = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, vocab_parallel=vp)
             fresh.load_checkpoint(folder)
             same = all(torch.equal(a, b) for a, b in ((eng.master, fresh.master), (eng.exp_avg, fresh.exp_avg), (eng.exp_avg_sq, fresh.exp_avg_sq)))
             same = same and all(torch.equal(eng.p[n], fresh.p[n]) for n in eng.p)
@@ -433,7 +439,7 @@ def _tp_worker(rank, world, port, q, folder=None):
                 nxt.append((float(loss), float(e.read_state().grad_norm)))
             ck = (bool(same), nxt, bool(torch.equal(eng.params, fresh.params)))
         # the DEFAULT initialisation (what train.py uses): every tensor rank must hold its own cut of one full model
-        dflt = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, seed=77)
+        dflt = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, seed=77, vocab_parallel=vp)
         init_shards = {n: p.float().cpu().numpy() for n, p in dflt.p.items()}
         q.put((rank, out, shards, ck, init_shards))
     finally:
@@ -441,10 +447,13 @@ def _tp_worker(rank, world, port, q, folder=None):
 
 
 @pytest.mark.timeout(600)
-def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
+@pytest.mark.parametrize("vp", [True, False], ids=["vocab_parallel_head", "whole_head"])
+def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
-    same micro-batches: same loss, same grad norm (replicated parameters counted once), and the two ranks' parameter shards
-    concatenate to the single-rank parameters (bf16 summation-order noise only)."""
+    same micro-batches: same loss, same grad norm (replicated parameters counted once), same AccPerplex metric, and the two ranks'
+    parameter shards concatenate to the single-rank parameters (bf16 summation-order noise only).  vp: the output head split by
+    vocabulary rows with the vocabulary-parallel loss (the reference's parallel_output=True, ops/linear.py:124-153 +
+    losses/ce_loss.py:26-36; default) or kept whole on both ranks."""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from internevo_amd.tensorpar import TensorParallel
@@ -453,13 +462,17 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     folder = str(tmp_path / "ck_tp2")
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853, q, folder)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853 if vp else 29857, q, folder, vp)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
     for p in procs:
         p.join(60)
+    from internevo_amd.metrics import AccPerplex
+
     eng = InternLM2Engine(_cfg(2), dev, init_fn=formula_init)
+    metric = AccPerplex(dev, None, None)
+    eng.attach_metric(metric)
     loader = iter(SyntheticLoader(128, 1, 2, False, 4000))
     ref = []
     for _ in range(3):
@@ -467,15 +480,23 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
         loss = eng.forward_backward(batch, labels)
         eng.step()
         ref.append((float(loss), float(eng.read_state().grad_norm)))
+    want_metric = metric.get_metric()
     (r0, o0, s0, c0, i0), (r1, o1, s1, c1, i1) = res
+    m0, m1 = o0.pop(), o1.pop()
+    replicated = ("embed", "norm") if vp else ("embed", "norm", "head")
+    unshard = lambda kind, parts: TensorParallel.unshard(kind, parts, vp)  # noqa: E731
+    # the metric of the three steps: identical on both tensor ranks, and the single-rank metric up to bf16 noise in the logits
+    assert m0 == m1, (m0, m1)
+    for key, w in want_metric.items():   # acc counts arg-max hits over 768 tokens: a near-tie flipped by bf16 noise moves it by 1.3e-3
+        assert abs(m0[key] - w) <= (5e-3 if key == "acc" else 2e-2 * abs(w)), (key, m0[key], w)
     # default init: the shards of a tensor group are different pieces of the full model a single rank draws from the same seed
     # (equal shards would receive equal gradients forever: half the heads and FFN units of the model would be duplicates)
     one_init = InternLM2Engine(_cfg(2), dev, seed=77)
     for n, p in one_init.p.items():
         kind = s0[n][0]
-        full = TensorParallel.unshard(kind, [torch.from_numpy(i0[n]), torch.from_numpy(i1[n])])
+        full = unshard(kind, [torch.from_numpy(i0[n]), torch.from_numpy(i1[n])])
         assert torch.equal(full, p.float().cpu()), f"default init of {n}: the tensor ranks' cuts do not concatenate to the single-rank tensor"
-        if kind not in ("embed", "norm", "head"):
+        if kind not in replicated:
             assert not (i0[n] == i1[n]).all(), f"default init of {n}: both tensor ranks hold the same shard"
     for k in range(3):
         print(f"step {k}: tp2 loss {o0[k][0]:.5f} gn {o0[k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
@@ -485,8 +506,8 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
     worst = 0.0
     for n, p in eng.p.items():
         kind = s0[n][0]
-        full = TensorParallel.unshard(kind, [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
-        if kind in ("embed", "norm", "head"):
+        full = unshard(kind, [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
+        if kind in replicated:
             assert (s0[n][1] == s1[n][1]).all(), f"replicated parameter {n} diverged between the ranks of the tensor group"
         worst = max(worst, float((full - p.float().cpu()).abs().max()))
     print("max |param diff| tp2 vs 1 rank:", worst)
@@ -503,7 +524,7 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
     one = InternLM2Engine(_cfg(2), dev)
     one.load_checkpoint(folder)
     for n, p in one.p.items():
-        full = TensorParallel.unshard(s0[n][0], [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
+        full = unshard(s0[n][0], [torch.from_numpy(s0[n][1]), torch.from_numpy(s1[n][1])])
         assert torch.equal(p.float().cpu(), full), n
     assert C.load_checkpoint(folder, _cfg(2).model)["tp_world"] == 2
     for _ in range(3):
@@ -512,3 +533,60 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend):
     loss = one.forward_backward(batch, labels)
     one.step()
     assert int(one.read_state().adam_step) == 4 and float(loss) < 6.5
+
+
+def _vp_ce_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        import internevo_amd.plugin as plugin
+
+        plugin.install(force=True)
+        from flash_attn.losses.cross_entropy import CrossEntropyLoss
+
+        g = torch.Generator().manual_seed(91)
+        rows, V = 96, 512
+        full = (3.0 * torch.randn(rows, V, generator=g)).to(torch.bfloat16)
+        labels = torch.randint(0, V, (rows,), generator=g)
+        labels[::7] = -100
+        up = torch.rand(rows, generator=g)
+        Vl = V // world
+        local = full[:, rank * Vl : (rank + 1) * Vl].contiguous().to(dev).requires_grad_(True)
+        loss_rows = CrossEntropyLoss(reduction="none", process_group=dist.group.WORLD)(local, labels.to(dev))
+        (loss_rows * up.to(dev)).sum().backward()
+        mean = CrossEntropyLoss(reduction="mean", inplace_backward=True, process_group=dist.group.WORLD)(local.detach().clone(), labels.to(dev))
+        q.put((rank, loss_rows.detach().float().cpu().numpy(), local.grad.float().cpu().numpy(), float(mean)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_vocab_parallel_cross_entropy_shim_matches_the_whole_vocabulary_loss(dev, backend):
+    """flash_attn.losses.cross_entropy.CrossEntropyLoss with a 2-rank process group (the loss of parallel_output=True configs,
+    losses/ce_loss.py:26-36): every rank feeds its half of the vocabulary columns; per-row losses, the mean and the gradient of each
+    half equal the oracle's cross entropy on the whole rows."""
+    from oracle import ops as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_vp_ce_worker, args=(r, 2, 29861, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    g = torch.Generator().manual_seed(91)
+    rows, V = 96, 512
+    full = (3.0 * torch.randn(rows, V, generator=g)).to(torch.bfloat16).float().requires_grad_(True)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::7] = -100
+    up = torch.rand(rows, generator=g)
+    want_rows = torch.nn.functional.cross_entropy(full, labels, reduction="none", ignore_index=-100)
+    (want_rows * up).sum().backward()
+    want_mean = float(O.cross_entropy(full.detach(), labels, 0.0))
+    grad = torch.cat([torch.from_numpy(r[2]) for r in res], dim=1)
+    for r in res:
+        assert torch.allclose(torch.from_numpy(r[1]), want_rows.detach(), rtol=1e-5, atol=1e-5), "per-row loss"
+        assert abs(r[3] - want_mean) <= 1e-5 * abs(want_mean)
+    assert torch.allclose(grad, full.grad, rtol=8e-3, atol=1e-4), float((grad - full.grad).abs().max())   # bf16 gradient rounding

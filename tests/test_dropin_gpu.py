@@ -141,7 +141,7 @@ def test_model_built_from_the_plugin_shims_matches_the_engine(dev, adapt_hf):
     loss_p = _dropin_loss(params, cfg.model, ids, lab, idx, cu, max_seqlen)
     (loss_p * scale).backward()
 
-    le, lp = float(loss_e), float(loss_p)
+    le, lp = float(loss_e), float(loss_p.detach())
     print(f"[drop-in] loss engine {le:.6f} plugin-composed {lp:.6f}")
     assert abs(le - lp) <= 1e-3 * abs(lp)
     worst = 0.0

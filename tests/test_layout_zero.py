@@ -272,14 +272,18 @@ def _tp_group_worker(rank, world, port, q):
         dist.all_reduce(d, group=tp.dp_group)
         ok = ok and float(d) == (4.0 if rank % 2 == 0 else 6.0) and (tp.tp_rank, tp.dp_rank, tp.dp_world) == (rank % 2, rank // 2, 2)
         full = {"wqkv": torch.arange(24.0).reshape(6, 4), "wo": torch.arange(16.0).reshape(4, 4), "w2": torch.arange(32.0).reshape(4, 8),
-                "norm": torch.arange(4.0), "embed": torch.arange(12.0).reshape(3, 4)}
+                "norm": torch.arange(4.0), "embed": torch.arange(12.0).reshape(3, 4), "head": torch.arange(40.0).reshape(10, 4)}
         for kind, w in full.items():
             mine = tp.shard(kind, w)
             parts = [TensorParallel(1, 0, 1).shard(kind, w)] if kind in ("norm", "embed") else None
-            other = type("O", (), {"tp": 2, "tp_rank": 1 - tp.tp_rank})()
+            other = type("O", (), {"tp": 2, "tp_rank": 1 - tp.tp_rank, "vocab_parallel": True})()
             theirs = TensorParallel.shard(other, kind, w)
             both = [mine, theirs] if tp.tp_rank == 0 else [theirs, mine]
             ok = ok and torch.equal(TensorParallel.unshard(kind, parts or both), w)
+            if kind == "head":   # vocabulary rows: 5 of the 10 per rank (and the whole head when the mode is off)
+                ok = ok and mine.shape == (5, 4) and TensorParallel(1, 0, 1).shard(kind, w).shape == (10, 4)
+                whole = type("O", (), {"tp": 2, "tp_rank": tp.tp_rank, "vocab_parallel": False})()
+                ok = ok and TensorParallel.shard(whole, kind, w).shape == (10, 4) and torch.equal(TensorParallel.unshard(kind, [w, w], False), w)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
