@@ -154,10 +154,15 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         mode = tensor.get("mode", "mtp")
         if mode == "isp":
             sp_size = int(tensor["size"])
-        elif mode == "mtp":
+        elif mode in ("mtp", "msp", "fsp"):
+            # msp / fsp (Megatron sequence parallelism, without / with overlap: model/ops/linear.py:338-441, utils.py:160-226) hold the
+            # SAME parameter shards and compute the same numbers as mtp; they shard the activations between the linears along the
+            # sequence (reduce-scatter after a row-parallel linear + all-gather in front of the next column-parallel one, the same
+            # bytes as mtp's all-reduce) to save activation memory and 1 - 1/tp of the norm work.  With 288 GB per GPU the engine keeps
+            # the activations whole and runs the mtp schedule for all three modes.
             tp_size = int(tensor["size"])
         else:
-            raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'isp')")
+            raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'msp', 'fsp', 'isp')")
         # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
     model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
     if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE"):

@@ -73,6 +73,11 @@ def test_reference_config_files_map(tmp_path):
     assert from_reference_dict(mtp).train.tp_size == 2 and from_reference_dict(mtp).train.sp_size == 1
     msp = copy.deepcopy(g)
     msp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="msp"), pipeline=dict(size=1))
+    # Megatron sequence parallelism: same parameter shards and numbers as mtp, run on the mtp schedule (config.py)
+    assert from_reference_dict(msp).train.tp_size == 2 and from_reference_dict(msp).train.sp_size == 1
+    msp["parallel"]["tensor"]["mode"] = "fsp"
+    assert from_reference_dict(msp).train.tp_size == 2
+    msp["parallel"]["tensor"]["mode"] = "ring"
     with pytest.raises(NotImplementedError):
         from_reference_dict(msp)
     # settings that would change the arithmetic are refused, not silently ignored
