@@ -234,6 +234,8 @@ int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_
  * pipelined across k-tiles (operands must each span < 4 GiB), 12 = 128x256 phased, 13 = 256x256 phased with two k-steps per phase and buffer-addressed DMA (operands < 4 GiB), 14 = 128x256 likewise,
  * 15 / 16 / 17 = 256x256 on four 32-deep LDS stages (k32 ring, counted vmcnt): 15 phased 8 waves, 16 one wave per SIMD, 17 = 16 with
  * the DMA pieces of an entry split over both k-steps (operands < 4 GiB);
+ * 18 = 11 with all DMA pieces issued two k-steps early, 19 = 256x256, one wave per SIMD, the whole k-tile's fragments in registers and the two
+ * 64-deep stages refilled operand by operand behind counted waits (operands < 4 GiB);
  * all LDS-DMA variants need K % 64 == 0; -1 = automatic (which can also cut a half-empty last round of 256x256 tiles off into a second launch
  * of 128x256 tiles, see ie_tune_gemm_tail_split). */
 int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb,

@@ -282,7 +282,14 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) 
         // round-2 same-box A/B at 16 384 tokens (profiles/r02_gemm_ring_ab.jsonl): dgrad +4 ... +11 % with the 8-wave phased ring (15),
         // wgrad +7 ... +10 % with the one-wave-per-SIMD ring (16), +2 ... +4 % more with its DMA pieces split over both k-steps (17).  The forward product (both operands k-contiguous) stays on 11: its
         // ring version reads 64-byte row segments instead of whole 128-byte lines and measured 1 ... 12 % slower.
-        if (d256 <= d128) return !any_kmajor ? 11 : (a_kmajor && b_kmajor) ? 17 : 15;
+        // Operand-wise refill (19: the whole k-tile's fragments in registers, the two 64-deep stages refilled operand by operand ~1.5
+        // tiles ahead behind counted waits, four barriers per tile): the forward product +3 ... +10 % over 11 on every 7B shape; dgrad
+        // level with the phased ring except on long / wide products (w1|w3 dgrad K = 28672: +8 %) -- profiles/r02_gemm_refill_ab.jsonl
+        if (d256 <= d128) {
+            if (!any_kmajor) return 19;
+            if (a_kmajor && b_kmajor) return 17;
+            return (!a_kmajor && (K >= 6144 || N >= 8192)) ? 19 : 15;
+        }
         return any_kmajor ? 5 : 8;    // 128x128: spreading helps the k-contiguous product only
     }
     const double c0 = shape_cost(M, N, 128, 128, 2, 1.00);
@@ -330,7 +337,7 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 18, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 19, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);

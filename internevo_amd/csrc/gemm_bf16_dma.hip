@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 
     constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23;
     const int nk = K / BK;
-    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -11;
+    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
     if constexpr (!RING) {
@@ -543,6 +543,105 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         }
         if (!lag) __builtin_amdgcn_s_barrier();
         __syncthreads();
+    } else if constexpr (SPREAD == -4) {
+        // ---- one wave per SIMD, OPERAND-WISE REFILL of the two 64-deep stages (the structure of hipBLASLt's 256x256x64 direct-to-LDS
+        // loop, read from its code object; 128-byte rows as in SPREAD -2, but the DMA of tile t+2 starts ~1.5 tiles before its use).
+        // A wave keeps the fragments of a WHOLE k-tile in registers (4 k-steps x (TM + TN) = 128 VGPRs; the accumulators sit in AGPRs),
+        // read half a tile ahead: B's second half first, then A's.  So early in tile t every wave holds all of B(t) (barrier 1) and
+        // then all of A(t) (barrier 2), and those LDS regions take B(t+2) / A(t+2) while tile t+1 lands in the other stage.  The
+        // landing waits are counted: barrier 3 needs this wave's pieces of B(t+1) (issued a tile ago; A(t+1) and the 10 pieces of
+        // tile t+2 issued so far stay in flight: vmcnt(18)), barrier 4 those of A(t+1) (vmcnt(15)).  Per tile: 64 MFMAs, 32 LDS reads,
+        // 16 DMA pieces, 4 barriers; one instruction per MFMA gap.
+        static_assert(G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8, "written for 4 waves x 128x128");
+        s16x8 af[4][G::TM], bfr[4][G::TN];
+        auto rdA = [&](const unsigned char* st, int ks, int i) {
+            af[ks][i] = A_KM ? frag_km<BM>(st, wm * G::WM + i * 32, ks, lane) : frag_kc(st, wm * G::WM + i * 32, ks, lane);
+        };
+        // The dgrad layout (A k-contiguous, B k-major) reads B with the untracked asm form (frag_km_nowait: no vmcnt(0) drain; the waits
+        // in front of barriers 1 and 2 cover the second half of a tile, the one at the end of a tile the first half of the next).
+        // With BOTH operands k-major the compiler parks fragments in scratch and would copy an asm result before it has arrived, so
+        // that layout keeps the tracked builtin (correct, drained; the dispatcher sends it to the k32 ring instead).
+        constexpr bool NOWAIT_B = B_KM && !A_KM;
+        auto rdB = [&](const unsigned char* st, int ks, int j) {
+            if constexpr (NOWAIT_B) bfr[ks][j] = frag_km_nowait<BN>(st + G::A_BYTES, wn * G::WN + j * 32, ks, lane);
+            else bfr[ks][j] = B_KM ? frag_km<BN>(st + G::A_BYTES, wn * G::WN + j * 32, ks, lane) : frag_kc(st + G::A_BYTES, wn * G::WN + j * 32, ks, lane);
+        };
+        if (nk > 1) {   // tile 1 into the second stage, B first (the order the counted waits assume)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) sb.issue_keep(q, smem + G::STAGE_BYTES + G::A_BYTES, wave);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) sa.issue_keep(q, smem + G::STAGE_BYTES, wave);
+            sa.advance_all();
+            sb.advance_all();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) rdA(smem, ks, i);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) rdB(smem, ks, j);
+        }
+        auto tile = [&](int t, auto fast_) {
+            constexpr bool FAST = decltype(fast_)::value;     // tiles t+1 and t+2 exist
+            const bool more1 = FAST || t + 1 < nk, more2 = FAST || t + 2 < nk;
+            unsigned char* cur = smem + (t & 1) * G::STAGE_BYTES;
+            const unsigned char* nxt = smem + ((t + 1) & 1) * G::STAGE_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                const int ks = m >> 4, i = (m >> 2) & 3, j = m & 3;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 8) {
+                    rdB(cur, 2 + (m >> 2), m & 3);                                   // B, k-steps 2 and 3
+                } else if (m == 8) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                    // 1: every wave holds all of B(t)
+                } else if (m < 14) {
+                    if (more2) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
+                } else if (m < 22) {
+                    rdA(cur, 2 + ((m - 14) >> 2), (m - 14) & 3);                     // A, k-steps 2 and 3
+                } else if (m == 22) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                    // 2: every wave holds all of A(t)
+                } else if (m < 26) {
+                    if (more2) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
+                } else if (m < 28) {
+                    if (more2) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
+                } else if (m == 28) {
+                    if (more1) {
+                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                // 3: B(t+1) complete
+                    }
+                } else if (m < 37) {
+                    if (more1) rdB(nxt, (m - 29) >> 2, (m - 29) & 3);                // B(t+1), k-steps 0 (registers free since MFMA 15) and 1 (since 31)
+                } else if (m < 42) {
+                    if (more2) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
+                } else if (m == 42) {
+                    if (more1) {
+                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                // 4: A(t+1) complete
+                    }
+                } else if (m < 51) {
+                    if (more1) rdA(nxt, (m - 43) >> 2, (m - 43) & 3);                // A(t+1), k-steps 0 and 1
+                } else if (m == 51) {
+                    if (more2) sa.issue_keep(7, cur, wave);                          // A(t+2) piece 7
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more2) {
+                sa.advance_all();
+                sb.advance_all();
+            }
+            if (NOWAIT_B) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        if (NOWAIT_B) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int t = 0;
+        for (; t + 2 < nk; ++t) tile(t, std::true_type{});
+        for (; t < nk; ++t) tile(t, std::false_type{});
+        __syncthreads();
     } else if constexpr (SPREAD == -2 || SPREAD == -3) {
         // ---- one wave per SIMD (4 waves, 128x128 per wave: 0.5 LDS reads per MFMA), software-pipelined ACROSS k-tiles.
         // The single barrier of a k-tile sits between k-step 2 and k-step 3: by then every wave has requested all four
@@ -783,6 +882,7 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 12) IE_SHAPE(256, 256, 2, 2, -22);
     else if (shape == 13) IE_SHAPE(256, 256, 2, 2, -23);
     else if (shape == 14) IE_SHAPE(256, 256, 2, 2, -3);
+    else if (shape == 15) IE_SHAPE(256, 256, 2, 2, -4);
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");

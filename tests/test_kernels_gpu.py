@@ -322,7 +322,7 @@ def test_gemm_small(dev, M, N, Kd, akm, bkm):
     close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"gemm {M}x{N}x{Kd} akm={akm} bkm={bkm}")
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_gemm_every_dma_tile_variant(dev, variant):
     """Each LDS-DMA schedule (ie_gemm_bf16_tile) on ragged M/N edges, a single k-tile, two and many k-tiles, all four operand
     layouts, a strided A view and accumulate -- the dispatcher only ever picks some of them for a given shape."""
