@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
                                                                   "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
     ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
+    ap.add_argument("--pp", type=int, default=1, help="pipeline-parallel size (non-interleaved 1F1B, parallel.pipeline=dict(size=pp)); "
+                    "N must be a multiple of it; data parallelism + ZeRO-1 run inside a stage")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Megatron 'mtp') group size, parallel.tensor=dict(size=tp, mode='mtp'); "
                                                        "must divide --gpus; data parallel size = gpus / tp")
     ap.add_argument("--zero", type=int, default=None, help="parallel.zero1.size: ranks that share one copy of the sharded optimizer state "
@@ -123,6 +125,7 @@ def main():
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
     cfg.train.sp_size = args.sp
     cfg.train.tp_size = args.tp
+    cfg.train.pp_size = args.pp
     cfg.model.checkpoint = args.checkpoint
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
@@ -174,7 +177,7 @@ def main():
         comm_info = {"backend": torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
     comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
 
-    tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp)
+    tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp * args.pp)
     sec_step = dt / args.steps
     total_tps = tokens_step / sec_step
     tgs = total_tps / world
@@ -203,7 +206,8 @@ def main():
                                else "tiny InternLM2 (hidden 512, 2 layers)",
                    "micro_batch_execution": ("merged: the micro_num micro-batches of a step run as one varlen pass" if eng.mm > 1 else
                                              "sequential gradient accumulation" + (", weight gradients batched over the micro-batches" if eng.batch_wgrad else "")),
-                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")},
+                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp * args.pp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")
+                   + (f" x pp{args.pp} (1F1B)" if args.pp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,
@@ -229,7 +233,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out["roofline"] = {
-            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd (4-wave buffer-DMA schedule) / dgrad / wgrad (8-wave phased schedule) of every linear layer)",
+            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd and long dgrads: one wave per SIMD, operand-wise refill of two 64-deep stages; other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
             "bound": "mfma",
             "achieved": ach / 1e12,
             "peak": MFMA_PEAK / 1e12,

@@ -122,6 +122,7 @@ class TrainConfig:
     zero1_size: int = -1
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
     tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
+    pp_size: int = 1                # parallel.pipeline = dict(size=pp): non-interleaved 1F1B pipeline parallelism (pipeline.py)
 
     @property
     def packed_length(self):
@@ -145,8 +146,9 @@ def _parse_dtype(s):
 def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     m, d = cfg["model"], cfg["data"]
     par = cfg.get("parallel", {})
-    if par.get("pipeline", {}).get("size", 1) != 1:
-        raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallel size must be 1")
+    pipe = par.get("pipeline", {})
+    pipe = pipe if isinstance(pipe, dict) else dict(size=pipe)
+    pp_size = int(pipe.get("size", 1))
     tensor = par.get("tensor", {})
     tensor = tensor if isinstance(tensor, dict) else dict(size=tensor, mode="mtp")  # launch.py normalises an int the same way
     sp_size = tp_size = 1
@@ -164,6 +166,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         else:
             raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'msp', 'fsp', 'isp')")
         # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
+    if pp_size > 1 and (sp_size > 1 or tp_size > 1):
+        raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallelism together with tensor / sequence parallelism")
     model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
     if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE"):
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")
@@ -239,7 +243,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size, tp_size=tp_size,
+        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size,
     )
     return PathConfig(model, train)
 

@@ -22,6 +22,7 @@ MI355X-first differences that do not change results beyond rounding order:
     (half the bytes of the reference's all-reduce + broadcast), launched per layer bucket as soon as
     the bucket's last weight-gradient GEMM is queued on the last micro-batch, overlapping backward.
 """
+import dataclasses
 import math
 
 import torch
@@ -32,6 +33,7 @@ from .config import PathConfig
 from .layout import FlatLayout
 from .schedule import Beta2Scheduler, CosineWarmupLR
 from .seqpar import SeqParallel
+from .pipeline import PipeParallel, partition_uniform
 from .tensorpar import TensorParallel
 from .zero import ZeroComm
 
@@ -41,14 +43,16 @@ BF16 = torch.bfloat16
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step).
         vocab_parallel (tensor parallelism only; default on): every tensor rank holds 1/tp of the head's vocabulary rows and the loss is
-        computed vocabulary-parallel (tensorpar.py); False = the whole head on every rank."""
+        computed vocabulary-parallel (tensorpar.py); False = the whole head on every rank.
+        pp_size (default: the config's parallel.pipeline.size): pipeline parallelism, non-interleaved 1F1B (pipeline.py): this rank
+        holds one contiguous range of layers (+ the embedding on the first stage, + norm / head / loss on the last)."""
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -61,6 +65,17 @@ class InternLM2Engine:
         sp_size = int(tc.sp_size if sp_size is None else sp_size)  # default: the config's parallel.tensor size (mode "isp")
         if tp_size > 1 and sp_size > 1:
             raise NotImplementedError("tensor parallelism and sequence parallelism are alternatives (parallel.tensor has ONE mode)")
+        pp_size = int(getattr(tc, "pp_size", 1) if pp_size is None else pp_size)
+        if pp_size > 1 and (tp_size > 1 or sp_size > 1 or mc.checkpoint_layers):
+            raise NotImplementedError("pipeline parallelism combines with data parallelism / ZeRO only (no tensor / sequence parallelism, "
+                                      "no activation checkpointing) in this round")
+        self.pp = pp_size
+        self.pipe = PipeParallel(pp_size, rank, world_size)
+        self.l0, l1 = partition_uniform(mc.num_layers, pp_size)[self.pipe.stage]   # this stage's layers [l0, l1) in the reference's numbering
+        if pp_size > 1:   # data parallelism and ZeRO-1 run inside a stage
+            process_group, world_size, rank = self.pipe.dp_group, self.pipe.dp_world, self.pipe.dp_rank
+            self.world, self.rank = world_size, rank
+            merge_micro, batch_wgrad = False, False   # the 1F1B schedule works on single micro-batches
         self.tpar = TensorParallel(tp_size, rank, world_size, vocab_parallel=True if vocab_parallel is None else vocab_parallel)
         self.tp = tp_size
         self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
@@ -68,6 +83,8 @@ class InternLM2Engine:
             raise NotImplementedError("label smoothing with the vocabulary-parallel head (its uniform term needs one more reduction): "
                                       "run with vocab_parallel=False")
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
+        if pp_size > 1:
+            self.lmc = dataclasses.replace(self.lmc, num_layers=l1 - self.l0)
         if tp_size > 1:
             # data parallelism and ZeRO-1 run over the ranks that hold the same shard
             process_group, world_size, rank = self.tpar.dp_group, self.tpar.dp_world, self.tpar.dp_rank
@@ -80,13 +97,15 @@ class InternLM2Engine:
         if world_size % zs:
             raise ValueError(f"parallel.zero1.size = {zs} must divide the data-parallel size {world_size}")
         self.world, self.rank = zs, rank % zs
-        self.layout = FlatLayout(self.lmc, zs)
+        self.layout = FlatLayout(self.lmc, zs, self.l0, self.pipe.first, self.pipe.last)
         L = self.layout
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs)
         self.sp = sp_size
         self.seqpar = SeqParallel(sp_size, rank, world_size)
         if tp_size > 1:  # every rank of a tensor group reads the same batches
             self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
+        if pp_size > 1:  # ... and so does every stage of a pipeline
+            self.seqpar.data_rank, self.seqpar.data_world = self.pipe.dp_rank, self.pipe.dp_world
         self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
         if sp_size > 1 and (mc.num_kv_attention_heads % sp_size or tc.packed_length % sp_size):
             raise ValueError("sequence parallel size must divide the kv head count and the packed length")
@@ -161,15 +180,17 @@ class InternLM2Engine:
         # of the same full model (the reference seeds TENSOR mode with seed + tp_rank for the same purpose,
         # parallel_context.py:639-641), and a tp = n run starts from exactly the weights of the tp = 1 run with the same seed.
         gen = torch.Generator(device=self.dev).manual_seed(seed)
-        for n, full in FlatLayout(mc, 1).params.items():
+        for n, full in FlatLayout(mc, 1).params.items():   # (a pipeline stage draws the whole sequence too and keeps its layers)
             if full.kind == "norm":
-                self.p[n].fill_(1.0)
+                if n in self.p:
+                    self.p[n].fill_(1.0)
                 continue
             std = mc.init_std
             if mc.use_scaled_init and full.kind in ("wo", "w2"):
                 std = mc.init_std / math.sqrt(2.0 * (full.layer + 1))
             w = torch.empty(full.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
-            self.p[n].copy_(self.tpar.shard(full.kind, w))
+            if n in self.p:
+                self.p[n].copy_(self.tpar.shard(full.kind, w))
 
     def sync_master_from_params(self):
         """fp32 master copy of this rank's shards (hybrid_zero_optim.py:214-233)."""
@@ -299,7 +320,7 @@ class InternLM2Engine:
 
     # ------------------------------------------------------------------------------------------ forward / backward
     def _w13(self, l):
-        s = self.layout.params[f"layers.{l}.feed_forward.w1.weight"]
+        s = self.layout.params[f"layers.{self.l0 + l}.feed_forward.w1.weight"]
         F, h = self.lmc.ffn_dim, self.lmc.hidden_size
         return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
 
@@ -313,7 +334,7 @@ class InternLM2Engine:
         F, eps = mc.ffn_dim, mc.layer_norm_epsilon
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, s = self.p, self.slot[l]
-        pre = f"layers.{l}."
+        pre = f"layers.{self.l0 + l}."   # (l counts this stage's layers; the names carry the reference's global layer numbers)
         if l == 0 or recompute:
             K.rmsnorm_fwd(self.a_x[l], p[pre + "attention_norm.weight"], eps, self.a_n1[s], self.a_rstd1[s])
         else:
@@ -343,16 +364,21 @@ class InternLM2Engine:
         return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
 
     def _forward_micro(self, ids, labels, cu, pos, max_seqlen, nseg=None):
-        mc = self.mc
+        mc = self.lmc   # (this stage's layer count under pipeline parallelism)
         L, eps = mc.num_layers, mc.layer_norm_epsilon
         p = self.p
         self._wait_bucket(0)              # bucket b's AdamW / all-gather of the previous step() may still be running on the optimizer stream
-        K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
+        if self.pipe.first:
+            K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
+        # (a later pipeline stage received its input -- the previous stage's output -- straight into a_x[0])
         ffn_out = None
         for l in range(L):
             self._wait_bucket(1 + l)
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
         self._wait_bucket(L + 1)
+        if not self.pipe.last:   # the stage's output = the residual stream after its last layer; norm, head and loss live on the last stage
+            torch.add(ffn_out, self.a_r2[self.slot[L - 1]], out=self.t_send)
+            return
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
         if self.mm > 1:
@@ -426,17 +452,6 @@ class InternLM2Engine:
         if first_micro:
             self._wait_optimizer()  # the previous step's AdamW reads the gradients this backward is about to overwrite
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
-        # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
-        # forward: a label owned by another rank is valid without a one-hot term here)
-        lab_b = self.t_lab_local if self.vp else labels
-        if self.mm > 1:
-            P = T // self.mm
-            for i in range(self.mm):
-                r = slice(i * P, (i + 1) * P)
-                K.ce_bwd(self.t_logits[r], lab_b[r], self.t_lse[r], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
-        else:
-            K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
-        dlog = self.t_logits
         bw = self.batch_wgrad
         r = self._mrows if bw else None
 
@@ -446,18 +461,33 @@ class InternLM2Engine:
             elif last_micro:  # every micro-batch's rows are in place: one GEMM over micro_num * T tokens
                 K.linear_wgrad(dy_all, x_all, gw, False)
 
-        K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
-        ar = self.tpar.all_reduce_sum_async(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
-        wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
-        if ar is not None:
-            ar.wait()
+        if self.pipe.last:
+            # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
+            # forward: a label owned by another rank is valid without a one-hot term here)
+            lab_b = self.t_lab_local if self.vp else labels
+            if self.mm > 1:
+                P = T // self.mm
+                for i in range(self.mm):
+                    rs = slice(i * P, (i + 1) * P)
+                    K.ce_bwd(self.t_logits[rs], lab_b[rs], self.t_lse[rs], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+            else:
+                K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+            dlog = self.t_logits
+
+            K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
+            ar = self.tpar.all_reduce_sum_async(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
+            wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
+            if ar is not None:
+                ar.wait()
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
-        K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
-        if last_micro:
-            self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
+        if self.pipe.last:
+            K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
+            if last_micro:
+                self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
+        # (an earlier pipeline stage received the gradient of its output from the next stage straight into t_h1 = d_out)
         spare = [self.t_h0, self.t_h2]
         for l in range(L - 1, -1, -1):
-            pre = f"layers.{l}."
+            pre = f"layers.{self.l0 + l}."
             w13, gw13 = self._w13(l)
             sl = self.slot[l]
             if l < mc.checkpoint_layers:
@@ -506,9 +536,12 @@ class InternLM2Engine:
             d_out = d_x
             if last_micro:
                 self.comm.reduce_bucket_async(self.grads, 1 + l)
+        if not self.pipe.first:
+            return d_out   # gradient of this stage's input: travels to the previous stage
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, 0)
+        return None
 
     def attach_metric(self, metric):
         """get_scheduler_hooks(metric, ...) of the reference (train/pipeline.py): the metric sees every micro-batch's logits."""
@@ -529,6 +562,8 @@ class InternLM2Engine:
         assert M == tc.micro_num and batch["input_ids"].shape[1] * self.mm == self.Tg
         if self.mm > 1:
             return self._forward_backward_merged(batch, labels)
+        if self.pp > 1:
+            return self._forward_backward_pipeline(batch, labels)
         lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T  # this rank's tokens of every micro-batch
         self.loss_acc.zero_()
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
@@ -549,6 +584,80 @@ class InternLM2Engine:
             self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
             self._backward_micro(ids_i, lab_i, cu, pos_i, max_seqlen, i == M - 1, i == 0)
         return self.loss_acc
+
+    # ---- pipeline parallelism: the 1F1B schedule of one stage (pipeline.py; pipeline_scheduler.py:430-560) ---------------------
+    _ACT_SETS = ("a_x", "a_n1", "a_rstd1", "a_q", "a_kv", "a_ctx", "a_lse", "a_r2", "a_n2", "a_rstd2", "a_w13")
+
+    def _alloc_inflight_sets(self):
+        """A stage keeps the saved activations of up to pp - stage micro-batches (forwarded, not yet backwarded): whole extra sets
+        of the per-layer activation lists, swapped in by _bind_inflight."""
+        n = min(self.pp - self.pipe.stage, self.tc.micro_num)
+        first = {name: getattr(self, name) for name in self._ACT_SETS}
+        self._sets = [first] + [{name: [torch.empty_like(t) for t in lst] for name, lst in first.items()} for _ in range(n - 1)]
+        h = self.lmc.hidden_size
+        self.t_send = torch.empty(self.T, h, dtype=BF16, device=self.dev)     # this stage's output on its way to the next stage
+
+    def _bind_inflight(self, i):
+        for name, lst in self._sets[i % len(self._sets)].items():
+            setattr(self, name, lst)
+        self.a_ctxl = self.a_ctx   # (no sequence parallelism under pipeline parallelism: the attention output is the wo input)
+
+    def _forward_backward_pipeline(self, batch, labels):
+        """One PipelineScheduler.forward_backward_step of this stage: warm-up forwards, one-forward-one-backward, cool-down backwards.
+        Between stages travel the [T, hidden] residual stream (forward, received straight into the first layer's input buffer) and its
+        gradient (backward, received straight into the buffer the layer backward reads); in the steady state a stage's send and the
+        matching receive are ONE paired exchange.  Returns the loss of the step (from the last stage) on every stage."""
+        tc, P = self.tc, self.pipe
+        M = tc.micro_num
+        if not hasattr(self, "_sets"):
+            self._alloc_inflight_sets()
+        self.loss_acc.zero_()
+        ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
+        lab_d = labels.to(self.dev, non_blocking=True)
+        pos_d = batch["indexes"].to(self.dev, non_blocking=True)
+        if self.metric is not None and self.metric.ntypes:
+            self.metric.set_current_type_ids(batch["type_ids"])
+
+        def args(i):
+            cu_h = batch["cu_seqlens"][i]
+            self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
+            return ids_d[i], lab_d[i], cu_h.to(self.dev, non_blocking=True), pos_d[i], int((cu_h[1:] - cu_h[:-1]).max())
+
+        def forward(i):
+            self._bind_inflight(i)
+            self._forward_micro(*args(i))
+            if P.last:
+                self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
+
+        def backward(i):
+            self._bind_inflight(i)
+            return self._backward_micro(*args(i), i == M - 1, i == 0)
+
+        def x_in(i):      # where micro-batch i's input of this stage is received
+            return self._sets[i % len(self._sets)]["a_x"][0]
+
+        warm = min(self.pp - P.stage - 1, M)
+        rem = M - warm
+        for i in range(warm):
+            P.exchange(recvs=[] if P.first else [(x_in(i), P.prev)])
+            forward(i)
+            P.exchange(sends=[(self.t_send, P.next)])          # (warm > 0 only on stages before the last)
+        if rem > 0:
+            P.exchange(recvs=[] if P.first else [(x_in(warm), P.prev)])
+        for i in range(rem):
+            forward(warm + i)
+            if not P.last:                                      # send_forward_recv_backward
+                P.exchange(sends=[(self.t_send, P.next)], recvs=[(self.t_h1, P.next)])
+            g_in = backward(i)
+            if i == rem - 1:
+                P.exchange(sends=[] if P.first else [(g_in, P.prev)])
+            else:                                               # send_backward_recv_forward
+                P.exchange(sends=[] if P.first else [(g_in, P.prev)], recvs=[] if P.first else [(x_in(warm + i + 1), P.prev)])
+        for i in range(rem, M):
+            P.exchange(recvs=[(self.t_h1, P.next)])
+            g_in = backward(i)
+            P.exchange(sends=[] if P.first else [(g_in, P.prev)])
+        return P.broadcast_from_last(self.loss_acc)
 
     def forward_only(self, input_ids, labels, metric=None):
         """One evaluation batch = NonPipelineScheduler.forward_backward_step(forward_only=True) as evaluate_on_val_dls drives it
@@ -627,7 +736,7 @@ class InternLM2Engine:
             shards.append(self.grads[s : s + n])
         if self.isp_rule > 1:
             self._apply_isp_grad_rule(shards)
-        K.sumsq(shards, self.sumsq, False, self.sumsq_ws)
+        K.sumsq([x for x in shards if x.numel()], self.sumsq, False, self.sumsq_ws)   # (empty: a bucket this pipeline stage does not own)
         if self.tp > 1:
             # compute_norm (solver/optimizer/utils.py:265-378) counts a parameter that is replicated over the tensor group (norm
             # weights; here also embedding and head) on ONE rank only: every rank of the group subtracts (1 - 1/tp) of its
@@ -640,6 +749,7 @@ class InternLM2Engine:
                 self.sumsq.sub_(torch.where(torch.isfinite(rs), rs * (1.0 - 1.0 / self.tp), torch.zeros_like(rs)))
         self.comm.all_reduce_sum(self.sumsq)
         self.tpar.all_reduce_sum(self.sumsq)
+        self.pipe.all_reduce_sum(self.sumsq)   # the norm (and the overflow decision) covers all stages of the pipeline (compute_norm: MODEL group)
         K.step_control(self.state, self.sumsq, self.scaler_cfg)
         lr = self.lr_sched.lr()
         beta2 = self.beta2_sched.beta2()
@@ -650,13 +760,15 @@ class InternLM2Engine:
             self.opt_stream.wait_event(ev)  # gradients, norm and step control are final
             for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
                 s, n = b.shard(self.rank, self.world)
+                if n == 0:   # a bucket this pipeline stage does not own
+                    continue
                 K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
                              self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
                 self.comm.gather_bucket_async(self.params, b.index)
                 done = torch.cuda.Event()
                 done.record(self.opt_stream)
                 self._bucket_ready[b.index] = done
-            self._opt_done = self._bucket_ready[L.buckets[-1].index]
+            self._opt_done = done
         # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter
         # exchange overlaps the next step's first layers; read_state()/named_parameters() drain them explicitly.
         # Engine.step steps the schedulers only after a successful update; success lives on the device, so the
@@ -829,6 +941,8 @@ class InternLM2Engine:
         return out
 
     def _checkpoint_guard(self):
+        if self.pp != 1:
+            raise NotImplementedError("checkpoints under pipeline parallelism are not implemented")
         if self.sp != 1:
             raise NotImplementedError("checkpoints cover pp = 1 without sequence parallelism in this round (any data-parallel and tensor-parallel size)")
 
@@ -929,6 +1043,7 @@ class InternLM2Engine:
         """named: the reference's FULL parameter tensors by name; under tensor parallelism every rank keeps its shard."""
         self.drain()
         for n, t in self._from_reference_names(named).items():
-            self.p[n].copy_(self.tpar.shard(self.layout.params[n].kind, t).to(self.dev, BF16))
+            if n in self.p:   # (a pipeline stage keeps its own layers)
+                self.p[n].copy_(self.tpar.shard(self.layout.params[n].kind, t).to(self.dev, BF16))
         if sync_master:
             self.sync_master_from_params()

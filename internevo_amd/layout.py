@@ -53,9 +53,14 @@ def _round_up(x, m):
 
 
 class FlatLayout:
-    def __init__(self, model_cfg, world_size=1):
+    def __init__(self, model_cfg, world_size=1, layer_lo=0, first=True, last=True):
+        """layer_lo / first / last: the layout of ONE pipeline stage -- model_cfg.num_layers layers numbered layer_lo ... in the
+        parameter names (the reference's global layer numbers), the embedding bucket only on the first stage and the norm + head bucket
+        only on the last one.  The bucket list keeps its shape on every stage (index 0 = embedding, 1 + i = local layer i, last =
+        norm + head): a bucket a stage does not own is EMPTY (size 0)."""
         self.cfg = model_cfg
         self.world = world_size
+        self.layer_lo, self.first, self.last = layer_lo, first, last
         c = model_cfg
         h, f, v = c.hidden_size, c.ffn_dim, c.vocab_size
         self.params: Dict[str, ParamSpec] = {}
@@ -80,9 +85,10 @@ class FlatLayout:
             off = cur["start"] + size
 
         cur = open_bucket()
-        add(cur, "tok_embeddings.weight", (v, h), "embed")
+        if first:
+            add(cur, "tok_embeddings.weight", (v, h), "embed")
         close_bucket(cur)
-        for l in range(c.num_layers):
+        for l in range(layer_lo, layer_lo + c.num_layers):
             cur = open_bucket()
             p = f"layers.{l}."
             add(cur, p + "attention_norm.weight", (h,), "norm", l)
@@ -94,8 +100,9 @@ class FlatLayout:
             add(cur, p + "feed_forward.w2.weight", (h, f), "w2", l)
             close_bucket(cur)
         cur = open_bucket()
-        add(cur, "norm.weight", (h,), "norm")
-        add(cur, "output.weight", (c.head_vocab, h), "head")   # all vocabulary rows, or this tensor rank's 1/tp of them
+        if last:
+            add(cur, "norm.weight", (h,), "norm")
+            add(cur, "output.weight", (c.head_vocab, h), "head")   # all vocabulary rows, or this tensor rank's 1/tp of them
         close_bucket(cur)
         self.total = off
 

@@ -83,7 +83,7 @@ class ZeroComm:
 
     # ---- gradients: bucket -> averaged shard on its owner ----------------------------------------
     def reduce_bucket_async(self, grads_flat, bucket_index):
-        if not self.active:
+        if not self.active or self.layout.buckets[bucket_index].size == 0:   # (size 0: a bucket this pipeline stage does not own)
             return
         b = self.layout.buckets[bucket_index]
         full = grads_flat[b.start : b.start + b.size]
@@ -115,7 +115,7 @@ class ZeroComm:
 
     # ---- parameters: updated shard -> every rank ---------------------------------------------------
     def gather_bucket_async(self, params_flat, bucket_index):
-        if not self.active:
+        if not self.active or self.layout.buckets[bucket_index].size == 0:
             return
         b = self.layout.buckets[bucket_index]
         full = params_flat[b.start : b.start + b.size]

@@ -590,3 +590,88 @@ def test_vocab_parallel_cross_entropy_shim_matches_the_whole_vocabulary_loss(dev
         assert torch.allclose(torch.from_numpy(r[1]), want_rows.detach(), rtol=1e-5, atol=1e-5), "per-row loss"
         assert abs(r[3] - want_mean) <= 1e-5 * abs(want_mean)
     assert torch.allclose(grad, full.grad, rtol=8e-3, atol=1e-4), float((grad - full.grad).abs().max())   # bf16 gradient rounding
+
+
+def _pp_cfg(layers, micro_num):
+    from internevo_amd.config import tiny
+
+    return tiny(hidden=256, layers=layers, heads=4, kv_heads=2, vocab=512, seq_len=128, micro_num=micro_num, lr=1e-3, total_steps=6)
+
+
+def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        eng = InternLM2Engine(_pp_cfg(layers, micro_num), dev, None, world, rank, init_fn=formula_init, pp_size=pp)
+        loader = iter(SyntheticLoader(128, 1, micro_num, fixed, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        q.put((rank, eng.pipe.stage, eng.pipe.dp_rank, out, {n: p.float().cpu().numpy() for n, p in eng.named_parameters()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("pp,dp,layers,micro_num", [(2, 1, 3, 4), (2, 1, 2, 1), pytest.param(4, 1, 5, 6, marks=pytest.mark.ranks(4)),
+                                                     pytest.param(2, 2, 2, 2, marks=pytest.mark.ranks(4))],
+                         ids=["pp2_3layers_4micro", "pp2_2layers_1micro", "pp4_5layers_6micro", "pp2_dp2"])
+def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, layers, micro_num):
+    """Non-interleaved 1F1B pipeline parallelism (parallel.pipeline = dict(size=pp); pipeline_scheduler.py:111-709) vs ONE rank on the
+    same micro-batches: same loss on every stage, same global grad norm, and the stages' parameters together are the single-rank
+    parameters after three optimizer steps.  3 layers over 2 stages / 5 over 4 = the uneven splits of partition_uniform (the last
+    stages take the extra layers); 4 and 6 micro-batches exercise warm-up, steady state and cool-down, 1 micro-batch the degenerate
+    schedule; pp2_dp2 = two pipelines of two stages with ZeRO-1 inside each stage (the single rank then runs the union of both
+    pipelines' micro-batches)."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    world = pp * dp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    fixed = dp > 1   # (the sampler interleaves data-parallel ranks: with fixed-length samples 1 rank x (dp * M) micro-batches is the same set)
+    procs = [ctx.Process(target=_pp_worker, args=(r, world, 29871 + micro_num + 10 * pp, q, pp, layers, micro_num, fixed)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_pp_cfg(layers, micro_num * dp), dev, init_fn=formula_init, merge_micro=False, batch_wgrad=False)
+    loader = iter(SyntheticLoader(128, 1, micro_num * dp, fixed, 4000))
+    ref = []
+    for _ in range(3):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm)))
+    for k in range(3):
+        print(f"step {k}: " + " | ".join(f"stage {r[1]} loss {r[3][k][0]:.5f} gn {r[3][k][1]:.4f}" for r in res) + f" | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        mean_loss = sum(r[3][k][0] for r in res) / len(res)   # (data parallelism: every pipeline has its own micro-batches)
+        assert abs(mean_loss - ref[k][0]) <= (1e-3 if dp == 1 else 2e-3) * abs(ref[k][0])
+        for r in res:
+            mine = [x for x in res if x[2] == r[2]]
+            assert all(x[3][k][0] == r[3][k][0] for x in mine), "every stage of a pipeline reports its last stage's loss"
+            assert abs(r[3][k][1] - res[0][3][k][1]) <= 1e-6 * r[3][k][1], "every rank reports the same global grad norm"
+            assert abs(r[3][k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    seen, worst = set(), 0.0
+    want = {n: p.float().cpu() for n, p in eng.named_parameters()}
+    for r in res:
+        assert ("tok_embeddings.weight" in r[4]) == (r[1] == 0) and ("output.weight" in r[4]) == (r[1] == pp - 1)
+        if r[2] != 0:
+            continue   # (the data-parallel replicas of a stage hold the same parameters)
+        for n, a in r[4].items():
+            assert n not in seen, f"{n} is held by two stages"
+            seen.add(n)
+            worst = max(worst, float((torch.from_numpy(a) - want[n]).abs().max()))
+    assert seen == set(want), "the stages together hold every parameter exactly once"
+    print("max |param diff| pipeline vs 1 rank:", worst)
+    assert worst <= 6e-3

@@ -55,10 +55,6 @@ def test_reference_config_files_map(tmp_path):
     )
     cfg = load_reference_config(str(p), seq_len=4096)
     assert cfg.model.ffn_dim == 14336 and cfg.model.qkv_dim == 6144 and cfg.train.seq_len == 4096 and cfg.train.clip_grad_norm == 1.0
-    bad = dict(model=dict(vocab_size=8, hidden_size=8, num_layers=1, num_attention_heads=1), data=dict(seq_len=8, micro_bsz=1, micro_num=1, total_steps=1),
-               parallel=dict(pipeline=dict(size=2)))
-    with pytest.raises(NotImplementedError):
-        from_reference_dict(bad)
     # configs/7B_isp_sft.py: tensor=dict(size=2, mode="isp"), weight=dict(size=4, overlap=True, memory_pool=True)
     import copy
     import runpy
@@ -73,6 +69,16 @@ def test_reference_config_files_map(tmp_path):
     assert from_reference_dict(mtp).train.tp_size == 2 and from_reference_dict(mtp).train.sp_size == 1
     msp = copy.deepcopy(g)
     msp["parallel"] = dict(zero1=dict(size=8), tensor=dict(size=2, mode="msp"), pipeline=dict(size=1))
+    pp = copy.deepcopy(g)
+    pp["parallel"] = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=4))
+    assert from_reference_dict(pp).train.pp_size == 4                       # non-interleaved 1F1B (pipeline.py)
+    pp["parallel"]["tensor"] = dict(size=2, mode="mtp")                     # ... but not together with tensor parallelism
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(pp)
+    pp["parallel"]["tensor"] = 1
+    pp["model"]["num_chunks"] = 2                                           # ... and not interleaved
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(pp)
     # Megatron sequence parallelism: same parameter shards and numbers as mtp, run on the mtp schedule (config.py)
     assert from_reference_dict(msp).train.tp_size == 2 and from_reference_dict(msp).train.sp_size == 1
     msp["parallel"]["tensor"]["mode"] = "fsp"
@@ -305,3 +311,37 @@ def test_tensor_parallel_groups_and_shards_gloo_world4():
     for p in procs:
         p.join(30)
     assert res == [(0, True), (1, True), (2, True), (3, True)], res
+
+
+def test_pipeline_partition_and_schedule():
+    """partition_uniform (solver/pipeline_utils.py:9-34, num_chunks = 1): L // pp layers per stage, the LAST L % pp stages one more;
+    the 1F1B order of a stage (pipeline_scheduler.py:430-560): pp - stage - 1 warm-up forwards, one-forward-one-backward, cool-down;
+    the layout of a stage holds its layers under their global numbers, the embedding on the first and norm + head on the last stage."""
+    from internevo_amd.config import tiny
+    from internevo_amd.layout import FlatLayout
+    from internevo_amd.pipeline import partition_uniform, schedule_1f1b
+
+    assert partition_uniform(32, 4) == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    assert partition_uniform(10, 4) == [(0, 2), (2, 4), (4, 7), (7, 10)]
+    with pytest.raises(ValueError):
+        partition_uniform(2, 4)
+    assert schedule_1f1b(0, 2, 3) == [("F", 0), ("F", 1), ("B", 0), ("F", 2), ("B", 1), ("B", 2)]
+    assert schedule_1f1b(1, 2, 3) == [("F", 0), ("B", 0), ("F", 1), ("B", 1), ("F", 2), ("B", 2)]
+    assert schedule_1f1b(0, 4, 2) == [("F", 0), ("F", 1), ("B", 0), ("B", 1)]
+    for s in range(4):   # every micro-batch forwarded before it is backwarded, never more than pp - stage in flight
+        inflight = worst = 0
+        for kind, _ in schedule_1f1b(s, 4, 8):
+            inflight += 1 if kind == "F" else -1
+            worst = max(worst, inflight)
+        assert inflight == 0 and worst == 4 - s
+    import dataclasses
+
+    mc = tiny(64, 5, 4, 2, 128, 32, 2).model
+    full = FlatLayout(mc, 1)
+    names = []
+    for st, (lo, hi) in enumerate(partition_uniform(5, 2)):
+        L = FlatLayout(dataclasses.replace(mc, num_layers=hi - lo), 2, lo, st == 0, st == 1)
+        assert len(L.buckets) == (hi - lo) + 2 and (L.buckets[0].size == 0) == (st != 0) and (L.buckets[-1].size == 0) == (st != 1)
+        assert all(L.params[n].shape == full.params[n].shape for n in L.params)
+        names += list(L.params)
+    assert names == list(full.params)
