@@ -241,6 +241,12 @@ int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_
 int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb,
                       int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
                       void* stream);
+/* `batch` equal products in ONE launch, operands `stride_*` ELEMENTS apart (multiples of 8): the E experts of a GShard MoE layer --
+ * expert e's [C, M] rows of the dispatch buffer x its [2F, M] weights (internlm/model/moe/experts.py: one module call per expert) --
+ * fill the chip together instead of one half-empty round each. */
+int ie_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, int a_kmajor, const void* B, int64_t ldb,
+                         int64_t stride_b, int b_kmajor, void* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N,
+                         int64_t K, int batch, int accumulate, void* stream);
 /* column sums of a [rows, cols] bf16 matrix (bias gradient of linear_bias_wgrad, has_bias=True) */
 int ie_colsum_bf16(const void* x, int64_t ld, void* out, int64_t rows, int64_t cols, void* stream);
 

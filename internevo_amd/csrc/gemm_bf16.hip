@@ -25,7 +25,7 @@
 #include "ie_common.h"
 
 extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
-                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream);
+                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt);
 
 namespace {
 
@@ -236,6 +236,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_k(const bf16
     }
 }
 
+// Column sums of a [rows, cols] bf16 matrix (bias gradient).  HBM-bound: 2 * rows * cols bytes.  A block owns 256 columns (32 lanes x 8
+// columns, 16-byte loads) and splits the rows over its 8 row-lanes, 4 rows in flight per lane; the 8 partial sums of a column meet in
+// LDS in a fixed order (deterministic, no atomics).  (The first version -- one thread per column walking the rows one dependent load
+// at a time -- took 1.04 ms for the [4096, 12288] Wqkv bias gradient, 23 % of the INTERNLM_MoE step; profiles/r02_moe_kernel_stats.md.)
+__global__ __launch_bounds__(256) void colsum_bf16_vec_k(const bf16_t* __restrict__ x, int64_t ld, bf16_t* __restrict__ out, int64_t rows,
+                                                         int64_t cols) {
+    __shared__ float part[8][256 + 8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * 256 + cx * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+        int64_t r = ry;
+        for (; r + 24 < rows; r += 32) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) unpack8(ld16(x + (r + 8 * u) * ld + c0), v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[u][e];
+        }
+        for (; r < rows; r += 8) {
+            float v[8];
+            unpack8(ld16(x + r * ld + c0), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[ry][cx * 8 + e] = acc[e];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += part[q][threadIdx.x];
+        out[c] = f2bf(s);
+    }
+}
+
+// any cols / alignment: one thread per column
 __global__ __launch_bounds__(256) void colsum_bf16_k(const bf16_t* __restrict__ x, int64_t ld, bf16_t* __restrict__ out, int64_t rows,
                                                      int64_t cols) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -261,19 +302,19 @@ void launch_shape(int a_km, int b_km, hipStream_t st, const bf16_t* A, int64_t l
 
 // CU-rounds a tile shape needs on 256 CUs (blocks_per_cu co-resident), weighted by a per-shape efficiency
 // prior (bigger tiles do more MFMA work per staged byte).  Smaller is better.
-inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu, double eff) {
-    const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu, double eff, int batch = 1) {
+    const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
     const int64_t slots = 256 * blocks_per_cu;
     const int64_t rounds = (tiles + slots - 1) / slots;
     return (double)rounds * slots * bm * bn / eff;  // ~ time: rounds x work per round / efficiency
 }
 
-int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {
+int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, int batch = 1) {
     const bool any_kmajor = a_kmajor || b_kmajor;
     // priors from the round-1 micro-benchmarks (profiles/r01_gemm_tile_tuning.json): relative MFMA efficiency per tile shape
     if (K > 0 && K % 64 == 0 && M >= 8 && N >= 8) {  // LDS-DMA kernels: 256x256 unless wave quantisation on 256 CUs favours 128x128
-        const double d256 = shape_cost(M, N, 256, 256, 1, 1.36);  // measured: variants 11 / 13 vs the 128x128 kernels on 1.5-round shapes (wqkv)
-        const double d128 = shape_cost(M, N, 128, 128, 2, 1.00);
+        const double d256 = shape_cost(M, N, 256, 256, 1, 1.36, batch);  // measured: variants 11 / 13 vs the 128x128 kernels on 1.5-round shapes (wqkv)
+        const double d128 = shape_cost(M, N, 128, 128, 2, 1.00, batch);
         // 256x256: k-contiguous operands -> one wave per SIMD (128x128 per wave), buffer-addressed DMA, fragments pipelined
         // across k-tiles; a k-major operand (two transposing reads per fragment) -> 8 waves, role-split load/compute phases of
         // two k-steps each, buffer-addressed DMA (+12 % dgrad, +7 % wgrad over one k-step per phase, profiles/)
@@ -328,7 +369,9 @@ inline TailSplit tail_split(int64_t M, int64_t N) {
 }
 
 int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
-                  int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+                  int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt = IeGemmBatch{1, 0, 0, 0}) {
+    IE_CHECK_ARG(bt.count >= 1 && bt.count <= 4096, "ie_gemm_bf16_batched: batch count out of range");
+    IE_CHECK_SUPPORTED(bt.count == 1 || (bt.sa % 8 == 0 && bt.sb % 8 == 0 && bt.sc % 8 == 0), "ie_gemm_bf16_batched: strides must be multiples of 8 elements");
     IE_CHECK_ARG(A && B && C, "ie_gemm_bf16: null pointer");
     IE_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "ie_gemm_bf16: negative size");
     IE_CHECK_ARG(M < (1ll << 30) && N < (1ll << 30) && K < (1ll << 30), "ie_gemm_bf16: size too large");
@@ -342,9 +385,9 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
     if (variant < 0) {
-        variant = pick_variant(M, N, K, a_kmajor != 0, b_kmajor != 0);
+        variant = pick_variant(M, N, K, a_kmajor != 0, b_kmajor != 0, bt.count);
         if ((variant == 11 || variant == 13 || variant >= 15) && !fits32) variant = 9;
-        const TailSplit ts = (g_tail_split && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
+        const TailSplit ts = (g_tail_split && bt.count == 1 && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
             const int tail_variant = g_tail_split == 2 ? 14 : g_tail_split == 3 ? 12 : ((a_kmajor || b_kmajor) ? 14 : 12);
             const char* a = (const char*)A;
@@ -365,7 +408,15 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
     IE_CHECK_SUPPORTED((variant != 11 && variant < 13) || fits32, "ie_gemm_bf16: tile variants 11 and 13..17 need operands smaller than 4 GiB");
     if (variant >= 4) {  // LDS-DMA kernels (gemm_bf16_dma.hip): need whole 64-wide k-tiles and >= 8 valid rows/cols to clamp to
         IE_CHECK_SUPPORTED(K > 0 && K % 64 == 0 && M >= 8 && N >= 8, "ie_gemm_bf16: the LDS-DMA variants need K % 64 == 0");
-        return ie_gemm_dma_launch(variant - 4, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
+        return ie_gemm_dma_launch(variant - 4, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream, bt);
+    }
+    if (bt.count > 1) {   // the register-staged kernels (ragged K) take one product per launch
+        for (int z = 0; z < bt.count; ++z) {
+            const int rc = gemm_dispatch(variant, (const bf16_t*)A + z * bt.sa, lda, a_kmajor, (const bf16_t*)B + z * bt.sb, ldb, b_kmajor,
+                                         (bf16_t*)C + z * bt.sc, ldc, M, N, K, accumulate, stream);
+            if (rc != IE_OK) return rc;
+        }
+        return IE_OK;
     }
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* a = (const bf16_t*)A;
@@ -392,6 +443,13 @@ extern "C" int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_
     return gemm_dispatch(variant, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
 }
 
+extern "C" int ie_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a, int a_kmajor, const void* B, int64_t ldb, int64_t stride_b,
+                                    int b_kmajor, void* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K, int batch, int accumulate,
+                                    void* stream) {
+    IE_CHECK_ARG(batch >= 1, "ie_gemm_bf16_batched: batch must be >= 1");
+    return gemm_dispatch(-1, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream, IeGemmBatch{batch, stride_a, stride_b, stride_c});
+}
+
 extern "C" int ie_tune_gemm_tail_split(int mode) {
     if (mode < 0 || mode > 3) return IE_ERR_INVALID;
     g_tail_split = mode;
@@ -401,7 +459,12 @@ extern "C" int ie_tune_gemm_tail_split(int mode) {
 extern "C" int ie_colsum_bf16(const void* x, int64_t ld, void* out, int64_t rows, int64_t cols, void* stream) {
     IE_CHECK_ARG(x && out && rows >= 0 && cols >= 0 && ld >= cols, "ie_colsum_bf16: bad argument");
     if (cols == 0) return IE_OK;
-    hipLaunchKernelGGL(colsum_bf16_k, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
-                       (bf16_t*)out, rows, cols);
+    const bool vec = cols % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15u) == 0;
+    if (vec)
+        hipLaunchKernelGGL(colsum_bf16_vec_k, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
+                           (bf16_t*)out, rows, cols);
+    else
+        hipLaunchKernelGGL(colsum_bf16_k, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
+                           (bf16_t*)out, rows, cols);
     return ie_launch_status("ie_colsum_bf16 launch");
 }

@@ -252,19 +252,26 @@ __device__ __forceinline__ s16x8 frag_km_nowait(const unsigned char* tile, int m
 // interleaved one by one with the MFMAs of the first n k-steps (a DMA issue costs ~60-180 cycles of issue time during
 // which this wave cannot feed the matrix pipe; spreading them lets the previous MFMAs cover that time).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int SPREAD>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
-                                                                     int64_t ldb, bf16_t* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                                     int accumulate, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_t* __restrict__ A0, int64_t lda, const bf16_t* __restrict__ B0,
+                                                                     int64_t ldb, bf16_t* __restrict__ C0, int64_t ldc, int M, int N, int K,
+                                                                     int accumulate, int tiles_m, int tiles_n, IeGemmBatch bt) {
     using G = DCfg<BM, BN, WAVES_M, WAVES_N>;
     constexpr int NT = G::NT, NW = G::NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM_BYTES];
 
-    const int nblk = tiles_m * tiles_n;
+    // strided batch (the experts of a MoE layer): ONE launch covers bt.count equal products; the XCD-contiguous tile numbering runs over
+    // the whole batch, so an XCD works through one product's tiles before the next and small products fill the chip together
+    const int nblk1 = tiles_m * tiles_n, nblk = nblk1 * bt.count;
     int id;
     {
         const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    const int bz = id / nblk1;
+    id -= bz * nblk1;
+    const bf16_t* __restrict__ A = A0 + bz * bt.sa;
+    const bf16_t* __restrict__ B = B0 + bz * bt.sb;
+    bf16_t* __restrict__ C = C0 + bz * bt.sc;
     const int GM = (accumulate >> 8) ? (accumulate >> 8) : 4;  // tile rows per group (bits 8.. of the flag word: ie_tune_gemm_group)
     const int abl = (accumulate >> 4) & 15;                     // timing ablations (IE_GEMM_ABLATE, results are then wrong)
     accumulate &= 1;
@@ -849,7 +856,7 @@ extern "C" int ie_tune_gemm_group(int gm) {
 }
 
 extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
-                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
+                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt) {
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
@@ -859,13 +866,13 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
 #define IE_SHAPE(BM_, BN_, WM_, WN_, SP_)                                                                                            \
     do {                                                                                                                          \
         const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (int)((N + BN_ - 1) / BN_);                                       \
-        dim3 grid((unsigned)(tiles_m * tiles_n)), block(64 * WM_ * WN_);                                                           \
+        dim3 grid((unsigned)(tiles_m * tiles_n * bt.count)), block(64 * WM_ * WN_);                                                           \
         if (a_kmajor) {                                                                                                           \
-            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
-            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, true, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt); \
         } else {                                                                                                                  \
-            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
-            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n); \
+            if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, true, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt); \
+            else hipLaunchKernelGGL((gemm_dma_k<BM_, BN_, WM_, WN_, false, false, SP_>), grid, block, 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt); \
         }                                                                                                                         \
     } while (0)
     if (shape == 0) IE_SHAPE(256, 256, 2, 4, 0);

@@ -126,3 +126,9 @@ __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 __device__ __forceinline__ uint2 ld8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
 __device__ __forceinline__ void st8(void* p, const uint2& v) { *reinterpret_cast<uint2*>(p) = v; }
+
+// strided batch of equal GEMMs in one launch (element strides between consecutive products; count = 1: a single product)
+struct IeGemmBatch {
+    int count;
+    int64_t sa, sb, sc;
+};

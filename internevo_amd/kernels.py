@@ -420,6 +420,34 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
     return gemm(dy, x, True, True, out, accumulate)
 
 
+def gemm_batched(A, B, out, a_kmajor=False, b_kmajor=False, accumulate=False):
+    """out[z] (+)= op(A[z]) @ op(B[z]) for the leading batch dimension z of three 3-D bf16 tensors (unit inner stride, equal batch strides
+    per tensor): ONE launch for all products (the experts of a MoE layer)."""
+    if not (A.dim() == B.dim() == out.dim() == 3 and A.shape[0] == B.shape[0] == out.shape[0]):
+        raise ValueError("gemm_batched: three 3-D tensors with the same batch size expected")
+    if A.stride(2) != 1 or B.stride(2) != 1 or out.stride(2) != 1:
+        raise ValueError("gemm_batched: unit inner strides expected")
+    Z = A.shape[0]
+    K_, M = (A.shape[1], A.shape[2]) if a_kmajor else (A.shape[2], A.shape[1])
+    Kb, N = (B.shape[1], B.shape[2]) if b_kmajor else (B.shape[2], B.shape[1])
+    if K_ != Kb or out.shape[1:] != (M, N):
+        raise ValueError(f"gemm_batched: shapes {tuple(A.shape)} x {tuple(B.shape)} -> {tuple(out.shape)}")
+    if M == 0 or N == 0 or Z == 0:
+        return out
+    if K_ == 0:
+        if not accumulate:
+            out.zero_()
+        return out
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
+    check(_L().ie_gemm_bf16_batched(_p(A), A.stride(1), A.stride(0), int(a_kmajor), _p(B), B.stride(1), B.stride(0), int(b_kmajor), _p(out),
+                                    out.stride(1), out.stride(0), M, N, K_, Z, int(accumulate), _stream()), "ie_gemm_bf16_batched")
+    if prof is not None:
+        prof.end(2.0 * Z * M * N * K_, 2.0 * Z * (M * K_ + N * K_ + M * N))
+    return out
+
+
 def colsum(x, out=None):
     rows, cols, ld = _rows_ld(x)
     if out is None:

@@ -6,8 +6,9 @@ experts, weighted combine, auxiliary load-balancing loss.  MI355X-first differen
   * index form: a token's two choices are two row indices into [E * C, M] expert buffers; dispatch is a gather, combine a 2-term
     weighted sum -- the reference builds [S, E, C] one-hot tensors and runs O(S E C M) einsums over them;
   * no autograd: `forward` keeps what `backward` needs in pre-allocated buffers, `backward` is explicit;
-  * the experts of one layer run as per-expert GEMMs over contiguous row ranges of the same buffers (w1 | w3 fused into one
-    [2F, M] operand per expert, as the dense FFN of the engine).
+  * the experts of one layer run as ONE strided-batched GEMM per product over contiguous row ranges of the same buffers
+    (ie_gemm_bf16_batched; w1 | w3 fused into one [2F, M] operand per expert, as the dense FFN of the engine): four experts of
+    2048 rows each fill the 256 CUs together where four separate launches left half-empty rounds.
 Expert parallelism (`parallel.expert`, all_to_all of the expert buffers over xGMI, gshard_layer.py:453-474): `ep_group` splits the E
 experts over the ranks of the group; the [E, C, M] buffer is exchanged by ONE all_to_all_single each way (rank r keeps the C-row
 blocks of its E/ep experts from every rank), mirrored in backward.
@@ -89,13 +90,6 @@ class MoELayer:
             recv.view(-1).copy_(r)
         return recv
 
-    def _expert_blocks(self):
-        """(local expert j, row range in the local buffers) for every [C, M] block this rank's experts process."""
-        C = self.C
-        for g in range(self.ep):
-            for j in range(self.El):
-                yield j, slice((g * self.El + j) * C, (g * self.El + j + 1) * C)
-
     def forward(self, x, wg, w13, w2, out, noise=None):
         """x bf16 [S, M] -> out bf16 [S, M]; returns the device scalar l_aux (bf16-rounded fp32).  noise: fp32 [S, E] to inject."""
         S, E, C, M, F = self.S, self.E, self.C, self.M, self.F
@@ -112,10 +106,16 @@ class MoELayer:
         check(L.ie_moe_dispatch(K._p(x), x.stride(0), K._p(self.token_of), E * C, M, K._p(self.ein), st()), "ie_moe_dispatch")
         ein = self._a2a(self.ein, self.xin) if self.ep > 1 else self.ein
         eo = self.xout if self.ep > 1 else self.eo
-        for j, r in self._expert_blocks():
-            K.linear_fwd(ein[r], w13[j], self.h13[r])
-            K.swiglu_fwd(self.h13[r][:, :F], self.h13[r][:, F:], self.act[r])
-            K.linear_fwd(self.act[r], w2[j], eo[r])
+        # the El local experts run as ONE strided-batched GEMM per product (and per source rank under expert parallelism): expert j's
+        # [C, M] block x its own weights; the SwiGLU gate covers all rows at once
+        El, ep = self.El, self.ep
+        for g in range(ep):
+            rows = slice(g * El * C, (g + 1) * El * C)
+            K.gemm_batched(ein[rows].view(El, C, M), w13, self.h13[rows].view(El, C, 2 * F))
+        K.swiglu_fwd(self.h13[:, :F], self.h13[:, F:], self.act)
+        for g in range(ep):
+            rows = slice(g * El * C, (g + 1) * El * C)
+            K.gemm_batched(self.act[rows].view(El, C, F), w2, eo[rows].view(El, C, M))
         if self.ep > 1:
             self._a2a(self.xout, self.eo)
         check(L.ie_moe_combine_fwd(K._p(self.eo), K._p(self.row), K._p(self.weight), S, M, K._p(out), out.stride(0), st()), "ie_moe_combine_fwd")
@@ -131,15 +131,17 @@ class MoELayer:
         d_eo = self._a2a(self.d_eo, self.d_xout) if self.ep > 1 else self.d_eo
         ein = self.xin if self.ep > 1 else self.ein
         d_ein = self.d_xin if self.ep > 1 else self.d_ein
-        first_of = {}
-        for j, r in self._expert_blocks():
-            acc = accumulate or j in first_of      # the blocks of one expert coming from different source ranks add up
-            first_of[j] = True
-            K.linear_dgrad(d_eo[r], w2[j], self.d_act[r])
-            K.linear_wgrad(d_eo[r], self.act[r], d_w2[j], acc)
-            K.swiglu_bwd(self.d_act[r], self.h13[r][:, :F], self.h13[r][:, F:], self.d_h13[r][:, :F], self.d_h13[r][:, F:])
-            K.linear_dgrad(self.d_h13[r], w13[j], d_ein[r])
-            K.linear_wgrad(self.d_h13[r], ein[r], d_w13[j], acc)
+        El, ep = self.El, self.ep
+        blocks = [slice(g * El * C, (g + 1) * El * C) for g in range(ep)]
+        for rows in blocks:      # dgrad of w2: d_act[e] = d_eo[e] @ w2[e]
+            K.gemm_batched(d_eo[rows].view(El, C, M), w2, self.d_act[rows].view(El, C, F), b_kmajor=True)
+        for g, rows in enumerate(blocks):   # the blocks of one expert coming from different source ranks add up
+            K.gemm_batched(d_eo[rows].view(El, C, M), self.act[rows].view(El, C, F), d_w2, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
+        K.swiglu_bwd(self.d_act, self.h13[:, :F], self.h13[:, F:], self.d_h13[:, :F], self.d_h13[:, F:])
+        for rows in blocks:
+            K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), w13, d_ein[rows].view(El, C, M), b_kmajor=True)
+        for g, rows in enumerate(blocks):
+            K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), ein[rows].view(El, C, M), d_w13, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
         if self.ep > 1:
             self._a2a(self.d_xin, self.d_ein)
         check(L.ie_moe_dispatch_bwd(K._p(self.d_ein), K._p(self.row), K._p(self.token_of), S, M, K._p(dx), dx.stride(0), st()), "ie_moe_dispatch_bwd")

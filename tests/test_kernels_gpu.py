@@ -613,3 +613,35 @@ def test_flash_attention_seq32768_properties(dev):
     close(dk[:P], dk_p.cpu(), 1e-2, 1e-2, "dK prefix (the head split of the long problem may differ: fp32 partial order)")
     close(dv[:P], dv_p.cpu(), 1e-2, 1e-2, "dV prefix")
     assert float(dk[P:].float().abs().max()) == 0.0 and float(dv[P:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cols,view", [(4096, 1536, False), (37, 256, False), (5, 8, False), (130, 24, True), (64, 100, False), (1, 264, False)])
+def test_colsum_bias_gradient(dev, rows, cols, view):
+    """ie_colsum_bf16 (the bias gradient of linear_bias_wgrad / the InternLM-1 block's biases): the 16-byte row-split kernel (cols % 8 == 0)
+    and the scalar fallback (cols = 100), ragged row counts, a strided column view."""
+    x = bf(torch.randn(rows, cols + (16 if view else 0), generator=g(71)))
+    xd = x.to(dev)
+    xs = xd[:, 8 : 8 + cols] if view else xd
+    ref = (x[:, 8 : 8 + cols] if view else x).float().sum(0)
+    close(K().colsum(xs), ref, 8e-3, 2e-3 * math.sqrt(rows), f"colsum {rows}x{cols}")
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("Z,M,N,Kd", [(4, 264, 520, 192), (3, 512, 256, 1024), (2, 40, 72, 40)])
+def test_gemm_strided_batch_equals_separate_products(dev, layout, Z, M, N, Kd):
+    """ie_gemm_bf16_batched (the experts of a MoE layer in one launch): every product of the batch equals the single-product GEMM bit for
+    bit, in the three operand layouts, with accumulate, on shapes that take the LDS-DMA kernels (K % 64 == 0) and the ragged fallback."""
+    akm, bkm = layout[0] == "t", layout[1] == "n"
+    A = bf(torch.randn((Z, Kd, M) if akm else (Z, M, Kd), generator=g(81))).to(dev)
+    B = bf(torch.randn((Z, Kd, N) if bkm else (Z, N, Kd), generator=g(82))).to(dev)
+    C0 = bf(torch.randn(Z, M, N, generator=g(83))).to(dev)
+    out = torch.empty(Z, M, N, dtype=torch.bfloat16, device=dev)
+    K().gemm_batched(A, B, out, akm, bkm)
+    for z in range(Z):
+        assert torch.equal(out[z], K().gemm(A[z], B[z], akm, bkm)), (layout, z)
+    acc = C0.clone()
+    K().gemm_batched(A, B, acc, akm, bkm, accumulate=True)
+    for z in range(Z):
+        one = C0[z].clone()
+        K().gemm(A[z], B[z], akm, bkm, out=one, accumulate=True)
+        assert torch.equal(acc[z], one), (layout, z, "accumulate")

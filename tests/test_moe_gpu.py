@@ -170,3 +170,75 @@ def test_gumbel_noise_is_reproducible_and_gumbel_distributed(dev):
     assert not torch.equal(a, b)
     # Gumbel(0, 1): mean = Euler-Mascheroni, variance = pi^2 / 6
     assert abs(float(a.mean()) - 0.5772) < 5e-3 and abs(float(a.var()) - 1.6449) < 2e-2
+
+
+def _ep_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.moe import MoELayer
+
+        g = torch.Generator().manual_seed(17)
+        S, E, M, F = 512, 4, 256, 512
+        wg = torch.randn(E, M, generator=g) * 0.05
+        w1, w3 = (torch.randn(E, F, M, generator=g) * 0.03).to(BF16), (torch.randn(E, F, M, generator=g) * 0.03).to(BF16)
+        w2 = (torch.randn(E, M, F, generator=g) * 0.03).to(BF16)
+        gr = torch.Generator().manual_seed(100 + rank)          # every rank has its OWN tokens
+        x = torch.randn(S, M, generator=gr).to(BF16)
+        dy = (torch.randn(S, M, generator=gr) * 0.1).to(BF16)
+        noise = MO.gumbel_noise((S, E), 30 + rank)
+        one = _run_layer(dev, x, dy, wg, w1, w3, w2, noise, 1.0, 4, 0.01)[1:]   # all experts local: what this rank's tokens must get
+        El = E // world
+        lay = MoELayer(M, F, E, S, dev, 1.0, 4, ep_group=dist.group.WORLD, ep_size=world, ep_rank=rank)
+        mine = slice(rank * El, (rank + 1) * El)
+        w13 = torch.cat([w1, w3], dim=1)[mine].contiguous().to(dev)
+        w2d, wgd, xd, dyd = w2[mine].contiguous().to(dev), wg.to(dev), x.to(dev), dy.to(dev)
+        out = torch.empty(S, M, dtype=BF16, device=dev)
+        l_aux = lay.forward(xd, wgd, w13, w2d, out, noise=noise.to(dev))
+        dx = torch.empty(S, M, dtype=BF16, device=dev)
+        d_wg, d_w13, d_w2 = torch.empty_like(wgd), torch.empty_like(w13), torch.empty_like(w2d)
+        lay.backward(dyd, wgd, w13, w2d, dx, d_wg, d_w13, d_w2, accumulate=False, loss_scale_dev=None, aux_factor=0.01)
+        q.put((rank, [t.float().numpy() if torch.is_tensor(t) else t for t in one],
+               [out.float().cpu().numpy(), float(l_aux), dx.float().cpu().numpy(), d_wg.cpu().numpy(), d_w13[:, :F].float().cpu().numpy(),
+                d_w13[:, F:].float().cpu().numpy(), d_w2.float().cpu().numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_expert_parallel_layer_equals_the_all_local_layer(dev):
+    """Expert parallelism (parallel.expert; gshard_layer.py:453-474: all_to_all of the [E, C, M] dispatch buffer) on two ranks, two of the four
+    experts each, every rank routing its OWN tokens: a rank's output, input gradient and gate gradient equal the layer that holds all
+    experts locally (same kernels, same routing), and the gradient of an expert's weights is the SUM of what the two ranks' tokens
+    contribute to it."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ep_worker, args=(r, 2, 29891, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, one, ep = q.get(timeout=240)
+        res[r] = (one, ep)
+    for p in procs:
+        p.join(60)
+    E, El = 4, 2
+    for r in range(2):
+        one, ep = res[r]
+        for k, what in ((0, "output"), (2, "d input"), (3, "d gate weight")):
+            _close(torch.from_numpy(ep[k]), torch.from_numpy(one[k]), f"rank {r} {what}", 1e-2)
+        assert ep[1] == one[1], "auxiliary loss of the rank's own tokens"
+        for k, what in ((4, "d w1"), (5, "d w3"), (6, "d w2")):
+            for j in range(El):
+                e = r * El + j
+                want = torch.from_numpy(res[0][0][k][e]) + torch.from_numpy(res[1][0][k][e])
+                _close(torch.from_numpy(ep[k][j]), want, f"rank {r} expert {e} {what}", 2e-2)
