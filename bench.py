@@ -176,6 +176,14 @@ def main():
         torch.distributed.all_reduce(seen)   # SUM of one-hot rows: entry r = the world size rank r reports
         comm_info = {"backend": torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
     comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
+    if world > 1 and args.tp == 1 and args.pp == 1:
+        # data-parallel replicas must hold bit-identical parameters after the timed steps (reduce-scatter -> AdamW on the shard -> all-gather):
+        # every rank's checksum, gathered; a broken exchange would show here instead of as a plausible-looking throughput
+        eng.drain()
+        chk = torch.zeros(world, dtype=torch.float64, device=dev)
+        chk[rank] = eng.params.double().abs().sum()
+        torch.distributed.all_reduce(chk)
+        comm_info["params_in_sync_across_ranks"] = bool((chk == chk[0]).all())
 
     tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp * args.pp)
     sec_step = dt / args.steps
