@@ -233,11 +233,11 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes): measured ratio to the algorithmic bytes x this run's algorithmic bytes
         traffic, traffic_note = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")) as f:
                 tj = json.load(f)
             traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
             traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
-                            "(profiles/r01_gemm_hbm_traffic.json; fabric-side L2 misses incl. Infinity-Cache hits: 8 XCD L2s each stream their own panels)")
+                            "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes; fabric-side L2 misses incl. Infinity-Cache hits: every block of 32 tiles of an XCD re-reads its 12 operand panels)")
         except (OSError, KeyError, ValueError):
             pass
         out["roofline"] = {
