@@ -56,6 +56,30 @@ class MoEEngine:
         if world_size > 1 and not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised for world_size > 1")
         self.backend = dist.get_backend(process_group) if world_size > 1 else None
+        # Expert parallelism as the reference sets it up (parallel_context.py:538-541: ep = min(data-parallel size, num_experts); expert groups =
+        # ep CONSECUTIVE data-parallel ranks, expert-data groups = the ranks with the same position in their expert group): every rank holds
+        # E / ep experts, its tokens visit the others through the all_to_all of the dispatch buffers (moe.MoELayer).
+        E_ = mc.num_experts
+        self.ep, self.ep_rank, self.ep_group, self.edp_group = 1, 0, None, None
+        if world_size > 1:
+            if process_group is not None:
+                raise NotImplementedError("MoEEngine runs over the default group (pure data parallelism + expert parallelism)")
+            ep = min(world_size, E_)
+            if world_size % ep or E_ % ep:
+                raise NotImplementedError(f"expert parallel size {ep} must divide the world size {world_size} and the number of experts {E_}")
+            for g in range(world_size // ep):          # collective: every rank creates every group, same order
+                ranks = list(range(g * ep, (g + 1) * ep))
+                grp = dist.new_group(ranks)
+                if rank in ranks:
+                    self.ep_group = grp
+            for j in range(ep):
+                ranks = list(range(j, world_size, ep))
+                grp = dist.new_group(ranks)
+                if rank in ranks:
+                    self.edp_group = grp
+            self.ep, self.ep_rank = ep, rank % ep
+        self.El = E_ // self.ep
+        self.groups = ("0_default", "1_fp32", f"2_moe_ep_size_{self.ep}")   # the optimizer groups' names (train/utils.py:25-80)
         self.noise_fn, self.calls = noise_fn, 0
         self.keep_routes = None   # set to [] to record (expert choices, gate logits) of every micro-batch and layer
         h, F, V, L, E = mc.hidden_size, ffn_dim(mc), mc.vocab_size, mc.num_layers, mc.num_experts
@@ -69,7 +93,7 @@ class MoEEngine:
             p = f"blocks.{l}."
             specs += [(p + "norm1.weight", (h,)), (p + "mixer.Wqkv.weight", (3 * h, h)), (p + "mixer.Wqkv.bias", (3 * h,)),
                       (p + "mixer.out_proj.weight", (h, h)), (p + "mixer.out_proj.bias", (h,)), (p + "norm2.weight", (h,)),
-                      (p + "mlp.w13", (E, 2 * F, h)), (p + "mlp.w2", (E, h, F))]   # experts: w1 | w3 fused per expert, all experts of a layer adjacent
+                      (p + "mlp.w13", (self.El, 2 * F, h)), (p + "mlp.w2", (self.El, h, F))]   # this rank's experts: w1 | w3 fused per expert, adjacent
         specs += [("norm.weight", (h,)), ("head.weight", (V, h))]
         off, self.spec = 0, {}
         for n, shp in specs:
@@ -119,7 +143,8 @@ class MoEEngine:
         self.a_q, self.a_kv, self.a_ctx = [e(T, H, d) for _ in range(L)], [e(T, 2, H, d) for _ in range(L)], [e(T, H, d) for _ in range(L)]
         self.a_lse = [e(H, T, dtype=torch.float32) for _ in range(L)]
         self.a_r2, self.a_n2, self.a_rstd2 = [e(T, h) for _ in range(L)], [e(T, h) for _ in range(L)], [e(T, dtype=torch.float32) for _ in range(L)]
-        self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed, layer_index=l) for l in range(L)]
+        self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * rank, layer_index=l, ep_group=self.ep_group,
+                             ep_size=self.ep, ep_rank=self.ep_rank) for l in range(L)]   # (every rank gates its own tokens with its own noise)
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
         self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * h), e(T, h), e(T, h), e(T, h)
         self.t_dq, self.t_dkv = e(T, H, d), e(T, 2, H, d)
@@ -167,7 +192,9 @@ class MoEEngine:
                 self.wg[int(n.split(".")[1])].copy_(t.float())
             elif ".experts." in n:
                 parts = n.split(".")
-                l, e_, w = int(parts[1]), int(parts[6]), parts[7]
+                l, e_, w = int(parts[1]), int(parts[6]) - self.ep_rank * self.El, parts[7]   # (names carry the GLOBAL expert index)
+                if not 0 <= e_ < self.El:
+                    continue                                                                 # another rank's expert
                 if w == "w2":
                     self.p[f"blocks.{l}.mlp.w2"][e_].copy_(t)
                 else:
@@ -187,7 +214,9 @@ class MoEEngine:
                 out[n] = self.wg[int(n.split(".")[1])]
             elif ".experts." in n:
                 parts = n.split(".")
-                l, e_, w = int(parts[1]), int(parts[6]), parts[7]
+                l, e_, w = int(parts[1]), int(parts[6]) - self.ep_rank * self.El, parts[7]
+                if not 0 <= e_ < self.El:
+                    continue                       # (held by another rank of the expert group)
                 out[n] = self.p[f"blocks.{l}.mlp.w2"][e_] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
             elif "mixer.Wqkv" in n:
                 out[n] = self._qkv_to_reference(self.p[n])
@@ -320,24 +349,56 @@ class MoEEngine:
         return self.loss_acc, self.moe_acc
 
     # ------------------------------------------------------------------------------------------ optimizer
-    def _all_reduce_avg(self, t):
-        if self.world == 1:
+    def _all_reduce(self, t, group, size, avg=True):
+        """In-place all-reduce (AVG, or SUM) over `group` of `size` ranks; RCCL directly, gloo (tests) through the host."""
+        if size == 1:
             return
         if self.backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
-        else:  # gloo test path
+            dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
+        else:
             c = t.detach().float().to("cpu")
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_((c / self.world).to(t.dtype))
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            t.copy_((c / size if avg else c).to(t.dtype))
+
+    def sync_replicas(self):
+        """sync_model_param (utils/parallel.py:71-107): dense parameters and gates from rank 0, every expert from the first rank of its
+        expert-data group."""
+        if self.world == 1:
+            return
+
+        def bcast(t, src, group):
+            if self.backend == "nccl":
+                dist.broadcast(t, src=src, group=group)
+            else:
+                c = t.detach().to("cpu")
+                dist.broadcast(c, src=src, group=group)
+                t.copy_(c)
+
+        for a, b in self.runs[0]:
+            bcast(self.params[a:b], 0, None)
+        bcast(self.wg, 0, None)
+        if self.world > self.ep:
+            for a, b in self.runs[2]:
+                bcast(self.params[a:b], self.ep_rank, self.edp_group)
+        self.master.copy_(self.params)
 
     def step(self):
         """HybridZeroOptimizer.step with the three parameter groups; stream-ordered, no host sync."""
         tc = self.tc
-        self._all_reduce_avg(self.grads)      # data parallel: every rank keeps the whole (replicated) optimizer state
-        self._all_reduce_avg(self.d_wg)
+        # data parallel, every rank keeps the (replicated) optimizer state of what it holds.  Dense parameters and gates: AVG over all ranks.
+        # Experts: an expert's gradient already sums what the tokens of every rank of its expert group contributed (one copy, one backward);
+        # the reference averages it over the expert-data group only (hybrid_zero_optim.py:166-167) -- no 1 / ep.
+        for a, b in self.runs[0]:
+            self._all_reduce(self.grads[a:b], None, self.world)
+        self._all_reduce(self.d_wg, None, self.world)
+        for a, b in self.runs[2]:
+            self._all_reduce(self.grads[a:b], self.edp_group, self.world // self.ep)
         K.sumsq([self.grads[a:b] for a, b in self.runs[0]], self.sumsq[0:1])
         K.sumsq(self.d_wg, self.sumsq[1:2])
         K.sumsq([self.grads[a:b] for a, b in self.runs[2]], self.sumsq[2:3])
+        if self.ep > 1:   # the moe group's squared norm: local sum of squares / dp, summed over the expert group (solver/optimizer/utils.py:362-368)
+            self.sumsq[2:3].div_(self.world)
+            self._all_reduce(self.sumsq[2:3], self.ep_group, self.ep, avg=False)
         check(K._L().ie_step_control_groups(K._p(self.state), K._p(self.sumsq), 3, self.scaler_cfg, K._p(self.group_inv), K._p(self.group_norm), K._stream()),
               "ie_step_control_groups")
         lr, beta2 = self.lr_sched.lr(), self.beta2_sched.beta2()
@@ -360,5 +421,5 @@ class MoEEngine:
         st = K.step_state_read(self.state)
         self.lr_sched.set_successful_steps(st.adam_step)
         self.beta2_sched.set_successful_steps(st.adam_step)
-        st.group_norms = dict(zip(GROUPS, (float(x) for x in self.group_norm.cpu())))
+        st.group_norms = dict(zip(self.groups, (float(x) for x in self.group_norm.cpu())))
         return st

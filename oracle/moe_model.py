@@ -153,8 +153,9 @@ class OracleMoETrainer(OracleTrainer):
             (self.scaler.scale * loss).backward()
         return total, moe_total
 
-    def update(self, total=0.0, moe_total=0.0):
-        """HybridZeroOptimizer.step on the accumulated gradients: group norms, overflow check, scaler, per-group clip, AdamW."""
+    def update(self, total=0.0, moe_total=0.0, moe_sq_scale=1.0):
+        """HybridZeroOptimizer.step on the accumulated gradients: group norms, overflow check, scaler, per-group clip, AdamW.
+        moe_sq_scale: factor on the squared norm of the expert group (expert-parallel runs: OracleMoEDataParallel)."""
         tc = self.tc
         groups = {"0_default": [], "1_fp32": [], "2_moe_ep_size_1": []}
         for n in self.names:
@@ -164,7 +165,7 @@ class OracleMoETrainer(OracleTrainer):
             acc = 0.0
             for n in names:
                 acc = acc + torch.norm(self.params[n].grad.float(), 2.0) ** 2.0
-            sq[gname] = float(acc)
+            sq[gname] = float(acc) * (moe_sq_scale if gname.startswith("2_moe") else 1.0)
         found_inf, found_nan = any(math.isinf(v) for v in sq.values()), any(math.isnan(v) for v in sq.values())
         loss_scale = self.scaler.scale
         if self.dtype != torch.float32:
@@ -189,3 +190,42 @@ class OracleMoETrainer(OracleTrainer):
         self.k += 1
         self.beta2_iter += 1
         return {"loss": total, "moe_loss": moe_total, "grad_norm": norms, "ok": True, "loss_scale": self.scaler.scale, "lr": lr}
+
+
+class OracleMoEDataParallel(OracleMoETrainer):
+    """`world` data-parallel ranks of the MoE family in ONE process, with the reference's AUTOMATIC expert parallelism
+    (parallel_context.py:538-541: ep = min(dp, num_experts); here world <= num_experts, so ep = world and every expert lives on exactly one rank):
+      * every rank gates its OWN micro-batches (noise seed 5000 + 1000 rank + call, as the harness injects it); its tokens visit experts on all
+        ranks through the all_to_all of gshard_layer.py:453-474 -- numerically the layer with all experts local;
+      * dense parameters and gates: gradients averaged over the data-parallel ranks (all-reduce AVG over DATA);
+      * expert parameters: an expert's gradient is the SUM of what every rank's tokens contribute (they all pass through the one copy of the
+        expert in one backward), then averaged over the expert-data group (hybrid_zero_optim.py:166-167) -- of size dp / ep = 1 here: no 1 / ep;
+      * the squared norm of the moe group: every rank's local sum of squares / dp, summed over the expert group
+        (solver/optimizer/utils.py:362-368) = (sum over ALL experts) / dp.
+    Pinned by tests/golden/train_moe2_bf16_rank{0,1}.json = the unmodified reference on two gloo ranks (make_golden.py --run-mp moe2_bf16)."""
+
+    def __init__(self, path_cfg, world, dtype=torch.bfloat16, init_fn=None):
+        super().__init__(path_cfg, dtype, init_fn)
+        if world > self.mc.num_experts or self.mc.num_experts % world:
+            raise NotImplementedError("emulates ep = dp (world <= num_experts, dividing it)")
+        self.world = world
+        self.calls_of = [0] * world
+
+    def train_step(self, batches, labels, forced=None):
+        """batches / labels: one entry per rank.  -> list of per-rank result dicts (the norms are global)."""
+        per_rank = []
+        for r in range(self.world):
+            self.noise_seed, self.calls = (lambda call, r=r: 5000 + 1000 * r + call), self.calls_of[r]
+            total, moe_total = self.backward(batches[r], labels[r], None if forced is None else forced[r])
+            self.calls_of[r] = self.calls
+            per_rank.append(({n: p.grad.detach().clone() for n, p in self.params.items()}, total, moe_total, self.routes))
+        with torch.no_grad():
+            for n, p in self.params.items():
+                gs = [pr[0][n] for pr in per_rank]
+                acc = gs[0].clone()
+                for g in gs[1:]:
+                    acc += g                                  # (the reduction sums in the gradient's dtype)
+                p.grad = acc if group_of(n).startswith("2_moe") else acc / self.world
+        self.routes_of = [pr[3] for pr in per_rank]
+        res = self.update(0.0, 0.0, moe_sq_scale=1.0 / self.world)
+        return [dict(res, loss=pr[1], moe_loss=pr[2]) for pr in per_rank]

@@ -334,8 +334,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
         calls = [0]
 
         def _noise(shape, device):  # the k-th gating call of the run (layer-major inside a micro-batch) gets gumbel_noise(seed = 5000 + k)
-            calls[0] += 1
-            return gumbel_noise(tuple(shape), 5000 + calls[0] - 1)
+            calls[0] += 1          # (every data-parallel rank gates its own tokens: rank r draws seed 5000 + 1000 r + k)
+            return gumbel_noise(tuple(shape), 5000 + 1000 * rank + calls[0] - 1)
 
         gl.gumbel_rsample = _noise
 
@@ -350,7 +350,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
     inner = model.model
     sp, wp = cfg_kw.get("sp", 1), cfg_kw.get("wp", 1)
-    if world > 1:
+    moe_mp = world > 1 and cfg_kw.get("model_type") == "INTERNLM_MoE"
+    if world > 1 and not moe_mp:
         from internevo_amd.config import ModelConfig
         from oracle.model import param_shapes
 
@@ -360,7 +361,20 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     tp = cfg_kw.get("tp", 1)
     with torch.no_grad():
         for name, p in inner.named_parameters():
-            if world > 1 and tp > 1:
+            if moe_mp:
+                # data parallel + the reference's automatic expert parallelism (ep = min(dp, experts), parallel_context.py:538-541): every
+                # rank holds the whole dense part and experts.wrapped_experts.{j} = GLOBAL expert ep_rank * (E / ep) + j
+                import re
+
+                m_ = re.search(r"wrapped_experts\.(\d+)\.", name)
+                if m_:
+                    El = cfg_kw["num_experts"] // gpc.get_world_size(ParallelMode.EXPERT)
+                    e = gpc.get_local_rank(ParallelMode.EXPERT) * El + int(m_.group(1))
+                    gname = name[: m_.start(1)] + str(e) + name[m_.end(1):]
+                    p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
+                else:
+                    p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+            elif world > 1 and tp > 1:
                 part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw)
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
@@ -748,6 +762,10 @@ RUNS_MP = {
     "tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2), 2),
     "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
+    # two data-parallel ranks of the MoE family: the reference then runs expert parallel (ep = 2, two of the four experts per rank, all_to_all of the
+    # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
+    "moe2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                         model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0), 2),
 }
 
 

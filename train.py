@@ -80,10 +80,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
                                   "(checkpoints / validation / tokenized folders are implemented for the dense model families)")
     tc = cfg.train
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
-    if world > 1:   # sync_model_param (utils/parallel.py:71-107)
-        torch.distributed.broadcast(eng.params, src=0)
-        torch.distributed.broadcast(eng.wg, src=0)
-        eng.master.copy_(eng.params)
+    eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
     loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world))
     out = []
     for step in range(tc.total_steps):
