@@ -278,9 +278,24 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // One query tile (64 rows = two 32-row sub-blocks) of one q head against this wave's 32 keys.  The serial chain
+    //   S / dP MFMAs -> softmax -> packing -> dV / dK MFMAs
+    // of the two sub-blocks is interleaved (ablations: the phases, not the LDS feed, cost the time, profiles/r02_flash_dkdv_ablation.jsonl):
+    //   A0: S0 / dP0 MFMAs            | row fragments fetched two k-steps ahead
+    //   A1: S1 / dP1 MFMAs            | softmax of sub-block 0: its 16 elements (fma, exp2, sub, mul, half a pack each) spread over the MFMA gaps
+    //   C0: dV / dK MFMAs of block 0  | softmax of sub-block 1 likewise; transposed fragments fetched two MFMAs ahead
+    //   C1: dV / dK MFMAs of block 1
+    // MFMAs are asm with explicit register files (flash_common.h): dK / dV accumulators and the K / V fragments live in AGPRs, the scores in
+    // arch VGPRs.  One wave hides 5-6 vector instructions under a 32-cycle MFMA (tools/probes/mfma_shadow.hip): one element per gap fits at
+    // D = 128.  Every gap is pinned by sched_barrier.  A sub-block that is masked entirely or lies behind the sequence is computed like the
+    // others and contributes zeros (the mask; lse = +inf behind the sequence).
     auto step = [&](auto stage_c, int it) {
         constexpr int S = decltype(stage_c)::value;
         const int q0 = (qt_start + it % nqt) * 64;
+        // wave-uniform: does this tile need the mask (the diagonal tile, the last keys)?  Unmasked tiles compare against a first row that
+        // no row is below, so the two extra vector instructions per element are the same in both cases (one code path: two copies of the
+        // tile body -- masked / unmasked -- made hipcc spill 91 VGPRs)
+        const bool need_mask = (CAUSAL && kw0 + 31 > q0) || (kw0 + 32 > len);
         const unsigned char* stage = smem + S * STAGE;
         unsigned char* nxt = smem + (1 - S) * STAGE;
         const bool more = it + 1 < nit;
@@ -289,95 +304,139 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         const unsigned char* dOs = stage + G::IMG_BYTES;
         const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
         const float* dlt_s = lse_s + 64;
-        // One wave per SIMD: nothing but this wave's own instruction stream can hide an LDS round trip, so every fragment is
-        // requested well before its MFMA -- the 16 row fragments of a sub-block in one burst (the second sub-block's under
-        // the first one's dV/dK MFMAs), the 16 transposed fragments BEFORE the softmax VALU block that they wait behind.
-        s16x8 qf[G::KS], dof[G::KS];
-        auto load_rows = [&](int qs) {
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                qf[ks] = row_frag<D>(Qs, 32 * qs, ks, fo);
-                dof[ks] = row_frag<D>(dOs, 32 * qs, ks, fo);
+        const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
+        const int first_rel = need_mask ? first_q - q0 - rl_lane : (int)0x80000000;   // the same in tile-local rows of this lane's registers 0 .. 3
+        constexpr int KS = G::KS, NTR = 2 * G::DB;      // MFMAs per accumulator in an A phase; (dV, dK) MFMA pairs in a C phase
+        constexpr int EA = 16 / (2 * KS) > 0 ? 16 / (2 * KS) : 1, EC = 16 / (2 * NTR) > 0 ? 16 / (2 * NTR) : 1;   // softmax elements per MFMA gap
+        constexpr int R = 3;                            // row fragments in flight (k-steps ahead + 1)
+        s16x8 rq[R], rdo[R];
+        auto fetch_rows = [&](int u) {                  // u = 0 .. 2 KS - 1: k-step u % KS of sub-block u / KS
+            rq[u % R] = row_frag<D>(Qs, 32 * (u / KS), u % KS, fo);
+            rdo[u % R] = row_frag<D>(dOs, 32 * (u / KS), u % KS, fo);
+        };
+        f32x16 s0, dp0, s1, dp1;
+        s16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
+        float4 l4[2], d4[2];                           // lse / delta of register groups gi, gi + 1 (gi = 4 qs + r / 4): fetched one group ahead
+        auto fetch_ld = [&](int gi) {
+            const int rl = 32 * (gi / 4) + 8 * (gi % 4) + rl_lane;   // tile-local row of registers 4 (r / 4) .. + 3
+            l4[gi % 2] = *reinterpret_cast<const float4*>(lse_s + rl);
+            d4[gi % 2] = *reinterpret_cast<const float4*>(dlt_s + rl);
+        };
+        float e_prev = 0.f;
+        ie_f32x2 t_prev = {0.f, 0.f};
+        // one element of a sub-block's softmax (register r of S / dP); behind the odd element of a pair the bf16 pack of the pair
+        auto elem = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int qs, int r) {
+            const int gi = 4 * qs + r / 4;
+            if (r % 4 == 0 && gi + 1 < 8) fetch_ld(gi + 1);
+            const float4 lq = l4[gi % 2], dq = d4[gi % 2];
+            const float lv = r % 4 == 0 ? lq.x : r % 4 == 1 ? lq.y : r % 4 == 2 ? lq.z : lq.w;
+            float e = __builtin_amdgcn_exp2f(fms_pinned(sv[r], sc2, lv));   // lse2 = +inf for rows >= len -> 0
+            e = (32 * qs + 8 * (r / 4) + r % 4) < first_rel ? 0.f : e;
+            if (r % 2 == 0) {   // dP - delta of the pair (r, r + 1) as one packed subtract, held HERE (hipcc otherwise hoists it up to the lse / delta load and waits there)
+                e_prev = e;
+                ie_f32x2 dl;
+                dl.x = r % 4 == 0 ? dq.x : dq.z;
+                dl.y = r % 4 == 0 ? dq.y : dq.w;
+                asm volatile("" : "+v"(dl));
+                t_prev.x = dpv[r] - dl.x;
+                t_prev.y = dpv[r + 1] - dl.y;
+            } else {   // registers r - 1, r -> 32-bit word (r / 2) % 4 of fragment r / 8
+                const float ds_prev = e_prev * t_prev.x, ds = e * t_prev.y;
+                union { uint4 u; s16x8 x; } a, b;
+                a.x = pf[r / 8];
+                b.x = dsf[r / 8];
+                const unsigned pp = pack2bf(e_prev, e), dd = pack2bf(ds_prev, ds);
+                const int w = (r / 2) % 4;
+                if (w == 0) { a.u.x = pp; b.u.x = dd; } else if (w == 1) { a.u.y = pp; b.u.y = dd; } else if (w == 2) { a.u.z = pp; b.u.z = dd; } else { a.u.w = pp; b.u.w = dd; }
+                pf[r / 8] = a.x;
+                dsf[r / 8] = b.x;
             }
         };
-        bool act[2];
+        s16x8 tfa[2], tfb[2];                           // transposed fragments in flight: [m % 2] for dV (dO^T) and dK (Q^T)
+        auto fetch_tr = [&](int m, int qs) {            // m = 0 .. NTR - 1: (s2, db) = (m / DB, m % DB) of sub-block qs
+            tfa[m % 2] = trans_frag<D>(dOs, m % G::DB, 2 * qs + m / G::DB, fo);
+            tfb[m % 2] = trans_frag<D>(Qs, m % G::DB, 2 * qs + m / G::DB, fo);
+        };
+        fetch_rows(0);
+        fetch_rows(1);
+        fetch_ld(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // A0 (the fragments of sub-block 1's first k-steps are requested under its last MFMAs)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) act[qs] = (q0 + 32 * qs) < len && (!CAUSAL || q0 + 32 * qs + 31 >= kw0);
-        if (act[0]) load_rows(0);
-        else if (act[1]) load_rows(1);
+        for (int ks = 0; ks < KS; ++ks) {
+            fetch_rows(ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) mfma_s_first(s0, rq[ks % R], kf[ks]);
+            else mfma_s(s0, rq[ks % R], kf[ks]);
+            if (ks == 0) mfma_s_first(dp0, rdo[ks % R], vf[ks]);
+            else mfma_s(dp0, rdo[ks % R], vf[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // A1 | softmax of sub-block 0
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            const int qb0 = q0 + 32 * qs;  // first query row of this sub-block
-            if (!act[qs]) continue;
-            f32x16 s = zero16(), dp = zero16();
+        for (int ks = 0; ks < KS; ++ks) {
+            const int u = KS + ks;
+            if (ks + 2 < KS) fetch_rows(u + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) mfma_s_first(s1, rq[u % R], kf[ks]);
+            else mfma_s(s1, rq[u % R], kf[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) asm volatile("s_nop 11" : "+v"(s0), "+v"(dp0));   // S0 / dP0: 12 wait states behind their last MFMA before the vector ALU reads them
+#pragma unroll
+            for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + x);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) mfma_s_first(dp1, rdo[u % R], vf[ks]);
+            else mfma_s(dp1, rdo[u % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], dp, 0, 0, 0);
-            }
-            // transposed fragments of this sub-block: requested now, consumed after the softmax block
-            s16x8 tdo[2][G::DB], tq[2][G::DB];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int db = 0; db < G::DB; ++db) {
-                    tdo[s2][db] = trans_frag<D>(dOs, db, 2 * qs + s2, fo);
-                    tq[s2][db] = trans_frag<D>(Qs, db, 2 * qs + s2, fo);
-                }
+            for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + EA + x);
+            if (ks == KS - 2) fetch_tr(0, 0);
+            if (ks == KS - 1) fetch_tr(1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const bool need_mask = (CAUSAL && kw0 + 31 > qb0) || (kw0 + 32 > len);
-            f32x16 p;
+        }
+        // C0 | softmax of sub-block 1
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rl = 32 * qs + 8 * g + rl_lane;  // tile-local row of regs 4g..4g+3
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rl);
-                const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + rl);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-                if (need_mask) {  // wave-uniform; selects instead of per-element branches
-                    const int first_q = (my_k >= len) ? 0x7fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const int qrow = q0 + rl + e;
-                        const float pv = qrow < first_q ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));  // lse2 = +inf for rows >= len -> 0
-                        p[r] = pv;
-                        s[r] = pv * (dp[r] - dv4[e]);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));
-                        p[r] = pv;
-                        s[r] = pv * (dp[r] - dv4[e]);
-                    }
-                }
-            }
+        for (int m = 0; m < NTR; ++m) {
+            mfma_o(dvacc[m % G::DB], tfa[m % 2], pf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
-            if (qs == 0 && act[1]) load_rows(1);  // the next sub-block's row fragments land under the MFMAs below
+            if (m == 0) asm volatile("s_nop 11" : "+v"(s1), "+v"(dp1));
+#pragma unroll
+            for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + x);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_o(dkacc[m % G::DB], tfb[m % 2], dsf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const s16x8 pf = pack_frag(p, s2);
-                const s16x8 dsf = pack_frag(s, s2);
+            for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + EC + x);
+            if (m + 2 < NTR) fetch_tr(m + 2, 0);
+            else fetch_tr(m + 2 - NTR, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // C1
 #pragma unroll
-                for (int db = 0; db < G::DB; ++db) {
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[s2][db], pf, dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[s2][db], dsf, dkacc[db], 0, 0, 0);
-                }
-            }
+        for (int m = 0; m < NTR; ++m) {
+            mfma_o(dvacc[m % G::DB], tfa[m % 2], pf1[m / G::DB]);
+            mfma_o(dkacc[m % G::DB], tfb[m % 2], dsf1[m / G::DB]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m + 2 < NTR) fetch_tr(m + 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) commit(nxt, lse_r, dlt_r);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-
+    auto pin = [&]() {
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) pin_acc(dkacc[db], dvacc[db]);
+    };
     for (int it = 0; it < nit; it += 2) {
+        pin();
         step(std::integral_constant<int, 0>{}, it);
+        pin();
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
+        pin();
     }
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) mfma_settle_acc(dkacc[db], dvacc[db]);
 
     if (k_valid && HS == 1) {
         bf16_t* dkp = dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;

@@ -200,10 +200,19 @@ __device__ __forceinline__ float fma_pinned(float a, float b, float c) {
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// a * b - c
+__device__ __forceinline__ float fms_pinned(float a, float b, float c) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ void max3_pinned(float& m, float a, float b) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
     asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 __device__ __forceinline__ void mfma_settle_acc(f32x16& a, f32x16& b) { asm volatile("s_nop 15" : "+a"(a), "+a"(b)); }
+// keeps loop-carried accumulators in the accumulator file across a loop edge (hipcc otherwise carries them in arch VGPRs and
+// copies all of them in and out -- 2 x 128 v_accvgpr moves per tile in the dK / dV kernel)
+__device__ __forceinline__ void pin_acc(f32x16& a, f32x16& b) { asm volatile("" : "+a"(a), "+a"(b)); }
 
 }  // namespace fa
