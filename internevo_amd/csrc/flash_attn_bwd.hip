@@ -1,5 +1,5 @@
 // K1 backward: varlen, causal / full, GQA flash attention for gfx950.  Deterministic (no atomics):
-//   1. flash_delta_k : delta[h][t] = sum_d dO * O
+//   1. flash_delta_k : delta[h][t] = sum_d dO * O, lse2[h][t] = lse[h][t] * log2(e)
 //   2. flash_dq_k    : one block per 128 query rows, loops over K/V tiles, recomputes P, dQ += dS K
 //   3. flash_dkdv_k  : one block per 64 keys (one wave per 32 keys), loops over the q heads of the
 //                      GQA group and their query tiles, recomputes P, dV += P^T dO, dK += dS^T Q
@@ -16,6 +16,28 @@
 
 #include <type_traits>
 
+// timing ablations of the dK / dV kernel (development only; results are then wrong): 1 no transposed reads, 2 no softmax, 4 no row reads,
+// 8 no S / dP MFMAs, 16 no dV / dK MFMAs, 32 no end-of-tile wait + barrier, 64 no lse / delta reads
+#ifndef IE_DKDV_ROW_AHEAD
+#define IE_DKDV_ROW_AHEAD 2
+#endif
+#ifndef IE_DKDV_TR_AHEAD
+#define IE_DKDV_TR_AHEAD 2
+#endif
+// IE_DKDV_TIMING (development only): s_memtime stamps at the phase boundaries of every tile, summed over all waves into g_dkdv_t and printed
+// by the launcher: [issue + first fetches, A0, A1, C0, C1, end-of-tile wait + barrier, tiles]
+#ifndef IE_DKDV_TIMING
+#define IE_DKDV_TIMING 0
+#endif
+#ifndef IE_FLASH_ABLATE
+#define IE_FLASH_ABLATE 0
+#endif
+#if IE_DKDV_TIMING
+__device__ unsigned long long g_dkdv_t[8];
+#define IE_STAMP(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
+#else
+#define IE_STAMP(i)
+#endif
 namespace {
 
 using namespace fa;
@@ -23,7 +45,8 @@ using namespace fa;
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ out,
-                                                     int64_t o_ts, float* __restrict__ delta, int64_t T, int hq) {
+                                                     int64_t o_ts, const float* __restrict__ lse, float* __restrict__ delta,
+                                                     float* __restrict__ lse2, int64_t T, int hq) {
     constexpr int TPP = D / 8;  // threads per (token, head) pair
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = gid / TPP;
@@ -45,6 +68,7 @@ __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ 
         const int64_t t = pair / hq;
         const int h = (int)(pair % hq);
         delta[(int64_t)h * T + t] = acc;
+        lse2[(int64_t)h * T + t] = lse[(int64_t)h * T + t] * kLog2e;   // the dK / dV kernel works in the log2 domain
     }
 }
 
@@ -225,32 +249,50 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len
     const int nit = grp * nqt;
 
+    // Q / dO descriptors end with this sequence: rows behind it arrive as zeros, and so do their lse2 / delta -- such a row gives S = 0,
+    // P = exp2(0 - 0) = 1, dP = 0, dS = 1 * (0 - 0) = 0 and adds exact zeros to dV (P^T dO) and dK (dS^T Q), with no instruction spent on it
     TileSrc<D, DKV_WAVES> qsrc, dosrc;
-    qsrc.init(q + (int64_t)tok0 * q_ts, q_ts, T - tok0, (int64_t)hq * D, wave, lane);
-    dosrc.init(dout + (int64_t)tok0 * do_ts, do_ts, T - tok0, (int64_t)hq * D, wave, lane);
-    // stage `it`: Q / dO images by DMA; lse (log2 domain) and delta through registers of threads 0..63
-    auto issue = [&](int it, unsigned char* stage, float& lse_r, float& dlt_r) {
-        const int h = h_first + it / nqt;
+    qsrc.init(q + (int64_t)tok0 * q_ts, q_ts, len, (int64_t)hq * D, wave, lane);
+    dosrc.init(dout + (int64_t)tok0 * do_ts, do_ts, len, (int64_t)hq * D, wave, lane);
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    // Every transfer of a stage is issued from inline asm (flash_common.h: issue_piece_asm); the only vmcnt waits of the tile loop are the
+    // explicit ones at the end of a tile.  lse2 / delta of the 64 rows: one buffer_load_dword ... lds each (lane = row), wave 0 / wave 1.
+    struct Next { int soff_q, soff_do; i32x4 rs_l, rs_d; int soff_ld; };
+    auto plan = [&](int it) {
+        Next n;
+        const int h = min(h_first + it / nqt, hq - 1);   // it == nit (the prefetch behind the last tile) may name a head this block does not own
         const int q0 = (qt_start + it % nqt) * 64;
-        const int rem = len - q0;
-        qsrc.issue(stage, q0, h * D, wave);
-        dosrc.issue(stage + G::IMG_BYTES, q0, h * D, wave);
-        if (threadIdx.x < 64) {
-            const bool ok = (int)threadIdx.x < rem;
-            lse_r = ok ? lse[(int64_t)h * T + tok0 + q0 + threadIdx.x] * kLog2e : INFINITY;
-            dlt_r = ok ? delta[(int64_t)h * T + tok0 + q0 + threadIdx.x] : 0.f;
-        }
+        n.soff_q = q0 * qsrc.ts2 + h * D * 2;
+        n.soff_do = q0 * dosrc.ts2 + h * D * 2;
+        const float* lp = lse + (int64_t)h * T + tok0;
+        const float* dp = delta + (int64_t)h * T + tok0;
+        n.rs_l[0] = (int)(uint32_t)(uintptr_t)lp;
+        n.rs_l[1] = (int)(((uintptr_t)lp >> 32) & 0xffff);
+        n.rs_d[0] = (int)(uint32_t)(uintptr_t)dp;
+        n.rs_d[1] = (int)(((uintptr_t)dp >> 32) & 0xffff);
+        n.rs_l[2] = n.rs_d[2] = len * 4;
+        n.rs_l[3] = n.rs_d[3] = 0x00020000;
+        n.soff_ld = q0 * 4;
+        return n;
     };
-    auto commit = [&](unsigned char* stage, float lse_r, float dlt_r) {
-        if (threadIdx.x < 64) {
-            reinterpret_cast<float*>(stage + 2 * G::IMG_BYTES)[threadIdx.x] = lse_r;
-            reinterpret_cast<float*>(stage + 2 * G::IMG_BYTES + 256)[threadIdx.x] = dlt_r;
-        }
+    auto issue_ld = [&](const Next& n, uint32_t stage_lds) {   // wave 0: lse2, wave 1: delta
+        if (wave == 0)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(stage_lds + 2 * G::IMG_BYTES), "v"(lane * 4), "s"(n.rs_l), "s"(n.soff_ld) : "memory");
+        if (wave == 1)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(stage_lds + 2 * G::IMG_BYTES + 256), "v"(lane * 4), "s"(n.rs_d), "s"(n.soff_ld) : "memory");
     };
-
-    float lse_r = 0.f, dlt_r = 0.f;
-    issue(0, smem, lse_r, dlt_r);
-    commit(smem, lse_r, dlt_r);
+    constexpr int PERW = TileSrc<D, DKV_WAVES>::PERW;
+    {
+        const Next n = plan(0);
+        issue_ld(n, smem_lds);
+#pragma unroll
+        for (int pq = 0; pq < PERW; ++pq) {
+            qsrc.issue_piece_asm(smem_lds, n.soff_q, wave, pq);
+            dosrc.issue_piece_asm(smem_lds + G::IMG_BYTES, n.soff_do, wave, pq);
+        }
+    }
 
     FragOffs<D> fo;
     fo.init(lane);
@@ -276,6 +318,10 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int rl_lane = 4 * (lane >> 5);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // a use of the K / V fragments in front of the loop: hipcc does not read the asm wait above and would otherwise wait for their global
+    // loads (vmcnt(0): everything, the asm transfers of the next tile included) at their first use INSIDE the tile loop, in every iteration
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+a"(kf[ks]), "+a"(vf[ks]));
     __syncthreads();
 
     // One query tile (64 rows = two 32-row sub-blocks) of one q head against this wave's 32 keys.  The serial chain
@@ -289,17 +335,24 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     // arch VGPRs.  One wave hides 5-6 vector instructions under a 32-cycle MFMA (tools/probes/mfma_shadow.hip): one element per gap fits at
     // D = 128.  Every gap is pinned by sched_barrier.  A sub-block that is masked entirely or lies behind the sequence is computed like the
     // others and contributes zeros (the mask; lse = +inf behind the sequence).
+#if IE_DKDV_TIMING
+    unsigned tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     auto step = [&](auto stage_c, int it) {
         constexpr int S = decltype(stage_c)::value;
+#if IE_DKDV_TIMING
+        unsigned long long ts[7];
+#endif
+        IE_STAMP(0);
         const int q0 = (qt_start + it % nqt) * 64;
         // wave-uniform: does this tile need the mask (the diagonal tile, the last keys)?  Unmasked tiles compare against a first row that
         // no row is below, so the two extra vector instructions per element are the same in both cases (one code path: two copies of the
         // tile body -- masked / unmasked -- made hipcc spill 91 VGPRs)
         const bool need_mask = (CAUSAL && kw0 + 31 > q0) || (kw0 + 32 > len);
         const unsigned char* stage = smem + S * STAGE;
-        unsigned char* nxt = smem + (1 - S) * STAGE;
-        const bool more = it + 1 < nit;
-        if (more) issue(it + 1, nxt, lse_r, dlt_r);
+        const Next nx = plan(it + 1);                   // the next tile's transfers go into the other stage, spread over the gaps of A0 / A1
+        const uint32_t nxt_lds = smem_lds + (1 - S) * STAGE;
+        issue_ld(nx, nxt_lds);
         const unsigned char* Qs = stage;
         const unsigned char* dOs = stage + G::IMG_BYTES;
         const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
@@ -308,16 +361,25 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         const int first_rel = need_mask ? first_q - q0 - rl_lane : (int)0x80000000;   // the same in tile-local rows of this lane's registers 0 .. 3
         constexpr int KS = G::KS, NTR = 2 * G::DB;      // MFMAs per accumulator in an A phase; (dV, dK) MFMA pairs in a C phase
         constexpr int EA = 16 / (2 * KS) > 0 ? 16 / (2 * KS) : 1, EC = 16 / (2 * NTR) > 0 ? 16 / (2 * NTR) : 1;   // softmax elements per MFMA gap
-        constexpr int R = 3;                            // row fragments in flight (k-steps ahead + 1)
+        constexpr int R = IE_DKDV_ROW_AHEAD + 1;        // row fragments in flight (k-steps ahead + 1)
+        constexpr int LT = IE_DKDV_TR_AHEAD;            // transposed fragments in flight (MFMA pairs ahead)
         s16x8 rq[R], rdo[R];
+        if (IE_FLASH_ABLATE & 4) for (int i = 0; i < R; ++i) { rq[i] = kf[i]; rdo[i] = vf[i]; }
         auto fetch_rows = [&](int u) {                  // u = 0 .. 2 KS - 1: k-step u % KS of sub-block u / KS
+            if (IE_FLASH_ABLATE & 4) return;
             rq[u % R] = row_frag<D>(Qs, 32 * (u / KS), u % KS, fo);
             rdo[u % R] = row_frag<D>(dOs, 32 * (u / KS), u % KS, fo);
         };
         f32x16 s0, dp0, s1, dp1;
+        if (IE_FLASH_ABLATE & 8) { s0 = dkacc[0]; dp0 = dkacc[1]; s1 = dvacc[0]; dp1 = dvacc[1]; }
+        auto MSF = [&](f32x16& d, const s16x8& a, s16x8& b_acc) { if (!(IE_FLASH_ABLATE & 8)) mfma_s_first(d, a, b_acc); };
+        auto MS = [&](f32x16& d, const s16x8& a, s16x8& b_acc) { if (!(IE_FLASH_ABLATE & 8)) mfma_s(d, a, b_acc); };
+        auto MO = [&](f32x16& d_acc, const s16x8& a, const s16x8& b) { if (!(IE_FLASH_ABLATE & 16)) mfma_o(d_acc, a, b); };
         s16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
         float4 l4[2], d4[2];                           // lse / delta of register groups gi, gi + 1 (gi = 4 qs + r / 4): fetched one group ahead
+        if (IE_FLASH_ABLATE & 64) { l4[0] = l4[1] = make_float4(1.f, 2.f, 3.f, 4.f); d4[0] = d4[1] = make_float4(.1f, .2f, .3f, .4f); }
         auto fetch_ld = [&](int gi) {
+            if (IE_FLASH_ABLATE & 64) return;
             const int rl = 32 * (gi / 4) + 8 * (gi % 4) + rl_lane;   // tile-local row of registers 4 (r / 4) .. + 3
             l4[gi % 2] = *reinterpret_cast<const float4*>(lse_s + rl);
             d4[gi % 2] = *reinterpret_cast<const float4*>(dlt_s + rl);
@@ -326,6 +388,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         ie_f32x2 t_prev = {0.f, 0.f};
         // one element of a sub-block's softmax (register r of S / dP); behind the odd element of a pair the bf16 pack of the pair
         auto elem = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int qs, int r) {
+            if (IE_FLASH_ABLATE & 2) return;
             const int gi = 4 * qs + r / 4;
             if (r % 4 == 0 && gi + 1 < 8) fetch_ld(gi + 1);
             const float4 lq = l4[gi % 2], dq = d4[gi % 2];
@@ -352,77 +415,94 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                 dsf[r / 8] = b.x;
             }
         };
-        s16x8 tfa[2], tfb[2];                           // transposed fragments in flight: [m % 2] for dV (dO^T) and dK (Q^T)
+        s16x8 tfa[LT], tfb[LT];                         // transposed fragments in flight: [m % LT] for dV (dO^T) and dK (Q^T)
+        if (IE_FLASH_ABLATE & 1) for (int i = 0; i < LT; ++i) { tfa[i] = kf[i]; tfb[i] = vf[i]; }
+        if (IE_FLASH_ABLATE & 2) { pf0[0] = pf0[1] = pf1[0] = pf1[1] = kf[2]; dsf0[0] = dsf0[1] = dsf1[0] = dsf1[1] = vf[2]; }
         auto fetch_tr = [&](int m, int qs) {            // m = 0 .. NTR - 1: (s2, db) = (m / DB, m % DB) of sub-block qs
-            tfa[m % 2] = trans_frag<D>(dOs, m % G::DB, 2 * qs + m / G::DB, fo);
-            tfb[m % 2] = trans_frag<D>(Qs, m % G::DB, 2 * qs + m / G::DB, fo);
+            if (IE_FLASH_ABLATE & 1) return;
+            tfa[m % LT] = trans_frag<D>(dOs, m % G::DB, 2 * qs + m / G::DB, fo);
+            tfb[m % LT] = trans_frag<D>(Qs, m % G::DB, 2 * qs + m / G::DB, fo);
         };
-        fetch_rows(0);
-        fetch_rows(1);
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u) fetch_rows(u);
         fetch_ld(0);
         __builtin_amdgcn_sched_barrier(0);
+        IE_STAMP(1);
         // A0 (the fragments of sub-block 1's first k-steps are requested under its last MFMAs)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            fetch_rows(ks + 2);
+            fetch_rows(ks + R - 1);
+            if ((ks * PERW) % KS == 0) qsrc.issue_piece_asm(nxt_lds, nx.soff_q, wave, ks * PERW / KS);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) mfma_s_first(s0, rq[ks % R], kf[ks]);
-            else mfma_s(s0, rq[ks % R], kf[ks]);
-            if (ks == 0) mfma_s_first(dp0, rdo[ks % R], vf[ks]);
-            else mfma_s(dp0, rdo[ks % R], vf[ks]);
+            if (ks == 0) MSF(s0, rq[ks % R], kf[ks]);
+            else MS(s0, rq[ks % R], kf[ks]);
+            if (ks == 0) MSF(dp0, rdo[ks % R], vf[ks]);
+            else MS(dp0, rdo[ks % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        IE_STAMP(2);
         // A1 | softmax of sub-block 0
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int u = KS + ks;
-            if (ks + 2 < KS) fetch_rows(u + 2);
+            if (ks + R - 1 < KS) fetch_rows(u + R - 1);
+            if ((ks * PERW) % KS == 0) dosrc.issue_piece_asm(nxt_lds + G::IMG_BYTES, nx.soff_do, wave, ks * PERW / KS);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) mfma_s_first(s1, rq[u % R], kf[ks]);
-            else mfma_s(s1, rq[u % R], kf[ks]);
+            if (ks == 0) MSF(s1, rq[u % R], kf[ks]);
+            else MS(s1, rq[u % R], kf[ks]);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) asm volatile("s_nop 11" : "+v"(s0), "+v"(dp0));   // S0 / dP0: 12 wait states behind their last MFMA before the vector ALU reads them
 #pragma unroll
             for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + x);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) mfma_s_first(dp1, rdo[u % R], vf[ks]);
-            else mfma_s(dp1, rdo[u % R], vf[ks]);
+            if (ks == 0) MSF(dp1, rdo[u % R], vf[ks]);
+            else MS(dp1, rdo[u % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + EA + x);
-            if (ks == KS - 2) fetch_tr(0, 0);
-            if (ks == KS - 1) fetch_tr(1, 0);
+            if (ks >= KS - LT) fetch_tr(ks - (KS - LT), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        IE_STAMP(3);
         // C0 | softmax of sub-block 1
 #pragma unroll
         for (int m = 0; m < NTR; ++m) {
-            mfma_o(dvacc[m % G::DB], tfa[m % 2], pf0[m / G::DB]);
+            MO(dvacc[m % G::DB], tfa[m % LT], pf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
             if (m == 0) asm volatile("s_nop 11" : "+v"(s1), "+v"(dp1));
 #pragma unroll
             for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + x);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_o(dkacc[m % G::DB], tfb[m % 2], dsf0[m / G::DB]);
+            MO(dkacc[m % G::DB], tfb[m % LT], dsf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + EC + x);
-            if (m + 2 < NTR) fetch_tr(m + 2, 0);
-            else fetch_tr(m + 2 - NTR, 1);
+            if (m + LT < NTR) fetch_tr(m + LT, 0);
+            else fetch_tr(m + LT - NTR, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        IE_STAMP(4);
         // C1
 #pragma unroll
         for (int m = 0; m < NTR; ++m) {
-            mfma_o(dvacc[m % G::DB], tfa[m % 2], pf1[m / G::DB]);
-            mfma_o(dkacc[m % G::DB], tfb[m % 2], dsf1[m / G::DB]);
+            MO(dvacc[m % G::DB], tfa[m % LT], pf1[m / G::DB]);
+            MO(dkacc[m % G::DB], tfb[m % LT], dsf1[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
-            if (m + 2 < NTR) fetch_tr(m + 2, 1);
+            if (m + LT < NTR) fetch_tr(m + LT, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) commit(nxt, lse_r, dlt_r);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        IE_STAMP(5);
+        if (!(IE_FLASH_ABLATE & 32)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#if IE_DKDV_TIMING
+        IE_STAMP(6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tacc[i] += (unsigned)(ts[i + 1] - ts[i]);
+        tacc[6] += 1;
+#endif
     };
     auto pin = [&]() {
 #pragma unroll
@@ -437,6 +517,10 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     }
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) mfma_settle_acc(dkacc[db], dvacc[db]);
+#if IE_DKDV_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_dkdv_t[i], (unsigned long long)tacc[i]);
+#endif
 
     if (k_valid && HS == 1) {
         bf16_t* dkp = dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
@@ -539,7 +623,7 @@ extern "C" int ie_tune_flash_dkdv_split(int split) {
 
 extern "C" int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d) {
     if (T < 0 || hq <= 0 || hkv <= 0 || d <= 0) return -1;
-    return (int64_t)hq * T + 2ll * 4 * T * hkv * d;  // delta + the largest set of dK/dV partials
+    return 2ll * hq * T + 2ll * 4 * T * hkv * d;  // delta + lse2 + the largest set of dK/dV partials
 }
 
 extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
@@ -555,13 +639,14 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
                        "ie_flash_attn_bwd: pointers must be 16-byte aligned and token strides multiples of 8");
     if (nseq == 0 || T == 0 || max_seqlen == 0) return IE_OK;
     hipStream_t st = (hipStream_t)stream;
+    float* lse2 = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | lse2[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
     {
         const int64_t threads = T * hq * (d / 8);
         dim3 grid((unsigned)((threads + 255) / 256));
         if (d == 128)
-            hipLaunchKernelGGL((flash_delta_k<128>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, delta, T, hq);
+            hipLaunchKernelGGL((flash_delta_k<128>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, lse2, T, hq);
         else
-            hipLaunchKernelGGL((flash_delta_k<64>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, delta, T, hq);
+            hipLaunchKernelGGL((flash_delta_k<64>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, lse2, T, hq);
     }
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq((unsigned)hq, nt128, (unsigned)nseq);
@@ -569,10 +654,10 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
     const int hs = dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
     dim3 gk(nkb * (unsigned)hkv * (unsigned)hs, 1, (unsigned)nseq);
-    float* part = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
+    float* part = lse2 + (int64_t)hq * T;
 #define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
-                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
                        softmax_scale, part)
 #define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
     do {                                                                                                                           \
@@ -608,6 +693,17 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
 #undef IE_DKDV
 #undef IE_DKDV_HS
 #undef IE_DKDV_W
+#if IE_DKDV_TIMING
+    {
+        hipStreamSynchronize(st);
+        unsigned long long h[8] = {0}, z[8] = {0};
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dkdv_t), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_dkdv_t), z, sizeof(z));
+        const double n = h[6] ? (double)h[6] : 1.0;
+        fprintf(stderr, "dkdv cycles per wave-tile: issue %.0f A0 %.0f A1 %.0f C0 %.0f C1 %.0f sync %.0f (tiles %llu)\n", h[0] / n, h[1] / n, h[2] / n,
+                h[3] / n, h[4] / n, h[5] / n, h[6]);
+    }
+#endif
     return ie_launch_status("ie_flash_attn_bwd launch");
 }
 

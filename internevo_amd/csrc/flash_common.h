@@ -27,6 +27,7 @@
 namespace fa {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -106,6 +107,22 @@ struct TileSrc {
 #pragma unroll
         for (int q = 0; q < PERW; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, voff[q], soff, 0, 0);
+#endif
+    }
+    // Piece q (0 .. PERW - 1) of the same transfer from inline asm, for kernels with ONE wave per SIMD that place the pieces in MFMA gaps.
+    // hipcc knows nothing about it: it neither drains it before the next LDS read (an LDS-DMA it knows about is a possible writer of every
+    // LDS address: `s_waitcnt vmcnt(0)` in front of the next ds_read, i.e. the prefetch of the next tile waited for at once -- 1260 of the
+    // 4460 cycles per tile of the dK / dV kernel) nor counts it in the vmcnt waits it inserts.  The caller waits with an explicit
+    // `s_waitcnt vmcnt(n)`.  soff = row0 * ts2 + extra * 2 (bytes).
+    __device__ __forceinline__ void issue_piece_asm(uint32_t img_lds, int soff, int wave, int q) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        i32x4 rs;
+        rs[0] = (int)(uint32_t)(uintptr_t)base;
+        rs[1] = (int)(((uintptr_t)base >> 32) & 0xffff);
+        rs[2] = (int)bytes;
+        rs[3] = 0x00020000;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(img_lds + (uint32_t)((wave + NW * q) * 1024)), "v"(voff[q]), "s"(rs), "s"(soff) : "memory");
 #endif
     }
 };
