@@ -1,5 +1,5 @@
 // K1 backward: varlen, causal / full, GQA flash attention for gfx950.  Deterministic (no atomics):
-//   1. flash_delta_k : delta[h][t] = sum_d dO * O, lse2[h][t] = lse[h][t] * log2(e)
+//   1. flash_delta_k : delta[h][t] = sum_d dO * O; for the dK/dV kernel also -delta and -lse / scale
 //   2. flash_dq_k    : one block per 128 query rows, loops over K/V tiles, recomputes P, dQ += dS K
 //   3. flash_dkdv_k  : one block per 64 keys (one wave per 32 keys), loops over the q heads of the
 //                      GQA group and their query tiles, recomputes P, dV += P^T dO, dK += dS^T Q
@@ -29,12 +29,20 @@
 #ifndef IE_DKDV_TIMING
 #define IE_DKDV_TIMING 0
 #endif
+// IE_DKDV_REPEAT = 1 .. 4 (development only, results wrong): phase A0 / A1 / C0 / C1 of every tile runs twice (the transfers once), so the
+// difference to the normal build is that phase's cost in place, with nothing perturbed
+#ifndef IE_DKDV_REPEAT
+#define IE_DKDV_REPEAT 0
+#endif
 #ifndef IE_FLASH_ABLATE
 #define IE_FLASH_ABLATE 0
 #endif
 #if IE_DKDV_TIMING
 __device__ unsigned long long g_dkdv_t[8];
-#define IE_STAMP(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
+// (the wait makes the stamp's registers valid before hipcc may copy or reuse them -- without it the late result lands in whatever the register
+// holds by then -- but it also drains the LDS reads in flight: the phase behind a stamp loses part of its prefetch.  IE_DKDV_REPEAT measures
+// without that.)
+#define IE_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]) :: "memory")
 #else
 #define IE_STAMP(i)
 #endif
@@ -46,7 +54,7 @@ using namespace fa;
 template <int D>
 __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ out,
                                                      int64_t o_ts, const float* __restrict__ lse, float* __restrict__ delta,
-                                                     float* __restrict__ lse2, int64_t T, int hq) {
+                                                     float* __restrict__ nlse, float* __restrict__ ndelta, float inv_scale, int64_t T, int hq) {
     constexpr int TPP = D / 8;  // threads per (token, head) pair
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = gid / TPP;
@@ -68,7 +76,9 @@ __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ 
         const int64_t t = pair / hq;
         const int h = (int)(pair % hq);
         delta[(int64_t)h * T + t] = acc;
-        lse2[(int64_t)h * T + t] = lse[(int64_t)h * T + t] * kLog2e;   // the dK / dV kernel works in the log2 domain
+        // the dK / dV kernel starts its S and dP accumulators from these: S' = q.k - lse / scale (so P = exp2(S' * scale * log2 e)), dP' = dP - delta
+        nlse[(int64_t)h * T + t] = -lse[(int64_t)h * T + t] * inv_scale;
+        ndelta[(int64_t)h * T + t] = -acc;
     }
 }
 
@@ -221,8 +231,13 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                                                                const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale,
                                                                float* __restrict__ part) {
     using G = Geo<D>;
-    constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, lse2[64], delta[64] (+ pad to keep 1 KiB alignment)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, -lse/scale [64], -delta [64] (+ pad to keep 1 KiB alignment)
+    // Pipeline stages.  Four waves (one block per CU: the registers allow one wave per SIMD) keep three: the transfers of tile it + 2 are
+    // spread over ALL MFMA gaps of tile it (one 1-KiB piece per 8 MFMAs: the CU's vector-memory path takes 16 cycles per piece, and four
+    // waves issuing a piece per 2 MFMAs at the same moment queued ~40 cycles per piece) and have a whole tile to land.  Two waves (two
+    // blocks per CU, 2 x 66 KB of LDS) keep two: the pieces of tile it + 1 go into the first half of tile it.
+    constexpr int NST = DKV_WAVES == 4 ? 3 : 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int seq = blockIdx.z;
     // x = (key block, head split, kv head), kv head fastest: every (split, head) of the heaviest key block is dispatched first
@@ -257,40 +272,38 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     // Every transfer of a stage is issued from inline asm (flash_common.h: issue_piece_asm); the only vmcnt waits of the tile loop are the
     // explicit ones at the end of a tile.  lse2 / delta of the 64 rows: one buffer_load_dword ... lds each (lane = row), wave 0 / wave 1.
-    struct Next { int soff_q, soff_do; i32x4 rs_l, rs_d; int soff_ld; };
-    auto plan = [&](int it) {
+    struct Next { int soff_q, soff_do; i32x4 rs_ld; int soff_ld; };
+    // tiles are visited head by head, query tiles ascending; (pl_h, pl_qt) = the next tile to request, advanced without a division
+    int pl_h = h_first, pl_qt = qt_start;
+    auto plan = [&]() {
         Next n;
-        const int h = min(h_first + it / nqt, hq - 1);   // it == nit (the prefetch behind the last tile) may name a head this block does not own
-        const int q0 = (qt_start + it % nqt) * 64;
+        const int h = min(pl_h, hq - 1);   // the requests behind the last tile may name a head this block does not own: any valid address will do
+        const int q0 = pl_qt * 64;
         n.soff_q = q0 * qsrc.ts2 + h * D * 2;
         n.soff_do = q0 * dosrc.ts2 + h * D * 2;
-        const float* lp = lse + (int64_t)h * T + tok0;
-        const float* dp = delta + (int64_t)h * T + tok0;
-        n.rs_l[0] = (int)(uint32_t)(uintptr_t)lp;
-        n.rs_l[1] = (int)(((uintptr_t)lp >> 32) & 0xffff);
-        n.rs_d[0] = (int)(uint32_t)(uintptr_t)dp;
-        n.rs_d[1] = (int)(((uintptr_t)dp >> 32) & 0xffff);
-        n.rs_l[2] = n.rs_d[2] = len * 4;
-        n.rs_l[3] = n.rs_d[3] = 0x00020000;
+        const float* lp = ((wave & 1) ? delta : lse) + (int64_t)h * T + tok0;   // even waves fetch -lse/scale, odd waves -delta (every wave one
+        n.rs_ld[0] = (int)(uint32_t)(uintptr_t)lp;                               // piece: the counted wait at the end of a tile is the same for all)
+        n.rs_ld[1] = (int)(((uintptr_t)lp >> 32) & 0xffff);
+        n.rs_ld[2] = len * 4;
+        n.rs_ld[3] = 0x00020000;
         n.soff_ld = q0 * 4;
+        if (++pl_qt == nqt_all) { pl_qt = qt_start; ++pl_h; }
         return n;
     };
-    auto issue_ld = [&](const Next& n, uint32_t stage_lds) {   // wave 0: lse2, wave 1: delta
-        if (wave == 0)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(stage_lds + 2 * G::IMG_BYTES), "v"(lane * 4), "s"(n.rs_l), "s"(n.soff_ld) : "memory");
-        if (wave == 1)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(stage_lds + 2 * G::IMG_BYTES + 256), "v"(lane * 4), "s"(n.rs_d), "s"(n.soff_ld) : "memory");
+    auto issue_ld = [&](const Next& n, uint32_t stage_lds) {   // one buffer_load_dword ... lds (lane = row) per wave
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                     :: "s"(stage_lds + 2 * G::IMG_BYTES + (wave & 1) * 256), "v"(lane * 4), "s"(n.rs_ld), "s"(n.soff_ld) : "memory");
     };
     constexpr int PERW = TileSrc<D, DKV_WAVES>::PERW;
-    {
-        const Next n = plan(0);
-        issue_ld(n, smem_lds);
+    constexpr int NPIECE = 2 * PERW + 1;   // transfers per wave and tile
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) {    // tiles 0 .. NST - 2 up front
+        const Next n = plan();
+        issue_ld(n, smem_lds + t * STAGE);
 #pragma unroll
         for (int pq = 0; pq < PERW; ++pq) {
-            qsrc.issue_piece_asm(smem_lds, n.soff_q, wave, pq);
-            dosrc.issue_piece_asm(smem_lds + G::IMG_BYTES, n.soff_do, wave, pq);
+            qsrc.issue_piece_asm(smem_lds + t * STAGE, n.soff_q, wave, pq);
+            dosrc.issue_piece_asm(smem_lds + t * STAGE + G::IMG_BYTES, n.soff_do, wave, pq);
         }
     }
 
@@ -338,21 +351,33 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #if IE_DKDV_TIMING
     unsigned tacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
+    int cur_qt = qt_start;   // query tile of the step that runs next
     auto step = [&](auto stage_c, int it) {
         constexpr int S = decltype(stage_c)::value;
 #if IE_DKDV_TIMING
         unsigned long long ts[7];
 #endif
         IE_STAMP(0);
-        const int q0 = (qt_start + it % nqt) * 64;
+        const int q0 = cur_qt * 64;
+        if (++cur_qt == nqt_all) cur_qt = qt_start;
         // wave-uniform: does this tile need the mask (the diagonal tile, the last keys)?  Unmasked tiles compare against a first row that
         // no row is below, so the two extra vector instructions per element are the same in both cases (one code path: two copies of the
         // tile body -- masked / unmasked -- made hipcc spill 91 VGPRs)
         const bool need_mask = (CAUSAL && kw0 + 31 > q0) || (kw0 + 32 > len);
         const unsigned char* stage = smem + S * STAGE;
-        const Next nx = plan(it + 1);                   // the next tile's transfers go into the other stage, spread over the gaps of A0 / A1
-        const uint32_t nxt_lds = smem_lds + (1 - S) * STAGE;
+        const Next nx = plan();                         // tile it + NST - 1 goes into the stage that tile it - 1 left, its pieces into the MFMA gaps
+        const uint32_t nxt_lds = smem_lds + ((S + NST - 1) % NST) * STAGE;
         issue_ld(nx, nxt_lds);
+        // slot j = 0 .. 4 KS - 1 (A0, A1, C0, C1: one per k-step / MFMA pair).  Three stages: Q pieces over A0 + A1, dO pieces over C0 + C1;
+        // two stages: Q pieces over A0, dO pieces over A1 (they must have landed at the end of this tile)
+        auto piece_slot = [&](int j) {
+            constexpr int SPAN = NST == 3 ? 2 * G::KS : G::KS;   // slots per image
+            if (j >= 2 * SPAN) return;
+            const int jj = j % SPAN;
+            if ((jj * PERW) % SPAN != 0) return;
+            if (j < SPAN) qsrc.issue_piece_asm(nxt_lds, nx.soff_q, wave, jj * PERW / SPAN);
+            else dosrc.issue_piece_asm(nxt_lds + G::IMG_BYTES, nx.soff_do, wave, jj * PERW / SPAN);
+        };
         const unsigned char* Qs = stage;
         const unsigned char* dOs = stage + G::IMG_BYTES;
         const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
         const int first_rel = need_mask ? first_q - q0 - rl_lane : (int)0x80000000;   // the same in tile-local rows of this lane's registers 0 .. 3
         constexpr int KS = G::KS, NTR = 2 * G::DB;      // MFMAs per accumulator in an A phase; (dV, dK) MFMA pairs in a C phase
-        constexpr int EA = 16 / (2 * KS) > 0 ? 16 / (2 * KS) : 1, EC = 16 / (2 * NTR) > 0 ? 16 / (2 * NTR) : 1;   // softmax elements per MFMA gap
+        static_assert((2 * KS == 16 || 2 * KS == 8) && 2 * NTR == 2 * KS, "softmax_gap is written for 16 or 8 gaps per phase");
         constexpr int R = IE_DKDV_ROW_AHEAD + 1;        // row fragments in flight (k-steps ahead + 1)
         constexpr int LT = IE_DKDV_TR_AHEAD;            // transposed fragments in flight (MFMA pairs ahead)
         s16x8 rq[R], rdo[R];
@@ -371,48 +396,62 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             rdo[u % R] = row_frag<D>(dOs, 32 * (u / KS), u % KS, fo);
         };
         f32x16 s0, dp0, s1, dp1;
-        if (IE_FLASH_ABLATE & 8) { s0 = dkacc[0]; dp0 = dkacc[1]; s1 = dvacc[0]; dp1 = dvacc[1]; }
-        auto MSF = [&](f32x16& d, const s16x8& a, s16x8& b_acc) { if (!(IE_FLASH_ABLATE & 8)) mfma_s_first(d, a, b_acc); };
         auto MS = [&](f32x16& d, const s16x8& a, s16x8& b_acc) { if (!(IE_FLASH_ABLATE & 8)) mfma_s(d, a, b_acc); };
         auto MO = [&](f32x16& d_acc, const s16x8& a, const s16x8& b) { if (!(IE_FLASH_ABLATE & 16)) mfma_o(d_acc, a, b); };
         s16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
-        float4 l4[2], d4[2];                           // lse / delta of register groups gi, gi + 1 (gi = 4 qs + r / 4): fetched one group ahead
-        if (IE_FLASH_ABLATE & 64) { l4[0] = l4[1] = make_float4(1.f, 2.f, 3.f, 4.f); d4[0] = d4[1] = make_float4(.1f, .2f, .3f, .4f); }
-        auto fetch_ld = [&](int gi) {
-            if (IE_FLASH_ABLATE & 64) return;
-            const int rl = 32 * (gi / 4) + 8 * (gi % 4) + rl_lane;   // tile-local row of registers 4 (r / 4) .. + 3
-            l4[gi % 2] = *reinterpret_cast<const float4*>(lse_s + rl);
-            d4[gi % 2] = *reinterpret_cast<const float4*>(dlt_s + rl);
+        // S / dP accumulators start from -lse / scale and -delta of their rows (registers 4 g .. 4 g + 3 = rows 8 g + 4 (lane / 32) + 0 .. 3 of the
+        // sub-block: one ds_read_b128 each), S in a tile that needs the mask from -1e30 where the key does not see the row: P = exp2(S' * sc2)
+        // and dS = P * dP' then take mul, exp2, mul and half a pack per element
+        auto load_bias = [&](f32x16& sv, f32x16& dpv, int qs) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rl = 32 * qs + 8 * g + rl_lane;
+                const float4 a = (IE_FLASH_ABLATE & 64) ? make_float4(-1.f, -2.f, -3.f, -4.f) : *reinterpret_cast<const float4*>(lse_s + rl);
+                const float4 b = (IE_FLASH_ABLATE & 64) ? make_float4(.1f, .2f, .3f, .4f) : *reinterpret_cast<const float4*>(dlt_s + rl);
+                sv[4 * g + 0] = a.x; sv[4 * g + 1] = a.y; sv[4 * g + 2] = a.z; sv[4 * g + 3] = a.w;
+                dpv[4 * g + 0] = b.x; dpv[4 * g + 1] = b.y; dpv[4 * g + 2] = b.z; dpv[4 * g + 3] = b.w;
+            }
         };
-        float e_prev = 0.f;
-        ie_f32x2 t_prev = {0.f, 0.f};
-        // one element of a sub-block's softmax (register r of S / dP); behind the odd element of a pair the bf16 pack of the pair
-        auto elem = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int qs, int r) {
+        auto apply_mask = [&](f32x16& sv, int qs) {
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = (32 * qs + 8 * (r / 4) + r % 4) < first_rel ? -1e30f : sv[r];
+            }
+        };
+        // The softmax of a sub-block, one register pair (r, r + 1) at a time, in two halves that sit in different MFMA gaps (asm: the
+        // instructions stay where they are written, dependent ones never adjacent, no compiler-inserted wait states):
+        //   half A: x = S' * sc2 (x2), P = exp2(x) (x2)        half B: dS = P * dP' (x2), bf16 pack of P and of dS
+        // D = 128 has 16 gaps per phase for the 8 pairs (A and B alternate); D = 64 has 8 gaps: A and B of a pair share a gap.
+        float pe0 = 0.f, pe1 = 0.f;
+        const float sc2v = sc2;   // (a copy in this scope: clang does not capture the outer variable for an asm operand of a nested lambda)
+        auto half_a = [&](const f32x16& sv, int p) {
             if (IE_FLASH_ABLATE & 2) return;
-            const int gi = 4 * qs + r / 4;
-            if (r % 4 == 0 && gi + 1 < 8) fetch_ld(gi + 1);
-            const float4 lq = l4[gi % 2], dq = d4[gi % 2];
-            const float lv = r % 4 == 0 ? lq.x : r % 4 == 1 ? lq.y : r % 4 == 2 ? lq.z : lq.w;
-            float e = __builtin_amdgcn_exp2f(fms_pinned(sv[r], sc2, lv));   // lse2 = +inf for rows >= len -> 0
-            e = (32 * qs + 8 * (r / 4) + r % 4) < first_rel ? 0.f : e;
-            if (r % 2 == 0) {   // dP - delta of the pair (r, r + 1) as one packed subtract, held HERE (hipcc otherwise hoists it up to the lse / delta load and waits there)
-                e_prev = e;
-                ie_f32x2 dl;
-                dl.x = r % 4 == 0 ? dq.x : dq.z;
-                dl.y = r % 4 == 0 ? dq.y : dq.w;
-                asm volatile("" : "+v"(dl));
-                t_prev.x = dpv[r] - dl.x;
-                t_prev.y = dpv[r + 1] - dl.y;
-            } else {   // registers r - 1, r -> 32-bit word (r / 2) % 4 of fragment r / 8
-                const float ds_prev = e_prev * t_prev.x, ds = e * t_prev.y;
-                union { uint4 u; s16x8 x; } a, b;
-                a.x = pf[r / 8];
-                b.x = dsf[r / 8];
-                const unsigned pp = pack2bf(e_prev, e), dd = pack2bf(ds_prev, ds);
-                const int w = (r / 2) % 4;
-                if (w == 0) { a.u.x = pp; b.u.x = dd; } else if (w == 1) { a.u.y = pp; b.u.y = dd; } else if (w == 2) { a.u.z = pp; b.u.z = dd; } else { a.u.w = pp; b.u.w = dd; }
-                pf[r / 8] = a.x;
-                dsf[r / 8] = b.x;
+            asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\tv_exp_f32 %0, %0\n\tv_exp_f32 %1, %1"
+                         : "=&v"(pe0), "=&v"(pe1) : "v"(sv[2 * p]), "v"(sv[2 * p + 1]), "v"(sc2v));
+        };
+        auto half_b = [&](const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int p) {
+            if (IE_FLASH_ABLATE & 2) return;
+            unsigned pp, dd;
+            float t0, t1;
+            asm volatile("v_mul_f32 %2, %4, %6\n\tv_mul_f32 %3, %5, %7\n\tv_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %2, %3"
+                         : "=&v"(pp), "=&v"(dd), "=&v"(t0), "=&v"(t1) : "v"(pe0), "v"(pe1), "v"(dpv[2 * p]), "v"(dpv[2 * p + 1]));
+            union { uint4 u; s16x8 x; } a, b;   // registers 2 p, 2 p + 1 -> 32-bit word p % 4 of fragment p / 4
+            a.x = pf[p / 4];
+            b.x = dsf[p / 4];
+            const int w = p % 4;
+            if (w == 0) { a.u.x = pp; b.u.x = dd; } else if (w == 1) { a.u.y = pp; b.u.y = dd; } else if (w == 2) { a.u.z = pp; b.u.z = dd; } else { a.u.w = pp; b.u.w = dd; }
+            pf[p / 4] = a.x;
+            dsf[p / 4] = b.x;
+        };
+        // gap j (0 .. GAPS - 1) of a phase
+        auto softmax_gap = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int j, int gaps) {
+            if (gaps == 16) {
+                if (j % 2 == 0) half_a(sv, j / 2);
+                else half_b(dpv, pf, dsf, j / 2);
+            } else {   // 8 gaps
+                half_a(sv, j);
+                asm volatile("s_nop 0");   // a transcendental's result needs one wait state before a vector ALU instruction reads it
+                half_b(dpv, pf, dsf, j);
             }
         };
         s16x8 tfa[LT], tfb[LT];                         // transposed fragments in flight: [m % LT] for dV (dO^T) and dK (Q^T)
@@ -425,58 +464,61 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         };
 #pragma unroll
         for (int u = 0; u < R - 1; ++u) fetch_rows(u);
-        fetch_ld(0);
+        load_bias(s0, dp0, 0);
+        apply_mask(s0, 0);
         __builtin_amdgcn_sched_barrier(0);
         IE_STAMP(1);
         // A0 (the fragments of sub-block 1's first k-steps are requested under its last MFMAs)
 #pragma unroll
+        for (int rep = 0; rep < (IE_DKDV_REPEAT == 1 ? 2 : 1); ++rep)
+#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             fetch_rows(ks + R - 1);
-            if ((ks * PERW) % KS == 0) qsrc.issue_piece_asm(nxt_lds, nx.soff_q, wave, ks * PERW / KS);
+            if (rep == 0) piece_slot(ks);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) MSF(s0, rq[ks % R], kf[ks]);
-            else MS(s0, rq[ks % R], kf[ks]);
-            if (ks == 0) MSF(dp0, rdo[ks % R], vf[ks]);
-            else MS(dp0, rdo[ks % R], vf[ks]);
+            MS(s0, rq[ks % R], kf[ks]);
+            MS(dp0, rdo[ks % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
+            if (ks == KS / 2 - 1) load_bias(s1, dp1, 1);     // sub-block 1's starting values: requested half way, masked (diagonal tiles only) at the end
+            if (ks == KS - 1) apply_mask(s1, 1);
         }
         IE_STAMP(2);
         // A1 | softmax of sub-block 0
 #pragma unroll
+        for (int rep = 0; rep < (IE_DKDV_REPEAT == 2 ? 2 : 1); ++rep)
+#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int u = KS + ks;
             if (ks + R - 1 < KS) fetch_rows(u + R - 1);
-            if ((ks * PERW) % KS == 0) dosrc.issue_piece_asm(nxt_lds + G::IMG_BYTES, nx.soff_do, wave, ks * PERW / KS);
+            if (rep == 0) piece_slot(KS + ks);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) MSF(s1, rq[u % R], kf[ks]);
-            else MS(s1, rq[u % R], kf[ks]);
+            MS(s1, rq[u % R], kf[ks]);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) asm volatile("s_nop 11" : "+v"(s0), "+v"(dp0));   // S0 / dP0: 12 wait states behind their last MFMA before the vector ALU reads them
-#pragma unroll
-            for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + x);
+            softmax_gap(s0, dp0, pf0, dsf0, 2 * ks, 2 * KS);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) MSF(dp1, rdo[u % R], vf[ks]);
-            else MS(dp1, rdo[u % R], vf[ks]);
+            MS(dp1, rdo[u % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int x = 0; x < EA; ++x) elem(s0, dp0, pf0, dsf0, 0, 2 * EA * ks + EA + x);
+            softmax_gap(s0, dp0, pf0, dsf0, 2 * ks + 1, 2 * KS);
             if (ks >= KS - LT) fetch_tr(ks - (KS - LT), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         IE_STAMP(3);
         // C0 | softmax of sub-block 1
 #pragma unroll
+        for (int rep = 0; rep < (IE_DKDV_REPEAT == 3 ? 2 : 1); ++rep)
+#pragma unroll
         for (int m = 0; m < NTR; ++m) {
+            if (rep == 0) piece_slot(2 * KS + m);
+            __builtin_amdgcn_sched_barrier(0);
             MO(dvacc[m % G::DB], tfa[m % LT], pf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
             if (m == 0) asm volatile("s_nop 11" : "+v"(s1), "+v"(dp1));
-#pragma unroll
-            for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + x);
+            softmax_gap(s1, dp1, pf1, dsf1, 2 * m, 2 * NTR);
             __builtin_amdgcn_sched_barrier(0);
             MO(dkacc[m % G::DB], tfb[m % LT], dsf0[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int x = 0; x < EC; ++x) elem(s1, dp1, pf1, dsf1, 1, 2 * EC * m + EC + x);
+            softmax_gap(s1, dp1, pf1, dsf1, 2 * m + 1, 2 * NTR);
             if (m + LT < NTR) fetch_tr(m + LT, 0);
             else fetch_tr(m + LT - NTR, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -484,7 +526,11 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         IE_STAMP(4);
         // C1
 #pragma unroll
+        for (int rep = 0; rep < (IE_DKDV_REPEAT == 4 ? 2 : 1); ++rep)
+#pragma unroll
         for (int m = 0; m < NTR; ++m) {
+            if (rep == 0) piece_slot(3 * KS + m);
+            __builtin_amdgcn_sched_barrier(0);
             MO(dvacc[m % G::DB], tfa[m % LT], pf1[m / G::DB]);
             MO(dkacc[m % G::DB], tfb[m % LT], dsf1[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
@@ -493,12 +539,14 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         }
         IE_STAMP(5);
         if (!(IE_FLASH_ABLATE & 32)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the next tile's pieces have landed (three stages: only this tile's NPIECE requests, all younger, may still be in flight); every wave
+            // is done with this tile's stage
+            if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
 #if IE_DKDV_TIMING
         IE_STAMP(6);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 6; ++i) tacc[i] += (unsigned)(ts[i + 1] - ts[i]);
         tacc[6] += 1;
@@ -508,13 +556,18 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) pin_acc(dkacc[db], dvacc[db]);
     };
-    for (int it = 0; it < nit; it += 2) {
+    for (int it = 0; it < nit; it += NST) {
         pin();
         step(std::integral_constant<int, 0>{}, it);
         pin();
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
         pin();
+        if (NST == 3) {
+            if (it + 2 < nit) step(std::integral_constant<int, 2 % NST>{}, it + 2);
+            pin();
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer into this block's LDS may outlive the block
 #pragma unroll
     for (int db = 0; db < G::DB; ++db) mfma_settle_acc(dkacc[db], dvacc[db]);
 #if IE_DKDV_TIMING
@@ -623,7 +676,7 @@ extern "C" int ie_tune_flash_dkdv_split(int split) {
 
 extern "C" int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d) {
     if (T < 0 || hq <= 0 || hkv <= 0 || d <= 0) return -1;
-    return 2ll * hq * T + 2ll * 4 * T * hkv * d;  // delta + lse2 + the largest set of dK/dV partials
+    return 3ll * hq * T + 2ll * 4 * T * hkv * d;  // delta, -lse / scale, -delta + the largest set of dK/dV partials
 }
 
 extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
@@ -639,14 +692,18 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
                        "ie_flash_attn_bwd: pointers must be 16-byte aligned and token strides multiples of 8");
     if (nseq == 0 || T == 0 || max_seqlen == 0) return IE_OK;
     hipStream_t st = (hipStream_t)stream;
-    float* lse2 = delta + (int64_t)hq * T;  // workspace layout: delta[hq*T] | lse2[hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
+    // workspace layout: delta[hq*T] | -lse/scale [hq*T] | -delta [hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
+    float* nlse = delta + (int64_t)hq * T;
+    float* ndelta = nlse + (int64_t)hq * T;
     {
         const int64_t threads = T * hq * (d / 8);
         dim3 grid((unsigned)((threads + 255) / 256));
         if (d == 128)
-            hipLaunchKernelGGL((flash_delta_k<128>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, lse2, T, hq);
+            hipLaunchKernelGGL((flash_delta_k<128>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, nlse, ndelta,
+                               1.f / softmax_scale, T, hq);
         else
-            hipLaunchKernelGGL((flash_delta_k<64>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, lse2, T, hq);
+            hipLaunchKernelGGL((flash_delta_k<64>), grid, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)out, o_ts, lse, delta, nlse, ndelta,
+                               1.f / softmax_scale, T, hq);
     }
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq((unsigned)hq, nt128, (unsigned)nseq);
@@ -654,10 +711,10 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
     const int hs = dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
     dim3 gk(nkb * (unsigned)hkv * (unsigned)hs, 1, (unsigned)nseq);
-    float* part = lse2 + (int64_t)hq * T;
+    float* part = ndelta + (int64_t)hq * T;
 #define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
-                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
                        softmax_scale, part)
 #define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
     do {                                                                                                                           \

@@ -217,6 +217,11 @@ __device__ __forceinline__ float fma_pinned(float a, float b, float c) {
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float mul_pinned(float a, float b) {
+    float r;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // a * b - c
 __device__ __forceinline__ float fms_pinned(float a, float b, float c) {
     float r;
