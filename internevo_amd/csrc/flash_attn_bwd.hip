@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // Block = DKV_WAVES waves x 32 keys.  With causal masking the work of a key block falls linearly with its
 // position, and there are only (len/64) x hkv blocks, so (a) blocks are small (64 keys) to get >= 2 per CU and
 // (b) the block index is folded so that the two blocks dispatched far apart (the ones that share a CU under
-// round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.
+// round-robin dispatch) are a heavy and a light one: kb(j) = j for the first half, mirrored for the second.  That holds while all blocks are
+// resident at once; a grid of several rounds is dispatched heaviest-first instead (the folded order ended such a grid with medium blocks,
+// a quarter of a CU's whole work each: ~8 % of the kernel at 4 x 4096 tokens).
 
 // HS > 1 (causal balance): the q heads of a kv head are split over HS blocks, each writing fp32 partial dK / dV
 // to part[2][HS][T][hkv][D]; flash_dkdv_reduce_k sums them in a fixed order (deterministic, no atomics).  With all blocks
@@ -232,11 +234,17 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                                                                float* __restrict__ part) {
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, -lse/scale [64], -delta [64] (+ pad to keep 1 KiB alignment)
-    // Pipeline stages.  Four waves (one block per CU: the registers allow one wave per SIMD) keep three: the transfers of tile it + 2 are
-    // spread over ALL MFMA gaps of tile it (one 1-KiB piece per 8 MFMAs: the CU's vector-memory path takes 16 cycles per piece, and four
-    // waves issuing a piece per 2 MFMAs at the same moment queued ~40 cycles per piece) and have a whole tile to land.  Two waves (two
-    // blocks per CU, 2 x 66 KB of LDS) keep two: the pieces of tile it + 1 go into the first half of tile it.
-    constexpr int NST = DKV_WAVES == 4 ? 3 : 2;
+    // Pipeline stages.  Four waves (one block per CU: the registers allow one wave per SIMD) keep FOUR and work EARLY: the transfers of tile
+    // it + 2 are spread over all MFMA gaps of tile it (one 1-KiB piece per 8 MFMAs: the CU's vector-memory path takes 16 cycles per piece, and
+    // four waves issuing a piece per 2 MFMAs at the same moment queued ~40 cycles per piece); the wait + barrier of a tile sit in front of its
+    // last phase (C1), so the head of tile it + 1 (first row fragments, starting values) is fetched under C1's MFMAs instead of in front of an
+    // idle matrix pipe.  That barrier proves every wave is through C0 of tile it, i.e. done with tile it - 1: the stage of tile it - 2, the
+    // one tile it + 2 goes to, has been free for a whole tile (with three stages the target would be tile it - 1's, still read in its C1 by a
+    // wave that is behind).  Two waves (two blocks per CU, 2 x 66 KB of LDS) keep two stages: the pieces of tile it + 1 go into the first half
+    // of tile it, wait + barrier at its end.
+    constexpr int NST = DKV_WAVES == 4 ? 4 : 2;
+    constexpr bool EARLY = NST == 4;
+    constexpr int PD = EARLY ? 2 : 1;   // tiles requested ahead
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int seq = blockIdx.z;
@@ -245,8 +253,11 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int hsi = (blockIdx.x / hkv) % HS;
     const int nkb = gridDim.x / (hkv * HS);
     const int j = blockIdx.x / (hkv * HS);
+    // one round (every block resident at once: 256 CUs x 2 two-wave blocks or 1 four-wave block): folded order, see above; more rounds:
+    // heaviest first (causal: the first keys see the most query tiles), so the blocks dispatched last are the light ones
+    const bool one_round = gridDim.x * gridDim.z <= (DKV_WAVES == 4 ? 256u : 512u);
     const int first = (nkb + 1) / 2;
-    const int kb = HS > 1 ? j : (j < first ? j : nkb - 1 - (j - first));  // HS > 1: plain order = heavy blocks first
+    const int kb = (HS > 1 || !one_round) ? j : (j < first ? j : nkb - 1 - (j - first));
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     const int k0 = kb * 32 * DKV_WAVES;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     constexpr int PERW = TileSrc<D, DKV_WAVES>::PERW;
     constexpr int NPIECE = 2 * PERW + 1;   // transfers per wave and tile
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t) {    // tiles 0 .. NST - 2 up front
+    for (int t = 0; t < PD; ++t) {    // tiles 0 .. PD - 1 up front
         const Next n = plan();
         issue_ld(n, smem_lds + t * STAGE);
 #pragma unroll
@@ -309,6 +320,14 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 
     FragOffs<D> fo;
     fo.init(lane);
+    // LDS reads carry a 16-bit immediate offset: stages 2 and 3 (behind 64 KiB) are reached from a second set of per-lane offsets
+    FragOffs<D> foh = fo;
+    if (NST > 2) {
+#pragma unroll
+        for (int i = 0; i < G::KS; ++i) foh.row[i] += 2 * STAGE;
+#pragma unroll
+        for (int i = 0; i < G::DB; ++i) { foh.tr0[i] += 2 * STAGE; foh.tr1[i] += 2 * STAGE; }
+    }
 
     // K, V fragments of this wave's 32 keys (B operands: lane = key)
     s16x8 kf[G::KS], vf[G::KS];
@@ -351,73 +370,105 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #if IE_DKDV_TIMING
     unsigned tacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
-    int cur_qt = qt_start;   // query tile of the step that runs next
+    constexpr int KS = G::KS, NTR = 2 * G::DB;      // MFMAs per accumulator in an A phase; (dV, dK) MFMA pairs in a C phase
+    static_assert((2 * KS == 16 || 2 * KS == 8) && NTR == KS, "softmax_gap is written for 16 or 8 gaps per phase");
+    constexpr int R = IE_DKDV_ROW_AHEAD + 1;        // row fragments in flight (k-steps ahead + 1)
+    constexpr int LT = IE_DKDV_TR_AHEAD;            // transposed fragments in flight (MFMA pairs ahead)
+    constexpr int SPAN = EARLY ? 2 * KS : KS;       // piece slots per image: EARLY Q over A0 + A1, dO over C0 + C1; else Q over A0, dO over A1
+    // The head of a tile -- its first row fragments, the starting values of S0 / dP0 and their mask -- is state carried into step():
+    // requested at the top of the tile (two stages) or under the previous tile's C1 MFMAs (EARLY).
+    struct TileInfo { int q0; bool need_mask; int first_rel; };
+    int cur_qt = qt_start;   // query tile the next tile_info() describes
+    const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
+    auto tile_info = [&]() {
+        TileInfo ti;
+        ti.q0 = cur_qt * 64;
+        if (++cur_qt == nqt_all) cur_qt = qt_start;
+        ti.need_mask = (CAUSAL && kw0 + 31 > ti.q0) || (kw0 + 32 > len);   // wave-uniform: the diagonal tile, the last keys
+        ti.first_rel = first_q - ti.q0 - rl_lane;                           // first visible row, tile-local, relative to this lane's registers 0 .. 3
+        return ti;
+    };
+    s16x8 rq[R], rdo[R];
+    f32x16 s0, dp0;
+    TileInfo ti;
+    if (IE_FLASH_ABLATE & 4) for (int i = 0; i < R; ++i) { rq[i] = kf[i]; rdo[i] = vf[i]; }
+    // (a stage is named by its index si: stage si lies at smem + si * STAGE; the reads address it as base(si) + offsets(si))
+    auto base = [&](int si) { return smem + (si % 2) * STAGE; };
+    auto offs = [&](int si) -> const FragOffs<D>& { return si >= 2 ? foh : fo; };
+    const int bias_lane[2] = {rl_lane * 4, rl_lane * 4 + 2 * STAGE};
+    auto fetch_rows = [&](int si, int u) {   // u = 0 .. 2 KS - 1: k-step u % KS of sub-block u / KS
+        if (IE_FLASH_ABLATE & 4) return;
+        rq[u % R] = row_frag<D>(base(si), 32 * (u / KS), u % KS, offs(si));
+        rdo[u % R] = row_frag<D>(base(si) + G::IMG_BYTES, 32 * (u / KS), u % KS, offs(si));
+    };
+    // S / dP accumulators start from -lse / scale and -delta of their rows (registers 4 g .. 4 g + 3 = rows 8 g + 4 (lane / 32) + 0 .. 3 of the
+    // sub-block: one ds_read_b128 each), S in a tile that needs the mask from -1e30 where the key does not see the row: P = exp2(S' * sc2)
+    // and dS = P * dP' then take mul, exp2, mul and half a pack per element
+    auto load_bias = [&](int si, f32x16& sv, f32x16& dpv, int qs) {
+        const unsigned char* lse_s = base(si) + 2 * G::IMG_BYTES + bias_lane[si >= 2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rb = (32 * qs + 8 * g) * 4;
+            const float4 a = (IE_FLASH_ABLATE & 64) ? make_float4(-1.f, -2.f, -3.f, -4.f) : *reinterpret_cast<const float4*>(lse_s + rb);
+            const float4 b = (IE_FLASH_ABLATE & 64) ? make_float4(.1f, .2f, .3f, .4f) : *reinterpret_cast<const float4*>(lse_s + 256 + rb);
+            sv[4 * g + 0] = a.x; sv[4 * g + 1] = a.y; sv[4 * g + 2] = a.z; sv[4 * g + 3] = a.w;
+            dpv[4 * g + 0] = b.x; dpv[4 * g + 1] = b.y; dpv[4 * g + 2] = b.z; dpv[4 * g + 3] = b.w;
+        }
+    };
+    auto apply_mask = [&](const TileInfo& t, f32x16& sv, int qs) {
+        if (t.need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = (32 * qs + 8 * (r / 4) + r % 4) < t.first_rel ? -1e30f : sv[r];
+        }
+    };
+    // number of this tile's transfers issued before slot `upto`
+    auto pieces_before = [](int upto) constexpr {
+        int n = 1;
+        for (int j = 0; j < upto && j < 2 * SPAN; ++j) n += ((j % SPAN) * PERW) % SPAN == 0;
+        return n;
+    };
+
+    // One query tile (64 rows = two 32-row sub-blocks) of one q head against this wave's 32 keys.  The serial chain
+    //   S / dP MFMAs -> softmax -> packing -> dV / dK MFMAs
+    // of the two sub-blocks is interleaved:
+    //   A0: S0 / dP0 MFMAs            | row fragments fetched two k-steps ahead; starting values of S1 / dP1
+    //   A1: S1 / dP1 MFMAs            | softmax of sub-block 0, one register pair per two gaps
+    //   C0: dV / dK MFMAs of block 0  | softmax of sub-block 1 likewise; transposed fragments fetched two MFMA pairs ahead
+    //   C1: dV / dK MFMAs of block 1  | EARLY: the head of the next tile
+    // and the transfers of a later tile go into the gaps one piece at a time.  MFMAs are asm with explicit register files (flash_common.h):
+    // dK / dV accumulators and the K / V fragments live in AGPRs, the scores in arch VGPRs.  Every gap is pinned by sched_barrier.  A
+    // sub-block that is masked entirely or lies behind the sequence is computed like the others and contributes zeros.
     auto step = [&](auto stage_c, int it) {
         constexpr int S = decltype(stage_c)::value;
 #if IE_DKDV_TIMING
         unsigned long long ts[7];
 #endif
         IE_STAMP(0);
-        const int q0 = cur_qt * 64;
-        if (++cur_qt == nqt_all) cur_qt = qt_start;
-        // wave-uniform: does this tile need the mask (the diagonal tile, the last keys)?  Unmasked tiles compare against a first row that
-        // no row is below, so the two extra vector instructions per element are the same in both cases (one code path: two copies of the
-        // tile body -- masked / unmasked -- made hipcc spill 91 VGPRs)
-        const bool need_mask = (CAUSAL && kw0 + 31 > q0) || (kw0 + 32 > len);
-        const unsigned char* stage = smem + S * STAGE;
-        const Next nx = plan();                         // tile it + NST - 1 goes into the stage that tile it - 1 left, its pieces into the MFMA gaps
-        const uint32_t nxt_lds = smem_lds + ((S + NST - 1) % NST) * STAGE;
+        constexpr int NS = (S + 1) % NST;               // the next tile's stage
+        if (!EARLY) {
+            ti = tile_info();
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u) fetch_rows(S, u);
+            load_bias(S, s0, dp0, 0);
+            apply_mask(ti, s0, 0);
+        }
+        const TileInfo tc = ti;                          // this tile (ti is overwritten with the next tile's under C1 when EARLY)
+        const Next nx = plan();                          // tile it + PD goes into a stage no wave reads any more, its pieces into the MFMA gaps
+        const uint32_t nxt_lds = smem_lds + ((S + PD) % NST) * STAGE;
         issue_ld(nx, nxt_lds);
-        // slot j = 0 .. 4 KS - 1 (A0, A1, C0, C1: one per k-step / MFMA pair).  Three stages: Q pieces over A0 + A1, dO pieces over C0 + C1;
-        // two stages: Q pieces over A0, dO pieces over A1 (they must have landed at the end of this tile)
-        auto piece_slot = [&](int j) {
-            constexpr int SPAN = NST == 3 ? 2 * G::KS : G::KS;   // slots per image
+        auto piece_slot = [&](int j) {                   // slot j = 0 .. 4 KS - 1 (A0, A1, C0, C1: one per k-step / MFMA pair)
             if (j >= 2 * SPAN) return;
             const int jj = j % SPAN;
             if ((jj * PERW) % SPAN != 0) return;
             if (j < SPAN) qsrc.issue_piece_asm(nxt_lds, nx.soff_q, wave, jj * PERW / SPAN);
             else dosrc.issue_piece_asm(nxt_lds + G::IMG_BYTES, nx.soff_do, wave, jj * PERW / SPAN);
         };
-        const unsigned char* Qs = stage;
-        const unsigned char* dOs = stage + G::IMG_BYTES;
-        const float* lse_s = reinterpret_cast<const float*>(stage + 2 * G::IMG_BYTES);
-        const float* dlt_s = lse_s + 64;
-        const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
-        const int first_rel = need_mask ? first_q - q0 - rl_lane : (int)0x80000000;   // the same in tile-local rows of this lane's registers 0 .. 3
-        constexpr int KS = G::KS, NTR = 2 * G::DB;      // MFMAs per accumulator in an A phase; (dV, dK) MFMA pairs in a C phase
-        static_assert((2 * KS == 16 || 2 * KS == 8) && 2 * NTR == 2 * KS, "softmax_gap is written for 16 or 8 gaps per phase");
-        constexpr int R = IE_DKDV_ROW_AHEAD + 1;        // row fragments in flight (k-steps ahead + 1)
-        constexpr int LT = IE_DKDV_TR_AHEAD;            // transposed fragments in flight (MFMA pairs ahead)
-        s16x8 rq[R], rdo[R];
-        if (IE_FLASH_ABLATE & 4) for (int i = 0; i < R; ++i) { rq[i] = kf[i]; rdo[i] = vf[i]; }
-        auto fetch_rows = [&](int u) {                  // u = 0 .. 2 KS - 1: k-step u % KS of sub-block u / KS
-            if (IE_FLASH_ABLATE & 4) return;
-            rq[u % R] = row_frag<D>(Qs, 32 * (u / KS), u % KS, fo);
-            rdo[u % R] = row_frag<D>(dOs, 32 * (u / KS), u % KS, fo);
-        };
-        f32x16 s0, dp0, s1, dp1;
+        const unsigned char* Qs = base(S);
+        const unsigned char* dOs = Qs + G::IMG_BYTES;
+        f32x16 s1, dp1;
         auto MS = [&](f32x16& d, const s16x8& a, s16x8& b_acc) { if (!(IE_FLASH_ABLATE & 8)) mfma_s(d, a, b_acc); };
         auto MO = [&](f32x16& d_acc, const s16x8& a, const s16x8& b) { if (!(IE_FLASH_ABLATE & 16)) mfma_o(d_acc, a, b); };
         s16x8 pf0[2], dsf0[2], pf1[2], dsf1[2];
-        // S / dP accumulators start from -lse / scale and -delta of their rows (registers 4 g .. 4 g + 3 = rows 8 g + 4 (lane / 32) + 0 .. 3 of the
-        // sub-block: one ds_read_b128 each), S in a tile that needs the mask from -1e30 where the key does not see the row: P = exp2(S' * sc2)
-        // and dS = P * dP' then take mul, exp2, mul and half a pack per element
-        auto load_bias = [&](f32x16& sv, f32x16& dpv, int qs) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rl = 32 * qs + 8 * g + rl_lane;
-                const float4 a = (IE_FLASH_ABLATE & 64) ? make_float4(-1.f, -2.f, -3.f, -4.f) : *reinterpret_cast<const float4*>(lse_s + rl);
-                const float4 b = (IE_FLASH_ABLATE & 64) ? make_float4(.1f, .2f, .3f, .4f) : *reinterpret_cast<const float4*>(dlt_s + rl);
-                sv[4 * g + 0] = a.x; sv[4 * g + 1] = a.y; sv[4 * g + 2] = a.z; sv[4 * g + 3] = a.w;
-                dpv[4 * g + 0] = b.x; dpv[4 * g + 1] = b.y; dpv[4 * g + 2] = b.z; dpv[4 * g + 3] = b.w;
-            }
-        };
-        auto apply_mask = [&](f32x16& sv, int qs) {
-            if (need_mask) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sv[r] = (32 * qs + 8 * (r / 4) + r % 4) < first_rel ? -1e30f : sv[r];
-            }
-        };
         // The softmax of a sub-block, one register pair (r, r + 1) at a time, in two halves that sit in different MFMA gaps (asm: the
         // instructions stay where they are written, dependent ones never adjacent, no compiler-inserted wait states):
         //   half A: x = S' * sc2 (x2), P = exp2(x) (x2)        half B: dS = P * dP' (x2), bf16 pack of P and of dS
@@ -443,8 +494,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             pf[p / 4] = a.x;
             dsf[p / 4] = b.x;
         };
-        // gap j (0 .. GAPS - 1) of a phase
-        auto softmax_gap = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int j, int gaps) {
+        auto softmax_gap = [&](const f32x16& sv, const f32x16& dpv, s16x8 (&pf)[2], s16x8 (&dsf)[2], int j, int gaps) {   // gap j of a phase
             if (gaps == 16) {
                 if (j % 2 == 0) half_a(sv, j / 2);
                 else half_b(dpv, pf, dsf, j / 2);
@@ -459,13 +509,9 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         if (IE_FLASH_ABLATE & 2) { pf0[0] = pf0[1] = pf1[0] = pf1[1] = kf[2]; dsf0[0] = dsf0[1] = dsf1[0] = dsf1[1] = vf[2]; }
         auto fetch_tr = [&](int m, int qs) {            // m = 0 .. NTR - 1: (s2, db) = (m / DB, m % DB) of sub-block qs
             if (IE_FLASH_ABLATE & 1) return;
-            tfa[m % LT] = trans_frag<D>(dOs, m % G::DB, 2 * qs + m / G::DB, fo);
-            tfb[m % LT] = trans_frag<D>(Qs, m % G::DB, 2 * qs + m / G::DB, fo);
+            tfa[m % LT] = trans_frag<D>(dOs, m % G::DB, 2 * qs + m / G::DB, offs(S));
+            tfb[m % LT] = trans_frag<D>(Qs, m % G::DB, 2 * qs + m / G::DB, offs(S));
         };
-#pragma unroll
-        for (int u = 0; u < R - 1; ++u) fetch_rows(u);
-        load_bias(s0, dp0, 0);
-        apply_mask(s0, 0);
         __builtin_amdgcn_sched_barrier(0);
         IE_STAMP(1);
         // A0 (the fragments of sub-block 1's first k-steps are requested under its last MFMAs)
@@ -473,14 +519,14 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         for (int rep = 0; rep < (IE_DKDV_REPEAT == 1 ? 2 : 1); ++rep)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            fetch_rows(ks + R - 1);
+            fetch_rows(S, ks + R - 1);
             if (rep == 0) piece_slot(ks);
             __builtin_amdgcn_sched_barrier(0);
             MS(s0, rq[ks % R], kf[ks]);
             MS(dp0, rdo[ks % R], vf[ks]);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == KS / 2 - 1) load_bias(s1, dp1, 1);     // sub-block 1's starting values: requested half way, masked (diagonal tiles only) at the end
-            if (ks == KS - 1) apply_mask(s1, 1);
+            if (ks == KS / 2 - 1) load_bias(S, s1, dp1, 1);   // sub-block 1's starting values: requested half way, masked (diagonal tiles only) at the end
+            if (ks == KS - 1) apply_mask(tc, s1, 1);
         }
         IE_STAMP(2);
         // A1 | softmax of sub-block 0
@@ -489,7 +535,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int u = KS + ks;
-            if (ks + R - 1 < KS) fetch_rows(u + R - 1);
+            if (ks + R - 1 < KS) fetch_rows(S, u + R - 1);
             if (rep == 0) piece_slot(KS + ks);
             __builtin_amdgcn_sched_barrier(0);
             MS(s1, rq[u % R], kf[ks]);
@@ -524,25 +570,35 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             __builtin_amdgcn_sched_barrier(0);
         }
         IE_STAMP(4);
+        if (EARLY && !(IE_FLASH_ABLATE & 32)) {
+            // EARLY: the next tile's pieces (requested a tile ago) have landed -- only this tile's, all younger, may still be in flight -- and
+            // every wave is done with the previous tile's stage.  The next tile's head goes under the MFMAs of C1.
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(pieces_before(3 * KS)) : "memory");
+            __syncthreads();
+        }
+        if (EARLY) ti = tile_info();
         // C1
 #pragma unroll
         for (int rep = 0; rep < (IE_DKDV_REPEAT == 4 ? 2 : 1); ++rep)
 #pragma unroll
         for (int m = 0; m < NTR; ++m) {
             if (rep == 0) piece_slot(3 * KS + m);
+            if (EARLY && rep == 0) {
+                if (m < R - 1) fetch_rows(NS, m);
+                if (m == R - 1) load_bias(NS, s0, dp0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             MO(dvacc[m % G::DB], tfa[m % LT], pf1[m / G::DB]);
             MO(dkacc[m % G::DB], tfb[m % LT], dsf1[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
             if (m + LT < NTR) fetch_tr(m + LT, 1);
+            if (EARLY && rep == 0 && m == NTR - 1) apply_mask(ti, s0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         IE_STAMP(5);
-        if (!(IE_FLASH_ABLATE & 32)) {
-            // the next tile's pieces have landed (three stages: only this tile's NPIECE requests, all younger, may still be in flight); every wave
-            // is done with this tile's stage
-            if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPIECE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!EARLY && !(IE_FLASH_ABLATE & 32)) {
+            // the next tile's pieces have landed; every wave is done with this tile's stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
 #if IE_DKDV_TIMING
@@ -556,14 +612,23 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #pragma unroll
         for (int db = 0; db < G::DB; ++db) pin_acc(dkacc[db], dvacc[db]);
     };
+    if (EARLY) {   // the head of tile 0
+        ti = tile_info();
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u) fetch_rows(0, u);
+        load_bias(0, s0, dp0, 0);
+        apply_mask(ti, s0, 0);
+    }
     for (int it = 0; it < nit; it += NST) {
         pin();
         step(std::integral_constant<int, 0>{}, it);
         pin();
         if (it + 1 < nit) step(std::integral_constant<int, 1>{}, it + 1);
         pin();
-        if (NST == 3) {
+        if (NST == 4) {
             if (it + 2 < nit) step(std::integral_constant<int, 2 % NST>{}, it + 2);
+            pin();
+            if (it + 3 < nit) step(std::integral_constant<int, 3 % NST>{}, it + 3);
             pin();
         }
     }

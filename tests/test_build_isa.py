@@ -37,3 +37,37 @@ def test_kernels_with_untracked_lds_reads_use_no_scratch(tmp_path):
             checked += 1
             assert int(scratch) == 0 and int(spills) == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs next to untracked LDS reads"
     assert checked >= 10, checked
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.timeout(600)
+def test_dkdv_kernel_keeps_its_register_files(tmp_path):
+    """The dK / dV attention kernel (flash_attn_bwd.hip) issues its MFMAs, its softmax and its LDS-DMA transfers from inline asm with explicit
+    register files: accumulators and K / V fragments in AGPRs across the tile loop, the transfers unknown to hipcc.  What the build must keep:
+    no scratch, no spills, no accumulator traffic between the register files inside the tile loop (hipcc once carried all 128 accumulator
+    registers in arch VGPRs around the loop edge: 256 v_accvgpr moves per tile), and no compiler-inserted `s_waitcnt vmcnt` in the loop (the
+    explicit ones sit in asm blocks): such a wait drains the transfers of the tiles ahead."""
+    out = tmp_path / "fbwd.s"
+    src = os.path.join(ROOT, "internevo_amd", "csrc", "flash_attn_bwd.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-I",
+                    os.path.join(ROOT, "include"), "-I", os.path.dirname(src), src, "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*flash_dkdv_kI\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(kernels) >= 24, f"metadata not parsed ({len(kernels)} kernels)"
+    for name, scratch, spills in kernels:
+        assert int(scratch) == 0 and int(spills) == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs"
+    checked = 0
+    for m in re.finditer(r"^(_ZN\S*flash_dkdv_kI\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        body = m.group(2)
+        start = body.find("Loop Header")
+        assert start > 0, m.group(1)
+        end = max(mm.end() for mm in re.finditer(r"s_cbranch_scc[01] \.LBB", body))
+        assert end > start, m.group(1)   # the back edge of the tile loop
+        loop = body[start:end]
+        assert loop.count("v_mfma_f32_32x32x16_bf16") >= 32, m.group(1)   # at least one whole tile
+        # strip the inline-asm blocks: what is left is hipcc's own code
+        own = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", loop, flags=re.S)
+        assert "v_accvgpr" not in own, f"{m.group(1)}: accumulator registers moved between the files inside the tile loop"
+        assert "vmcnt" not in own, f"{m.group(1)}: compiler-inserted vmcnt wait inside the tile loop"
+        checked += 1
+    assert checked >= 24, checked
