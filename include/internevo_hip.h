@@ -264,8 +264,9 @@ int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, const void* v,
                       void* out, int64_t o_ts, float* lse, const int32_t* cu_seqlens, int nseq,
                       int64_t T, int max_seqlen, int hq, int hkv, int d, float softmax_scale,
                       int causal, void* stream);
-/* delta: fp32 workspace of ie_flash_attn_bwd_workspace(T, hq, hkv, d) floats (delta[hq, T] followed by the deterministic
- * per-head-split partial dK / dV sums of the causal-balanced dK/dV kernel).  dq [T,hq,d] (stride dq_ts), dk/dv [T,hkv,d]
+/* delta: fp32 workspace of ie_flash_attn_bwd_workspace(T, hq, hkv, d) floats (delta[hq, T], then -lse / scale [hq, T] and -delta [hq, T],
+ * the start values of the dK/dV kernel's S / dP accumulators, then the deterministic per-head-split partial dK / dV sums of the
+ * causal-balanced dK/dV kernel).  dq [T,hq,d] (stride dq_ts), dk/dv [T,hkv,d]
  * (stride dkv_ts). */
 int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d);
 int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k,
