@@ -523,6 +523,46 @@ def test_flash_bwd_dkdv_head_split_and_trailing_tokens(dev, split):
     assert bool((dkv[200:] == 7.0).all()), "rows of tokens outside every sequence must not be written"
 
 
+@pytest.mark.parametrize("lens,hq,hkv,d,causal,split", [
+    ([300, 700, 257], 4, 2, 128, True, 0),     # ragged; key blocks of 128 with idle waves; 1 .. 11 query tiles per block
+    ([1, 129, 64, 512], 4, 1, 64, True, 0),    # a one-token sequence, head dim 64 (8 MFMA gaps per phase)
+    ([333, 90], 2, 2, 128, False, 0),          # full attention: every block sees every query tile
+    ([1100], 8, 2, 128, True, 2),              # more tiles per block than LDS stages, with the head split (fp32 partial sums)
+    ([64, 65, 127, 128, 129], 2, 1, 128, True, 0),   # 1 .. 3 tiles per block: fewer than the four pipeline stages
+])
+def test_flash_bwd_four_wave_dkdv_blocks(dev, lens, hq, hkv, d, causal, split):
+    """ie_tune_flash_bwd_variant(1): the dK/dV kernel with four waves per block, four LDS stages, transfers requested two tiles ahead and
+    the tile barrier in front of the last phase (the next tile's first fragments and start values are fetched under it).  Against the
+    oracle, and bit-identical to the default two-wave kernel (same arithmetic per key, same order of the query tiles)."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(90)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(91)))
+    do = bf(torch.randn(T, hq, d, generator=g(92)))
+    q32, kv32 = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, causal)
+    (ref * do.float()).sum().backward()
+    qd, kvd, cud = q.to(dev), kv.to(dev), cu.to(dev)
+    out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cud, max(lens), None, causal)
+    got = {}
+    try:
+        L.ie_tune_flash_dkdv_split(split)
+        for variant in (0, 1):
+            assert L.ie_tune_flash_bwd_variant(variant) == 0
+            got[variant] = [t.clone() for t in K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cud, max(lens), None, causal)]
+    finally:
+        L.ie_tune_flash_bwd_variant(0)
+        L.ie_tune_flash_dkdv_split(0)
+    dq, dk, dv = got[1]
+    close(dq, q32.grad, 2e-2, 3e-2, "dq (four-wave dK/dV build)")
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "dk four waves")
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv four waves")
+    assert torch.equal(got[0][1], dk) and torch.equal(got[0][2], dv), "the two block shapes must give bit-identical dK / dV"
+
+
 # ---------------------------------------------------------------------------------------------- edge cases of the C ABI
 def test_empty_inputs_are_no_ops(dev):
     """Zero rows / zero tokens / zero-sized products: every entry point returns success without launching (the reference's torch
