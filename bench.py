@@ -90,7 +90,8 @@ def main():
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
                                                                   "(needed for --seq-len 32768 on one GPU); changes the Megatron flops factor to 4")
     ap.add_argument("--micro-num", type=int, default=None, help="override data.micro_num (gradient accumulation steps)")
-    ap.add_argument("--pp", type=int, default=1, help="pipeline-parallel size (non-interleaved 1F1B, parallel.pipeline=dict(size=pp)); "
+    ap.add_argument("--num-chunks", type=int, default=1, help="model chunks per pipeline stage (model.num_chunks; > 1 = interleaved 1F1B; needs --pp > 1)")
+    ap.add_argument("--pp", type=int, default=1, help="pipeline-parallel size (1F1B, parallel.pipeline=dict(size=pp)); "
                     "N must be a multiple of it; data parallelism + ZeRO-1 run inside a stage")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Megatron 'mtp') group size, parallel.tensor=dict(size=tp, mode='mtp'); "
                                                        "must divide --gpus; data parallel size = gpus / tp")
@@ -126,6 +127,7 @@ def main():
     cfg.train.sp_size = args.sp
     cfg.train.tp_size = args.tp
     cfg.train.pp_size = args.pp
+    cfg.train.num_chunks = args.num_chunks if args.pp > 1 else 1
     cfg.model.checkpoint = args.checkpoint
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
@@ -215,7 +217,7 @@ def main():
                    "micro_batch_execution": ("merged: the micro_num micro-batches of a step run as one varlen pass" if eng.mm > 1 else
                                              "sequential gradient accumulation" + (", weight gradients batched over the micro-batches" if eng.batch_wgrad else "")),
                    "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp * args.pp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")
-                   + (f" x pp{args.pp} (1F1B)" if args.pp > 1 else "")},
+                   + (f" x pp{args.pp} ({'interleaved ' if args.num_chunks > 1 else ''}1F1B{f', {args.num_chunks} chunks' if args.num_chunks > 1 else ''})" if args.pp > 1 else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,

@@ -122,7 +122,8 @@ class TrainConfig:
     zero1_size: int = -1
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
     tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
-    pp_size: int = 1                # parallel.pipeline = dict(size=pp): non-interleaved 1F1B pipeline parallelism (pipeline.py)
+    pp_size: int = 1                # parallel.pipeline = dict(size=pp): 1F1B pipeline parallelism (pipeline.py)
+    num_chunks: int = 1             # model.num_chunks: model chunks per pipeline stage (> 1: the interleaved 1F1B schedule)
 
     @property
     def packed_length(self):
@@ -208,8 +209,15 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.apply_post_layer_norm")
     if m.get("embed_grad_scale", 1) != 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.embed_grad_scale != 1")
-    if m.get("num_chunks", 1) != 1:
-        raise NotImplementedError(f"{_UNSUPPORTED}: model.num_chunks != 1 (interleaved pipeline stages)")
+    num_chunks = int(m.get("num_chunks", 1))
+    if num_chunks > 1:
+        # InterleavedPipelineScheduler (pipeline_scheduler.py:736-757) and partition_uniform (pipeline_utils.py:9-12) assert the same
+        if pp_size == 1:
+            num_chunks = 1   # (without pipeline parallelism the chunks of a rank are one model: nothing to interleave)
+        elif d["micro_num"] % pp_size:
+            raise ValueError(f"num_microbatches: {d['micro_num']} must be an integer multiple of pipeline parallel world size")
+        elif m["num_layers"] % num_chunks:
+            raise ValueError("Layer length should be divided by the number of chunks, otherwise parameter method is recomended")
     for key in ("drop_rate", "attn_drop_rate", "dropout"):
         if m.get(key, 0):
             raise NotImplementedError(f"{_UNSUPPORTED}: model.{key} > 0 (the path trains without dropout)")
@@ -243,7 +251,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size,
+        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size, num_chunks=num_chunks,
     )
     return PathConfig(model, train)
 

@@ -33,7 +33,7 @@ from .config import PathConfig
 from .layout import FlatLayout
 from .schedule import Beta2Scheduler, CosineWarmupLR
 from .seqpar import SeqParallel
-from .pipeline import PipeParallel, partition_uniform
+from .pipeline import PipeParallel, interleaved_plan, partition_chunks, partition_uniform
 from .tensorpar import TensorParallel
 from .zero import ZeroComm
 
@@ -43,7 +43,7 @@ BF16 = torch.bfloat16
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
@@ -71,7 +71,16 @@ class InternLM2Engine:
                                       "no activation checkpointing) in this round")
         self.pp = pp_size
         self.pipe = PipeParallel(pp_size, rank, world_size)
-        self.l0, l1 = partition_uniform(mc.num_layers, pp_size)[self.pipe.stage]   # this stage's layers [l0, l1) in the reference's numbering
+        # this stage's layers in the reference's numbering: one range, or one range per model chunk (interleaved schedule); `chunks` = the
+        # same ranges in local layer indices, `gid[l]` = the global number of local layer l
+        nch = int(getattr(tc, "num_chunks", 1) if num_chunks is None else num_chunks) if pp_size > 1 else 1
+        ranges = partition_chunks(mc.num_layers, pp_size, nch)[self.pipe.stage] if nch > 1 else [partition_uniform(mc.num_layers, pp_size)[self.pipe.stage]]
+        self.gid = [l for lo, hi in ranges for l in range(lo, hi)]
+        self.chunks, n0 = [], 0
+        for lo, hi in ranges:
+            self.chunks.append((n0, n0 + hi - lo))
+            n0 += hi - lo
+        self.nch = nch
         if pp_size > 1:   # data parallelism and ZeRO-1 run inside a stage
             process_group, world_size, rank = self.pipe.dp_group, self.pipe.dp_world, self.pipe.dp_rank
             self.world, self.rank = world_size, rank
@@ -84,7 +93,7 @@ class InternLM2Engine:
                                       "run with vocab_parallel=False")
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
         if pp_size > 1:
-            self.lmc = dataclasses.replace(self.lmc, num_layers=l1 - self.l0)
+            self.lmc = dataclasses.replace(self.lmc, num_layers=len(self.gid))
         if tp_size > 1:
             # data parallelism and ZeRO-1 run over the ranks that hold the same shard
             process_group, world_size, rank = self.tpar.dp_group, self.tpar.dp_world, self.tpar.dp_rank
@@ -97,7 +106,7 @@ class InternLM2Engine:
         if world_size % zs:
             raise ValueError(f"parallel.zero1.size = {zs} must divide the data-parallel size {world_size}")
         self.world, self.rank = zs, rank % zs
-        self.layout = FlatLayout(self.lmc, zs, self.l0, self.pipe.first, self.pipe.last)
+        self.layout = FlatLayout(self.lmc, zs, self.gid, self.pipe.first, self.pipe.last)
         L = self.layout
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs)
         self.sp = sp_size
@@ -320,7 +329,7 @@ class InternLM2Engine:
 
     # ------------------------------------------------------------------------------------------ forward / backward
     def _w13(self, l):
-        s = self.layout.params[f"layers.{self.l0 + l}.feed_forward.w1.weight"]
+        s = self.layout.params[f"layers.{self.gid[l]}.feed_forward.w1.weight"]
         F, h = self.lmc.ffn_dim, self.lmc.hidden_size
         return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
 
@@ -334,8 +343,8 @@ class InternLM2Engine:
         F, eps = mc.ffn_dim, mc.layer_norm_epsilon
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, s = self.p, self.slot[l]
-        pre = f"layers.{self.l0 + l}."   # (l counts this stage's layers; the names carry the reference's global layer numbers)
-        if l == 0 or recompute:
+        pre = f"layers.{self.gid[l]}."   # (l counts this stage's layers; the names carry the reference's global layer numbers)
+        if prev_ffn_out is None or recompute:   # (the first layer of the model / of a pipeline stage / of a model chunk: its input is in a_x[l])
             K.rmsnorm_fwd(self.a_x[l], p[pre + "attention_norm.weight"], eps, self.a_n1[s], self.a_rstd1[s])
         else:
             K.add_rmsnorm_fwd(prev_ffn_out, self.a_r2[self.slot[l - 1]], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[s], self.a_rstd1[s])
@@ -363,22 +372,31 @@ class InternLM2Engine:
         K.linear_fwd(self.t_act, p[pre + "feed_forward.w2.weight"], self.t_h1)
         return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
 
-    def _forward_micro(self, ids, labels, cu, pos, max_seqlen, nseg=None):
+    def _chunk(self, chunk):
+        """(first local layer, end, is the model's first part, is its last part) of a forward / backward pass: the whole stage, or one of
+        its model chunks under the interleaved pipeline schedule."""
+        if chunk is None:
+            return 0, self.lmc.num_layers, self.pipe.first, self.pipe.last
+        la, lb = self.chunks[chunk]
+        return la, lb, self.pipe.first and chunk == 0, self.pipe.last and chunk == self.nch - 1
+
+    def _forward_micro(self, ids, labels, cu, pos, max_seqlen, nseg=None, chunk=None):
         mc = self.lmc   # (this stage's layer count under pipeline parallelism)
         L, eps = mc.num_layers, mc.layer_norm_epsilon
+        la, lb, is_first, is_last = self._chunk(chunk)
         p = self.p
         self._wait_bucket(0)              # bucket b's AdamW / all-gather of the previous step() may still be running on the optimizer stream
-        if self.pipe.first:
+        if is_first:
             K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
-        # (a later pipeline stage received its input -- the previous stage's output -- straight into a_x[0])
+        # (a later pipeline stage / model chunk received its input -- the previous one's output -- straight into a_x[la])
         ffn_out = None
-        for l in range(L):
+        for l in range(la, lb):
             self._wait_bucket(1 + l)
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
-        self._wait_bucket(L + 1)
-        if not self.pipe.last:   # the stage's output = the residual stream after its last layer; norm, head and loss live on the last stage
-            torch.add(ffn_out, self.a_r2[self.slot[L - 1]], out=self.t_send)
+        if not is_last:   # the output = the residual stream after the last layer; norm, head and loss live behind the model's last layer
+            torch.add(ffn_out, self.a_r2[self.slot[lb - 1]], out=self.t_send)
             return
+        self._wait_bucket(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
         if self.mm > 1:
@@ -439,9 +457,10 @@ class InternLM2Engine:
             self.t_nll[r].copy_(rows)
             self.metric.update_fused(self.t_nll[r], am, lab)
 
-    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False):
+    def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False, chunk=None):
         mc, tc = self.lmc, self.tc
         L, F = mc.num_layers, mc.ffn_dim
+        la, lb, is_first, is_last = self._chunk(chunk)
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, g = self.p, self.g
         T = self.T
@@ -461,7 +480,7 @@ class InternLM2Engine:
             elif last_micro:  # every micro-batch's rows are in place: one GEMM over micro_num * T tokens
                 K.linear_wgrad(dy_all, x_all, gw, False)
 
-        if self.pipe.last:
+        if is_last:
             # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
             # forward: a label owned by another rank is valid without a one-hot term here)
             lab_b = self.t_lab_local if self.vp else labels
@@ -480,14 +499,14 @@ class InternLM2Engine:
             if ar is not None:
                 ar.wait()
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
-        if self.pipe.last:
+        if is_last:
             K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
             if last_micro:
                 self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
-        # (an earlier pipeline stage received the gradient of its output from the next stage straight into t_h1 = d_out)
+        # (an earlier pipeline stage / model chunk received the gradient of its output from the next one into t_h1 = d_out)
         spare = [self.t_h0, self.t_h2]
-        for l in range(L - 1, -1, -1):
-            pre = f"layers.{self.l0 + l}."
+        for l in range(lb - 1, la - 1, -1):
+            pre = f"layers.{self.gid[l]}."
             w13, gw13 = self._w13(l)
             sl = self.slot[l]
             if l < mc.checkpoint_layers:
@@ -536,8 +555,8 @@ class InternLM2Engine:
             d_out = d_x
             if last_micro:
                 self.comm.reduce_bucket_async(self.grads, 1 + l)
-        if not self.pipe.first:
-            return d_out   # gradient of this stage's input: travels to the previous stage
+        if not is_first:
+            return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, 0)
@@ -563,7 +582,7 @@ class InternLM2Engine:
         if self.mm > 1:
             return self._forward_backward_merged(batch, labels)
         if self.pp > 1:
-            return self._forward_backward_pipeline(batch, labels)
+            return self._forward_backward_interleaved(batch, labels) if self.nch > 1 else self._forward_backward_pipeline(batch, labels)
         lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T  # this rank's tokens of every micro-batch
         self.loss_acc.zero_()
         ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
@@ -657,6 +676,79 @@ class InternLM2Engine:
             P.exchange(recvs=[(self.t_h1, P.next)])
             g_in = backward(i)
             P.exchange(sends=[] if P.first else [(g_in, P.prev)])
+        return P.broadcast_from_last(self.loss_acc)
+
+    def _forward_backward_interleaved(self, batch, labels):
+        """One InterleavedPipelineScheduler.forward_backward_step of this stage (pipeline.py: interleaved_plan): the stage's num_chunks model
+        chunks work through micro_num * num_chunks forward and backward micro-steps in the reference's order, on the common clock of the
+        plan -- per tick at most one micro-step, then ONE paired exchange with whatever this stage sends and receives behind that tick.  A
+        forward input is received straight into its micro-batch's activation set (the first layer of the chunk), an output gradient into
+        that micro-batch's own buffer until its backward micro-step runs.  Returns the loss of the step on every stage."""
+        tc, P = self.tc, self.pipe
+        M, C = tc.micro_num, self.nch
+        if not hasattr(self, "_plan"):
+            self._plan = interleaved_plan(self.pp, C, M)[P.stage]
+            # activation sets: a micro-batch owns one from its first arrival / forward to its last backward micro-step
+            start, end = {}, {}
+            for t, tick in enumerate(self._plan):
+                seen = [m for k, m, c, _ in tick["recvs"] if k == "F"] + ([tick["op"][1]] if tick["op"] else [])
+                for m in seen:
+                    start.setdefault(m, t)
+                if tick["op"] and tick["op"][0] == "B":
+                    end[tick["op"][1]] = t
+            free, busy, self._slot_of = [], [], {}
+            for m in sorted(start, key=lambda m: (start[m], m)):
+                for other in [o for o in busy if end[o] < start[m]]:
+                    busy.remove(other)
+                    free.append(self._slot_of[other])
+                self._slot_of[m] = free.pop(0) if free else len(set(self._slot_of.values()))
+                busy.append(m)
+            n = len(set(self._slot_of.values()))
+            # (with micro_num == pp every forward runs before the first backward, on the model's last chunk too: the final norm's saved
+            # values, the logits and the loss rows are per micro-batch as well, not only the layers' activations)
+            names = self._ACT_SETS + (("a_xf", "a_nf", "a_rstdf", "t_logits", "t_lse", "t_loss_rows", "t_loss") if P.last else ())
+            first = {name: getattr(self, name) for name in names}
+            clone = lambda v: [torch.empty_like(t) for t in v] if isinstance(v, list) else torch.empty_like(v)
+            self._sets = [first] + [{name: clone(v) for name, v in first.items()} for _ in range(n - 1)]
+            h = self.lmc.hidden_size
+            self.t_send = torch.empty(self.T, h, dtype=BF16, device=self.dev)
+            self._gbuf = {}
+        self.loss_acc.zero_()
+        ids_d = batch["input_ids"].to(self.dev, non_blocking=True)
+        lab_d = labels.to(self.dev, non_blocking=True)
+        pos_d = batch["indexes"].to(self.dev, non_blocking=True)
+        if self.metric is not None and self.metric.ntypes:
+            self.metric.set_current_type_ids(batch["type_ids"])
+
+        def args(i):
+            cu_h = batch["cu_seqlens"][i]
+            self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
+            return ids_d[i], lab_d[i], cu_h.to(self.dev, non_blocking=True), pos_d[i], int((cu_h[1:] - cu_h[:-1]).max())
+
+        def gbuf(m, c):
+            key = (self._slot_of[m], c)
+            if key not in self._gbuf:
+                self._gbuf[key] = torch.empty(self.T, self.lmc.hidden_size, dtype=BF16, device=self.dev)
+            return self._gbuf[key]
+
+        last_v = self.pp * C - 1
+        for tick in self._plan:
+            g_in = None
+            if tick["op"] is not None:
+                kind, m, c = tick["op"]
+                self._bind_inflight(self._slot_of[m])
+                v = c * self.pp + P.stage
+                if kind == "F":
+                    self._forward_micro(*args(m), chunk=c)
+                    if v == last_v:
+                        self.loss_acc.add_(self.t_loss[0:1], alpha=1.0 / M)
+                else:
+                    if v != last_v:
+                        self.t_h1.copy_(gbuf(m, c))
+                    g_in = self._backward_micro(*args(m), m == M - 1, m == 0, chunk=c)
+            sends = [(self.t_send if k == "F" else g_in, P.stage_rank[to]) for k, m, c, to in tick["sends"]]
+            recvs = [(self._sets[self._slot_of[m]]["a_x"][self.chunks[c][0]] if k == "F" else gbuf(m, c), P.stage_rank[frm]) for k, m, c, frm in tick["recvs"]]
+            P.exchange(sends=sends, recvs=recvs)
         return P.broadcast_from_last(self.loss_acc)
 
     def forward_only(self, input_ids, labels, metric=None):

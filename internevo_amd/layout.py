@@ -55,8 +55,8 @@ def _round_up(x, m):
 class FlatLayout:
     def __init__(self, model_cfg, world_size=1, layer_lo=0, first=True, last=True):
         """layer_lo / first / last: the layout of ONE pipeline stage -- model_cfg.num_layers layers numbered layer_lo ... in the
-        parameter names (the reference's global layer numbers), the embedding bucket only on the first stage and the norm + head bucket
-        only on the last one.  The bucket list keeps its shape on every stage (index 0 = embedding, 1 + i = local layer i, last =
+        parameter names (the reference's global layer numbers; a LIST of numbers for a stage that holds several model chunks), the
+        embedding bucket only on the first stage and the norm + head bucket only on the last one.  The bucket list keeps its shape on every stage (index 0 = embedding, 1 + i = local layer i, last =
         norm + head): a bucket a stage does not own is EMPTY (size 0)."""
         self.cfg = model_cfg
         self.world = world_size
@@ -88,7 +88,10 @@ class FlatLayout:
         if first:
             add(cur, "tok_embeddings.weight", (v, h), "embed")
         close_bucket(cur)
-        for l in range(layer_lo, layer_lo + c.num_layers):
+        layer_ids = list(layer_lo) if isinstance(layer_lo, (list, tuple)) else list(range(layer_lo, layer_lo + c.num_layers))
+        assert len(layer_ids) == c.num_layers
+        self.layer_ids = layer_ids
+        for l in layer_ids:
             cur = open_bucket()
             p = f"layers.{l}."
             add(cur, p + "attention_norm.weight", (h,), "norm", l)

@@ -598,7 +598,7 @@ def _pp_cfg(layers, micro_num):
     return tiny(hidden=256, layers=layers, heads=4, kv_heads=2, vocab=512, seq_len=128, micro_num=micro_num, lr=1e-3, total_steps=6)
 
 
-def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed):
+def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1):
     import torch.distributed as dist
 
     dev = _init_dist(rank, world, port)
@@ -607,7 +607,7 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed):
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        eng = InternLM2Engine(_pp_cfg(layers, micro_num), dev, None, world, rank, init_fn=formula_init, pp_size=pp)
+        eng = InternLM2Engine(_pp_cfg(layers, micro_num), dev, None, world, rank, init_fn=formula_init, pp_size=pp, num_chunks=chunks)
         loader = iter(SyntheticLoader(128, 1, micro_num, fixed, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
         for _ in range(3):
@@ -621,11 +621,15 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("pp,dp,layers,micro_num", [(2, 1, 3, 4), (2, 1, 2, 1), pytest.param(4, 1, 5, 6, marks=pytest.mark.ranks(4)),
-                                                     pytest.param(2, 2, 2, 2, marks=pytest.mark.ranks(4))],
-                         ids=["pp2_3layers_4micro", "pp2_2layers_1micro", "pp4_5layers_6micro", "pp2_dp2"])
-def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, layers, micro_num):
-    """Non-interleaved 1F1B pipeline parallelism (parallel.pipeline = dict(size=pp); pipeline_scheduler.py:111-709) vs ONE rank on the
+@pytest.mark.parametrize("pp,dp,layers,micro_num,chunks", [
+    (2, 1, 3, 4, 1), (2, 1, 2, 1, 1), pytest.param(4, 1, 5, 6, 1, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 2, 2, 1, marks=pytest.mark.ranks(4)),
+    (2, 1, 4, 4, 2), (2, 1, 6, 2, 3), pytest.param(4, 1, 8, 8, 2, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 4, 2, 2, marks=pytest.mark.ranks(4))],
+    ids=["pp2_3layers_4micro", "pp2_2layers_1micro", "pp4_5layers_6micro", "pp2_dp2",
+         "interleaved_pp2_2chunks_4micro", "interleaved_pp2_3chunks_all_warmup", "interleaved_pp4_2chunks_8micro", "interleaved_pp2_dp2"])
+def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, layers, micro_num, chunks):
+    """1F1B pipeline parallelism (parallel.pipeline = dict(size=pp); pipeline_scheduler.py:111-709), non-interleaved and -- chunks > 1,
+    model.num_chunks -- interleaved (:711-1430: every stage holds `chunks` model chunks, micro-batches go round the ring of stages once
+    per chunk; micro_num == pp is the reference's all-warm-up special case), vs ONE rank on the
     same micro-batches: same loss on every stage, same global grad norm, and the stages' parameters together are the single-rank
     parameters after three optimizer steps.  3 layers over 2 stages / 5 over 4 = the uneven splits of partition_uniform (the last
     stages take the extra layers); 4 and 6 micro-batches exercise warm-up, steady state and cool-down, 1 micro-batch the degenerate
@@ -639,7 +643,7 @@ def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, la
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     fixed = dp > 1   # (the sampler interleaves data-parallel ranks: with fixed-length samples 1 rank x (dp * M) micro-batches is the same set)
-    procs = [ctx.Process(target=_pp_worker, args=(r, world, 29871 + micro_num + 10 * pp, q, pp, layers, micro_num, fixed)) for r in range(world)]
+    procs = [ctx.Process(target=_pp_worker, args=(r, world, 29871 + micro_num + 10 * pp + 100 * chunks, q, pp, layers, micro_num, fixed, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, world), key=lambda x: x[0])

@@ -76,9 +76,17 @@ def test_reference_config_files_map(tmp_path):
     with pytest.raises(NotImplementedError):
         from_reference_dict(pp)
     pp["parallel"]["tensor"] = 1
-    pp["model"]["num_chunks"] = 2                                           # ... and not interleaved
-    with pytest.raises(NotImplementedError):
+    pp["model"]["num_chunks"] = 2                                           # interleaved 1F1B: two model chunks per stage
+    pp["data"]["micro_num"] = 8
+    assert from_reference_dict(pp).train.num_chunks == 2 and from_reference_dict(pp).train.pp_size == 4
+    pp["data"]["micro_num"] = 6                                             # (the reference's own assertions: micro_num % pp, layers % chunks)
+    with pytest.raises(ValueError):
         from_reference_dict(pp)
+    pp["data"]["micro_num"], pp["model"]["num_chunks"] = 8, 3
+    with pytest.raises(ValueError):
+        from_reference_dict(pp)
+    pp["parallel"]["pipeline"] = dict(size=1)                               # without pipeline stages there is nothing to interleave
+    assert from_reference_dict(pp).train.num_chunks == 1
     # Megatron sequence parallelism: same parameter shards and numbers as mtp, run on the mtp schedule (config.py)
     assert from_reference_dict(msp).train.tp_size == 2 and from_reference_dict(msp).train.sp_size == 1
     msp["parallel"]["tensor"]["mode"] = "fsp"
@@ -88,7 +96,7 @@ def test_reference_config_files_map(tmp_path):
         from_reference_dict(msp)
     # settings that would change the arithmetic are refused, not silently ignored
     for path, value in ((("use_fp32_norm",), True), (("model", "norm_type"), "layernorm"), (("model", "apply_post_layer_norm"), True),
-                        (("model", "embed_grad_scale"), 0.1), (("model", "num_chunks"), 2), (("model", "attn_drop_rate"), 0.1),
+                        (("model", "embed_grad_scale"), 0.1), (("model", "attn_drop_rate"), 0.1),
                         (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"), (("data", "skip_batches"), "1-3"),
                         (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False),
                         (("data", "use_packed_dataset"), False)):
@@ -345,3 +353,72 @@ def test_pipeline_partition_and_schedule():
         assert all(L.params[n].shape == full.params[n].shape for n in L.params)
         names += list(L.params)
     assert names == list(full.params)
+
+
+def test_interleaved_pipeline_partition_order_and_plan():
+    """Interleaved 1F1B (model.num_chunks > 1): the layer ranges of partition_uniform (pipeline_utils.py:9-34), the micro-step order of
+    InterleavedPipelineScheduler (pipeline_scheduler.py:925-945, 1327-1373) and the tick plan that moves the messages."""
+    import os
+    import sys
+
+    from internevo_amd.pipeline import interleaved_order, interleaved_plan, partition_chunks
+
+    assert partition_chunks(8, 2, 2) == [[(0, 2), (4, 6)], [(2, 4), (6, 8)]]
+    assert partition_chunks(12, 4, 1) == [[(0, 3)], [(3, 6)], [(6, 9)], [(9, 12)]]
+    assert partition_chunks(10, 2, 2) == [[(0, 2), (5, 7)], [(2, 5), (7, 10)]]       # 5 layers per chunk over 2 stages: the last stage takes the extra one
+    with pytest.raises(ValueError):
+        partition_chunks(9, 2, 2)
+    ref_root = "/root/reference"
+    if os.path.isdir(ref_root):   # the reference's own function (pure python), when the reference is mounted
+        import importlib.util
+        import types
+
+        stub = types.ModuleType("internlm.utils.logger")
+        stub.get_logger = lambda *_a, **_k: None
+        saved = {k: sys.modules.get(k) for k in ("internlm", "internlm.utils", "internlm.utils.logger")}
+        try:
+            sys.modules.update({"internlm": types.ModuleType("internlm"), "internlm.utils": types.ModuleType("internlm.utils"), "internlm.utils.logger": stub})
+            spec = importlib.util.spec_from_file_location("_ref_pipeline_utils", os.path.join(ref_root, "internlm/solver/pipeline_utils.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            for n, pp, c in [(8, 2, 2), (32, 4, 2), (30, 4, 2), (24, 4, 3), (12, 4, 1), (10, 2, 2)]:
+                assert [list(map(tuple, x)) for x in mod.partition_uniform(n, pp, c)] == partition_chunks(n, pp, c), (n, pp, c)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+
+    # the reference's order, spelled out for stage 0 of 2 stages x 2 chunks x 4 micro-batches: 2 + 2 warm-up forwards, pairs, cool-down
+    assert interleaved_order(0, 2, 2, 4) == [("F", 0, 0), ("F", 1, 0), ("F", 0, 1), ("F", 1, 1), ("F", 2, 0), ("B", 0, 1), ("F", 3, 0), ("B", 1, 1),
+                                             ("F", 2, 1), ("B", 0, 0), ("F", 3, 1), ("B", 1, 0), ("B", 2, 1), ("B", 3, 1), ("B", 2, 0), ("B", 3, 0)]
+    assert [k for k, _, _ in interleaved_order(1, 2, 2, 2)] == ["F"] * 4 + ["B"] * 4          # micro_num == pp: everything is warm-up
+    with pytest.raises(ValueError):
+        interleaved_order(0, 4, 2, 6)
+    for pp, chunks, micro in [(2, 2, 2), (2, 2, 4), (4, 2, 8), (4, 3, 4), (2, 4, 6), (3, 2, 9)]:
+        plan = interleaved_plan(pp, chunks, micro)
+        ticks = len(plan[0])
+        assert all(len(p) == ticks for p in plan)                                  # every stage makes the same number of exchanges
+        last_v = pp * chunks - 1
+        for s in range(pp):
+            ops = [t["op"] for t in plan[s] if t["op"]]
+            assert ops == interleaved_order(s, pp, chunks, micro)                  # the reference's order, only delayed
+            arrived = set()
+            for t in plan[s]:
+                if t["op"]:
+                    kind, m, c = t["op"]
+                    v = c * pp + s
+                    if (kind == "F" and v > 0) or (kind == "B" and v < last_v):
+                        assert (kind, m, c) in arrived, (pp, chunks, micro, s, t["op"])   # an input is received in an EARLIER tick's exchange
+                    if kind == "B":
+                        assert ("F", m, c) in {o for o in ops[: ops.index(t["op"])]}      # the backward of a chunk follows its forward
+                arrived |= {(k, m, c) for k, m, c, _ in t["recvs"]}
+            for c in range(chunks):    # gradients accumulate over the micro-batches in ascending order, as without a pipeline
+                assert [m for k, m, cc in ops if k == "B" and cc == c] == list(range(micro))
+        for t in range(ticks):         # a send and its receive are in the same tick's exchange, between ring neighbours
+            sends = sorted((k, m, c, s, to) for s in range(pp) for k, m, c, to in plan[s][t]["sends"])
+            recvs = sorted((k, m, c, frm, s) for s in range(pp) for k, m, c, frm in plan[s][t]["recvs"])
+            assert sends == recvs
+            assert all(abs(a - b) in (1, pp - 1) for _, _, _, a, b in sends)
+        assert ticks < 2 * micro * chunks + 2 * pp * chunks                        # bubble bounded by the fill / drain of the ring
