@@ -212,6 +212,19 @@ int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream
  *      ie_scale_bf16: x *= factor in place (the embed/head gradient re-scale of the ISP averaging rule). */
 int ie_seq_head_permute(const void* in, void* out, int64_t A, int B, int S, int64_t C, int inverse, void* stream);
 int ie_scale_bf16(void* x, int64_t n, float factor, void* stream);
+
+/* ScaleColumnParallelLinearWithNormHead.forward (internlm/model/ops/linear.py:124-153) and the embedding's gradient scale
+ * (modeling_internlm2.py:970-973; embed_grad_scale = weight_scale = s):
+ *   ie_grad_scale_mix:  x <- s x + (1 - s) x.detach() in place, the value as the reference's bf16 expression rounds it (embedding output);
+ *   ie_head_weight_fwd: out[rows, cols] = the weight the head multiplies by = F.normalize(s w + (1 - s) w.detach()) (norm_head: rows scaled
+ *                       to unit length, inv_norm[rows] saved; scale = 1 skips the mix);
+ *   ie_head_weight_bwd: dw (= or +=) s * (dy - y (y . dy)) * inv_norm per row, dy = gradient w.r.t. `out` (a weight-gradient GEMM's result),
+ *                       y = `out`.  Rows are independent: a vocabulary-parallel head calls these on its own rows. */
+int ie_grad_scale_mix(void* x, int64_t n, float scale, void* stream);
+int ie_head_weight_fwd(const void* w, int64_t w_ld, void* out, int64_t out_ld, float* inv_norm, int64_t rows, int64_t cols, float scale,
+                       int norm_head, void* stream);
+int ie_head_weight_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, const float* inv_norm, void* dw, int64_t dw_ld, int64_t rows,
+                       int64_t cols, float scale, int norm_head, int accumulate, void* stream);
 int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -86,6 +86,9 @@ SIGNATURES = {
     "ie_add_bf16": (I, [P, P, P, I64, P]),
     "ie_seq_head_permute": (I, [P, P, I64, I, I, I64, I, P]),
     "ie_scale_bf16": (I, [P, I64, F, P]),
+    "ie_grad_scale_mix": (I, [P, I64, F, P]),
+    "ie_head_weight_fwd": (I, [P, I64, P, I64, P, I64, I64, F, I, P]),
+    "ie_head_weight_bwd": (I, [P, I64, P, I64, P, P, I64, I64, I64, F, I, I, P]),
     "ie_cast": (I, [P, I, P, I, I64, P]),
     "ie_gemm_bf16": (I, [P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),
     "ie_gemm_bf16_tile": (I, [I, P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),

@@ -39,6 +39,9 @@ class ModelConfig:
     moe_capacity_factor: float = 1.0     # moe = dict(capacity_factor, min_capacity, ...)
     moe_min_capacity: int = 4
     moe_loss_coeff: float = 1.0          # loss.moe_loss_coeff (launch.py:433-434 default)
+    # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) and the embedding's gradient scale (modeling_internlm2.py:970-973)
+    embed_grad_scale: float = 1.0        # s: x -> s x + (1 - s) x.detach() on the embedding output AND on the head weight (weight_scale = s)
+    norm_head: bool = False              # the head multiplies by its weight with every row scaled to unit length (F.normalize)
 
     @property
     def head_dim(self):
@@ -207,8 +210,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.norm_type {m.get('norm_type')!r} (rmsnorm only)")
     if m.get("apply_post_layer_norm", False):
         raise NotImplementedError(f"{_UNSUPPORTED}: model.apply_post_layer_norm")
-    if m.get("embed_grad_scale", 1) != 1:
-        raise NotImplementedError(f"{_UNSUPPORTED}: model.embed_grad_scale != 1")
+    if (m.get("embed_grad_scale", 1) != 1 or m.get("norm_head", False)) and (model_type != "INTERNLM2_PUBLIC" or pp_size > 1):
+        raise NotImplementedError(f"{_UNSUPPORTED}: model.embed_grad_scale != 1 / model.norm_head outside the InternLM2 family or with pipeline parallelism")
     num_chunks = int(m.get("num_chunks", 1))
     if num_chunks > 1:
         # InterleavedPipelineScheduler (pipeline_scheduler.py:736-757) and partition_uniform (pipeline_utils.py:9-12) assert the same
@@ -237,7 +240,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
         # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
-        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type, **moe_kw,
+        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
+        embed_grad_scale=float(m.get("embed_grad_scale", 1)), norm_head=bool(m.get("norm_head", False)), **moe_kw,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]
@@ -273,10 +277,11 @@ def llama2_7b(seq_len=4096) -> PathConfig:
     return PathConfig(ModelConfig(vocab_size=32000, model_type="LLAMA2", adapt_hf=False), TrainConfig(seq_len=seq_len))
 
 
-def tiny(hidden=512, layers=2, heads=8, kv_heads=2, vocab=1024, seq_len=256, micro_num=2, lr=1e-3, total_steps=5, model_type="INTERNLM2_PUBLIC") -> PathConfig:
+def tiny(hidden=512, layers=2, heads=8, kv_heads=2, vocab=1024, seq_len=256, micro_num=2, lr=1e-3, total_steps=5, model_type="INTERNLM2_PUBLIC",
+         embed_grad_scale=1.0, norm_head=False) -> PathConfig:
     """BASELINE.json configs[0]: the CPU-runnable plumbing case (SURVEY.md section 8d "tiny config")."""
     return PathConfig(
         ModelConfig(vocab_size=vocab, hidden_size=hidden, num_layers=layers, num_attention_heads=heads, num_kv_attention_heads=kv_heads,
-                    model_type=model_type, adapt_hf=model_type != "LLAMA2"),
+                    model_type=model_type, adapt_hf=model_type != "LLAMA2", embed_grad_scale=embed_grad_scale, norm_head=norm_head),
         TrainConfig(seq_len=seq_len, micro_bsz=1, micro_num=micro_num, total_steps=total_steps, lr=lr, fixed_random_dataset_seqlen=True),
     )

@@ -324,6 +324,66 @@ __global__ __launch_bounds__(256) void scale_bf16_k(bf16_t* __restrict__ x, int6
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = f2bf(bf2f(x[i]) * f);
 }
 
+
+// ---- ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) and the embedding's gradient scale (modeling_internlm2.py:970-973) ----
+// x -> s x + (1 - s) x.detach(): the VALUE the reference computes in bf16 (three roundings: s x, (1 - s) x, their sum); the gradient factor s
+// is applied by the backward kernels
+__device__ __forceinline__ float grad_scale_mix(float x, float s) {
+    return rbf(rbf(s * x) + rbf((1.f - s) * x));
+}
+
+__global__ __launch_bounds__(256) void grad_scale_mix_k(bf16_t* __restrict__ x, int64_t n, float s) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = f2bf(grad_scale_mix(bf2f(x[i]), s));
+}
+
+// one block per weight row: out = normalize(mix(w)) (each step optional); inv_norm[row] = 1 / max(bf16(||e||), 1e-12) for the backward
+__global__ __launch_bounds__(256) void head_weight_fwd_k(const bf16_t* __restrict__ w, int64_t w_ld, bf16_t* __restrict__ out, int64_t o_ld,
+                                                         float* __restrict__ inv_norm, int64_t cols, float s, int norm_head) {
+    __shared__ float scratch[8];
+    const int64_t row = blockIdx.x;
+    const bf16_t* wr = w + row * w_ld;
+    bf16_t* orow = out + row * o_ld;
+    float ss = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        float e = bf2f(wr[c]);
+        if (s != 1.f) e = grad_scale_mix(e, s);
+        ss += e * e;
+        if (!norm_head) orow[c] = f2bf(e);
+    }
+    if (!norm_head) return;
+    ss = block_sum<4>(ss, scratch);
+    const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);   // F.normalize: input.norm(2, dim, keepdim=True) (a bf16 tensor) .clamp_min(eps)
+    if (threadIdx.x == 0) inv_norm[row] = 1.f / n;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        float e = bf2f(wr[c]);
+        if (s != 1.f) e = grad_scale_mix(e, s);
+        orow[c] = f2bf(e / n);
+    }
+}
+
+// gradient of the above: dy = gradient w.r.t. the weight the GEMM used, y = that weight (normalised rows); dw (+)= s * (dy - y (y . dy)) / n
+__global__ __launch_bounds__(256) void head_weight_bwd_k(const bf16_t* __restrict__ dy, int64_t dy_ld, const bf16_t* __restrict__ y, int64_t y_ld,
+                                                         const float* __restrict__ inv_norm, bf16_t* __restrict__ dw, int64_t dw_ld, int64_t cols,
+                                                         float s, int norm_head, int accumulate) {
+    __shared__ float scratch[8];
+    const int64_t row = blockIdx.x;
+    const bf16_t* dr = dy + row * dy_ld;
+    const bf16_t* yr = y + row * y_ld;
+    bf16_t* wr = dw + row * dw_ld;
+    float dot = 0.f, inv = 1.f;
+    if (norm_head) {
+        for (int64_t c = threadIdx.x; c < cols; c += 256) dot += bf2f(dr[c]) * bf2f(yr[c]);
+        dot = block_sum<4>(dot, scratch);
+        inv = inv_norm[row];
+    }
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        float g = bf2f(dr[c]);
+        if (norm_head) g = (g - bf2f(yr[c]) * dot) * inv;
+        g *= s;
+        wr[c] = f2bf(accumulate ? bf2f(wr[c]) + g : g);
+    }
+}
+
 }  // namespace
 
 extern "C" int ie_apply_rotary(const void* x1, const void* x2, const void* cos_, const void* sin_, void* out1, void* out2,
@@ -428,6 +488,31 @@ extern "C" int ie_scale_bf16(void* x, int64_t n, float factor, void* stream) {
     if (n == 0) return IE_OK;
     hipLaunchKernelGGL(scale_bf16_k, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n, factor);
     return ie_launch_status("ie_scale_bf16 launch");
+}
+
+extern "C" int ie_grad_scale_mix(void* x, int64_t n, float scale, void* stream) {
+    IE_CHECK_ARG(x && n >= 0, "ie_grad_scale_mix: bad argument");
+    if (n == 0) return IE_OK;
+    hipLaunchKernelGGL(grad_scale_mix_k, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n, scale);
+    return ie_launch_status("ie_grad_scale_mix launch");
+}
+
+extern "C" int ie_head_weight_fwd(const void* w, int64_t w_ld, void* out, int64_t out_ld, float* inv_norm, int64_t rows, int64_t cols, float scale,
+                                  int norm_head, void* stream) {
+    IE_CHECK_ARG(w && out && rows >= 0 && cols > 0 && (inv_norm || !norm_head), "ie_head_weight_fwd: bad argument");
+    if (rows == 0) return IE_OK;
+    hipLaunchKernelGGL(head_weight_fwd_k, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, w_ld, (bf16_t*)out, out_ld, inv_norm,
+                       cols, scale, norm_head);
+    return ie_launch_status("ie_head_weight_fwd launch");
+}
+
+extern "C" int ie_head_weight_bwd(const void* dy, int64_t dy_ld, const void* y, int64_t y_ld, const float* inv_norm, void* dw, int64_t dw_ld, int64_t rows,
+                                  int64_t cols, float scale, int norm_head, int accumulate, void* stream) {
+    IE_CHECK_ARG(dy && y && dw && rows >= 0 && cols > 0 && (inv_norm || !norm_head), "ie_head_weight_bwd: bad argument");
+    if (rows == 0) return IE_OK;
+    hipLaunchKernelGGL(head_weight_bwd_k, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_ld, (const bf16_t*)y, y_ld, inv_norm,
+                       (bf16_t*)dw, dw_ld, cols, scale, norm_head, accumulate);
+    return ie_launch_status("ie_head_weight_bwd launch");
 }
 
 extern "C" int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {

@@ -263,6 +263,13 @@ class InternLM2Engine:
             self.t_dctx_full = e(Tg, hql, d)
             self.t_loss_red = e(2, dtype=torch.float32)
         self.t_logits = e(T, mc.head_vocab)
+        # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153): with embed_grad_scale != 1 / norm_head the head multiplies by a function of
+        # its weight (kernels.head_weight_fwd), rebuilt in every forward pass like the reference does; the weight gradient goes through t_head_dw
+        self.head_fn = (mc.embed_grad_scale != 1.0 or mc.norm_head) and self.pipe.last
+        if self.head_fn:
+            self.t_head_w = e(mc.head_vocab, mc.hidden_size)
+            self.t_head_dw = e(mc.head_vocab, mc.hidden_size)
+            self.t_head_inv = e(mc.head_vocab, dtype=torch.float32)
         if self.vp:
             self.t_lab_local = e(T, dtype=torch.int64)   # labels in this rank's vocabulary range (-1: valid, owned by another rank)
         self.t_loss_rows = e(T, dtype=torch.float32)
@@ -388,6 +395,8 @@ class InternLM2Engine:
         self._wait_bucket(0)              # bucket b's AdamW / all-gather of the previous step() may still be running on the optimizer stream
         if is_first:
             K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
+            if mc.embed_grad_scale != 1.0:   # modeling_internlm2.py:970-973 (the value; the backward scales the gradient)
+                K.grad_scale_mix(self.a_x[0], mc.embed_grad_scale)
         # (a later pipeline stage / model chunk received its input -- the previous one's output -- straight into a_x[la])
         ffn_out = None
         for l in range(la, lb):
@@ -398,7 +407,9 @@ class InternLM2Engine:
             return
         self._wait_bucket(L + 1)
         K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
-        K.linear_fwd(self.a_nf, p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
+        if self.head_fn:
+            K.head_weight_fwd(p["output.weight"], mc.embed_grad_scale, mc.norm_head, self.t_head_w, self.t_head_inv)
+        K.linear_fwd(self.a_nf, self.t_head_w if self.head_fn else p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
         if self.mm > 1:
             # merged pass: the loss (and the metric) stay per micro-batch -- each has its own valid-token count (loss = mean over
             # micro-batches of the mean token loss, no_pipeline_scheduler.py:146)
@@ -493,9 +504,17 @@ class InternLM2Engine:
                 K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
             dlog = self.t_logits
 
-            K.linear_dgrad(dlog, p["output.weight"], self.t_h0)
+            K.linear_dgrad(dlog, self.t_head_w if self.head_fn else p["output.weight"], self.t_h0)
             ar = self.tpar.all_reduce_sum_async(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
-            wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
+            if not self.head_fn:
+                wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
+            else:   # the gradient w.r.t. the weight the GEMM used, then through normalize / the gradient scale into the parameter's gradient
+                if not bw:
+                    K.linear_wgrad(dlog, self.a_nf, self.t_head_dw, False)
+                    K.head_weight_bwd(self.t_head_dw, self.t_head_w, self.t_head_inv, mc.embed_grad_scale, mc.norm_head, g["output.weight"], acc)
+                elif last_micro:
+                    K.linear_wgrad(self.st_logits, self.st_nf, self.t_head_dw, False)
+                    K.head_weight_bwd(self.t_head_dw, self.t_head_w, self.t_head_inv, mc.embed_grad_scale, mc.norm_head, g["output.weight"], False)
             if ar is not None:
                 ar.wait()
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
@@ -557,6 +576,8 @@ class InternLM2Engine:
                 self.comm.reduce_bucket_async(self.grads, 1 + l)
         if not is_first:
             return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
+        if mc.embed_grad_scale != 1.0:
+            K.scale_bf16(d_out, mc.embed_grad_scale)   # d(s x + (1 - s) x.detach()) / dx = s
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
             self.comm.reduce_bucket_async(self.grads, 0)

@@ -192,6 +192,31 @@ def scale_bf16(x, factor):
     return x
 
 
+def grad_scale_mix(x, scale):
+    """x <- scale * x + (1 - scale) * x.detach() in place: the value of the reference's bf16 expression (modeling_internlm2.py:970-973)."""
+    _contig(x, "x")
+    check(_L().ie_grad_scale_mix(_p(x), x.numel(), float(scale), _stream()), "ie_grad_scale_mix")
+    return x
+
+
+def head_weight_fwd(w, scale, norm_head, out, inv_norm=None):
+    """The weight ScaleColumnParallelLinearWithNormHead multiplies by (ops/linear.py:124-153): out = F.normalize(scale w + (1 - scale) w.detach())."""
+    rows, cols = w.shape
+    assert out.shape == w.shape and w.stride(1) == 1 and out.stride(1) == 1 and (inv_norm is not None or not norm_head)
+    check(_L().ie_head_weight_fwd(_p(w), w.stride(0), _p(out), out.stride(0), _p(inv_norm) if inv_norm is not None else None, rows, cols, float(scale),
+                                  int(bool(norm_head)), _stream()), "ie_head_weight_fwd")
+    return out
+
+
+def head_weight_bwd(dy, y, inv_norm, scale, norm_head, dw, accumulate):
+    """dw (= or +=) the gradient of head_weight_fwd's input, from dy = the gradient w.r.t. its output y."""
+    rows, cols = y.shape
+    assert dy.shape == y.shape == dw.shape and dy.stride(1) == 1 and y.stride(1) == 1 and dw.stride(1) == 1
+    check(_L().ie_head_weight_bwd(_p(dy), dy.stride(0), _p(y), y.stride(0), _p(inv_norm) if inv_norm is not None else None, _p(dw), dw.stride(0), rows, cols,
+                                  float(scale), int(bool(norm_head)), int(bool(accumulate)), _stream()), "ie_head_weight_bwd")
+    return dw
+
+
 # ------------------------------------------------------------------------------------------ CE
 def ce_fwd(logits, labels, ignore_index=-100, label_smoothing=0.0, loss_rows=None, lse=None, out=None, argmax_rows=None, nll_rows=None):
     """logits [rows, V] (bf16|fp32, row stride arbitrary), labels int64 [rows] ->

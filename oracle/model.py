@@ -84,6 +84,9 @@ def forward_logits(params, mc, input_ids, indexes=None, cu_seqlens=None):
     if cu_seqlens is None:
         cu_seqlens = torch.tensor([0, S], dtype=torch.int32)
     h = F.embedding(input_ids, p["tok_embeddings.weight"])
+    egs = float(getattr(mc, "embed_grad_scale", 1.0))
+    if egs != 1:   # modeling_internlm2.py:970-973: the value is (nearly) unchanged, the gradient into the embedding scaled by egs
+        h = egs * h + (1 - egs) * h.detach()
     for l in range(mc.num_layers):
         pre = f"layers.{l}."
         residual = h
@@ -107,7 +110,12 @@ def forward_logits(params, mc, input_ids, indexes=None, cu_seqlens=None):
         ffn = F.linear(O.swiglu(a, b), p[pre + "feed_forward.w2.weight"])
         h = ffn + residual
     x = O.rms_norm(h.float(), p["norm.weight"], mc.layer_norm_epsilon)
-    logits = F.linear(x, p["output.weight"])
+    w = p["output.weight"]
+    if egs != 1:   # ScaleColumnParallelLinear.forward (ops/linear.py:125-128): weight_scale = embed_grad_scale
+        w = w * egs + (1 - egs) * w.detach()
+    if getattr(mc, "norm_head", False):   # ops/linear.py:129-136 (training branch)
+        w = F.normalize(w)
+    logits = F.linear(x, w)
     return logits.float()
 
 

@@ -185,8 +185,10 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 
 
 def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1,
-                num_experts=1, capacity_factor=1.0):
+                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False):
     cfg = _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp, wp, model_type, tp)
+    if embed_grad_scale != 1 or norm_head:   # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) + the embedding's gradient scale (modeling_internlm2.py:970-973)
+        cfg["model"].update(embed_grad_scale=embed_grad_scale, norm_head=norm_head)
     if model_type == "INTERNLM_MoE":   # configs/7B_MoE4_sft.py: the InternLM-1 block (MHA with biases) + a GShard MoE in place of every MLP
         m = cfg["model"]
         for k in ("num_kv_attention_heads", "no_bias"):
@@ -746,6 +748,12 @@ RUNS = {
                                        model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0)),
     "moe_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
                                         model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0)),
+    # the output head's options no shipped config turns on: weight normalised per row (norm_head) and the GLM-130B gradient scale of the embedding
+    # and of the head weight (embed_grad_scale)
+    "normhead_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                            embed_grad_scale=0.1, norm_head=True)),
+    "normhead_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                             embed_grad_scale=0.1, norm_head=True)),
     # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
     "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
     "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),

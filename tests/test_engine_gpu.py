@@ -24,7 +24,7 @@ def _run(dev, gold, steps, with_oracle=True):
 
     c = gold["config"]
     cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"],
-               model_type=c.get("model_type", "INTERNLM2_PUBLIC"))
+               model_type=c.get("model_type", "INTERNLM2_PUBLIC"), embed_grad_scale=c.get("embed_grad_scale", 1.0), norm_head=c.get("norm_head", False))
     eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
     ora = OracleTrainer(cfg, torch.bfloat16) if with_oracle else None
     loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
@@ -39,10 +39,14 @@ def _run(dev, gold, steps, with_oracle=True):
     return rows, eng, ora
 
 
-@pytest.mark.parametrize("tag", ["pin_bf16", "cfg0_bf16", "llama_bf16"])  # llama_bf16: model_type LLAMA2 (BASELINE configs[2]'s family)
+# llama_bf16: model_type LLAMA2 (BASELINE configs[2]'s family); normhead_bf16: norm_head + embed_grad_scale = 0.1
+# (ScaleColumnParallelLinearWithNormHead, ops/linear.py:79-153), over its first three steps: this run's loss falls 6.4 -> 0.9 in six steps and
+# bf16 rounding-order differences grow accordingly (5e-5, 2e-4, 4e-4, then 1.3e-3 in the fourth step; the oracle itself leaves the
+# reference's bf16 run by 4e-3 in the fifth while retracing its fp32 run to 2e-5 over all six)
+@pytest.mark.parametrize("tag", ["pin_bf16", "cfg0_bf16", "llama_bf16", "normhead_bf16"])
 def test_engine_matches_reference_trajectory(dev, tag):
     gold = json.load(open(os.path.join(G, f"train_{tag}.json")))
-    steps = len(gold["steps"])
+    steps = 3 if tag == "normhead_bf16" else len(gold["steps"])
     rows, eng, ora = _run(dev, gold, steps)
     report = []
     for k, ((loss, gn, ls, skip, ref), w) in enumerate(zip(rows, gold["steps"])):

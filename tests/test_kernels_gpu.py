@@ -563,6 +563,36 @@ def test_flash_bwd_four_wave_dkdv_blocks(dev, lens, hq, hkv, d, causal, split):
     assert torch.equal(got[0][1], dk) and torch.equal(got[0][2], dv), "the two block shapes must give bit-identical dK / dV"
 
 
+@pytest.mark.parametrize("scale,norm_head", [(0.1, True), (1.0, True), (0.25, False)])
+@pytest.mark.parametrize("rows,cols,view", [(512, 256, False), (37, 1000, False), (64, 4096, True)])
+def test_head_weight_function_and_embedding_gradient_scale(dev, scale, norm_head, rows, cols, view):
+    """ScaleColumnParallelLinearWithNormHead.forward's weight expression (ops/linear.py:124-136) and its gradient, and the embedding's
+    s x + (1 - s) x.detach() (modeling_internlm2.py:970-973), against torch autograd on the same bf16 expressions."""
+    import torch.nn.functional as F
+
+    w = bf(torch.randn(rows, cols + (8 if view else 0), generator=g(95)) * 0.05)
+    dy = bf(torch.randn(rows, cols, generator=g(96)))
+    wv = w[:, :cols]
+    wr = wv.clone().requires_grad_(True)
+    e = wr * scale + (1 - scale) * wr.detach() if scale != 1 else wr
+    y = F.normalize(e) if norm_head else e
+    (y.float() * dy.float()).sum().backward()
+    wd = w.to(dev)
+    out = torch.empty(rows, cols, dtype=torch.bfloat16, device=dev)
+    inv = torch.empty(rows, dtype=torch.float32, device=dev)
+    K().head_weight_fwd(wd[:, :cols], scale, norm_head, out, inv)
+    close(out, y.detach(), 8e-3, 1e-6, "head weight")             # one bf16 rounding of the quotient where torch rounds norm and quotient
+    acc0 = bf(torch.randn(rows, cols, generator=g(97)))
+    dw = acc0.to(dev).clone()
+    K().head_weight_bwd(dy.to(dev), out, inv, scale, norm_head, dw, True)
+    close(dw, acc0.float() + wr.grad.float(), 2e-2, 2e-2 * float(wr.grad.float().abs().max()) + 8e-3, "head weight gradient (accumulated)")
+    K().head_weight_bwd(dy.to(dev), out, inv, scale, norm_head, dw, False)
+    close(dw, wr.grad, 2e-2, 2e-2 * float(wr.grad.float().abs().max()), "head weight gradient")
+    x = bf(torch.randn(1000, generator=g(98)))
+    want = scale * x + (1 - scale) * x
+    close(K().grad_scale_mix(x.to(dev).clone(), scale), want, 0, 0, "embedding mix (exact: the same three roundings)")
+
+
 # ---------------------------------------------------------------------------------------------- edge cases of the C ABI
 def test_empty_inputs_are_no_ops(dev):
     """Zero rows / zero tokens / zero-sized products: every entry point returns success without launching (the reference's torch

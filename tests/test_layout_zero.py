@@ -96,7 +96,7 @@ def test_reference_config_files_map(tmp_path):
         from_reference_dict(msp)
     # settings that would change the arithmetic are refused, not silently ignored
     for path, value in ((("use_fp32_norm",), True), (("model", "norm_type"), "layernorm"), (("model", "apply_post_layer_norm"), True),
-                        (("model", "embed_grad_scale"), 0.1), (("model", "attn_drop_rate"), 0.1),
+                        (("model", "attn_drop_rate"), 0.1),
                         (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"), (("data", "skip_batches"), "1-3"),
                         (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False),
                         (("data", "use_packed_dataset"), False)):
@@ -107,6 +107,13 @@ def test_reference_config_files_map(tmp_path):
         node[path[-1]] = value
         with pytest.raises(NotImplementedError):
             from_reference_dict(c)
+    # ScaleColumnParallelLinearWithNormHead's options map (InternLM2 family, no pipeline stages)
+    nh = copy.deepcopy(g)
+    nh["model"].update(embed_grad_scale=0.1, norm_head=True)
+    assert from_reference_dict(nh).model.embed_grad_scale == 0.1 and from_reference_dict(nh).model.norm_head is True
+    nh["parallel"] = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=2))
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(nh)
     from internevo_amd.config import ModelConfig
     from internevo_amd.layout import FlatLayout
 
