@@ -6,18 +6,22 @@
 // The recompute costs 7 instead of 5 tile products but keeps every output written by exactly one
 // workgroup in a fixed order, so the result is bit-reproducible run to run.
 //
-// Tiles arrive by LDS-DMA into double-buffered natural-layout images (flash_common.h); one image serves
-// both the row fragments (ds_read_b128) and the transposed fragments (ds_read_b64_tr_b16), so the dQ kernel
+// Tiles arrive by LDS-DMA into natural-layout images (flash_common.h), two pipeline stages (four in the four-wave dK/dV block); one image
+// serves both the row fragments (ds_read_b128) and the transposed fragments (ds_read_b64_tr_b16), so the dQ kernel
 // stages only K and V, the dK/dV kernel only Q and dO.  In the dQ kernel scores are formed transposed
 // (lane = query row), in the dK/dV kernel un-transposed (lane = key), so the accumulator registers of
-// S / dS are directly the k-slots of the next MFMA.  Tile loops are unrolled by the two pipeline stages:
-// every LDS address is a precomputed per-lane offset + an immediate.
+// S / dS are directly the k-slots of the next MFMA.  Tile loops are unrolled by the pipeline stages:
+// every LDS address is a precomputed per-lane offset + an immediate.  The dK/dV kernel is described at its definition; what was measured
+// while it was rebuilt in round 2: profiles/r02_flash_dkdv_rework.md.
+
+// Development switches of the dK/dV kernel (tools/kbench/mkvariant.sh builds a variant library with them; the product build defines none):
+//   IE_DKDV_ROW_AHEAD / IE_DKDV_TR_AHEAD: LDS prefetch distances (k-steps / MFMA pairs)
 #include "flash_common.h"
 
 #include <type_traits>
 
-// timing ablations of the dK / dV kernel (development only; results are then wrong): 1 no transposed reads, 2 no softmax, 4 no row reads,
-// 8 no S / dP MFMAs, 16 no dV / dK MFMAs, 32 no end-of-tile wait + barrier, 64 no lse / delta reads
+//   IE_FLASH_ABLATE (results then wrong): 1 no transposed reads, 2 no softmax, 4 no row reads, 8 no S / dP MFMAs, 16 no dV / dK MFMAs,
+//                   32 no tile wait + barrier, 64 no start-value reads
 #ifndef IE_DKDV_ROW_AHEAD
 #define IE_DKDV_ROW_AHEAD 2
 #endif
