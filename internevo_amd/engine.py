@@ -23,6 +23,7 @@ MI355X-first differences that do not change results beyond rounding order:
     the bucket's last weight-gradient GEMM is queued on the last micro-batch, overlapping backward.
 """
 import dataclasses
+import os
 import math
 
 import torch
@@ -869,8 +870,9 @@ class InternLM2Engine:
         main = torch.cuda.current_stream(self.dev)
         ev = torch.cuda.Event()
         ev.record(main)
-        with torch.cuda.stream(self.opt_stream):
-            self.opt_stream.wait_event(ev)  # gradients, norm and step control are final
+        opt_stream = main if os.environ.get("IE_SERIAL_ADAMW") == "1" else self.opt_stream   # (A/B switch: AdamW in line with the step)
+        with torch.cuda.stream(opt_stream):
+            opt_stream.wait_event(ev)  # gradients, norm and step control are final
             for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
                 s, n = b.shard(self.rank, self.world)
                 if n == 0:   # a bucket this pipeline stage does not own
@@ -879,7 +881,7 @@ class InternLM2Engine:
                              self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
                 self.comm.gather_bucket_async(self.params, b.index)
                 done = torch.cuda.Event()
-                done.record(self.opt_stream)
+                done.record(opt_stream)
                 self._bucket_ready[b.index] = done
             self._opt_done = done
         # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter

@@ -118,6 +118,17 @@ class MoEEngine:
                 self.runs[g][-1] = (self.runs[g][-1][0], o + numel)
             else:
                 self.runs[g].append((o, o + numel))
+        # AdamW of the previous step runs on its own stream under the next forward pass (as in the dense engine): one event per run, and the
+        # forward waits for the runs that hold the layer it is about to use
+        self.opt_stream = torch.cuda.Stream(device=device)
+        self._opt_events = None        # {run start offset: event}, "gate": event -- of the step() still in flight, if any
+
+        def run_of(name):
+            o = self.spec[name][0]
+            return next(a for grp in (0, 2) for a, b in self.runs[grp] if a <= o < b)
+
+        self._layer_runs = [sorted({run_of(f"blocks.{l}.norm1.weight"), run_of(f"blocks.{l}.mlp.w13"), run_of(f"blocks.{l}.mlp.w2")}) for l in range(L)]
+        self._embed_run, self._head_runs = run_of("embedding.weight"), sorted({run_of("norm.weight"), run_of("head.weight")})
         self._init_params(seed, init_fn)
         self.master.copy_(self.params)
         # ---- step state
@@ -185,6 +196,7 @@ class MoEEngine:
 
     def load_named_parameters(self, named, sync_master=True):
         """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters())."""
+        self._wait_optimizer()
         F = self.F
         for n, t in named.items():
             t = t.to(self.dev)
@@ -208,6 +220,7 @@ class MoEEngine:
 
     def named_parameters(self):
         """(reference name, tensor) pairs (copies for the re-ordered / fused tensors)."""
+        self._wait_optimizer()
         F, out = self.F, {}
         for n, shp in self.reference_param_shapes().items():
             if n.endswith("gate.wg.weight"):
@@ -258,11 +271,13 @@ class MoEEngine:
     def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
         mc, p = self.mc, self.p
         L, eps, H, d = mc.num_layers, mc.layer_norm_epsilon, mc.num_attention_heads, mc.head_dim
+        self._wait_runs([self._embed_run, "gate"])
         K.embedding_fwd(p["embedding.weight"], ids, self.a_x[0])
         moe_out = None
         self.l_aux = []
         for l in range(L):
             pre = f"blocks.{l}."
+            self._wait_runs(self._layer_runs[l])
             if l == 0:
                 K.rmsnorm_fwd(self.a_x[0], p[pre + "norm1.weight"], eps, self.a_n1[0], self.a_rstd1[0])
             else:
@@ -276,12 +291,14 @@ class MoEEngine:
             K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "norm2.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
             moe_out = self.t_h1
             self.l_aux.append(self.moe[l].forward(self.a_n2[l], self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], moe_out, noise=self._noise(self.T, mc.num_experts)).clone())
+        self._wait_runs(self._head_runs)
         K.add_rmsnorm_fwd(moe_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["head.weight"], self.t_logits)
         K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, acc, inv_m):
         mc, tc, p, g = self.mc, self.tc, self.p, self.g
+        self._wait_optimizer()   # the backward overwrites the gradients the last step's AdamW reads
         L, H, d, T = mc.num_layers, mc.num_attention_heads, mc.head_dim, self.T
         ws = self.t_norm_ws
         K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], inv_m, -100, tc.label_smoothing)
@@ -320,6 +337,19 @@ class MoEEngine:
             K.add_bf16(gb, tmp, gb)
         else:
             K.colsum(dy, gb)
+
+    def _wait_runs(self, keys):
+        """The current stream waits for the AdamW launches of the given runs (no-op when no step is in flight)."""
+        if self._opt_events is not None:
+            cur = torch.cuda.current_stream()
+            for k in keys:
+                cur.wait_event(self._opt_events[k])
+
+    def _wait_optimizer(self):
+        """Everything the last step() queued on the optimizer stream is ordered in front of what the current stream does next."""
+        if self._opt_events is not None:
+            torch.cuda.current_stream().wait_stream(self.opt_stream)
+            self._opt_events = None
 
     def forward_backward(self, batch, labels):
         """One NonPipelineScheduler.forward_backward_step.  Returns (loss incl. the moe loss, moe loss) as device scalars."""
@@ -365,6 +395,7 @@ class MoEEngine:
         expert-data group."""
         if self.world == 1:
             return
+        self._wait_optimizer()
 
         def bcast(t, src, group):
             if self.backend == "nccl":
@@ -409,10 +440,19 @@ class MoEEngine:
                                          K._p(self.group_inv[group : group + 1]), lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay, K._stream()),
                   "ie_adamw_step_group")
 
-        for grp in (0, 2):
-            for a, b in self.runs[grp]:
+        # on the optimizer stream, in the order the next forward pass needs the parameters (gates, then run by run from the embedding up)
+        self._wait_optimizer()
+        self.opt_stream.wait_stream(torch.cuda.current_stream())
+        events = {}
+        with torch.cuda.stream(self.opt_stream):
+            adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
+            events["gate"] = torch.cuda.Event()
+            events["gate"].record(self.opt_stream)
+            for a, b, grp in sorted((a, b, grp) for grp in (0, 2) for a, b in self.runs[grp]):
                 adam(self.grads[a:b], self.master[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.params[a:b], grp)
-        adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
+                events[a] = torch.cuda.Event()
+                events[a].record(self.opt_stream)
+        self._opt_events = events
         self.lr_sched.step()
         self.beta2_sched.step()
         self.step_count += 1
