@@ -429,3 +429,7 @@ def test_interleaved_pipeline_partition_order_and_plan():
             assert sends == recvs
             assert all(abs(a - b) in (1, pp - 1) for _, _, _, a, b in sends)
         assert ticks < 2 * micro * chunks + 2 * pp * chunks                        # bubble bounded by the fill / drain of the ring
+    for pp in range(2, 9):             # the replay always completes (a stage whose input has not arrived idles, it never blocks the others)
+        for chunks in (2, 3, 4):
+            for k in (1, 2, 3):
+                assert len(interleaved_plan(pp, chunks, pp * k)[0]) >= 2 * pp * k * chunks
