@@ -74,6 +74,24 @@ def cpu_baseline(cfg, budget_note=True):
     }
 
 
+def _self_launch(n):
+    """Re-run this command line as n ranks under torch.distributed.run on 127.0.0.1 with a free port; returns its exit code."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < (1 if os.environ.get("IE_BENCH_BACKEND") == "gloo" else n):
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (one process per GPU over RCCL)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,17 +127,44 @@ def main():
     K.LINEAR_FWD_VARIANT = args.fwd_variant
     if args.gemm_tail_split is not None:
         assert K._L().ie_tune_gemm_tail_split(args.gemm_tail_split) == 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over RCCL) and hand their
+        # single JSON line through.  Under torch.distributed.run (the driver's N > 1 command) WORLD_SIZE is set and this is skipped.
+        raise SystemExit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    # IE_BENCH_BACKEND=gloo is a TEST HOOK for boxes with one GPU (RCCL refuses two ranks on one device): every rank on cuda:0, the
+    # collectives staged through the host by comm.StagedGlooBackend -- it exercises the launch, the N-rank engine and this file's
+    # reductions end to end; the line it prints says so and is not a measurement.
+    staged = os.environ.get("IE_BENCH_BACKEND") == "gloo" and world > 1
+    if staged:
+        local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); one process per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        from internevo_amd.comm import backend_for
+
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        be = backend_for(None)
+
+        def all_reduce(t, op="sum"):   # over all ranks of the job, through the same Backend the engine uses
+            if op == "max":            # (max of non-negative values: gather and reduce locally)
+                parts = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+                be.all_gather(parts, t.contiguous().view(-1), None).wait()
+                t.copy_(parts.view(world, -1).max(dim=0).values.view_as(t))
+            else:
+                be.all_reduce(t, None).wait()
+            return t
 
     cfg = (internlm2_7b(args.seq_len) if args.config == "7B_internlm2" else llama2_7b(args.seq_len) if args.config == "7B_llama2"
            else tiny(seq_len=min(args.seq_len, 256)))
@@ -145,10 +190,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # loss / grad norm / loss scale of EVERY step (warm-up included), kept on the device: three 4-byte stream-ordered copies per step, no
+    # host synchronisation inside the timed region (grad_norm = IeStepState byte 32, loss_scale = byte 0)
+    traj = torch.zeros(args.warmup + args.steps, 3, dtype=torch.float32, device=dev)
+    n_done = [0]
+
     def one_step():
         batch, labels = next(loader)
         loss = eng.forward_backward(batch, labels)
         eng.step()
+        row = traj[n_done[0]]
+        row[0:1].copy_(loss.view(-1)[0:1])
+        row[1:2].copy_(eng.state[32:36].view(torch.float32))
+        row[2:3].copy_(eng.state[0:4].view(torch.float32))
+        n_done[0] += 1
         return loss
 
     for _ in range(args.warmup):
@@ -166,8 +221,7 @@ def main():
     K.GEMM_PROFILER = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        dt = float(all_reduce(t, "max"))
     st = eng.read_state()
     loss_val = float(loss)
     # what every rank sees of the communicator (rank 0 prints it: a job that silently ran as N independent 1-rank jobs would show here)
@@ -175,8 +229,9 @@ def main():
     if world > 1:
         seen = torch.zeros(world, dtype=torch.int64, device=dev)
         seen[rank] = torch.distributed.get_world_size()
-        torch.distributed.all_reduce(seen)   # SUM of one-hot rows: entry r = the world size rank r reports
-        comm_info = {"backend": torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
+        all_reduce(seen)   # SUM of one-hot rows: entry r = the world size rank r reports
+        comm_info = {"backend": "gloo, all ranks on ONE GPU, host-staged collectives (IE_BENCH_BACKEND test hook: NOT a measurement)" if staged
+                     else torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
     comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
     if world > 1 and args.tp == 1 and args.pp == 1:
         # data-parallel replicas must hold bit-identical parameters after the timed steps (reduce-scatter -> AdamW on the shard -> all-gather):
@@ -184,7 +239,7 @@ def main():
         eng.drain()
         chk = torch.zeros(world, dtype=torch.float64, device=dev)
         chk[rank] = eng.params.double().abs().sum()
-        torch.distributed.all_reduce(chk)
+        all_reduce(chk)
         comm_info["params_in_sync_across_ranks"] = bool((chk == chk[0]).all())
 
     tokens_step = tc.packed_length * tc.micro_num * world // (args.sp * args.tp * args.pp)
@@ -223,6 +278,10 @@ def main():
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,
         "frac_bf16_mfma_peak": exact_flops_per_token(mc, tc.seq_len) * tgs / MFMA_PEAK,
         "loss_last_step": loss_val,
+        # every step of this run in order, warm-up steps first (this rank's loss; the global grad norm; the loss scale after the step)
+        "loss_trajectory": [round(float(x), 5) for x in traj[:, 0].tolist()],
+        "grad_norm_trajectory": [round(float(x), 5) for x in traj[:, 1].tolist()],
+        "loss_scale_trajectory": [float(x) for x in traj[:, 2].tolist()],
         "grad_norm_last_step": st.grad_norm,
         "loss_scale": st.loss_scale,
         "skipped_steps": st.skipped_total,

@@ -217,12 +217,14 @@ def remove_stale_shards(folder, zero_world, tp_world):
     """Before a save into an existing folder: drop the shard / plan / topology files of an earlier save by a LARGER layout.  The
     loaders infer the saved layout from the highest file index present (saved_zero_world / saved_tp_world, as the reference's
     components.py:294-306 does), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would be merged as if
-    they belonged to it.  Called by ONE rank, before anyone writes."""
+    they belonged to it.  Called by ONE rank, before anyone writes.  Returns the names of the files it removed (the engine logs
+    them: this DELETES files in the user's checkpoint folder -- only names this module itself writes, only out-of-range indices)."""
+    removed = []
     if not os.path.isdir(folder):
-        return
+        return removed
     import re
 
-    for fn in os.listdir(folder):
+    for fn in sorted(os.listdir(folder)):
         m = re.fullmatch(r"optimizer_tp(\d+)_pp0_zo(\d+)\.pt", fn)
         stale = bool(m) and (int(m.group(1)) >= tp_world or int(m.group(2)) >= zero_world)
         m = re.fullmatch(r"(?:model_tp(\d+)_pp0\.pt|topo_tp(\d+)_pp0\.json)", fn)
@@ -231,6 +233,8 @@ def remove_stale_shards(folder, zero_world, tp_world):
         stale = stale or (bool(m) and (int(m.group(1)) != zero_world * tp_world or int(m.group(2)) >= tp_world or int(m.group(4)) >= zero_world))
         if stale:
             os.remove(os.path.join(folder, fn))
+            removed.append(fn)
+    return removed
 
 
 def saved_zero_world(folder, tp_rank=0):

@@ -36,7 +36,7 @@ from .schedule import Beta2Scheduler, CosineWarmupLR
 from .seqpar import SeqParallel
 from .pipeline import PipeParallel, interleaved_plan, partition_chunks, partition_uniform
 from .tensorpar import TensorParallel
-from .zero import ZeroComm
+from .zero import ZeroComm, job_dp_groups
 
 BF16 = torch.bfloat16
 
@@ -71,6 +71,9 @@ class InternLM2Engine:
             raise NotImplementedError("pipeline parallelism combines with data parallelism / ZeRO only (no tensor / sequence parallelism, "
                                       "no activation checkpointing) in this round")
         self.pp = pp_size
+        # every data-parallel group of the job (hybrid ZeRO creates its sub-groups collectively over all of them); a caller-supplied
+        # process group is taken as the job's only one
+        dp_groups = job_dp_groups(world_size, tp=tp_size, pp=pp_size) if process_group is None else None
         self.pipe = PipeParallel(pp_size, rank, world_size)
         # this stage's layers in the reference's numbering: one range, or one range per model chunk (interleaved schedule); `chunks` = the
         # same ranges in local layer indices, `gid[l]` = the global number of local layer l
@@ -109,7 +112,7 @@ class InternLM2Engine:
         self.world, self.rank = zs, rank % zs
         self.layout = FlatLayout(self.lmc, zs, self.gid, self.pipe.first, self.pipe.last)
         L = self.layout
-        self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs)
+        self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs, dp_groups=dp_groups)
         self.sp = sp_size
         self.seqpar = SeqParallel(sp_size, rank, world_size)
         if tp_size > 1:  # every rank of a tensor group reads the same batches
@@ -780,6 +783,8 @@ class InternLM2Engine:
         nothing saved for a backward that matters, gradients untouched).  `metric`: an AccPerplex that sees these logits instead
         of the training metric.  Returns the device scalar mean over micro-batches of the mean token loss."""
         tc = self.tc
+        if self.pp > 1:
+            raise NotImplementedError("forward-only (evaluation) passes have no pipeline schedule: run validation with parallel.pipeline.size = 1")
         B, S = input_ids.shape
         if S != tc.seq_len or B % tc.micro_bsz:
             raise ValueError(f"evaluation batch {tuple(input_ids.shape)}: rows must be seq_len = {tc.seq_len} long, their number a multiple of micro_bsz = {tc.micro_bsz}")
@@ -1085,7 +1090,9 @@ class InternLM2Engine:
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
         tp, t = self.tp, self.tpar.tp_rank
         if self.dp_rank == 0 and t == 0:   # shards of an earlier, larger layout in the same folder would be merged into this save by any loader
-            C.remove_stale_shards(folder, W, tp)
+            gone = C.remove_stale_shards(folder, W, tp)
+            if gone:
+                print(f"[internevo_amd] save_checkpoint({folder}): removed {len(gone)} shard files of an earlier, larger layout: {', '.join(gone)}", flush=True)
         self.comm.barrier()
         self.tpar.barrier()
         hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)

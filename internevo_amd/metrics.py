@@ -60,14 +60,12 @@ class AccPerplex:
     def get_metric(self, reset=True):
         """metrics.py:201-247 + :312-339 (keys, order, rounding identical)."""
         if self.dp_pg is not None or (self.dp_world > 1 and dist.is_initialized()):
-            if dist.get_backend(self.dp_pg) == "nccl":
-                dist.all_reduce(self._f, op=dist.ReduceOp.SUM, group=self.dp_pg)
-                dist.all_reduce(self._i, op=dist.ReduceOp.SUM, group=self.dp_pg)
-            else:  # gloo test path: stage through the host
-                for t in (self._f, self._i):
-                    c = t.cpu()
-                    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.dp_pg)
-                    t.copy_(c)
+            from .comm import backend_for
+
+            be = backend_for(self.dp_pg)
+            works = [be.all_reduce(t, self.dp_pg) for t in (self._f, self._i)]
+            for w in works:
+                w.wait()
         f, i = self._f.cpu(), self._i.cpu()
         n = self.ntypes
         right, total, tlp, loss, token_num, total_bytes = (f[k : k + 1] for k in range(6))

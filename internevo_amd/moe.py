@@ -79,15 +79,11 @@ class MoELayer:
     # ---- expert parallel exchange: [ep][El*C rows] send blocks <-> [ep][El*C] received (rank-major); the local experts then see,
     # for local expert j, the rows {g*El*C + j*C .. +C} of every source rank g -- processed as ep separate [C, M] GEMM operands
     def _a2a(self, send, recv):
-        import torch.distributed as dist
+        from .comm import backend_for
 
-        if dist.get_backend(self.ep_group) == "nccl":
-            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.ep_group)
-        else:  # gloo test path
-            s = send.detach().reshape(-1).to("cpu", copy=True)
-            r = torch.empty_like(s)
-            dist.all_to_all_single(r, s, group=self.ep_group)
-            recv.view(-1).copy_(r)
+        if getattr(self, "_be", None) is None:
+            self._be = backend_for(self.ep_group)
+        self._be.all_to_all(recv, send, self.ep_group).wait()
         return recv
 
     def forward(self, x, wg, w13, w2, out, noise=None):

@@ -9,9 +9,12 @@ Host-side mirror of
                                                       train/utils.py:25-80, solver/optimizer/hybrid_zero_optim.py:760-779,863-876
 Same construction as engine.InternLM2Engine (explicit backward over pre-allocated buffers, flat bf16 parameters / gradients, device-
 resident loss scale and step control, no host synchronisation inside a step); the scope of this engine is the single-rank and the
-data-parallel step (gradients averaged by all-reduce over the data-parallel group, optimizer state replicated -- `parallel.zero1.size = 1`
-semantics; the experts are local, expert parallel size 1).  Tensor / sequence parallelism, checkpoints and merged micro-batches are the
-dense engine's and are refused here (config.py).
+data-parallel step with the reference's automatic expert parallelism: ep = min(world, num_experts) (parallel_context.py:538-541), expert
+groups of ep CONSECUTIVE ranks each holding num_experts / ep experts, the [E, C, M] dispatch / combine buffers exchanged by one all_to_all per
+direction (moe.MoELayer), dense parameters and gates averaged by all-reduce over all ranks, an expert's gradient summed over its expert
+group's tokens and averaged over its expert-data group only, the moe group's norm scaled as solver/optimizer/utils.py:362-368; optimizer
+state replicated (`parallel.zero1.size = 1` semantics).  Tensor / sequence / pipeline parallelism, checkpoints and merged micro-batches
+are the dense engine's and are refused here (config.py).
 Weights: Wqkv is kept in the [head][q, k, v][d] row order of the shared rotary / attention kernels and converted at the naming boundary
 (`named_parameters` / `load_named_parameters`), exactly like LLAMA2's wq / wk / wv in the dense engine.
 """
@@ -22,6 +25,7 @@ import torch.distributed as dist
 
 from . import kernels as K
 from ._lib import IeScalerConfig, check
+from .comm import backend_for
 from .config import PathConfig
 from .moe import MoELayer
 from .schedule import Beta2Scheduler, CosineWarmupLR
@@ -55,7 +59,8 @@ class MoEEngine:
         self.dev, self.world, self.rank, self.group = device, world_size, rank, process_group
         if world_size > 1 and not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised for world_size > 1")
-        self.backend = dist.get_backend(process_group) if world_size > 1 else None
+        self.be = backend_for(process_group) if world_size > 1 else None
+        self.backend = self.be.name if self.be else None
         # Expert parallelism as the reference sets it up (parallel_context.py:538-541: ep = min(data-parallel size, num_experts); expert groups =
         # ep CONSECUTIVE data-parallel ranks, expert-data groups = the ranks with the same position in their expert group): every rank holds
         # E / ep experts, its tokens visit the others through the all_to_all of the dispatch buffers (moe.MoELayer).
@@ -380,15 +385,10 @@ class MoEEngine:
 
     # ------------------------------------------------------------------------------------------ optimizer
     def _all_reduce(self, t, group, size, avg=True):
-        """In-place all-reduce (AVG, or SUM) over `group` of `size` ranks; RCCL directly, gloo (tests) through the host."""
+        """In-place all-reduce (AVG, or SUM) over `group` of `size` ranks (comm.Backend)."""
         if size == 1:
             return
-        if self.backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
-        else:
-            c = t.detach().float().to("cpu")
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
-            t.copy_((c / size if avg else c).to(t.dtype))
+        self.be.all_reduce(t, group, avg=avg).wait()
 
     def sync_replicas(self):
         """sync_model_param (utils/parallel.py:71-107): dense parameters and gates from rank 0, every expert from the first rank of its
@@ -398,12 +398,7 @@ class MoEEngine:
         self._wait_optimizer()
 
         def bcast(t, src, group):
-            if self.backend == "nccl":
-                dist.broadcast(t, src=src, group=group)
-            else:
-                c = t.detach().to("cpu")
-                dist.broadcast(c, src=src, group=group)
-                t.copy_(c)
+            self.be.broadcast(t, src, group).wait()
 
         for a, b in self.runs[0]:
             bcast(self.params[a:b], 0, None)

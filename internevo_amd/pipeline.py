@@ -26,8 +26,9 @@ and receives behind it.  All stages then run the same number of ticks with ONE p
 same tick's exchange: no ordering of individual sends and receives between two ranks can deadlock (RCCL point-to-point operations of a pair
 share a stream), and a message that arrives before its consumer runs waits in that micro-batch's own buffer.
 """
-import torch
 import torch.distributed as dist
+
+from .comm import backend_for
 
 
 def partition_uniform(num_layers, pp):
@@ -134,6 +135,7 @@ class PipeParallel:
         self.stage_rank = [s * self.dp_world + self.dp_rank for s in range(pp_size)]   # global rank of every stage of this pipeline (the ring of the interleaved schedule)
         self.dp_group = self.group = None
         self.backend = None
+        self.be = None
         if pp_size > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for pipeline parallelism")
@@ -147,50 +149,27 @@ class PipeParallel:
                 grp = dist.new_group(ranks)
                 if rank in ranks:
                     self.group = grp
-            self.backend = dist.get_backend(self.group)
+            self.be = backend_for(self.group)
+            self.backend = self.be.name
 
     # ---- point to point: one call = the sends and receives that may proceed together ----------------------------------------
     def exchange(self, sends=(), recvs=()):
-        """sends / recvs: [(device tensor, global peer rank)].  Returns after all of them completed (the receive buffers are valid,
-        the send buffers reusable).  RCCL: device buffers directly; gloo (tests): staged through the host."""
+        """sends / recvs: [(device tensor, global peer rank)].  Returns after all of them are ordered in front of the current stream
+        (the receive buffers are valid, the send buffers reusable): ONE batch_isend_irecv on RCCL."""
         if not sends and not recvs:
             return
-        if self.backend == "nccl":
-            ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends] + [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            return
-        host_s = [(t.detach().to("cpu", copy=True).contiguous(), peer) for t, peer in sends]
-        host_r = [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
-        work = [dist.isend(c, peer) for c, peer in host_s] + [dist.irecv(c, peer) for c, peer in host_r]
-        for w in work:
-            w.wait()
-        for (t, _), (c, _) in zip(recvs, host_r):
-            t.copy_(c)
+        self.be.exchange(list(sends), list(recvs)).wait()
 
     def all_reduce_sum(self, t):
         """In-place sum over the stages of this pipeline (squared gradient norm)."""
-        if self.pp == 1:
-            return t
-        if self.backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            c = t.detach().to("cpu", copy=True)
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(c)
+        if self.pp > 1:
+            self.be.all_reduce(t, self.group).wait()
         return t
 
     def broadcast_from_last(self, t):
         """The last stage's value of `t` (the loss) on every stage of the pipeline."""
-        if self.pp == 1:
-            return t
-        src = (self.pp - 1) * self.dp_world + self.dp_rank
-        if self.backend == "nccl":
-            dist.broadcast(t, src=src, group=self.group)
-        else:
-            c = t.detach().to("cpu", copy=True)
-            dist.broadcast(c, src=src, group=self.group)
-            t.copy_(c)
+        if self.pp > 1:
+            self.be.broadcast(t, (self.pp - 1) * self.dp_world + self.dp_rank, self.group).wait()
         return t
 
     def barrier(self):

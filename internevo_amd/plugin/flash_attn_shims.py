@@ -123,13 +123,9 @@ def _group_all_gather(t, group):
 
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    else:  # gloo (tests): through the host
-        c = t.detach().to("cpu", copy=True).contiguous()
-        parts = [torch.empty_like(c) for _ in range(world)]
-        dist.all_gather(parts, c, group=group)
-        out.copy_(torch.stack(parts))
+    from ..comm import backend_for
+
+    backend_for(group).all_gather(out, t.contiguous(), group).wait()
     return out
 
 

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from .comm import backend_for
 
 
 class SeqParallel:
@@ -32,6 +33,7 @@ class SeqParallel:
         self.data_world = world_size // sp_size
         self.group = None
         self.backend = None
+        self.be = None
         if sp_size > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for sequence parallelism")
@@ -42,33 +44,23 @@ class SeqParallel:
                 grp = dist.new_group(ranks)
                 if rank in ranks:
                     self.group = grp
-            self.backend = dist.get_backend(self.group)
+            self.be = backend_for(self.group)
+            self.backend = self.be.name
 
     # ---- the exchange: send[r] (contiguous chunk r) -> rank r; recv[s] <- rank s -------------------------------------
     def all_to_all_async(self, send, recv):
         """Start the exchange; returns a handle whose .wait() orders the current stream behind it.  On RCCL it runs on c10d's
         stream (after the work already queued on the current stream), so kernels launched before .wait() overlap it -- the engine
-        puts the neighbouring weight-gradient GEMM / the other tensor's packing copy there.  (gloo test path: done on return.)"""
+        puts the neighbouring weight-gradient GEMM / the other tensor's packing copy there.  `recv` is valid only after .wait()."""
         # flat views: chunk r of the send buffer is its r-th 1/sp, whatever shape the caller gives the tensors
-        if self.backend == "nccl":
-            return dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
-        s = send.detach().reshape(-1).to("cpu", copy=True)   # CPU tensors only
-        r = torch.empty_like(s)
-        dist.all_to_all_single(r, s, group=self.group)
-        recv.view(-1).copy_(r)
-        return _DONE
+        return self.be.all_to_all(recv, send, self.group)
 
     def all_to_all(self, send, recv):
         self.all_to_all_async(send, recv).wait()
         return recv
 
     def all_reduce_sum(self, t):
-        if self.backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            c = t.detach().to("cpu", copy=True)
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(c)
+        self.be.all_reduce(t, self.group).wait()
         return t
 
     # ---- heads <-> sequence ------------------------------------------------------------------------------------------
@@ -94,14 +86,6 @@ class SeqParallel:
 
     def scatter_seq_gather_heads(self, x_full, B, recv_buf, out_local):
         return self.scatter_seq_gather_heads_async(x_full, B, recv_buf, out_local).wait()
-
-
-class _Done:
-    def wait(self):
-        return True
-
-
-_DONE = _Done()
 
 
 class _Exchange:

@@ -22,13 +22,7 @@ the same numbers.
 import torch
 import torch.distributed as dist
 
-
-class _Done:
-    def wait(self):
-        return True
-
-
-_DONE = _Done()
+from .comm import DONE, backend_for
 
 
 class TensorParallel:
@@ -43,6 +37,7 @@ class TensorParallel:
         self.group = None      # the tensor group this rank belongs to
         self.dp_group = None   # ranks holding the same shard (gradient averaging / ZeRO-1)
         self.backend = None
+        self.be = None
         if tp_size > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for tensor parallelism")
@@ -56,52 +51,37 @@ class TensorParallel:
                 grp = dist.new_group(ranks)
                 if rank in ranks:
                     self.dp_group = grp
-            self.backend = dist.get_backend(self.group)
-
-    def all_reduce_sum(self, t):
-        """In-place sum over the tensor group (the `g` operator of a row-parallel output / a column-parallel input gradient)."""
-        if self.tp == 1:
-            return t
-        if self.backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        else:  # gloo test path: through the host
-            c = t.detach().to("cpu", copy=True)
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(c)
-        return t
+            self.be = backend_for(self.group)
+            self.backend = self.be.name
 
     def all_reduce_sum_async(self, t):
-        """Start the in-place sum and return a handle; `.wait()` orders the CURRENT stream behind it.  On RCCL the collective runs
-        on c10d's own HIP stream (which first waits for the work already queued on the current stream, i.e. for the GEMM that
-        produced `t`), so kernels launched between this call and `.wait()` overlap it: the engine puts the weight-gradient GEMM of
-        the same layer there, as the reference does with its column-parallel backward (model/utils.py:329-345: all_reduce(grad_input,
-        async_op=True) -> wgrad -> handle.wait()).  On the gloo test path the sum is already complete when this returns."""
+        """Start the in-place sum over the tensor group (the `g` operator of a row-parallel output / a column-parallel input gradient)
+        and return a handle; `.wait()` orders the CURRENT stream behind it.  On RCCL the collective runs on c10d's own HIP stream
+        (which first waits for the work already queued on the current stream, i.e. for the GEMM that produced `t`), so kernels
+        launched between this call and `.wait()` overlap it: the engine puts the weight-gradient GEMM of the same layer there, as
+        the reference does with its column-parallel backward (model/utils.py:329-345: all_reduce(grad_input, async_op=True) ->
+        wgrad -> handle.wait()).  `t` must not be touched before `.wait()` (the staged test backend lands the sum only there)."""
         if self.tp == 1:
-            return _DONE
-        if self.backend == "nccl":
-            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.all_reduce_sum(t)
-        return _DONE
+            return DONE
+        return self.be.all_reduce(t, self.group)
+
+    def all_reduce_sum(self, t):
+        self.all_reduce_sum_async(t).wait()
+        return t
 
     def all_gather(self, t):
         """[tp, *t.shape] tensor with every rank's `t` (rank order).  Small per-token statistics only (vocabulary-parallel loss)."""
         if self.tp == 1:
             return t.unsqueeze(0)
         out = torch.empty((self.tp,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        if self.backend == "nccl":
-            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        else:  # gloo test path: through the host
-            c = t.detach().to("cpu", copy=True).contiguous()
-            parts = [torch.empty_like(c) for _ in range(self.tp)]
-            dist.all_gather(parts, c, group=self.group)
-            out.copy_(torch.stack(parts))
+        self.be.all_gather(out, t.contiguous(), self.group).wait()
         return out
 
-    # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def barrier(self):
         if self.tp > 1:
             dist.barrier(group=self.group)
 
+    # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
         if self.tp == 1 or kind in ("embed", "norm") or (kind == "head" and not self.vocab_parallel):

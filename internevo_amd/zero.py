@@ -11,15 +11,31 @@ all-reduce + broadcast (2x the necessary bytes, the owner needs only its shard) 
   all_gather_into_tensor      <- updated bf16 shards, in place in the flat params
 launched asynchronously per bucket (c10d runs them on its own HIP stream and orders them against
 the compute stream), waited only where the values are consumed.
-Backends: "nccl" (= RCCL on ROCm) is the product path.  "gloo" exists for the multi-process tests
-(CPU tensors, or device tensors staged through the host): same bucket/shard arithmetic, synchronous.
+Backends: every collective goes through a comm.Backend ("nccl" = RCCL, the product; "gloo" = the staged
+test backend that lands results only in wait()): there is ONE code path here, the tests drive the very
+calls, aliasing and wait() placement the RCCL run executes (comm.py).
 """
 import torch
 import torch.distributed as dist
 
+from .comm import backend_for
+
+
+def job_dp_groups(world_size, tp=1, pp=1):
+    """Every data-parallel group of a job as lists of global ranks, in a job-wide fixed order: the ranks that hold the same
+    model-parallel shard.  Tensor (or sequence-as-tensor) groups are consecutive ranks, so their data-parallel groups are the
+    residue classes modulo tp (tensorpar.py); pipeline stages are blocks of consecutive ranks (pipeline.py), so a stage IS a
+    data-parallel group (parallel_context.py:499-520, process_group_initializer.py)."""
+    if tp > 1 and pp > 1:
+        raise NotImplementedError("pipeline x tensor parallelism")
+    if pp > 1:
+        per = world_size // pp
+        return [list(range(s * per, (s + 1) * per)) for s in range(pp)]
+    return [list(range(t, world_size, tp)) for t in range(tp)]
+
 
 class ZeroComm:
-    def __init__(self, layout, group=None, world_size=1, rank=0, force_collectives=False, zero_size=None):
+    def __init__(self, layout, group=None, world_size=1, rank=0, force_collectives=False, zero_size=None, dp_groups=None):
         """group / world_size / rank: the data-parallel group (ranks that hold the same model-parallel shard).
         zero_size = z < world_size: hybrid ZeRO ("ZeRO-1.5", parallel.zero1.size; parallel_context.py:499-520,
         process_group_initializer.py:249-329): the fp32 state is sharded over groups of z CONSECUTIVE data-parallel ranks and
@@ -27,6 +43,9 @@ class ZeroComm:
         whole data-parallel group: reduce-scatter(AVG) inside the zero group, all-reduce(AVG) of the 1/z shard across the
         replicas (ranks with the same position in their zero group); parameters are all-gathered inside the zero group.
         `layout` must have been built for z shards.
+        dp_groups: EVERY data-parallel group of the job (job_dp_groups), needed for hybrid ZeRO when the job has more than one
+        (tensor or pipeline parallelism): new_group is collective over the whole job, so every rank creates every zero / replica
+        group of every data-parallel group in the same order.  None = this group is the only one.
         force_collectives: issue the collectives even on a 1-rank group (they are identities there) -- lets a single-GPU
         test drive the exact RCCL call sequence of the multi-GPU path."""
         self.layout = layout
@@ -46,40 +65,44 @@ class ZeroComm:
         self.gathers = {}
         self.active = world_size > 1 or force_collectives
         self.side = None
+        self.be = None
         if self.active:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for world_size > 1")
-            self.backend = dist.get_backend(group)
+            self.be = backend_for(group)
+            self.backend = self.be.name
             if z < world_size:
                 members = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+                if len(members) != world_size:
+                    raise ValueError(f"the data-parallel group has {len(members)} ranks, world_size says {world_size}")
+                groups = [list(g) for g in dp_groups] if dp_groups is not None else [members]
+                if members not in groups:
+                    raise ValueError(f"this rank's data-parallel group {members} is not among the job's {groups}")
+                me = members[rank]
                 # every rank of the job takes part in the creation of every group, in the same order (new_group is collective
                 # over the default group): callers construct ZeroComm on all ranks at the same point
-                for others in self._all_dp_groups(members):
+                for others in groups:
                     for g0 in range(0, world_size, z):
                         ranks = others[g0 : g0 + z]
                         grp = dist.new_group(ranks)
-                        if members[rank] in ranks and others == members:
+                        if me in ranks:
                             self.group = grp
                     for j in range(z):
                         ranks = others[j::z]
                         grp = dist.new_group(ranks)
-                        if members[rank] in ranks and others == members:
+                        if me in ranks:
                             self.replica_group = grp
-                if self.backend == "nccl":
-                    # the second hop is ordered behind the first on a side stream, never on the compute stream
-                    self.side = torch.cuda.Stream()
+                assert self.group is not group and self.replica_group is not None
         else:
             self.backend = None
 
-    @staticmethod
-    def _all_dp_groups(members):
-        """All data-parallel groups of the job, as lists of global ranks, in a job-wide fixed order.  Data-parallel groups are the
-        residue classes of the global rank modulo the model-parallel size (tensorpar.py: rank % tp), i.e. strided by
-        stride = members[1] - members[0]."""
-        if len(members) < 2:
-            return [members]
-        stride = members[1] - members[0]
-        return [[m - members[0] + o for m in members] for o in range(stride)]
+    def _side_stream(self, device):
+        """The stream the second hop of hybrid ZeRO is ordered on (never the compute stream); None on a CPU test."""
+        if device.type != "cuda":
+            return None
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
+        return self.side
 
     # ---- gradients: bucket -> averaged shard on its owner ----------------------------------------
     def reduce_bucket_async(self, grads_flat, bucket_index):
@@ -88,30 +111,25 @@ class ZeroComm:
         b = self.layout.buckets[bucket_index]
         full = grads_flat[b.start : b.start + b.size]
         s, n = b.shard(self.rank, self.world)
-        shard = grads_flat[s : s + n]
-        if self.backend == "nccl":
-            if self.replica_group is None:
-                work = dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        shard = grads_flat[s : s + n]     # the owner's slice OF `full`: the reduce-scatter is in place
+        if self.replica_group is None:
+            work = self.be.reduce_scatter(shard, full, self.group, avg=True)
+        else:
+            side = self._side_stream(grads_flat.device)
+            if side is None:
+                first = self.be.reduce_scatter(shard, full, self.group, avg=True)
+                first.wait()
+                work = self.be.all_reduce(shard, self.replica_group, avg=True)
             else:
                 cur = torch.cuda.current_stream(grads_flat.device)
                 ready = torch.cuda.Event()
                 ready.record(cur)                       # the bucket's last weight gradient is queued
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(ready)
-                    first = dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    first = self.be.reduce_scatter(shard, full, self.group, avg=True)
                     first.wait()                        # orders the SIDE stream (not the compute stream) behind the first hop
-                    work = dist.all_reduce(shard, op=dist.ReduceOp.AVG, group=self.replica_group, async_op=True)
-            self.pending.append((work, None))
-        else:
-            # test path: gloo has no AVG / in-place reduce-scatter and no device tensors -> host staging, SUM, scale
-            src = full.detach().to("cpu", copy=True)
-            tmp = torch.empty(n, dtype=src.dtype)
-            dist.reduce_scatter_tensor(tmp, src, op=dist.ReduceOp.SUM, group=self.group)
-            acc = tmp.float() / self.world
-            if self.replica_group is not None:
-                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.replica_group)
-                acc /= self.n_replica
-            shard.copy_(acc.to(shard.dtype))
+                    work = self.be.all_reduce(shard, self.replica_group, avg=True)
+        self.pending.append(work)
 
     # ---- parameters: updated shard -> every rank ---------------------------------------------------
     def gather_bucket_async(self, params_flat, bucket_index):
@@ -120,32 +138,19 @@ class ZeroComm:
         b = self.layout.buckets[bucket_index]
         full = params_flat[b.start : b.start + b.size]
         s, n = b.shard(self.rank, self.world)
-        shard = params_flat[s : s + n]
-        if self.backend == "nccl":
-            work = dist.all_gather_into_tensor(full, shard, group=self.group, async_op=True)
-            self.gathers[bucket_index] = work
-        else:
-            src = shard.detach().to("cpu", copy=True)
-            tmp = torch.empty(b.size, dtype=src.dtype)
-            dist.all_gather_into_tensor(tmp, src, group=self.group)
-            full.copy_(tmp)
+        shard = params_flat[s : s + n]    # the owner's slice OF `full`: the all-gather is in place
+        self.gathers[bucket_index] = self.be.all_gather(full, shard, self.group)
 
     def gather_full_bucket(self, local_flat, local_offset, bucket_index):
-        """Checkpointing only (synchronous): this rank's slice of a bucket of optimizer state -> the whole bucket on every rank.
-        Returns a device tensor on the RCCL path, a host tensor on the gloo test path."""
+        """Checkpointing only (synchronous): this rank's slice of a bucket of optimizer state -> the whole bucket on every rank."""
         b = self.layout.buckets[bucket_index]
         n = b.size // self.world
         shard = local_flat[local_offset : local_offset + n]
         if not self.active or self.world == 1:
             return shard
-        if self.backend == "nccl":
-            full = torch.empty(b.size, dtype=shard.dtype, device=shard.device)
-            dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
-            return full
-        src = shard.detach().to("cpu", copy=True)
-        tmp = torch.empty(b.size, dtype=src.dtype)
-        dist.all_gather_into_tensor(tmp, src, group=self.group)
-        return tmp
+        full = torch.empty(b.size, dtype=shard.dtype, device=shard.device)
+        self.be.all_gather(full, shard.contiguous(), self.group).wait()
+        return full
 
     def barrier(self):
         if self.active and self.dp_world > 1:
@@ -160,10 +165,8 @@ class ZeroComm:
             work.wait()
 
     def wait_all(self):
-        for work, fin in self.pending:
+        for work in self.pending:
             work.wait()
-            if fin is not None:
-                fin()
         self.pending = []
 
     def wait_all_gathers(self):
@@ -171,13 +174,10 @@ class ZeroComm:
             self.wait_gather(b)
 
     def all_reduce_sum(self, t):
+        """In-place sum over the ZERO group (the squared-norm scalar: every replica holds the same shards, so the sum over one
+        zero group is the global value -- solver/optimizer/utils.py:352-357 reduces over ZERO1 too)."""
         if self.active:
-            if self.backend == "nccl":
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            else:
-                c = t.detach().to("cpu", copy=True)
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-                t.copy_(c)
+            self.be.all_reduce(t, self.group).wait()
         return t
 
     def broadcast_params(self, params_flat, src=0):
@@ -185,9 +185,4 @@ class ZeroComm:
         if self.active:
             if self.dp_group is not None:
                 src = dist.get_global_rank(self.dp_group, src)  # `src` counts inside the data-parallel group
-            if self.backend == "nccl":
-                dist.broadcast(params_flat, src=src, group=self.dp_group)
-            else:
-                c = params_flat.detach().to("cpu", copy=True)
-                dist.broadcast(c, src=src, group=self.dp_group)
-                params_flat.copy_(c)
+            self.be.broadcast(params_flat, src, self.dp_group).wait()

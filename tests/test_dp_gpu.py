@@ -318,6 +318,58 @@ def test_rccl_call_sequence_on_one_rank_group(dev):
     assert (p0 == p1).all()
 
 
+def _rccl_prims_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from internevo_amd.comm import RcclBackend, backend_for
+
+        be = backend_for(None)
+        ok = isinstance(be, RcclBackend)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        x = torch.randn(4096, generator=gen, device=dev).to(torch.bfloat16)
+        want = x.clone()
+        # in place, destination aliasing the source: the forms zero.py issues
+        be.reduce_scatter(x[0:4096], x, None, avg=True).wait()
+        ok &= bool(torch.equal(x, want))
+        be.all_gather(x, x[0:4096], None).wait()
+        ok &= bool(torch.equal(x, want))
+        be.all_reduce(x, None, avg=True).wait()
+        be.all_reduce(x, None).wait()
+        ok &= bool(torch.equal(x, want))
+        y = torch.empty_like(x)
+        be.all_to_all(y, x, None).wait()
+        ok &= bool(torch.equal(y, want))
+        be.broadcast(x, 0, None).wait()
+        ok &= bool(torch.equal(x, want))
+        # the paired point-to-point batch of pipeline.py, with this rank as its own neighbour
+        z = torch.zeros_like(x)
+        be.exchange([(x, 0)], [(z, 0)]).wait()
+        torch.cuda.synchronize()
+        ok &= bool(torch.equal(z, want))
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_primitives_on_one_rank_group(dev):
+    """comm.RcclBackend -- every primitive the parallel modes use (in-place reduce-scatter / all-gather on aliasing slices, all-reduce
+    AVG and SUM, all_to_all_single, broadcast, the batched isend + irecv pair) -- through real RCCL on a one-rank communicator, where
+    each of them must be an identity."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_prims_worker, args=(29877, q))
+    p.start()
+    assert _collect(q, [p], 1)[0] is True
+    p.join(60)
+
+
 def _sp_worker(rank, world, port, q):
     import torch.distributed as dist
 
@@ -598,7 +650,7 @@ def _pp_cfg(layers, micro_num):
     return tiny(hidden=256, layers=layers, heads=4, kv_heads=2, vocab=512, seq_len=128, micro_num=micro_num, lr=1e-3, total_steps=6)
 
 
-def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1):
+def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1, zero=None):
     import torch.distributed as dist
 
     dev = _init_dist(rank, world, port)
@@ -607,7 +659,9 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1):
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        eng = InternLM2Engine(_pp_cfg(layers, micro_num), dev, None, world, rank, init_fn=formula_init, pp_size=pp, num_chunks=chunks)
+        eng = InternLM2Engine(_pp_cfg(layers, micro_num), dev, None, world, rank, init_fn=formula_init, pp_size=pp, num_chunks=chunks, zero_size=zero)
+        if zero:   # hybrid ZeRO inside every stage: this stage's own zero / replica groups (the ADVICE r2 case: stage >= 1 used to keep the whole dp group)
+            assert (eng.world, eng.comm.n_replica) == (zero, eng.pipe.dp_world // zero) and eng.comm.replica_group is not None
         loader = iter(SyntheticLoader(128, 1, micro_num, fixed, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
         for _ in range(3):
@@ -621,12 +675,14 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("pp,dp,layers,micro_num,chunks", [
-    (2, 1, 3, 4, 1), (2, 1, 2, 1, 1), pytest.param(4, 1, 5, 6, 1, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 2, 2, 1, marks=pytest.mark.ranks(4)),
-    (2, 1, 4, 4, 2), (2, 1, 6, 2, 3), pytest.param(4, 1, 8, 8, 2, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 4, 2, 2, marks=pytest.mark.ranks(4))],
+@pytest.mark.parametrize("pp,dp,layers,micro_num,chunks,zero", [
+    (2, 1, 3, 4, 1, None), (2, 1, 2, 1, 1, None), pytest.param(4, 1, 5, 6, 1, None, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 2, 2, 1, None, marks=pytest.mark.ranks(4)),
+    (2, 1, 4, 4, 2, None), (2, 1, 6, 2, 3, None), pytest.param(4, 1, 8, 8, 2, None, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 4, 2, 2, None, marks=pytest.mark.ranks(4)),
+    pytest.param(2, 4, 3, 2, 1, 2, marks=pytest.mark.ranks(8))],
     ids=["pp2_3layers_4micro", "pp2_2layers_1micro", "pp4_5layers_6micro", "pp2_dp2",
-         "interleaved_pp2_2chunks_4micro", "interleaved_pp2_3chunks_all_warmup", "interleaved_pp4_2chunks_8micro", "interleaved_pp2_dp2"])
-def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, layers, micro_num, chunks):
+         "interleaved_pp2_2chunks_4micro", "interleaved_pp2_3chunks_all_warmup", "interleaved_pp4_2chunks_8micro", "interleaved_pp2_dp2",
+         "pp2_dp4_hybrid_zero2"])
+def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, layers, micro_num, chunks, zero):
     """1F1B pipeline parallelism (parallel.pipeline = dict(size=pp); pipeline_scheduler.py:111-709), non-interleaved and -- chunks > 1,
     model.num_chunks -- interleaved (:711-1430: every stage holds `chunks` model chunks, micro-batches go round the ring of stages once
     per chunk; micro_num == pp is the reference's all-warm-up special case), vs ONE rank on the
@@ -634,7 +690,7 @@ def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, la
     parameters after three optimizer steps.  3 layers over 2 stages / 5 over 4 = the uneven splits of partition_uniform (the last
     stages take the extra layers); 4 and 6 micro-batches exercise warm-up, steady state and cool-down, 1 micro-batch the degenerate
     schedule; pp2_dp2 = two pipelines of two stages with ZeRO-1 inside each stage (the single rank then runs the union of both
-    pipelines' micro-batches)."""
+    pipelines' micro-batches); pp2_dp4_hybrid_zero2 = parallel.zero1.size 2 inside stages of four data-parallel ranks."""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
@@ -643,7 +699,8 @@ def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, la
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     fixed = dp > 1   # (the sampler interleaves data-parallel ranks: with fixed-length samples 1 rank x (dp * M) micro-batches is the same set)
-    procs = [ctx.Process(target=_pp_worker, args=(r, world, 29871 + micro_num + 10 * pp + 100 * chunks, q, pp, layers, micro_num, fixed, chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_pp_worker, args=(r, world, 29871 + micro_num + 10 * pp + 100 * chunks + 7 * dp, q, pp, layers, micro_num, fixed, chunks, zero))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, world), key=lambda x: x[0])

@@ -362,3 +362,44 @@ def test_engine_7b_shaped_layer_full_size_matches_oracle(dev):
             worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
     print("max |param diff| after 2 steps:", worst)
     assert worst <= 8e-3
+
+
+@pytest.mark.timeout(2400)
+def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
+    """The step bench.py times, at the model's full WIDTH with one layer: micro_num = 4 micro-batches of ONE 4096-token sequence each
+    (fixed_random_dataset_seqlen=True, the benchmark's data) run as the merged 16 384-row pass -- the 16 384-row GEMM tile dispatch, the
+    attention call of four 4096-token sequences (flash_fwd64_k, multi-round dK/dV grid with head split), the per-micro-batch cross-entropy
+    segments, one weight gradient over all 16 384 tokens -- against the CPU oracle, which walks the four micro-batches one after the
+    other with autograd's bf16 gradient accumulation."""
+    from internevo_amd.config import internlm2_7b
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+    from oracle.step import OracleTrainer
+
+    cfg = internlm2_7b(4096)
+    cfg.model.num_layers = 1
+    cfg.train.micro_num = 4
+    cfg.train.total_steps = 4
+    cfg.train.fixed_random_dataset_seqlen = True
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    assert eng.mm == 4 and eng.Tg == 16384, "the merged pass must be the automatic choice here, as in bench.py"
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    loader = iter(SyntheticLoader(4096, 1, 4, True, 4000))
+    for k in range(2):
+        batch, labels = next(loader)
+        assert all(len(c) == 2 for c in batch["cu_seqlens"])   # one 4096-token sequence per micro-batch
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        ref = ora.train_step(batch, labels)
+        print(f"7B-width merged step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
+        assert st.skip == 0
+        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])            # the north star's loss tolerance
+        assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+    worst = 0.0
+    for n, p in eng.named_parameters():
+        if n in ("layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
+            worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
+    print("max |param diff| after 2 merged steps:", worst)
+    assert worst <= 8e-3

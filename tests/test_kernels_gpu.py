@@ -24,10 +24,20 @@ def bf(t):
     return t.to(torch.bfloat16)
 
 
-def close(got, ref, rtol, atol, what=""):
+FLASH_RMS = 5e-3   # ||got - ref|| / ||ref|| bound of every flash-attention output / gradient (bf16 P and dS tiles, fp32 accumulation)
+
+
+def close(got, ref, rtol, atol, what="", rms=None):
+    """Element-wise |got - ref| <= atol + rtol |ref|, and -- `rms` given -- the relative l2 error ||got - ref|| / ||ref|| <= rms: the element-wise
+    bound has to admit the bf16 rounding of the largest elements, the l2 bound catches a systematic error of a few per cent in one tile
+    product that the absolute term would let through."""
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    if rms is not None:
+        rel = float((got - ref).double().norm() / ref.double().norm().clamp_min(1e-30))
+        print(f"[rel-l2] {what}: {rel:.3e} (bound {rms:.1e})")
+        assert rel <= rms, f"{what}: relative l2 error {rel:.3e} > {rms:.1e}"
     err = (got - ref).abs()
     tol = atol + rtol * ref.abs()
     bad = err > tol
@@ -406,11 +416,11 @@ def _attn_case(dev, lens, hq, hkv, d, causal, seed):
     (ref * do.float()).sum().backward()
     qd, kvd = q.to(dev), kv.to(dev)
     out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), None, causal)
-    close(out, ref, 1.6e-2, 2e-2, f"flash fwd lens={lens} hq={hq} hkv={hkv} d={d} causal={causal}")
+    close(out, ref, 1.6e-2, 2e-2, f"flash fwd lens={lens} hq={hq} hkv={hkv} d={d} causal={causal}", rms=FLASH_RMS)
     dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
-    close(dq, q32.grad, 2e-2, 3e-2, "flash dq")
-    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "flash dk")
-    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "flash dv")
+    close(dq, q32.grad, 2e-2, 3e-2, "flash dq", rms=FLASH_RMS)
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "flash dk", rms=FLASH_RMS)
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "flash dv", rms=FLASH_RMS)
 
 
 @pytest.mark.parametrize("lens,hq,hkv,d,causal", [
@@ -426,6 +436,15 @@ def test_flash_attention(dev, lens, hq, hkv, d, causal):
     _attn_case(dev, lens, hq, hkv, d, causal, 60)
 
 
+@pytest.mark.timeout(1200)
+def test_flash_attention_benchmark_regime_matches_oracle(dev):
+    """The attention call of the BENCHMARK step itself (bench.py, configs[1] with the micro-batches merged): four packed sequences of 4096
+    tokens = 16 384 rows, 32 query / 8 kv heads of 128, causal, through the DEFAULT dispatch -- flash_fwd64_k (automatic from 2048 tokens per
+    sequence), the multi-round heaviest-first dK/dV grid with its automatic head split + reduce kernel, the dQ kernel -- forward and
+    backward against the CPU oracle (dense fp32 attention per sequence, autograd), element-wise and in relative l2."""
+    _attn_case(dev, [4096] * 4, 32, 8, 128, True, 64)
+
+
 def test_flash_attention_lse_and_big_scores(dev):
     # large-magnitude scores exercise the online-softmax rescale path (guide section 5.4 rule 26)
     T, hq, hkv, d = 300, 2, 1, 128
@@ -435,7 +454,7 @@ def test_flash_attention_lse_and_big_scores(dev):
     kv[200, 0] *= 12.0  # one spiky key late in the sequence
     out, lse = K().flash_attn_fwd(q.to(dev), kv.to(dev)[:, 0], kv.to(dev)[:, 1], cu.to(dev), T, None, True)
     ref = O.attention_varlen(q.float(), kv.float(), cu, True)
-    close(out, ref, 1.6e-2, 2e-2, "flash fwd with spike")
+    close(out, ref, 1.6e-2, 2e-2, "flash fwd with spike", rms=FLASH_RMS)
     k = kv[:, 0].float().repeat_interleave(hq // hkv, 1)
     s = torch.einsum("thd,shd->hts", q.float(), k) / math.sqrt(d)
     s = s.masked_fill(torch.arange(T)[None, :] > torch.arange(T)[:, None], float("-inf"))
@@ -471,13 +490,13 @@ def test_flash_forward_64_rows_per_wave(dev, variant, lens, hq, hkv, d, causal):
         out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), None, causal)
     finally:
         L.ie_tune_flash_fwd_variant(-1)
-    close(out, ref, 1.6e-2, 2e-2, f"flash fwd64 variant {variant} lens={lens}")
+    close(out, ref, 1.6e-2, 2e-2, f"flash fwd64 variant {variant} lens={lens}", rms=FLASH_RMS)
     # the saved log-sum-exp must serve the backward: gradients through the variant's (out, lse)
     dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
     # (the spiky key makes gradients of magnitude ~10: absolute tolerance relative to the largest reference entry)
-    close(dq, q32.grad, 2e-2, 1e-2 * float(q32.grad.abs().max()), "flash dq from fwd64 lse")
-    close(dk, kv32.grad[:, 0], 2e-2, 1e-2 * float(kv32.grad[:, 0].abs().max()), "flash dk from fwd64 lse")
-    close(dv, kv32.grad[:, 1], 2e-2, 1e-2 * float(kv32.grad[:, 1].abs().max()), "flash dv from fwd64 lse")
+    close(dq, q32.grad, 2e-2, 1e-2 * float(q32.grad.abs().max()), "flash dq from fwd64 lse", rms=FLASH_RMS)
+    close(dk, kv32.grad[:, 0], 2e-2, 1e-2 * float(kv32.grad[:, 0].abs().max()), "flash dk from fwd64 lse", rms=FLASH_RMS)
+    close(dv, kv32.grad[:, 1], 2e-2, 1e-2 * float(kv32.grad[:, 1].abs().max()), "flash dv from fwd64 lse", rms=FLASH_RMS)
 
 
 # ---------------------------------------------------------------------------------------------- a18
@@ -518,8 +537,8 @@ def test_flash_bwd_dkdv_head_split_and_trailing_tokens(dev, split):
         dq, dk, dv = k.flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), 130, None, True, dk=dkv[:, 0], dv=dkv[:, 1])
     finally:
         k._L().ie_tune_flash_dkdv_split(0)
-    close(dk[:200], kv32.grad[:, 0], 2e-2, 3e-2, f"dk split {split}")
-    close(dv[:200], kv32.grad[:, 1], 2e-2, 3e-2, f"dv split {split}")
+    close(dk[:200], kv32.grad[:, 0], 2e-2, 3e-2, f"dk split {split}", rms=FLASH_RMS)
+    close(dv[:200], kv32.grad[:, 1], 2e-2, 3e-2, f"dv split {split}", rms=FLASH_RMS)
     assert bool((dkv[200:] == 7.0).all()), "rows of tokens outside every sequence must not be written"
 
 
@@ -557,9 +576,9 @@ def test_flash_bwd_four_wave_dkdv_blocks(dev, lens, hq, hkv, d, causal, split):
         L.ie_tune_flash_bwd_variant(0)
         L.ie_tune_flash_dkdv_split(0)
     dq, dk, dv = got[1]
-    close(dq, q32.grad, 2e-2, 3e-2, "dq (four-wave dK/dV build)")
-    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "dk four waves")
-    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv four waves")
+    close(dq, q32.grad, 2e-2, 3e-2, "dq (four-wave dK/dV build)", rms=FLASH_RMS)
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "dk four waves", rms=FLASH_RMS)
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv four waves", rms=FLASH_RMS)
     assert torch.equal(got[0][1], dk) and torch.equal(got[0][2], dv), "the two block shapes must give bit-identical dK / dV"
 
 
@@ -680,8 +699,8 @@ def test_flash_attention_seq32768_properties(dev):
     dq, dk, dv = k.flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], out, lse, cu, T, None, True)
     dq_p, dk_p, dv_p = k.flash_attn_bwd(do[:P].contiguous(), q[:P].contiguous(), kv[:P, 0], kv[:P, 1], out_p, lse_p, cu_p, P, None, True)
     assert torch.equal(dq[:P], dq_p) and float(dq[P:].float().abs().max()) == 0.0
-    close(dk[:P], dk_p.cpu(), 1e-2, 1e-2, "dK prefix (the head split of the long problem may differ: fp32 partial order)")
-    close(dv[:P], dv_p.cpu(), 1e-2, 1e-2, "dV prefix")
+    close(dk[:P], dk_p.cpu(), 1e-2, 1e-2, "dK prefix (the head split of the long problem may differ: fp32 partial order)", rms=FLASH_RMS)
+    close(dv[:P], dv_p.cpu(), 1e-2, 1e-2, "dV prefix", rms=FLASH_RMS)
     assert float(dk[P:].float().abs().max()) == 0.0 and float(dv[P:].float().abs().max()) == 0.0
 
 

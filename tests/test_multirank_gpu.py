@@ -1,0 +1,240 @@
+"""The parallel layouts BASELINE.json's configs name, at their rank counts, on real kernels: every rank of the job is a process on the
+box's GPU(s) and runs the product engine over a comm.Backend (staged gloo on a one-GPU box -- results land only in wait(), destinations
+alias their sources as on RCCL -- and RCCL itself when the box has one GPU per rank; `backend` fixture of test_dp_gpu).
+
+  * configs[3] (configs/7B_isp_sft.py): Ulysses / ISP sequence parallelism at sp = 4 and sp = 8 with ONE kv head per rank
+    (multi_head_attention.py:56-135 with Hkv / sp = 1), with and without data parallelism on top;
+  * configs[2] (configs/7B_llama2.py, TP = 2 + hybrid ZeRO on 8 GPUs): LLAMA2, tensor size 2 x data-parallel size 4 with the optimizer
+    state sharded over zero groups of 2 (parallel.zero1.size = 2: reduce-scatter inside, all-reduce across the two replicas);
+  * pipeline size 2 x data-parallel size 4 x zero1.size 2 (the zero / replica groups of EVERY stage are created by every rank).
+Each run must reproduce ONE rank stepping through the union of the job's micro-batches: loss, global grad norm, trained parameters.
+"""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from test_dp_gpu import _collect, _init_dist, backend  # noqa: F401  (the fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sp_cfg(heads, kv_heads, micro_num, model_type="INTERNLM2_PUBLIC"):
+    from internevo_amd.config import tiny
+
+    return tiny(hidden=64 * heads, layers=2, heads=heads, kv_heads=kv_heads, vocab=512, seq_len=256, micro_num=micro_num, lr=1e-3, total_steps=6,
+                model_type=model_type)
+
+
+def _run_one_rank(dev, cfg, micro_num, fixed, steps=3, **kw):
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init, **kw)
+    loader = iter(SyntheticLoader(cfg.train.seq_len, 1, micro_num, fixed, 4000))
+    ref = []
+    for _ in range(steps):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref.append((float(loss), float(eng.read_state().grad_norm)))
+    return eng, ref
+
+
+def _sp_worker(rank, world, port, q, sp, heads, kv_heads, micro_num, fixed):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        eng = InternLM2Engine(_sp_cfg(heads, kv_heads, micro_num), dev, None, world, rank, init_fn=formula_init, sp_size=sp)
+        assert eng.a_kv[0].shape[2] == kv_heads // sp and eng.T == 256 // sp
+        loader = iter(SyntheticLoader(256, 1, micro_num, fixed, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        eng.drain()
+        q.put((rank, out, eng.params.float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("sp,dp,heads,kv_heads", [
+    pytest.param(4, 1, 8, 4, marks=pytest.mark.ranks(4)), pytest.param(8, 1, 16, 8, marks=pytest.mark.ranks(8)), pytest.param(4, 2, 8, 4, marks=pytest.mark.ranks(8))],
+    ids=["sp4_one_kv_head_per_rank", "sp8_one_kv_head_per_rank", "sp4_x_dp2"])
+def test_sequence_parallel_sp4_sp8_equals_single_rank_step(dev, backend, sp, dp, heads, kv_heads):  # noqa: F811
+    """configs[3]'s layout: the packed sequence cut into sp contiguous parts, attention on all tokens with Hkv / sp = 1 kv head (and
+    Hq / sp = 2 query heads) per rank after the all-to-all, ISP's gradient averaging rule, ZeRO-1 over all sp x dp ranks."""
+    from internevo_amd.layout import FlatLayout
+
+    world, M = sp * dp, 2
+    fixed = dp > 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, 29500 + 7 * sp + dp, q, sp, heads, kv_heads, M, fixed)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    cfg1 = _sp_cfg(heads, kv_heads, M * dp)
+    eng, ref = _run_one_rank(dev, cfg1, M * dp, fixed, emulate_isp_grad_rule=sp)
+    p0 = torch.from_numpy(res[0][2])
+    for r in res[1:]:
+        assert torch.equal(torch.from_numpy(r[2]), p0), f"rank {r[0]} disagrees with rank 0 on the parameters after the all-gather"
+    for k in range(3):
+        groups = [res[g * sp][1][k] for g in range(dp)]          # one (loss, norm) per sequence group
+        mean_loss = sum(x[0] for x in groups) / dp
+        print(f"step {k}: sp{sp} x dp{dp} loss {mean_loss:.5f} gn {groups[0][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        for r in res:
+            assert r[1][k][0] == res[(r[0] // sp) * sp][1][k][0], "the ranks of a sequence group report the same (global) loss"
+            assert abs(r[1][k][1] - res[0][1][k][1]) <= 1e-6 * r[1][k][1], "every rank reports the same global grad norm"
+        assert abs(mean_loss - ref[k][0]) <= (1e-3 if dp == 1 else 2e-3) * abs(ref[k][0])
+        assert abs(groups[0][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    Lw, L1 = FlatLayout(cfg1.model, world), eng.layout
+    ref_params = eng.params.float().cpu()
+    worst = 0.0
+    for n, s in L1.params.items():
+        s2 = Lw.params[n]
+        worst = max(worst, float((ref_params[s.offset : s.offset + s.numel] - p0[s2.offset : s2.offset + s2.numel]).abs().max()))
+    print(f"max |param diff| sp{sp} x dp{dp} vs 1 rank:", worst)
+    assert worst <= 6e-3
+
+
+def _tp_zero_worker(rank, world, port, q, tp, zero, micro_num):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        cfg = _sp_cfg(4, 2, micro_num, "LLAMA2")
+        eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, tp_size=tp, zero_size=zero)
+        assert (eng.dp_world, eng.world, eng.comm.n_replica) == (world // tp, zero, world // tp // zero)
+        assert eng.comm.replica_group is not None and eng.comm.group is not eng.tpar.dp_group
+        loader = iter(SyntheticLoader(256, 1, micro_num, True, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        eng.drain()
+        q.put((rank, out, {n: (eng.layout.params[n].kind, p.float().cpu().numpy()) for n, p in eng.p.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.ranks(8)
+def test_llama2_tensor_parallel_2_with_hybrid_zero_on_8_ranks(dev, backend):  # noqa: F811
+    """configs[2] as BASELINE.json names it: LLAMA2, parallel.tensor size 2 (mtp), 8 ranks = 4 data-parallel replicas of the tensor group,
+    parallel.zero1.size = 2 (hybrid ZeRO: two zero groups per tensor rank, reduce-scatter inside + all-reduce across)."""
+    from internevo_amd.tensorpar import TensorParallel
+
+    world, tp, zero, M = 8, 2, 2, 2
+    dp = world // tp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_zero_worker, args=(r, world, 29611, q, tp, zero, M)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng, ref = _run_one_rank(dev, _sp_cfg(4, 2, M * dp, "LLAMA2"), M * dp, True)
+    for k in range(3):
+        mean_loss = sum(res[g * tp][1][k][0] for g in range(dp)) / dp
+        print(f"step {k}: tp2 x dp4 (zero 2) loss {mean_loss:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        for r in res:
+            assert r[1][k][0] == res[(r[0] // tp) * tp][1][k][0], "both ranks of a tensor group compute the same loss"
+            assert abs(r[1][k][1] - res[0][1][k][1]) <= 1e-6 * r[1][k][1], "every rank reports the same global grad norm"
+        assert abs(mean_loss - ref[k][0]) <= 2e-3 * abs(ref[k][0])
+        assert abs(res[0][1][k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    # data-parallel replicas of a tensor rank hold identical shards (two hops = one average over all four) ...
+    for r in res[tp:]:
+        for n, (kind, a) in r[2].items():
+            assert (a == res[r[0] % tp][2][n][1]).all(), f"rank {r[0]}: {n} differs from tensor rank {r[0] % tp} of the first replica"
+    # ... and the two tensor ranks' shards concatenate to the single-rank parameters
+    worst = 0.0
+    for n, p in eng.p.items():
+        kind = res[0][2][n][0]
+        full = TensorParallel.unshard(kind, [torch.from_numpy(res[t][2][n][1]) for t in range(tp)], True)
+        worst = max(worst, float((full - p.float().cpu()).abs().max()))
+    print("max |param diff| tp2 x dp4 x zero2 vs 1 rank:", worst)
+    assert worst <= 6e-3
+
+
+def _sp_big_worker(rank, world, port, q, seq):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.config import internlm2_7b
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        cfg = internlm2_7b(seq)
+        cfg.model.num_layers = 1
+        cfg.train.micro_num, cfg.train.total_steps = 1, 4
+        eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, sp_size=world)
+        assert eng.a_kv[0].shape == (seq, 2, 1, 128) and eng.a_q[0].shape == (seq, 4, 128)   # all tokens, this rank's ONE kv head / 4 q heads
+        loader = iter(SyntheticLoader(seq, 1, 1, True, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(2):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        eng.drain()
+        chk = {n: float(p.float().abs().sum()) for n, p in eng.named_parameters()}
+        q.put((rank, out, chk))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.ranks(8)
+def test_isp_config3_layout_seq32768_sp8_at_7b_width(dev, backend):  # noqa: F811
+    """configs[3] at its real sequence shape: ONE 32 768-token sequence per micro-batch over sp = 8 ranks (4096 local tokens each), the 7B
+    model's width (hidden 4096, 32 / 8 heads of 128 -> 4 query heads and ONE kv head per rank in attention, FFN 14336, vocabulary 92 544) with one
+    layer, so that eight ranks share one GPU; against ONE rank running the same 32 768-token micro-batch with the ISP rule emulated."""
+    from internevo_amd.config import internlm2_7b
+
+    seq, world = 32768, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sp_big_worker, args=(r, world, 29631, q, seq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world, timeout=1200), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    cfg = internlm2_7b(seq)
+    cfg.model.num_layers = 1
+    cfg.train.micro_num, cfg.train.total_steps = 1, 4
+    eng, ref = _run_one_rank(dev, cfg, 1, True, steps=2, emulate_isp_grad_rule=world)
+    for k in range(2):
+        print(f"step {k}: sp8 @ 32768 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
+        for r in res:
+            assert r[1][k] == res[0][1][k], "every rank of the sequence group reports the same loss and global grad norm"
+        assert abs(res[0][1][k][0] - ref[k][0]) <= 1e-3 * abs(ref[k][0])
+        assert abs(res[0][1][k][1] - ref[k][1]) <= 2e-2 * ref[k][1]
+    want = {n: float(p.float().abs().sum()) for n, p in eng.named_parameters()}
+    for r in res:
+        for n, v in r[2].items():
+            assert v == res[0][2][n], f"rank {r[0]}: {n} differs from rank 0 after the all-gather"
+    for n, v in want.items():
+        assert abs(res[0][2][n] - v) <= 2e-3 * v, (n, res[0][2][n], v)

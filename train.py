@@ -155,7 +155,9 @@ def main(argv=None, log=print):
         loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen,
                                      data_rank=eng.seqpar.data_rank, data_world_size=dp_world)
         dataset_types = ["en", "cn", "code"]  # the dummy dataset's type list (build_dataloader.py:93)
-    metric = AccPerplex(dev, eng.tpar.dp_group, dataset_types, dp_world_size=dp_world)
+    # pipeline parallelism: only the last stage sees logits; the others hold zero accumulators and the packed all-reduce runs over the
+    # whole job, so every rank (the logging rank 0 included) reports the job's metric
+    metric = AccPerplex(dev, eng.tpar.dp_group, dataset_types, dp_world_size=world if eng.pp > 1 else dp_world)
     eng.attach_metric(metric)
     loader = iter(loader_obj)
     if run_state and run_state["sampler"] is not None:
@@ -180,10 +182,12 @@ def main(argv=None, log=print):
                 continue
             val_loaders[name] = vl
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
-    if save_folder and eng.sp > 1:
-        # say so at start-up instead of silently writing nothing every checkpoint_every steps
-        raise NotImplementedError("ckpt.enable_save_ckpt with sequence parallelism (parallel.tensor mode 'isp'): checkpoints cover tensor sizes "
-                                  "of mode 'mtp' and any data-parallel size; set enable_save_ckpt=False for an isp run")
+    if save_folder and (eng.sp > 1 or eng.pp > 1):
+        # say so at start-up instead of training until the first checkpoint_every step and dying there
+        raise NotImplementedError("ckpt.enable_save_ckpt with sequence parallelism (parallel.tensor mode 'isp') or pipeline parallelism: checkpoints "
+                                  "cover tensor sizes of mode 'mtp' and any data-parallel size; set enable_save_ckpt=False for such a run")
+    if val_loaders and eng.pp > 1:
+        raise NotImplementedError("data.valid_every > 0 with pipeline parallelism: the forward-only pass has no pipeline schedule; set valid_every=0")
     every = int(ck.get("checkpoint_every", 0) or 0)
     ctx = run_state["context"] if run_state else None
     consumed = ctx["num_consumed_tokens"] if ctx else 0
