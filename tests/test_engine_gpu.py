@@ -403,3 +403,54 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
             worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
     print("max |param diff| after 2 merged steps:", worst)
     assert worst <= 8e-3
+
+
+@pytest.mark.timeout(900)
+def test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width(dev):
+    """The 7B bench run's loss makes an excursion in its first steps (11.4 -> 27.7 at step 3 with grad norm 185 -> 0.9 -> 0.004: BENCH_r02).  The
+    benchmark's recipe -- lr 1e-4 from step 0 (no warm-up inside 20 steps), AdamW, the synthetic RandomDataset batches -- at the 7B model's
+    width with two layers was run through the CPU oracle (tools/loss_spike_oracle.py -> tests/golden/spike_7bwidth_oracle.json, committed);
+    the HIP engine must retrace that trajectory step for step, excursion included: it is the optimizer's doing (Adam's first updates are
+    sign-like steps of size lr in EVERY coordinate; on a data set of repeated small-integer runs the logits of the few tokens that occur
+    overshoot), not a kernel's.  The reference's own loss test allows 1.5x spikes of this kind (tests/test_training/test_loss.py:32-43)."""
+    import json
+    import os
+
+    from internevo_amd.config import internlm2_7b
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spike_7bwidth_oracle.json")
+    with open(path) as f:
+        gold = json.load(f)
+    cfg = internlm2_7b(gold["seq_len"])
+    cfg.model.num_layers = gold["layers"]
+    cfg.train.micro_num = gold["micro_num"]
+    cfg.train.fixed_random_dataset_seqlen = True
+    assert (cfg.train.lr, cfg.train.total_steps, cfg.train.warmup_ratio) == (gold["lr"], gold["total_steps"], gold["warmup_ratio"])
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    loader = iter(SyntheticLoader(gold["seq_len"], 1, gold["micro_num"], True, 1_000_000))
+    got = []
+    for k, ref in enumerate(gold["steps"]):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        got.append((float(loss), float(st.grad_norm)))
+        print(f"step {k}: HIP loss {got[-1][0]:.5f} grad_norm {got[-1][1]:.4f} | oracle loss {ref['loss']:.5f} grad_norm {ref['grad_norm']:.4f}")
+    # Steps 0-2 (12.4 -> 0.23 -> 0.022: the model memorises the periodic samples at once) must agree to the north star's tolerances.  From the
+    # first excursion on the trajectory is chaotic -- a bf16-level difference decides how far an overshoot goes -- so there the assertion is
+    # the QUALITATIVE one this test exists for: both runs make excursions of an order of magnitude and come back, on the same steps.
+    for k in range(3):
+        (l, n), ref = got[k], gold["steps"][k]
+        assert abs(l - ref["loss"]) <= (1e-3 if k < 2 else 2e-2) * abs(ref["loss"]), (k, l, ref["loss"])
+        assert abs(n - ref["grad_norm"]) <= (2e-2 if k < 2 else 1e-1) * ref["grad_norm"], (k, n, ref["grad_norm"])
+    ora = [r["loss"] for r in gold["steps"]]
+    hip = [g_[0] for g_ in got]
+    assert max(ora[3:]) >= 10 * min(ora[2:]), "the committed oracle trajectory no longer shows the excursion this test is about"
+    assert max(hip[3:]) >= 10 * min(hip[2:]) and min(hip[3:]) <= 0.1, hip
+    up_o = {k for k in range(3, len(ora)) if ora[k] > 5 * ora[k - 1]}
+    up_h = {k for k in range(3, len(hip)) if hip[k] > 5 * hip[k - 1]}
+    print("excursion steps: oracle", sorted(up_o), "HIP", sorted(up_h))
+    assert up_o & up_h, "the HIP run and the oracle spike on different steps"
