@@ -123,6 +123,8 @@ class TrainConfig:
     clip_grad_norm: float = 1.0
     label_smoothing: float = 0.0
     zero1_size: int = -1
+    wp_size: int = 1                # parallel.weight = dict(size=wp): ISP weight parallelism -- the engine shards the layer weights over groups of wp ranks
+                                    # only when they do not fit resident (engine.py, weight_parallel)
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
     tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
     pp_size: int = 1                # parallel.pipeline = dict(size=pp): 1F1B pipeline parallelism (pipeline.py)
@@ -169,7 +171,13 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
             tp_size = int(tensor["size"])
         else:
             raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'msp', 'fsp', 'isp')")
-        # parallel.weight (size, overlap, memory_pool) needs no counterpart: the weights stay resident (seqpar.py)
+    # parallel.weight (size, overlap, memory_pool): the weight-parallel size is honoured when the resident layout does not fit the GPU (or when
+    # the engine is told to, weight_parallel=True); overlap / memory_pool describe what the engine always does then (prefetch on a side stream
+    # into a two-slot pool)
+    weight = par.get("weight", {})
+    wp_size = int(weight.get("size", 1) if isinstance(weight, dict) else weight)
+    if wp_size > 1 and tensor.get("mode", "mtp") != "isp" and tensor.get("size", 1) != 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: parallel.weight.size > 1 outside tensor mode 'isp'")
     if pp_size > 1 and (sp_size > 1 or tp_size > 1):
         raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallelism together with tensor / sequence parallelism")
     model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
@@ -255,7 +263,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size, num_chunks=num_chunks,
+        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size, num_chunks=num_chunks, wp_size=wp_size,
     )
     return PathConfig(model, train)
 

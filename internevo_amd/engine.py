@@ -44,7 +44,7 @@ BF16 = torch.bfloat16
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
@@ -53,7 +53,13 @@ class InternLM2Engine:
         vocab_parallel (tensor parallelism only; default on): every tensor rank holds 1/tp of the head's vocabulary rows and the loss is
         computed vocabulary-parallel (tensorpar.py); False = the whole head on every rank.
         pp_size (default: the config's parallel.pipeline.size): pipeline parallelism, non-interleaved 1F1B (pipeline.py): this rank
-        holds one contiguous range of layers (+ the embedding on the first stage, + norm / head / loss on the last)."""
+        holds one contiguous range of layers (+ the embedding on the first stage, + norm / head / loss on the last).
+        weight_parallel (ISP's weight parallelism, parallel.weight = dict(size=wp); core/communication/isp.py:31-526, ops/linear.py:357-378):
+        True = every rank keeps only its 1/wp part of each LAYER's bf16 weights and gradients (wp = the zero group: cfg.train.wp_size, or the
+        whole data-parallel group); a layer's weights are all-gathered into a two-slot pool right before the layer runs, forward and
+        backward, the next layer's gather running on a side stream under this layer's kernels, and its weight gradients are
+        reduce-scattered (AVG) out of a pool slot every micro-batch and accumulated in the resident shard.  None = automatic: on only when
+        the config asks for wp > 1 AND the resident layout (weights whole on every GPU) does not fit this GPU's memory; False = resident."""
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -109,6 +115,22 @@ class InternLM2Engine:
         zs = world_size if (zs is None or zs <= 0 or zs >= world_size) else int(zs)
         if world_size % zs:
             raise ValueError(f"parallel.zero1.size = {zs} must divide the data-parallel size {world_size}")
+        wp_cfg = int(getattr(tc, "wp_size", 1) or 1)
+        if weight_parallel is None:   # resident weights are the faster design: shard only what does not fit (static sizes: every rank decides alike)
+            full = FlatLayout(self.lmc, 1, self.gid, self.pipe.first, self.pipe.last).total
+            total = torch.cuda.get_device_properties(device).total_memory if device.type == "cuda" else 0
+            weight_parallel = wp_cfg > 1 and total > 0 and 4 * full + 12 * full / max(zs, 1) > 0.7 * total
+        self.wp_mode = bool(weight_parallel)
+        if self.wp_mode:
+            if tp_size > 1 or pp_size > 1 or (mc.embed_grad_scale != 1.0 or mc.norm_head):
+                raise NotImplementedError("weight parallelism combines with data / sequence parallelism (the ISP configuration) only")
+            if wp_cfg > 1:
+                if zs != world_size and zs != wp_cfg:
+                    raise NotImplementedError(f"parallel.weight.size = {wp_cfg} with parallel.zero1.size = {zs}: here the weight group IS the zero "
+                                              "group (fp32 state, bf16 weights and gradients are cut the same way); leave zero1.size at -1")
+                zs = wp_cfg
+                if world_size % zs:
+                    raise ValueError(f"parallel.weight.size = {zs} must divide the data-parallel size {world_size}")
         self.world, self.rank = zs, rank % zs
         self.layout = FlatLayout(self.lmc, zs, self.gid, self.pipe.first, self.pipe.last)
         L = self.layout
@@ -124,14 +146,42 @@ class InternLM2Engine:
             raise ValueError("sequence parallel size must divide the kv head count and the packed length")
 
         # ---- flat parameter / gradient buffers + ZeRO-1 fp32 state of this rank's shards
-        self.params = torch.zeros(L.total, dtype=BF16, device=device)
-        self.grads = torch.zeros(L.total, dtype=BF16, device=device)
+        # Physical placement of the buckets inside `params` / `grads`.  Resident: the layout's own offsets.  Weight parallel: a layer bucket
+        # occupies only this rank's shard there; its whole image exists in one of two pool slots while the layer runs (layer l -> slot l % 2).
+        nb = len(L.buckets)
+        self._wp_buckets = set(range(1, nb - 1)) if self.wp_mode else set()
+        self._pbase, off = [], 0
+        for b in L.buckets:
+            self._pbase.append(off)
+            off += b.size // zs if b.index in self._wp_buckets else b.size
+        assert self.wp_mode or off == L.total
+        self.params = torch.zeros(off, dtype=BF16, device=device)
+        self.grads = torch.zeros(off, dtype=BF16, device=device)
         nloc = L.local_numel()
         self.master = torch.zeros(nloc, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(nloc, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(nloc, dtype=torch.float32, device=device)
-        self.p = {n: self.params[s.offset : s.offset + s.numel].view(s.shape) for n, s in L.params.items()}
-        self.g = {n: self.grads[s.offset : s.offset + s.numel].view(s.shape) for n, s in L.params.items()}
+        if self.wp_mode:
+            slot = max(L.buckets[i].size for i in self._wp_buckets)
+            self.pool_p = [torch.zeros(slot, dtype=BF16, device=device) for _ in range(2)]   # (padding stays zero: nothing writes it)
+            self.pool_g = [torch.zeros(slot, dtype=BF16, device=device) for _ in range(2)]
+            self.t_gshard = [torch.empty(slot // zs, dtype=BF16, device=device) for _ in range(2)]   # reduce-scatter target of a later micro-batch
+            self.wp_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+            self._wp_inflight, self._wp_rs, self._slot_layer = {}, [None, None], [None, None]
+
+        def backing(spec, flat, pool):   # (storage tensor, element offset) a parameter's view lives in
+            b = L.buckets[spec.bucket]
+            if b.index in self._wp_buckets:
+                return pool[(b.index - 1) % 2], spec.offset - b.start
+            return flat, spec.offset - b.start + self._pbase[b.index]
+
+        self.p, self.g, self.p13, self.g13 = {}, {}, {}, {}
+        for n, sp_ in L.params.items():
+            for dst, dst13, flat, pool in ((self.p, self.p13, self.params, getattr(self, "pool_p", None)), (self.g, self.g13, self.grads, getattr(self, "pool_g", None))):
+                t, o = backing(sp_, flat, pool)
+                dst[n] = t[o : o + sp_.numel].view(sp_.shape)
+                if sp_.kind == "w1":     # w1 and w3 are adjacent: one [2F, h] GEMM operand
+                    dst13[sp_.layer] = t[o : o + 2 * sp_.numel].view(2 * sp_.shape[0], sp_.shape[1])
         self._init_params(init, seed, init_fn)
         self.sync_master_from_params()
 
@@ -153,6 +203,10 @@ class InternLM2Engine:
         can_merge = tc.micro_num > 1 and sp_size == 1 and mc.checkpoint_layers == 0
         if merge_micro and not can_merge:
             raise ValueError("merge_micro needs micro_num > 1, no sequence parallelism and no activation checkpointing")
+        if self.wp_mode:
+            if batch_wgrad:
+                raise ValueError("batch_wgrad keeps gradients in place across micro-batches; weight parallelism reduce-scatters them per micro-batch")
+            batch_wgrad = False
         if merge_micro is None and batch_wgrad:
             merge_micro = False  # an explicit request for the staged per-micro-batch path
         if merge_micro is None:
@@ -196,21 +250,49 @@ class InternLM2Engine:
         for n, full in FlatLayout(mc, 1).params.items():   # (a pipeline stage draws the whole sequence too and keeps its layers)
             if full.kind == "norm":
                 if n in self.p:
-                    self.p[n].fill_(1.0)
+                    self._store_param(n, torch.ones(full.shape, dtype=BF16, device=self.dev))
                 continue
             std = mc.init_std
             if mc.use_scaled_init and full.kind in ("wo", "w2"):
                 std = mc.init_std / math.sqrt(2.0 * (full.layer + 1))
             w = torch.empty(full.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
             if n in self.p:
-                self.p[n].copy_(self.tpar.shard(full.kind, w))
+                self._store_param(n, self.tpar.shard(full.kind, w))
+
+    # ---- where a bucket lives (resident: the layout's offsets; weight parallel: layer buckets hold this rank's shard only) ----------
+    def _shard(self, flat, b):
+        """this rank's 1/world part of bucket b inside `flat` (params or grads)."""
+        n = b.size // self.world
+        s = self._pbase[b.index] + (0 if b.index in self._wp_buckets else self.rank * n)
+        return flat[s : s + n]
+
+    def _full(self, flat, b):
+        """bucket b whole (resident buckets only)."""
+        assert b.index not in self._wp_buckets
+        return flat[self._pbase[b.index] : self._pbase[b.index] + b.size]
+
+    def _store_param(self, name, value):
+        """value: this rank's (tensor-parallel cut of the) WHOLE parameter -> its storage; under weight parallelism only the part of a layer
+        parameter that falls into this rank's shard of the bucket is kept."""
+        spec = self.layout.params[name]
+        b = self.layout.buckets[spec.bucket]
+        if b.index not in self._wp_buckets:
+            self.p[name].copy_(value)
+            return
+        n = b.size // self.world
+        s0 = b.start + self.rank * n
+        a, z = max(s0, spec.offset), min(s0 + n, spec.offset + spec.numel)
+        if a < z:
+            self._shard(self.params, b)[a - s0 : z - s0].copy_(value.reshape(-1)[a - spec.offset : z - spec.offset])
 
     def sync_master_from_params(self):
         """fp32 master copy of this rank's shards (hybrid_zero_optim.py:214-233)."""
         L = self.layout
         for b, lo in zip(L.buckets, L.local_offsets()):
-            s, n = b.shard(self.rank, self.world)
-            self.master[lo : lo + n].copy_(self.params[s : s + n])
+            n = b.size // self.world
+            self.master[lo : lo + n].copy_(self._shard(self.params, b))
+        if self.wp_mode:
+            self._slot_layer = [None, None]   # whatever the pool holds is stale now
 
     def _ensure_rotary(self, seqlen):
         if seqlen <= self._rot_len:
@@ -340,9 +422,80 @@ class InternLM2Engine:
 
     # ------------------------------------------------------------------------------------------ forward / backward
     def _w13(self, l):
-        s = self.layout.params[f"layers.{self.gid[l]}.feed_forward.w1.weight"]
-        F, h = self.lmc.ffn_dim, self.lmc.hidden_size
-        return self.params[s.offset : s.offset + 2 * F * h].view(2 * F, h), self.grads[s.offset : s.offset + 2 * F * h].view(2 * F, h)
+        return self.p13[self.gid[l]], self.g13[self.gid[l]]
+
+    # ---- weight parallelism: a layer's weights exist whole only in its pool slot, around the layer's own kernels ----------------------
+    def _wp_gather(self, l):
+        """Start the all-gather of layer l's weight shards into slot l % 2 on the side stream: behind everything queued so far on the compute
+        stream (the slot's previous tenant, layer l +- 2, is done by then) and behind the optimizer's update of the shard."""
+        slot, b = l % 2, self.layout.buckets[1 + l]
+        if self._slot_layer[slot] == l or l in self._wp_inflight:
+            return
+        self._slot_layer[slot] = None
+        full, shard = self.pool_p[slot][: b.size], self._shard(self.params, b)
+        if not self.comm.active:      # one rank: the shard is the bucket (the pool logic runs, the collectives are identities)
+            full.copy_(shard)
+            self._wp_inflight[l] = None
+            return
+        if self.wp_stream is None:   # CPU tensors (tests)
+            self._wp_inflight[l] = self.comm.all_gather_async(full, shard)
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(self.wp_stream):
+            self.wp_stream.wait_event(ev)
+            ready = self._bucket_ready[b.index]
+            if ready is not None:
+                self.wp_stream.wait_event(ready)
+            self._wp_inflight[l] = self.comm.all_gather_async(full, shard)
+
+    def _layer_ready(self, l, nxt):
+        """Before the first kernel that reads layer l's weights.  Resident: order the stream behind the optimizer's work on the bucket.
+        Weight parallel: wait for the gather of layer l, then start the gather of `nxt` (the layer this pass visits next) into the other
+        slot, and make sure that slot's gradient image has left (its reduce-scatter of two layers ago)."""
+        if not self.wp_mode:
+            self._wait_bucket(1 + l)
+            return
+        self._wp_gather(l)
+        work = self._wp_inflight.pop(l, None)
+        if work is not None:
+            work.wait()                 # the compute stream continues behind the collective
+        self._slot_layer[l % 2] = l
+        self._wp_finish_rs(l % 2)
+        if nxt is not None:
+            self._wp_gather(nxt)
+
+    def _wp_reduce(self, l, first_micro):
+        """Layer l's weight gradients of this micro-batch (whole, in pool slot l % 2) -> averaged over all ranks into this rank's gradient
+        shard: written by the first micro-batch of a step, accumulated by the others (the reference's ISP hooks reduce-scatter every
+        micro-batch too: isp.py:143-526)."""
+        slot, b = l % 2, self.layout.buckets[1 + l]
+        full, shard = self.pool_g[slot][: b.size], self._shard(self.grads, b)
+        if not self.comm.active:
+            shard.copy_(full[: shard.numel()]) if first_micro else shard.add_(full[: shard.numel()])
+            return
+        if first_micro:
+            self._wp_rs[slot] = (self.comm.reduce_scatter_async(full, shard), None)
+        else:
+            tmp = self.t_gshard[slot][: shard.numel()]
+            self._wp_rs[slot] = (self.comm.reduce_scatter_async(full, tmp), lambda: shard.add_(tmp))
+
+    def _wp_finish_rs(self, slot):
+        ent = self._wp_rs[slot]
+        if ent is not None:
+            work, fin = ent
+            work.wait()
+            if fin is not None:
+                fin()
+            self._wp_rs[slot] = None
+
+    def _reduce_bucket(self, bi):
+        """Start the averaging of a RESIDENT bucket's gradients over the data-parallel group (embedding, head; every bucket without weight
+        parallelism): reduce-scatter into the owner's slice, in place."""
+        b = self.layout.buckets[bi]
+        if self.comm.active and b.size:
+            self.comm.pending.append(self.comm.reduce_scatter_async(self._full(self.grads, b), self._shard(self.grads, b)))
 
     def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
         """One PackedFlashLlamaLayer1D (modeling_internlm2.py:684-740) into activation slot slot[l].
@@ -404,7 +557,7 @@ class InternLM2Engine:
         # (a later pipeline stage / model chunk received its input -- the previous one's output -- straight into a_x[la])
         ffn_out = None
         for l in range(la, lb):
-            self._wait_bucket(1 + l)
+            self._layer_ready(l, l + 1 if l + 1 < lb else None)
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
         if not is_last:   # the output = the residual stream after the last layer; norm, head and loss live behind the model's last layer
             torch.add(ffn_out, self.a_r2[self.slot[lb - 1]], out=self.t_send)
@@ -483,15 +636,16 @@ class InternLM2Engine:
         # the first micro-batch of a step WRITES the gradients, the others accumulate: no zero_grad pass over 15.5 GB and no read of
         # the old value in the first weight-gradient epilogues (bucket padding is zero from allocation and never written)
         acc = not first_micro
+        acc_l = acc and not self.wp_mode   # layer gradients under weight parallelism: written whole into the pool slot, accumulated as shards
         if first_micro:
             self._wait_optimizer()  # the previous step's AdamW reads the gradients this backward is about to overwrite
         # d(loss_scale * loss / micro_num) / dlogits, in place over the logits (inplace_backward=True, ce_loss.py:31)
         bw = self.batch_wgrad
         r = self._mrows if bw else None
 
-        def wgrad(dy, x, gw, dy_all, x_all):
+        def wgrad(dy, x, gw, dy_all, x_all, a=None):
             if not bw:
-                K.linear_wgrad(dy, x, gw, acc)
+                K.linear_wgrad(dy, x, gw, acc if a is None else a)
             elif last_micro:  # every micro-batch's rows are in place: one GEMM over micro_num * T tokens
                 K.linear_wgrad(dy_all, x_all, gw, False)
 
@@ -525,33 +679,35 @@ class InternLM2Engine:
         if is_last:
             K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
             if last_micro:
-                self.comm.reduce_bucket_async(self.grads, len(self.layout.buckets) - 1)
+                self._reduce_bucket(len(self.layout.buckets) - 1)
         # (an earlier pipeline stage / model chunk received the gradient of its output from the next one into t_h1 = d_out)
         spare = [self.t_h0, self.t_h2]
         for l in range(lb - 1, la - 1, -1):
             pre = f"layers.{self.gid[l]}."
             w13, gw13 = self._w13(l)
             sl = self.slot[l]
+            if self.wp_mode:
+                self._layer_ready(l, l - 1 if l - 1 >= la else None)
             if l < mc.checkpoint_layers:
                 self._layer_forward(l, None, cu, pos, max_seqlen, True)
             # feed-forward
             t_act, t_dw13, t_qkv = (self.st_act[l][r], self.st_dw13[l][r], self.st_dqkv[l][r]) if bw else (self.t_act, self.t_dw13, self.t_qkv)
             K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
             K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], t_dw13[:, :F], t_dw13[:, F:], t_act)
-            wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None)
+            wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None, acc_l)
             d_n2 = spare[0]
             K.linear_dgrad(t_dw13, w13, d_n2)
             ar = self.tpar.all_reduce_sum_async(d_n2)   # input gradient of the column-parallel w1 | w3: summed over the tensor group ...
-            wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None)   # ... under this GEMM
+            wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None, acc_l)   # ... under this GEMM
             ar.wait()
             d_r2 = self.st_dr2[l][r] if bw else spare[1]
-            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc, ws, d_r2)
+            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc_l, ws, d_r2)
             # attention
             d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
             # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53); d_ctx travels under wo's weight gradient
             xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if self.sp > 1 else None
-            wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None)
+            wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None, acc_l)
             d_ctx_full = d_ctx.view(T, -1, d) if self.sp == 1 else xc.wait()
             K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
                              max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
@@ -565,26 +721,28 @@ class InternLM2Engine:
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
             ar = self.tpar.all_reduce_sum_async(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient
-            wgrad(t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], self.st_dqkv[l] if bw else None, self.st_n1[l] if bw else None)
+            wgrad(t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], self.st_dqkv[l] if bw else None, self.st_n1[l] if bw else None, acc_l)
             ar.wait()
             if bw:    # the layer below reads its output gradient from its own staging rows (it is the dY of that layer's w2)
                 d_x = self.st_dout[l - 1][r] if l > 0 else self.t_h1
             else:
                 d_x = d_out  # the old d_out buffer is free now
-            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc, ws, d_x)
+            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc_l, ws, d_x)
             # rotate buffers: next d_out = d_x; spare = the two others
             if not bw:
                 spare = [d_n2, d_r2]
             d_out = d_x
-            if last_micro:
-                self.comm.reduce_bucket_async(self.grads, 1 + l)
+            if self.wp_mode:
+                self._wp_reduce(l, first_micro)
+            elif last_micro:
+                self._reduce_bucket(1 + l)
         if not is_first:
             return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
         if mc.embed_grad_scale != 1.0:
             K.scale_bf16(d_out, mc.embed_grad_scale)   # d(s x + (1 - s) x.detach()) / dx = s
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
-            self.comm.reduce_bucket_async(self.grads, 0)
+            self._reduce_bucket(0)
         return None
 
     def attach_metric(self, metric):
@@ -849,10 +1007,10 @@ class InternLM2Engine:
         tc, L = self.tc, self.layout
         self.comm.wait_all()
         # squared grad norm over this rank's (already averaged) shards, then summed over ranks (compute_norm, utils.py:265-378)
-        shards = []
-        for b in L.buckets:
-            s, n = b.shard(self.rank, self.world)
-            shards.append(self.grads[s : s + n])
+        if self.wp_mode:   # the last layers' reduce-scatters out of the pool
+            for slot in (0, 1):
+                self._wp_finish_rs(slot)
+        shards = [self._shard(self.grads, b) for b in L.buckets]
         if self.isp_rule > 1:
             self._apply_isp_grad_rule(shards)
         K.sumsq([x for x in shards if x.numel()], self.sumsq, False, self.sumsq_ws)   # (empty: a bucket this pipeline stage does not own)
@@ -879,16 +1037,19 @@ class InternLM2Engine:
         with torch.cuda.stream(opt_stream):
             opt_stream.wait_event(ev)  # gradients, norm and step control are final
             for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
-                s, n = b.shard(self.rank, self.world)
+                n = b.size // self.world
                 if n == 0:   # a bucket this pipeline stage does not own
                     continue
-                K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self.params[s : s + n],
+                K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self._shard(self.params, b),
                              self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
-                self.comm.gather_bucket_async(self.params, b.index)
+                if b.index not in self._wp_buckets and self.comm.active:   # (a weight-parallel layer is gathered when it runs, into its pool slot)
+                    self.comm.gathers[b.index] = self.comm.all_gather_async(self._full(self.params, b), self._shard(self.params, b))
                 done = torch.cuda.Event()
                 done.record(opt_stream)
                 self._bucket_ready[b.index] = done
             self._opt_done = done
+        if self.wp_mode:
+            self._slot_layer = [None, None]   # the pool holds the weights of before this update
         # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter
         # exchange overlaps the next step's first layers; read_state()/named_parameters() drain them explicitly.
         # Engine.step steps the schedulers only after a successful update; success lives on the device, so the
@@ -908,7 +1069,7 @@ class InternLM2Engine:
             s0, n0 = b.shard(self.rank, self.world)
             a, z = max(s0, spec.offset), min(s0 + n0, spec.offset + spec.numel)
             if a < z:
-                out.append(self.grads[a:z])
+                out.append(self._shard(self.grads, b)[a - s0 : z - s0])
         return out
 
     def _apply_isp_grad_rule(self, shards):
@@ -934,7 +1095,7 @@ class InternLM2Engine:
                 s0, n0 = b.shard(self.rank, self.world)
                 a, z = max(s0, spec.offset), min(s0 + n0, spec.offset + spec.numel)
                 if a < z:
-                    K.scale_bf16(self.grads[a:z], n_)
+                    K.scale_bf16(sh[a - s0 : z - s0], n_)
 
     def _wait_bucket(self, b):
         """Order the current stream behind the optimizer-stream work on bucket b (AdamW, and its all-gather when world > 1)."""
@@ -951,6 +1112,14 @@ class InternLM2Engine:
 
     def drain(self):
         """Order the current stream behind everything the last step() left running (call before touching eng.params directly)."""
+        if getattr(self, "wp_mode", False) and hasattr(self, "_wp_rs"):
+            for l in list(self._wp_inflight):
+                w = self._wp_inflight.pop(l)
+                if w is not None:
+                    w.wait()
+            for slot in (0, 1):
+                self._wp_finish_rs(slot)
+            self._slot_layer = [None, None]
         for b in range(len(getattr(self, "_bucket_ready", ()))):  # (also called while the constructor is still loading the weights)
             self._wait_bucket(b)
         if getattr(self, "_opt_done", None) is not None:
@@ -1026,7 +1195,25 @@ class InternLM2Engine:
     def named_parameters(self):
         """(reference name, bf16 tensor) pairs -- views of the flat buffer, except LLAMA2's wq / wk / wv (copies)."""
         self.drain()
+        if self.wp_mode:
+            return self._to_reference_names(self._gathered_params()).items()
         return self._to_reference_names(self.p).items()
+
+    def _gathered_params(self):
+        """Weight parallelism: every parameter whole (engine names) -- the resident ones as views, the layer parameters as COPIES out of a
+        collective all-gather per layer bucket (tests, reporting; never on the step's path)."""
+        L, out = self.layout, {}
+        for b in L.buckets:
+            if b.index in self._wp_buckets:
+                full = torch.empty(b.size, dtype=BF16, device=self.dev)
+                if self.comm.active:
+                    self.comm.all_gather_async(full, self._shard(self.params, b)).wait()
+                else:
+                    full.copy_(self._shard(self.params, b))
+            for n in b.params:
+                spec = L.params[n]
+                out[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape) if b.index in self._wp_buckets else self.p[n]
+        return out
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def _named_shard_views(self, flat_local):
@@ -1061,6 +1248,8 @@ class InternLM2Engine:
         return out
 
     def _checkpoint_guard(self):
+        if self.wp_mode:
+            raise NotImplementedError("checkpoints under weight parallelism are not implemented (the reference writes model_wp{w}_pp0.pt row shards)")
         if self.pp != 1:
             raise NotImplementedError("checkpoints under pipeline parallelism are not implemented")
         if self.sp != 1:
@@ -1166,6 +1355,6 @@ class InternLM2Engine:
         self.drain()
         for n, t in self._from_reference_names(named).items():
             if n in self.p:   # (a pipeline stage keeps its own layers)
-                self.p[n].copy_(self.tpar.shard(self.layout.params[n].kind, t).to(self.dev, BF16))
+                self._store_param(n, self.tpar.shard(self.layout.params[n].kind, t).to(self.dev, BF16))
         if sync_master:
             self.sync_master_from_params()

@@ -105,41 +105,47 @@ class ZeroComm:
         return self.side
 
     # ---- gradients: bucket -> averaged shard on its owner ----------------------------------------
+    def reduce_scatter_async(self, full, shard):
+        """full (a whole bucket of gradients) -> `shard` = this rank's 1/world part averaged over the WHOLE data-parallel group: one
+        reduce-scatter(AVG), or under hybrid ZeRO reduce-scatter(AVG) inside the zero group + all-reduce(AVG) across the replicas, the
+        second hop ordered on a side stream.  `shard` may be the rank's own slice of `full` (in place) or any other tensor of that size
+        (weight parallelism: from a pool slot into the resident gradient shard).  Returns the Work to wait for."""
+        if self.replica_group is None:
+            return self.be.reduce_scatter(shard, full, self.group, avg=True)
+        side = self._side_stream(full.device)
+        if side is None:
+            first = self.be.reduce_scatter(shard, full, self.group, avg=True)
+            first.wait()
+            return self.be.all_reduce(shard, self.replica_group, avg=True)
+        cur = torch.cuda.current_stream(full.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                       # the bucket's last weight gradient is queued
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            first = self.be.reduce_scatter(shard, full, self.group, avg=True)
+            first.wait()                        # orders the SIDE stream (not the compute stream) behind the first hop
+            return self.be.all_reduce(shard, self.replica_group, avg=True)
+
     def reduce_bucket_async(self, grads_flat, bucket_index):
         if not self.active or self.layout.buckets[bucket_index].size == 0:   # (size 0: a bucket this pipeline stage does not own)
             return
         b = self.layout.buckets[bucket_index]
         full = grads_flat[b.start : b.start + b.size]
         s, n = b.shard(self.rank, self.world)
-        shard = grads_flat[s : s + n]     # the owner's slice OF `full`: the reduce-scatter is in place
-        if self.replica_group is None:
-            work = self.be.reduce_scatter(shard, full, self.group, avg=True)
-        else:
-            side = self._side_stream(grads_flat.device)
-            if side is None:
-                first = self.be.reduce_scatter(shard, full, self.group, avg=True)
-                first.wait()
-                work = self.be.all_reduce(shard, self.replica_group, avg=True)
-            else:
-                cur = torch.cuda.current_stream(grads_flat.device)
-                ready = torch.cuda.Event()
-                ready.record(cur)                       # the bucket's last weight gradient is queued
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    first = self.be.reduce_scatter(shard, full, self.group, avg=True)
-                    first.wait()                        # orders the SIDE stream (not the compute stream) behind the first hop
-                    work = self.be.all_reduce(shard, self.replica_group, avg=True)
-        self.pending.append(work)
+        self.pending.append(self.reduce_scatter_async(full, grads_flat[s : s + n]))   # the owner's slice OF `full`: in place
 
     # ---- parameters: updated shard -> every rank ---------------------------------------------------
+    def all_gather_async(self, full, shard):
+        """every zero-group rank's `shard` -> `full` (rank order); `shard` may be the rank's own slice of `full`."""
+        return self.be.all_gather(full, shard, self.group)
+
     def gather_bucket_async(self, params_flat, bucket_index):
         if not self.active or self.layout.buckets[bucket_index].size == 0:
             return
         b = self.layout.buckets[bucket_index]
         full = params_flat[b.start : b.start + b.size]
         s, n = b.shard(self.rank, self.world)
-        shard = params_flat[s : s + n]    # the owner's slice OF `full`: the all-gather is in place
-        self.gathers[bucket_index] = self.be.all_gather(full, shard, self.group)
+        self.gathers[bucket_index] = self.all_gather_async(full, params_flat[s : s + n])   # in place
 
     def gather_full_bucket(self, local_flat, local_offset, bucket_index):
         """Checkpointing only (synchronous): this rank's slice of a bucket of optimizer state -> the whole bucket on every rank."""

@@ -185,8 +185,11 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 
 
 def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1,
-                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False):
+                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False, pp=1, chunks=1):
     cfg = _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp, wp, model_type, tp)
+    if pp > 1:   # parallel.pipeline (PipelineScheduler; chunks > 1: model.num_chunks -> InterleavedPipelineScheduler, pipeline_scheduler.py:711)
+        cfg["parallel"]["pipeline"] = dict(size=pp, interleaved_overlap=chunks > 1)   # ("only support interleaved pipeline scheduler with overlap", launch.py)
+        cfg["model"]["num_chunks"] = chunks
     if embed_grad_scale != 1 or norm_head:   # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) + the embedding's gradient scale (modeling_internlm2.py:970-973)
         cfg["model"].update(embed_grad_scale=embed_grad_scale, norm_head=norm_head)
     if model_type == "INTERNLM_MoE":   # configs/7B_MoE4_sft.py: the InternLM-1 block (MHA with biases) + a GShard MoE in place of every MLP
@@ -350,10 +353,10 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
 
     model = initialize_model()
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
-    inner = model.model
+    inner = model.model if not isinstance(model, torch.nn.ModuleList) else None   # (a pipeline stage with several chunks: a list of wrapped models)
     sp, wp = cfg_kw.get("sp", 1), cfg_kw.get("wp", 1)
     moe_mp = world > 1 and cfg_kw.get("model_type") == "INTERNLM_MoE"
-    if world > 1 and not moe_mp:
+    if world > 1 and not moe_mp and cfg_kw.get("pp", 1) == 1:
         from internevo_amd.config import ModelConfig
         from oracle.model import param_shapes
 
@@ -361,9 +364,27 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                                                num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]))
         tp_rank, wp_rank = gpc.get_local_rank(ParallelMode.TENSOR), gpc.get_local_rank(ParallelMode.WEIGHT)
     tp = cfg_kw.get("tp", 1)
+    pp = cfg_kw.get("pp", 1)
+
+    def _stage_named_parameters():
+        """(global reference name, parameter) of this pipeline stage: every model chunk numbers its layers from 0 (modeling_internlm2.py:897-925),
+        the global number is local + the chunk's first layer (partition_uniform, pipeline_utils.py:9-34)."""
+        import re
+
+        from internlm.solver.pipeline_utils import partition_uniform
+
+        parts = partition_uniform(cfg_kw["layers"], pp, cfg_kw.get("chunks", 1))[gpc.get_local_rank(ParallelMode.PIPELINE)]
+        chunk_models = list(model) if isinstance(model, torch.nn.ModuleList) else [model]
+        assert len(chunk_models) == len(parts)
+        for cm, (start, _end) in zip(chunk_models, parts):
+            for name, p in cm.model.named_parameters():
+                yield re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name), p
+
     with torch.no_grad():
-        for name, p in inner.named_parameters():
-            if moe_mp:
+        for name, p in (_stage_named_parameters() if pp > 1 else inner.named_parameters()):
+            if pp > 1:
+                p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
+            elif moe_mp:
                 # data parallel + the reference's automatic expert parallelism (ep = min(dp, experts), parallel_context.py:538-541): every
                 # rank holds the whole dense part and experts.wrapped_experts.{j} = GLOBAL expert ep_rank * (E / ep) + j
                 import re
@@ -416,7 +437,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
         lr_used = optimizer.optim.param_groups[0]["lr"]
         ok, norms = trainer.step()
         t_steps.append(time.time() - t0)
-        rec["steps"].append({"loss": float(loss.item()), **({"moe_loss": float(moe_loss)} if moe_loss is not None else {}),
+        # (pipeline parallelism: only the last stage has the loss, pipeline_scheduler.py:694-709)
+        rec["steps"].append({"loss": float(loss.item()) if loss is not None else None, **({"moe_loss": float(moe_loss)} if moe_loss is not None else {}),
                              "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
                              "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used,
                              "metric": metric.get_metric(reset=True)})  # train.py:264-275 reads the metric every step
@@ -425,7 +447,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     rec["threads"] = torch.get_num_threads()
     # a fingerprint of the trained weights (bf16 shadow params) for end-state parity
     with torch.no_grad():
-        rec["param_fingerprint"] = {name: [float(p.float().sum()), float(p.float().abs().sum())] for name, p in inner.named_parameters()}
+        rec["param_fingerprint"] = {name: [float(p.float().sum()), float(p.float().abs().sum())]
+                                    for name, p in (_stage_named_parameters() if pp > 1 else inner.named_parameters())}
     rec["world"], rec["rank"] = world, rank
     if tag in RUNS_TIMING:  # a timing record, not a parity fixture: profiles/, with what the numbers mean
         c = cfg_kw
@@ -437,7 +460,7 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                         f"{c['layers']} layers, {dtype}, seq {c['seq_len']}, micro_bsz 1 x micro_num {c['micro_num']}; timed in the build container",
                    host_cores=os.cpu_count(), tokens_per_step=tokens, sec_per_step_timed=sum(timed) / len(timed),
                    tokens_per_second=tokens / (sum(timed) / len(timed)))
-        out_path = os.path.join(ROOT, "profiles", "r02_reference_cpu_path.json")
+        out_path = os.path.join(ROOT, "profiles", f"r03_reference_cpu_path_{c['layers']}layer.json")
     else:
         out_path = os.path.join(HERE, f"train_{tag}.json" if world == 1 else f"train_{tag}_rank{rank}.json")
     with open(out_path, "w") as f:
@@ -757,10 +780,16 @@ RUNS = {
     # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
     "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
     "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
+    # the single-rank twin of the pipeline runs pp2_* / pp2i_* below (4 layers, 4 micro-batches)
+    "pin4_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6)),
+    "pin4_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6)),
 }
 # BASELINE.md section 3 / SURVEY.md 8d: the reference's own CPU path on the 7B shape (2 layers), for the number bench.py quotes beside
 # the port's (`python make_golden.py --run cpu7b_2layer`; ~15 GB of host memory, minutes per step; not part of the fixture regeneration)
+# Two depths, so that bench.py can extrapolate the reference's time per step linearly to the model's 32 layers exactly as it extrapolates the port's
+# (t(L) = t(1) + (L - 1) (t(2) - t(1))): `python make_golden.py --run cpu7b_1layer`, `--run cpu7b_2layer` -> profiles/r03_reference_cpu_path_{1,2}layer.json
 RUNS_TIMING = {
+    "cpu7b_1layer": ("torch.bfloat16", dict(use_packed=False, seq_len=4096, hidden=4096, heads=32, kv_heads=8, vocab=92544, layers=1, micro_num=1, total_steps=3)),
     "cpu7b_2layer": ("torch.bfloat16", dict(use_packed=False, seq_len=4096, hidden=4096, heads=32, kv_heads=8, vocab=92544, layers=2, micro_num=1, total_steps=3)),
 }
 # two-process runs of the reference's ISP mode (configs/7B_isp_sft.py shape: tensor=dict(size=sp, mode="isp"), weight=dict(size=wp))
@@ -774,6 +803,13 @@ RUNS_MP = {
     # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
     "moe2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
                                          model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0), 2),
+    # two pipeline stages (parallel.pipeline = dict(size=2)): PipelineScheduler (1F1B, pipeline_scheduler.py:111-709) on the 4-layer model of
+    # pin4_* with 4 micro-batches (warm-up, steady state and cool-down all occur), and InterleavedPipelineScheduler (:711-1430) with two model
+    # chunks per stage; both must retrace the single-rank pin4_* runs
+    "pp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2), 2),
+    "pp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2), 2),
+    "pp2i_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2, chunks=2), 2),
+    "pp2i_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2, chunks=2), 2),
 }
 
 

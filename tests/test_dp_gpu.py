@@ -736,3 +736,61 @@ def test_pipeline_parallel_step_equals_single_rank_step(dev, backend, pp, dp, la
     assert seen == set(want), "the stages together hold every parameter exactly once"
     print("max |param diff| pipeline vs 1 rank:", worst)
     assert worst <= 6e-3
+
+
+def _pp_ref_worker(rank, world, port, q, chunks):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.config import tiny
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        cfg = tiny(hidden=256, layers=4, heads=4, kv_heads=2, vocab=512, seq_len=128, micro_num=4, lr=1e-3, total_steps=6)
+        eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, pp_size=2, num_chunks=chunks)
+        loader = iter(SyntheticLoader(128, 1, 4, True, 4000))
+        out = []
+        for _ in range(6):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm), float(st.loss_scale), int(st.skip)))
+        fp = {n: float(p.float().abs().sum()) for n, p in eng.named_parameters()}
+        q.put((rank, out, fp))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("tag,chunks", [("pp2", 1), ("pp2i", 2)], ids=["1f1b", "interleaved_2_chunks"])
+def test_pipeline_engine_retraces_the_reference_pipeline_runs(dev, backend, tag, chunks):
+    """The HIP engine with two pipeline stages against the REAL reference's two-process pipeline runs (tests/golden/train_pp2*_bf16_rank*.json:
+    PipelineScheduler / InterleavedPipelineScheduler on gloo, make_golden.py --run-mp): the same model, closed-form weights, batches and
+    recipe.  Every step: the last stage's loss (here broadcast to all stages) to the north star's 1e-3, the global gradient norm to 2e-2,
+    the loss scale; at the end every stage's trained parameters against the reference's fingerprint of its stage (the same layers:
+    partition_uniform)."""
+    import json
+
+    gold = [json.load(open(os.path.join(ROOT, "tests", "golden", f"train_{tag}_bf16_rank{r}.json"))) for r in range(2)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pp_ref_worker, args=(r, 2, 29921 + chunks, q, chunks)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for k, (a, b, w) in enumerate(zip(res[0][1], res[1][1], gold[1]["steps"])):
+        print(f"step {k}: HIP pp2 loss {b[0]:.5f} gn {b[1]:.4f} | reference pp2 loss {w['loss']:.5f} gn {w['grad_norm']['0_default']:.4f}")
+        assert a == b, "both stages report the same loss, norm and scaler state"
+        assert b[3] == 0 and w["ok"] and b[2] == w["loss_scale"]
+        assert abs(b[0] - w["loss"]) <= 1e-3 * abs(w["loss"]), (k, b[0], w["loss"])
+        assert abs(b[1] - w["grad_norm"]["0_default"]) <= 2e-2 * w["grad_norm"]["0_default"], (k, b[1], w["grad_norm"])
+    for r in range(2):
+        assert set(res[r][2]) == set(gold[r]["param_fingerprint"]), "stage r holds the parameters the reference's stage r holds"
+        for n, v in res[r][2].items():
+            w = gold[r]["param_fingerprint"][n][1]
+            assert abs(v - w) <= 3e-3 * w, (n, v, w)

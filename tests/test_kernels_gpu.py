@@ -493,8 +493,10 @@ def test_flash_forward_64_rows_per_wave(dev, variant, lens, hq, hkv, d, causal):
     close(out, ref, 1.6e-2, 2e-2, f"flash fwd64 variant {variant} lens={lens}", rms=FLASH_RMS)
     # the saved log-sum-exp must serve the backward: gradients through the variant's (out, lse)
     dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
-    # (the spiky key makes gradients of magnitude ~10: absolute tolerance relative to the largest reference entry)
-    close(dq, q32.grad, 2e-2, 1e-2 * float(q32.grad.abs().max()), "flash dq from fwd64 lse", rms=FLASH_RMS)
+    # (the spiky key makes gradients of magnitude ~10: absolute tolerance relative to the largest reference entry.  dQ's l2 bound is wider
+    # here: the rows that see the spike have P ~ one-hot, so dS = P (dP - delta) is a cancellation whose bf16 rounding error is multiplied by
+    # the 12x key -- measured 5e-3 ... 1e-2 on these inputs against 2.5e-3 without the spike; dK / dV keep the common bound)
+    close(dq, q32.grad, 2e-2, 1e-2 * float(q32.grad.abs().max()), "flash dq from fwd64 lse", rms=4 * FLASH_RMS)
     close(dk, kv32.grad[:, 0], 2e-2, 1e-2 * float(kv32.grad[:, 0].abs().max()), "flash dk from fwd64 lse", rms=FLASH_RMS)
     close(dv, kv32.grad[:, 1], 2e-2, 1e-2 * float(kv32.grad[:, 1].abs().max()), "flash dv from fwd64 lse", rms=FLASH_RMS)
 

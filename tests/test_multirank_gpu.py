@@ -238,3 +238,112 @@ def test_isp_config3_layout_seq32768_sp8_at_7b_width(dev, backend):  # noqa: F81
             assert v == res[0][2][n], f"rank {r[0]}: {n} differs from rank 0 after the all-gather"
     for n, v in want.items():
         assert abs(res[0][2][n] - v) <= 2e-3 * v, (n, res[0][2][n], v)
+
+
+# ---------------------------------------------------------------------------------------------------- ISP weight parallelism (row a19)
+def _wp_worker(rank, world, port, q, sp, wp, micro_num):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        out = {}
+        for mode in ("resident", "weight_parallel"):
+            cfg = _sp_cfg(4, 2, micro_num)
+            cfg.model.num_layers = 3          # odd: the two pool slots change tenants in both directions
+            cfg.train.wp_size = wp
+            eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, sp_size=sp, weight_parallel=mode == "weight_parallel",
+                                  zero_size=wp if mode == "resident" else None, merge_micro=False, batch_wgrad=False)
+            if mode == "weight_parallel":
+                L = eng.layout
+                assert eng.wp_mode and eng.world == wp and eng.comm.n_replica == world // wp
+                # what a rank keeps of a layer: 1 / wp of the bucket, weights and gradients
+                assert eng.params.numel() == L.buckets[0].size + L.buckets[-1].size + sum(b.size // wp for b in L.buckets[1:-1])
+            loader = iter(SyntheticLoader(256, 1, micro_num, True, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+            tr = []
+            for _ in range(3):
+                batch, labels = next(loader)
+                loss = eng.forward_backward(batch, labels)
+                eng.step()     # (no read_state in between: the next forward's gathers must order themselves behind the optimizer stream)
+                tr.append(loss.clone())
+            st = eng.read_state()
+            out[mode] = ([float(x) for x in tr], float(st.grad_norm), {n: p.float().cpu().numpy() for n, p in eng.named_parameters()})
+            del eng
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,sp,wp,micro_num", [
+    (2, 1, 2, 1), pytest.param(4, 2, 2, 2, marks=pytest.mark.ranks(4)), pytest.param(4, 2, 4, 2, marks=pytest.mark.ranks(4))],
+    ids=["dp2_wp2_bit_identical", "sp2_wp2_two_replicas", "sp2_wp4"])
+def test_weight_parallel_step_equals_resident_step(dev, backend, world, sp, wp, micro_num):  # noqa: F811
+    """ISP's weight parallelism (parallel.weight = dict(size=wp); isp.py:31-526, ops/linear.py:357-378, model/utils.py:466-586): every rank
+    keeps 1 / wp of each layer's weights and gradients, a layer's weights are all-gathered into a two-slot pool for the layer's forward and
+    again for its backward (the next layer's gather in flight on a side stream), its weight gradients are reduce-scattered out of the pool
+    every micro-batch.  Against the RESIDENT engine on the same ranks with the optimizer state cut the same way (zero group = weight
+    group): with one micro-batch per step the two must agree bit for bit (same reduce-scatter, same AdamW on the same shards); with
+    gradient accumulation the shards are summed after the reduce-scatter instead of before (bf16 rounding order).  sp2_wp2_two_replicas:
+    configs/7B_isp_sft.py's shape in small -- tensor (sequence) size 2, weight size 2 of 4 ranks, so the weight gradient takes the second
+    hop across the two weight-data replicas."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wp_worker, args=(r, world, 29701 + 3 * world + wp + sp, q, sp, wp, micro_num)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for rank, out in res:
+        (la, ga, pa), (lb, gb, pb) = out["resident"], out["weight_parallel"]
+        print(f"rank {rank}: resident loss {la} gn {ga:.5f} | weight parallel loss {lb} gn {gb:.5f}")
+        assert set(pa) == set(pb)
+        if micro_num == 1:
+            assert la == lb and ga == gb, "one micro-batch per step: weight parallelism must not change a single bit"
+            for n in pa:
+                assert (pa[n] == pb[n]).all(), n
+        else:
+            for x, y in zip(la, lb):
+                assert abs(x - y) <= 1e-3 * abs(x)
+            assert abs(ga - gb) <= 1e-2 * ga
+            worst = max(float(abs(pa[n] - pb[n]).max()) for n in pa)
+            assert worst <= 6e-3, worst
+    for rank, out in res[1:]:   # every rank gathers the same whole model
+        for n, a in out["weight_parallel"][2].items():
+            assert (a == res[0][1]["weight_parallel"][2][n]).all(), (rank, n)
+
+
+def test_weight_parallel_pool_on_one_rank_is_bit_identical(dev):
+    """One rank, weight_parallel=True: the shard is the whole bucket and every collective an identity, but the layer weights and gradients
+    still travel through the two pool slots (forward 0..L-1, backward L-1..0, the next micro-batch starting on what the backward left in the
+    slots, the optimizer update invalidating them).  Sequential micro-batches and the merged pass, against the resident engine: bit for bit."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    for merge in (False, True):
+        got = {}
+        for wpm in (False, True):
+            cfg = _sp_cfg(4, 2, 3)
+            cfg.model.num_layers = 3
+            eng = InternLM2Engine(cfg, dev, init_fn=formula_init, weight_parallel=wpm, merge_micro=merge, batch_wgrad=False)
+            loader = iter(SyntheticLoader(256, 1, 3, False, 4000))
+            tr = []
+            for _ in range(3):
+                batch, labels = next(loader)
+                tr.append(eng.forward_backward(batch, labels).clone())
+                eng.step()
+            st = eng.read_state()
+            got[wpm] = ([float(x) for x in tr], float(st.grad_norm), {n: p.float().cpu() for n, p in eng.named_parameters()})
+        (la, ga, pa), (lb, gb, pb) = got[False], got[True]
+        print(f"merge={merge}: resident {la} {ga} | pool {lb} {gb}")
+        if merge:
+            assert la == lb and ga == gb
+            assert all(torch.equal(pa[n], pb[n]) for n in pa)
+        else:   # accumulation in the bf16 shard after each micro-batch instead of inside the weight-gradient epilogue: same sums, one more rounding
+            assert all(abs(x - y) <= 1e-3 * abs(x) for x, y in zip(la, lb)) and abs(ga - gb) <= 1e-2 * ga
+            assert max(float((pa[n] - pb[n]).abs().max()) for n in pa) <= 6e-3
