@@ -471,7 +471,339 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
         }
 }
 
-int g_fwd_variant = -1;  // -1: automatic; 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: 64 rows per wave, THR = 4
+// ------------------------------------------------------------------------------------------------
+// K1 forward, one wave per SIMD, FOLDED softmax (round 3; variant 3).  Same block / wave / LDS geometry as flash_fwd64_k; what changes is
+// the vector-ALU work per score, which is what bounds that kernel (7 VALU, 2 of them transcendental, + their wait states in every
+// 32-cycle MFMA gap of its phase 1, where ~5 issues hide: profiles/r03_flash_fwd_isa_mix.md), and where in the tile it runs:
+//   * Q is multiplied by softmax_scale * log2(e) ONCE, when its fragments are loaded (rounded to bf16: a relative perturbation of 2^-9 of
+//     an input that is itself a bf16 GEMM output), so the MFMA accumulators hold scores in log2 units;
+//   * the reference maximum is subtracted BY THE MATRIX PIPE: every score accumulator starts with one extra k-step whose K-side fragment
+//     is the constant e_0 (1 in contraction slot 0, 0 elsewhere) and whose Q-side fragment carries -mhat[row] in slot 0, i.e.
+//     S' = K Q~^T - mhat.  mhat is a bf16-representable reference (a truncated running maximum), moved only when some row's maximum
+//     rises more than THR above it.  Softmax is invariant under the choice of the reference, so the result is exact; p <= 2^THR (+ the
+//     truncation, 2^-7 |mhat|).  4 extra MFMAs per 64-key tile (68 instead of 64) replace 64 v_fma and their 32 wait states;
+//   * what is left per score: half a v_max3, v_exp, v_add (row sum), half a v_cvt_pk.  Nothing in the common tile crosses lanes: row sums
+//     are kept as per-lane partial sums (joined once in the epilogue) and the decision "no row rose more than THR above its reference"
+//     is taken on the per-lane partial maxima.  A moved reference is the rare branch: O and the partial sums are rescaled by 2^-delta,
+//     the scores of this tile and -- one tile later -- those of the next tile, already being formed against the old reference, get one
+//     v_sub each;
+//   * phase 1 (S'(t+1): 36 MFMAs) carries the exponentials / sums / packs of the first 32-key half of tile t and, once the first half
+//     of S'(t+1) is complete, its in-lane maxima; phase 2 (O += V^T P: 32 MFMAs, first key half first) the second half of tile t, the
+//     other maxima and the decision.  Exponentials are issued one MFMA gap ahead of the adds / packs that read them (no dependent
+//     neighbours).  ~4 non-MFMA issues per gap in phase 1, ~5 in phase 2 (flash_fwd64_k: 9.3 and 4.6).
+template <int D, bool CAUSAL, int THR>
+__global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
+                                                         const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out,
+                                                         int64_t o_ts, float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T,
+                                                         int hq, int hkv, float scale) {
+    using G = Geo<D>;
+    constexpr int IMG = G::IMG_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * IMG];  // K stage 0, K stage 1, V stage 0, V stage 1
+
+    const int seq = blockIdx.z;
+    const int h = ((int)blockIdx.x % hkv) * (hq / hkv) + (int)blockIdx.x / hkv;  // the q heads of one kv head share an XCD's L2
+    const int qt = gridDim.y - 1 - blockIdx.y;                                    // heaviest (last) query tiles first
+    const int tok0 = cu[seq];
+    const int len = cu[seq + 1] - tok0;
+    const int q0 = qt * 256;
+    if (q0 >= len) return;
+    const int hk = h / (hq / hkv);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qw0 = q0 + wave * 64;
+    int my_q[2];
+    bool q_valid[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        my_q[X] = qw0 + 32 * X + (lane & 31);
+        q_valid[X] = my_q[X] < len;
+    }
+    const int kv_end = CAUSAL ? min(len, q0 + 256) : len;
+    const int nt = (kv_end + 63) / 64;                                                    // tiles the block streams
+    const int ntw = qw0 >= len ? 0 : (CAUSAL ? min(nt, qw0 / 64 + 1) : nt);               // tiles this wave computes on
+
+    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    TileSrc<D, 4> ksrc, vsrc;
+    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
+    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
+    unsigned char* Kst = smem;
+    unsigned char* Vst = smem + 2 * IMG;
+    ksrc.issue(Kst, 0, 0, wave);
+    if (nt > 1) ksrc.issue(Kst + IMG, 64, 0, wave);
+    vsrc.issue(Vst, 0, 0, wave);
+
+    FragOffs<D> fo;
+    fo.init(lane);
+
+    const float sc2 = scale * kLog2e;
+    s16x8 qf[2][G::KS];   // Q~ = bf16(q * scale * log2 e)
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const bf16_t* qp = q + (int64_t)(tok0 + my_q[X]) * q_ts + (int64_t)h * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            union { uint4 u; s16x8 s; } cv;
+            cv.u = q_valid[X] ? ld16(qp + ks * 16) : z4();
+            float f[8];
+            unpack8(cv.u, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= sc2;
+            cv.u = pack8(f);
+            qf[X][ks] = cv.s;
+        }
+    }
+    // the extra k-step: K-side e_0 (contraction slot 0 lives in element 0 of lanes 0..31), Q-side -mhat[row] in the same slot
+    s16x8 ones, mq[2];   // (mq lives in the accumulation file like the Q fragments)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 0, mq[0][e] = 0, mq[1][e] = 0;
+    if (lane < 32) ones[0] = (short)0x3F80;
+    auto mfma_fold = [&](f32x16& d, int X) {   // d = e_0 (x) (-mhat): the start value of a score accumulator
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d), "+a"(mq[X]) : "v"(ones));
+    };
+
+    f32x16 oacc[2][G::DB];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) oacc[X][db] = zero16();
+    // l_part: PER-LANE partial row sums (a lane sums the 32 keys of every tile that its registers hold; the two lanes of a row are added
+    // once, in the epilogue), two independent chains per 32-row block.
+    float mhat[2] = {0.f, 0.f}, l_part[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, mm[2] = {0.f, 0.f};
+    bool resc = false;   // the decision of the tile about to start: its rows rose more than THR above the reference (mm: in-lane maxima)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+    auto xhalf_max = [&](float v) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    auto xhalf_sum = [&](float v) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+    auto set_mq = [&](int X) {   // bf16(-mhat) into contraction slot 0 of the Q-side fragment (mhat is bf16-representable: exact)
+        const unsigned bits = __float_as_uint(-mhat[X]) >> 16;
+        mq[X][0] = (lane < 32) ? (short)bits : (short)0;
+    };
+    // masks of key half c of tile t (wave-uniform decision: diagonal / last tiles only); selects, no per-element branches
+    auto apply_mask_c = [&](f32x16 (&s)[2][2], int t, int c) {
+        const int kv0 = t * 64 + 32 * c;
+        if (!((CAUSAL && kv0 + 31 > qw0) || (kv0 + 32 > len))) return;
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int lim = CAUSAL ? min(len - 1, my_q[X]) : len - 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + creg_row(r, lane);
+                s[X][c][r] = key > lim ? -INFINITY : s[X][c][r];
+            }
+        }
+    };
+    auto apply_mask = [&](f32x16 (&s)[2][2], int t) {
+        apply_mask_c(s, t, 0);
+        apply_mask_c(s, t, 1);
+    };
+
+    // ---- prologue: S'(0) against reference 0 (its tile moves the reference to the first maxima)
+    f32x16 sA[2][2], sB[2][2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntw > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const s16x8 kfr = row_frag<D>(Kst, 32 * c, ks, fo);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    if (ks == 0) mfma_s_first(sA[X][c], kfr, qf[X][ks]);
+                    else mfma_s(sA[X][c], kfr, qf[X][ks]);
+                }
+            }
+        mfma_settle(sA[0][0], sA[0][1], sA[1][0], sA[1][1]);
+        apply_mask(sA, 0);
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            float mx0 = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx0 = fmaxf(mx0, sA[X][c][r]);
+            const float m = xhalf_max(mx0);   // (key 0 is visible to every row: finite)
+            mhat[X] = __uint_as_float(__float_as_uint(m == -INFINITY ? 0.f : m) & 0xffff0000u);
+            set_mq(X);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sA[X][c][r] -= mhat[X];
+        }
+        asm volatile("s_nop 1" : "+a"(mq[0]), "+a"(mq[1]));   // accumulation-file write -> MFMA source
+    }
+
+    constexpr int NM1 = 4 * G::KS + 4;   // MFMAs of phase 1 (the four accumulators' extra k-steps included)
+    constexpr int NM2 = 8 * G::DB;       // MFMAs of phase 2
+    constexpr int U1 = 32, U2 = 32;      // scores per lane finished in phase 1 (first key half) / phase 2 (second half: P.V reads it last)
+    constexpr int GF2 = NM2 * 3 / 4 - 1; // phase-2 gaps for the second half's scores (packed before the last quarter of the products)
+
+    // tile t with its scores (against the reference mhat) in `sc`; the scores of tile t+1 go to `sn`.  PAR = t & 1: the LDS stages.
+    auto tile = [&](auto par_c, int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
+        constexpr int PAR = decltype(par_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) ksrc.issue(Kst + PAR * IMG, (t + 2) * 64, 0, wave);
+        if (t + 1 < nt) vsrc.issue(Vst + (1 - PAR) * IMG, (t + 1) * 64, 0, wave);
+        if (t >= ntw) return;
+        const unsigned char* Kn = Kst + (1 - PAR) * IMG;
+        const unsigned char* Vc = Vst + PAR * IMG;
+        const bool has_next = t + 1 < ntw;
+
+        if (resc) {   // (rare) the reference of both row blocks moves up to their rows' maxima; rows that did not rise keep theirs
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const float m = xhalf_max(mm[X]);                       // row maximum above the reference (-inf: a fully masked row)
+                const float nm = __uint_as_float(__float_as_uint(mhat[X] + fmaxf(m, 0.f)) & 0xffff0000u);   // never down; truncated to bf16
+                const float dlt = nm - mhat[X];
+                const float al = __builtin_amdgcn_exp2f(-dlt);
+                mhat[X] = nm;
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db) acc_scale(oacc[X][db], al);
+                l_part[X][0] *= al;
+                l_part[X][1] *= al;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[X][c][r] -= dlt;   // formed against the old reference
+                set_mq(X);
+            }
+            asm volatile("s_nop 1" : "+a"(mq[0]), "+a"(mq[1]));   // accumulation-file write -> MFMA source
+            resc = false;
+        }
+
+        u32x4 pf[2][2][2];  // P fragments [X][c][s2]: 8 bf16 = keys 32c + 16*s2-step in C/D register order
+        // score o of a lane's 64, in the order the P.V products consume them: o -> (c, 16-key step s2, X, r)
+        auto E = [&](int o) {   // p = 2^S'
+            const int c = o >> 5, s2 = (o >> 4) & 1, X = (o >> 3) & 1, r = 8 * s2 + (o & 7);
+            asm volatile("v_exp_f32 %0, %0" : "+v"(sc[X][c][r]));
+        };
+        auto SP = [&](int o) {  // row sum; every second score: the bf16 pair
+            const int c = o >> 5, s2 = (o >> 4) & 1, X = (o >> 3) & 1, r = 8 * s2 + (o & 7);
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_part[X][o & 1]) : "v"(sc[X][c][r]));
+            if (o & 1) pf[X][c][s2][(r & 7) >> 1] = pack2bf(sc[X][c][r - 1], sc[X][c][r]);   // (native convert: the register tuple is hipcc's to place)
+        };
+        // gap g of Gn gaps works on scores [lo(g), lo(g + 1)) of U starting at o0: their exponentials now, sums / packs of the previous gap's
+        auto fin_gap = [&](int g, int Gn, int U, int o0) {
+            const int a0 = ((g - 1) * U / Gn) & ~1, a1 = (g * U / Gn) & ~1, a2 = g >= Gn ? a1 : (((g + 1) * U / Gn) & ~1);
+#pragma unroll
+            for (int o = a1; o < a2; ++o) E(o0 + o);
+            if (g > 0) {
+#pragma unroll
+                for (int o = a0; o < a1; ++o) SP(o0 + o);
+            }
+        };
+
+        constexpr int PF = 3, NK = 2 * G::KS, NV = 4 * G::DB;
+        s16x8 kq[NK], vq[NV];
+        auto load_v = [&](int j) { vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
+        // ---- phase 1: S'(t+1) = [e_0 | K(t+1)] [-mhat | Q~]^T   beside   the first key half of softmax(t)
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    mfma_fold(sn[X][c], X);
+                    fin_gap(c * (NM1 / 2) + X, NM1, U1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const int j = c * G::KS + ks;
+                    if (j + PF < NK) kq[j + PF] = row_frag<D>(Kn, 32 * ((j + PF) / G::KS), (j + PF) % G::KS, fo);
+                    else load_v(j + PF - NK);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) {
+                        mfma_s(sn[X][c], kq[j], qf[X][ks]);
+                        fin_gap(c * (NM1 / 2) + 2 + 2 * ks + X, NM1, U1, 0);
+                        __builtin_amdgcn_sched_barrier(0);  // this gap's vector ALU work stays in the shadow of this MFMA
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) load_v(j);
+#pragma unroll
+            for (int g = 0; g < NM1; ++g) fin_gap(g, NM1, U1, 0);
+        }
+        fin_gap(NM1, NM1, U1, 0);   // sums / packs of the last gap's scores
+
+        // ---- phase 2: O += V(t)^T P(t), first key half first   beside   the second key half of softmax(t) and the in-lane maxima of S'(t+1),
+        // one v_max3 (4 scores) per MFMA; then the decision.  On a wave's last tile the maxima run over stale registers and are dropped: no
+        // branches inside the phase.
+        if (has_next) apply_mask(sn, t + 1);
+        float mx[2][2];   // two chains per 32-row block (every chain starts from its first pair: no -inf moves)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = j / (2 * G::DB), s2 = (j / G::DB) & 1, db = j % G::DB;
+            if (j + PF < NV) load_v(j + PF);
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const int g = 2 * j + X;
+                mfma_o(oacc[X][db], vq[j], __builtin_bit_cast(s16x8, pf[X][c][s2]));
+                if (g <= GF2) fin_gap(g, GF2, U2, U1);
+                {   // scores e = 2g, 2g + 1 of S'(t+1): row block Y, key half cc, registers rr, rr + 1
+                    const int e0 = g * (64 / NM2);
+#pragma unroll
+                    for (int u = 0; u < 64 / NM2; u += 2) {
+                        const int e = e0 + u, Y = e >> 5, cc = (e >> 4) & 1, rr = e & 15, n = (e & 31) >> 1, ch = n & 1;   // pair n of row block Y
+                        if (n < 2) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx[Y][ch]) : "v"(sn[Y][cc][rr]), "v"(sn[Y][cc][rr + 1]));
+                        else max3_pinned(mx[Y][ch], sn[Y][cc][rr], sn[Y][cc][rr + 1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {   // the decision about tile t+1, on per-lane partial maxima: nothing crosses lanes
+            float top;
+#pragma unroll
+            for (int Y = 0; Y < 2; ++Y) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mm[Y]) : "v"(mx[Y][0]), "v"(mx[Y][1]));
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(top) : "v"(mm[0]), "v"(mm[1]));
+            resc = has_next & !__all(top <= (float)THR);
+        }
+    };
+
+    for (int t = 0; t < nt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t, sA, sB);
+        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1, sB, sA);
+    }
+
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int db = 0; db < G::DB; db += 2) mfma_settle_acc(oacc[X][db], oacc[X][db + 1]);
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+        if (q_valid[X]) {
+            const float l_row = xhalf_sum(l_part[X][0] + l_part[X][1]);
+            const float inv = l_row > 0.f ? 1.f / l_row : 0.f;
+            bf16_t* op = out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D;
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack2bf(oacc[X][db][4 * g + 0] * inv, oacc[X][db][4 * g + 1] * inv);
+                    w.y = pack2bf(oacc[X][db][4 * g + 2] * inv, oacc[X][db][4 * g + 3] * inv);
+                    st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
+                }
+            // natural-log LSE from log2-unit scores: (mhat + log2 l) ln 2
+            if (lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_row > 0.f) ? (mhat[X] + __builtin_amdgcn_logf(l_row)) * kLn2 : -INFINITY;
+        }
+}
+
+int g_fwd_variant = -1;  // -1: automatic; 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: 64 rows per wave, THR = 4;
+                         // 3: 64 rows per wave, folded softmax (flash_fwd64f_k), THR = 4
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -492,6 +824,16 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     // A/B runs (4 x 4096 causal: 679 vs 713 us, full attention 4 x 2048: 337 vs 351 us; profiles/r02_flash_attention.md); ragged packs
     // of short sequences leave too many of its 256-row blocks half empty (8 x <= 3000: 360 vs 336 us)
     const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? 2 : 0);
+    if (fwd_variant >= 3) {
+        dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
+#define IE_LF(DD, CA)                                                                                                                 \
+    hipLaunchKernelGGL((flash_fwd64f_k<DD, CA, 4>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, \
+                       kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
+        if (d == 128) { if (causal) IE_LF(128, true); else IE_LF(128, false); }
+        else          { if (causal) IE_LF(64, true); else IE_LF(64, false); }
+#undef IE_LF
+        return ie_launch_status("ie_flash_attn_fwd launch");
+    }
     if (fwd_variant > 0) {
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_L64(DD, CA, TH)                                                                                                           \
@@ -516,7 +858,7 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
 
 // tuning hook (A/B benchmarking only): kernel variant of the forward
 extern "C" int ie_tune_flash_fwd_variant(int variant) {
-    IE_CHECK_ARG(variant >= -1 && variant <= 2, "ie_tune_flash_fwd_variant: -1 (automatic), 0, 1 or 2");
+    IE_CHECK_ARG(variant >= -1 && variant <= 3, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3");
     g_fwd_variant = variant;
     return IE_OK;
 }

@@ -445,6 +445,46 @@ def test_flash_attention_benchmark_regime_matches_oracle(dev):
     _attn_case(dev, [4096] * 4, 32, 8, 128, True, 64)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("lens,hq,hkv,d,causal", [([4096, 4096], 8, 2, 128, True), ([2048, 3000], 4, 4, 128, False), ([1024, 777], 4, 2, 64, True)])
+def test_flash_forward_folded_softmax_long_sequences(dev, lens, hq, hkv, d, causal):
+    """flash_fwd64f_k (variant 3) at benchmark-length sequences against the oracle: forward, the saved log-sum-exp (natural log, from
+    log2-unit scores: (mhat + log2 l) ln 2), and the backward through its (out, lse).  Rows of negative-only and of large scores: q is
+    shifted for a quarter of the heads so that whole rows sit far below / above the initial reference 0."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(90)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(91)))
+    kv[:, 0, 0, :8] += 2.0                                   # a common component in the keys of kv head 0 ...
+    q[:, 0, :8] -= 3.0                                       # ... against which q head 0 scores uniformly low (all scores << 0)
+    q[:, hq - 1, :8] += 3.0 if hkv == 1 else 0.0
+    do = bf(torch.randn(T, hq, d, generator=g(92)))
+    q32, kv32 = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, causal)
+    (ref * do.float()).sum().backward()
+    qd, kvd = q.to(dev), kv.to(dev)
+    try:
+        assert L.ie_tune_flash_fwd_variant(3) == 0
+        out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), None, causal)
+    finally:
+        L.ie_tune_flash_fwd_variant(-1)
+    close(out, ref, 1.6e-2, 2e-2, f"folded fwd lens={lens}", rms=FLASH_RMS)
+    # log-sum-exp of the first sequence's first kv group, dense
+    n0 = lens[0]
+    kk = kv[:n0, 0].float().repeat_interleave(hq // hkv, 1)
+    sc = torch.einsum("thd,shd->hts", q[:n0].float(), kk) / math.sqrt(d)
+    if causal:
+        sc = sc.masked_fill(torch.arange(n0)[None, :] > torch.arange(n0)[:, None], float("-inf"))
+    close(lse[:, :n0], torch.logsumexp(sc, -1), 2e-3, 2e-2, "folded lse")
+    dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), None, causal)
+    close(dq, q32.grad, 2e-2, 3e-2, "dq through the folded forward", rms=FLASH_RMS)
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "dk through the folded forward", rms=FLASH_RMS)
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv through the folded forward", rms=FLASH_RMS)
+
+
 def test_flash_attention_lse_and_big_scores(dev):
     # large-magnitude scores exercise the online-softmax rescale path (guide section 5.4 rule 26)
     T, hq, hkv, d = 300, 2, 1, 128
@@ -461,7 +501,7 @@ def test_flash_attention_lse_and_big_scores(dev):
     close(lse, torch.logsumexp(s, -1), 1e-3, 1e-2, "flash lse")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("lens,hq,hkv,d,causal", [
     ([300, 700, 257], 4, 2, 128, True),    # ragged: 256-row blocks with idle waves, a tail block of one row
     ([1, 129, 64, 512], 4, 1, 64, True),
@@ -470,8 +510,9 @@ def test_flash_attention_lse_and_big_scores(dev):
 ])
 def test_flash_forward_64_rows_per_wave(dev, variant, lens, hq, hkv, d, causal):
     """The one-wave-per-SIMD forward (flash_fwd64_k; picked automatically for long head-dim-128 sequences) against the oracle, with
-    the exact rescale (variant 1) and the deferred rescale (variant 2), including a late spiky key that forces the rescale branch
-    of the deferred form (guide section 5.4 rule 26) and the log-sum-exp the backward consumes."""
+    the exact rescale (variant 1) and the deferred rescale (variant 2), and the folded-softmax kernel flash_fwd64f_k (variant 3: Q
+    prescaled, the reference maximum subtracted by an extra MFMA k-step, per-lane partial row sums), including a late spiky key that
+    forces the rescale branch of the deferred forms (guide section 5.4 rule 26) and the log-sum-exp the backward consumes."""
     from internevo_amd import _lib
 
     L = _lib.load()
