@@ -319,13 +319,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg)
-            # the reference's OWN CPU path (unmodified trainer, torch CPU kernels) was timed once in the build container -- /root/reference
-            # does not exist on the GPU box -- on the 7B shape cut to 2 layers: quoted beside the port's figure
-            with open(os.path.join(ROOT, "profiles", "r02_reference_cpu_path.json")) as f:
-                rj = json.load(f)
-            out["cpu_baseline"]["reference_path_build_container"] = {
-                "kind": "reference", "value": rj["tokens_per_second"], "unit": "tokens/s (7B-shaped model cut to 2 layers, bf16, seq 4096)",
-                "cores": rj["threads"], "sec_per_4096_token_step": rj["sec_per_step_timed"], "source": "profiles/r02_reference_cpu_path.json"}
+            out["cpu_baseline"]["machine"] = "this GPU box's host cores"
+            # The reference's OWN CPU path (unmodified trainer, torch CPU kernels) cannot run here -- /root/reference does not exist on the GPU
+            # box -- so it was timed in the build container at TWO depths of the 7B shape (tests/golden/make_golden.py --run cpu7b_1layer /
+            # cpu7b_2layer) and is extrapolated to the model's depth exactly like the port's figure above: t(L) = t(1) + (L - 1) (t(2) - t(1)).
+            rj = [json.load(open(os.path.join(ROOT, "profiles", f"r03_reference_cpu_path_{n}layer.json"))) for n in (1, 2)]
+            t1, t2 = rj[0]["sec_per_step_timed"], rj[1]["sec_per_step_timed"]
+            full = t1 + (cfg.model.num_layers - 1) * (t2 - t1)
+            out["cpu_baseline"]["reference"] = {
+                "kind": "reference", "value": rj[0]["tokens_per_step"] / full, "unit": "tokens/s", "cores": rj[0]["threads"],
+                "machine": f"build container ({rj[0]['host_cores']} host cores; not this box)",
+                "sample": f"the unmodified reference training step on a 7B-shaped model with 1 layer ({t1:.2f} s) and 2 layers ({t2:.2f} s) per "
+                          f"{rj[0]['tokens_per_step']}-token step, linearly extrapolated to {cfg.model.num_layers} layers ({full:.1f} s); torch CPU bf16, "
+                          f"{rj[0]['threads']} threads",
+                "source": "profiles/r03_reference_cpu_path_{1,2}layer.json"}
         except Exception as e:  # the baseline must never take the measurement down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
     if rank == 0:

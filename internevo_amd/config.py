@@ -269,9 +269,35 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
 
 
 def load_reference_config(path: str, seq_len: Optional[int] = None) -> PathConfig:
-    """Run an InternEvo `configs/*.py` and map it (parallel_context.py:77-127 semantics)."""
-    g = runpy.run_path(path)
-    cfg = {k: v for k, v in g.items() if not k.startswith("__")}
+    """Run an InternEvo `configs/*.py` and map it (parallel_context.py:77-127 semantics).  Pure-Python-style configs (configs/demo.py:2-6:
+    `with read_base(): from configs._base_... import *`) resolve without the reference installed: `read_base` is an empty context manager
+    (internlm/utils/utils.py:5-18) -- supplied here when `internlm` is not importable -- and the `configs.` package is found next to the
+    file (the folder above the file's own folder goes onto sys.path for the duration of the run)."""
+    import contextlib
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    path = os.path.abspath(path)
+    root = os.path.dirname(os.path.dirname(path))
+    stubs = []
+    if importlib.util.find_spec("internlm") is None:
+        for name in ("internlm", "internlm.utils", "internlm.utils.utils"):
+            mod = types.ModuleType(name)
+            mod.__path__ = []
+            sys.modules[name] = mod
+            stubs.append(name)
+        sys.modules["internlm.utils.utils"].read_base = contextlib.contextmanager(lambda: (yield))
+    sys.path.insert(0, root)
+    before = set(sys.modules)
+    try:
+        g = runpy.run_path(path)
+    finally:
+        sys.path.remove(root)
+        for name in stubs + [m for m in set(sys.modules) - before if m == "configs" or m.startswith("configs.")]:
+            sys.modules.pop(name, None)
+    cfg = {k: v for k, v in g.items() if not k.startswith("__") and not isinstance(v, types.ModuleType) and not callable(v)}
     return from_reference_dict(cfg, seq_len)
 
 

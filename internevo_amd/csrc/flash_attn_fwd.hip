@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
     for (int e = 0; e < 8; ++e) ones[e] = 0, mq[0][e] = 0, mq[1][e] = 0;
     if (lane < 32) ones[0] = (short)0x3F80;
     auto mfma_fold = [&](f32x16& d, int X) {   // d = e_0 (x) (-mhat): the start value of a score accumulator
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d), "+a"(mq[X]) : "v"(ones));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(mq[X]) : "v"(ones));   // src0 = K side (e_0), src1 = Q side
     };
 
     f32x16 oacc[2][G::DB];

@@ -433,3 +433,18 @@ def test_interleaved_pipeline_partition_order_and_plan():
         for chunks in (2, 3, 4):
             for k in (1, 2, 3):
                 assert len(interleaved_plan(pp, chunks, pp * k)[0]) >= 2 * pp * k * chunks
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference tree is not mounted")
+def test_pure_python_style_config_loads_without_the_reference_installed(tmp_path):
+    """configs/demo.py opens with `from internlm.utils.utils import read_base` / `with read_base(): from configs._base_... import *`
+    (demo.py:2-6).  load_reference_config must resolve it in a process where `internlm` is NOT importable (round-2 review), and map the
+    ISP config's parallel section (tensor 2 / isp, weight 4)."""
+    import subprocess
+
+    code = ("import sys, importlib.util; sys.path.insert(0, %r); assert importlib.util.find_spec('internlm') is None; "
+            "from internevo_amd.config import load_reference_config as L; c = L('/root/reference/configs/demo.py'); "
+            "i = L('/root/reference/configs/7B_isp_sft.py'); "
+            "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["32", "4096", "92544", "2", "4", "False"], out
