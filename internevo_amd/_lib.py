@@ -68,6 +68,8 @@ SIGNATURES = {
     "ie_apply_rotary": (I, [P, P, P, P, P, P, I, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, P]),
     "ie_qkv_rotary_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),
     "ie_qkv_rotary_bwd": (I, [P, P, P, P, P, P, I64, I, I, I, I, P]),
+    "ie_qkv_rotary_fwd_scaled": (I, [P, P, P, P, P, P, I64, I, I, I, I, F, P]),
+    "ie_qkv_rotary_bwd_scaled": (I, [P, P, P, P, P, P, I64, I, I, I, I, F, P]),
     "ie_swiglu_fwd": (I, [P, I64, P, I64, P, I64, I64, I64, P]),
     "ie_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, P]),
     "ie_ce_fwd": (I, [P, I, I64, P, P, P, I64, I64, I64, F, P]),

@@ -47,7 +47,7 @@ template <int D, bool INTERLEAVED>
 __global__ __launch_bounds__(256) void qkv_rotary_fwd_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cs,
                                                         const bf16_t* __restrict__ sn, const int64_t* __restrict__ pos,
                                                         bf16_t* __restrict__ q_out, bf16_t* __restrict__ kv_out, int64_t T,
-                                                        int hkv, int qpk) {
+                                                        int hkv, int qpk, float q_scale) {
     constexpr int CH = D / 16;  // 16-element spans per head
     constexpr int H2 = D / 2;
     const int gs = qpk + 2;
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void qkv_rotary_fwd_k(const bf16_t* __restrict
         o1[e] = x1[e] * co[e] - x2[e] * si[e];
         o2[e] = x1[e] * si[e] + x2[e] * co[e];
     }
+    if (s < qpk && q_scale != 1.f) {   // the attention's softmax scale rides on q (fp32, before the one rounding to bf16)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o1[e] *= q_scale, o2[e] *= q_scale;
+    }
     st16(dst + i0, pack8(o1));
     st16(dst + H2 + i0, pack8(o2));
 }
@@ -101,7 +105,7 @@ template <int D, bool INTERLEAVED>
 __global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dkv,
                                                         const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
                                                         const int64_t* __restrict__ pos, bf16_t* __restrict__ dqkv, int64_t T,
-                                                        int hkv, int qpk) {
+                                                        int hkv, int qpk, float dq_scale) {
     constexpr int CH = D / 16;
     constexpr int H2 = D / 2;
     const int gs = qpk + 2;
@@ -134,6 +138,10 @@ __global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict
     for (int e = 0; e < 8; ++e) {
         x1[e] = d1[e] * co[e] + d2[e] * si[e];
         x2[e] = -d1[e] * si[e] + d2[e] * co[e];
+    }
+    if (s < qpk && dq_scale != 1.f) {   // chain rule of the forward's q_scale (and whatever factor the attention backward left on dq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x1[e] *= dq_scale, x2[e] *= dq_scale;
     }
     if (INTERLEAVED) {
         float lo[8], hi[8];
@@ -404,9 +412,10 @@ extern "C" int ie_apply_rotary(const void* x1, const void* x2, const void* cos_,
     return ie_launch_status("ie_apply_rotary launch");
 }
 
-extern "C" int ie_qkv_rotary_fwd(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos, void* q_out, void* kv_out,
-                                 int64_t T, int hkv, int q_per_kv, int d, int interleaved, void* stream) {
+extern "C" int ie_qkv_rotary_fwd_scaled(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos, void* q_out, void* kv_out,
+                                        int64_t T, int hkv, int q_per_kv, int d, int interleaved, float q_scale, void* stream) {
     IE_CHECK_ARG(qkv && cos_ && sin_ && pos && q_out && kv_out, "ie_qkv_rotary_fwd: null pointer");
+    IE_CHECK_ARG(q_scale > 0.f, "ie_qkv_rotary_fwd_scaled: q_scale must be positive");
     IE_CHECK_ARG(T >= 0 && hkv > 0 && q_per_kv > 0, "ie_qkv_rotary_fwd: bad shape");
     IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_qkv_rotary_fwd: head dim must be 64 or 128");
     IE_CHECK_ARG(aligned16(qkv) && aligned16(cos_) && aligned16(sin_) && aligned16(q_out) && aligned16(kv_out),
@@ -417,16 +426,22 @@ extern "C" int ie_qkv_rotary_fwd(const void* qkv, const void* cos_, const void* 
     hipStream_t st = (hipStream_t)stream;
 #define IE_L(DD, IL)                                                                                                      \
     hipLaunchKernelGGL((qkv_rotary_fwd_k<DD, IL>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)cos_,         \
-                       (const bf16_t*)sin_, pos, (bf16_t*)q_out, (bf16_t*)kv_out, T, hkv, q_per_kv)
+                       (const bf16_t*)sin_, pos, (bf16_t*)q_out, (bf16_t*)kv_out, T, hkv, q_per_kv, q_scale)
     if (d == 128) { if (interleaved) IE_L(128, true); else IE_L(128, false); }
     else          { if (interleaved) IE_L(64, true); else IE_L(64, false); }
 #undef IE_L
     return ie_launch_status("ie_qkv_rotary_fwd launch");
 }
 
-extern "C" int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* cos_, const void* sin_, const int64_t* pos, void* dqkv,
+extern "C" int ie_qkv_rotary_fwd(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos, void* q_out, void* kv_out,
                                  int64_t T, int hkv, int q_per_kv, int d, int interleaved, void* stream) {
+    return ie_qkv_rotary_fwd_scaled(qkv, cos_, sin_, pos, q_out, kv_out, T, hkv, q_per_kv, d, interleaved, 1.f, stream);
+}
+
+extern "C" int ie_qkv_rotary_bwd_scaled(const void* dq, const void* dkv, const void* cos_, const void* sin_, const int64_t* pos, void* dqkv,
+                                        int64_t T, int hkv, int q_per_kv, int d, int interleaved, float dq_scale, void* stream) {
     IE_CHECK_ARG(dq && dkv && cos_ && sin_ && pos && dqkv, "ie_qkv_rotary_bwd: null pointer");
+    IE_CHECK_ARG(dq_scale > 0.f, "ie_qkv_rotary_bwd_scaled: dq_scale must be positive");
     IE_CHECK_ARG(T >= 0 && hkv > 0 && q_per_kv > 0, "ie_qkv_rotary_bwd: bad shape");
     IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_qkv_rotary_bwd: head dim must be 64 or 128");
     IE_CHECK_ARG(aligned16(dq) && aligned16(dkv) && aligned16(cos_) && aligned16(sin_) && aligned16(dqkv),
@@ -437,11 +452,16 @@ extern "C" int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* co
     hipStream_t st = (hipStream_t)stream;
 #define IE_L(DD, IL)                                                                                                   \
     hipLaunchKernelGGL((qkv_rotary_bwd_k<DD, IL>), grid, dim3(256), 0, st, (const bf16_t*)dq, (const bf16_t*)dkv,       \
-                       (const bf16_t*)cos_, (const bf16_t*)sin_, pos, (bf16_t*)dqkv, T, hkv, q_per_kv)
+                       (const bf16_t*)cos_, (const bf16_t*)sin_, pos, (bf16_t*)dqkv, T, hkv, q_per_kv, dq_scale)
     if (d == 128) { if (interleaved) IE_L(128, true); else IE_L(128, false); }
     else          { if (interleaved) IE_L(64, true); else IE_L(64, false); }
 #undef IE_L
     return ie_launch_status("ie_qkv_rotary_bwd launch");
+}
+
+extern "C" int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* cos_, const void* sin_, const int64_t* pos, void* dqkv,
+                                 int64_t T, int hkv, int q_per_kv, int d, int interleaved, void* stream) {
+    return ie_qkv_rotary_bwd_scaled(dq, dkv, cos_, sin_, pos, dqkv, T, hkv, q_per_kv, d, interleaved, 1.f, stream);
 }
 
 extern "C" int ie_swiglu_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows,

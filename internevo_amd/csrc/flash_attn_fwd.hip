@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
 //     of S'(t+1) is complete, its in-lane maxima; phase 2 (O += V^T P: 32 MFMAs, first key half first) the second half of tile t, the
 //     other maxima and the decision.  Exponentials are issued one MFMA gap ahead of the adds / packs that read them (no dependent
 //     neighbours).  ~4 non-MFMA issues per gap in phase 1, ~5 in phase 2 (flash_fwd64_k: 9.3 and 4.6).
-template <int D, bool CAUSAL, int THR>
+// ABL (timing ablations only, results wrong; kbench variants 10 + ABL): 1 no landing wait, 2 no barrier, 4 no K / V transfers in the loop,
+// 8 no softmax vector work
+template <int D, bool CAUSAL, int THR, int ABL = 0, int PFD = 3>
 __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
                                                          const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out,
                                                          int64_t o_ts, float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T,
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
     vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
     unsigned char* Kst = smem;
     unsigned char* Vst = smem + 2 * IMG;
+    const uint32_t Kst_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem, Vst_lds = Kst_lds + 2 * IMG;
     ksrc.issue(Kst, 0, 0, wave);
     if (nt > 1) ksrc.issue(Kst + IMG, 64, 0, wave);
     vsrc.issue(Vst, 0, 0, wave);
@@ -545,11 +548,13 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
         for (int ks = 0; ks < G::KS; ++ks) {
             union { uint4 u; s16x8 s; } cv;
             cv.u = q_valid[X] ? ld16(qp + ks * 16) : z4();
-            float f[8];
-            unpack8(cv.u, f);
+            if (fabsf(sc2 - 1.f) > 1e-6f) {   // (a caller that stored q pre-scaled -- ie_qkv_rotary_fwd_scaled -- passes softmax_scale = ln 2)
+                float f[8];
+                unpack8(cv.u, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= sc2;
-            cv.u = pack8(f);
+                for (int e = 0; e < 8; ++e) f[e] *= sc2;
+                cv.u = pack8(f);
+            }
             qf[X][ks] = cv.s;
         }
     }
@@ -648,11 +653,24 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
     // tile t with its scores (against the reference mhat) in `sc`; the scores of tile t+1 go to `sn`.  PAR = t & 1: the LDS stages.
     auto tile = [&](auto par_c, int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
         constexpr int PAR = decltype(par_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) ksrc.issue(Kst + PAR * IMG, (t + 2) * 64, 0, wave);
-        if (t + 1 < nt) vsrc.issue(Vst + (1 - PAR) * IMG, (t + 1) * 64, 0, wave);
-        if (t >= ntw) return;
+        if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        // K(t+2) / V(t+1) go into the stages the barrier just freed, one 1-KiB piece per fourth MFMA gap of phase 1 (inline asm: hipcc neither
+        // counts nor drains them; the wait at the top of the next tile is the explicit vmcnt(0) above).  Issued as one burst behind the
+        // barrier they cost the whole burst in matrix-pipe idle time: 57 of 620 us on the 4 x 4096 call (profiles/r03_flash_fwd_ablation.md).
+        constexpr int PERW = TileSrc<D, 4>::PERW;
+        auto dma_piece = [&](int i) {
+            if (ABL & 4) return;
+            // (unconditional: a tile behind the block's last one is read and never used -- rows of the next sequence, or zeros behind the
+            // tensor (num_records) -- which keeps the gaps free of branches; the epilogue waits for the stragglers)
+            if (i < PERW) ksrc.issue_piece_asm(Kst_lds + PAR * IMG, (t + 2) * 64 * ksrc.ts2, wave, i);
+            else if (i < 2 * PERW) vsrc.issue_piece_asm(Vst_lds + (1 - PAR) * IMG, (t + 1) * 64 * vsrc.ts2, wave, i - PERW);
+        };
+        if (t >= ntw) {   // this wave has no rows left that see tile t: it still moves its share of the tiles
+#pragma unroll
+            for (int i = 0; i < 2 * PERW; ++i) dma_piece(i);
+            return;
+        }
         const unsigned char* Kn = Kst + (1 - PAR) * IMG;
         const unsigned char* Vc = Vst + PAR * IMG;
         const bool has_next = t + 1 < ntw;
@@ -683,12 +701,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
         // score o of a lane's 64, in the order the P.V products consume them: o -> (c, 16-key step s2, X, r)
         auto E = [&](int o) {   // p = 2^S'
             const int c = o >> 5, s2 = (o >> 4) & 1, X = (o >> 3) & 1, r = 8 * s2 + (o & 7);
-            asm volatile("v_exp_f32 %0, %0" : "+v"(sc[X][c][r]));
+            if (!(ABL & 8)) asm volatile("v_exp_f32 %0, %0" : "+v"(sc[X][c][r]));
         };
         auto SP = [&](int o) {  // row sum; every second score: the bf16 pair
             const int c = o >> 5, s2 = (o >> 4) & 1, X = (o >> 3) & 1, r = 8 * s2 + (o & 7);
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_part[X][o & 1]) : "v"(sc[X][c][r]));
-            if (o & 1) pf[X][c][s2][(r & 7) >> 1] = pack2bf(sc[X][c][r - 1], sc[X][c][r]);   // (native convert: the register tuple is hipcc's to place)
+            if (!(ABL & 8)) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_part[X][o & 1]) : "v"(sc[X][c][r]));
+            if (o & 1) pf[X][c][s2][(r & 7) >> 1] = (ABL & 8) ? __float_as_uint(sc[X][c][r]) : pack2bf(sc[X][c][r - 1], sc[X][c][r]);   // (native convert: the register tuple is hipcc's to place)
         };
         // gap g of Gn gaps works on scores [lo(g), lo(g + 1)) of U starting at o0: their exponentials now, sums / packs of the previous gap's
         auto fin_gap = [&](int g, int Gn, int U, int o0) {
@@ -701,13 +719,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
             }
         };
 
-        constexpr int PF = 3, NK = 2 * G::KS, NV = 4 * G::DB;
+        constexpr int PF = PFD, NK = 2 * G::KS, NV = 4 * G::DB;
         s16x8 kq[NK], vq[NV];
-        auto load_v = [&](int j) { vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
+        auto load_v = [&](int j) { if (!(ABL & 16)) vq[j] = trans_frag<D>(Vc, j % G::DB, j / G::DB, fo); };
+        auto load_k = [&](int j) { if (!(ABL & 16)) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo); };
         // ---- phase 1: S'(t+1) = [e_0 | K(t+1)] [-mhat | Q~]^T   beside   the first key half of softmax(t)
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < PF; ++j) kq[j] = row_frag<D>(Kn, 32 * (j / G::KS), j % G::KS, fo);
+            for (int j = 0; j < PF; ++j) load_k(j);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -715,22 +734,26 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
                 for (int X = 0; X < 2; ++X) {
                     mfma_fold(sn[X][c], X);
                     fin_gap(c * (NM1 / 2) + X, NM1, U1, 0);
+                    if ((c * (NM1 / 2) + X) % 4 == 1) dma_piece((c * (NM1 / 2) + X) / 4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
                     const int j = c * G::KS + ks;
-                    if (j + PF < NK) kq[j + PF] = row_frag<D>(Kn, 32 * ((j + PF) / G::KS), (j + PF) % G::KS, fo);
+                    if (j + PF < NK) load_k(j + PF);
                     else load_v(j + PF - NK);
 #pragma unroll
                     for (int X = 0; X < 2; ++X) {
                         mfma_s(sn[X][c], kq[j], qf[X][ks]);
                         fin_gap(c * (NM1 / 2) + 2 + 2 * ks + X, NM1, U1, 0);
+                        if ((c * (NM1 / 2) + 2 + 2 * ks + X) % 4 == 1) dma_piece((c * (NM1 / 2) + 2 + 2 * ks + X) / 4);
                         __builtin_amdgcn_sched_barrier(0);  // this gap's vector ALU work stays in the shadow of this MFMA
                     }
                 }
             }
         } else {
+#pragma unroll
+            for (int i = 0; i < 2 * PERW; ++i) dma_piece(i);
 #pragma unroll
             for (int j = 0; j < PF; ++j) load_v(j);
 #pragma unroll
@@ -757,7 +780,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
 #pragma unroll
                     for (int u = 0; u < 64 / NM2; u += 2) {
                         const int e = e0 + u, Y = e >> 5, cc = (e >> 4) & 1, rr = e & 15, n = (e & 31) >> 1, ch = n & 1;   // pair n of row block Y
-                        if (n < 2) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx[Y][ch]) : "v"(sn[Y][cc][rr]), "v"(sn[Y][cc][rr + 1]));
+                        if (ABL & 8) { if (n < 2) mx[Y][ch] = 0.f; }
+                        else if (n < 2) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx[Y][ch]) : "v"(sn[Y][cc][rr]), "v"(sn[Y][cc][rr + 1]));
                         else max3_pinned(mx[Y][ch], sn[Y][cc][rr], sn[Y][cc][rr + 1]);
                     }
                 }
@@ -778,6 +802,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
         if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1, sB, sA);
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tiles' look-ahead transfers have landed before the block gives its LDS back
 #pragma unroll
     for (int X = 0; X < 2; ++X)
 #pragma unroll
@@ -823,7 +848,31 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     // automatic: 64 rows per wave (deferred rescale) for long sequences of head dim 128, where it measures 4-5 % faster in same-box
     // A/B runs (4 x 4096 causal: 679 vs 713 us, full attention 4 x 2048: 337 vs 351 us; profiles/r02_flash_attention.md); ragged packs
     // of short sequences leave too many of its 256-row blocks half empty (8 x <= 3000: 360 vs 336 us)
-    const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? 2 : 0);
+    // ... and the folded-softmax kernel (variant 3) where that one was picked AND the caller stored q pre-scaled (softmax_scale = ln 2, i.e.
+    // scale * log2 e = 1: ie_qkv_rotary_fwd_scaled): scaling q inside the attention kernel costs one more bf16 rounding of q, which the
+    // backward kernels (they recompute the scores from the q they are given) would not see
+    const bool prescaled = fabsf(softmax_scale * kLog2e - 1.f) < 1e-6f;
+    const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? (prescaled ? 3 : 2) : 0);
+    if (fwd_variant >= 10 && d == 128 && causal) {   // timing ablations of the folded kernel (results wrong)
+        dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
+#define IE_LA(AB)                                                                                                                     \
+    hipLaunchKernelGGL((flash_fwd64f_k<128, true, 4, AB>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, \
+                       kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
+        switch (fwd_variant - 10) {
+            case 1: IE_LA(1); break;
+            case 3: IE_LA(3); break;
+            case 7: IE_LA(7); break;
+            case 8: IE_LA(8); break;
+            case 15: IE_LA(15); break;
+            case 16: IE_LA(16); break;
+            case 31: IE_LA(31); break;
+            case 40: hipLaunchKernelGGL((flash_fwd64f_k<128, true, 4, 0, 5>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale); break;
+            case 41: hipLaunchKernelGGL((flash_fwd64f_k<128, true, 4, 0, 7>), grid64, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale); break;
+            default: IE_LA(0); break;
+        }
+#undef IE_LA
+        return ie_launch_status("ie_flash_attn_fwd launch");
+    }
     if (fwd_variant >= 3) {
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_LF(DD, CA)                                                                                                                 \
@@ -858,7 +907,7 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
 
 // tuning hook (A/B benchmarking only): kernel variant of the forward
 extern "C" int ie_tune_flash_fwd_variant(int variant) {
-    IE_CHECK_ARG(variant >= -1 && variant <= 3, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3");
+    IE_CHECK_ARG(variant >= -1 && variant <= 60, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3 (10 + ABL: timing ablations of variant 3)");
     g_fwd_variant = variant;
     return IE_OK;
 }

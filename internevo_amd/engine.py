@@ -39,6 +39,7 @@ from .tensorpar import TensorParallel
 from .zero import ZeroComm, job_dp_groups
 
 BF16 = torch.bfloat16
+_LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 
 
 class InternLM2Engine:
@@ -194,6 +195,12 @@ class InternLM2Engine:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self.sumsq_ws = torch.empty(K._L().ie_sumsq_max_partials() * (len(L.buckets) + 1), dtype=torch.float32, device=device)
 
+        # ---- the softmax scale rides on q: the rotary kernel stores bf16(q * scale * log2 e) (one rounding, like the unscaled q), attention is
+        # called with softmax_scale = ln 2 (scale * log2 e inside the kernels becomes 1: scores come off the MFMA accumulators in log2 units,
+        # which is what the folded-softmax forward kernel wants), and the rotary backward undoes both factors on dq in fp32
+        self.attn_scale = _LN2
+        self.q_scale = (mc.head_dim ** -0.5) * _LOG2E
+        self.dq_scale = self.q_scale / _LN2
         # ---- rotary tables (embedding.py:301-327: fp32 -> bf16), sized on demand
         self._rot_len = 0
         self._ensure_rotary(tc.seq_len)
@@ -514,14 +521,14 @@ class InternLM2Engine:
             K.add_rmsnorm_fwd(prev_ffn_out, self.a_r2[self.slot[l - 1]], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[s], self.a_rstd1[s])
         K.linear_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.t_qkv)
         if self.sp == 1:
-            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s])
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s], self.q_scale)
         else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
-            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl)
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl, self.q_scale)
             xq = self.seqpar.scatter_heads_gather_seq_async(self.t_ql, 1, self.t_xq, self.a_q[s])     # q's exchange runs under kv's packing copy
             xkv = self.seqpar.scatter_heads_gather_seq_async(self.t_kvl, 2, self.t_xkv, self.a_kv[s])  # and the two exchanges beside each other
             xq.wait()
             xkv.wait()
-        K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, None, True, self.a_ctx[s], self.a_lse[s])
+        K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, self.attn_scale, True, self.a_ctx[s], self.a_lse[s])
         if self.sp > 1:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
@@ -710,14 +717,14 @@ class InternLM2Engine:
             wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None, acc_l)
             d_ctx_full = d_ctx.view(T, -1, d) if self.sp == 1 else xc.wait()
             K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
-                             max_seqlen, None, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+                             max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
             if self.sp == 1:
                 dq_l, dkv_l = self.t_dq, self.t_dkv
             else:
                 xq = self.seqpar.scatter_seq_gather_heads_async(self.t_dq, 1, self.t_xq, self.t_ql)
                 xkv = self.seqpar.scatter_seq_gather_heads_async(self.t_dkv, 2, self.t_xkv, self.t_kvl)   # both in flight; dq unpacks under dkv's
                 dq_l, dkv_l = xq.wait(), xkv.wait()
-            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv)
+            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv, self.dq_scale)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
             ar = self.tpar.all_reduce_sum_async(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient

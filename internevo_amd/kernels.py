@@ -125,26 +125,27 @@ def apply_rotary(x1, x2, cos, sin, out1, out2, conj):
                                cos2.stride(0), int(bool(conj)), _stream()), "ie_apply_rotary")
 
 
-def qkv_rotary_fwd(qkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, q_out=None, kv_out=None):
-    """qkv [T, hkv*(q_per_kv+2)*d] -> q [T, hkv*q_per_kv, d], kv [T, 2, hkv, d]."""
+def qkv_rotary_fwd(qkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, q_out=None, kv_out=None, q_scale=1.0):
+    """qkv [T, hkv*(q_per_kv+2)*d] -> q [T, hkv*q_per_kv, d], kv [T, 2, hkv, d].  q_scale: factor applied to the rotated q in fp32 before its
+    rounding to bf16 (the engine puts softmax_scale * log2 e there and calls attention with softmax_scale = ln 2)."""
     _contig(qkv, "qkv")
     T = qkv.numel() // (hkv * (q_per_kv + 2) * d)
     if q_out is None:
         q_out = torch.empty((T, hkv * q_per_kv, d), dtype=qkv.dtype, device=qkv.device)
     if kv_out is None:
         kv_out = torch.empty((T, 2, hkv, d), dtype=qkv.dtype, device=qkv.device)
-    check(_L().ie_qkv_rotary_fwd(_p(qkv), _p(cos), _p(sin), _p(pos), _p(q_out), _p(kv_out), T, hkv, q_per_kv, d, int(interleaved),
-                                 _stream()), "ie_qkv_rotary_fwd")
+    check(_L().ie_qkv_rotary_fwd_scaled(_p(qkv), _p(cos), _p(sin), _p(pos), _p(q_out), _p(kv_out), T, hkv, q_per_kv, d, int(interleaved),
+                                        float(q_scale), _stream()), "ie_qkv_rotary_fwd_scaled")
     return q_out, kv_out
 
 
-def qkv_rotary_bwd(dq, dkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, dqkv_out=None):
+def qkv_rotary_bwd(dq, dkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, dqkv_out=None, dq_scale=1.0):
     _contig(dq, "dq"); _contig(dkv, "dkv")
     T = dq.numel() // (hkv * q_per_kv * d)
     if dqkv_out is None:
         dqkv_out = torch.empty((T, hkv * (q_per_kv + 2) * d), dtype=dq.dtype, device=dq.device)
-    check(_L().ie_qkv_rotary_bwd(_p(dq), _p(dkv), _p(cos), _p(sin), _p(pos), _p(dqkv_out), T, hkv, q_per_kv, d, int(interleaved),
-                                 _stream()), "ie_qkv_rotary_bwd")
+    check(_L().ie_qkv_rotary_bwd_scaled(_p(dq), _p(dkv), _p(cos), _p(sin), _p(pos), _p(dqkv_out), T, hkv, q_per_kv, d, int(interleaved),
+                                        float(dq_scale), _stream()), "ie_qkv_rotary_bwd_scaled")
     return dqkv_out
 
 

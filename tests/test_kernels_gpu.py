@@ -485,6 +485,52 @@ def test_flash_forward_folded_softmax_long_sequences(dev, lens, hq, hkv, d, caus
     close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv through the folded forward", rms=FLASH_RMS)
 
 
+@pytest.mark.parametrize("lens,hq,hkv,d", [([2048, 2500], 8, 2, 128), ([300, 90], 4, 2, 64)])
+def test_attention_with_the_softmax_scale_on_q(dev, lens, hq, hkv, d):
+    """The engine's arrangement (engine.py: q_scale / attn_scale / dq_scale): ie_qkv_rotary_fwd_scaled stores q~ = bf16(q * scale * log2 e),
+    attention runs with softmax_scale = ln 2 (for long head-dim-128 sequences that selects the folded-softmax kernel), the backward's dq
+    comes back as ln 2 * dL/dq~ and ie_qkv_rotary_bwd_scaled multiplies it by scale * log2 e / ln 2.  Here with the rotation switched off
+    (cos = 1, sin = 0) so that the oracle is plain attention on q: out, lse, dq, dk, dv must match it, and the automatic dispatch must have
+    taken variant 3 for the long case (bit-identical to the forced variant)."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    qpk = hq // hkv
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    qkv = bf(torch.randn(T, hkv, qpk + 2, d, generator=g(95)))
+    do = bf(torch.randn(T, hq, d, generator=g(96)))
+    cos = torch.ones(max(lens), d // 2, dtype=torch.bfloat16)
+    sin = torch.zeros(max(lens), d // 2, dtype=torch.bfloat16)
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int64)
+    scale = d ** -0.5
+    LOG2E, LN2 = 1.4426950408889634, 0.6931471805599453
+    # oracle: q / k / v as the unscaled split gives them (non-interleaved layout: no shuffle)
+    q_ref = qkv[:, :, :qpk].reshape(T, hq, d)
+    kv_ref = torch.stack([qkv[:, :, qpk], qkv[:, :, qpk + 1]], dim=1)
+    q32, kv32 = q_ref.float().requires_grad_(True), kv_ref.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, True)
+    (ref * do.float()).sum().backward()
+    k = K()
+    qs, kvd = k.qkv_rotary_fwd(qkv.reshape(T, -1).to(dev), cos.to(dev), sin.to(dev), pos.to(dev), hkv, qpk, d, False, q_scale=scale * LOG2E)
+    close(qs, q_ref.float() * (scale * LOG2E), 8e-3, 1e-6, "pre-scaled q")
+    out, lse = k.flash_attn_fwd(qs, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), LN2, True)
+    if d == 128:
+        try:
+            assert L.ie_tune_flash_fwd_variant(3) == 0
+            out3, lse3 = k.flash_attn_fwd(qs, kvd[:, 0], kvd[:, 1], cu.to(dev), max(lens), LN2, True)
+        finally:
+            L.ie_tune_flash_fwd_variant(-1)
+        assert torch.equal(out, out3) and torch.equal(lse, lse3), "softmax_scale = ln 2 on a long head-dim-128 problem must pick the folded kernel"
+    close(out, ref, 1.6e-2, 2e-2, "attention on pre-scaled q", rms=FLASH_RMS)
+    dq, dk, dv = k.flash_attn_bwd(do.to(dev), qs, kvd[:, 0], kvd[:, 1], out, lse, cu.to(dev), max(lens), LN2, True)
+    dkv = torch.stack([dk, dv], dim=1)
+    dqkv = k.qkv_rotary_bwd(dq, dkv, cos.to(dev), sin.to(dev), pos.to(dev), hkv, qpk, d, False, dq_scale=scale * LOG2E / LN2).reshape(T, hkv, qpk + 2, d)
+    close(dqkv[:, :, :qpk].reshape(T, hq, d), q32.grad, 2e-2, 3e-2, "dq through the scaled pair", rms=FLASH_RMS)
+    close(dqkv[:, :, qpk], kv32.grad[:, 0], 2e-2, 3e-2, "dk through the scaled pair", rms=FLASH_RMS)
+    close(dqkv[:, :, qpk + 1], kv32.grad[:, 1], 2e-2, 3e-2, "dv through the scaled pair", rms=FLASH_RMS)
+
+
 def test_flash_attention_lse_and_big_scores(dev):
     # large-magnitude scores exercise the online-softmax rescale path (guide section 5.4 rule 26)
     T, hq, hkv, d = 300, 2, 1, 128
