@@ -115,6 +115,8 @@ def main():
                                                        "must divide --gpus; data parallel size = gpus / tp")
     ap.add_argument("--zero", type=int, default=None, help="parallel.zero1.size: ranks that share one copy of the sharded optimizer state "
                                                             "(hybrid ZeRO when smaller than the data-parallel size; default: the whole data-parallel group)")
+    ap.add_argument("--scale-on-q", action="store_true", help="A/B only: engine scale_on_q=True (softmax scale folded into the rotary kernel's q, folded-softmax "
+                                                               "attention forward; moves a bf16 rounding point away from the reference's -- see engine.py)")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
                                                        "must divide --gpus; data parallel size = gpus / sp")
     args = ap.parse_args()
@@ -178,7 +180,7 @@ def main():
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None,
-                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero)
+                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero, scale_on_q=args.scale_on_q)
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()

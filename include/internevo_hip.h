@@ -87,8 +87,7 @@ int ie_qkv_rotary_bwd(const void* dq, const void* dkv, const void* cos_, const v
  * softmax_scale to flash_attn, modeling_internlm2.py:446-468): q_out = bf16(q_scale * rotated q), the product taken in fp32 before the
  * one rounding, so that the attention kernels read scores in log2 units straight off the MFMA accumulators (q_scale = softmax_scale *
  * log2 e, attention called with softmax_scale = ln 2: ie_flash_attn_fwd then picks the folded-softmax kernel); the backward multiplies
- * the incoming dq by dq_scale (chain rule of q_scale times whatever factor the attention backward left on dq) before the conjugate
- * rotation.  q_scale = dq_scale = 1 is exactly the unscaled pair. */
+ * the incoming dq (= dL/dq_out) by dq_scale (the chain rule's q_scale) before the conjugate rotation.  q_scale = dq_scale = 1 is exactly the unscaled pair. */
 int ie_qkv_rotary_fwd_scaled(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos,
                              void* q_out, void* kv_out, int64_t T, int hkv, int q_per_kv, int d,
                              int interleaved, float q_scale, void* stream);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict
         x1[e] = d1[e] * co[e] + d2[e] * si[e];
         x2[e] = -d1[e] * si[e] + d2[e] * co[e];
     }
-    if (s < qpk && dq_scale != 1.f) {   // chain rule of the forward's q_scale (and whatever factor the attention backward left on dq)
+    if (s < qpk && dq_scale != 1.f) {   // chain rule of the forward's q_scale
 #pragma unroll
         for (int e = 0; e < 8; ++e) x1[e] *= dq_scale, x2[e] *= dq_scale;
     }

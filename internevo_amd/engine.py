@@ -45,7 +45,7 @@ _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
@@ -60,7 +60,12 @@ class InternLM2Engine:
         whole data-parallel group); a layer's weights are all-gathered into a two-slot pool right before the layer runs, forward and
         backward, the next layer's gather running on a side stream under this layer's kernels, and its weight gradients are
         reduce-scattered (AVG) out of a pool slot every micro-batch and accumulated in the resident shard.  None = automatic: on only when
-        the config asks for wp > 1 AND the resident layout (weights whole on every GPU) does not fit this GPU's memory; False = resident."""
+        the config asks for wp > 1 AND the resident layout (weights whole on every GPU) does not fit this GPU's memory; False = resident.
+        scale_on_q (default off): the rotary kernel stores q already multiplied by softmax_scale * log2 e (ie_qkv_rotary_fwd_scaled) and
+        attention runs at softmax_scale = ln 2, which lets the forward take the folded-softmax kernel (+7 % on the 4 x 4096 attention call,
+        profiles/r03_flash_fwd_folded.md).  Same mathematics, but q is rounded to bf16 AFTER the scale instead of before it as the reference
+        does: the attention inputs are no longer bit-identical to the reference's, and the tiny-model trajectories drift from the reference
+        runs 3-4x faster (3e-3 instead of 7e-4 in the loss after six steps, measured) -- outside the 1e-3 parity bound, hence opt-in."""
         self.cfg = cfg
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
@@ -195,12 +200,13 @@ class InternLM2Engine:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self.sumsq_ws = torch.empty(K._L().ie_sumsq_max_partials() * (len(L.buckets) + 1), dtype=torch.float32, device=device)
 
-        # ---- the softmax scale rides on q: the rotary kernel stores bf16(q * scale * log2 e) (one rounding, like the unscaled q), attention is
-        # called with softmax_scale = ln 2 (scale * log2 e inside the kernels becomes 1: scores come off the MFMA accumulators in log2 units,
-        # which is what the folded-softmax forward kernel wants), and the rotary backward undoes both factors on dq in fp32
-        self.attn_scale = _LN2
-        self.q_scale = (mc.head_dim ** -0.5) * _LOG2E
-        self.dq_scale = self.q_scale / _LN2
+        # ---- scale_on_q: the rotary kernel stores bf16(q * scale * log2 e) (one rounding, like the unscaled q), attention is called with
+        # softmax_scale = ln 2 (scale * log2 e inside the kernels becomes 1: scores come off the MFMA accumulators in log2 units, which is
+        # what the folded-softmax forward kernel wants), and the rotary backward applies the chain rule's q_scale to dq in fp32
+        self.scale_on_q = bool(int(os.environ.get("IE_SCALE_ON_Q", "0")) if scale_on_q is None else scale_on_q)
+        self.attn_scale = _LN2 if self.scale_on_q else None          # (None: 1 / sqrt(head_dim) inside the attention kernels, as the reference)
+        self.q_scale = (mc.head_dim ** -0.5) * _LOG2E if self.scale_on_q else 1.0
+        self.dq_scale = self.q_scale          # chain rule: the attention backward returns dL/d(q~) of q~ = q_scale * q
         # ---- rotary tables (embedding.py:301-327: fp32 -> bf16), sized on demand
         self._rot_len = 0
         self._ensure_rotary(tc.seq_len)
