@@ -76,7 +76,7 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
         qkv = F.linear(x, p[pre + "mixer.Wqkv.weight"], p[pre + "mixer.Wqkv.bias"])          # "(three h d)"
         # the shared rotary / attention helpers take InternLM2's [kv group][q, k, v] order: with one q head per kv head that is [h][three][d]
         qkv = qkv.reshape(S, 3, H, d).permute(0, 2, 1, 3).reshape(S, 3 * H * d)
-        q, kv = O.qkv_split_rotary(qkv, cos, sin, indexes, H, 1, d, interleaved=False)
+        q, kv = O.qkv_split_rotary(qkv, cos, sin, indexes, H, 1, d, interleaved=False, inplace_qkv_form=True)
         ctx = O.attention_varlen(q, kv, cu_seqlens, causal=True)
         attn = F.linear(ctx.reshape(S, -1), p[pre + "mixer.out_proj.weight"], p[pre + "mixer.out_proj.bias"])
         residual = attn + residual

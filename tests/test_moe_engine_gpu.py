@@ -72,7 +72,7 @@ def test_moe_engine_matches_reference_trajectory(dev):
             print(f"[parity moe] routing: {flips} of {total} choices differ from the CPU oracle, all near-ties")
             assert flips <= 0.10 * total
         if k < 2:    # the reference's own trajectory, before routing flips compound through the updates
-            assert abs(float(loss) - w["loss"]) <= 2e-3 * w["loss"], (k, float(loss), w["loss"])
+            assert abs(float(loss) - w["loss"]) <= 1e-3 * w["loss"], (k, float(loss), w["loss"])   # (measured 3.9e-4 and 1.4e-4)
         # part 2: downstream of the decisions
         # steps 0-2 (measured: loss within 3e-4, norms within 2.5e-2) at the dense tolerances; from step 3 on the two weight sets have
         # drifted apart by bf16 update rounding and the engine's choices are no longer the oracle's own arg-maxes (a 2-layer, 128-token model at
