@@ -17,8 +17,12 @@ class FlashAttnVarlenKVPackedFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, return_softmax=False):
         _check_no_dropout(dropout_p)
-        if cu_seqlens_q.data_ptr() != cu_seqlens_k.data_ptr() and not torch.equal(cu_seqlens_q, cu_seqlens_k):
-            raise NotImplementedError("self-attention only: cu_seqlens_q must equal cu_seqlens_k")
+        if cu_seqlens_q.data_ptr() != cu_seqlens_k.data_ptr():
+            # self-attention only.  What the host knows is checked here; the element-wise comparison stays on the device (an asynchronous
+            # assert: no device -> host synchronisation on the step's path, a mismatch surfaces as a device-side assertion)
+            if cu_seqlens_q.shape != cu_seqlens_k.shape or q.shape[0] != kv.shape[0] or int(max_seqlen_q) != int(max_seqlen_k):
+                raise NotImplementedError("self-attention only: cu_seqlens_q must equal cu_seqlens_k")
+            torch._assert_async((cu_seqlens_q == cu_seqlens_k).all())
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         cu = cu_seqlens_q.to(torch.int32)
