@@ -243,7 +243,7 @@ class InternLM2Engine:
         # time by the SwiGLU backward: 2 F bytes per token and layer less HBM traffic in backward (12 F -> 10 F), 2 F T bytes per layer more
         # memory (15 GB for the 7B merged pass).  On when that fits with room to spare; the values are the same bits either way.
         self.a_act = None
-        if not self.batch_wgrad and device.type == "cuda":
+        if not self.batch_wgrad and device.type == "cuda" and os.environ.get("IE_KEEP_ACT", "1") != "0":   # (IE_KEEP_ACT=0: A/B switch)
             lm = self.lmc
             nslot = len(self.a_w13)
             need = 2 * nslot * self.T * lm.ffn_dim
