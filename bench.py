@@ -115,6 +115,8 @@ def main():
                                                        "must divide --gpus; data parallel size = gpus / tp")
     ap.add_argument("--zero", type=int, default=None, help="parallel.zero1.size: ranks that share one copy of the sharded optimizer state "
                                                             "(hybrid ZeRO when smaller than the data-parallel size; default: the whole data-parallel group)")
+    ap.add_argument("--wp", type=int, default=0, help="ISP weight parallelism (parallel.weight = dict(size=wp)): every rank keeps 1/wp of each layer's weights and "
+                                                      "gradients, gathered per layer into a two-slot pool (engine weight_parallel=True); 0 = resident weights")
     ap.add_argument("--scale-on-q", action="store_true", help="A/B only: engine scale_on_q=True (softmax scale folded into the rotary kernel's q, folded-softmax "
                                                                "attention forward; moves a bf16 rounding point away from the reference's -- see engine.py)")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
@@ -174,13 +176,15 @@ def main():
     cfg.train.sp_size = args.sp
     cfg.train.tp_size = args.tp
     cfg.train.pp_size = args.pp
+    cfg.train.wp_size = max(args.wp, 1)
     cfg.train.num_chunks = args.num_chunks if args.pp > 1 else 1
     cfg.model.checkpoint = args.checkpoint
     if args.micro_num:
         cfg.train.micro_num = args.micro_num
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None,
-                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero, scale_on_q=args.scale_on_q)
+                          merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero, scale_on_q=args.scale_on_q,
+                          weight_parallel=True if args.wp else None)
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()
@@ -235,7 +239,7 @@ def main():
         comm_info = {"backend": "gloo, all ranks on ONE GPU, host-staged collectives (IE_BENCH_BACKEND test hook: NOT a measurement)" if staged
                      else torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
     comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
-    if world > 1 and args.tp == 1 and args.pp == 1:
+    if world > 1 and args.tp == 1 and args.pp == 1 and not eng.wp_mode:
         # data-parallel replicas must hold bit-identical parameters after the timed steps (reduce-scatter -> AdamW on the shard -> all-gather):
         # every rank's checksum, gathered; a broken exchange would show here instead of as a plausible-looking throughput
         eng.drain()
@@ -274,7 +278,8 @@ def main():
                    "micro_batch_execution": ("merged: the micro_num micro-batches of a step run as one varlen pass" if eng.mm > 1 else
                                              "sequential gradient accumulation" + (", weight gradients batched over the micro-batches" if eng.batch_wgrad else "")),
                    "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp * args.pp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")
-                   + (f" x pp{args.pp} ({'interleaved ' if args.num_chunks > 1 else ''}1F1B{f', {args.num_chunks} chunks' if args.num_chunks > 1 else ''})" if args.pp > 1 else "")},
+                   + (f" x pp{args.pp} ({'interleaved ' if args.num_chunks > 1 else ''}1F1B{f', {args.num_chunks} chunks' if args.num_chunks > 1 else ''})" if args.pp > 1 else "")
+                   + (f", weight parallel wp{eng.world} (layer weights / gradients sharded, two-slot pool)" if eng.wp_mode else "")},
         "tgs": tgs,
         "tflops_per_gpu_reference_formula": ref_flops_tok * tgs / 1e12,
         "tflops_per_gpu_exact_causal": exact_flops_per_token(mc, tc.seq_len) * tgs / 1e12,
