@@ -31,6 +31,9 @@ class ModelConfig:
     head_dim_override: Optional[int] = None
     ffn_dim_override: Optional[int] = None
     head_vocab_override: Optional[int] = None   # tensor parallelism: vocabulary rows of the head on this rank
+    embed_dim_override: Optional[int] = None    # tensor parallelism with embed_split_hidden: hidden columns of the embedding on this rank
+    embed_split_hidden: bool = False            # model.embed_split_hidden (modules/embedding.py:24-60): under tensor parallelism every rank holds
+                                                # h / tp columns of the embedding and the looked-up rows are all-gathered along the hidden dim
     # init (modeling_internlm2.py:646-672; scaled init for wo / w2)
     init_std: float = 0.02
     use_scaled_init: bool = True
@@ -73,6 +76,11 @@ class ModelConfig:
         """Rows of the output head THIS rank holds: the whole vocabulary, or 1/tp of it under the vocabulary-parallel head."""
         return self.head_vocab_override or self.vocab_size
 
+    @property
+    def embed_dim(self):
+        """Hidden columns of the embedding THIS rank holds."""
+        return self.embed_dim_override or self.hidden_size
+
     def tp_shard(self, tp, vocab_parallel=True):
         """The model one rank of a tensor-parallel group of size tp holds (Megatron "mtp" split, model/ops/linear.py:205-337):
         1/tp of the attention heads (whole kv groups), 1/tp of the FFN width and -- vocab_parallel, the reference's
@@ -86,7 +94,8 @@ class ModelConfig:
             raise ValueError(f"tensor parallel size {tp} must divide the vocabulary size {self.vocab_size}")
         return dataclasses.replace(self, num_attention_heads=self.num_attention_heads // tp, num_kv_attention_heads=self.num_kv_attention_heads // tp,
                                    head_dim_override=self.head_dim, ffn_dim_override=self.ffn_dim // tp,
-                                   head_vocab_override=self.vocab_size // tp if vocab_parallel else None)
+                                   head_vocab_override=self.vocab_size // tp if vocab_parallel else None,
+                                   embed_dim_override=self.hidden_size // tp if self.embed_split_hidden else None)
 
     def num_params(self):
         h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size
@@ -249,7 +258,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
         # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
         adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
-        embed_grad_scale=float(m.get("embed_grad_scale", 1)), norm_head=bool(m.get("norm_head", False)), **moe_kw,
+        embed_grad_scale=float(m.get("embed_grad_scale", 1)), norm_head=bool(m.get("norm_head", False)),
+        embed_split_hidden=bool(m.get("embed_split_hidden", False)) and model_type != "INTERNLM_MoE", **moe_kw,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]

@@ -101,13 +101,14 @@ class InternLM2Engine:
             process_group, world_size, rank = self.pipe.dp_group, self.pipe.dp_world, self.pipe.dp_rank
             self.world, self.rank = world_size, rank
             merge_micro, batch_wgrad = False, False   # the 1F1B schedule works on single micro-batches
-        self.tpar = TensorParallel(tp_size, rank, world_size, vocab_parallel=True if vocab_parallel is None else vocab_parallel)
+        self.tpar = TensorParallel(tp_size, rank, world_size, vocab_parallel=True if vocab_parallel is None else vocab_parallel,
+                                   embed_split=getattr(mc, "embed_split_hidden", False))
+        self.embed_split = self.tpar.embed_split
         self.tp = tp_size
         self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
-        if self.vp and tc.label_smoothing > 0:
-            raise NotImplementedError("label smoothing with the vocabulary-parallel head (its uniform term needs one more reduction): "
-                                      "run with vocab_parallel=False")
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
+        if tp_size > 1 and not self.embed_split and self.lmc.embed_dim != mc.hidden_size:
+            self.lmc = dataclasses.replace(self.lmc, embed_dim_override=None)
         if pp_size > 1:
             self.lmc = dataclasses.replace(self.lmc, num_layers=len(self.gid))
         if tp_size > 1:
@@ -387,6 +388,8 @@ class InternLM2Engine:
         self.t_delta = e(K._L().ie_flash_attn_bwd_workspace(Tg, hql, hkvl, d), dtype=torch.float32)
         self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
         self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
+        if getattr(self, "embed_split", False):
+            self.t_emb_loc = e(T, mc.embed_dim)
         self.scale_view = self.state[:4].view(torch.float32)  # IeStepState.loss_scale, read by the CE backward on device
 
     def _alloc_wgrad_stage(self, want):
@@ -574,7 +577,13 @@ class InternLM2Engine:
         la, lb, is_first, is_last = self._chunk(chunk)
         p = self.p
         self._wait_bucket(0)              # bucket b's AdamW / all-gather of the previous step() may still be running on the optimizer stream
-        if is_first:
+        if is_first and self.embed_split:
+            # Embedding1D under tensor parallelism (modules/embedding.py:52-60): this rank's h / tp columns of the looked-up rows, all-gathered
+            # along the hidden dimension (gather_forward_split_backward)
+            K.embedding_fwd(p["tok_embeddings.weight"], ids, self.t_emb_loc)
+            allc = self.tpar.all_gather(self.t_emb_loc)                                   # [tp, T, h / tp]
+            self.a_x[0].view(self.T, self.tp, -1).copy_(allc.permute(1, 0, 2))
+        elif is_first:
             K.embedding_fwd(p["tok_embeddings.weight"], ids, self.a_x[0])
             if mc.embed_grad_scale != 1.0:   # modeling_internlm2.py:970-973 (the value; the backward scales the gradient)
                 K.grad_scale_mix(self.a_x[0], mc.embed_grad_scale)
@@ -635,9 +644,18 @@ class InternLM2Engine:
         else:
             K.ce_fwd(logits, ll, -100, 0.0, rows, lse, out)
         # rows = local lse - logit[label] where the label is here, else 0  ->  the target logit this rank contributes
-        stats = self.tpar.all_gather(torch.stack([lse, torch.where(here, lse - rows, torch.zeros_like(rows))]))   # [tp, 2, rows]
+        eps = self.tc.label_smoothing
+        mine = [lse, torch.where(here, lse - rows, torch.zeros_like(rows))]
+        if eps > 0:   # the smoothing term needs the mean logit over the WHOLE vocabulary (ce_loss.py:15-36 / flash-attn's smoothed parallel loss): one more statistic
+            mine.append(logits.float().sum(dim=1))
+        stats = self.tpar.all_gather(torch.stack(mine))   # [tp, 2 or 3, rows]
         lse.copy_(torch.logsumexp(stats[:, 0], dim=0))
-        rows.copy_(torch.where(lab != -100, lse - stats[:, 1].sum(dim=0), torch.zeros_like(rows)))
+        nll = torch.where(lab != -100, lse - stats[:, 1].sum(dim=0), torch.zeros_like(rows))
+        if eps > 0:
+            smooth = lse - stats[:, 2].sum(dim=0) / float(Vl * self.tp)
+            rows.copy_(torch.where(lab != -100, (1.0 - eps) * nll + eps * smooth, torch.zeros_like(rows)))
+        else:
+            rows.copy_(nll)
         K.ce_mean(rows, lab, -100, out)
         if metric:
             # first index of the row maximum over the whole vocabulary: the largest local maximum, the lowest rank on ties
@@ -646,8 +664,20 @@ class InternLM2Engine:
             cand = self.tpar.all_gather(torch.stack([top, (am + v0).float()]))                                     # [tp, 2, rows]
             win = cand[:, 0].max(dim=0).indices
             am.copy_(cand[:, 1].gather(0, win.unsqueeze(0)).squeeze(0).to(torch.int32))
-            self.t_nll[r].copy_(rows)
+            self.t_nll[r].copy_(nll)   # (the metric's loss is the plain negative log-likelihood, smoothing or not)
             self.metric.update_fused(self.t_nll[r], am, lab)
+
+    def _vp_smoothing_target_fix(self, dlogits, lab_local, count):
+        """Vocabulary-parallel head with label smoothing: ce_bwd ran with eps / tp, which makes the uniform term right (eps / V over the whole
+        vocabulary) and leaves the target's coefficient at -(1 - eps / tp) where -(1 - eps) is wanted: add eps (1 - 1 / tp) g to the target's
+        element on the rank that owns it, g = loss scale / (valid tokens * micro_num) as in the kernel."""
+        eps = self.tc.label_smoothing
+        if not self.vp or eps <= 0:
+            return
+        own = lab_local >= 0                                  # (-100: ignored, -1: valid but another rank's column)
+        g = self.scale_view * (eps * (1.0 - 1.0 / self.tp) / self.tc.micro_num) / count     # one device scalar: no host synchronisation
+        src = torch.where(own, g, torch.zeros_like(g)).to(dlogits.dtype).unsqueeze(1)
+        dlogits.scatter_add_(1, lab_local.clamp(min=0).unsqueeze(1), src)
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, last_micro, first_micro=False, chunk=None):
         mc, tc = self.lmc, self.tc
@@ -677,13 +707,18 @@ class InternLM2Engine:
             # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
             # forward: a label owned by another rank is valid without a one-hot term here)
             lab_b = self.t_lab_local if self.vp else labels
+            # label smoothing on 1/tp of the vocabulary: the kernel's uniform term eps' / V_local is the full-vocabulary eps / V for eps' = eps / tp
+            # (the target's coefficient is put right below)
+            eps_k = tc.label_smoothing / self.tp if self.vp else tc.label_smoothing
             if self.mm > 1:
                 P = T // self.mm
                 for i in range(self.mm):
                     rs = slice(i * P, (i + 1) * P)
-                    K.ce_bwd(self.t_logits[rs], lab_b[rs], self.t_lse[rs], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+                    K.ce_bwd(self.t_logits[rs], lab_b[rs], self.t_lse[rs], self.scale_view, self.t_loss_seg[i, 1:2], 1.0 / tc.micro_num, -100, eps_k)
+                    self._vp_smoothing_target_fix(self.t_logits[rs], lab_b[rs], self.t_loss_seg[i, 1:2])
             else:
-                K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, tc.label_smoothing)
+                K.ce_bwd(self.t_logits, lab_b, self.t_lse, self.scale_view, self.t_loss[1:2], 1.0 / tc.micro_num, -100, eps_k)
+                self._vp_smoothing_target_fix(self.t_logits, lab_b, self.t_loss[1:2])
             dlog = self.t_logits
 
             K.linear_dgrad(dlog, self.t_head_w if self.head_fn else p["output.weight"], self.t_h0)
@@ -768,6 +803,9 @@ class InternLM2Engine:
             return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
         if mc.embed_grad_scale != 1.0:
             K.scale_bf16(d_out, mc.embed_grad_scale)   # d(s x + (1 - s) x.detach()) / dx = s
+        if self.embed_split:   # ... split backward: this rank's columns of the gradient
+            self.t_emb_loc.copy_(d_out.view(T, self.tp, -1)[:, self.tpar.tp_rank])
+            d_out = self.t_emb_loc
         K.embedding_bwd(d_out, ids, g["tok_embeddings.weight"], acc, self.t_emb_ws)
         if last_micro:
             self._reduce_bucket(0)
@@ -1094,7 +1132,7 @@ class InternLM2Engine:
         L = self.layout
         out = []
         for spec in L.params.values():
-            if spec.kind not in ("embed", "norm", "head") or (spec.kind == "head" and self.vp):
+            if spec.kind not in ("embed", "norm", "head") or (spec.kind == "head" and self.vp) or (spec.kind == "embed" and self.embed_split):
                 continue
             b = L.buckets[spec.bucket]
             s0, n0 = b.shard(self.rank, self.world)
@@ -1294,7 +1332,8 @@ class InternLM2Engine:
 
         out = self._to_reference_names(named)
         if self.tp > 1:
-            for n in ("tok_embeddings.weight",) if self.vp else ("tok_embeddings.weight", "output.weight"):
+            whole = ([] if self.embed_split else ["tok_embeddings.weight"]) + ([] if self.vp else ["output.weight"])
+            for n in whole:   # (what this engine keeps whole is cut the reference's way for its files; what it holds cut already is written as is)
                 if n in out:
                     out[n] = C.tp_shard(n, out[n], self.tpar.tp_rank, self.tp)
         return out

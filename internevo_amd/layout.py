@@ -86,7 +86,7 @@ class FlatLayout:
 
         cur = open_bucket()
         if first:
-            add(cur, "tok_embeddings.weight", (v, h), "embed")
+            add(cur, "tok_embeddings.weight", (v, getattr(c, "embed_dim", h)), "embed")   # all hidden columns, or this tensor rank's h / tp (embed_split_hidden)
         close_bucket(cur)
         layer_ids = list(layer_lo) if isinstance(layer_lo, (list, tuple)) else list(range(layer_lo, layer_lo + c.num_layers))
         assert len(layer_ids) == c.num_layers

@@ -15,9 +15,9 @@ V/tp rows of the head and computes [T, V/tp] logits; the cross-entropy runs on t
 (labels another rank owns become "valid, not here"), and ONE all-gather of two floats per token (local log-sum-exp, local target
 logit) replaces flash-attn's three all-reduces (max, sum-exp, target); the backward uses the global log-sum-exp, and the head's
 input gradient is summed over the group under its weight gradient.  `vocab_parallel=False` keeps the whole head on every rank
-(logits computed redundantly).  The embedding is kept whole on every rank in both modes (the reference splits its hidden
-dimension and all-gathers the activations, modules/embedding.py:52-60): 0.76 GB of 288, no exchange; losses and gradients are
-the same numbers.
+(logits computed redundantly).  The embedding: whole on every rank (0.76 GB of 288, no exchange) unless `model.embed_split_hidden` asks for the reference's
+layout (modules/embedding.py:24-60: every rank holds h / tp columns, the looked-up rows are all-gathered along the hidden dimension, the
+backward keeps its own columns of the gradient); losses and gradients are the same numbers.
 """
 import torch
 import torch.distributed as dist
@@ -26,11 +26,12 @@ from .comm import DONE, backend_for
 
 
 class TensorParallel:
-    def __init__(self, tp_size, rank, world_size, vocab_parallel=True):
+    def __init__(self, tp_size, rank, world_size, vocab_parallel=True, embed_split=False):
         if world_size % tp_size != 0:
             raise ValueError(f"world size {world_size} is not a multiple of the tensor-parallel size {tp_size}")
         self.tp = tp_size
         self.vocab_parallel = bool(vocab_parallel) and tp_size > 1
+        self.embed_split = bool(embed_split) and tp_size > 1   # model.embed_split_hidden: the embedding cut along the hidden dim
         self.tp_rank = rank % tp_size
         self.dp_rank = rank // tp_size
         self.dp_world = world_size // tp_size
@@ -84,18 +85,18 @@ class TensorParallel:
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
-        if self.tp == 1 or kind in ("embed", "norm") or (kind == "head" and not self.vocab_parallel):
+        if self.tp == 1 or kind == "norm" or (kind == "embed" and not self.embed_split) or (kind == "head" and not self.vocab_parallel):
             return full
         r, tp = self.tp_rank, self.tp
         if kind in ("wqkv", "w1", "w3", "head"):  # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups; head: vocabulary rows)
             n = full.shape[0] // tp
             return full[r * n : (r + 1) * n]
-        n = full.shape[1] // tp               # row-parallel (wo, w2): input columns
+        n = full.shape[1] // tp               # row-parallel (wo, w2): input columns; the hidden-split embedding: hidden columns
         return full[:, r * n : (r + 1) * n]
 
     @staticmethod
-    def unshard(kind, parts, vocab_parallel=True):
+    def unshard(kind, parts, vocab_parallel=True, embed_split=False):
         """Inverse of shard() given every rank's part in rank order."""
-        if kind in ("embed", "norm") or (kind == "head" and not vocab_parallel) or len(parts) == 1:
+        if kind == "norm" or (kind == "embed" and not embed_split) or (kind == "head" and not vocab_parallel) or len(parts) == 1:
             return parts[0]
         return torch.cat(parts, dim=0 if kind in ("wqkv", "w1", "w3", "head") else 1)

@@ -451,7 +451,13 @@ def test_sequence_parallel_step_equals_single_rank_step(dev, backend):
     assert worst <= 6e-3
 
 
-def _tp_worker(rank, world, port, q, folder=None, vp=True):
+def _tp_cfg(es):
+    cfg = _cfg(2)
+    cfg.model.embed_split_hidden = bool(es)   # model.embed_split_hidden: the embedding cut along the hidden dim under tensor parallelism
+    return cfg
+
+
+def _tp_worker(rank, world, port, q, folder=None, vp=True, es=False):
     import torch.distributed as dist
 
     dev = _init_dist(rank, world, port)
@@ -462,8 +468,9 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True):
 
         from internevo_amd.metrics import AccPerplex
 
-        eng = InternLM2Engine(_cfg(2), dev, None, world, rank, init_fn=formula_init, tp_size=2, vocab_parallel=vp)
+        eng = InternLM2Engine(_tp_cfg(es), dev, None, world, rank, init_fn=formula_init, tp_size=2, vocab_parallel=vp)
         assert eng.p["output.weight"].shape[0] == (_cfg(2).model.vocab_size // 2 if vp else _cfg(2).model.vocab_size)
+        assert eng.p["tok_embeddings.weight"].shape[1] == (_cfg(2).model.hidden_size // 2 if es else _cfg(2).model.hidden_size)
         metric = AccPerplex(dev, None, None)
         eng.attach_metric(metric)
         loader = iter(SyntheticLoader(128, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
@@ -479,7 +486,7 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True):
         ck = None
         if folder is not None:  # checkpoint round trip on the tensor-parallel ranks: one model + optimizer + plan file per tensor rank
             eng.save_checkpoint(folder)
-            fresh = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, vocab_parallel=vp)
+            fresh = InternLM2Engine(_tp_cfg(es), dev, None, world, rank, tp_size=2, vocab_parallel=vp)
             fresh.load_checkpoint(folder)
             same = all(torch.equal(a, b) for a, b in ((eng.master, fresh.master), (eng.exp_avg, fresh.exp_avg), (eng.exp_avg_sq, fresh.exp_avg_sq)))
             same = same and all(torch.equal(eng.p[n], fresh.p[n]) for n in eng.p)
@@ -491,7 +498,7 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True):
                 nxt.append((float(loss), float(e.read_state().grad_norm)))
             ck = (bool(same), nxt, bool(torch.equal(eng.params, fresh.params)))
         # the DEFAULT initialisation (what train.py uses): every tensor rank must hold its own cut of one full model
-        dflt = InternLM2Engine(_cfg(2), dev, None, world, rank, tp_size=2, seed=77, vocab_parallel=vp)
+        dflt = InternLM2Engine(_tp_cfg(es), dev, None, world, rank, tp_size=2, seed=77, vocab_parallel=vp)
         init_shards = {n: p.float().cpu().numpy() for n, p in dflt.p.items()}
         q.put((rank, out, shards, ck, init_shards))
     finally:
@@ -499,13 +506,14 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("vp", [True, False], ids=["vocab_parallel_head", "whole_head"])
-def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp):
+@pytest.mark.parametrize("vp,es", [(True, False), (False, False), (True, True)], ids=["vocab_parallel_head", "whole_head", "hidden_split_embedding"])
+def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp, es):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
     same micro-batches: same loss, same grad norm (replicated parameters counted once), same AccPerplex metric, and the two ranks'
     parameter shards concatenate to the single-rank parameters (bf16 summation-order noise only).  vp: the output head split by
     vocabulary rows with the vocabulary-parallel loss (the reference's parallel_output=True, ops/linear.py:124-153 +
-    losses/ce_loss.py:26-36; default) or kept whole on both ranks."""
+    losses/ce_loss.py:26-36; default) or kept whole on both ranks.  es: model.embed_split_hidden -- the embedding cut along the hidden dimension,
+    looked-up rows all-gathered in forward, the gradient split in backward (modules/embedding.py:24-60) -- instead of whole on both ranks."""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from internevo_amd.tensorpar import TensorParallel
@@ -514,7 +522,7 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     folder = str(tmp_path / "ck_tp2")
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29853 if vp else 29857, q, folder, vp)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, (29853 if vp else 29857) + 2 * es, q, folder, vp, es)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
@@ -535,8 +543,8 @@ def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp
     want_metric = metric.get_metric()
     (r0, o0, s0, c0, i0), (r1, o1, s1, c1, i1) = res
     m0, m1 = o0.pop(), o1.pop()
-    replicated = ("embed", "norm") if vp else ("embed", "norm", "head")
-    unshard = lambda kind, parts: TensorParallel.unshard(kind, parts, vp)  # noqa: E731
+    replicated = ("norm",) + (() if es else ("embed",)) + (() if vp else ("head",))
+    unshard = lambda kind, parts: TensorParallel.unshard(kind, parts, vp, es)  # noqa: E731
     # the metric of the three steps: identical on both tensor ranks, and the single-rank metric up to bf16 noise in the logits
     assert m0 == m1, (m0, m1)
     for key, w in want_metric.items():   # acc counts arg-max hits over 768 tokens: a near-tie flipped by bf16 noise moves it by 1.3e-3

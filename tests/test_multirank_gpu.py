@@ -347,3 +347,78 @@ def test_weight_parallel_pool_on_one_rank_is_bit_identical(dev):
         else:   # accumulation in the bf16 shard after each micro-batch instead of inside the weight-gradient epilogue: same sums, one more rounding
             assert all(abs(x - y) <= 1e-3 * abs(x) for x, y in zip(la, lb)) and abs(ga - gb) <= 1e-2 * ga
             assert max(float((pa[n] - pb[n]).abs().max()) for n in pa) <= 6e-3
+
+
+# ---------------------------------------------------------------------------------------------------- label smoothing, vocabulary-parallel loss
+def _ls_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from internevo_amd.metrics import AccPerplex
+        from oracle.model import formula_init
+
+        cfg = _sp_cfg(4, 2, 2)
+        cfg.train.label_smoothing = 0.1
+        eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, tp_size=2, vocab_parallel=True)
+        metric = AccPerplex(dev, None, None)
+        eng.attach_metric(metric)
+        loader = iter(SyntheticLoader(256, 1, 2, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        q.put((rank, out, metric.get_metric()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_label_smoothing_under_the_vocabulary_parallel_loss(dev, backend):  # noqa: F811
+    """loss.label_smoothing = 0.1 with the head split over two tensor ranks (the reference: flash-attn's vocabulary-parallel CrossEntropyLoss
+    with label_smoothing, losses/ce_loss.py:15-36): the uniform term needs the mean logit over the WHOLE vocabulary (one more gathered
+    statistic), the backward runs the fused kernel with eps / tp and puts the target's coefficient right.  Against one rank with the whole
+    vocabulary (same kernels, smoothing inside them) and, step 0, against the CPU oracle; the metric's loss stays the unsmoothed NLL."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from oracle.model import formula_init
+    from oracle.step import OracleTrainer
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ls_worker, args=(r, 2, 29781, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    cfg = _sp_cfg(4, 2, 2)
+    cfg.train.label_smoothing = 0.1
+    eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+    metric = AccPerplex(dev, None, None)
+    eng.attach_metric(metric)
+    ora = OracleTrainer(cfg, torch.bfloat16)
+    loader = iter(SyntheticLoader(256, 1, 2, False, 4000))
+    for k in range(3):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        one = (float(loss), float(eng.read_state().grad_norm))
+        (l0, g0), (l1, g1) = res[0][1][k], res[1][1][k]
+        print(f"step {k}: tp2 vocabulary-parallel {l0:.5f} / {g0:.4f} | one rank {one[0]:.5f} / {one[1]:.4f}")
+        assert (l0, g0) == (l1, g1)
+        assert abs(l0 - one[0]) <= 1e-3 * one[0] and abs(g0 - one[1]) <= 2e-2 * one[1]
+        if k == 0:
+            ref = ora.train_step(batch, labels)
+            print(f"        oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
+            assert abs(l0 - ref["loss"]) <= 1e-3 * ref["loss"] and abs(g0 - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+    m1 = metric.get_metric()
+    assert res[0][2] == res[1][2]
+    for key, w in m1.items():
+        assert abs(res[0][2][key] - w) <= (5e-3 if key == "acc" else 2e-2 * abs(w)), (key, res[0][2][key], w)
+    assert m1["loss_from_metric"] < float(loss) + 1.0   # (the metric carries the plain NLL)
