@@ -85,7 +85,7 @@ class TensorParallel:
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
-        if self.tp == 1 or kind == "norm" or (kind == "embed" and not self.embed_split) or (kind == "head" and not self.vocab_parallel):
+        if self.tp == 1 or kind == "norm" or (kind == "embed" and not getattr(self, "embed_split", False)) or (kind == "head" and not self.vocab_parallel):
             return full
         r, tp = self.tp_rank, self.tp
         if kind in ("wqkv", "w1", "w3", "head"):  # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups; head: vocabulary rows)
