@@ -189,15 +189,22 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: parallel.weight.size > 1 outside tensor mode 'isp'")
     if pp_size > 1 and (sp_size > 1 or tp_size > 1):
         raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallelism together with tensor / sequence parallelism")
-    model_type = cfg.get("model_type", "INTERNLM2_PUBLIC")
-    if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE"):
+    model_type = cfg.get("model_type", "INTERNLM")   # the reference's default (initialize/launch.py:78-79)
+    if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE", "INTERNLM"):
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")
     moe_kw = {}
-    if model_type == "INTERNLM_MoE":
+    if model_type == "INTERNLM" or (model_type == "INTERNLM_MoE" and m.get("num_experts", 1) <= 1):
+        # the dense InternLM-1 model (modeling_internlm.py, configs/7B_sft.py; INTERNLM_MoE with one expert builds the same block): MoEEngine's
+        # dense branch -- data parallelism only
+        if sp_size > 1 or tp_size > 1 or pp_size > 1:
+            raise NotImplementedError(f"{_UNSUPPORTED}: the InternLM-1 family with tensor / sequence / pipeline parallelism (data parallelism only)")
+        if not m.get("use_swiglu", True) or m.get("residual_in_fp32", False) or m.get("num_kv_attention_heads", m["num_attention_heads"]) != m["num_attention_heads"]:
+            raise NotImplementedError(f"{_UNSUPPORTED}: InternLM-1 with use_swiglu=False / residual_in_fp32 / grouped-query attention")
+        moe_kw = dict(num_experts=1)
+        model_type = "INTERNLM"
+    elif model_type == "INTERNLM_MoE":
         # configs/7B_MoE4_sft.py: GShard top-2 MoE in every block (internevo_amd/moe_engine.py)
         moe = cfg.get("moe", {}) or {}
-        if m.get("num_experts", 1) <= 1:
-            raise NotImplementedError(f"{_UNSUPPORTED}: model_type INTERNLM_MoE with num_experts <= 1 (the dense InternLM-1 model)")
         if m.get("moe_type", "GShard") != "GShard":
             raise NotImplementedError(f"{_UNSUPPORTED}: model.moe_type {m.get('moe_type')!r} (GShard only)")
         if m.get("moe_use_residual", False):
@@ -218,7 +225,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     ck = 1.0 if ck is True else 0.0 if ck is False else float(ck)
     if not 0.0 <= ck <= 1.0:
         raise ValueError(f'model.checkpoint: "{ck}" should >=0 and <=1')  # launch.py:300-303
-    if not m.get("no_bias", True) and model_type != "INTERNLM_MoE":   # (the InternLM-1 block of INTERNLM_MoE always has attention biases)
+    if not m.get("no_bias", True) and model_type not in ("INTERNLM_MoE", "INTERNLM"):   # (the InternLM-1 block always has attention biases)
         raise NotImplementedError(f"{_UNSUPPORTED}: linear bias")
     # settings that change the arithmetic of the step: refuse them instead of training something else than the config describes
     if cfg.get("use_fp32_norm", False):
@@ -259,7 +266,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
         adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
         embed_grad_scale=float(m.get("embed_grad_scale", 1)), norm_head=bool(m.get("norm_head", False)),
-        embed_split_hidden=bool(m.get("embed_split_hidden", False)) and model_type != "INTERNLM_MoE", **moe_kw,
+        embed_split_hidden=bool(m.get("embed_split_hidden", False)) and model_type not in ("INTERNLM_MoE", "INTERNLM"), **moe_kw,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]

@@ -51,8 +51,11 @@ class MoEEngine:
         run (layer-major inside a micro-batch); None = generated on the device from (seed, layer, call)."""
         self.cfg, self.mc, self.tc = cfg, cfg.model, cfg.train
         mc, tc = self.mc, self.tc
-        if mc.model_type != "INTERNLM_MoE" or mc.num_experts < 2:
-            raise ValueError("MoEEngine runs model_type INTERNLM_MoE with num_experts > 1")
+        if mc.model_type not in ("INTERNLM_MoE", "INTERNLM"):
+            raise ValueError("MoEEngine runs the InternLM-1 families: model_type INTERNLM_MoE, or the dense INTERNLM model")
+        # dense: the InternLM-1 model proper (modeling_internlm.py; INTERNLM_MoE with num_experts = 1 builds the same block, modeling_moe.py:120-140):
+        # a plain SwiGLU FeedForward in place of the MoE -- no gate, no auxiliary loss, one optimizer group
+        self.dense = mc.model_type == "INTERNLM" or mc.num_experts < 2
         if mc.num_kv_attention_heads != mc.num_attention_heads:
             raise NotImplementedError("the InternLM-1 block has no grouped-query attention")
         K._L()
@@ -64,9 +67,9 @@ class MoEEngine:
         # Expert parallelism as the reference sets it up (parallel_context.py:538-541: ep = min(data-parallel size, num_experts); expert groups =
         # ep CONSECUTIVE data-parallel ranks, expert-data groups = the ranks with the same position in their expert group): every rank holds
         # E / ep experts, its tokens visit the others through the all_to_all of the dispatch buffers (moe.MoELayer).
-        E_ = mc.num_experts
+        E_ = max(mc.num_experts, 1)
         self.ep, self.ep_rank, self.ep_group, self.edp_group = 1, 0, None, None
-        if world_size > 1:
+        if world_size > 1 and not self.dense:
             if process_group is not None:
                 raise NotImplementedError("MoEEngine runs over the default group (pure data parallelism + expert parallelism)")
             ep = min(world_size, E_)
@@ -87,7 +90,7 @@ class MoEEngine:
         self.groups = ("0_default", "1_fp32", f"2_moe_ep_size_{self.ep}")   # the optimizer groups' names (train/utils.py:25-80)
         self.noise_fn, self.calls = noise_fn, 0
         self.keep_routes = None   # set to [] to record (expert choices, gate logits) of every micro-batch and layer
-        h, F, V, L, E = mc.hidden_size, ffn_dim(mc), mc.vocab_size, mc.num_layers, mc.num_experts
+        h, F, V, L, E = mc.hidden_size, ffn_dim(mc), mc.vocab_size, mc.num_layers, E_
         self.F = F
         H, d = mc.num_attention_heads, mc.head_dim
         if d not in (64, 128):
@@ -117,7 +120,7 @@ class MoEEngine:
         # slices of the flat buffer by optimizer group (contiguous runs: experts of a layer vs everything else)
         self.runs = {0: [], 2: []}
         for n, (o, s) in self.spec.items():
-            g = 2 if n.endswith(("mlp.w13", "mlp.w2")) else 0
+            g = 2 if n.endswith(("mlp.w13", "mlp.w2")) and not self.dense else 0
             numel = (math.prod(s) + 7) // 8 * 8
             if self.runs[g] and self.runs[g][-1][1] == o:   # adjacent parameters of one group: one launch
                 self.runs[g][-1] = (self.runs[g][-1][0], o + numel)
@@ -159,8 +162,13 @@ class MoEEngine:
         self.a_q, self.a_kv, self.a_ctx = [e(T, H, d) for _ in range(L)], [e(T, 2, H, d) for _ in range(L)], [e(T, H, d) for _ in range(L)]
         self.a_lse = [e(H, T, dtype=torch.float32) for _ in range(L)]
         self.a_r2, self.a_n2, self.a_rstd2 = [e(T, h) for _ in range(L)], [e(T, h) for _ in range(L)], [e(T, dtype=torch.float32) for _ in range(L)]
-        self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * rank, layer_index=l, ep_group=self.ep_group,
-                             ep_size=self.ep, ep_rank=self.ep_rank) for l in range(L)]   # (every rank gates its own tokens with its own noise)
+        if self.dense:
+            self.moe = None
+            self.a_h13 = [e(T, 2 * F) for _ in range(L)]
+            self.t_act, self.t_dact, self.t_dh13 = e(T, F), e(T, F), e(T, 2 * F)
+        else:
+            self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * rank, layer_index=l, ep_group=self.ep_group,
+                                 ep_size=self.ep, ep_rank=self.ep_rank) for l in range(L)]   # (every rank gates its own tokens with its own noise)
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
         self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * h), e(T, h), e(T, h), e(T, h)
         self.t_dq, self.t_dkv = e(T, H, d), e(T, 2, H, d)
@@ -176,13 +184,16 @@ class MoEEngine:
     # ------------------------------------------------------------------------------------------ parameters
     def reference_param_shapes(self):
         mc, out = self.mc, {}
-        h, F, V, E = mc.hidden_size, self.F, mc.vocab_size, mc.num_experts
+        h, F, V, E = mc.hidden_size, self.F, mc.vocab_size, max(mc.num_experts, 1)
         out["embedding.weight"] = (V, h)
         for l in range(mc.num_layers):
             p = f"blocks.{l}."
             out[p + "mixer.Wqkv.weight"], out[p + "mixer.Wqkv.bias"] = (3 * h, h), (3 * h,)
             out[p + "mixer.out_proj.weight"], out[p + "mixer.out_proj.bias"] = (h, h), (h,)
             out[p + "norm1.weight"], out[p + "norm2.weight"] = (h,), (h,)
+            if self.dense:
+                out[p + "mlp.w1.weight"], out[p + "mlp.w2.weight"], out[p + "mlp.w3.weight"] = (F, h), (h, F), (F, h)
+                continue
             out[p + "mlp.moe_layer.gate.wg.weight"] = (E, h)
             for e_ in range(E):
                 q = p + f"mlp.moe_layer.experts.wrapped_experts.{e_}."
@@ -218,6 +229,12 @@ class MoEEngine:
                     self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
             elif "mixer.Wqkv" in n:
                 self.p[n].copy_(self._qkv_to_engine(t))
+            elif self.dense and ".mlp.w" in n:   # blocks.{l}.mlp.w1 / w2 / w3.weight -> the fused [1, 2F, h] / [1, h, F] tensors
+                l, w = int(n.split(".")[1]), n.split(".")[3]
+                if w == "w2":
+                    self.p[f"blocks.{l}.mlp.w2"][0].copy_(t)
+                else:
+                    self.p[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
             else:
                 self.p[n].copy_(t)
         if sync_master:
@@ -238,6 +255,9 @@ class MoEEngine:
                 out[n] = self.p[f"blocks.{l}.mlp.w2"][e_] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
             elif "mixer.Wqkv" in n:
                 out[n] = self._qkv_to_reference(self.p[n])
+            elif self.dense and ".mlp.w" in n:
+                l, w = int(n.split(".")[1]), n.split(".")[3]
+                out[n] = self.p[f"blocks.{l}.mlp.w2"][0] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
             else:
                 out[n] = self.p[n]
         return out.items()
@@ -295,6 +315,12 @@ class MoEEngine:
             self._bias_add(self.t_h0, p[pre + "mixer.out_proj.bias"])
             K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "norm2.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
             moe_out = self.t_h1
+            if self.dense:   # FeedForward (modules/mlp.py:82-86): w2(silu(w1 x) * w3 x), w1 | w3 as one GEMM
+                F_ = self.F
+                K.linear_fwd(self.a_n2[l], p[pre + "mlp.w13"][0], self.a_h13[l])
+                K.swiglu_fwd(self.a_h13[l][:, :F_], self.a_h13[l][:, F_:], self.t_act)
+                K.linear_fwd(self.t_act, p[pre + "mlp.w2"][0], moe_out)
+                continue
             self.l_aux.append(self.moe[l].forward(self.a_n2[l], self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], moe_out, noise=self._noise(self.T, mc.num_experts)).clone())
         self._wait_runs(self._head_runs)
         K.add_rmsnorm_fwd(moe_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
@@ -315,8 +341,16 @@ class MoEEngine:
         for l in range(L - 1, -1, -1):
             pre = f"blocks.{l}."
             d_n2 = spare[0]
-            self.moe[l].backward(d_h, self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], d_n2, self.d_wg[l], g[pre + "mlp.w13"], g[pre + "mlp.w2"],
-                                 accumulate=acc, loss_scale_dev=self.scale_view, aux_factor=mc.moe_loss_coeff * inv_m)
+            if self.dense:
+                F_ = self.F
+                K.linear_dgrad(d_h, p[pre + "mlp.w2"][0], self.t_dact)
+                K.swiglu_bwd(self.t_dact, self.a_h13[l][:, :F_], self.a_h13[l][:, F_:], self.t_dh13[:, :F_], self.t_dh13[:, F_:], self.t_act)
+                K.linear_wgrad(d_h, self.t_act, g[pre + "mlp.w2"][0], acc)
+                K.linear_dgrad(self.t_dh13, p[pre + "mlp.w13"][0], d_n2)
+                K.linear_wgrad(self.t_dh13, self.a_n2[l], g[pre + "mlp.w13"][0], acc)
+            else:
+                self.moe[l].backward(d_h, self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], d_n2, self.d_wg[l], g[pre + "mlp.w13"], g[pre + "mlp.w2"],
+                                     accumulate=acc, loss_scale_dev=self.scale_view, aux_factor=mc.moe_loss_coeff * inv_m)
             d_r2 = spare[1]
             K.rmsnorm_bwd(d_n2, self.a_r2[l], p[pre + "norm2.weight"], self.a_rstd2[l], d_h, g[pre + "norm2.weight"], acc, ws, d_r2)
             self._bias_grad(d_r2, g[pre + "mixer.out_proj.bias"], self.t_bias1, acc)
@@ -371,6 +405,10 @@ class MoEEngine:
             max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())
             cu = cu_h.to(self.dev, non_blocking=True)
             self._forward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen)
+            if self.dense:   # no auxiliary loss
+                self.loss_acc.add_(self.t_loss[0:1] / M)
+                self._backward_micro(ids_d[i], lab_d[i], cu, pos_d[i], max_seqlen, i > 0, 1.0 / M)
+                continue
             if self.keep_routes is not None:   # diagnostics / parity tests: the discrete decisions of this micro-batch, layer by layer
                 self.keep_routes.append([(m.expert.clone(), m.logits.clone()) for m in self.moe])
             # moe loss: sum of the layers' l_aux (model-dtype scalars) * coeff / micro_num, in the model dtype (no_pipeline_scheduler.py:134-145)
@@ -421,7 +459,10 @@ class MoEEngine:
             self._all_reduce(self.grads[a:b], self.edp_group, self.world // self.ep)
         K.sumsq([self.grads[a:b] for a, b in self.runs[0]], self.sumsq[0:1])
         K.sumsq(self.d_wg, self.sumsq[1:2])
-        K.sumsq([self.grads[a:b] for a, b in self.runs[2]], self.sumsq[2:3])
+        if self.runs[2]:
+            K.sumsq([self.grads[a:b] for a, b in self.runs[2]], self.sumsq[2:3])
+        else:
+            self.sumsq[2:3].zero_()   # (the dense model has no expert group)
         if self.ep > 1:   # the moe group's squared norm: local sum of squares / dp, summed over the expert group (solver/optimizer/utils.py:362-368)
             self.sumsq[2:3].div_(self.world)
             self._all_reduce(self.sumsq[2:3], self.ep_group, self.ep, avg=False)
@@ -440,7 +481,8 @@ class MoEEngine:
         self.opt_stream.wait_stream(torch.cuda.current_stream())
         events = {}
         with torch.cuda.stream(self.opt_stream):
-            adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
+            if not self.dense:
+                adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
             events["gate"] = torch.cuda.Event()
             events["gate"].record(self.opt_stream)
             for a, b, grp in sorted((a, b, grp) for grp in (0, 2) for a, b in self.runs[grp]):

@@ -1,5 +1,6 @@
-"""TEST INFRASTRUCTURE -- CPU oracle of the INTERNLM_MoE model family (BASELINE configs[4], configs/7B_MoE4_sft.py) and of its training
-step.  Restates in plain torch:
+"""TEST INFRASTRUCTURE -- CPU oracle of the InternLM-1 model families -- INTERNLM_MoE (BASELINE configs[4], configs/7B_MoE4_sft.py) and, with
+num_experts = 1, the dense INTERNLM model (modeling_internlm.py, configs/7B_sft.py: the same block with a plain SwiGLU FeedForward) -- and of
+their training step.  Restates in plain torch:
   PackedFlashInternLm1D / PackedFlashBaseLayer1D         internlm/model/modeling_moe.py:33-257,262-444 (embedding -> blocks -> norm -> head;
       block = norm1 -> MHA -> residual -> norm2 -> MoE -> residual, norms fed the fp32-cast residual)
   MHA (InternLM-1 attention: packed Wqkv "(three h d)" with bias, NeoX rotary on q / k, out_proj with bias)
@@ -36,6 +37,9 @@ def param_shapes(mc):
         out[p + "mixer.Wqkv.weight"], out[p + "mixer.Wqkv.bias"] = (3 * h, h), (3 * h,)
         out[p + "mixer.out_proj.weight"], out[p + "mixer.out_proj.bias"] = (h, h), (h,)
         out[p + "norm1.weight"], out[p + "norm2.weight"] = (h,), (h,)
+        if E <= 1:   # the dense InternLM-1 model (modeling_internlm.py:118-131; modeling_moe.py with num_experts = 1): a plain SwiGLU FeedForward
+            out[p + "mlp.w1.weight"], out[p + "mlp.w2.weight"], out[p + "mlp.w3.weight"] = (f, h), (h, f), (f, h)
+            continue
         out[p + "mlp.moe_layer.gate.wg.weight"] = (E, h)
         for e in range(E):
             q = p + f"mlp.moe_layer.experts.wrapped_experts.{e}."
@@ -81,6 +85,10 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
         attn = F.linear(ctx.reshape(S, -1), p[pre + "mixer.out_proj.weight"], p[pre + "mixer.out_proj.bias"])
         residual = attn + residual
         x = O.rms_norm(residual.float(), p[pre + "norm2.weight"], mc.layer_norm_epsilon)
+        if E <= 1:   # FeedForward.forward (modules/mlp.py:82-86): w2(silu(w1 x) * w3 x)
+            y = F.linear(O.swiglu(F.linear(x, p[pre + "mlp.w1.weight"]), F.linear(x, p[pre + "mlp.w3.weight"])), p[pre + "mlp.w2.weight"])
+            h = y + residual
+            continue
         ex = pre + "mlp.moe_layer.experts.wrapped_experts."
         w1 = torch.stack([p[ex + f"{e}.w1.weight"] for e in range(E)])
         w3 = torch.stack([p[ex + f"{e}.w3.weight"] for e in range(E)])
@@ -145,11 +153,14 @@ class OracleMoETrainer(OracleTrainer):
             self.routes.append([])
             logits, l_auxes = forward_logits(self.params, mc, batch["input_ids"][i], self._noise(S), idx, cu, self.routes[-1], None if forced is None else forced[i])
             loss = O.cross_entropy(logits, labels[i], tc.label_smoothing)
-            moe_loss = sum(l_auxes) * mc.moe_loss_coeff        # model-dtype tensors (the gate's outputs are cast back to it)
-            moe_loss = moe_loss / M
-            loss = loss / M + moe_loss
+            if l_auxes:
+                moe_loss = sum(l_auxes) * mc.moe_loss_coeff        # model-dtype tensors (the gate's outputs are cast back to it)
+                moe_loss = moe_loss / M
+                loss = loss / M + moe_loss
+                moe_total += float(moe_loss.detach())
+            else:                                                  # the dense InternLM-1 model: no auxiliary loss
+                loss = loss / M
             total += float(loss.detach())
-            moe_total += float(moe_loss.detach())
             (self.scaler.scale * loss).backward()
         return total, moe_total
 

@@ -192,6 +192,11 @@ def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, laye
         cfg["model"]["num_chunks"] = chunks
     if embed_grad_scale != 1 or norm_head:   # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) + the embedding's gradient scale (modeling_internlm2.py:970-973)
         cfg["model"].update(embed_grad_scale=embed_grad_scale, norm_head=norm_head)
+    if model_type == "INTERNLM":   # the dense InternLM-1 model (modeling_internlm.py; configs/7B_sft.py): MHA with biases, no GQA, SwiGLU FeedForward
+        m = cfg["model"]
+        for k in ("num_kv_attention_heads", "no_bias"):
+            m.pop(k, None)
+        m.update(mlp_ratio=8 / 3)
     if model_type == "INTERNLM_MoE":   # configs/7B_MoE4_sft.py: the InternLM-1 block (MHA with biases) + a GShard MoE in place of every MLP
         m = cfg["model"]
         for k in ("num_kv_attention_heads", "no_bias"):
@@ -331,6 +336,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     from internlm.core.trainer import TrainState
 
     from oracle.model import formula_init  # closed-form weights shared with the oracle / HIP engine
+    if cfg_kw.get("model_type") == "INTERNLM":
+        from oracle.model import moe_formula_init as formula_init  # noqa: F811  (biases are small normal numbers, not norm gains)
     if cfg_kw.get("model_type") == "INTERNLM_MoE":
         import internlm.model.moe.gshard_layer as gl
         from oracle.model import moe_formula_init as formula_init  # noqa: F811
@@ -780,6 +787,9 @@ RUNS = {
     # BASELINE.json configs[2]'s model family (configs/7B_llama2.py: model_type LLAMA2 = separate wq / wk / wv, adapt_hf False)
     "llama_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
     "llama_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="LLAMA2")),
+    # the dense InternLM-1 family (model_type INTERNLM: every published reference number, configs/7B_sft.py)
+    "v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="INTERNLM")),
+    "v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, model_type="INTERNLM")),
     # the single-rank twin of the pipeline runs pp2_* / pp2i_* below (4 layers, 4 micro-batches)
     "pin4_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6)),
     "pin4_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6)),

@@ -272,8 +272,15 @@ def test_shipped_reference_configs_map():
     assert (a.model.model_type, a.model.vocab_size, a.model.num_kv_attention_heads, a.train.micro_num, a.model.adapt_hf) == ("INTERNLM2_PUBLIC", 92544, 8, 4, True)
     b = load_reference_config("/root/reference/configs/7B_llama2.py")
     assert (b.model.model_type, b.model.vocab_size, b.model.num_kv_attention_heads, b.model.adapt_hf, b.train.sp_size) == ("LLAMA2", 32000, 8, False, 1)
-    c = load_reference_config("/root/reference/configs/7B_isp_sft.py")
-    assert c.train.sp_size == 2
+    # a config without `model_type` is the dense InternLM-1 model (initialize/launch.py:78-79): configs/7B_sft.py loads as that family,
+    # configs/7B_isp_sft.py (the same model under tensor mode "isp", size 2) is refused instead of being trained as InternLM2
+    c = load_reference_config("/root/reference/configs/7B_sft.py")
+    assert (c.model.model_type, c.model.num_experts, c.model.num_kv_attention_heads, c.model.vocab_size) == ("INTERNLM", 1, 32, 103168)
+    from internevo_amd.moe_engine import ffn_dim as dense_ffn
+
+    assert dense_ffn(c.model) == 11008   # int(4096 * 8/3) rounded up to a multiple of 256 (modules/mlp.py:52)
+    with pytest.raises(NotImplementedError, match="InternLM-1 family"):
+        load_reference_config("/root/reference/configs/7B_isp_sft.py")
     # BASELINE configs[4]: model_type INTERNLM_MoE, 4 experts, top-2 (moe_engine.MoEEngine)
     d = load_reference_config("/root/reference/configs/7B_MoE4_sft.py")
     assert (d.model.model_type, d.model.num_experts, d.model.num_kv_attention_heads, d.model.moe_capacity_factor, d.model.moe_min_capacity,
@@ -442,9 +449,14 @@ def test_pure_python_style_config_loads_without_the_reference_installed(tmp_path
     ISP config's parallel section (tensor 2 / isp, weight 4)."""
     import subprocess
 
+    # configs/7B_isp_sft.py names no model_type = the dense InternLM-1 model (launch.py:78-79), which this engine runs data-parallel only: its
+    # parallel section is mapped through a config that re-exports the file for the InternLM2 model
+    isp = tmp_path / "isp_internlm2.py"
+    isp.write_text("import runpy\nglobals().update({k: v for k, v in runpy.run_path('/root/reference/configs/7B_isp_sft.py').items() if not k.startswith('__')})\n"
+                   "model_type = 'INTERNLM2_PUBLIC'\n")
     code = ("import sys, importlib.util; sys.path.insert(0, %r); assert importlib.util.find_spec('internlm') is None; "
             "from internevo_amd.config import load_reference_config as L; c = L('/root/reference/configs/demo.py'); "
-            "i = L('/root/reference/configs/7B_isp_sft.py'); "
-            "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % ROOT
+            "i = L(%r); "
+            "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % (ROOT, str(isp))
     out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, check=True).stdout.split()
     assert out == ["32", "4096", "92544", "2", "4", "False"], out

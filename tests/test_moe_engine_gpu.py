@@ -94,6 +94,59 @@ def test_moe_engine_matches_reference_trajectory(dev):
     assert worst <= 1e-1
 
 
+def _v1_cfg(gold):
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+
+    c = gold["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    return PathConfig(mc, tc)
+
+
+def test_dense_internlm1_engine_matches_reference_trajectory(dev):
+    """model_type INTERNLM (modeling_internlm.py, configs/7B_sft.py -- the model of the reference's published numbers): the InternLM-1 block
+    with a plain SwiGLU FeedForward = MoEEngine's dense branch.  Six steps against the UNMODIFIED reference's bf16 CPU run
+    (tests/golden/train_v1_bf16.json, make_golden.py --run v1_bf16) and against the pinned oracle (oracle.moe_model with num_experts = 1, which
+    retraces that run on CPU): loss within 1e-3 relative (north_star), total gradient norm within 2e-2, loss scale equal, no skipped step;
+    the trained weights against the oracle's."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.moe_engine import MoEEngine
+    from oracle.model import moe_formula_init
+    from oracle.moe_model import OracleMoETrainer
+
+    gold = json.load(open(os.path.join(G, "train_v1_bf16.json")))
+    cfg = _v1_cfg(gold)
+    eng = MoEEngine(cfg, dev, init_fn=moe_formula_init)
+    assert eng.dense and eng.ep == 1
+    ora = OracleMoETrainer(cfg, torch.bfloat16)
+    assert sorted(n for n, _ in eng.named_parameters()) == sorted(ora.params), "parameter names of the dense model"
+    loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"]))
+    worst_loss = worst_norm = 0.0
+    for k, w in enumerate(gold["steps"]):
+        batch, labels = next(loader)
+        loss, moe_loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        ref = ora.train_step(batch, labels)
+        total = sum(v * v for v in st.group_norms.values()) ** 0.5
+        ref_total = sum(v * v for v in ref["grad_norm"].values()) ** 0.5
+        want = w["grad_norm"]["0_default"]
+        print(f"step {k}: HIP loss {float(loss):.5f} norm {total:.4f} | oracle {ref['loss']:.5f} {ref_total:.4f} | reference {w['loss']:.5f} {want:.4f}")
+        assert st.skip == 0 and st.loss_scale == w["loss_scale"] and float(moe_loss) == 0.0
+        worst_loss = max(worst_loss, abs(float(loss) - w["loss"]) / w["loss"], abs(float(loss) - ref["loss"]) / ref["loss"])
+        worst_norm = max(worst_norm, abs(total - want) / want, abs(total - ref_total) / ref_total)
+        assert abs(float(loss) - w["loss"]) <= 1e-3 * w["loss"], (k, float(loss), w["loss"])
+        assert abs(float(loss) - ref["loss"]) <= 1e-3 * ref["loss"], (k, float(loss), ref["loss"])
+        assert abs(total - want) <= 2e-2 * want and abs(total - ref_total) <= 2e-2 * ref_total, (k, total, want, ref_total)
+    print(f"[parity dense v1] max relative loss deviation {worst_loss:.2e} (bound 1e-3), total gradient norm {worst_norm:.2e} (bound 2e-2)")
+    worst = 0.0
+    for n, p in eng.named_parameters():
+        worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
+    print("max |param diff| vs the oracle after training:", worst)
+    assert worst <= 2e-2
+
+
 def test_moe_engine_runs_with_device_generated_noise_and_default_init(dev):
     """The production path: Gumbel noise from the device generator, the family's default initialisation; the loss must fall."""
     from internevo_amd.data import SyntheticLoader

@@ -124,7 +124,7 @@ def main(argv=None, log=print):
     dev = torch.device("cuda", local_rank)
     if world > 1 and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL
-    if mc.model_type == "INTERNLM_MoE":
+    if mc.model_type in ("INTERNLM_MoE", "INTERNLM"):   # the InternLM-1 families (MoE, or the dense model on the same engine)
         return _train_moe(cfg, raw, dev, world, rank, args, log)
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
     ck = raw.get("ckpt", {}) or {}
