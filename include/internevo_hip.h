@@ -107,6 +107,21 @@ int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, co
                   int64_t ldb, void* da, int64_t ldda, void* db, int64_t lddb, void* act_out,
                   int64_t ldact, int64_t rows, int64_t cols, void* stream);
 
+/* The two FFN products with the SwiGLU arithmetic in their epilogues (FeedForward.forward, internlm/model/modules/mlp.py:82-86, and its
+ * autograd backward): ONE launch each when the shape rides on the 256x256 refill-schedule GEMM (K % 64 == 0, F % 128 == 0 forward), otherwise
+ * the product followed by the kernel above -- bit-identical results either way.
+ *   fwd: h13[M, 2F] = x[M, K] @ w13[2F, K]^T (rows 0..F-1 = w1, F..2F-1 = w3);  act[M, F] = bf16(bf16(silu(h13[:, :F])) * h13[:, F:])
+ *   bwd: dh13[M, 2F] = (d gate | d up) of the gate at h13 for d(act) = dy[M, K] @ w2[K, F]; d(act) itself is written only on the two-launch path
+ *        (dact_scratch [M, F], always required).
+ * ie_tune_ffn_fuse(mode): bit 0 = fuse the forward product (default on), bit 1 = fuse the input-gradient product (default off: measured no faster,
+ * profiles/r03_ffn_fuse_ab.jsonl); 0 forces the two-launch path everywhere. */
+int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, int64_t ldw, void* h13, int64_t ldh, void* act, int64_t ld_act,
+                       int64_t M, int64_t F, int64_t K, void* stream);
+int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, int64_t ldw, const void* h13, int64_t ldh, void* dh13, int64_t ldd,
+                       void* dact_scratch, int64_t ld_scratch, int64_t M, int64_t F, int64_t K, void* stream);
+int ie_tune_ffn_fuse(int mode);
+int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K);   /* 1 = one launch for this shape */
+
 /* ------------------------------------------------------------------------------------------------
  * K4  Softmax cross-entropy.  Replaces flash_attn.losses.cross_entropy.CrossEntropyLoss
  *     (internlm/model/losses/ce_loss.py:26-36) / nn.CrossEntropyLoss (:37-40).

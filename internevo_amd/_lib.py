@@ -100,6 +100,10 @@ SIGNATURES = {
     "ie_flash_attn_bwd": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, I64, P, P, I64, P, I, I64, I, I, I, I, F, I, P]),
     "ie_tune_flash_dq_occupancy": (I, [I]),
     "ie_tune_gemm_group": (I, [I]),
+    "ie_tune_ffn_fuse": (I, [I]),
+    "ie_gemm_swiglu_is_fused": (I, [I, I64, I64, I64]),
+    "ie_gemm_swiglu_fwd": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
+    "ie_gemm_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "ie_tune_gemm_tail_split": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
     "ie_bias_add_bf16": (I, [P, I64, P, I64, I64, P]),

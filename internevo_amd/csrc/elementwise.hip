@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // SwiGLU.  Reference: Silu(w1_o, w3_o) = F.silu(w1_o) * w3_o on bf16 tensors (model/utils.py:684-688):
 // silu evaluated in fp32, rounded to bf16, product rounded to bf16.
-__device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + __expf(-a)); }
-
+// (element arithmetic: swiglu_fwd1 / swiglu_bwd1 in ie_common.h, shared with the fused GEMM epilogues)
 __global__ __launch_bounds__(256) void swiglu_fwd_k(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b,
                                                     int64_t ldb, bf16_t* __restrict__ out, int64_t ldo, int64_t rows,
                                                     int64_t cols8) {
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_k(const bf16_t* __restrict__ a
         unpack8(ld16(a + r * lda + c), av);
         unpack8(ld16(b + r * ldb + c), bv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rbf(av[e] * sigmoidf_(av[e])) * bv[e];
+        for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(av[e], bv[e]);
         st16(out + r * ldo + c, pack8(o));
     }
 }
@@ -190,14 +189,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const bf16_t* __restrict__ d
         unpack8(ld16(b + r * ldb + c), bv);
         unpack8(ld16(dout + r * lddo + c), gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sg = sigmoidf_(av[e]);
-            const float s = rbf(av[e] * sg);                  // bf16 silu(a), as saved by autograd
-            const float ds = rbf(gv[e] * bv[e]);              // grad wrt silu output (bf16 mul backward)
-            oa[e] = ds * (sg * (1.f + av[e] * (1.f - sg)));   // silu'(a)
-            ob[e] = gv[e] * s;
-            oc[e] = s * bv[e];
-        }
+        for (int e = 0; e < 8; ++e) swiglu_bwd1(gv[e], av[e], bv[e], oa[e], ob[e], oc[e]);
         st16(da + r * ldda + c, pack8(oa));
         st16(db + r * lddb + c, pack8(ob));
         if (act) st16(act + r * ldact + c, pack8(oc));

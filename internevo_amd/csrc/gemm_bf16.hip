@@ -27,6 +27,12 @@
 extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
                                   int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt);
 
+extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* h13,
+                                         int64_t ld_h13, void* act, int64_t ld_act, int64_t M, int64_t F, int64_t K, void* stream);
+extern "C" int ie_swiglu_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);
+extern "C" int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, const void* b, int64_t ldb, void* da, int64_t ldda, void* db,
+                             int64_t lddb, void* act, int64_t ldact, int64_t rows, int64_t cols, void* stream);
+
 namespace {
 
 constexpr int BK = 64;
@@ -436,6 +442,58 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
 extern "C" int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
                             int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
     return gemm_dispatch(-1, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);
+}
+
+// ---- the FFN products with the SwiGLU arithmetic fused into their epilogues (a7) ---------------------------------------------------
+// Fused (one launch, the refill-schedule kernel with EPI 1 / 2) when the plain dispatcher would have picked that schedule for the shape;
+// otherwise the same two launches as before (product, then the elementwise kernel).  Results are bit-identical either way.
+// bit 0: the forward product (on: -134 us per 16 384-row layer call, profiles/r03_ffn_fuse_ab.jsonl); bit 1: the w2 input-gradient product (off:
+// measured level to slower -- the epilogues of all CUs coincide, gemm_bf16_dma.hip EPI 2)
+static int g_ffn_fuse = 1;
+extern "C" int ie_tune_ffn_fuse(int mode) {
+    if (mode < 0 || mode > 3) return IE_ERR_INVALID;
+    g_ffn_fuse = mode;
+    return IE_OK;
+}
+
+// 1 when the shape takes the one-launch path (contiguous, 16-byte aligned operands assumed), 0 when it takes two launches
+extern "C" int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K) {
+    if (!(g_ffn_fuse & (bwd ? 2 : 1)) || K <= 0 || K % 64 != 0 || M < 8 || F < 8) return 0;
+    if (bwd) return pick_variant(M, F, K, false, true) == 19 && !(g_tail_split && tail_split(M, F).on);
+    return F % 128 == 0 && pick_variant(M, 2 * F, K, false, false) == 19 && !(g_tail_split && tail_split(M, 2 * F).on);
+}
+
+extern "C" int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, int64_t ldw, void* h13, int64_t ldh, void* act, int64_t ld_act, int64_t M,
+                                  int64_t F, int64_t K, void* stream) {
+    IE_CHECK_ARG(x && w13 && h13 && act, "ie_gemm_swiglu_fwd: null pointer");
+    IE_CHECK_ARG(M >= 0 && F >= 0 && K >= 0 && M < (1ll << 30) && F < (1ll << 29) && K < (1ll << 30), "ie_gemm_swiglu_fwd: bad size");
+    IE_CHECK_ARG(ldx >= K && ldw >= K && ldh >= 2 * F && ld_act >= F, "ie_gemm_swiglu_fwd: leading dimension too small");
+    IE_CHECK_SUPPORTED(aligned16(act) && ld_act % 8 == 0 && F % 8 == 0, "ie_gemm_swiglu_fwd: act must be 16-byte aligned, F and its leading dimension multiples of 8");
+    if (M == 0 || F == 0) return IE_OK;
+    const bool fits32 = M * ldx * 2 < (1ll << 32) && 2 * F * ldw * 2 < (1ll << 32);
+    const bool fuse = (g_ffn_fuse & 1) && K > 0 && K % 64 == 0 && F % 128 == 0 && M >= 8 && fits32 && aligned16(x) && aligned16(w13) && aligned16(h13) && ldx % 8 == 0 &&
+                      ldw % 8 == 0 && ldh % 8 == 0 && pick_variant(M, 2 * F, K, false, false) == 19 && !(g_tail_split && tail_split(M, 2 * F).on);
+    if (fuse) return ie_gemm_swiglu_dma_launch(0, x, ldx, w13, ldw, h13, ldh, nullptr, 0, act, ld_act, M, F, K, stream);
+    const int rc = gemm_dispatch(-1, x, ldx, 0, w13, ldw, 0, h13, ldh, M, 2 * F, K, 0, stream);
+    if (rc != IE_OK) return rc;
+    return ie_swiglu_fwd(h13, ldh, (const bf16_t*)h13 + F, ldh, act, ld_act, M, F, stream);
+}
+
+extern "C" int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, int64_t ldw, const void* h13, int64_t ldh, void* dh13, int64_t ldd,
+                                  void* dact_scratch, int64_t ld_scratch, int64_t M, int64_t F, int64_t K, void* stream) {
+    IE_CHECK_ARG(dy && w2 && h13 && dh13 && dact_scratch, "ie_gemm_swiglu_bwd: null pointer");
+    IE_CHECK_ARG(M >= 0 && F >= 0 && K >= 0 && M < (1ll << 30) && F < (1ll << 29) && K < (1ll << 30), "ie_gemm_swiglu_bwd: bad size");
+    IE_CHECK_ARG(ldy >= K && ldw >= F && ldh >= 2 * F && ldd >= 2 * F && ld_scratch >= F, "ie_gemm_swiglu_bwd: leading dimension too small");
+    IE_CHECK_SUPPORTED(aligned16(h13) && aligned16(dh13) && ldh % 8 == 0 && ldd % 8 == 0 && F % 8 == 0,
+                       "ie_gemm_swiglu_bwd: h13 / dh13 must be 16-byte aligned, F and the leading dimensions multiples of 8");
+    if (M == 0 || F == 0) return IE_OK;
+    const bool fits32 = M * ldy * 2 < (1ll << 32) && K * ldw * 2 < (1ll << 32);
+    const bool fuse = (g_ffn_fuse & 2) && K > 0 && K % 64 == 0 && M >= 8 && F >= 8 && fits32 && aligned16(dy) && aligned16(w2) && ldy % 8 == 0 && ldw % 8 == 0 &&
+                      pick_variant(M, F, K, false, true) == 19 && !(g_tail_split && tail_split(M, F).on);
+    if (fuse) return ie_gemm_swiglu_dma_launch(1, dy, ldy, w2, ldw, dh13, ldd, h13, ldh, nullptr, 0, M, F, K, stream);
+    const int rc = gemm_dispatch(-1, dy, ldy, 0, w2, ldw, 1, dact_scratch, ld_scratch, M, F, K, 0, stream);
+    if (rc != IE_OK) return rc;
+    return ie_swiglu_bwd(dact_scratch, ld_scratch, h13, ldh, (const bf16_t*)h13 + F, ldh, dh13, ldd, (bf16_t*)dh13 + F, ldd, nullptr, 0, M, F, stream);
 }
 
 extern "C" int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,

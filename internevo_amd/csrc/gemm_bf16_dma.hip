@@ -251,7 +251,7 @@ __device__ __forceinline__ s16x8 frag_km_nowait(const unsigned char* tile, int m
 // SPREAD = 0: the next tile's DMA instructions are all issued at the top of the k-tile; SPREAD = n > 0: they are
 // interleaved one by one with the MFMAs of the first n k-steps (a DMA issue costs ~60-180 cycles of issue time during
 // which this wave cannot feed the matrix pipe; spreading them lets the previous MFMAs cover that time).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int SPREAD>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int SPREAD, int EPI = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_t* __restrict__ A0, int64_t lda, const bf16_t* __restrict__ B0,
                                                                      int64_t ldb, bf16_t* __restrict__ C0, int64_t ldc, int M, int N, int K,
                                                                      int accumulate, int tiles_m, int tiles_n, IeGemmBatch bt) {
@@ -281,7 +281,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     const int gsz = min(tiles_m - first_m, GM);
     const int pm = first_m + (id % width) % gsz;
     const int pn = (id % width) / gsz;
-    const int m0 = pm * BM, n0 = pn * BN;
+    // EPI 1 (w1 | w3 forward with the SwiGLU epilogue): tile column block pn = B rows pn*BN/2 .. +BN/2 of w1 AND the same rows of w3 (f rows further)
+    static_assert(EPI == 0 || (SPREAD == -4 && !A_KM && BM == 256 && BN == 256 && WAVES_M * WAVES_N == 4), "the fused epilogues ride on the refill schedule");
+    static_assert(EPI != 1 || !B_KM, "EPI 1: the forward product");
+    const int m0 = pm * BM, n0 = EPI == 1 ? pn * (BN / 2) : pn * BN;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,6 +306,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     if constexpr (!RING) {
         sa.init(A, lda, m0, M, K, wave, lane);
         sb.init(B, ldb, n0, N, K, wave, lane);
+        if constexpr (EPI == 1) {   // the pieces that carry tile rows BN/2.. come from w3: (f - BN/2) rows further down
+#pragma unroll
+            for (int q = 0; q < decltype(sb)::PERW; ++q)
+                if (8 * NW * q >= BN / 2) sb.soff[q] += (int)((bt.f - BN / 2) * ldb * 2);
+        }
         sa.issue(smem, wave);
         sb.issue(smem + G::A_BYTES, wave);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -807,6 +815,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     }
 
     // ---- epilogue (as gemm_bf16.hip): D^T accumulators -> LDS [m][n] bf16 -> 16-byte row stores
+    if ((abl & 8) && !(abl & 4) && M != -12345) return;   // timing ablation: no epilogue at all
+    auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int m = wm * G::WM + i * 32 + (lane & 31);
@@ -822,14 +832,70 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
             }
         }
     }
+    };
+    stage();
     __syncthreads();
+    if constexpr (EPI == 1) {
+        // [BM][BN/2 gate | BN/2 up] -> h13 (both halves, at columns n0.. and f + n0..) and act = silu(gate) * up
+        constexpr int CH = BN / 16;   // 16-byte chunks per half row
+        bf16_t* __restrict__ ACT = (bf16_t*)bt.act;
+        const int F = (int)bt.f;
+#pragma unroll
+        for (int q = 0; q < BM * CH / NT; ++q) {
+            const int c = threadIdx.x + NT * q;
+            const int row = c / CH, nc = c % CH;
+            const int gm = m0 + row, gn = n0 + nc * 8;
+            if (gm < M && gn < F) {
+                const uint4 g = ld16(smem + row * G::CPITCH + nc * 16), u = ld16(smem + row * G::CPITCH + BN + nc * 16);
+                float gv[8], uv[8], o[8];
+                unpack8(g, gv);
+                unpack8(u, uv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(gv[e], uv[e]);
+                bf16_t* dst = C + (int64_t)gm * ldc + gn;
+                st16(dst, g);
+                st16(dst + F, u);
+                st16(ACT + (int64_t)gm * bt.ld_act + gn, pack8(o));
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == 2) {
+        // the tile is d(act) [BM][BN]: with gate | up from h13, d(gate) | d(up) -> C = dh13 [M, 2f].  Measured (profiles/r03_ffn_fuse_ab.jsonl): NOT
+        // faster than the two-launch path -- all 256 CUs reach their epilogues together (equal tiles, one block per CU), so this epilogue's 512 KB
+        // per tile move in chip-wide bursts at HBM speed with nothing to hide them (1826 vs 1798 us at 16 384 rows; requesting the h13 reads
+        // before the accumulators are staged: 2016 us).  Off by default (ie_tune_ffn_fuse bit 1).
+        constexpr int CH = BN / 8;
+        const bf16_t* __restrict__ H13 = (const bf16_t*)bt.aux;
+        const int F = (int)bt.f;
+#pragma unroll 4
+        for (int q = 0; q < BM * CH / NT; ++q) {
+            const int c = threadIdx.x + NT * q;
+            const int row = c / CH, nc = c % CH;
+            const int gm = m0 + row, gn = n0 + nc * 8;
+            if (gm < M && gn < N) {
+                const bf16_t* hp = H13 + (int64_t)gm * bt.ld_aux + gn;
+                float gv[8], av[8], bv[8], oa[8], ob[8], oc;
+                unpack8(ld16(hp), av);
+                unpack8(ld16(hp + F), bv);
+                unpack8(ld16(smem + row * G::CPITCH + nc * 16), gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) swiglu_bwd1(gv[e], av[e], bv[e], oa[e], ob[e], oc);
+                bf16_t* dst = C + (int64_t)gm * ldc + gn;
+                st16(dst, pack8(oa));
+                st16(dst + F, pack8(ob));
+            }
+        }
+        return;
+    }
     constexpr int CPR = BN / 8;
+    const bool no_store = (abl & 12) == 12;   // timing ablation: staging and LDS reads, but no global stores
 #pragma unroll
     for (int q = 0; q < BM * CPR / NT; ++q) {
         const int c = threadIdx.x + NT * q;
         const int row = c / CPR, nc = c % CPR;
         const int gm = m0 + row, gn = n0 + nc * 8;
-        if (gm < M && gn < N) {
+        if (gm < M && gn < N && !(no_store && gm != -12345)) {
             uint4 v = ld16(smem + row * G::CPITCH + nc * 16);
             bf16_t* dst = C + (int64_t)gm * ldc + gn;
             if (accumulate) {
@@ -893,4 +959,26 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
+}
+
+// The two FFN products with the SwiGLU arithmetic in their epilogues (refill schedule, 256x256 tiles; the caller has checked K % 64 == 0,
+// F % 128 == 0 (fwd) and that the operands fit 32-bit buffer offsets).
+//   fwd: h13[M, 2F] = x[M, K] @ (w1 | w3)[2F, K]^T and act[M, F] = silu(h13[:, :F]) * h13[:, F:]
+//   bwd: dh13[M, 2F] = SwiGLU backward of (dy[M, K] @ w2[K, F]) at h13
+extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* h13,
+                                         int64_t ld_h13, void* act, int64_t ld_act, int64_t M, int64_t F, int64_t K, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    IeGemmBatch bt{1, 0, 0, 0, F, h13, ld_h13, act, ld_act};
+    const int tiles_m = (int)((M + 255) / 256);
+    const int flags = (g_gemm_group << 8);
+    if (!bwd) {
+        const int tiles_n = (int)(F / 128);
+        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -4, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, bt);
+    } else {
+        const int tiles_n = (int)((F + 255) / 256);
+        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, true, -4, 2>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, bt);
+    }
+    return ie_launch_status("ie_gemm_swiglu (dma) launch");
 }

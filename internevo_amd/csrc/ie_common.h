@@ -131,4 +131,27 @@ __device__ __forceinline__ void st8(void* p, const uint2& v) { *reinterpret_cast
 struct IeGemmBatch {
     int count;
     int64_t sa, sb, sc;
+    // fused SwiGLU epilogues of the FFN products (gemm_bf16_dma.hip, template parameter EPI; unused otherwise):
+    //   EPI 1 (w1 | w3 forward): B = [2F, K] (w1 rows, then w3 rows); a 256-column tile = 128 gate columns + the SAME 128 up columns, the epilogue
+    //     writes both to C = h13 [M, 2F] and silu(gate) * up to act [M, F];
+    //   EPI 2 (w2 dgrad): the tile of d(act) never reaches memory: with gate | up read from h13 = aux the epilogue writes d(gate) | d(up) to C = dh13.
+    int64_t f;            // F
+    const void* aux;      // EPI 2: h13 [M, 2F]
+    int64_t ld_aux;
+    void* act;            // EPI 1: act [M, F]
+    int64_t ld_act;
 };
+
+// SwiGLU element arithmetic shared by the elementwise kernels and the fused GEMM epilogues (bit-identical by construction).
+// Reference: Silu(w1_o, w3_o) = F.silu(w1_o) * w3_o on bf16 tensors (model/utils.py:684-688): silu evaluated in fp32, rounded to bf16,
+// product rounded to bf16; the backward sees the bf16 silu(a) autograd saved and the bf16 gradient of the product.
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + __expf(-a)); }
+__device__ __forceinline__ float swiglu_fwd1(float a, float b) { return rbf(a * sigmoidf_(a)) * b; }
+__device__ __forceinline__ void swiglu_bwd1(float g, float a, float b, float& da, float& db, float& act) {
+    const float sg = sigmoidf_(a);
+    const float s = rbf(a * sg);                    // bf16 silu(a), as saved by autograd
+    const float ds = rbf(g * b);                    // grad wrt silu output (bf16 mul backward)
+    da = ds * (sg * (1.f + a * (1.f - sg)));        // silu'(a)
+    db = g * s;
+    act = s * b;
+}

@@ -555,11 +555,11 @@ class InternLM2Engine:
         self.tpar.all_reduce_sum(attn_out)   # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism)
         K.add_rmsnorm_fwd(attn_out, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[s], self.a_n2[s], self.a_rstd2[s])
         w13, _ = self._w13(l)
-        K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
         if recompute:
+            K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
             return None
         act = self.t_act if self.a_act is None else self.a_act[s]
-        K.swiglu_fwd(self.a_w13[s][:, :F], self.a_w13[s][:, F:], act)
+        K.linear_swiglu_fwd(self.a_n2[s], w13, self.a_w13[s], act)   # w1 | w3 product with the gate in its epilogue (one launch at the 7B shapes)
         K.linear_fwd(act, p[pre + "feed_forward.w2.weight"], self.t_h1)
         return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
 
@@ -751,11 +751,12 @@ class InternLM2Engine:
                 self._layer_forward(l, None, cu, pos, max_seqlen, True)
             # feed-forward
             t_act, t_dw13, t_qkv = (self.st_act[l][r], self.st_dw13[l][r], self.st_dqkv[l][r]) if bw else (self.t_act, self.t_dw13, self.t_qkv)
-            K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
             if self.a_act is not None and l >= mc.checkpoint_layers:   # the product is still there from the forward
                 t_act = self.a_act[sl]
-                K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], t_dw13[:, :F], t_dw13[:, F:], None)
+                # d(act) = d_out @ w2 never reaches memory: the gate's backward sits in the product's epilogue (one launch at the 7B shapes)
+                K.linear_dgrad_swiglu_bwd(d_out, p[pre + "feed_forward.w2.weight"], self.a_w13[sl], t_dw13, self.t_dact)
             else:
+                K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
                 K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], t_dw13[:, :F], t_dw13[:, F:], t_act)
             wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None, acc_l)
             d_n2 = spare[0]

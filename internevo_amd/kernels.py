@@ -446,6 +446,40 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
     return gemm(dy, x, True, True, out, accumulate)
 
 
+def linear_swiglu_fwd(x, w13, h13, act):
+    """h13[T, 2F] = x[T, K] @ w13[2F, K]^T (w1 rows, then w3 rows) and act[T, F] = silu(h13[:, :F]) * h13[:, F:] -- one launch when the shape
+    rides on the refill-schedule GEMM (ie_gemm_swiglu_fwd), the product + swiglu_fwd otherwise; bit-identical either way."""
+    M, K = x.shape
+    F = w13.shape[0] // 2
+    if w13.shape != (2 * F, K) or h13.shape != (M, 2 * F) or act.shape != (M, F) or any(t.stride(1) != 1 for t in (x, w13, h13, act)):
+        raise ValueError("linear_swiglu_fwd: bad shapes")
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
+    check(_L().ie_gemm_swiglu_fwd(_p(x), x.stride(0), _p(w13), w13.stride(0), _p(h13), h13.stride(0), _p(act), act.stride(0), M, F, K, _stream()),
+          "ie_gemm_swiglu_fwd")
+    if prof is not None:   # (the product's algorithmic work; the gate's 6 F bytes per row ride along)
+        prof.end(2.0 * M * 2 * F * K, 2.0 * (M * K + 2 * F * K + M * 2 * F))
+    return h13, act
+
+
+def linear_dgrad_swiglu_bwd(dy, w2, h13, dh13, dact_scratch):
+    """dh13[T, 2F] = SwiGLU backward at h13 of d(act) = dy[T, K] @ w2[K, F] (w2 = the [h, F] weight of the down projection)."""
+    M, K = dy.shape
+    F = w2.shape[1]
+    if w2.shape != (K, F) or h13.shape != (M, 2 * F) or dh13.shape != (M, 2 * F) or dact_scratch.shape != (M, F) or any(
+            t.stride(1) != 1 for t in (dy, w2, h13, dh13, dact_scratch)):
+        raise ValueError("linear_dgrad_swiglu_bwd: bad shapes")
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
+    check(_L().ie_gemm_swiglu_bwd(_p(dy), dy.stride(0), _p(w2), w2.stride(0), _p(h13), h13.stride(0), _p(dh13), dh13.stride(0), _p(dact_scratch),
+                                  dact_scratch.stride(0), M, F, K, _stream()), "ie_gemm_swiglu_bwd")
+    if prof is not None:
+        prof.end(2.0 * M * F * K, 2.0 * (M * K + F * K + M * F))
+    return dh13
+
+
 def gemm_batched(A, B, out, a_kmajor=False, b_kmajor=False, accumulate=False):
     """out[z] (+)= op(A[z]) @ op(B[z]) for the leading batch dimension z of three 3-D bf16 tensors (unit inner stride, equal batch strides
     per tensor): ONE launch for all products (the experts of a MoE layer)."""

@@ -830,3 +830,41 @@ def test_gemm_strided_batch_equals_separate_products(dev, layout, Z, M, N, Kd):
         one = C0[z].clone()
         K().gemm(A[z], B[z], akm, bkm, out=one, accumulate=True)
         assert torch.equal(acc[z], one), (layout, z, "accumulate")
+
+
+@pytest.mark.parametrize("M,F,Kd", [(4096, 8192, 1024), (4000, 8192, 1024), (1000, 512, 200), (16384, 14336, 4096)], ids=["tiles", "ragged_rows", "two_launch_shape", "7b_shape"])
+def test_ffn_products_with_the_swiglu_epilogues_equal_the_two_launch_path_bit_for_bit(dev, M, F, Kd):
+    """ie_gemm_swiglu_fwd / _bwd (a7): the w1 | w3 forward product writes silu(gate) * up from its epilogue (a 256-column tile = 128 gate
+    columns + the same 128 up columns), the w2 input-gradient product applies the gate's backward in its epilogue (d(act) never reaches
+    memory).  Same arithmetic as swiglu_fwd_k / swiglu_bwd_k (shared device functions) on the same bf16-rounded products: the results must
+    be IDENTICAL to the product followed by the elementwise kernel (which the oracle tests pin), also with a ragged last row tile, and
+    shapes off the fused schedule must take the two-launch path by themselves."""
+    Kk = K()
+    L = Kk._L()
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(M, Kd, device=dev, generator=g).to(torch.bfloat16)
+    w13 = (torch.randn(2 * F, Kd, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    w2 = (torch.randn(Kd, F, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    dy = torch.randn(M, Kd, device=dev, generator=g).to(torch.bfloat16)
+    out = {}
+    for mode in (0, 3):    # 0: two launches everywhere; 3: both products fused (the default, 1, fuses the forward product only)
+        L.ie_tune_ffn_fuse(mode)
+        try:
+            if mode == 3:
+                fused = (int(L.ie_gemm_swiglu_is_fused(0, M, F, Kd)), int(L.ie_gemm_swiglu_is_fused(1, M, F, Kd)))
+                assert fused == ((0, 0) if F == 512 else (1, 1)), fused
+            h13 = torch.full((M, 2 * F), 7.0, device=dev, dtype=torch.bfloat16)
+            act = torch.full((M, F), 7.0, device=dev, dtype=torch.bfloat16)
+            dh13 = torch.full((M, 2 * F), 7.0, device=dev, dtype=torch.bfloat16)
+            dact = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+            Kk.linear_swiglu_fwd(x, w13, h13, act)
+            Kk.linear_dgrad_swiglu_bwd(dy, w2, h13, dh13, dact)
+            torch.cuda.synchronize()
+            out[mode] = (h13, act, dh13)
+        finally:
+            L.ie_tune_ffn_fuse(1)
+    for name, a, b in zip(("h13", "act", "dh13"), out[0], out[3]):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ, max |diff| {float((a.float() - b.float()).abs().max())}"
+    # and the two-launch path is the plain product + the elementwise kernels
+    ref = Kk.linear_fwd(x, w13)
+    assert torch.equal(out[0][0], ref) and torch.equal(out[0][1], Kk.swiglu_fwd(ref[:, :F], ref[:, F:]))
