@@ -136,6 +136,7 @@ class TrainConfig:
                                     # only when they do not fit resident (engine.py, weight_parallel)
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
     tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
+    tp_mode: str = "mtp"            # "msp" / "fsp": the same shards with the activations between the linears sharded along the sequence
     pp_size: int = 1                # parallel.pipeline = dict(size=pp): 1F1B pipeline parallelism (pipeline.py)
     num_chunks: int = 1             # model.num_chunks: model chunks per pipeline stage (> 1: the interleaved 1F1B schedule)
 
@@ -167,17 +168,19 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     tensor = par.get("tensor", {})
     tensor = tensor if isinstance(tensor, dict) else dict(size=tensor, mode="mtp")  # launch.py normalises an int the same way
     sp_size = tp_size = 1
+    tp_mode = "mtp"
     if tensor.get("size", 1) != 1:
         mode = tensor.get("mode", "mtp")
         if mode == "isp":
             sp_size = int(tensor["size"])
         elif mode in ("mtp", "msp", "fsp"):
             # msp / fsp (Megatron sequence parallelism, without / with overlap: model/ops/linear.py:338-441, utils.py:160-226) hold the
-            # SAME parameter shards and compute the same numbers as mtp; they shard the activations between the linears along the
-            # sequence (reduce-scatter after a row-parallel linear + all-gather in front of the next column-parallel one, the same
-            # bytes as mtp's all-reduce) to save activation memory and 1 - 1/tp of the norm work.  With 288 GB per GPU the engine keeps
-            # the activations whole and runs the mtp schedule for all three modes.
+            # SAME parameter shards as mtp; the activations between the linears are sharded along the sequence (reduce-scatter after a
+            # row-parallel linear + all-gather in front of the next column-parallel one, the same bytes as mtp's all-reduce), the norms and
+            # residual adds run on T / tp rows, and the norm weights' gradients are AVERAGED over the tensor group (hybrid_zero_optim.py:315-353) --
+            # engine.py `seq_shard`.  The two modes differ in the reference only in how the exchanges overlap the products.
             tp_size = int(tensor["size"])
+            tp_mode = mode
         else:
             raise NotImplementedError(f"{_UNSUPPORTED}: tensor parallel mode {mode!r} (supported: 'mtp', 'msp', 'fsp', 'isp')")
     # parallel.weight (size, overlap, memory_pool): the weight-parallel size is honoured when the resident layout does not fit the GPU (or when
@@ -280,7 +283,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size, tp_size=tp_size, pp_size=pp_size, num_chunks=num_chunks, wp_size=wp_size,
+        sp_size=sp_size, tp_size=tp_size, tp_mode=tp_mode, pp_size=pp_size, num_chunks=num_chunks, wp_size=wp_size,
     )
     return PathConfig(model, train)
 

@@ -45,12 +45,17 @@ _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None, tp_mode=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step).
+        tp_mode (default: the config's parallel.tensor mode): "msp" / "fsp" = tensor parallelism with the activations BETWEEN the linears sharded
+        along the sequence (model/utils.py:228-463, ops/linear.py:260-354): the residual stream, the norms and the residual adds live on this
+        rank's T / tp token rows; a norm's output is all-gathered in front of the column-parallel product, a row-parallel product's partial sums are
+        reduce-scattered, the backward mirrors it, and the norm weights' gradients (each rank's cover its own rows) are AVERAGED over the tensor
+        group as the reference does (hybrid_zero_optim.py:315-353, ReduceOp.AVG) -- pinned on tests/golden/train_msp2_*.json.
         vocab_parallel (tensor parallelism only; default on): every tensor rank holds 1/tp of the head's vocabulary rows and the loss is
         computed vocabulary-parallel (tensorpar.py); False = the whole head on every rank.
         pp_size (default: the config's parallel.pipeline.size): pipeline parallelism, non-interleaved 1F1B (pipeline.py): this rank
@@ -105,6 +110,7 @@ class InternLM2Engine:
                                    embed_split=getattr(mc, "embed_split_hidden", False))
         self.embed_split = self.tpar.embed_split
         self.tp = tp_size
+        self.ss = tp_size > 1 and (getattr(tc, "tp_mode", "mtp") if tp_mode is None else tp_mode) in ("msp", "fsp")   # sequence-sharded activations
         self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
         if tp_size > 1 and not self.embed_split and self.lmc.embed_dim != mc.hidden_size:
@@ -237,6 +243,7 @@ class InternLM2Engine:
         self.n_pass = tc.micro_num // self.mm               # passes (gradient-accumulation steps) per optimizer step
         self.Tg = tc.packed_length * self.mm    # tokens of a pass
         self.T = self.Tg // sp_size             # tokens this rank owns (all of them without sequence parallelism)
+        self.rl = self.tpar.rows(self.T) if self.ss else slice(None)   # the rows of the residual stream this rank works on (msp / fsp: T / tp of them)
         self._alloc(self.T)
         self.t_loss_seg = torch.empty(self.mm, 2, dtype=torch.float32, device=device)  # per micro-batch [mean loss, valid tokens]
         self.batch_wgrad = self._alloc_wgrad_stage(batch_wgrad)
@@ -532,12 +539,15 @@ class InternLM2Engine:
         mc = self.lmc
         F, eps = mc.ffn_dim, mc.layer_norm_epsilon
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
-        p, s = self.p, self.slot[l]
+        p, s, rl = self.p, self.slot[l], self.rl
         pre = f"layers.{self.gid[l]}."   # (l counts this stage's layers; the names carry the reference's global layer numbers)
         if prev_ffn_out is None or recompute:   # (the first layer of the model / of a pipeline stage / of a model chunk: its input is in a_x[l])
-            K.rmsnorm_fwd(self.a_x[l], p[pre + "attention_norm.weight"], eps, self.a_n1[s], self.a_rstd1[s])
+            K.rmsnorm_fwd(self.a_x[l][rl], p[pre + "attention_norm.weight"], eps, self.a_n1[s][rl], self.a_rstd1[s][rl])
         else:
-            K.add_rmsnorm_fwd(prev_ffn_out, self.a_r2[self.slot[l - 1]], p[pre + "attention_norm.weight"], eps, self.a_x[l], self.a_n1[s], self.a_rstd1[s])
+            K.add_rmsnorm_fwd(prev_ffn_out[rl], self.a_r2[self.slot[l - 1]][rl], p[pre + "attention_norm.weight"], eps, self.a_x[l][rl], self.a_n1[s][rl],
+                              self.a_rstd1[s][rl])
+        if self.ss:   # all-gather in front of the column-parallel wqkv (the gathered rows are kept: its weight gradient reads them)
+            self.tpar.all_gather_rows_async(self.a_n1[s]).wait()
         K.linear_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.t_qkv)
         if self.sp == 1:
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s], self.q_scale)
@@ -552,8 +562,11 @@ class InternLM2Engine:
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
         K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
-        self.tpar.all_reduce_sum(attn_out)   # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism)
-        K.add_rmsnorm_fwd(attn_out, self.a_x[l], p[pre + "ffn_norm.weight"], eps, self.a_r2[s], self.a_n2[s], self.a_rstd2[s])
+        # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism); msp / fsp: summed into this rank's rows only
+        (self.tpar.reduce_scatter_rows_async(attn_out) if self.ss else self.tpar.all_reduce_sum_async(attn_out)).wait()
+        K.add_rmsnorm_fwd(attn_out[rl], self.a_x[l][rl], p[pre + "ffn_norm.weight"], eps, self.a_r2[s][rl], self.a_n2[s][rl], self.a_rstd2[s][rl])
+        if self.ss:
+            self.tpar.all_gather_rows_async(self.a_n2[s]).wait()
         w13, _ = self._w13(l)
         if recompute:
             K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
@@ -561,7 +574,8 @@ class InternLM2Engine:
         act = self.t_act if self.a_act is None else self.a_act[s]
         K.linear_swiglu_fwd(self.a_n2[s], w13, self.a_w13[s], act)   # w1 | w3 product with the gate in its epilogue (one launch at the 7B shapes)
         K.linear_fwd(act, p[pre + "feed_forward.w2.weight"], self.t_h1)
-        return self.tpar.all_reduce_sum(self.t_h1)   # row-parallel w2
+        (self.tpar.reduce_scatter_rows_async(self.t_h1) if self.ss else self.tpar.all_reduce_sum_async(self.t_h1)).wait()   # row-parallel w2
+        return self.t_h1
 
     def _chunk(self, chunk):
         """(first local layer, end, is the model's first part, is its last part) of a forward / backward pass: the whole stage, or one of
@@ -596,7 +610,10 @@ class InternLM2Engine:
             torch.add(ffn_out, self.a_r2[self.slot[lb - 1]], out=self.t_send)
             return
         self._wait_bucket(L + 1)
-        K.add_rmsnorm_fwd(ffn_out, self.a_r2[self.slot[L - 1]], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
+        rl = self.rl
+        K.add_rmsnorm_fwd(ffn_out[rl], self.a_r2[self.slot[L - 1]][rl], p["norm.weight"], eps, self.a_xf[rl], self.a_nf[rl], self.a_rstdf[rl])
+        if self.ss:   # the head is column-parallel: all-gather along the sequence in front of it (ops/linear.py:146-153, gather_dim=1)
+            self.tpar.all_gather_rows_async(self.a_nf).wait()
         if self.head_fn:
             K.head_weight_fwd(p["output.weight"], mc.embed_grad_scale, mc.norm_head, self.t_head_w, self.t_head_inv)
         K.linear_fwd(self.a_nf, self.t_head_w if self.head_fn else p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
@@ -687,6 +704,10 @@ class InternLM2Engine:
         p, g = self.p, self.g
         T = self.T
         ws = self.t_norm_ws
+        # msp / fsp: the residual stream's gradients live on this rank's rows `rl`; a column-parallel product's input gradient is reduce-scattered
+        # into them, and the gradient in front of a row-parallel product's backward is all-gathered (the mirror of the forward)
+        ss, rl = self.ss, self.rl
+        tp_sum = self.tpar.reduce_scatter_rows_async if ss else self.tpar.all_reduce_sum_async
         # the first micro-batch of a step WRITES the gradients, the others accumulate: no zero_grad pass over 15.5 GB and no read of
         # the old value in the first weight-gradient epilogues (bucket padding is zero from allocation and never written)
         acc = not first_micro
@@ -722,7 +743,7 @@ class InternLM2Engine:
             dlog = self.t_logits
 
             K.linear_dgrad(dlog, self.t_head_w if self.head_fn else p["output.weight"], self.t_h0)
-            ar = self.tpar.all_reduce_sum_async(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
+            ar = tp_sum(self.t_h0) if self.vp else None   # column-parallel head: its input gradient is a partial sum
             if not self.head_fn:
                 wgrad(dlog, self.a_nf, g["output.weight"], self.st_logits if bw else None, self.st_nf if bw else None)
             else:   # the gradient w.r.t. the weight the GEMM used, then through normalize / the gradient scale into the parameter's gradient
@@ -736,8 +757,12 @@ class InternLM2Engine:
                 ar.wait()
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
         if is_last:
-            K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_out)
+            K.rmsnorm_bwd(self.t_h0[rl], self.a_xf[rl], p["norm.weight"], self.a_rstdf[rl], None, g["norm.weight"], acc, ws, d_out[rl])
+            if ss:   # d(residual stream) in front of the last layer's row-parallel w2
+                self.tpar.all_gather_rows_async(d_out).wait()
             if last_micro:
+                if ss:
+                    self.tpar.all_reduce_avg(g["norm.weight"])
                 self._reduce_bucket(len(self.layout.buckets) - 1)
         # (an earlier pipeline stage / model chunk received the gradient of its output from the next one into t_h1 = d_out)
         spare = [self.t_h0, self.t_h2]
@@ -761,11 +786,13 @@ class InternLM2Engine:
             wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None, acc_l)
             d_n2 = spare[0]
             K.linear_dgrad(t_dw13, w13, d_n2)
-            ar = self.tpar.all_reduce_sum_async(d_n2)   # input gradient of the column-parallel w1 | w3: summed over the tensor group ...
+            ar = tp_sum(d_n2)   # input gradient of the column-parallel w1 | w3: summed over the tensor group ...
             wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None, acc_l)   # ... under this GEMM
             ar.wait()
             d_r2 = self.st_dr2[l][r] if bw else spare[1]
-            K.rmsnorm_bwd(d_n2, self.a_r2[sl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl], d_out, g[pre + "ffn_norm.weight"], acc_l, ws, d_r2)
+            K.rmsnorm_bwd(d_n2[rl], self.a_r2[sl][rl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl][rl], d_out[rl], g[pre + "ffn_norm.weight"], acc_l, ws, d_r2[rl])
+            if ss:   # in front of the row-parallel wo's backward
+                self.tpar.all_gather_rows_async(d_r2).wait()
             # attention
             d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
             K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
@@ -784,14 +811,19 @@ class InternLM2Engine:
             K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv, self.dq_scale)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
-            ar = self.tpar.all_reduce_sum_async(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient
+            ar = tp_sum(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient
             wgrad(t_qkv, self.a_n1[sl], g[pre + "attention.wqkv.weight"], self.st_dqkv[l] if bw else None, self.st_n1[l] if bw else None, acc_l)
             ar.wait()
             if bw:    # the layer below reads its output gradient from its own staging rows (it is the dY of that layer's w2)
                 d_x = self.st_dout[l - 1][r] if l > 0 else self.t_h1
             else:
                 d_x = d_out  # the old d_out buffer is free now
-            K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "attention_norm.weight"], self.a_rstd1[sl], d_r2, g[pre + "attention_norm.weight"], acc_l, ws, d_x)
+            K.rmsnorm_bwd(d_n1[rl], self.a_x[l][rl], p[pre + "attention_norm.weight"], self.a_rstd1[sl][rl], d_r2[rl], g[pre + "attention_norm.weight"], acc_l, ws, d_x[rl])
+            if ss:   # the layer below starts with its row-parallel w2's backward (layer 0: the embedding's backward gathers the sequence, embedding.py:57-58)
+                self.tpar.all_gather_rows_async(d_x).wait()
+                if last_micro:
+                    self.tpar.all_reduce_avg(g[pre + "attention_norm.weight"])
+                    self.tpar.all_reduce_avg(g[pre + "ffn_norm.weight"])
             # rotate buffers: next d_out = d_x; spare = the two others
             if not bw:
                 spare = [d_n2, d_r2]

@@ -1,4 +1,4 @@
-"""Megatron-style tensor parallelism of the transformer layers ("mtp", parallel.tensor = dict(size=tp, mode="mtp")).
+"""Megatron-style tensor parallelism of the transformer layers (parallel.tensor = dict(size=tp, mode="mtp" | "msp" | "fsp")).
 
 Reference behaviour being matched (model/ops/linear.py:205-337, model/utils.py:228-346, modeling_internlm2.py:86-189,
 modules/mlp.py:100-140): wqkv / w1 / w3 are column-parallel (each rank owns the output rows of its 1/tp of the kv groups / FFN
@@ -68,6 +68,35 @@ class TensorParallel:
 
     def all_reduce_sum(self, t):
         self.all_reduce_sum_async(t).wait()
+        return t
+
+    # ---- sequence-sharded activations ("msp" / "fsp": model/utils.py:228-463, ops/linear.py:260-354) -------------------------------------
+    def rows(self, T):
+        """This rank's token rows of a [T, ...] activation (split_forward_gather_backward along the sequence, modules/embedding.py:57-58)."""
+        if T % self.tp:
+            raise ValueError(f"{T} token rows do not split over {self.tp} tensor ranks")
+        n = T // self.tp
+        return slice(self.tp_rank * n, (self.tp_rank + 1) * n)
+
+    def reduce_scatter_rows_async(self, t):
+        """The row-parallel output / column-parallel input gradient `t` [T, C] (a partial sum on every rank) -> summed over the tensor group
+        into THIS rank's rows, in place (the other rows are dead afterwards).  Handle as all_reduce_sum_async."""
+        if self.tp == 1:
+            return DONE
+        return self.be.reduce_scatter(t[self.rows(t.shape[0])], t, self.group, avg=False)
+
+    def all_gather_rows_async(self, t):
+        """Every rank's rows of `t` [T, C] -> the whole tensor on every rank, in place (all-gather in front of a column-parallel product,
+        and of a row-parallel product's backward)."""
+        if self.tp == 1:
+            return DONE
+        return self.be.all_gather(t, t[self.rows(t.shape[0])], self.group)
+
+    def all_reduce_avg(self, t):
+        """reduce_tensor(..., ParallelMode.TENSOR) of a norm weight's gradient under sequence-sharded activations: ReduceOp.AVG
+        (solver/optimizer/utils.py:120) -- every rank's gradient covers its own rows, the reference averages (it does not sum) them."""
+        if self.tp > 1:
+            self.be.all_reduce(t, self.group, avg=True).wait()
         return t
 
     def all_gather(self, t):

@@ -185,8 +185,10 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 
 
 def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1,
-                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False, pp=1, chunks=1):
+                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False, pp=1, chunks=1, tp_mode="mtp"):
     cfg = _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp, wp, model_type, tp)
+    if tp > 1 and tp_mode != "mtp":   # "msp" / "fsp": Megatron tensor parallelism with sequence-sharded activations between the linears
+        cfg["parallel"]["tensor"]["mode"] = tp_mode
     if pp > 1:   # parallel.pipeline (PipelineScheduler; chunks > 1: model.num_chunks -> InterleavedPipelineScheduler, pipeline_scheduler.py:711)
         cfg["parallel"]["pipeline"] = dict(size=pp, interleaved_overlap=chunks > 1)   # ("only support interleaved pipeline scheduler with overlap", launch.py)
         cfg["model"]["num_chunks"] = chunks
@@ -807,6 +809,12 @@ RUNS_MP = {
     # two-process Megatron tensor parallelism (parallel.tensor = dict(size=2, mode="mtp")), same model / data as pin_*: must retrace them
     "tp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2), 2),
     "tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2), 2),
+    # the sequence-sharded Megatron modes (tensor = dict(size=2, mode="msp" / "fsp")): activations between the linears split along the sequence, all-gather before
+    # the column-parallel products, reduce-scatter after the row-parallel ones, norm-weight gradients AVERAGED over the tensor group (hybrid_zero_optim.py:315-353)
+    "msp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="msp"), 2),
+    "msp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="msp"), 2),
+    "fsp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="fsp"), 2),
+    "fsp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="fsp"), 2),
     "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     # two data-parallel ranks of the MoE family: the reference then runs expert parallel (ep = 2, two of the four experts per rank, all_to_all of the

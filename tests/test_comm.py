@@ -136,3 +136,42 @@ def test_hybrid_zero_groups_for_every_data_parallel_group_of_the_job(pp, tp):
     left stage 1 with the whole data-parallel group and shards sized for two)."""
     res = _spawn(_hybrid_worker, 8, 29751 + pp, pp, tp, 2, timeout=300)
     assert all(ok for _, ok in res), res
+
+
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.tensorpar import TensorParallel
+
+        tp = TensorParallel(2, rank, world)
+        T, C = 8, 4
+        rl = tp.rows(T)
+        ok = rl == slice(rank * 4, rank * 4 + 4)
+        # a row-parallel product's partial sums -> summed into this rank's rows, in place; the other rows keep the partial (dead) values until wait()
+        part = (torch.arange(T * C, dtype=torch.float32).view(T, C) * (rank + 1)).to(torch.bfloat16)
+        before = part.clone()
+        w = tp.reduce_scatter_rows_async(part)
+        ok &= bool(torch.equal(part, before))
+        w.wait()
+        ok &= bool(torch.equal(part[rl].float(), (torch.arange(T * C, dtype=torch.float32).view(T, C) * 3)[rl]))
+        # every rank's rows -> the whole tensor, in place
+        full = torch.zeros(T, C, dtype=torch.bfloat16)
+        full[rl] = rank + 1
+        tp.all_gather_rows_async(full).wait()
+        ok &= bool((full[:4] == 1).all() and (full[4:] == 2).all())
+        # a norm weight's gradient: AVERAGED over the tensor group
+        gsum = torch.full((C,), float(rank + 1))
+        tp.all_reduce_avg(gsum)
+        ok &= bool((gsum == 1.5).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_sequence_sharded_activation_exchanges_of_the_tensor_group():
+    """tensorpar.rows / reduce_scatter_rows_async / all_gather_rows_async / all_reduce_avg (the msp / fsp modes) on two gloo ranks."""
+    res = _spawn(_rows_worker, 2, 29761)
+    assert all(ok for _, ok in res), res
