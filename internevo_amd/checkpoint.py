@@ -41,6 +41,13 @@ _PM_MODULE = "internlm.core.context.process_group_initializer"
 
 def state_dict_order(model_cfg):
     """Parameter names in the reference's module order (PackedFlashLlama1D.state_dict())."""
+    if getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "INTERNLM":   # PackedFlashInternLm1D (modeling_internlm.py; pinned by tests/golden/ckpt_v1.json)
+        names = ["embedding.weight"]
+        for l in range(model_cfg.num_layers):
+            p = f"blocks.{l}."
+            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight", p + "mixer.out_proj.bias", p + "norm1.weight", p + "norm2.weight",
+                      p + "mlp.w1.weight", p + "mlp.w2.weight", p + "mlp.w3.weight"]
+        return names + ["norm.weight", "head.weight"]
     names = ["tok_embeddings.weight"]
     llama = getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2"  # modeling_llama.py: wq, wk, wv instead of wqkv
     for l in range(model_cfg.num_layers):

@@ -288,8 +288,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     return PathConfig(model, train)
 
 
-def load_reference_config(path: str, seq_len: Optional[int] = None) -> PathConfig:
-    """Run an InternEvo `configs/*.py` and map it (parallel_context.py:77-127 semantics).  Pure-Python-style configs (configs/demo.py:2-6:
+def run_reference_config(path: str) -> dict:
+    """The variables an InternEvo `configs/*.py` defines (Config.from_file, parallel_context.py:77-127).  Pure-Python-style configs (configs/demo.py:2-6:
     `with read_base(): from configs._base_... import *`) resolve without the reference installed: `read_base` is an empty context manager
     (internlm/utils/utils.py:5-18) -- supplied here when `internlm` is not importable -- and the `configs.` package is found next to the
     file (the folder above the file's own folder goes onto sys.path for the duration of the run)."""
@@ -317,8 +317,12 @@ def load_reference_config(path: str, seq_len: Optional[int] = None) -> PathConfi
         sys.path.remove(root)
         for name in stubs + [m for m in set(sys.modules) - before if m == "configs" or m.startswith("configs.")]:
             sys.modules.pop(name, None)
-    cfg = {k: v for k, v in g.items() if not k.startswith("__") and not isinstance(v, types.ModuleType) and not callable(v)}
-    return from_reference_dict(cfg, seq_len)
+    return {k: v for k, v in g.items() if not k.startswith("__") and not isinstance(v, types.ModuleType) and not callable(v)}
+
+
+def load_reference_config(path: str, seq_len: Optional[int] = None) -> PathConfig:
+    """Run an InternEvo `configs/*.py` (run_reference_config) and map it onto this engine's PathConfig."""
+    return from_reference_dict(run_reference_config(path), seq_len)
 
 
 def internlm2_7b(seq_len=4096) -> PathConfig:

@@ -210,10 +210,13 @@ class MoEEngine:
         H, d = self.mc.num_attention_heads, self.mc.head_dim
         return t.reshape(H, 3, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
 
-    def load_named_parameters(self, named, sync_master=True):
-        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters())."""
+    def load_named_parameters(self, named, sync_master=True, views=None):
+        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters()).  views: `_views(flat)` of another buffer
+        of the same layout to fill instead of the bf16 parameters (checkpoints: master weights, moments)."""
         self._wait_optimizer()
         F = self.F
+        P = self.p if views is None else views
+        sync_master = sync_master and views is None
         for n, t in named.items():
             t = t.to(self.dev)
             if n.endswith("gate.wg.weight"):
@@ -224,26 +227,32 @@ class MoEEngine:
                 if not 0 <= e_ < self.El:
                     continue                                                                 # another rank's expert
                 if w == "w2":
-                    self.p[f"blocks.{l}.mlp.w2"][e_].copy_(t)
+                    P[f"blocks.{l}.mlp.w2"][e_].copy_(t)
                 else:
-                    self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
+                    P[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
             elif "mixer.Wqkv" in n:
-                self.p[n].copy_(self._qkv_to_engine(t))
+                P[n].copy_(self._qkv_to_engine(t))
             elif self.dense and ".mlp.w" in n:   # blocks.{l}.mlp.w1 / w2 / w3.weight -> the fused [1, 2F, h] / [1, h, F] tensors
                 l, w = int(n.split(".")[1]), n.split(".")[3]
                 if w == "w2":
-                    self.p[f"blocks.{l}.mlp.w2"][0].copy_(t)
+                    P[f"blocks.{l}.mlp.w2"][0].copy_(t)
                 else:
-                    self.p[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
+                    P[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
             else:
-                self.p[n].copy_(t)
+                P[n].copy_(t)
         if sync_master:
             self.master.copy_(self.params)
 
-    def named_parameters(self):
-        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors)."""
+    def _views(self, flat):
+        """The engine-named views of a flat buffer laid out like `params` (master weights, Adam moments)."""
+        return {n: flat[o : o + math.prod(s)].view(s) for n, (o, s) in self.spec.items()}
+
+    def named_parameters(self, views=None):
+        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors).  views: `_views(flat)` of another buffer of the same layout
+        (the fp32 master weights / moments, for checkpoints) instead of the bf16 parameters."""
         self._wait_optimizer()
         F, out = self.F, {}
+        P = self.p if views is None else views
         for n, shp in self.reference_param_shapes().items():
             if n.endswith("gate.wg.weight"):
                 out[n] = self.wg[int(n.split(".")[1])]
@@ -252,14 +261,14 @@ class MoEEngine:
                 l, e_, w = int(parts[1]), int(parts[6]) - self.ep_rank * self.El, parts[7]
                 if not 0 <= e_ < self.El:
                     continue                       # (held by another rank of the expert group)
-                out[n] = self.p[f"blocks.{l}.mlp.w2"][e_] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
+                out[n] = P[f"blocks.{l}.mlp.w2"][e_] if w == "w2" else P[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
             elif "mixer.Wqkv" in n:
-                out[n] = self._qkv_to_reference(self.p[n])
+                out[n] = self._qkv_to_reference(P[n])
             elif self.dense and ".mlp.w" in n:
                 l, w = int(n.split(".")[1]), n.split(".")[3]
-                out[n] = self.p[f"blocks.{l}.mlp.w2"][0] if w == "w2" else self.p[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
+                out[n] = P[f"blocks.{l}.mlp.w2"][0] if w == "w2" else P[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)]
             else:
-                out[n] = self.p[n]
+                out[n] = P[n]
         return out.items()
 
     def _init_params(self, seed, init_fn):
@@ -493,6 +502,54 @@ class MoEEngine:
         self.lr_sched.step()
         self.beta2_sched.step()
         self.step_count += 1
+
+    # ---- checkpoints (the dense model): InternEvo's files, internevo_amd/checkpoint.py -------------------------------------------------------
+    def _checkpoint_guard(self):
+        if not self.dense:
+            raise NotImplementedError("checkpoints of the MoE model (three optimizer groups, expert shards per expert-parallel rank) are not implemented")
+
+    def save_checkpoint(self, folder):
+        """model_tp0_pp0.pt + the hybrid-ZeRO optimizer shards in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284): this
+        engine keeps the optimizer state replicated on every data-parallel rank, so rank r writes the reference's partition r of it (a W-rank
+        reference job, or this engine at any world size, resumes from the folder).  Collective."""
+        from . import checkpoint as C
+
+        self._checkpoint_guard()
+        st = self.read_state()
+        self._wait_optimizer()
+        torch.cuda.synchronize(self.dev)
+        tc, W, r = self.tc, self.world, self.rank
+        if r == 0:
+            C.remove_stale_shards(folder, W, 1)
+        if W > 1:
+            dist.barrier(group=self.group)
+        hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
+        scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
+        cpu = lambda views: {n: t.detach().to("cpu", copy=True) for n, t in self.named_parameters(views)}  # noqa: E731
+        C.save_checkpoint(folder, self.mc, cpu(None), cpu(self._views(self.master)), cpu(self._views(self.exp_avg)), cpu(self._views(self.exp_avg_sq)),
+                          st.adam_step, scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0))
+        if W > 1:
+            dist.barrier(group=self.group)
+
+    def load_checkpoint(self, folder):
+        """Resume from InternEvo checkpoint files written by the reference or by save_checkpoint at ANY ZeRO-1 world (the shards are merged)."""
+        from . import checkpoint as C
+
+        self._checkpoint_guard()
+        ck = C.load_checkpoint(folder, self.mc)
+        self._wait_optimizer()
+        self.load_named_parameters(ck["params"], sync_master=ck["master"] is None)
+        if ck["master"] is None:
+            return
+        for flat, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
+            self.load_named_parameters(ck[key], views=self._views(flat))
+        st = K.step_state_read(self.state)
+        st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
+        st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0
+        self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.dev))
+        self.lr_sched.set_successful_steps(ck["adam_step"])
+        self.beta2_sched.set_successful_steps(ck["adam_step"])
+        self.step_count = ck["adam_step"]
 
     def read_state(self):
         st = K.step_state_read(self.state)

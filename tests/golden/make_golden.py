@@ -521,12 +521,13 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1, tp=1):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
     world = 2 (`--ckpt-mp`, one process per rank over gloo): data parallel 2 = ZeRO-1 world 2 -> ckpt_ref_dp2/ with one optimizer
-    shard and one partition-plan file per rank (hybrid_zero_optim.py:254-284)."""
+    shard and one partition-plan file per rank (hybrid_zero_optim.py:254-284).
+    model_type = "INTERNLM" (`--ckpt-v1`): the dense InternLM-1 model (modeling_internlm.py; the reference's default model type) -> ckpt_ref_v1/."""
     import shutil
 
     shim_cpu_accelerator()
@@ -549,6 +550,10 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1):
     from oracle.model import formula_init
 
     kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
+    if model_type == "INTERNLM":
+        from oracle.model import moe_formula_init as formula_init  # noqa: F811
+
+        kw = dict(kw, model_type="INTERNLM")
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=1, tp=tp)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
@@ -584,7 +589,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -655,7 +660,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1):
         if rank != 0:
             return
     rec["files"] = sorted(os.listdir(folder))
-    with open(os.path.join(HERE, "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
+    with open(os.path.join(HERE, "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
 
@@ -1216,6 +1221,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt":
         gen_checkpoint()
         sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-v1":
+        gen_checkpoint(port=29794, model_type="INTERNLM")
+        sys.exit(0)
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-rank":
         gen_checkpoint(port=29797, rank=int(sys.argv[2]), world=2)
         sys.exit(0)
@@ -1247,7 +1255,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -493,3 +493,54 @@ def test_stale_shards_of_a_larger_layout_are_removed_before_a_save(tmp_path):
     assert left == sorted(["model_tp0_pp0.pt", "topo_tp0_pp0.json", "optimizer_tp0_pp0_zo0.pt", "optimizer_tp0_pp0_zo1.pt",
                            "context.pt", "sampler.pt", "schedulder.pt"]), left   # the gpus-8 plans name another world size: all gone
     assert C.saved_zero_world(str(tmp_path)) == 2 and C.saved_tp_world(str(tmp_path)) == 1
+
+
+def _v1_model_cfg(gold):
+    from internevo_amd.config import ModelConfig
+
+    c = gold["config"]
+    return ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                       mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+
+
+def test_dense_internlm1_reference_checkpoint_loads_saves_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_v1/: the REAL reference's checkpoint of the dense InternLM-1 model (model_type INTERNLM, its default; make_golden.py
+    --ckpt-v1) after two training steps; ckpt_v1.json = the structure it saw and the two steps it trained afterwards.  The loader reads it (module
+    order, ZeRO partition plan checked inside), the writer reproduces the model and optimizer files tensor for tensor, and the oracle resumed from
+    it retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoETrainer
+
+    gold = json.load(open(os.path.join(G, "ckpt_v1.json")))
+    ref = os.path.join(G, "ckpt_ref_v1")
+    mc = _v1_model_cfg(gold)
+    ck = C.load_checkpoint(ref, mc)
+    assert [["model." + n, str(ck["params"][n].dtype), list(ck["params"][n].shape)] for n in C.state_dict_order(mc)] == gold["model_keys"]
+    assert ck["adam_step"] == 2 and ck["scaler"] == dict(scale=65536.0, growth_step=2, hysteresis_step=0)
+    for n, p in ck["params"].items():
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), p), n
+    out = str(tmp_path / "ck")
+    C.save_checkpoint(out, mc, ck["params"], ck["master"], ck["exp_avg"], ck["exp_avg_sq"], ck["adam_step"], ck["scaler"], ck["lr"],
+                      dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3))
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    a, b = ld(ref, "model_tp0_pp0.pt"), ld(out, "model_tp0_pp0.pt")
+    assert list(a) == list(b) and all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a)
+    oa, ob = C._load(os.path.join(ref, "optimizer_tp0_pp0_zo0.pt")), C._load(os.path.join(out, "optimizer_tp0_pp0_zo0.pt"))
+    assert torch.equal(oa["flat_fp32_weights"][0].detach(), ob["flat_fp32_weights"][0]) and oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"]
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(oa["base_optim_states"]["state"][0][k], ob["base_optim_states"]["state"][0][k])
+    # the oracle resumes where the reference went on
+    c = gold["config"]
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    tr = OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for w in gold["steps"][gold["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        total = sum(v * v for v in r["grad_norm"].values()) ** 0.5
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(total - w["grad_norm"]["0_default"]) <= 1e-2 * total, (r, w)
+        assert abs(r["lr"] - w["lr"]) <= 1e-12

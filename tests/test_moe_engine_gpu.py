@@ -147,6 +147,56 @@ def test_dense_internlm1_engine_matches_reference_trajectory(dev):
     assert worst <= 2e-2
 
 
+def test_dense_internlm1_engine_resumes_from_the_reference_checkpoint_and_its_own(dev, tmp_path):
+    """tests/golden/ckpt_ref_v1/ (the REAL reference's model + optimizer files of the dense InternLM-1 model after two steps, make_golden.py --ckpt-v1):
+    the HIP engine loads them and its next two steps are the reference's (ckpt_v1.json: loss <= 1e-3, gradient norm <= 2e-2, same lr and loss
+    scale); then its own save_checkpoint -> a fresh engine -> bit-identical buffers and a bit-identical next step; the saved files load back
+    through the reference-format reader."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.moe_engine import MoEEngine
+
+    gold = json.load(open(os.path.join(G, "ckpt_v1.json")))
+    c = gold["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    cfg = PathConfig(mc, tc)
+    eng = MoEEngine(cfg, dev, seed=5)
+    eng.load_checkpoint(os.path.join(G, "ckpt_ref_v1"))
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for k, w in enumerate(gold["steps"][gold["saved_after_step"]:]):
+        batch, labels = next(loader)
+        lr = eng.lr_sched.lr()
+        loss, _ = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        total = sum(v * v for v in st.group_norms.values()) ** 0.5
+        print(f"resumed step {k}: HIP loss {float(loss):.5f} norm {total:.4f} lr {lr:.3e} | reference {w['loss']:.5f} {w['grad_norm']['0_default']:.4f} {w['lr']:.3e}")
+        assert abs(float(loss) - w["loss"]) <= 1e-3 * w["loss"] and abs(total - w["grad_norm"]["0_default"]) <= 2e-2 * total
+        assert abs(lr - w["lr"]) <= 1e-12 and st.loss_scale == w["loss_scale"] and st.skip == 0
+    folder = str(tmp_path / "ck_v1")
+    eng.save_checkpoint(folder)
+    assert sorted(os.listdir(folder)) == ["gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "optimizer_tp0_pp0_zo0.pt", "topo_tp0_pp0.json"]
+    fresh = MoEEngine(cfg, dev, seed=9)
+    fresh.load_checkpoint(folder)
+    torch.cuda.synchronize()
+    for name in ("params", "master", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(eng, name), getattr(fresh, name)), name
+    batch, labels = next(loader)
+    nxt = []
+    for e in (eng, fresh):
+        loss, _ = e.forward_backward(batch, labels)
+        e.step()
+        nxt.append((float(loss), e.read_state().group_norms))
+    assert nxt[0] == nxt[1] and torch.equal(eng.params, fresh.params)
+    ck = C.load_checkpoint(folder, mc)
+    assert ck["adam_step"] == 4 and set(ck["params"]) == {n for n, _ in eng.named_parameters()}
+
+
 def test_moe_engine_runs_with_device_generated_noise_and_default_init(dev):
     """The production path: Gumbel noise from the device generator, the family's default initialisation; the loss must fall."""
     from internevo_amd.data import SyntheticLoader

@@ -12,7 +12,6 @@ resumes from `ckpt.load_ckpt_info` / `ckpt.load_ckpt_folder` (any data-parallel 
 """
 import argparse
 import os
-import runpy
 import sys
 import time
 
@@ -70,20 +69,33 @@ def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
 def _train_moe(cfg, raw, dev, world, rank, args, log):
     """The hot loop for model_type INTERNLM_MoE (configs/7B_MoE4_sft.py) on internevo_amd.moe_engine.MoEEngine: synthetic RandomDataset batches,
     forward / backward with the moe loss, the three-group optimizer step, one log line per step with the reference's loss / moe_loss /
-    per-group grad_norm keys (train/pipeline.py:494-530).  Checkpoints, validation and tokenized folders are the dense engine's: refused."""
+    per-group grad_norm keys (train/pipeline.py:494-530).  The dense INTERNLM model (the reference's default model type) runs on the same engine and
+    saves / resumes InternEvo checkpoints (model + optimizer files); validation and tokenized folders are the InternLM2 engine's: refused."""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.moe_engine import MoEEngine
 
     data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
-    if ck.get("enable_save_ckpt", False) or data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0:
-        raise NotImplementedError("INTERNLM_MoE runs: set ckpt.enable_save_ckpt=False, data.train_folder=None and data.valid_every=0 "
-                                  "(checkpoints / validation / tokenized folders are implemented for the dense model families)")
+    dense = cfg.model.model_type == "INTERNLM"
+    load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
+    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and not dense):
+        raise NotImplementedError("InternLM-1 family runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
+                                  "the InternLM2 / LLaMA engine); checkpoints are implemented for the dense INTERNLM model, not for INTERNLM_MoE")
     tc = cfg.train
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
-    loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world))
+    loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world)
+    first_step = 0
+    if load_folder and os.path.isdir(load_folder):   # model + optimizer files of the reference / of save_checkpoint, any ZeRO world; the batch stream moves on
+        eng.load_checkpoint(load_folder)
+        first_step = eng.step_count
+        log(f"load_ckpt_folder: {load_folder} (resuming at batch {first_step})")
+    loader = iter(loader_obj)
+    for _ in range(first_step):
+        next(loader)
+    every = int(ck.get("checkpoint_every", 0) or 0)
     out = []
-    for step in range(tc.total_steps):
+    for step in range(first_step, tc.total_steps):
         start = time.time()
         batch, labels = next(loader)
         loss, moe_loss = eng.forward_backward(batch, labels)
@@ -96,6 +108,10 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
             if st.skip:
                 log(f"Warning: skip parameter update at step {step}.")
             log(" ".join(f"{k}={v}" for k, v in infos.items()))
+        if save_folder and every > 0 and ((step + 1) % every == 0 or step + 1 == tc.total_steps):
+            eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))   # collective: rank r writes the reference's ZeRO partition r
+            if rank == 0:
+                log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
     if world > 1:
         torch.distributed.barrier()
     return out
@@ -103,13 +119,13 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
 
 def main(argv=None, log=print):
     args = parse_args(argv)
-    from internevo_amd.config import from_reference_dict
+    from internevo_amd.config import from_reference_dict, run_reference_config
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from internevo_amd.metrics import AccPerplex
     from internevo_amd.trainlog import TgsStatistic, get_megatron_flops, line, step_infos
 
-    raw = {k: v for k, v in runpy.run_path(args.config).items() if not k.startswith("__")}
+    raw = run_reference_config(args.config)   # (also configs that open with `with read_base(): from configs._base_... import *`)
     cfg = from_reference_dict(raw)
     tc, mc = cfg.train, cfg.model
     data_raw = raw.get("data", {}) or {}
