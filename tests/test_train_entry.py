@@ -87,6 +87,32 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_train_entry_default_model_type_is_the_dense_internlm1_model_and_resumes(dev, tmp_path):
+    """A config WITHOUT `model_type` (configs/7B_sft.py) is the reference's dense InternLM-1 model (launch.py:78-79): train.py runs it on the InternLM-1
+    engine, writes InternEvo checkpoints every 2 steps and a second run resumed from the step-2 folder reproduces steps 2 and 3 exactly."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    v1 = CFG.replace('model_type = "INTERNLM2_PUBLIC"\n', "").replace("no_bias=True, mlp_ratio=3.5", "mlp_ratio=8 / 3").replace("num_kv_attention_heads=2, ", "")
+    assert "model_type" not in v1
+    folder = str(tmp_path / "ckpts")
+    cfg1 = tmp_path / "cfg1.py"
+    cfg1.write_text(v1.format(steps=4, save=True, folder=folder, load=str(tmp_path / "none")))
+    lines = []
+    run1 = train.main(["--config", str(cfg1), "--launcher", "torch"], log=lines.append)
+    assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"] and run1[0]["loss"] > run1[3]["loss"] and run1[0]["moe_loss"] == 0.0
+    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "optimizer_tp0_pp0_zo0.pt", "topo_tp0_pp0.json"]
+    sd = torch.load(os.path.join(folder, "2", "model_tp0_pp0.pt"), weights_only=False)
+    assert list(sd)[:3] == ["model.embedding.weight", "model.blocks.0.mixer.Wqkv.weight", "model.blocks.0.mixer.Wqkv.bias"]
+    cfg2 = tmp_path / "cfg2.py"
+    cfg2.write_text(v1.format(steps=4, save=False, folder=folder, load=os.path.join(folder, "2")))
+    run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run2] == [2, 3]
+    for a, b in zip(run1[2:], run2):
+        assert (a["loss"], a["grad_norm"], a["lr"], a["loss_scale"]) == (b["loss"], b["grad_norm"], b["lr"], b["loss_scale"])
+
+
+@pytest.mark.gpu
 def test_train_entry_on_a_tokenized_folder(dev, tmp_path):
     """data.train_folder = a folder of tokenized .bin / .meta files (tests/golden/folder_fixture.py): the loader's packs (pinned
     against the real pipeline in test_tokenized_folder_pipeline_matches_reference) drive the HIP engine; the metric splits by the
