@@ -58,6 +58,28 @@ def state_dict_order(model_cfg):
     return names + ["norm.weight", "output.weight"]
 
 
+def stage_order(model_cfg, n_layers, first, last):
+    """Names in ONE pipeline stage's state dict (`model_tp{t}_pp{p}.pt`): the stage numbers its layers from 0 (modeling_internlm2.py:897-925), the
+    embedding lives on the first stage, norm + head on the last (pinned by tests/golden/ckpt_pp2_rank*.json)."""
+    import dataclasses
+
+    full = state_dict_order(dataclasses.replace(model_cfg, num_layers=n_layers))
+    head, tail = full[:1], full[-2:]
+    return (head if first else []) + full[1:-2] + (tail if last else [])
+
+
+def stage_to_global(name, layer_lo):
+    """A stage-local parameter name -> the model's name (layer number + the stage's first layer)."""
+    import re
+
+    return re.sub(r"^layers\.(\d+)\.", lambda m: f"layers.{int(m.group(1)) + layer_lo}.", name)
+
+
+def global_to_stage(name, layer_lo):
+    """The model's parameter name -> the name inside the stage whose first layer is layer_lo."""
+    return stage_to_global(name, -layer_lo)
+
+
 def zero_flat_order(named_shapes):
     """ZeRO rank-0 order of a parameter group on one rank: stable sort by numel, descending (hybrid_zero_optim.py:254-284)."""
     def numel(shape):
@@ -172,20 +194,21 @@ def _load(path):
 
 
 def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16,
-                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0):
+                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0, pp_world=1, pp_rank=0, order=None):
     """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
     hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr").
     zero_world > 1: one optimizer + plan file per rank in `zero_ranks` (default: all); the state dicts then only need the
     parameters those ranks own (zero_rank_names).  write_model=False skips the model / topology files (the reference writes them
     from data-parallel rank 0 only) and `params` may then be None if `shapes` (name -> shape, module order) is given.
     tp_world > 1: the tensors are tensor-parallel rank `tp_rank`'s LOCAL parts (tp_shard); the files carry that rank in their names
-    and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself."""
+    and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself.
+    pp_world > 1: ONE pipeline stage's files (`..._pp{pp_rank}...`); `order` = the stage's local names (stage_order) and every dict is keyed by them."""
     os.makedirs(folder, exist_ok=True)
-    order = state_dict_order(model_cfg)
+    order = state_dict_order(model_cfg) if order is None else list(order)
     if write_model:
         sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
-        torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp0.pt"))
-        torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_pp0.json"))
+        torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp{pp_rank}.pt"))
+        torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_pp{pp_rank}.json"))
     if shapes is None:
         shapes = {n: tuple(params[n].shape) for n in order}
     flat_order = zero_flat_order([(n, tuple(shapes[n])) for n in order])
@@ -216,11 +239,11 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
                 "flat_fp32_weights": {0: flat(master)},
                 "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
             }
-            torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp0_zo{r}.pt"))
-            torch.save(plan, os.path.join(folder, f"gpus-{zero_world * tp_world}_wp-0_tp-{tp_rank}_dp-{r}_pp-0_zo-{r}.pt"))
+            torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp{pp_rank}_zo{r}.pt"))
+            torch.save(plan, os.path.join(folder, f"gpus-{zero_world * tp_world * pp_world}_wp-0_tp-{tp_rank}_dp-{r}_pp-{pp_rank}_zo-{r}.pt"))
 
 
-def remove_stale_shards(folder, zero_world, tp_world):
+def remove_stale_shards(folder, zero_world, tp_world, pp_world=1):
     """Before a save into an existing folder: drop the shard / plan / topology files of an earlier save by a LARGER layout.  The
     loaders infer the saved layout from the highest file index present (saved_zero_world / saved_tp_world, as the reference's
     components.py:294-306 does), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would be merged as if
@@ -232,21 +255,22 @@ def remove_stale_shards(folder, zero_world, tp_world):
     import re
 
     for fn in sorted(os.listdir(folder)):
-        m = re.fullmatch(r"optimizer_tp(\d+)_pp0_zo(\d+)\.pt", fn)
-        stale = bool(m) and (int(m.group(1)) >= tp_world or int(m.group(2)) >= zero_world)
-        m = re.fullmatch(r"(?:model_tp(\d+)_pp0\.pt|topo_tp(\d+)_pp0\.json)", fn)
-        stale = stale or (bool(m) and int(m.group(1) or m.group(2)) >= tp_world)
-        m = re.fullmatch(r"gpus-(\d+)_wp-0_tp-(\d+)_dp-(\d+)_pp-0_zo-(\d+)\.pt", fn)
-        stale = stale or (bool(m) and (int(m.group(1)) != zero_world * tp_world or int(m.group(2)) >= tp_world or int(m.group(4)) >= zero_world))
+        m = re.fullmatch(r"optimizer_tp(\d+)_pp(\d+)_zo(\d+)\.pt", fn)
+        stale = bool(m) and (int(m.group(1)) >= tp_world or int(m.group(2)) >= pp_world or int(m.group(3)) >= zero_world)
+        m = re.fullmatch(r"(?:model_tp(\d+)_pp(\d+)\.pt|topo_tp(\d+)_pp(\d+)\.json)", fn)
+        stale = stale or (bool(m) and (int(m.group(1) or m.group(3)) >= tp_world or int(m.group(2) or m.group(4)) >= pp_world))
+        m = re.fullmatch(r"gpus-(\d+)_wp-0_tp-(\d+)_dp-(\d+)_pp-(\d+)_zo-(\d+)\.pt", fn)
+        stale = stale or (bool(m) and (int(m.group(1)) != zero_world * tp_world * pp_world or int(m.group(2)) >= tp_world or int(m.group(4)) >= pp_world
+                                       or int(m.group(5)) >= zero_world))
         if stale:
             os.remove(os.path.join(folder, fn))
             removed.append(fn)
     return removed
 
 
-def saved_zero_world(folder, tp_rank=0):
+def saved_zero_world(folder, tp_rank=0, pp_rank=0):
     """Number of ZeRO-1 optimizer shards of a tensor rank in the folder (components.py:294-306 counts them the same way); 0 = weights only."""
-    n, pre = 0, f"optimizer_tp{tp_rank}_pp0_zo"
+    n, pre = 0, f"optimizer_tp{tp_rank}_pp{pp_rank}_zo"
     for fn in os.listdir(folder):
         if fn.startswith(pre) and fn.endswith(".pt"):
             n = max(n, int(fn[len(pre):-3]) + 1)
@@ -261,10 +285,29 @@ def saved_tp_world(folder):
     return n
 
 
-def _load_tp_rank(folder, model_cfg, t, tp_world, want):
-    """One tensor rank's files -> its LOCAL named tensors (all its ZeRO shards merged)."""
-    order = state_dict_order(model_cfg)
-    sd = torch.load(os.path.join(folder, f"model_tp{t}_pp0.pt"), map_location="cpu", weights_only=False)
+def saved_pp_world(folder):
+    n = 0
+    import re
+
+    for fn in os.listdir(folder):
+        m = re.fullmatch(r"model_tp0_pp(\d+)\.pt", fn)
+        if m:
+            n = max(n, int(m.group(1)) + 1)
+    return n
+
+
+def _stage_layers(sd):
+    """Number of layers in a stage's state dict (its layers are numbered from 0)."""
+    import re
+
+    idx = [int(m.group(1)) for m in (re.match(r"(?:model\.)?layers\.(\d+)\.", k) for k in sd) if m]
+    return max(idx) + 1 if idx else 0
+
+
+def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1):
+    """One tensor rank's files (of one pipeline stage) -> its LOCAL named tensors (all its ZeRO shards merged).  want: GLOBAL names."""
+    sd = torch.load(os.path.join(folder, f"model_tp{t}_pp{pp_rank}.pt"), map_location="cpu", weights_only=False)
+    order = state_dict_order(model_cfg) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1)
     params = {}
     for n in order:
         key = "model." + n if "model." + n in sd else n
@@ -272,7 +315,7 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want):
             raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
         params[n] = sd[key].detach()
     out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
-    zero_world = saved_zero_world(folder, t)
+    zero_world = saved_zero_world(folder, t, pp_rank)
     if zero_world == 0:
         return out
     flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
@@ -281,11 +324,11 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want):
     merged = dict(master={}, exp_avg={}, exp_avg_sq={})
     head = None
     for r in range(zero_world):
-        opt_path = os.path.join(folder, f"optimizer_tp{t}_pp0_zo{r}.pt")
+        opt_path = os.path.join(folder, f"optimizer_tp{t}_pp{pp_rank}_zo{r}.pt")
         if not os.path.exists(opt_path):
             raise FileNotFoundError(f"{opt_path}: the folder holds shards up to zo{zero_world - 1} but not this one")
         st = _load(opt_path)
-        plan_path = os.path.join(folder, f"gpus-{zero_world * tp_world}_wp-0_tp-{t}_dp-{r}_pp-0_zo-{r}.pt")
+        plan_path = os.path.join(folder, f"gpus-{zero_world * tp_world * pp_world}_wp-0_tp-{t}_dp-{r}_pp-{pp_rank}_zo-{r}.pt")
         plan = _load(plan_path) if os.path.exists(plan_path) else st.get("zero_devide_optim_plan")
         if plan is not None and list(plan[0]) != plan_ids:
             raise ValueError(f"zero_devide_optim_plan of the checkpoint does not match this model's partition over {zero_world} ranks")
@@ -297,7 +340,7 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want):
                 k = 1
                 for d in shape:
                     k *= d
-                if want is None or n in want:
+                if want is None or n in want or pp_world > 1:   # (a stage's names are local: filtered after the merge)
                     into[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
                 o += k
             if o != vec.numel():
@@ -327,6 +370,31 @@ def load_checkpoint(folder, model_cfg, want=None):
     tp_world = saved_tp_world(folder)
     if tp_world == 0:
         raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")
+    pp_world = saved_pp_world(folder)
+    if pp_world > 1:
+        # one set of files per pipeline stage, each numbering its layers from 0: merged into the whole model under its own names (so that ANY layout --
+        # another pipeline size, or none -- can resume from the folder)
+        if tp_world != 1:
+            raise NotImplementedError("checkpoints with pipeline AND tensor parallelism")
+        out, lo = None, 0
+        for p_ in range(pp_world):
+            st = _load_tp_rank(folder, model_cfg, 0, 1, want, p_, pp_world)
+            n_layers = 1 + max([int(n.split(".")[1]) for n in st["params"] if n.startswith("layers.")], default=-1)
+            ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items() if want is None or stage_to_global(n, lo) in want}  # noqa: E731
+            named = {k: ({stage_to_global(n, lo): v for n, v in st[k].items()} if k == "params" else ren(st[k])) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+            if out is None:
+                out = dict(st, **named)
+            else:
+                same = ("adam_step", "lr", "scaler", "zero_world")
+                if {k: st[k] for k in same} != {k: out[k] for k in same}:
+                    raise ValueError(f"pipeline stage {p_} disagrees with stage 0 on the step / scaler / lr / ZeRO world")
+                for k, d in named.items():
+                    if d is not None:
+                        out[k].update(d)
+            lo += n_layers
+        if lo != model_cfg.num_layers:
+            raise ValueError(f"the {pp_world} pipeline stages of the checkpoint hold {lo} layers, the model {model_cfg.num_layers}")
+        return dict(out, tp_world=1, pp_world=pp_world)
     ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want) for t in range(tp_world)]
     out = dict(ranks[0], tp_world=tp_world)
     if tp_world == 1:

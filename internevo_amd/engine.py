@@ -1352,10 +1352,10 @@ class InternLM2Engine:
     def _checkpoint_guard(self):
         if self.wp_mode:
             raise NotImplementedError("checkpoints under weight parallelism are not implemented (the reference writes model_wp{w}_pp0.pt row shards)")
-        if self.pp != 1:
-            raise NotImplementedError("checkpoints under pipeline parallelism are not implemented")
+        if self.pp != 1 and (self.nch != 1 or self.tp != 1):
+            raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule without tensor parallelism")
         if self.sp != 1:
-            raise NotImplementedError("checkpoints cover pp = 1 without sequence parallelism in this round (any data-parallel and tensor-parallel size)")
+            raise NotImplementedError("checkpoints are not implemented under sequence parallelism (any data-parallel, tensor-parallel and pipeline size otherwise)")
 
     def _local_reference_named(self, named):
         """engine-named tensors of this rank -> the reference's names AND the reference's tensor-parallel cut: the layer weights are
@@ -1372,38 +1372,49 @@ class InternLM2Engine:
         return out
 
     def save_checkpoint(self, folder):
-        """InternEvo's checkpoint files (checkpoint.py): per tensor rank the model weights (written by its data-parallel rank 0) and
-        one hybrid-ZeRO optimizer shard + partition plan per data-parallel rank, in the reference's whole-parameter partition
-        (hybrid_zero_optim.py:254-284).  Collective."""
+        """InternEvo's checkpoint files (checkpoint.py): per tensor rank (and pipeline stage) the model weights (written by its data-parallel
+        rank 0) and one hybrid-ZeRO optimizer shard + partition plan per data-parallel rank, in the reference's whole-parameter partition
+        (hybrid_zero_optim.py:254-284).  A pipeline stage writes `..._pp{stage}...` files whose layers are numbered from 0, as the reference's
+        stage does (tests/golden/ckpt_ref_pp2/).  Collective."""
         from . import checkpoint as C
 
         self._checkpoint_guard()
         st = self.read_state()  # drains the optimizer stream
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
         tp, t = self.tp, self.tpar.tp_rank
-        if self.dp_rank == 0 and t == 0:   # shards of an earlier, larger layout in the same folder would be merged into this save by any loader
-            gone = C.remove_stale_shards(folder, W, tp)
+        pp, ps = self.pp, self.pipe.stage
+        if self.dp_rank == 0 and t == 0 and ps == 0:   # shards of an earlier, larger layout in the same folder would be merged into this save by any loader
+            gone = C.remove_stale_shards(folder, W, tp, pp)
             if gone:
                 print(f"[internevo_amd] save_checkpoint({folder}): removed {len(gone)} shard files of an earlier, larger layout: {', '.join(gone)}", flush=True)
-        self.comm.barrier()
-        self.tpar.barrier()
+
+        def everyone():   # the data-parallel ranks of this stage, then the stages of this pipeline: behind it every rank of the job has been here
+            self.comm.barrier()
+            self.tpar.barrier()
+            self.pipe.barrier()
+
+        everyone()
         hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
         scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
-        cpu = lambda d: {n: x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
+        # this stage's parameters under the reference's names, module order; inside the files a stage numbers its layers from 0
+        lo_layer = self.gid[0] if pp > 1 else 0
+        glob = [n for n in C.state_dict_order(self.mc) if self._engine_name(n) in self.p]
+        loc = lambda n: C.global_to_stage(n, lo_layer)  # noqa: E731
+        stage = dict(pp_world=pp, pp_rank=ps, order=[loc(n) for n in glob]) if pp > 1 else {}
+        cpu = lambda d: {loc(n): x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
         if W == 1:
             if self.dp_rank == 0:
                 C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
-                                  cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t)
-            self.comm.barrier()
-            self.tpar.barrier()
+                                  cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t, **stage)
+            everyone()
             return
         shapes = {}
         for n, shp in self.reference_param_shapes().items():  # FULL shapes -> this tensor rank's local shapes
             d = C.tp_split_dim(n)
             shapes[n] = tuple(x // tp if (tp > 1 and i == d) else x for i, x in enumerate(shp))
-        shapes = {n: shapes[n] for n in C.state_dict_order(self.mc)}
-        mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole)
-        need = {self._engine_name(n) for n in mine}
+        shapes = {loc(n): shapes[n] for n in glob}
+        mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole; stage-local names)
+        need = {self._engine_name(C.stage_to_global(n, lo_layer)) for n in mine}
         state = {}
         for key, flat in (("master", self.master), ("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             named = {}
@@ -1415,17 +1426,16 @@ class InternLM2Engine:
                         named[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape).to("cpu", copy=True)
                 del full
             ref_named = self._local_reference_named(named)
-            state[key] = {n: ref_named[n] for n in mine}
+            state[key] = {n: ref_named[C.stage_to_global(n, lo_layer)] for n in mine}
         if self.comm.replica == 0:   # hybrid ZeRO: every zero group holds the same shards, the first one writes them
             C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
-                              scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t)
-        self.comm.barrier()  # the folder is complete when any rank returns
-        self.tpar.barrier()
+                              scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t, **stage)
+        everyone()  # the folder is complete when any rank returns
 
     def load_checkpoint(self, folder):
-        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world and ANY
-        tensor-parallel size: the shards are merged into full tensors and re-cut into this engine's tensor-parallel parts and
-        bucket slices)."""
+        """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world, ANY
+        tensor-parallel size and ANY pipeline size: the shards are merged into full tensors under the model's own names and re-cut into this
+        engine's stage, tensor-parallel parts and bucket slices)."""
         from . import checkpoint as C
 
         self._checkpoint_guard()
@@ -1437,12 +1447,13 @@ class InternLM2Engine:
         self.drain()
         kind = lambda n: self.layout.params[n].kind  # noqa: E731
         for n, full in self._from_reference_names(ck["params"]).items():
-            self.p[n].copy_(self.tpar.shard(kind(n), full).to(self.dev, BF16))
+            if n in self.p:   # (a pipeline stage keeps its own layers)
+                self.p[n].copy_(self.tpar.shard(kind(n), full).to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return
         for flat, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
-            src = {n: self.tpar.shard(kind(n), full).reshape(-1) for n, full in self._from_reference_names(ck[key]).items()}
+            src = {n: self.tpar.shard(kind(n), full).reshape(-1) for n, full in self._from_reference_names(ck[key]).items() if n in self.p}
             for n, a, k, lo in pieces:
                 flat[lo : lo + k].copy_(src[n][a : a + k].to(self.dev))
         st = K.step_state_read(self.state)

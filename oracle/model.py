@@ -83,7 +83,7 @@ def forward_logits(params, mc, input_ids, indexes=None, cu_seqlens=None):
     cos, sin = O.rotary_cos_sin(int(indexes.max()) + 1, d, mc.rope_base, dt)
     if cu_seqlens is None:
         cu_seqlens = torch.tensor([0, S], dtype=torch.int32)
-    h = F.embedding(input_ids, p["tok_embeddings.weight"])
+    h = O.embedding(input_ids, p["tok_embeddings.weight"])   # (F.embedding; its backward in the CPU kernel's or the accelerator kernel's arithmetic, ops.py)
     egs = float(getattr(mc, "embed_grad_scale", 1.0))
     if egs != 1:   # modeling_internlm2.py:970-973: the value is (nearly) unchanged, the gradient into the embedding scaled by egs
         h = egs * h + (1 - egs) * h.detach()

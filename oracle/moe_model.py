@@ -71,7 +71,7 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
     cos, sin = O.rotary_cos_sin(int(indexes.max()) + 1, d, mc.rope_base, dt)
     if cu_seqlens is None:
         cu_seqlens = torch.tensor([0, S], dtype=torch.int32)
-    h = F.embedding(input_ids, p["embedding.weight"])
+    h = O.embedding(input_ids, p["embedding.weight"])
     l_auxes = []
     for l in range(mc.num_layers):
         pre = f"blocks.{l}."

@@ -521,13 +521,15 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
     world = 2 (`--ckpt-mp`, one process per rank over gloo): data parallel 2 = ZeRO-1 world 2 -> ckpt_ref_dp2/ with one optimizer
     shard and one partition-plan file per rank (hybrid_zero_optim.py:254-284).
-    model_type = "INTERNLM" (`--ckpt-v1`): the dense InternLM-1 model (modeling_internlm.py; the reference's default model type) -> ckpt_ref_v1/."""
+    model_type = "INTERNLM" (`--ckpt-v1`): the dense InternLM-1 model (modeling_internlm.py; the reference's default model type) -> ckpt_ref_v1/.
+    pp = 2 (`--ckpt-pp`, two processes): two pipeline stages of a 4-layer model -> ckpt_ref_pp2/ with one model / optimizer / plan / topo file per stage
+    (`model_tp0_pp{s}.pt`: every stage numbers its layers from 0) and ckpt_pp2_rank{s}.json."""
     import shutil
 
     shim_cpu_accelerator()
@@ -554,6 +556,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
         from oracle.model import moe_formula_init as formula_init  # noqa: F811
 
         kw = dict(kw, model_type="INTERNLM")
+    if pp > 1:
+        kw = dict(kw, layers=4, micro_num=4, pp=pp)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=1, tp=tp)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
@@ -570,7 +574,16 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
             full_shapes = param_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"],
                                                    num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"]))
             tp_rank = gpc.get_local_rank(ParallelMode.TENSOR)
-        for name, p in model.model.named_parameters():
+        if pp > 1:   # a stage numbers its layers from 0: the closed-form weights go by the GLOBAL layer number (partition_uniform)
+            import re
+
+            from internlm.solver.pipeline_utils import partition_uniform
+
+            (start, _end), = partition_uniform(kw["layers"], pp, 1)[gpc.get_local_rank(ParallelMode.PIPELINE)]
+            for name, p in model.model.named_parameters():
+                gname = re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name)
+                p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
+        for name, p in (model.model.named_parameters() if pp == 1 else ()):
             if tp > 1:
                 part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw)
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
@@ -589,7 +602,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -622,7 +635,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
         else:
             train_state.inf_nan_skip_batches += 1
         train_state.num_consumed_tokens += batch[1].nelement() * gpc.get_world_size(ParallelMode.DATA)
-        rec["steps"].append({"loss": float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+        rec["steps"].append({"loss": None if loss is None else float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
                              "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
@@ -657,9 +670,13 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None):
         import torch.distributed as dist
 
         dist.barrier()
-        if rank != 0:
+        if rank != 0 and pp == 1:
             return
     rec["files"] = sorted(os.listdir(folder))
+    if pp > 1:
+        with open(os.path.join(HERE, f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
+            json.dump(rec, f, indent=1, default=str)
+        return
     with open(os.path.join(HERE, "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
@@ -1221,6 +1238,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt":
         gen_checkpoint()
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-pp-rank":
+        gen_checkpoint(port=29793, rank=int(sys.argv[2]), world=2, pp=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-v1":
         gen_checkpoint(port=29794, model_type="INTERNLM")
         sys.exit(0)
@@ -1255,7 +1278,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

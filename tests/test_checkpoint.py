@@ -544,3 +544,52 @@ def test_dense_internlm1_reference_checkpoint_loads_saves_and_resumes(tmp_path):
         total = sum(v * v for v in r["grad_norm"].values()) ** 0.5
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(total - w["grad_norm"]["0_default"]) <= 1e-2 * total, (r, w)
         assert abs(r["lr"] - w["lr"]) <= 1e-12
+
+
+def test_pipeline_stage_checkpoint_files_of_the_reference_load_save_and_resume(tmp_path):
+    """tests/golden/ckpt_ref_pp2/: the REAL reference with parallel.pipeline = dict(size=2) on two processes (make_golden.py --ckpt-pp) wrote one model /
+    optimizer / plan / topo file per STAGE after two steps; a stage numbers its layers from 0 (model_tp0_pp1.pt holds layers.0, layers.1 = the model's
+    layers 2, 3, then norm and output).  The loader merges the stages into the whole model under its own names (any layout can resume from the folder),
+    the writer reproduces each stage's files tensor for tensor from the stage's slice, and the single-rank oracle resumed from the merge retraces the
+    reference's next two steps (ckpt_pp2_rank1.json: the last stage reports the loss)."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    ref = os.path.join(G, "ckpt_ref_pp2")
+    g0, g1 = (json.load(open(os.path.join(G, f"ckpt_pp2_rank{r}.json"))) for r in (0, 1))
+    c = g1["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    mc = cfg.model
+    assert C.saved_pp_world(ref) == 2
+    assert [["model." + n, "torch.bfloat16", None] for n in C.stage_order(mc, 2, True, False)] == [[k[0], k[1], None] for k in g0["model_keys"]]
+    assert ["model." + n for n in C.stage_order(mc, 2, False, True)] == [k[0] for k in g1["model_keys"]]
+    ck = C.load_checkpoint(ref, mc)
+    assert list(ck["params"]) == C.state_dict_order(mc) and ck["pp_world"] == 2 and ck["adam_step"] == 2
+    assert set(ck["master"]) == set(ck["params"]) == set(ck["exp_avg"])
+    # every stage's files again from its slice of the merged state
+    out = str(tmp_path / "ck")
+    for p_, (lo, n) in enumerate([(0, 2), (2, 2)]):
+        order = C.stage_order(mc, n, p_ == 0, p_ == 1)
+        cut = lambda d: {k: d[C.stage_to_global(k, lo)] for k in order}  # noqa: E731
+        C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"],
+                          dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3), pp_world=2, pp_rank=p_, order=order)
+    assert sorted(os.listdir(out)) == g1["files"]
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    for p_ in (0, 1):
+        a, b = ld(ref, f"model_tp0_pp{p_}.pt"), ld(out, f"model_tp0_pp{p_}.pt")
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+        oa, ob = C._load(os.path.join(ref, f"optimizer_tp0_pp{p_}_zo0.pt")), C._load(os.path.join(out, f"optimizer_tp0_pp{p_}_zo0.pt"))
+        assert torch.equal(oa["flat_fp32_weights"][0].detach(), ob["flat_fp32_weights"][0]) and oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"]
+        assert torch.equal(oa["base_optim_states"]["state"][0]["exp_avg_sq"], ob["base_optim_states"]["state"][0]["exp_avg_sq"])
+        assert C._load(os.path.join(ref, f"gpus-2_wp-0_tp-0_dp-0_pp-{p_}_zo-0.pt")) == C._load(os.path.join(out, f"gpus-2_wp-0_tp-0_dp-0_pp-{p_}_zo-0.pt"))
+    # the single-rank oracle resumes where the two-stage reference went on
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, g1["num_samples"]))
+    for _ in range(g1["saved_after_step"]):
+        next(loader)
+    for w in g1["steps"][g1["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)

@@ -682,6 +682,100 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1, zer
         dist.destroy_process_group()
 
 
+def _pp_ckpt_worker(rank, world, port, q, folder, dp):
+    import json
+
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.config import tiny
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+
+        G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        gold = json.load(open(os.path.join(G, "ckpt_pp2_rank1.json")))
+        c = gold["config"]
+        cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, pp_size=2)
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_pp2"))    # the reference's two-stage files (merged, re-cut into this stage)
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        out = []
+        for _ in range(2 if dp == 1 else 1):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm), eng.lr_sched.lr(), float(st.loss_scale)))
+        eng.save_checkpoint(folder)                              # ... and this engine's own stage files
+        fresh = InternLM2Engine(cfg, dev, None, world, rank, seed=50 + rank, pp_size=2)
+        fresh.load_checkpoint(folder)
+        same = all(torch.equal(getattr(eng, k), getattr(fresh, k)) for k in ("params", "master", "exp_avg", "exp_avg_sq"))
+        batch, labels = next(loader)
+        nxt = []
+        for e in (eng, fresh):
+            loss = e.forward_backward(batch, labels)
+            e.step()
+            nxt.append((float(loss), float(e.read_state().grad_norm)))
+        q.put((rank, eng.pipe.stage, out, bool(same), nxt, bool(torch.equal(eng.params, fresh.params))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dp", [1, pytest.param(2, marks=pytest.mark.ranks(4))], ids=["pp2", "pp2_dp2"])
+def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, backend, tmp_path, dp):
+    """Checkpoints under pipeline parallelism (non-interleaved): one model / optimizer / plan / topo file per STAGE with the stage's layers numbered
+    from 0, as the reference writes them (checkpoint/components.py:95-410, tests/golden/ckpt_ref_pp2/ from a real two-process run).  Two stages load the
+    reference's files and their next two steps are the reference's (ckpt_pp2_rank1.json: loss on every stage -- this engine broadcasts it -- within 1e-3,
+    global norm within 2e-2, same lr and loss scale); their own save_checkpoint writes the same file set, from which fresh engines resume
+    bit-identically and a ONE-rank engine (no pipeline) resumes to the same next loss.  dp = 2: two pipelines, ZeRO-1 shards per stage."""
+    import json
+
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(G, "ckpt_pp2_rank1.json")))
+    folder = str(tmp_path / "ck_pp2")
+    world = 2 * dp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pp_ckpt_worker, args=(r, world, 29861 + dp, q, folder, dp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for rank, stage, out, same, nxt, same_after in res:
+        assert same and same_after and nxt[0] == nxt[1], f"rank {rank} (stage {stage}): a fresh pipeline engine does not resume bit-identically"
+        if dp == 1:
+            for (loss, gn, lr, scale), w in zip(out, gold["steps"][gold["saved_after_step"]:]):
+                print(f"stage {stage}: resumed loss {loss:.5f} gn {gn:.4f} | reference {w['loss'] if w['loss'] is not None else float('nan'):.5f} {w['grad_norm']['0_default']:.4f}")
+                assert abs(gn - w["grad_norm"]["0_default"]) <= 2e-2 * gn and abs(lr - w["lr"]) <= 1e-12 and scale == w["loss_scale"]
+                assert abs(loss - w["loss"]) <= 1e-3 * w["loss"]
+    want = sorted([f"model_tp0_pp{p}.pt" for p in (0, 1)] + [f"topo_tp0_pp{p}.json" for p in (0, 1)] + [f"optimizer_tp0_pp{p}_zo{z}.pt" for p in (0, 1) for z in range(dp)]
+                  + [f"gpus-{world}_wp-0_tp-0_dp-{z}_pp-{p}_zo-{z}.pt" for p in (0, 1) for z in range(dp)])
+    assert sorted(os.listdir(folder)) == want
+    if dp == 1:   # the same folder into an engine WITHOUT pipeline parallelism
+        c = gold["config"]
+        cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+        one = InternLM2Engine(cfg, dev, seed=99)
+        one.load_checkpoint(folder)
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+        for _ in range(gold["saved_after_step"] + 2):
+            next(loader)
+        batch, labels = next(loader)
+        loss = one.forward_backward(batch, labels)
+        one.step()
+        got = (float(loss), float(one.read_state().grad_norm))
+        print("one rank from the two-stage folder:", got, "| the pipeline's next step:", res[0][4][0])
+        assert abs(got[0] - res[0][4][0][0]) <= 1e-3 * got[0] and abs(got[1] - res[0][4][0][1]) <= 2e-2 * got[1]
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("pp,dp,layers,micro_num,chunks,zero", [
     (2, 1, 3, 4, 1, None), (2, 1, 2, 1, 1, None), pytest.param(4, 1, 5, 6, 1, None, marks=pytest.mark.ranks(4)), pytest.param(2, 2, 2, 2, 1, None, marks=pytest.mark.ranks(4)),

@@ -371,7 +371,7 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
     attention call of four 4096-token sequences (flash_fwd64_k, multi-round dK/dV grid with head split), the per-micro-batch cross-entropy
     segments, one weight gradient over all 16 384 tokens -- against the CPU oracle, which walks the four micro-batches one after the
     other with autograd's bf16 gradient accumulation.  Checked: loss and global gradient norm of two steps, EVERY parameter's gradient of
-    the first step in relative l2 (sharper than the norm), the trained weights.
+    both steps in relative l2 (sharper than the norm), the trained weights.
     lr is 1e-5 here, not the recipe's 1e-4: Adam's first update is lr * sign(g) in every coordinate, so wherever |g| is at rounding level the
     sign -- and with it a 2 lr difference in that weight -- is decided by bf16 summation order; at 1e-4 on this data (loss 11.9 -> 2.3 in one
     step) that moved step 1's gradient norm by 11 % between HIP and oracle while step 0 agreed to 2e-5 / 4e-3 (measured; the benchmark
@@ -379,6 +379,7 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
+    from oracle import ops as O
     from oracle.model import formula_init
     from oracle.step import OracleTrainer
 
@@ -398,22 +399,21 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
         loss = eng.forward_backward(batch, labels)
         eng.step()
         st = eng.read_state()
-        ref = ora.train_step(batch, labels)
+        with O.embedding_grad_in_fp32():   # the accelerator kernel's arithmetic for the embedding's weight gradient (oracle/ops.py): on this data -- a handful of
+            ref = ora.train_step(batch, labels)   # tokens, each thousands of times per step -- the CPU kernel's row-by-row bf16 sum swamps (measured: 3.5 % of
+        # the embedding gradient lost at step 0, 30 % at step 1, which alone moved step 1's global norm 7.8 % away while every other gradient agreed to 3.7e-3)
         print(f"7B-width merged step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
         assert st.skip == 0
         assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])            # the north star's loss tolerance
         assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
-        if k == 0:   # the (loss-scaled, accumulated) gradients themselves: the engine's flat gradient buffer is untouched until the next backward
-            worst_g = {}
-            for n, g_ in eng.g.items():
-                want = ora.params[n].grad.float()
-                rel = float((g_.float().cpu() - want).norm() / want.norm())
-                print(f"   grad {n}: relative l2 difference {rel:.2e}")
-                # (the embedding sums thousands of bf16 rows per occurring token in the oracle's order, in fp32 here: its gap is the widest,
-                # 3.5e-2 measured)
-                worst_g[n] = rel
-            bad = {n: r for n, r in worst_g.items() if r > (6e-2 if n == "tok_embeddings.weight" else 1.5e-2)}
-            assert not bad, bad
+        # the (loss-scaled, accumulated) gradients themselves, both steps: the engine's flat gradient buffer is untouched until the next backward
+        worst_g = {}
+        for n, g_ in eng.g.items():
+            want = ora.params[n].grad.float()
+            worst_g[n] = float((g_.float().cpu() - want).norm() / want.norm())
+            print(f"   step {k} grad {n}: relative l2 difference {worst_g[n]:.2e}")
+        bad = {n: r for n, r in worst_g.items() if r > 1.5e-2}
+        assert not bad, bad
     worst = 0.0
     for n, p in eng.named_parameters():
         if n in ("layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
@@ -438,9 +438,15 @@ def test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width(dev)
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spike_7bwidth_oracle.json")
-    with open(path) as f:
+    # two committed oracle trajectories of the same recipe: the embedding's weight gradient summed per token in fp32 (torch's accelerator kernel -- and
+    # embedding_bwd_k) or row by row in bf16 (torch's CPU kernel, i.e. the arithmetic of the reference's CPU runs; oracle/ops.py).  On this data the second
+    # one swamps (a token occurs thousands of times per step): the engine is compared with the first, and must be closer to it than to the second
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gdir, "spike_7bwidth_oracle_fp32embed.json")) as f:
         gold = json.load(f)
+    with open(os.path.join(gdir, "spike_7bwidth_oracle.json")) as f:
+        cpu_arith = json.load(f)
+    assert gold["embedding_grad"].startswith("fp32") and [gold[k] for k in ("layers", "micro_num", "seq_len", "lr")] == [cpu_arith[k] for k in ("layers", "micro_num", "seq_len", "lr")]
     cfg = internlm2_7b(gold["seq_len"])
     cfg.model.num_layers = gold["layers"]
     cfg.train.micro_num = gold["micro_num"]
@@ -457,14 +463,18 @@ def test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width(dev)
         got.append((float(loss), float(st.grad_norm)))
         print(f"step {k}: HIP loss {got[-1][0]:.5f} grad_norm {got[-1][1]:.4f} | oracle loss {ref['loss']:.5f} grad_norm {ref['grad_norm']:.4f}")
     # Step 0 (identical weights) must agree to the north star's tolerances.  From then on the run is in the regime where Adam's lr * sign(g)
-    # updates at full learning rate let bf16 summation order decide individual weights (see the merged-step test above): measured on the
-    # GPU, the HIP engine stays within 1.2 % of the oracle's loss on all eight steps, excursions included (step 5: 1.850 vs 1.859 with
-    # gradient norms 121 vs 110; step 6: 0.0241 vs 0.0218 with norms 3.5 vs 2.9) -- asserted as 2.5 % + 4e-3 on the loss and 30 % on the
-    # norm -- and spikes on the same steps.
+    # updates at full learning rate let bf16 summation order decide individual weights: measured on the GPU, the HIP engine stays within 2 % of
+    # the oracle's loss on all eight steps, excursions included (step 5: 1.850 vs 1.872 with gradient norms 121.5 vs 122.3; step 6: 0.0241 vs 0.0246
+    # with norms 3.48 vs 3.55), and within 5.1 % of its gradient norm -- asserted as 2.5 % + 4e-3 on the loss and 8 % on the norm.  (Against the
+    # CPU-kernel trajectory the norms of steps 5 and 6 are 11 % and 18 % apart: the swamped embedding gradient, not a kernel.)
     for k, ((l, n), ref) in enumerate(zip(got, gold["steps"])):
-        tl, ta, tn = (1e-3, 0.0, 2e-2) if k == 0 else (2.5e-2, 4e-3, 3e-1)
+        tl, ta, tn = (1e-3, 0.0, 2e-2) if k == 0 else (2.5e-2, 4e-3, 8e-2)
         assert abs(l - ref["loss"]) <= tl * abs(ref["loss"]) + ta, (k, l, ref["loss"])
         assert abs(n - ref["grad_norm"]) <= tn * ref["grad_norm"], (k, n, ref["grad_norm"])
+    far = sum(abs(n - r["grad_norm"]) / r["grad_norm"] for (_, n), r in zip(got, cpu_arith["steps"]))
+    near = sum(abs(n - r["grad_norm"]) / r["grad_norm"] for (_, n), r in zip(got, gold["steps"]))
+    print(f"summed relative gradient-norm distance over the 8 steps: {near:.3f} to the fp32-sum oracle, {far:.3f} to the CPU-kernel oracle")
+    assert near < 0.5 * far
     ora = [r["loss"] for r in gold["steps"]]
     hip = [g_[0] for g_ in got]
     assert max(ora[3:]) >= 10 * min(ora[2:]), "the committed oracle trajectory no longer shows the excursion this test is about"

@@ -28,11 +28,16 @@ def main():
     ap.add_argument("--micro-num", type=int, default=1)
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "spike_7bwidth_oracle.json"))
+    ap.add_argument("--embed-grad-fp32", action="store_true",
+                    help="the embedding's weight gradient summed per token in fp32 (torch's accelerator kernel; oracle/ops.py) instead of the CPU kernel's row-by-row bf16 sum")
     args = ap.parse_args()
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
+    from oracle import ops as O
     from oracle.step import OracleTrainer
 
+    if args.embed_grad_fp32:
+        O.embedding_grad_in_fp32().__enter__()
     cfg = internlm2_7b(args.seq_len)
     cfg.model.num_layers = args.layers
     cfg.train.micro_num = args.micro_num
@@ -48,7 +53,7 @@ def main():
         print(f"step {k}: loss {r['loss']:.5f} grad_norm {r['grad_norm']:.4f} scale {r['loss_scale']} ({time.time() - t0:.1f} s)", flush=True)
     out = {"what": "oracle (CPU, bf16) trajectory of bench.py's recipe at 7B width", "layers": args.layers, "micro_num": args.micro_num,
            "seq_len": args.seq_len, "lr": cfg.train.lr, "total_steps": cfg.train.total_steps, "warmup_ratio": cfg.train.warmup_ratio,
-           "init": "oracle.model.formula_init", "data": "SyntheticLoader(seq_len, 1, micro_num, fixed_seqlen=True, 1_000_000)", "steps": steps,
+           "init": "oracle.model.formula_init", "embedding_grad": "fp32 sums per token (accelerator kernel)" if args.embed_grad_fp32 else "row-by-row bf16 sum (CPU kernel)", "data": "SyntheticLoader(seq_len, 1, micro_num, fixed_seqlen=True, 1_000_000)", "steps": steps,
            "threads": torch.get_num_threads()}
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
