@@ -552,10 +552,24 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
     from oracle.model import formula_init
 
     kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
-    if model_type == "INTERNLM":
+    if model_type in ("INTERNLM", "INTERNLM_MoE"):
         from oracle.model import moe_formula_init as formula_init  # noqa: F811
 
-        kw = dict(kw, model_type="INTERNLM")
+        kw = dict(kw, model_type=model_type)
+        if model_type == "INTERNLM_MoE":   # `--ckpt-moe`: 4 experts, top-2 (noise injected as in the training fixtures) -> ckpt_ref_moe/: the model file without the
+            # experts, one model_moe_layer{l}_expert{e}_tp0.pt per expert, three optimizer groups
+            import internlm.model.moe.gshard_layer as gl
+
+            from oracle import moe as MO
+
+            kw = dict(kw, num_experts=4, capacity_factor=1.0)
+            calls = {"n": 0}
+
+            def gumbel(shape, device):
+                calls["n"] += 1
+                return MO.gumbel_noise(tuple(shape), 5000 + calls["n"] - 1).to(device)
+
+            gl.gumbel_rsample = gumbel
     if pp > 1:
         kw = dict(kw, layers=4, micro_num=4, pp=pp)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
@@ -602,7 +616,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -627,7 +641,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
         trainer.zero_grad()
         if batch[0].get("type_ids", None) is not None:
             metric.set_current_type_ids(type_ids=batch[0].pop("type_ids", None))
-        _, _, loss = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        res = trainer.execute_schedule(batch, forward_only=False, return_loss=True, return_output_label=False)
+        loss, moe_loss = res[2], (res[3] if len(res) > 3 else None)   # MoE models: (outputs, labels, loss, moe_loss), no_pipeline_scheduler.py:237
         lr_used = optimizer.optim.param_groups[0]["lr"]
         ok, norms = trainer.step()
         if ok:
@@ -635,7 +650,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
         else:
             train_state.inf_nan_skip_batches += 1
         train_state.num_consumed_tokens += batch[1].nelement() * gpc.get_world_size(ParallelMode.DATA)
-        rec["steps"].append({"loss": None if loss is None else float(loss.item()), "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
+        rec["steps"].append({"loss": None if loss is None else float(loss.item()), **({"moe_loss": float(moe_loss)} if moe_loss is not None else {}),
+                             "grad_norm": {k: float(v) for k, v in norms.items()}, "ok": bool(ok),
                              "loss_scale": float(optimizer.loss_scale.item()), "lr": lr_used})
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
@@ -677,7 +693,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
         with open(os.path.join(HERE, f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
             json.dump(rec, f, indent=1, default=str)
         return
-    with open(os.path.join(HERE, "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
+    with open(os.path.join(HERE, "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
 
@@ -1244,6 +1260,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe":
+        gen_checkpoint(port=29792, model_type="INTERNLM_MoE")
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-v1":
         gen_checkpoint(port=29794, model_type="INTERNLM")
         sys.exit(0)

@@ -705,10 +705,11 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp):
         out = []
         for _ in range(2 if dp == 1 else 1):
             batch, labels = next(loader)
+            lr = eng.lr_sched.lr()
             loss = eng.forward_backward(batch, labels)
             eng.step()
             st = eng.read_state()
-            out.append((float(loss), float(st.grad_norm), eng.lr_sched.lr(), float(st.loss_scale)))
+            out.append((float(loss), float(st.grad_norm), lr, float(st.loss_scale)))
         eng.save_checkpoint(folder)                              # ... and this engine's own stage files
         fresh = InternLM2Engine(cfg, dev, None, world, rank, seed=50 + rank, pp_size=2)
         fresh.load_checkpoint(folder)

@@ -198,10 +198,12 @@ def main(argv=None, log=print):
                 continue
             val_loaders[name] = vl
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
-    if save_folder and (eng.sp > 1 or eng.pp > 1):
+    if save_folder:
         # say so at start-up instead of training until the first checkpoint_every step and dying there
-        raise NotImplementedError("ckpt.enable_save_ckpt with sequence parallelism (parallel.tensor mode 'isp') or pipeline parallelism: checkpoints "
-                                  "cover tensor sizes of mode 'mtp' and any data-parallel size; set enable_save_ckpt=False for such a run")
+        try:
+            eng._checkpoint_guard()
+        except NotImplementedError as e:
+            raise NotImplementedError(f"ckpt.enable_save_ckpt: {e}; set enable_save_ckpt=False for such a run") from None
     if val_loaders and eng.pp > 1:
         raise NotImplementedError("data.valid_every > 0 with pipeline parallelism: the forward-only pass has no pipeline schedule; set valid_every=0")
     every = int(ck.get("checkpoint_every", 0) or 0)
