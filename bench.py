@@ -113,6 +113,8 @@ def main():
                     "N must be a multiple of it; data parallelism + ZeRO-1 run inside a stage")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Megatron 'mtp') group size, parallel.tensor=dict(size=tp, mode='mtp'); "
                                                        "must divide --gpus; data parallel size = gpus / tp")
+    ap.add_argument("--tp-mode", default="mtp", choices=["mtp", "msp", "fsp"], help="parallel.tensor mode with --tp > 1: msp / fsp shard the activations between the "
+                    "linears along the sequence (reduce-scatter / all-gather of token rows instead of all-reduces)")
     ap.add_argument("--zero", type=int, default=None, help="parallel.zero1.size: ranks that share one copy of the sharded optimizer state "
                                                             "(hybrid ZeRO when smaller than the data-parallel size; default: the whole data-parallel group)")
     ap.add_argument("--wp", type=int, default=0, help="ISP weight parallelism (parallel.weight = dict(size=wp)): every rank keeps 1/wp of each layer's weights and "
@@ -175,6 +177,7 @@ def main():
     cfg.train.fixed_random_dataset_seqlen = True  # concrete synthetic input of the metric
     cfg.train.sp_size = args.sp
     cfg.train.tp_size = args.tp
+    cfg.train.tp_mode = args.tp_mode
     cfg.train.pp_size = args.pp
     cfg.train.wp_size = max(args.wp, 1)
     cfg.train.num_chunks = args.num_chunks if args.pp > 1 else 1
@@ -277,7 +280,7 @@ def main():
                                else "tiny InternLM2 (hidden 512, 2 layers)",
                    "micro_batch_execution": ("merged: the micro_num micro-batches of a step run as one varlen pass" if eng.mm > 1 else
                                              "sequential gradient accumulation" + (", weight gradients batched over the micro-batches" if eng.batch_wgrad else "")),
-                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp * args.pp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} (mtp)" if args.tp > 1 else "")
+                   "tokens_per_step": tokens_step, "parallelism": f"dp{world // (args.sp * args.tp * args.pp)}" + (f" x sp{args.sp} (Ulysses/ISP)" if args.sp > 1 else "") + (f" x tp{args.tp} ({args.tp_mode})" if args.tp > 1 else "")
                    + (f" x pp{args.pp} ({'interleaved ' if args.num_chunks > 1 else ''}1F1B{f', {args.num_chunks} chunks' if args.num_chunks > 1 else ''})" if args.pp > 1 else "")
                    + (f", weight parallel wp{eng.world} (layer weights / gradients sharded, two-slot pool)" if eng.wp_mode else "")},
         "tgs": tgs,
