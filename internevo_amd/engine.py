@@ -1043,8 +1043,8 @@ class InternLM2Engine:
         nothing saved for a backward that matters, gradients untouched).  `metric`: an AccPerplex that sees these logits instead
         of the training metric.  Returns the device scalar mean over micro-batches of the mean token loss."""
         tc = self.tc
-        if self.pp > 1:
-            raise NotImplementedError("forward-only (evaluation) passes have no pipeline schedule: run validation with parallel.pipeline.size = 1")
+        if self.pp > 1 and self.nch > 1:
+            raise NotImplementedError("forward-only (evaluation) passes under the INTERLEAVED pipeline schedule: run validation with model.num_chunks = 1")
         B, S = input_ids.shape
         if S != tc.seq_len or B % tc.micro_bsz:
             raise ValueError(f"evaluation batch {tuple(input_ids.shape)}: rows must be seq_len = {tc.seq_len} long, their number a multiple of micro_bsz = {tc.micro_bsz}")
@@ -1064,6 +1064,25 @@ class InternLM2Engine:
         out = torch.zeros(1, dtype=torch.float32, device=self.dev)
         train_metric = self.metric
         self.attach_metric(metric)  # allocates the argmax / nll rows on first use
+        if self.pp > 1:
+            # PipelineScheduler._forward_only_step (pipeline_scheduler.py:340-428): every micro-batch walks the stages once -- receive the residual
+            # stream from the previous stage, run this stage's layers, send it on; the last stage holds logits, loss and metric, and its loss is
+            # handed to every stage at the end (as the training step does)
+            P = self.pipe
+            if not hasattr(self, "_sets"):
+                self._alloc_inflight_sets()
+            try:
+                for i in range(npass):
+                    self._bind_inflight(0)
+                    P.exchange(recvs=[] if P.first else [(self.a_x[0], P.prev)])
+                    self._forward_micro(ids_d[i], lab_d[i], cu, pos_d, S)
+                    if P.last:
+                        out.add_(self.t_loss[0:1], alpha=1.0 / M)
+                    else:
+                        P.exchange(sends=[(self.t_send, P.next)])
+            finally:
+                self.metric = train_metric
+            return P.broadcast_from_last(out)
         self._bind_micro(0)
         try:
             for i in range(npass):

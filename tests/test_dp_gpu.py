@@ -682,6 +682,62 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1, zer
         dist.destroy_process_group()
 
 
+def _pp_eval_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.engine import InternLM2Engine
+        from internevo_amd.metrics import AccPerplex
+        from oracle.model import formula_init
+
+        eng = InternLM2Engine(_pp_cfg(3, 2), dev, None, world, rank, init_fn=formula_init, pp_size=2)
+        g = torch.Generator().manual_seed(9)
+        ids = torch.randint(1, 512, (4, 128), generator=g)
+        labels = torch.roll(ids, -1, dims=1)
+        labels[:, -1] = -100
+        ids[3, 100:] = 0
+        labels[3, 99:] = -100       # a zero-padded row, as the validation collate function makes them
+        metric = AccPerplex(dev, None, None, dp_world_size=world)
+        loss = float(eng.forward_only(ids, labels, metric))
+        q.put((rank, loss, metric.get_metric()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_forward_only_pass_under_pipeline_parallelism(dev, backend):
+    """PipelineScheduler._forward_only_step (pipeline_scheduler.py:340-428), the validation pass under parallel.pipeline: every micro-batch walks the two
+    stages once; the loss (on every stage, as in training) and the AccPerplex metric (summed over the job, only the last stage sees logits) equal one
+    rank's forward-only pass over the same batch."""
+    from internevo_amd.engine import InternLM2Engine
+    from internevo_amd.metrics import AccPerplex
+    from oracle.model import formula_init
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pp_eval_worker, args=(r, 2, 29867, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_pp_cfg(3, 2), dev, init_fn=formula_init)
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(1, 512, (4, 128), generator=g)
+    labels = torch.roll(ids, -1, dims=1)
+    labels[:, -1] = -100
+    ids[3, 100:] = 0
+    labels[3, 99:] = -100
+    metric = AccPerplex(dev, None, None)
+    want = float(eng.forward_only(ids, labels, metric))
+    wm = metric.get_metric()
+    (_, l0, m0), (_, l1, m1) = res
+    print("forward-only: two stages", l0, m0, "| one rank", want, wm)
+    assert l0 == l1 and m0 == m1
+    assert abs(l0 - want) <= 1e-3 * want and abs(m0["acc"] - wm["acc"]) <= 5e-3 and abs(m0["perplexity"] - wm["perplexity"]) <= 1e-2 * wm["perplexity"]
+
+
 def _pp_ckpt_worker(rank, world, port, q, folder, dp):
     import json
 

@@ -49,7 +49,9 @@ def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
     from internevo_amd.metrics import AccPerplex
 
     infos_all = {}
-    metric = AccPerplex(dev, eng.tpar.dp_group, None, dp_world_size=eng.seqpar.data_world)
+    # (pipeline parallelism: only the last stage sees logits; the metric is summed over the whole job, the other stages adding zeros -- as the training metric)
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    metric = AccPerplex(dev, eng.tpar.dp_group, None, dp_world_size=world if eng.pp > 1 else eng.seqpar.data_world)
     for name, vl in val_loaders.items():
         if len(vl) == 0:
             log(f"Validation dataset: {name} is empty")
@@ -204,8 +206,9 @@ def main(argv=None, log=print):
             eng._checkpoint_guard()
         except NotImplementedError as e:
             raise NotImplementedError(f"ckpt.enable_save_ckpt: {e}; set enable_save_ckpt=False for such a run") from None
-    if val_loaders and eng.pp > 1:
-        raise NotImplementedError("data.valid_every > 0 with pipeline parallelism: the forward-only pass has no pipeline schedule; set valid_every=0")
+    if val_loaders and eng.pp > 1 and eng.nch > 1:
+        raise NotImplementedError("data.valid_every > 0 with the interleaved pipeline schedule (model.num_chunks > 1): the forward-only pass walks the stages "
+                                  "once per micro-batch; set valid_every=0 or num_chunks=1")
     every = int(ck.get("checkpoint_every", 0) or 0)
     ctx = run_state["context"] if run_state else None
     consumed = ctx["num_consumed_tokens"] if ctx else 0
