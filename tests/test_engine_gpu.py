@@ -393,9 +393,10 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
     assert eng.mm == 4 and eng.Tg == 16384, "the merged pass must be the automatic choice here, as in bench.py"
     ora = OracleTrainer(cfg, torch.bfloat16)
     loader = iter(SyntheticLoader(4096, 1, 4, True, 4000))
-    for k in range(1):   # ONE step here (the oracle needs 75 s per 16 384-token step at this width); with two, step 1 agreed the same way once the oracle's
-        # embedding gradient used the accelerator arithmetic (measured: loss 3e-5, norm 4e-3, every gradient <= 3.8e-3); the eight-step trajectory of the
-        # benchmark recipe is retraced against a committed oracle run by the next test
+    for k in range(1):   # ONE step here (the oracle needs 75 s per 16 384-token step at this width).  Run with two steps during round 3, step 1 passed the
+        # same assertions (loss 1e-3, norm 2e-2, every gradient 1.5e-2) once the oracle's embedding gradient used the accelerator arithmetic -- with the CPU
+        # arithmetic its embedding gradient alone was 57 % away and the global norm 7.8 %.  The eight-step trajectory of the benchmark recipe is retraced
+        # against a committed oracle run by the next test
         batch, labels = next(loader)
         assert all(len(c) == 2 for c in batch["cu_seqlens"])   # one 4096-token sequence per micro-batch
         loss = eng.forward_backward(batch, labels)
