@@ -84,9 +84,10 @@ class InternLM2Engine:
         if tp_size > 1 and sp_size > 1:
             raise NotImplementedError("tensor parallelism and sequence parallelism are alternatives (parallel.tensor has ONE mode)")
         pp_size = int(getattr(tc, "pp_size", 1) if pp_size is None else pp_size)
-        if pp_size > 1 and (tp_size > 1 or sp_size > 1 or mc.checkpoint_layers):
-            raise NotImplementedError("pipeline parallelism combines with data parallelism / ZeRO only (no tensor / sequence parallelism, "
-                                      "no activation checkpointing) in this round")
+        tp_ss = tp_size > 1 and (getattr(tc, "tp_mode", "mtp") if tp_mode is None else tp_mode) in ("msp", "fsp")
+        if pp_size > 1 and (tp_ss or sp_size > 1 or mc.checkpoint_layers):
+            raise NotImplementedError("pipeline parallelism combines with data parallelism / ZeRO and Megatron tensor parallelism of mode 'mtp' (no "
+                                      "sequence-sharded tensor modes, no Ulysses / ISP sequence parallelism, no activation checkpointing)")
         self.pp = pp_size
         # every data-parallel group of the job (hybrid ZeRO creates its sub-groups collectively over all of them); a caller-supplied
         # process group is taken as the job's only one
@@ -107,10 +108,10 @@ class InternLM2Engine:
             self.world, self.rank = world_size, rank
             merge_micro, batch_wgrad = False, False   # the 1F1B schedule works on single micro-batches
         self.tpar = TensorParallel(tp_size, rank, world_size, vocab_parallel=True if vocab_parallel is None else vocab_parallel,
-                                   embed_split=getattr(mc, "embed_split_hidden", False))
+                                   embed_split=getattr(mc, "embed_split_hidden", False), stages=pp_size, stage=self.pipe.stage)
         self.embed_split = self.tpar.embed_split
         self.tp = tp_size
-        self.ss = tp_size > 1 and (getattr(tc, "tp_mode", "mtp") if tp_mode is None else tp_mode) in ("msp", "fsp")   # sequence-sharded activations
+        self.ss = tp_ss   # sequence-sharded activations
         self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
         if tp_size > 1 and not self.embed_split and self.lmc.embed_dim != mc.hidden_size:
@@ -150,10 +151,10 @@ class InternLM2Engine:
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs, dp_groups=dp_groups)
         self.sp = sp_size
         self.seqpar = SeqParallel(sp_size, rank, world_size)
-        if tp_size > 1:  # every rank of a tensor group reads the same batches
-            self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
-        if pp_size > 1:  # ... and so does every stage of a pipeline
+        if pp_size > 1:  # every stage of a pipeline reads the same batches
             self.seqpar.data_rank, self.seqpar.data_world = self.pipe.dp_rank, self.pipe.dp_world
+        if tp_size > 1:  # ... and so does every rank of a tensor group (inside a stage, under pipeline parallelism)
+            self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
         self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
         if sp_size > 1 and (mc.num_kv_attention_heads % sp_size or tc.packed_length % sp_size):
             raise ValueError("sequence parallel size must divide the kv head count and the packed length")

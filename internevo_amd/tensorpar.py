@@ -26,7 +26,10 @@ from .comm import DONE, backend_for
 
 
 class TensorParallel:
-    def __init__(self, tp_size, rank, world_size, vocab_parallel=True, embed_split=False):
+    def __init__(self, tp_size, rank, world_size, vocab_parallel=True, embed_split=False, stages=1, stage=0):
+        """rank / world_size: this rank inside ONE pipeline stage and the stage's size (the whole job without pipeline parallelism); stages / stage:
+        the pipeline size and this rank's stage -- stage s occupies the global ranks s * world_size ... (parallel_context.py: tensor is the innermost
+        dimension, then data, then pipeline).  Every rank of the job creates every group of every stage, in the same order."""
         if world_size % tp_size != 0:
             raise ValueError(f"world size {world_size} is not a multiple of the tensor-parallel size {tp_size}")
         self.tp = tp_size
@@ -42,16 +45,19 @@ class TensorParallel:
         if tp_size > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for tensor parallelism")
-            for g in range(world_size // tp_size):  # consecutive ranks form a tensor group (parallel_context.py: innermost dimension)
-                ranks = list(range(g * tp_size, (g + 1) * tp_size))
-                grp = dist.new_group(ranks)
-                if rank in ranks:
-                    self.group = grp
-            for t in range(tp_size):
-                ranks = list(range(t, world_size, tp_size))
-                grp = dist.new_group(ranks)
-                if rank in ranks:
-                    self.dp_group = grp
+            me = stage * world_size + rank
+            for s_ in range(stages):
+                base = s_ * world_size
+                for g in range(world_size // tp_size):  # consecutive ranks form a tensor group (parallel_context.py: innermost dimension)
+                    ranks = [base + r for r in range(g * tp_size, (g + 1) * tp_size)]
+                    grp = dist.new_group(ranks)
+                    if me in ranks:
+                        self.group = grp
+                for t in range(tp_size):                # the ranks of a stage that hold the same shard
+                    ranks = [base + r for r in range(t, world_size, tp_size)]
+                    grp = dist.new_group(ranks)
+                    if me in ranks:
+                        self.dp_group = grp
             self.be = backend_for(self.group)
             self.backend = self.be.name
 

@@ -25,13 +25,9 @@ def job_dp_groups(world_size, tp=1, pp=1):
     """Every data-parallel group of a job as lists of global ranks, in a job-wide fixed order: the ranks that hold the same
     model-parallel shard.  Tensor (or sequence-as-tensor) groups are consecutive ranks, so their data-parallel groups are the
     residue classes modulo tp (tensorpar.py); pipeline stages are blocks of consecutive ranks (pipeline.py), so a stage IS a
-    data-parallel group (parallel_context.py:499-520, process_group_initializer.py)."""
-    if tp > 1 and pp > 1:
-        raise NotImplementedError("pipeline x tensor parallelism")
-    if pp > 1:
-        per = world_size // pp
-        return [list(range(s * per, (s + 1) * per)) for s in range(pp)]
-    return [list(range(t, world_size, tp)) for t in range(tp)]
+    data-parallel group (parallel_context.py:499-520, process_group_initializer.py); with both, the residue classes inside every stage."""
+    per = world_size // pp   # ranks of a stage; inside it the tensor groups are the innermost dimension
+    return [[s * per + r for r in range(t, per, tp)] for s in range(pp) for t in range(tp)]
 
 
 class ZeroComm:

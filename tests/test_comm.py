@@ -175,3 +175,38 @@ def test_sequence_sharded_activation_exchanges_of_the_tensor_group():
     """tensorpar.rows / reduce_scatter_rows_async / all_gather_rows_async / all_reduce_avg (the msp / fsp modes) on two gloo ranks."""
     res = _spawn(_rows_worker, 2, 29761)
     assert all(ok for _, ok in res), res
+
+
+def _pp_tp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.pipeline import PipeParallel
+        from internevo_amd.tensorpar import TensorParallel
+        from internevo_amd.zero import job_dp_groups
+
+        pp, tp = 2, 2
+        pipe = PipeParallel(pp, rank, world)                       # stages = blocks of world / pp consecutive ranks
+        tpar = TensorParallel(tp, pipe.dp_rank, pipe.dp_world, stages=pp, stage=pipe.stage)
+        per = world // pp
+        base, local = pipe.stage * per, rank % per
+        ok = dist.get_process_group_ranks(tpar.group) == [base + (local // tp) * tp + i for i in range(tp)]        # consecutive ranks inside the stage
+        ok &= dist.get_process_group_ranks(tpar.dp_group) == [base + r for r in range(local % tp, per, tp)]         # same shard, same stage
+        ok &= dist.get_process_group_ranks(tpar.dp_group) in job_dp_groups(world, tp=tp, pp=pp)
+        ok &= dist.get_process_group_ranks(pipe.group) == [local, per + local]                                       # same position in every stage
+        ok &= (tpar.tp_rank, tpar.dp_rank, tpar.dp_world) == (local % tp, local // tp, per // tp)
+        t = torch.full((2,), float(rank))
+        tpar.all_reduce_sum(t)
+        ok &= bool((t == sum(dist.get_process_group_ranks(tpar.group))).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_tensor_groups_inside_pipeline_stages():
+    """pipeline 2 x tensor 2 x data 2 on 8 gloo ranks: tensor groups and same-shard data-parallel groups live INSIDE a stage, pipelines connect equal
+    positions of the stages (parallel_context.py: tensor innermost, then data, then pipeline), and job_dp_groups lists exactly those data-parallel groups."""
+    res = _spawn(_pp_tp_worker, 8, 29771, timeout=300)
+    assert all(ok for _, ok in res), res

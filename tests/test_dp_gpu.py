@@ -682,6 +682,65 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1, zer
         dist.destroy_process_group()
 
 
+def _pp_tp_worker(rank, world, port, q, chunks):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+        from oracle.model import formula_init
+
+        eng = InternLM2Engine(_pp_cfg(4, 4), dev, None, world, rank, init_fn=formula_init, pp_size=2, tp_size=2, num_chunks=chunks, vocab_parallel=True)
+        assert (eng.pipe.stage, eng.tpar.tp_rank, eng.dp_world) == (rank // 2, rank % 2, 1)
+        loader = iter(SyntheticLoader(128, 1, 4, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        out = []
+        for _ in range(3):
+            batch, labels = next(loader)
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            out.append((float(loss), float(eng.read_state().grad_norm)))
+        eng.drain()
+        q.put((rank, out, {n: p.float().cpu().numpy() for n, p in eng.p.items() if "norm" in n}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.ranks(4)
+@pytest.mark.parametrize("chunks", [1, 2], ids=["1f1b", "interleaved"])
+def test_pipeline_with_tensor_parallelism_equals_single_rank_step(dev, backend, chunks):
+    """parallel.pipeline = dict(size=2) together with parallel.tensor = dict(size=2, mode="mtp") on four ranks (tensor groups inside a stage, a rank's
+    pipeline peer holds the same tensor position; vocabulary-parallel loss on the last stage): loss on every rank, global gradient norm (tensor-replicated
+    parameters counted once, summed over the tensor group AND the stages) as ONE rank on the same micro-batches; norm weights stay equal inside a tensor group."""
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pp_tp_worker, args=(r, 4, 29841 + chunks, q, chunks)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 4), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    eng = InternLM2Engine(_pp_cfg(4, 4), dev, init_fn=formula_init)
+    loader = iter(SyntheticLoader(128, 1, 4, False, 4000))
+    for k in range(3):
+        batch, labels = next(loader)
+        loss = eng.forward_backward(batch, labels)
+        eng.step()
+        ref = (float(loss), float(eng.read_state().grad_norm))
+        print(f"step {k}: pp2 x tp2 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[0]:.5f} gn {ref[1]:.4f}")
+        for r in res:
+            assert r[1][k] == res[0][1][k], "every rank of the job reports the same loss and global norm"
+        assert abs(res[0][1][k][0] - ref[0]) <= 1e-3 * ref[0] and abs(res[0][1][k][1] - ref[1]) <= 2e-2 * ref[1]
+    for a, b in ((res[0], res[1]), (res[2], res[3])):   # the two tensor ranks of a stage
+        assert set(a[2]) == set(b[2]) and all((a[2][n] == b[2][n]).all() for n in a[2]), "norm weights diverged inside a tensor group"
+    assert not (set(res[0][2]) & set(res[2][2])), "the stages hold different layers"
+
+
 def _pp_eval_worker(rank, world, port, q):
     import torch.distributed as dist
 

@@ -72,7 +72,12 @@ def test_reference_config_files_map(tmp_path):
     pp = copy.deepcopy(g)
     pp["parallel"] = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=4))
     assert from_reference_dict(pp).train.pp_size == 4                       # non-interleaved 1F1B (pipeline.py)
-    pp["parallel"]["tensor"] = dict(size=2, mode="mtp")                     # ... but not together with tensor parallelism
+    pp["parallel"]["tensor"] = dict(size=2, mode="mtp")                     # ... together with Megatron tensor parallelism of mode mtp
+    assert (from_reference_dict(pp).train.pp_size, from_reference_dict(pp).train.tp_size) == (4, 2)
+    pp["parallel"]["tensor"] = dict(size=2, mode="msp")                     # ... but not with the sequence-sharded tensor modes / sequence parallelism
+    with pytest.raises(NotImplementedError):
+        from_reference_dict(pp)
+    pp["parallel"]["tensor"] = dict(size=2, mode="isp")
     with pytest.raises(NotImplementedError):
         from_reference_dict(pp)
     pp["parallel"]["tensor"] = 1
@@ -87,7 +92,7 @@ def test_reference_config_files_map(tmp_path):
         from_reference_dict(pp)
     pp["parallel"]["pipeline"] = dict(size=1)                               # without pipeline stages there is nothing to interleave
     assert from_reference_dict(pp).train.num_chunks == 1
-    # Megatron sequence parallelism: same parameter shards and numbers as mtp, run on the mtp schedule (config.py)
+    # Megatron sequence parallelism (msp / fsp): the same parameter shards as mtp, activations between the linears sharded along the sequence (engine.py seq_shard)
     assert from_reference_dict(msp).train.tp_size == 2 and from_reference_dict(msp).train.sp_size == 1
     msp["parallel"]["tensor"]["mode"] = "fsp"
     assert from_reference_dict(msp).train.tp_size == 2

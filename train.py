@@ -51,7 +51,7 @@ def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
     infos_all = {}
     # (pipeline parallelism: only the last stage sees logits; the metric is summed over the whole job, the other stages adding zeros -- as the training metric)
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    metric = AccPerplex(dev, eng.tpar.dp_group, None, dp_world_size=world if eng.pp > 1 else eng.seqpar.data_world)
+    metric = AccPerplex(dev, None if eng.pp > 1 else eng.tpar.dp_group, None, dp_world_size=world if eng.pp > 1 else eng.seqpar.data_world)
     for name, vl in val_loaders.items():
         if len(vl) == 0:
             log(f"Validation dataset: {name} is empty")
@@ -175,7 +175,9 @@ def main(argv=None, log=print):
         dataset_types = ["en", "cn", "code"]  # the dummy dataset's type list (build_dataloader.py:93)
     # pipeline parallelism: only the last stage sees logits; the others hold zero accumulators and the packed all-reduce runs over the
     # whole job, so every rank (the logging rank 0 included) reports the job's metric
-    metric = AccPerplex(dev, eng.tpar.dp_group, dataset_types, dp_world_size=world if eng.pp > 1 else dp_world)
+    # (pipeline parallelism: summed over the whole job -- only the last stage sees logits, the others add zeros; tensor ranks inside a stage count the same
+    # tokens, which leaves the accuracy and perplexity RATIOS unchanged)
+    metric = AccPerplex(dev, None if eng.pp > 1 else eng.tpar.dp_group, dataset_types, dp_world_size=world if eng.pp > 1 else dp_world)
     eng.attach_metric(metric)
     loader = iter(loader_obj)
     if run_state and run_state["sampler"] is not None:
