@@ -16,7 +16,6 @@ traffic of ISP (3x the parameter bytes per micro-batch) disappears; what remains
 the engine reproduces (engine.py `_apply_isp_grad_rule`).  The exchange itself is ONE `all_to_all_single` per tensor over
 xGMI with a single packing copy on the send side (ie_seq_head_permute); the receive buffer already is the gathered tensor.
 """
-import torch
 import torch.distributed as dist
 
 from . import kernels as K

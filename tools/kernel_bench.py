@@ -9,7 +9,6 @@ usage: python tools/kernel_bench.py [--quick] [--json out.json]
 """
 import argparse
 import json
-import math
 import os
 import sys
 
