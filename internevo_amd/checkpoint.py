@@ -48,6 +48,15 @@ def state_dict_order(model_cfg):
             names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight", p + "mixer.out_proj.bias", p + "norm1.weight", p + "norm2.weight",
                       p + "mlp.w1.weight", p + "mlp.w2.weight", p + "mlp.w3.weight"]
         return names + ["norm.weight", "head.weight"]
+    if getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "INTERNLM_MoE":   # PackedFlashInternLm1D of modeling_moe.py (pinned by tests/golden/ckpt_moe.json)
+        names = ["embedding.weight"]
+        for l in range(model_cfg.num_layers):
+            p = f"blocks.{l}."
+            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight", p + "mixer.out_proj.bias", p + "norm1.weight", p + "norm2.weight",
+                      p + "mlp.moe_layer.gate.wg.weight"]
+            for e in range(model_cfg.num_experts):
+                names += [p + f"mlp.moe_layer.experts.wrapped_experts.{e}.w{k}.weight" for k in (1, 2, 3)]
+        return names + ["norm.weight", "head.weight"]
     names = ["tok_embeddings.weight"]
     llama = getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2"  # modeling_llama.py: wq, wk, wv instead of wqkv
     for l in range(model_cfg.num_layers):
@@ -163,8 +172,9 @@ class _RefEnumModule:
                 sys.modules[name] = types.ModuleType(name)
                 self.created.append(name)
         mod = sys.modules[_PM_MODULE]
-        pm = enum.Enum("ParallelMode", {"ZERO1": "zero1"}, module=_PM_MODULE)
+        pm = enum.Enum("ParallelMode", {"ZERO1": "zero1", "EXPERT_DATA": "expert_data"}, module=_PM_MODULE)
         mod.ParallelMode = pm
+        self.pm = pm
         return pm.ZERO1
 
     def __exit__(self, *exc):
@@ -406,6 +416,113 @@ def load_checkpoint(folder, model_cfg, want=None):
     for key in ("params", "master", "exp_avg", "exp_avg_sq"):
         if ranks[0][key] is not None:
             out[key] = {n: tp_unshard(n, [r[key][n] for r in ranks]) for n in ranks[0][key]}
+    return out
+
+
+# ---- the MoE model (model_type INTERNLM_MoE): three optimizer groups, one model file per expert ---------------------------------------------------------
+# What the reference writes for it (checkpoint/components.py:31-93 try_load / try_save_moe_checkpoint, train/utils.py:25-80 create_param_groups; pinned
+# by tests/golden/ckpt_ref_moe/, make_golden.py --ckpt-moe):
+#   model_tp0_pp0.pt                               the state dict WITHOUT the experts (the gates, fp32 modules, are in it)
+#   model_moe_layer{l}_expert{e}_tp0.pt            one expert's w1 / w2 / w3 under its GLOBAL expert number
+#   optimizer_tp0_pp0_zo0.pt                       base_optim_states.state {0, 1, 2}, param_groups [default, fp32 (the gates), moe_ep_size_{ep} (the experts,
+#                                                  optimizer_mode EXPERT_DATA)], flat_fp32_weights {0, 1, 2}, the plan with one list per group
+# Covered here: one data-parallel rank (zero world 1, expert parallel size 1).
+def moe_groups(model_cfg):
+    """[(group name, parameter names in module order)] of the three optimizer groups."""
+    order = state_dict_order(model_cfg)
+    gates = [n for n in order if n.endswith("gate.wg.weight")]
+    experts = [n for n in order if ".experts." in n]
+    dense = [n for n in order if n not in set(gates) | set(experts)]
+    return [("default", dense), ("fp32", gates), ("moe_ep_size_1", experts)]
+
+
+def _expert_file(name):
+    parts = name.split(".")   # blocks.{l}.mlp.moe_layer.experts.wrapped_experts.{e}.w1.weight
+    return f"model_moe_layer{parts[1]}_expert{parts[6]}_tp0.pt"
+
+
+def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16):
+    """params: name -> host tensor (gates fp32, the rest in the model dtype); master / exp_avg / exp_avg_sq: name -> fp32 host tensor; the rest as
+    save_checkpoint."""
+    os.makedirs(folder, exist_ok=True)
+    groups = moe_groups(model_cfg)
+    experts = set(groups[2][1])
+    sd = collections.OrderedDict()
+    per_expert = collections.OrderedDict()
+    for n in state_dict_order(model_cfg):
+        t = params[n].detach().to("cpu", torch.float32 if n.endswith("gate.wg.weight") else param_dtype).contiguous()
+        if n in experts:
+            per_expert.setdefault(_expert_file(n), collections.OrderedDict())["model." + n] = t
+        else:
+            sd["model." + n] = t
+    torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
+    for fn, esd in per_expert.items():
+        torch.save(esd, os.path.join(folder, fn))
+    torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
+    flat_orders = [zero_flat_order([(n, tuple(params[n].shape)) for n in names]) for _, names in groups]
+    plan = [[_plan_ids(fo, list(range(len(fo))))] for fo in flat_orders]
+
+    def flat(named, fo):
+        return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n, _ in fo])
+
+    with _RefEnumModule() as zero1:
+        pm = type(zero1)
+        tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
+                    differentiable=False, fused=True, decoupled_weight_decay=True)
+        wd, ilr = hyper["weight_decay"], hyper["initial_lr"]
+        # key order as the reference's groups carry it
+        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=[0]),
+               dict(name="fp32", optimizer_mode=zero1, weight_decay=wd, **tail, dtype=torch.float32, initial_lr=ilr, params=[1]),
+               dict(name=groups[2][0], moe=True, optimizer_mode=pm.EXPERT_DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=[2])]
+        states = {
+            "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]), "_hysteresis_step": int(scaler["hysteresis_step"])},
+            "base_optim_states": {
+                "state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, fo), "exp_avg_sq": flat(exp_avg_sq, fo)}
+                          for g, fo in enumerate(flat_orders)},
+                "param_groups": pgs,
+            },
+            "flat_fp32_weights": {g: flat(master, fo) for g, fo in enumerate(flat_orders)},
+            "zero_devide_optim_plan": plan,
+        }
+        torch.save(states, os.path.join(folder, "optimizer_tp0_pp0_zo0.pt"))
+        torch.save(plan, os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt"))
+
+
+def load_moe_checkpoint(folder, model_cfg):
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr) of a one-rank INTERNLM_MoE checkpoint (the reference's
+    or save_moe_checkpoint's); optimizer entries None when the folder holds weights only."""
+    order = state_dict_order(model_cfg)
+    sd = dict(torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False))
+    for n in order:
+        if ".experts." in n and "model." + n not in sd:
+            sd.update(torch.load(os.path.join(folder, _expert_file(n)), map_location="cpu", weights_only=False))
+    params = {n: sd["model." + n].detach() for n in order}
+    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None)
+    opt = os.path.join(folder, "optimizer_tp0_pp0_zo0.pt")
+    if not os.path.exists(opt):
+        return out
+    if os.path.exists(os.path.join(folder, "optimizer_tp0_pp0_zo1.pt")):
+        raise NotImplementedError("INTERNLM_MoE checkpoints of more than one data-parallel rank (expert shards per expert-parallel rank) are not implemented")
+    st = _load(opt)
+    merged = dict(master={}, exp_avg={}, exp_avg_sq={})
+    for g, (_, names) in enumerate(moe_groups(model_cfg)):
+        fo = zero_flat_order([(n, tuple(params[n].shape)) for n in names])
+        if list(st["zero_devide_optim_plan"][g][0]) != _plan_ids(fo, list(range(len(fo)))):
+            raise ValueError(f"zero_devide_optim_plan of group {g} does not match this model")
+        for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
+                         ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
+            o = 0
+            for n, shape in fo:
+                k = 1
+                for d in shape:
+                    k *= d
+                merged[key][n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)
+                o += k
+            if o != vec.numel():
+                raise ValueError(f"group {g}: the flat vector holds {vec.numel()} elements, this model's group {o}")
+    gs, base = st["grad_scaler"], st["base_optim_states"]
+    out.update(merged, adam_step=int(float(base["state"][0]["step"])), lr=float(base["param_groups"][0]["lr"]),
+               scaler=dict(scale=float(gs["_scale"]), growth_step=int(gs["_growth_step"]), hysteresis_step=int(gs["_hysteresis_step"])))
     return out
 
 

@@ -210,17 +210,19 @@ class MoEEngine:
         H, d = self.mc.num_attention_heads, self.mc.head_dim
         return t.reshape(H, 3, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
 
-    def load_named_parameters(self, named, sync_master=True, views=None):
-        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters()).  views: `_views(flat)` of another buffer
-        of the same layout to fill instead of the bf16 parameters (checkpoints: master weights, moments)."""
+    def load_named_parameters(self, named, sync_master=True, views=None, gates=None):
+        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters()).  views / gates: `_views(flat)` of another
+        buffer of the same layout and the [L, E, h] fp32 tensor to fill instead of the bf16 parameters and the gate weights (checkpoints: master
+        weights, moments)."""
         self._wait_optimizer()
         F = self.F
         P = self.p if views is None else views
+        WG = self.wg if gates is None else gates
         sync_master = sync_master and views is None
         for n, t in named.items():
             t = t.to(self.dev)
             if n.endswith("gate.wg.weight"):
-                self.wg[int(n.split(".")[1])].copy_(t.float())
+                WG[int(n.split(".")[1])].copy_(t.float())
             elif ".experts." in n:
                 parts = n.split(".")
                 l, e_, w = int(parts[1]), int(parts[6]) - self.ep_rank * self.El, parts[7]   # (names carry the GLOBAL expert index)
@@ -247,15 +249,16 @@ class MoEEngine:
         """The engine-named views of a flat buffer laid out like `params` (master weights, Adam moments)."""
         return {n: flat[o : o + math.prod(s)].view(s) for n, (o, s) in self.spec.items()}
 
-    def named_parameters(self, views=None):
-        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors).  views: `_views(flat)` of another buffer of the same layout
-        (the fp32 master weights / moments, for checkpoints) instead of the bf16 parameters."""
+    def named_parameters(self, views=None, gates=None):
+        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors).  views / gates: `_views(flat)` of another buffer of the same
+        layout and an [L, E, h] fp32 tensor (the fp32 master weights / moments, for checkpoints) instead of the bf16 parameters and the gate weights."""
         self._wait_optimizer()
         F, out = self.F, {}
         P = self.p if views is None else views
+        WG = self.wg if gates is None else gates
         for n, shp in self.reference_param_shapes().items():
             if n.endswith("gate.wg.weight"):
-                out[n] = self.wg[int(n.split(".")[1])]
+                out[n] = WG[int(n.split(".")[1])]
             elif ".experts." in n:
                 parts = n.split(".")
                 l, e_, w = int(parts[1]), int(parts[6]) - self.ep_rank * self.El, parts[7]
@@ -505,8 +508,9 @@ class MoEEngine:
 
     # ---- checkpoints (the dense model): InternEvo's files, internevo_amd/checkpoint.py -------------------------------------------------------
     def _checkpoint_guard(self):
-        if not self.dense:
-            raise NotImplementedError("checkpoints of the MoE model (three optimizer groups, expert shards per expert-parallel rank) are not implemented")
+        if not self.dense and self.world != 1:
+            raise NotImplementedError("checkpoints of the MoE model cover one data-parallel rank (with more, the experts are sharded over the expert-parallel "
+                                      "group and the moe optimizer group over the expert-data group: not implemented)")
 
     def save_checkpoint(self, folder):
         """model_tp0_pp0.pt + the hybrid-ZeRO optimizer shards in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284): this
@@ -519,6 +523,13 @@ class MoEEngine:
         self._wait_optimizer()
         torch.cuda.synchronize(self.dev)
         tc, W, r = self.tc, self.world, self.rank
+        if not self.dense:   # the MoE model: the model file without the experts, one file per expert, three optimizer groups (checkpoint.save_moe_checkpoint)
+            hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
+            scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
+            cpu = lambda views, gates: {n: t.detach().to("cpu", copy=True) for n, t in self.named_parameters(views, gates)}  # noqa: E731
+            C.save_moe_checkpoint(folder, self.mc, cpu(None, None), cpu(self._views(self.master), self.wg), cpu(self._views(self.exp_avg), self.wg_m),
+                                  cpu(self._views(self.exp_avg_sq), self.wg_v), st.adam_step, scaler, self.lr_sched.lr(), hyper)
+            return
         if r == 0:
             C.remove_stale_shards(folder, W, 1)
         if W > 1:
@@ -536,13 +547,14 @@ class MoEEngine:
         from . import checkpoint as C
 
         self._checkpoint_guard()
-        ck = C.load_checkpoint(folder, self.mc)
+        ck = C.load_checkpoint(folder, self.mc) if self.dense else C.load_moe_checkpoint(folder, self.mc)
         self._wait_optimizer()
         self.load_named_parameters(ck["params"], sync_master=ck["master"] is None)
         if ck["master"] is None:
             return
-        for flat, key in ((self.master, "master"), (self.exp_avg, "exp_avg"), (self.exp_avg_sq, "exp_avg_sq")):
-            self.load_named_parameters(ck[key], views=self._views(flat))
+        scratch = torch.empty_like(self.wg)   # (the gates are fp32 parameters: their master copy IS the parameter, already loaded)
+        for flat, gates, key in ((self.master, scratch, "master"), (self.exp_avg, self.wg_m, "exp_avg"), (self.exp_avg_sq, self.wg_v, "exp_avg_sq")):
+            self.load_named_parameters(ck[key], views=self._views(flat), gates=gates)
         st = K.step_state_read(self.state)
         st.loss_scale, st.growth_step, st.hysteresis_step = ck["scaler"]["scale"], ck["scaler"]["growth_step"], ck["scaler"]["hysteresis_step"]
         st.adam_step, st.skip, st.found_inf, st.found_nan = ck["adam_step"], 0, 0, 0

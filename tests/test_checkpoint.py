@@ -593,3 +593,56 @@ def test_pipeline_stage_checkpoint_files_of_the_reference_load_save_and_resume(t
     for w in g1["steps"][g1["saved_after_step"]:]:
         r = tr.train_step(*next(loader))
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
+
+
+def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_moe/: the REAL reference's INTERNLM_MoE checkpoint (4 experts, top-2; make_golden.py --ckpt-moe) after two steps: the model
+    file without the experts, one `model_moe_layer{l}_expert{e}_tp0.pt` per expert, and an optimizer file with THREE groups (default / fp32 = the gates /
+    moe_ep_size_1 = the experts, optimizer_mode EXPERT_DATA).  checkpoint.load_moe_checkpoint reads it (module order, dtypes, the per-group plans
+    checked), save_moe_checkpoint reproduces every file tensor for tensor and key for key, and the oracle resumed from it -- gating noise continued at
+    the eighth call -- retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoETrainer
+
+    gold = json.load(open(os.path.join(G, "ckpt_moe.json")))
+    ref, c = os.path.join(G, "ckpt_ref_moe"), gold["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+    ck = C.load_moe_checkpoint(ref, mc)
+    assert [["model." + n, str(ck["params"][n].dtype), list(ck["params"][n].shape)] for n in C.state_dict_order(mc)] == gold["model_keys"]
+    assert ck["adam_step"] == 2 and ck["scaler"] == dict(scale=65536.0, growth_step=2, hysteresis_step=0)
+    assert [len(names) for _, names in C.moe_groups(mc)] == [len(v) for v in gold["param_group_order"].values()] == [15, 2, 24]
+    out = str(tmp_path / "ck")
+    C.save_moe_checkpoint(out, mc, ck["params"], ck["master"], ck["exp_avg"], ck["exp_avg_sq"], ck["adam_step"], ck["scaler"], ck["lr"],
+                          dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3))
+    assert sorted(os.listdir(out)) == [f for f in gold["files"] if f not in ("context.pt", "sampler.pt", "schedulder.pt")]
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    for fn in os.listdir(out):
+        if fn.startswith("model_"):
+            a, b = ld(ref, fn), ld(out, fn)
+            assert list(a) == list(b) and all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a), fn
+    oa, ob = C._load(os.path.join(ref, "optimizer_tp0_pp0_zo0.pt")), C._load(os.path.join(out, "optimizer_tp0_pp0_zo0.pt"))
+    assert oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"] == C._load(os.path.join(out, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt"))
+    for g in (0, 1, 2):
+        assert torch.equal(oa["flat_fp32_weights"][g].detach(), ob["flat_fp32_weights"][g])
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa["base_optim_states"]["state"][g][k], ob["base_optim_states"]["state"][g][k]), (g, k)
+        ga, gb = oa["base_optim_states"]["param_groups"][g], ob["base_optim_states"]["param_groups"][g]
+        assert list(ga) == list(gb)
+        assert all((str(ga[k]) == str(gb[k])) if k == "optimizer_mode" else (ga[k] == gb[k]) for k in ga), (ga, gb)
+        assert ("expert_data" if g == 2 else "zero1") in str(gb["optimizer_mode"])
+    # the oracle resumes where the reference went on
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    tr = OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16)
+    tr.load_state(ck)
+    tr.calls = gold["saved_after_step"] * c["micro_num"] * c["layers"]   # gating calls so far (the harness seeds the k-th call with 5000 + k)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for w in gold["steps"][gold["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["moe_loss"] - w["moe_loss"]) <= 3e-2 * w["moe_loss"], (r, w)
+        for k, v in w["grad_norm"].items():
+            assert abs(r["grad_norm"][k] - v) <= 3e-2 * v, (k, r["grad_norm"], w["grad_norm"])

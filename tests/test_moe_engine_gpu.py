@@ -197,6 +197,60 @@ def test_dense_internlm1_engine_resumes_from_the_reference_checkpoint_and_its_ow
     assert ck["adam_step"] == 4 and set(ck["params"]) == {n for n, _ in eng.named_parameters()}
 
 
+def test_moe_engine_resumes_from_the_reference_checkpoint_and_its_own(dev, tmp_path):
+    """tests/golden/ckpt_ref_moe/ (the REAL reference's INTERNLM_MoE checkpoint after two steps: model file without the experts, one file per expert, three
+    optimizer groups; make_golden.py --ckpt-moe): the HIP engine loads it and -- gating noise continued at the eighth call -- its next step is the
+    reference's (ckpt_moe.json: loss <= 1e-3, moe loss 3e-2, the three group norms 3e-2); the step after within the sanity band of near-tie routing flips;
+    then its own save_checkpoint -> a fresh engine -> bit-identical buffers (gates and their moments included) and a bit-identical next step."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.moe_engine import MoEEngine
+    from oracle import moe as MO
+
+    gold = json.load(open(os.path.join(G, "ckpt_moe.json")))
+    c = gold["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    cfg = PathConfig(mc, tc)
+    noise = lambda call, S, E: MO.gumbel_noise((S, E), 5000 + call).to(dev)  # noqa: E731
+    eng = MoEEngine(cfg, dev, seed=5, noise_fn=noise)
+    eng.load_checkpoint(os.path.join(G, "ckpt_ref_moe"))
+    eng.calls = gold["saved_after_step"] * c["micro_num"] * c["layers"]
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for k, w in enumerate(gold["steps"][gold["saved_after_step"]:]):
+        batch, labels = next(loader)
+        loss, moe_loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        print(f"resumed step {k}: HIP loss {float(loss):.5f} moe {float(moe_loss):.5f} norms {st.group_norms} | reference {w['loss']:.5f} {w['moe_loss']:.5f} {w['grad_norm']}")
+        lt, mt, nt = (1e-3, 3e-2, 3e-2) if k == 0 else (3e-2, 3e-1, 5e-1)
+        assert abs(float(loss) - w["loss"]) <= lt * w["loss"] and abs(float(moe_loss) - w["moe_loss"]) <= mt * w["moe_loss"]
+        for (gname, v), (_, want) in zip(st.group_norms.items(), w["grad_norm"].items()):
+            assert abs(v - want) <= nt * want, (k, gname, v, want)
+        assert st.loss_scale == w["loss_scale"] and st.skip == 0
+    folder = str(tmp_path / "ck_moe")
+    eng.save_checkpoint(folder)
+    assert sorted(os.listdir(folder)) == [f for f in gold["files"] if f not in ("context.pt", "sampler.pt", "schedulder.pt")]
+    fresh = MoEEngine(cfg, dev, seed=9, noise_fn=noise)
+    fresh.load_checkpoint(folder)
+    fresh.calls = eng.calls
+    torch.cuda.synchronize()
+    for name in ("params", "master", "exp_avg", "exp_avg_sq", "wg", "wg_m", "wg_v"):
+        assert torch.equal(getattr(eng, name), getattr(fresh, name)), name
+    batch, labels = next(loader)
+    nxt = []
+    for e in (eng, fresh):
+        loss, moe_loss = e.forward_backward(batch, labels)
+        e.step()
+        nxt.append((float(loss), float(moe_loss), e.read_state().group_norms))
+    assert nxt[0] == nxt[1] and torch.equal(eng.params, fresh.params) and torch.equal(eng.wg, fresh.wg)
+    assert C.load_moe_checkpoint(folder, mc)["adam_step"] == 4
+
+
 def test_moe_engine_runs_with_device_generated_noise_and_default_init(dev):
     """The production path: Gumbel noise from the device generator, the family's default initialisation; the loss must fall."""
     from internevo_amd.data import SyntheticLoader

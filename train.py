@@ -80,9 +80,9 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     dense = cfg.model.model_type == "INTERNLM"
     load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
-    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and not dense):
+    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and not dense and world > 1):
         raise NotImplementedError("InternLM-1 family runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
-                                  "the InternLM2 / LLaMA engine); checkpoints are implemented for the dense INTERNLM model, not for INTERNLM_MoE")
+                                  "the InternLM2 / LLaMA engine); INTERNLM_MoE checkpoints cover one data-parallel rank (the dense INTERNLM model: any number)")
     tc = cfg.train
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
