@@ -308,7 +308,7 @@ def main():
                 tj = json.load(f)
             traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
             traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
-                            "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes; fabric-side L2 misses incl. Infinity-Cache hits: every block of 32 tiles of an XCD re-reads its 12 operand panels)")
+                            "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes, a committed measurement -- not re-measured by this run; fabric-side L2 misses incl. Infinity-Cache hits: every block of 32 tiles of an XCD re-reads its 12 operand panels; the round-3 w1|w3 launch with the gate in its epilogue fetches the same and writes 0.47 GB more, profiles/r03_ffn_traffic.md)")
         except (OSError, KeyError, ValueError):
             pass
         out["roofline"] = {
