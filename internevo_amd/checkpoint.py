@@ -314,9 +314,11 @@ def _stage_layers(sd):
     return max(idx) + 1 if idx else 0
 
 
-def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1):
-    """One tensor rank's files (of one pipeline stage) -> its LOCAL named tensors (all its ZeRO shards merged).  want: GLOBAL names."""
-    sd = torch.load(os.path.join(folder, f"model_tp{t}_pp{pp_rank}.pt"), map_location="cpu", weights_only=False)
+def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, sd=None):
+    """One tensor rank's files (of one pipeline stage) -> its LOCAL named tensors (all its ZeRO shards merged).  want: the names (as this stage's files
+    carry them) whose optimizer tensors are kept; sd: the stage's model state dict if the caller has read it already."""
+    if sd is None:
+        sd = torch.load(os.path.join(folder, f"model_tp{t}_pp{pp_rank}.pt"), map_location="cpu", weights_only=False)
     order = state_dict_order(model_cfg) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1)
     params = {}
     for n in order:
@@ -350,7 +352,7 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1):
                 k = 1
                 for d in shape:
                     k *= d
-                if want is None or n in want or pp_world > 1:   # (a stage's names are local: filtered after the merge)
+                if want is None or n in want:
                     into[n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)  # the reference saves nn.Parameters (requires_grad)
                 o += k
             if o != vec.numel():
@@ -388,10 +390,13 @@ def load_checkpoint(folder, model_cfg, want=None):
             raise NotImplementedError("checkpoints with pipeline AND tensor parallelism")
         out, lo = None, 0
         for p_ in range(pp_world):
-            st = _load_tp_rank(folder, model_cfg, 0, 1, want, p_, pp_world)
-            n_layers = 1 + max([int(n.split(".")[1]) for n in st["params"] if n.startswith("layers.")], default=-1)
-            ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items() if want is None or stage_to_global(n, lo) in want}  # noqa: E731
-            named = {k: ({stage_to_global(n, lo): v for n, v in st[k].items()} if k == "params" else ren(st[k])) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+            sd = torch.load(os.path.join(folder, f"model_tp0_pp{p_}.pt"), map_location="cpu", weights_only=False)
+            n_layers = _stage_layers(sd)
+            # (the optimizer tensors a caller does not want -- another stage's, another ZeRO rank's -- are dropped while the flat vectors are cut, not after)
+            local_want = None if want is None else {n for n in stage_order(model_cfg, n_layers, p_ == 0, p_ == pp_world - 1) if stage_to_global(n, lo) in want}
+            st = _load_tp_rank(folder, model_cfg, 0, 1, local_want, p_, pp_world, sd=sd)
+            ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items()}  # noqa: E731
+            named = {k: ren(st[k]) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
             if out is None:
                 out = dict(st, **named)
             else:

@@ -568,6 +568,11 @@ def test_pipeline_stage_checkpoint_files_of_the_reference_load_save_and_resume(t
     ck = C.load_checkpoint(ref, mc)
     assert list(ck["params"]) == C.state_dict_order(mc) and ck["pp_world"] == 2 and ck["adam_step"] == 2
     assert set(ck["master"]) == set(ck["params"]) == set(ck["exp_avg"])
+    # `want` (what one engine rank keeps of the optimizer state: names of the whole model, any stage) is applied while the flat vectors are cut
+    some = {"layers.3.attention.wo.weight", "layers.0.ffn_norm.weight", "norm.weight"}
+    part = C.load_checkpoint(ref, mc, want=some)
+    assert set(part["master"]) == set(part["exp_avg_sq"]) == some and list(part["params"]) == C.state_dict_order(mc)
+    assert all(torch.equal(part[k][n], ck[k][n]) for k in ("master", "exp_avg", "exp_avg_sq") for n in some)
     # every stage's files again from its slice of the merged state
     out = str(tmp_path / "ck")
     for p_, (lo, n) in enumerate([(0, 2), (2, 2)]):
