@@ -63,15 +63,24 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
     """input_ids [S] (one packed row / one micro-batch).  noise_fn(layer) -> fp32 [S, E] Gumbel noise of that layer's gate.
     Returns (fp32 logits [S, V], [l_aux per layer])."""
     p = params
-    dt = p["embedding.weight"].dtype
     S = input_ids.shape[0]
-    H, d, E = mc.num_attention_heads, mc.hidden_size // mc.num_attention_heads, mc.num_experts
     if indexes is None:
         indexes = torch.arange(S)
-    cos, sin = O.rotary_cos_sin(int(indexes.max()) + 1, d, mc.rope_base, dt)
     if cu_seqlens is None:
         cu_seqlens = torch.tensor([0, S], dtype=torch.int32)
     h = O.embedding(input_ids, p["embedding.weight"])
+    h, l_auxes = run_blocks(p, mc, h, indexes, cu_seqlens, noise_fn, routes, forced)
+    x = O.rms_norm(h.float(), p["norm.weight"], mc.layer_norm_epsilon)
+    return F.linear(x, p["head.weight"]).float(), l_auxes
+
+
+def run_blocks(p, mc, h, indexes, cu_seqlens, noise_fn=None, routes=None, forced=None):
+    """The stack of PackedFlashBaseLayer1D blocks (modeling_internlm.py:56-260 / modeling_moe.py) on the residual stream h [S, hidden] of one packed row;
+    the stream keeps the dtype it comes in with (the reference's own block test feeds fp32 rows to bf16 blocks).  -> (h, [l_aux per MoE layer])."""
+    S = h.shape[0]
+    H, d, E = mc.num_attention_heads, mc.hidden_size // mc.num_attention_heads, mc.num_experts
+    dt = p["blocks.0.norm1.weight"].dtype
+    cos, sin = O.rotary_cos_sin(int(indexes.max()) + 1, d, mc.rope_base, dt)
     l_auxes = []
     for l in range(mc.num_layers):
         pre = f"blocks.{l}."
@@ -99,8 +108,7 @@ def forward_logits(params, mc, input_ids, noise_fn, indexes=None, cu_seqlens=Non
         if routes is not None:   # (diagnostics: which expert / slot every token got in this layer)
             routes.append(route)
         h = y + residual
-    x = O.rms_norm(h.float(), p["norm.weight"], mc.layer_norm_epsilon)
-    return F.linear(x, p["head.weight"]).float(), l_auxes
+    return h, l_auxes
 
 
 class OracleMoETrainer(OracleTrainer):

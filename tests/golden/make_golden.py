@@ -1002,6 +1002,48 @@ def gen_moe():
         json.dump(meta, f, indent=1)
 
 
+def gen_block_v1(port=29788):
+    """The reference's own known-answer test of the InternLM-1 block (tests/test_model/test_model_internlm.py:93-199, check_block): four
+    PackedFlashBaseLayer1D(hidden 4, 2 heads, mlp_ratio 2, rmsnorm, swiglu, use_scaled_init) in bf16 applied to its 4 x 4 input -- two sequences of two tokens
+    -- whose output must equal `standard_result` within rtol 1e-3 / atol 5e-3.  Here on CPU (the test itself needs an accelerator: its weights come from the
+    accelerator's generator, so only its tolerance band, not its bits, can be met): the same blocks, seed 1024, the two sequences as an unpacked [2, 2, 4]
+    batch; recorded are the weights, the output and, for a seeded upstream gradient, the input gradient -> block_v1.npz / block_v1.json."""
+    shim_cpu_accelerator()
+    import internlm  # noqa: F401
+    from internlm.initialize.launch import args_sanity_check, launch
+    from internlm.model.modeling_internlm import PackedFlashBaseLayer1D
+
+    cfg = tiny_config("torch.bfloat16", use_packed=False, seq_len=2, hidden=4, heads=2, kv_heads=2, vocab=16, layers=4, micro_num=1, total_steps=2,
+                      model_type="INTERNLM")
+    launch(config=cfg, rank=0, world_size=1, host="::1", port=port, backend="gloo", local_rank=0, seed=1024)
+    args_sanity_check()
+    torch.manual_seed(1024)
+    blocks = [PackedFlashBaseLayer1D(hidden_size=4, num_attention_heads=2, mlp_ratio=2, attn_drop_rate=0.0, drop_rate=0.0, dtype=torch.bfloat16,
+                                     layer_norm_epsilon=1e-5, checkpoint=False, layer_idx=lid, residual_in_fp32=False, device=torch.device("cpu"),
+                                     norm_type="rmsnorm", dropout_selective_checkpoint=True, use_scaled_init=True, use_swiglu=True, use_flash_attn=False)
+              for lid in range(4)]
+    x0 = torch.tensor([[-1.1620, 1.3113, 0.1507, 2.2698], [-1.2610, 1.0990, 0.3787, -0.3478], [1.4001, 1.1982, -0.6696, 0.3269], [1.3304, 1.2262, 1.0735, -1.1169]])
+    standard = [[-1.1621, 1.3111, 0.1509, 2.2697], [-1.2611, 1.0988, 0.3787, -0.3478], [1.4000, 1.1982, -0.6694, 0.3268], [1.3303, 1.2262, 1.0736, -1.1169]]
+    h = x0.reshape(2, 2, 4).clone().requires_grad_(True)     # cu_seqlens [0, 2, 4], indexes [0, 1, 0, 1] of the test = two rows of an unpacked batch
+    out = h
+    arrays = {"input": x0.numpy()}
+    for lid, b in enumerate(blocks):
+        b = b.to(torch.bfloat16)
+        out = b(out)
+        for n, prm in b.named_parameters():
+            arrays[f"blocks.{lid}.{n}"] = prm.detach().float().numpy()
+    dy = torch.randn(out.shape, generator=torch.Generator().manual_seed(7))
+    out.backward(dy.to(out.dtype))
+    arrays.update(output=out.detach().float().reshape(4, 4).numpy(), dy=dy.reshape(4, 4).numpy(), input_grad=h.grad.float().reshape(4, 4).numpy())
+    np.savez_compressed(os.path.join(OUT, "block_v1.npz"), **arrays)
+    meta = {"source": "tests/test_model/test_model_internlm.py:93-199 (check_block)", "standard_result": standard, "rtol": 1e-3, "atol": 5e-3,
+            "output_dtype": str(out.dtype), "hidden": 4, "heads": 2, "layers": 4, "ffn": int(blocks[0].mlp.w1.weight.shape[0]),
+            "max_abs_output_minus_standard": float((out.detach().float().reshape(4, 4) - torch.tensor(standard)).abs().max())}
+    with open(os.path.join(OUT, "block_v1.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("block_v1:", meta)
+
+
 def gen_moe_layer(port=29789):
     """The REAL GShardMOELayer (gshard_layer.py:360-498: TopKGate in fp32 behind NaiveAMP's fp32-module hooks, naive_amp.py:160-206, whose
     outputs -- combine weights, l_aux -- come back rounded to bf16; experts = FeedForward SwiGLU modules, moe/experts.py) run forward
@@ -1281,6 +1323,9 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--moe":
         gen_moe()
         sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--block-v1":
+        gen_block_v1()
+        sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--moe-layer":
         gen_moe_layer()
         sys.exit(0)
@@ -1297,7 +1342,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--block-v1", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])
