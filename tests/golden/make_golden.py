@@ -29,8 +29,8 @@ What it pins
   moe.npz / moe.json   (--moe)  the reference's top2gating + dispatch / combine einsums with injected Gumbel noise -> oracle/moe.py (groundwork
                        for SURVEY 8f rank 2; no product code yet)
   eval.json            (--eval)  evaluate_on_val_dls of the reference on its default validation set, on two sets of weights
-  (--run-mp isp2_*)    2-process ISP runs of the reference; their output is NOT committed: the reference's unpacked CPU path bypasses
-                       DistributedAttention, so they pin nothing about the sequence-parallel exchange (scope row a19)
+  (--run-mp isp2_* / isp2v1_*)  2-process ISP runs of the reference (InternLM2 / InternLM-1 blocks), fp32 and bf16 -> train_isp2*_rank{0,1}.json: pin the gradient rule, the
+                       two clipping groups of a bf16 ISP run and (InternLM-1: its CPU path runs DistributedAttention) the exchange itself (oracle/isp.py)
 
 The CPU accelerator shim is the one described in SURVEY.md section 8(c): the reference has no CPU backend,
 so the cached CUDA_Accelerator instance is re-pointed at torch CPU calls before launch().
@@ -287,13 +287,13 @@ def _full_param_slice(name, shard_shape, formula_init, rank_in_tp, tp, rank_in_w
     full = formula_init(name, full_shapes[name])
     if tuple(full.shape) == tuple(shard_shape):
         return full
-    if name == "tok_embeddings.weight":
+    if name in ("tok_embeddings.weight", "embedding.weight"):   # (InternLM2 / InternLM-1 names)
         n = full.shape[1] // tp
         return full[:, rank_in_tp * n : (rank_in_tp + 1) * n]
-    if name == "output.weight":
+    if name in ("output.weight", "head.weight"):
         n = full.shape[0] // tp
         return full[rank_in_tp * n : (rank_in_tp + 1) * n]
-    n = full.shape[0] // wp
+    n = full.shape[0] // wp     # (ISPLinear weights AND biases: rows over WEIGHT)
     return full[rank_in_wp * n : (rank_in_wp + 1) * n]
 
 
@@ -371,6 +371,11 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
 
         full_shapes = param_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
                                                num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]))
+        if cfg_kw.get("model_type") == "INTERNLM":   # the InternLM-1 block's names and shapes (biases, mlp_ratio 8 / 3)
+            from oracle.moe_model import param_shapes as v1_shapes
+
+            full_shapes = v1_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"], num_attention_heads=cfg_kw["heads"],
+                                                num_kv_attention_heads=cfg_kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
         tp_rank, wp_rank = gpc.get_local_rank(ParallelMode.TENSOR), gpc.get_local_rank(ParallelMode.WEIGHT)
     tp = cfg_kw.get("tp", 1)
     pp = cfg_kw.get("pp", 1)
@@ -855,6 +860,13 @@ RUNS_MP = {
     "fsp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="fsp"), 2),
     "isp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
     "isp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2), 2),
+    # the same two-process ISP shape on the dense InternLM-1 model (configs/7B_isp_sft.py names no model_type: launch.py:78-79 -> INTERNLM).  Its unpacked
+    # CPU path DOES run DistributedAttention (multi_head_attention.py:394,634-660: self.inner_attn(qkv), the qkv-packed exchange) over the gathered
+    # sequence, with the rotary positions restarting in every rank's chunk
+    "isp2v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2,
+                                          model_type="INTERNLM"), 2),
+    "isp2v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2,
+                                           model_type="INTERNLM"), 2),
     # two data-parallel ranks of the MoE family: the reference then runs expert parallel (ep = 2, two of the four experts per rank, all_to_all of the
     # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
     "moe2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
