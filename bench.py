@@ -123,7 +123,13 @@ def main():
                                                                "attention forward; moves a bf16 rounding point away from the reference's -- see engine.py)")
     ap.add_argument("--sp", type=int, default=1, help="sequence-parallel (Ulysses / ISP) group size, parallel.tensor=dict(size=sp, mode='isp'); "
                                                        "must divide --gpus; data parallel size = gpus / sp")
+    ap.add_argument("--rccl-channels", type=int, default=0, help="N > 1 diagnostics: cap RCCL's channel count (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS = n, set before the "
+                    "communicator is created): fewer channels = fewer CUs held by a collective, for longer (DESIGN.md section 6); 0 = RCCL's default")
+    ap.add_argument("--rs-under-w13-only", action="store_true", help="N > 1 diagnostics: launch a layer bucket's gradient reduce-scatter in front of the next layer's "
+                    "w1 | w3 backward products instead of right behind its last weight gradient (engine rs_under_w13)")
     args = ap.parse_args()
+    if args.rccl_channels > 0:   # (inherited by the ranks of a self-launched run; read by RCCL when the communicator is created)
+        os.environ["NCCL_MAX_NCHANNELS"] = os.environ["NCCL_MIN_NCHANNELS"] = str(args.rccl_channels)
 
     from internevo_amd import kernels as K
     from internevo_amd.config import internlm2_7b, llama2_7b, tiny
@@ -187,7 +193,7 @@ def main():
     tc, mc = cfg.train, cfg.model
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=1024, batch_wgrad=False if args.no_batch_wgrad else None,
                           merge_micro=None if args.merge_micro is None else bool(args.merge_micro), zero_size=args.zero, scale_on_q=args.scale_on_q,
-                          weight_parallel=True if args.wp else None)
+                          weight_parallel=True if args.wp else None, rs_under_w13=args.rs_under_w13_only)
     if world > 1:
         eng.comm.broadcast_params(eng.params)  # over the data-parallel group (the ranks that hold the same shard)
         eng.sync_master_from_params()
@@ -221,6 +227,10 @@ def main():
     if not args.no_kernel_timing:
         prof = K.KernelProfiler()
         K.GEMM_PROFILER = prof
+    from internevo_amd import comm as C_
+
+    waits = C_.WaitTimer()   # exposed communication: HIP events around every Work.wait() of the timed steps (comm.py; nothing is recorded on one rank)
+    C_.TIMER = waits
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -228,9 +238,17 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     K.GEMM_PROFILER = None
+    C_.TIMER = None
+    # per rank and step: milliseconds the waiting stream stood still in Work.wait(), by collective kind; over the ranks: max and mean
+    kinds = ("reduce_scatter", "all_gather", "all_reduce", "all_to_all", "send_recv", "broadcast", "other")
+    ws = waits.summary()
+    exposed = torch.tensor([ws.get(k, (0.0, 0))[0] / args.steps for k in kinds] + [float(sum(v[1] for v in ws.values())) / args.steps], device=dev, dtype=torch.float64)
+    exp_max, exp_sum = exposed.clone(), exposed.clone()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dt = float(all_reduce(t, "max"))
+        all_reduce(exp_max, "max")
+        all_reduce(exp_sum)
     st = eng.read_state()
     loss_val = float(loss)
     # what every rank sees of the communicator (rank 0 prints it: a job that silently ran as N independent 1-rank jobs would show here)
@@ -242,6 +260,16 @@ def main():
         comm_info = {"backend": "gloo, all ranks on ONE GPU, host-staged collectives (IE_BENCH_BACKEND test hook: NOT a measurement)" if staged
                      else torch.distributed.get_backend() + " (RCCL over xGMI)", "rccl_world_size_per_rank": [int(x) for x in seen.tolist()]}
     comm_info.update(data_parallel_size=eng.dp_world, zero_shards_per_bucket=eng.world, zero_replicas=eng.comm.n_replica)
+    comm_info["exposed_wait_ms_per_step"] = {
+        "what": "time the waiting HIP stream stood still inside Work.wait() per step (events on that stream around every wait of the timed steps), by collective "
+                "kind: gradient reduce-scatters (+ the hybrid-ZeRO second hop under all_reduce), parameter all-gathers, norm / tensor-parallel all-reduces, "
+                "Ulysses / expert all-to-alls, pipeline send-recv; max and mean over the ranks",
+        "max_over_ranks": {k: round(float(exp_max[i]), 3) for i, k in enumerate(kinds) if float(exp_max[i]) > 0},
+        "mean_over_ranks": {k: round(float(exp_sum[i]) / world, 3) for i, k in enumerate(kinds) if float(exp_sum[i]) > 0},
+        "total_max_over_ranks": round(float(exp_max[: len(kinds)].sum()), 3), "total_mean_over_ranks": round(float(exp_sum[: len(kinds)].sum()) / world, 3),
+        "waits_per_step_mean": round(float(exp_sum[-1]) / world, 1)}
+    comm_info["rccl_channels"] = args.rccl_channels or "default"
+    comm_info["gradient_reduce_scatter_launch"] = "in front of the next layer's w1|w3 backward products" if eng.rs_under_w13 else "behind the bucket's last weight gradient"
     if world > 1 and args.tp == 1 and args.pp == 1 and not eng.wp_mode:
         # data-parallel replicas must hold bit-identical parameters after the timed steps (reduce-scatter -> AdamW on the shard -> all-gather):
         # every rank's checksum, gathered; a broken exchange would show here instead of as a plausible-looking throughput

@@ -81,7 +81,7 @@ def stage_to_global(name, layer_lo):
     """A stage-local parameter name -> the model's name (layer number + the stage's first layer)."""
     import re
 
-    return re.sub(r"^layers\.(\d+)\.", lambda m: f"layers.{int(m.group(1)) + layer_lo}.", name)
+    return re.sub(r"^(layers|blocks)\.(\d+)\.", lambda m: f"{m.group(1)}.{int(m.group(2)) + layer_lo}.", name)   # (InternLM2 / InternLM-1 names)
 
 
 def global_to_stage(name, layer_lo):
@@ -310,7 +310,7 @@ def _stage_layers(sd):
     """Number of layers in a stage's state dict (its layers are numbered from 0)."""
     import re
 
-    idx = [int(m.group(1)) for m in (re.match(r"(?:model\.)?layers\.(\d+)\.", k) for k in sd) if m]
+    idx = [int(m.group(1)) for m in (re.match(r"(?:model\.)?(?:layers|blocks)\.(\d+)\.", k) for k in sd) if m]
     return max(idx) + 1 if idx else 0
 
 

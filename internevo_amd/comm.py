@@ -23,19 +23,49 @@ import torch
 import torch.distributed as dist
 
 
+class WaitTimer:
+    """Exposed communication time (bench.py): while `comm.TIMER` holds one of these, every Work.wait() is bracketed by two HIP events on the caller's
+    current stream -- the first completes when the stream reaches the wait, the second when the stream may continue behind the collective -- so their
+    distance is the time the COMPUTE stream stood still for that collective (0 when the collective had finished under earlier kernels).  No host
+    synchronisation; read with `summary()` after the timed region."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def summary(self):
+        """{kind: (milliseconds the waiting stream was held, number of waits)} -- synchronises."""
+        out = {}
+        for kind, e0, e1 in self.pairs:
+            e1.synchronize()
+            ms, n = out.get(kind, (0.0, 0))
+            out[kind] = (ms + e0.elapsed_time(e1), n + 1)
+        return out
+
+
+TIMER = None   # a WaitTimer while bench.py times its steps
+
+
 class Work:
     """A collective in flight.  wait(): order the caller's current stream behind it (and, staged backend, land the result)."""
 
-    def __init__(self, handle=None, land=None):
-        self._handle, self._land = handle, land
+    def __init__(self, handle=None, land=None, kind=None):
+        self._handle, self._land, self.kind = handle, land, kind
 
     def wait(self):
+        timer = TIMER if (self._handle is not None or self._land is not None) and torch.cuda.is_available() else None
+        if timer is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self._handle is not None:
             self._handle.wait()
             self._handle = None
         if self._land is not None:
             land, self._land = self._land, None
             land()
+        if timer is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            timer.pairs.append((self.kind or "other", e0, e1))
         return True
 
 
@@ -47,21 +77,21 @@ class RcclBackend:
 
     def reduce_scatter(self, shard, full, group, avg=True):
         """full -> this rank's 1/world part, reduced over the group; `shard` may be (and in the engine is) the rank's own slice of `full`."""
-        return Work(dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
+        return Work(dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True), kind="reduce_scatter")
 
     def all_reduce(self, t, group, avg=False):
-        return Work(dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
+        return Work(dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True), kind="all_reduce")
 
     def all_gather(self, full, shard, group):
         """every rank's `shard` -> `full` (rank order); `shard` may be the rank's own slice of `full`."""
-        return Work(dist.all_gather_into_tensor(full, shard, group=group, async_op=True))
+        return Work(dist.all_gather_into_tensor(full, shard, group=group, async_op=True), kind="all_gather")
 
     def all_to_all(self, recv, send, group):
         """chunk r of the flat `send` -> rank r; chunk s of the flat `recv` <- rank s."""
-        return Work(dist.all_to_all_single(recv.view(-1), send.view(-1), group=group, async_op=True))
+        return Work(dist.all_to_all_single(recv.view(-1), send.view(-1), group=group, async_op=True), kind="all_to_all")
 
     def broadcast(self, t, src, group):
-        return Work(dist.broadcast(t, src=src, group=group, async_op=True))
+        return Work(dist.broadcast(t, src=src, group=group, async_op=True), kind="broadcast")
 
     def exchange(self, sends, recvs):
         """[(tensor, global peer rank)] each: the sends and receives that may proceed together, as ONE batch (RCCL runs the point-to-point
@@ -76,7 +106,7 @@ class RcclBackend:
                 for w in works:
                     w.wait()
 
-        return Work(_All())
+        return Work(_All(), kind="send_recv")
 
 
 def _host(t):
@@ -98,7 +128,7 @@ class StagedGlooBackend:
         part = acc.view(-1)[r * n : (r + 1) * n]
         if avg:
             part = part / world
-        return Work(land=lambda: shard.view(-1).copy_(part.to(shard.dtype)))
+        return Work(land=lambda: shard.view(-1).copy_(part.to(shard.dtype)), kind="reduce_scatter")
 
     def all_reduce(self, t, group, avg=False):
         c = _host(t)
@@ -106,24 +136,24 @@ class StagedGlooBackend:
         dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
         if avg:
             wide = wide / dist.get_world_size(group)
-        return Work(land=lambda: t.copy_(wide.to(t.dtype)))
+        return Work(land=lambda: t.copy_(wide.to(t.dtype)), kind="all_reduce")
 
     def all_gather(self, full, shard, group):
         c = _host(shard)
         parts = [torch.empty_like(c) for _ in range(dist.get_world_size(group))]
         dist.all_gather(parts, c, group=group)
-        return Work(land=lambda: full.view(-1).copy_(torch.cat([p.view(-1) for p in parts])))
+        return Work(land=lambda: full.view(-1).copy_(torch.cat([p.view(-1) for p in parts])), kind="all_gather")
 
     def all_to_all(self, recv, send, group):
         s = _host(send).view(-1)
         r = torch.empty_like(s)
         dist.all_to_all_single(r, s, group=group)
-        return Work(land=lambda: recv.view(-1).copy_(r))
+        return Work(land=lambda: recv.view(-1).copy_(r), kind="all_to_all")
 
     def broadcast(self, t, src, group):
         c = _host(t)
         dist.broadcast(c, src=src, group=group)
-        return Work(land=lambda: t.copy_(c))
+        return Work(land=lambda: t.copy_(c), kind="broadcast")
 
     def exchange(self, sends, recvs):
         if not sends and not recvs:
@@ -138,7 +168,7 @@ class StagedGlooBackend:
             for (t, _), (c, _) in zip(recvs, host_r):
                 t.copy_(c)
 
-        return Work(land=land)
+        return Work(land=land, kind="send_recv")
 
 
 def backend_for(group=None):

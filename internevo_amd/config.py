@@ -47,6 +47,11 @@ class ModelConfig:
     norm_head: bool = False              # the head multiplies by its weight with every row scaled to unit length (F.normalize)
 
     @property
+    def attn_bias(self):
+        """The InternLM-1 block (modeling_internlm.py / modeling_moe.py; multi_head_attention.py:371-408): Wqkv and out_proj carry a bias."""
+        return self.model_type in ("INTERNLM", "INTERNLM_MoE")
+
+    @property
     def head_dim(self):
         return self.head_dim_override or self.hidden_size // self.num_attention_heads
 
@@ -99,7 +104,7 @@ class ModelConfig:
 
     def num_params(self):
         h, f, v = self.hidden_size, self.ffn_dim, self.vocab_size
-        per_layer = self.qkv_dim * h + h * h + 3 * f * h + 2 * h
+        per_layer = self.qkv_dim * h + h * h + 3 * f * h + 2 * h + (self.qkv_dim + h if self.attn_bias else 0)
         return per_layer * self.num_layers + 2 * v * h + h
 
 
@@ -198,10 +203,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")
     moe_kw = {}
     if model_type == "INTERNLM" or (model_type == "INTERNLM_MoE" and m.get("num_experts", 1) <= 1):
-        # the dense InternLM-1 model (modeling_internlm.py, configs/7B_sft.py; INTERNLM_MoE with one expert builds the same block): MoEEngine's
-        # dense branch -- data parallelism only
-        if sp_size > 1 or tp_size > 1 or pp_size > 1:
-            raise NotImplementedError(f"{_UNSUPPORTED}: the InternLM-1 family with tensor / sequence / pipeline parallelism (data parallelism only)")
+        # the dense InternLM-1 model (modeling_internlm.py; configs/7B_sft.py, configs/7B_isp_sft.py; INTERNLM_MoE with one expert builds the same block):
+        # engine.InternLM2Engine's InternLM-1 block variant (packed Wqkv "(three h d)" + biases) under every parallel mode of that engine
         if not m.get("use_swiglu", True) or m.get("residual_in_fp32", False) or m.get("num_kv_attention_heads", m["num_attention_heads"]) != m["num_attention_heads"]:
             raise NotImplementedError(f"{_UNSUPPORTED}: InternLM-1 with use_swiglu=False / residual_in_fp32 / grouped-query attention")
         moe_kw = dict(num_experts=1)
@@ -238,7 +241,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.norm_type {m.get('norm_type')!r} (rmsnorm only)")
     if m.get("apply_post_layer_norm", False):
         raise NotImplementedError(f"{_UNSUPPORTED}: model.apply_post_layer_norm")
-    if (m.get("embed_grad_scale", 1) != 1 or m.get("norm_head", False)) and (model_type != "INTERNLM2_PUBLIC" or pp_size > 1):
+    if (m.get("embed_grad_scale", 1) != 1 or m.get("norm_head", False)) and (model_type != "INTERNLM2_PUBLIC" or pp_size > 1):   # (norm_head: InternLM2's head only)
         raise NotImplementedError(f"{_UNSUPPORTED}: model.embed_grad_scale != 1 / model.norm_head outside the InternLM2 family or with pipeline parallelism")
     num_chunks = int(m.get("num_chunks", 1))
     if num_chunks > 1:
@@ -268,9 +271,9 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         num_attention_heads=m["num_attention_heads"], num_kv_attention_heads=m.get("num_kv_attention_heads", m["num_attention_heads"]),
         mlp_ratio=m.get("mlp_ratio", 4), layer_norm_epsilon=m.get("layer_norm_epsilon", 1e-5), rope_base=m.get("rope_base", 10000),
         # builder defaults differ: modeling_internlm2.py:1071 adapt_hf=True, modeling_llama.py:1039 adapt_hf=False
-        adapt_hf=m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
+        adapt_hf=True if model_type in ("INTERNLM", "INTERNLM_MoE") else m.get("adapt_hf", model_type != "LLAMA2"), checkpoint=ck, model_type=model_type,
         embed_grad_scale=float(m.get("embed_grad_scale", 1)), norm_head=bool(m.get("norm_head", False)),
-        embed_split_hidden=bool(m.get("embed_split_hidden", False)) and model_type not in ("INTERNLM_MoE", "INTERNLM"), **moe_kw,
+        embed_split_hidden=bool(m.get("embed_split_hidden", False)) and model_type != "INTERNLM_MoE", **moe_kw,
     )
     adam, ls, gs = cfg["adam"], cfg["lr_scheduler"], cfg["grad_scaler"]
     hz = cfg["hybrid_zero_optimizer"]

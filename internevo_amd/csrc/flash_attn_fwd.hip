@@ -853,6 +853,7 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     // backward kernels (they recompute the scores from the q they are given) would not see
     const bool prescaled = fabsf(softmax_scale * kLog2e - 1.f) < 1e-6f;
     const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? (prescaled ? 3 : 2) : 0);
+#ifdef IE_ENABLE_ABLATIONS   // profiling builds only (hipcc -DIE_ENABLE_ABLATIONS): the shipped library holds no kernel with wrong results
     if (fwd_variant >= 10 && d == 128 && causal) {   // timing ablations of the folded kernel (results wrong)
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_LA(AB)                                                                                                                     \
@@ -873,6 +874,7 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
 #undef IE_LA
         return ie_launch_status("ie_flash_attn_fwd launch");
     }
+#endif
     if (fwd_variant >= 3) {
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_LF(DD, CA)                                                                                                                 \
@@ -907,7 +909,13 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
 
 // tuning hook (A/B benchmarking only): kernel variant of the forward
 extern "C" int ie_tune_flash_fwd_variant(int variant) {
+#ifdef IE_ENABLE_ABLATIONS
     IE_CHECK_ARG(variant >= -1 && variant <= 60, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3 (10 + ABL: timing ablations of variant 3)");
+#else
+    // (forcing 3 at a softmax_scale other than ln 2 scales q inside the kernel: one more bf16 rounding of q than the backward kernels see -- correct to
+    // bf16 rounding, tested in tests/test_kernels_gpu.py, but not what the automatic dispatch ever picks)
+    IE_CHECK_ARG(variant >= -1 && variant <= 3, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3");
+#endif
     g_fwd_variant = variant;
     return IE_OK;
 }

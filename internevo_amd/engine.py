@@ -45,7 +45,7 @@ _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None, tp_mode=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None, tp_mode=None, rs_under_w13=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
@@ -66,6 +66,10 @@ class InternLM2Engine:
         backward, the next layer's gather running on a side stream under this layer's kernels, and its weight gradients are
         reduce-scattered (AVG) out of a pool slot every micro-batch and accumulated in the resident shard.  None = automatic: on only when
         the config asks for wp > 1 AND the resident layout (weights whole on every GPU) does not fit this GPU's memory; False = resident.
+        rs_under_w13 (default off; IE_RS_UNDER_W13=1): a layer bucket's gradient reduce-scatter is launched in front of the NEXT layer's w1 | w3 backward
+        products (28 rounds of tiles each at the 7B shapes) instead of right behind the layer's last weight gradient, where it first meets the 4- and
+        6-round wo / wqkv products of the layer below: a collective that holds a few CUs costs every product it overlaps one more round of tiles
+         -- an A/B switch for the first multi-GPU runs, same results.
         scale_on_q (default off): the rotary kernel stores q already multiplied by softmax_scale * log2 e (ie_qkv_rotary_fwd_scaled) and
         attention runs at softmax_scale = ln 2, which lets the forward take the folded-softmax kernel (+7 % on the 4 x 4096 attention call,
         profiles/r03_flash_fwd_folded.md).  Same mathematics, but q is rounded to bf16 AFTER the scale instead of before it as the reference
@@ -91,7 +95,9 @@ class InternLM2Engine:
         self.pp = pp_size
         # every data-parallel group of the job (hybrid ZeRO creates its sub-groups collectively over all of them); a caller-supplied
         # process group is taken as the job's only one
-        dp_groups = job_dp_groups(world_size, tp=tp_size, pp=pp_size) if process_group is None else None
+        # (under tensor / pipeline parallelism the engine derives the per-shard data-parallel groups itself, whatever group the caller handed in: every
+        # rank of the job must then create the SAME list of hybrid-ZeRO sub-groups -- dist.new_group is collective over the default group)
+        dp_groups = job_dp_groups(world_size, tp=tp_size, pp=pp_size) if (process_group is None or tp_size > 1 or pp_size > 1) else None
         self.pipe = PipeParallel(pp_size, rank, world_size)
         # this stage's layers in the reference's numbering: one range, or one range per model chunk (interleaved schedule); `chunks` = the
         # same ranges in local layer indices, `gid[l]` = the global number of local layer l
@@ -111,6 +117,9 @@ class InternLM2Engine:
                                    embed_split=getattr(mc, "embed_split_hidden", False), stages=pp_size, stage=self.pipe.stage)
         self.embed_split = self.tpar.embed_split
         self.tp = tp_size
+        self.rs_under_w13 = bool(int(os.environ.get("IE_RS_UNDER_W13", "0")) if rs_under_w13 is None else rs_under_w13)
+        self._rs_deferred = None
+        self.bias = bool(getattr(mc, "attn_bias", False))   # the InternLM-1 block: Wqkv / out_proj with bias (model_type INTERNLM)
         self.ss = tp_ss   # sequence-sharded activations
         self.vp = self.tpar.vocab_parallel   # vocabulary-parallel head + loss
         self.lmc = mc.tp_shard(tp_size, self.vp)   # what this rank holds / computes: 1/tp of the heads, of the FFN width and of the head's rows
@@ -206,6 +215,13 @@ class InternLM2Engine:
         self.lr_sched = CosineWarmupLR(tc.lr, tc.total_steps, tc.warmup_ratio, tc.eta_min, tc.init_steps)
         self.beta2_sched = Beta2Scheduler(tc.adam_beta2, tc.adam_beta2_c)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        # ISP (tensor mode "isp"): embedding and head are the optimizer group "1_embed_head" (train/utils.py:42-43), the rest "0_default"; every group has
+        # its own norm and is unscaled / clipped by its OWN factor (hybrid_zero_optim.py:760-779,863-876; pinned on tests/golden/train_isp2*_bf16_rank*.json)
+        self.isp_groups = self.isp_rule > 1
+        if self.isp_groups:
+            self.sumsq_g = torch.zeros(2, dtype=torch.float32, device=device)
+            self.group_inv = torch.zeros(2, dtype=torch.float32, device=device)
+            self.group_norm = torch.zeros(2, dtype=torch.float32, device=device)
         self.sumsq_ws = torch.empty(K._L().ie_sumsq_max_partials() * (len(L.buckets) + 1), dtype=torch.float32, device=device)
 
         # ---- scale_on_q: the rotary kernel stores bf16(q * scale * log2 e) (one rounding, like the unscaled q), attention is called with
@@ -255,7 +271,9 @@ class InternLM2Engine:
         if not self.batch_wgrad and device.type == "cuda" and os.environ.get("IE_KEEP_ACT", "1") != "0":   # (IE_KEEP_ACT=0: A/B switch)
             lm = self.lmc
             nslot = len(self.a_w13)
-            need = 2 * nslot * self.T * lm.ffn_dim
+            # under pipeline parallelism a stage keeps one activation SET per in-flight micro-batch (up to pp, or the interleaved plan's slot count)
+            sets = 1 if pp_size == 1 else (min(pp_size - self.pipe.stage, tc.micro_num) if self.nch == 1 else tc.micro_num)
+            need = 2 * nslot * self.T * lm.ffn_dim * sets
             if need + (24 << 30) < torch.cuda.mem_get_info(device)[0]:
                 self.a_act = [torch.empty(self.T, lm.ffn_dim, dtype=BF16, device=device) for _ in range(nslot)]
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
@@ -279,14 +297,20 @@ class InternLM2Engine:
         # of the same full model (the reference seeds TENSOR mode with seed + tp_rank for the same purpose,
         # parallel_context.py:639-641), and a tp = n run starts from exactly the weights of the tp = 1 run with the same seed.
         gen = torch.Generator(device=self.dev).manual_seed(seed)
+        v1 = self._is_v1()
         for n, full in FlatLayout(mc, 1).params.items():   # (a pipeline stage draws the whole sequence too and keeps its layers)
-            if full.kind == "norm":
+            if full.kind == "norm" or full.kind in ("bqkv", "bo"):   # unit norm gains, zero biases
                 if n in self.p:
-                    self._store_param(n, torch.ones(full.shape, dtype=BF16, device=self.dev))
+                    self._store_param(n, self.tpar.shard(full.kind, (torch.ones if full.kind == "norm" else torch.zeros)(full.shape, dtype=BF16, device=self.dev)))
                 continue
             std = mc.init_std
             if mc.use_scaled_init and full.kind in ("wo", "w2"):
                 std = mc.init_std / math.sqrt(2.0 * (full.layer + 1))
+            if v1:   # modeling_internlm.py:161-195,:331-333,:380-382: normal(0.006) Wqkv / w1 / w3, normal(0.0015) (0.006 / sqrt(2 (l + 1)) with use_scaled_init)
+                     # out_proj / w2, normal(0.0052) embedding / head
+                std = 0.0052 if full.kind in ("embed", "head") else 0.006
+                if full.kind in ("wo", "w2"):
+                    std = 0.006 / math.sqrt(2.0 * (full.layer + 1)) if mc.use_scaled_init else 0.0015
             w = torch.empty(full.shape, dtype=torch.float32, device=self.dev).normal_(0.0, std, generator=gen)
             if n in self.p:
                 self._store_param(n, self.tpar.shard(full.kind, w))
@@ -368,6 +392,8 @@ class InternLM2Engine:
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
         # transient
         self.t_qkv = e(T, mc.qkv_dim)
+        if self.bias:
+            self.t_bias = e(max(mc.qkv_dim, h))   # a micro-batch's bias gradient on its way into the accumulated one
         self.t_h0, self.t_h1, self.t_h2 = e(T, h), e(T, h), e(T, h)
         self.t_h3 = e(T, h) if nck else None          # wo output of a recomputed layer (t_h0..2 carry gradients then)
         self.t_act = e(T, F)
@@ -468,10 +494,12 @@ class InternLM2Engine:
         self._slot_layer[slot] = None
         full, shard = self.pool_p[slot][: b.size], self._shard(self.params, b)
         if not self.comm.active:      # one rank: the shard is the bucket (the pool logic runs, the collectives are identities)
+            self._wait_bucket(b.index)   # the optimizer stream may still be updating the shard (the multi-rank branch waits for the same event)
             full.copy_(shard)
             self._wp_inflight[l] = None
             return
         if self.wp_stream is None:   # CPU tensors (tests)
+            self._wait_bucket(b.index)
             self._wp_inflight[l] = self.comm.all_gather_async(full, shard)
             return
         cur = torch.cuda.current_stream(self.dev)
@@ -531,6 +559,24 @@ class InternLM2Engine:
         if self.comm.active and b.size:
             self.comm.pending.append(self.comm.reduce_scatter_async(self._full(self.grads, b), self._shard(self.grads, b)))
 
+    def _gathered_rows(self, x, product):
+        """msp / fsp: `x` [T, C] holds this rank's token rows; product(rows) is a row-wise product that reads x[rows] (a column-parallel linear's forward,
+        a row-parallel linear's input gradient).  The all-gather of the other ranks' rows runs UNDER the product of this rank's own rows, the rest
+        follows behind the wait -- the reference's fsp overlap (FusedDenseFunc, model/utils.py:228-346: async all-gather of x under the weight cast,
+        re-gather in backward under the input gradient).  Without sequence-sharded activations: product over all rows.  Same values either way (the
+        products are row-wise); the gain needs xGMI to be measured."""
+        if not self.ss:
+            product(slice(None))
+            return
+        work = self.tpar.all_gather_rows_async(x)
+        rl, T = self.rl, x.shape[0]
+        product(rl)
+        work.wait()
+        if rl.start > 0:
+            product(slice(0, rl.start))
+        if rl.stop < T:
+            product(slice(rl.stop, T))
+
     def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
         """One PackedFlashLlamaLayer1D (modeling_internlm2.py:684-740) into activation slot slot[l].
         recompute=False: the forward proper; the layer input a_x[l] = prev_ffn_out + previous layer's r2 is produced
@@ -547,9 +593,10 @@ class InternLM2Engine:
         else:
             K.add_rmsnorm_fwd(prev_ffn_out[rl], self.a_r2[self.slot[l - 1]][rl], p[pre + "attention_norm.weight"], eps, self.a_x[l][rl], self.a_n1[s][rl],
                               self.a_rstd1[s][rl])
-        if self.ss:   # all-gather in front of the column-parallel wqkv (the gathered rows are kept: its weight gradient reads them)
-            self.tpar.all_gather_rows_async(self.a_n1[s]).wait()
-        K.linear_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.t_qkv)
+        # (msp / fsp: all-gather in front of the column-parallel wqkv, under the product of the local rows; the gathered rows are kept: its weight gradient reads them)
+        self._gathered_rows(self.a_n1[s], lambda r: K.linear_fwd(self.a_n1[s][r], p[pre + "attention.wqkv.weight"], self.t_qkv[r]))
+        if self.bias:   # the InternLM-1 block (multi_head_attention.py:371-396): Wqkv carries a bias
+            K.bias_add(self.t_qkv, p[pre + "attention.wqkv.bias"])
         if self.sp == 1:
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s], self.q_scale)
         else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
@@ -565,15 +612,16 @@ class InternLM2Engine:
         K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
         # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism); msp / fsp: summed into this rank's rows only
         (self.tpar.reduce_scatter_rows_async(attn_out) if self.ss else self.tpar.all_reduce_sum_async(attn_out)).wait()
+        if self.bias:   # out_proj's bias, once, on the summed output (the reference's row-parallel linear holds it on tensor rank 0 only, ops/linear.py:318-324)
+            K.bias_add(attn_out[rl], p[pre + "attention.wo.bias"])
         K.add_rmsnorm_fwd(attn_out[rl], self.a_x[l][rl], p[pre + "ffn_norm.weight"], eps, self.a_r2[s][rl], self.a_n2[s][rl], self.a_rstd2[s][rl])
-        if self.ss:
-            self.tpar.all_gather_rows_async(self.a_n2[s]).wait()
         w13, _ = self._w13(l)
         if recompute:
-            K.linear_fwd(self.a_n2[s], w13, self.a_w13[s])
+            self._gathered_rows(self.a_n2[s], lambda r: K.linear_fwd(self.a_n2[s][r], w13, self.a_w13[s][r]))
             return None
         act = self.t_act if self.a_act is None else self.a_act[s]
-        K.linear_swiglu_fwd(self.a_n2[s], w13, self.a_w13[s], act)   # w1 | w3 product with the gate in its epilogue (one launch at the 7B shapes)
+        # w1 | w3 product with the gate in its epilogue (one launch at the 7B shapes)
+        self._gathered_rows(self.a_n2[s], lambda r: K.linear_swiglu_fwd(self.a_n2[s][r], w13, self.a_w13[s][r], act[r]))
         K.linear_fwd(act, p[pre + "feed_forward.w2.weight"], self.t_h1)
         (self.tpar.reduce_scatter_rows_async(self.t_h1) if self.ss else self.tpar.all_reduce_sum_async(self.t_h1)).wait()   # row-parallel w2
         return self.t_h1
@@ -613,11 +661,11 @@ class InternLM2Engine:
         self._wait_bucket(L + 1)
         rl = self.rl
         K.add_rmsnorm_fwd(ffn_out[rl], self.a_r2[self.slot[L - 1]][rl], p["norm.weight"], eps, self.a_xf[rl], self.a_nf[rl], self.a_rstdf[rl])
-        if self.ss:   # the head is column-parallel: all-gather along the sequence in front of it (ops/linear.py:146-153, gather_dim=1)
-            self.tpar.all_gather_rows_async(self.a_nf).wait()
         if self.head_fn:
             K.head_weight_fwd(p["output.weight"], mc.embed_grad_scale, mc.norm_head, self.t_head_w, self.t_head_inv)
-        K.linear_fwd(self.a_nf, self.t_head_w if self.head_fn else p["output.weight"], self.t_logits)   # [T, V], or this tensor rank's [T, V / tp] columns
+        # [T, V], or this tensor rank's [T, V / tp] columns (msp / fsp: the head is column-parallel: all-gather along the sequence in front of it, ops/linear.py:146-153)
+        head_w = self.t_head_w if self.head_fn else p["output.weight"]
+        self._gathered_rows(self.a_nf, lambda r: K.linear_fwd(self.a_nf[r], head_w, self.t_logits[r]))
         if self.mm > 1:
             # merged pass: the loss (and the metric) stay per micro-batch -- each has its own valid-token count (loss = mean over
             # micro-batches of the mean token loss, no_pipeline_scheduler.py:146)
@@ -725,6 +773,18 @@ class InternLM2Engine:
             elif last_micro:  # every micro-batch's rows are in place: one GEMM over micro_num * T tokens
                 K.linear_wgrad(dy_all, x_all, gw, False)
 
+        def bgrad(dy, gb, dy_all, a):
+            """gradient of a linear's bias = column sums of its output gradient (linear_bias_wgrad, model/utils.py:590-631), fp32 sums rounded once"""
+            if bw:
+                if last_micro:
+                    K.colsum(dy_all, gb)
+            elif a:
+                tmp = self.t_bias[: gb.numel()]
+                K.colsum(dy, tmp)
+                K.add_bf16(gb, tmp, gb)
+            else:
+                K.colsum(dy, gb)
+
         if is_last:
             # (vocabulary-parallel head: t_lse holds the GLOBAL log-sum-exp, the labels are the ones mapped into this rank's range by the
             # forward: a label owned by another rank is valid without a one-hot term here)
@@ -759,8 +819,7 @@ class InternLM2Engine:
         d_out = self.st_dout[L - 1][r] if bw else self.t_h1
         if is_last:
             K.rmsnorm_bwd(self.t_h0[rl], self.a_xf[rl], p["norm.weight"], self.a_rstdf[rl], None, g["norm.weight"], acc, ws, d_out[rl])
-            if ss:   # d(residual stream) in front of the last layer's row-parallel w2
-                self.tpar.all_gather_rows_async(d_out).wait()
+            # (msp / fsp: d(residual stream) is all-gathered in front of the last layer's row-parallel w2, at the top of the layer loop)
             if last_micro:
                 if ss:
                     self.tpar.all_reduce_avg(g["norm.weight"])
@@ -777,26 +836,34 @@ class InternLM2Engine:
                 self._layer_forward(l, None, cu, pos, max_seqlen, True)
             # feed-forward
             t_act, t_dw13, t_qkv = (self.st_act[l][r], self.st_dw13[l][r], self.st_dqkv[l][r]) if bw else (self.t_act, self.t_dw13, self.t_qkv)
+            # msp / fsp: d_out arrives on this rank's rows (from the norm backward above / of the layer above, or a later pipeline stage -- whole then, the
+            # gather an identity); its all-gather in front of the row-parallel w2's backward runs under the local rows' input gradient
             if self.a_act is not None and l >= mc.checkpoint_layers:   # the product is still there from the forward
                 t_act = self.a_act[sl]
                 # d(act) = d_out @ w2 never reaches memory: the gate's backward sits in the product's epilogue (one launch at the 7B shapes)
-                K.linear_dgrad_swiglu_bwd(d_out, p[pre + "feed_forward.w2.weight"], self.a_w13[sl], t_dw13, self.t_dact)
+                self._gathered_rows(d_out, lambda r: K.linear_dgrad_swiglu_bwd(d_out[r], p[pre + "feed_forward.w2.weight"], self.a_w13[sl][r], t_dw13[r], self.t_dact[r]))
             else:
-                K.linear_dgrad(d_out, p[pre + "feed_forward.w2.weight"], self.t_dact)
-                K.swiglu_bwd(self.t_dact, self.a_w13[sl][:, :F], self.a_w13[sl][:, F:], t_dw13[:, :F], t_dw13[:, F:], t_act)
+                def ffn_bwd(r, t_act=t_act):
+                    K.linear_dgrad(d_out[r], p[pre + "feed_forward.w2.weight"], self.t_dact[r])
+                    K.swiglu_bwd(self.t_dact[r], self.a_w13[sl][r, :F], self.a_w13[sl][r, F:], t_dw13[r, :F], t_dw13[r, F:], t_act[r])
+
+                self._gathered_rows(d_out, ffn_bwd)
             wgrad(d_out, t_act, g[pre + "feed_forward.w2.weight"], self.st_dout[l] if bw else None, self.st_act[l] if bw else None, acc_l)
             d_n2 = spare[0]
+            if self._rs_deferred is not None:   # rs_under_w13: the bucket of the layer above leaves now, under this layer's two longest products
+                self._reduce_bucket(self._rs_deferred)
+                self._rs_deferred = None
             K.linear_dgrad(t_dw13, w13, d_n2)
             ar = tp_sum(d_n2)   # input gradient of the column-parallel w1 | w3: summed over the tensor group ...
             wgrad(t_dw13, self.a_n2[sl], gw13, self.st_dw13[l] if bw else None, self.st_n2[l] if bw else None, acc_l)   # ... under this GEMM
             ar.wait()
             d_r2 = self.st_dr2[l][r] if bw else spare[1]
             K.rmsnorm_bwd(d_n2[rl], self.a_r2[sl][rl], p[pre + "ffn_norm.weight"], self.a_rstd2[sl][rl], d_out[rl], g[pre + "ffn_norm.weight"], acc_l, ws, d_r2[rl])
-            if ss:   # in front of the row-parallel wo's backward
-                self.tpar.all_gather_rows_async(d_r2).wait()
-            # attention
+            # attention (msp / fsp: d_r2's all-gather in front of the row-parallel wo's backward, under the local rows' input gradient)
             d_ctx = d_n2.view(-1)[: T * mc.num_attention_heads * d].view(T, mc.num_attention_heads * d)  # reuse ([T, h], or 1/tp of it)
-            K.linear_dgrad(d_r2, p[pre + "attention.wo.weight"], d_ctx)
+            self._gathered_rows(d_r2, lambda r: K.linear_dgrad(d_r2[r], p[pre + "attention.wo.weight"], d_ctx[r]))
+            if self.bias:
+                bgrad(d_r2, g[pre + "attention.wo.bias"], self.st_dr2[l] if bw else None, acc_l)
             # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53); d_ctx travels under wo's weight gradient
             xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if self.sp > 1 else None
             wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None, acc_l)
@@ -810,6 +877,8 @@ class InternLM2Engine:
                 xkv = self.seqpar.scatter_seq_gather_heads_async(self.t_dkv, 2, self.t_xkv, self.t_kvl)   # both in flight; dq unpacks under dkv's
                 dq_l, dkv_l = xq.wait(), xkv.wait()
             K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv, self.dq_scale)
+            if self.bias:
+                bgrad(t_qkv, g[pre + "attention.wqkv.bias"], self.st_dqkv[l] if bw else None, acc_l)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)
             K.linear_dgrad(t_qkv, p[pre + "attention.wqkv.weight"], d_n1)
             ar = tp_sum(d_n1)   # input gradient of the column-parallel wqkv, overlapped with its weight gradient
@@ -820,8 +889,7 @@ class InternLM2Engine:
             else:
                 d_x = d_out  # the old d_out buffer is free now
             K.rmsnorm_bwd(d_n1[rl], self.a_x[l][rl], p[pre + "attention_norm.weight"], self.a_rstd1[sl][rl], d_r2[rl], g[pre + "attention_norm.weight"], acc_l, ws, d_x[rl])
-            if ss:   # the layer below starts with its row-parallel w2's backward (layer 0: the embedding's backward gathers the sequence, embedding.py:57-58)
-                self.tpar.all_gather_rows_async(d_x).wait()
+            if ss:   # (the layer below starts with its row-parallel w2's backward, which gathers d_x's rows; layer 0: after the loop)
                 if last_micro:
                     self.tpar.all_reduce_avg(g[pre + "attention_norm.weight"])
                     self.tpar.all_reduce_avg(g[pre + "ffn_norm.weight"])
@@ -832,7 +900,12 @@ class InternLM2Engine:
             if self.wp_mode:
                 self._wp_reduce(l, first_micro)
             elif last_micro:
-                self._reduce_bucket(1 + l)
+                if self.rs_under_w13 and l > la:
+                    self._rs_deferred = 1 + l
+                else:
+                    self._reduce_bucket(1 + l)
+        if ss:   # the embedding's backward (or the previous pipeline stage) takes the whole sequence (embedding.py:57-58)
+            self.tpar.all_gather_rows_async(d_out).wait()
         if not is_first:
             return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
         if mc.embed_grad_scale != 1.0:
@@ -1135,6 +1208,9 @@ class InternLM2Engine:
         shards = [self._shard(self.grads, b) for b in L.buckets]
         if self.isp_rule > 1:
             self._apply_isp_grad_rule(shards)
+        if self.isp_groups:
+            self._step_isp_groups(shards)
+            return
         K.sumsq([x for x in shards if x.numel()], self.sumsq, False, self.sumsq_ws)   # (empty: a bucket this pipeline stage does not own)
         if self.tp > 1:
             # compute_norm (solver/optimizer/utils.py:265-378) counts a parameter that is replicated over the tensor group (norm
@@ -1180,12 +1256,71 @@ class InternLM2Engine:
         self.beta2_sched.step()
         self.step_count += 1
 
+    def _group_pieces(self):
+        """ISP's two optimizer groups inside this rank's bucket shards: [(bucket, offset inside the shard, length, group)] -- group 1 ("1_embed_head") =
+        the embedding bucket and the head's part of the last bucket, group 0 ("0_default") = everything else (bucket padding is zero in every buffer and
+        belongs to whichever piece it falls into)."""
+        if getattr(self, "_pieces", None) is None:
+            L, out = self.layout, []
+            head = L.params["output.weight"]
+            for b in L.buckets:
+                s0, n = b.shard(self.rank, self.world)
+                if n == 0:
+                    continue
+                if b.index == 0:
+                    out.append((b, 0, n, 1))
+                elif b.index != len(L.buckets) - 1:
+                    out.append((b, 0, n, 0))
+                else:
+                    cut = min(max(head.offset - s0, 0), n)   # elements of this shard in front of the head
+                    if cut:
+                        out.append((b, 0, cut, 0))
+                    if n - cut:
+                        out.append((b, cut, n - cut, 1))
+            self._pieces = out
+        return self._pieces
+
+    def _step_isp_groups(self, shards):
+        """step() of an ISP run: two group norms, one overflow decision, every group clipped by its own norm; AdamW per piece with its group's factor."""
+        tc, L = self.tc, self.layout
+        pieces = self._group_pieces()
+        for grp in (0, 1):
+            K.sumsq([shards[b.index][o : o + n] for b, o, n, g_ in pieces if g_ == grp], self.sumsq_g[grp : grp + 1], False, self.sumsq_ws)
+        self.comm.all_reduce_sum(self.sumsq_g)
+        K.step_control_groups(self.state, self.sumsq_g, self.scaler_cfg, self.group_inv, self.group_norm)
+        lr, beta2 = self.lr_sched.lr(), self.beta2_sched.beta2()
+        main = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        opt_stream = main if os.environ.get("IE_SERIAL_ADAMW") == "1" else self.opt_stream
+        offs = L.local_offsets()
+        with torch.cuda.stream(opt_stream):
+            opt_stream.wait_event(ev)
+            done = None
+            for i, (b, o, n, grp) in enumerate(pieces):
+                lo = offs[b.index] + o
+                K.adamw_step_group(shards[b.index][o : o + n], self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n],
+                                   self._shard(self.params, b)[o : o + n], self.state, self.group_inv[grp : grp + 1], lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
+                if i + 1 < len(pieces) and pieces[i + 1][0] is b:
+                    continue   # (the bucket's second piece follows)
+                if b.index not in self._wp_buckets and self.comm.active:
+                    self.comm.gathers[b.index] = self.comm.all_gather_async(self._full(self.params, b), self._shard(self.params, b))
+                done = torch.cuda.Event()
+                done.record(opt_stream)
+                self._bucket_ready[b.index] = done
+            self._opt_done = done
+        if self.wp_mode:
+            self._slot_layer = [None, None]
+        self.lr_sched.step()
+        self.beta2_sched.step()
+        self.step_count += 1
+
     def _replicated_grad_slices(self, shards):
         """Views of this rank's ZeRO gradient shards that belong to parameters held whole by every rank of the tensor group."""
         L = self.layout
         out = []
         for spec in L.params.values():
-            if spec.kind not in ("embed", "norm", "head") or (spec.kind == "head" and self.vp) or (spec.kind == "embed" and self.embed_split):
+            if spec.kind not in ("embed", "norm", "head", "bo") or (spec.kind == "head" and self.vp) or (spec.kind == "embed" and self.embed_split):
                 continue
             b = L.buckets[spec.bucket]
             s0, n0 = b.shard(self.rank, self.world)
@@ -1254,6 +1389,9 @@ class InternLM2Engine:
         st = K.step_state_read(self.state)
         self.lr_sched.set_successful_steps(st.adam_step)
         self.beta2_sched.set_successful_steps(st.adam_step)
+        if self.isp_groups:   # the reference reports one norm per optimizer group (hybrid_zero_optim.py:801-803); st.grad_norm is the norm over both
+            gn = [float(x) for x in self.group_norm.cpu()]
+            st.group_norms = {"0_default": gn[0], "1_embed_head": gn[1]}
         return st
 
     # ------------------------------------------------------------------------------------------ utilities
@@ -1262,6 +1400,34 @@ class InternLM2Engine:
     # converts at the naming boundary (named_parameters, load_named_parameters, checkpoints).
     def _is_llama(self):
         return getattr(self.mc, "model_type", "INTERNLM2_PUBLIC") == "LLAMA2"
+
+    # The dense InternLM-1 model (model_type INTERNLM: modeling_internlm.py, the model configs/7B_sft.py and configs/7B_isp_sft.py build) is the same
+    # block with other parameter names, a Wqkv packed "(three h d)" (multi_head_attention.py:428-431) and biases on Wqkv / out_proj.  The engine keeps
+    # its own names and InternLM2's row order -- with one q head per kv head [kv group][q, k, v][d] is [h][three][d] -- and converts at the naming boundary.
+    _V1_LAYER = {"attention_norm.weight": "norm1.weight", "attention.wqkv.weight": "mixer.Wqkv.weight", "attention.wqkv.bias": "mixer.Wqkv.bias",
+                 "attention.wo.weight": "mixer.out_proj.weight", "attention.wo.bias": "mixer.out_proj.bias", "ffn_norm.weight": "norm2.weight",
+                 "feed_forward.w1.weight": "mlp.w1.weight", "feed_forward.w2.weight": "mlp.w2.weight", "feed_forward.w3.weight": "mlp.w3.weight"}
+    _V1_TOP = {"tok_embeddings.weight": "embedding.weight", "norm.weight": "norm.weight", "output.weight": "head.weight"}
+
+    def _is_v1(self):
+        return getattr(self.mc, "model_type", "INTERNLM2_PUBLIC") == "INTERNLM"
+
+    def _v1_name(self, n, to_reference):
+        top = self._V1_TOP if to_reference else {v: k for k, v in self._V1_TOP.items()}
+        if n in top:
+            return top[n]
+        src, dst = ("layers.", "blocks.") if to_reference else ("blocks.", "layers.")
+        lay = self._V1_LAYER if to_reference else {v: k for k, v in self._V1_LAYER.items()}
+        assert n.startswith(src), n
+        l, rest = n[len(src):].split(".", 1)
+        return f"{dst}{l}.{lay[rest]}"
+
+    def _v1_qkv(self, t, to_reference):
+        """Wqkv weight [3 H d, h] / bias [3 H d] of H heads (all of them, or a tensor rank's): engine rows [H][three][d] <-> reference rows "(three h d)"."""
+        d = self.mc.head_dim
+        H = t.shape[0] // (3 * d)
+        v = t.reshape(H, 3, d, -1) if to_reference else t.reshape(3, H, d, -1)
+        return v.permute(1, 0, 2, 3).reshape(t.shape)
 
     def _split_wqkv(self, t):
         mc = self.mc
@@ -1276,7 +1442,9 @@ class InternLM2Engine:
         return torch.cat([wq.reshape(hkv, qpk, d, -1), wk.reshape(hkv, 1, d, -1), wv.reshape(hkv, 1, d, -1)], dim=1).reshape(hkv * (qpk + 2) * d, -1)
 
     def _to_reference_names(self, named):
-        """engine names -> the reference's parameter names (a copy for the LLAMA2 projections, the same tensors otherwise)."""
+        """engine names -> the reference's parameter names (a copy for the LLAMA2 projections / the InternLM-1 Wqkv, the same tensors otherwise)."""
+        if self._is_v1():
+            return {self._v1_name(n, True): (self._v1_qkv(t, True) if ".attention.wqkv." in n else t) for n, t in named.items()}
         if not self._is_llama():
             return dict(named)
         out = {}
@@ -1289,6 +1457,8 @@ class InternLM2Engine:
         return out
 
     def _from_reference_names(self, named):
+        if self._is_v1():
+            return {self._v1_name(n, False): (self._v1_qkv(t, False) if ".mixer.Wqkv." in n else t) for n, t in named.items()}
         if not self._is_llama():
             return dict(named)
         out = {n: t for n, t in named.items() if not n.endswith(("attention.wq.weight", "attention.wk.weight", "attention.wv.weight"))}
@@ -1301,6 +1471,8 @@ class InternLM2Engine:
     def reference_param_shapes(self):
         """Shapes of the FULL (un-sharded) parameters under the reference's names."""
         shapes = {n: s.shape for n, s in FlatLayout(self.mc, 1).params.items()}
+        if self._is_v1():
+            return {self._v1_name(n, True): shp for n, shp in shapes.items()}
         if self._is_llama():
             mc, out = self.mc, {}
             for n, shp in shapes.items():
@@ -1352,6 +1524,8 @@ class InternLM2Engine:
         """the reference's parameter name -> the engine parameter that holds it (LLAMA2: wq / wk / wv live in the fused wqkv)."""
         if self._is_llama() and ref_name.endswith(("attention.wq.weight", "attention.wk.weight", "attention.wv.weight")):
             return ref_name[: -len("wq.weight")] + "wqkv.weight"
+        if self._is_v1():
+            return self._v1_name(ref_name, False)
         return ref_name
 
     def _shard_pieces(self):
@@ -1374,6 +1548,9 @@ class InternLM2Engine:
             raise NotImplementedError("checkpoints under weight parallelism are not implemented (the reference writes model_wp{w}_pp0.pt row shards)")
         if self.pp != 1 and (self.nch != 1 or self.tp != 1):
             raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule without tensor parallelism")
+        if self._is_v1() and self.tp != 1:
+            raise NotImplementedError("checkpoints of the InternLM-1 model under tensor parallelism are not implemented (a tensor rank's Wqkv rows are "
+                                      "\"(three h/tp d)\": the ranks' files do not concatenate into the single-rank layout)")
         if self.sp != 1:
             raise NotImplementedError("checkpoints are not implemented under sequence parallelism (any data-parallel, tensor-parallel and pipeline size otherwise)")
 

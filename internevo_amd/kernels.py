@@ -325,6 +325,24 @@ def adamw_step(g, p32, m, v, p16, st, lr, beta1, beta2, eps, weight_decay):
           "ie_adamw_step")
 
 
+def step_control_groups(st, sumsq_dev, cfg: IeScalerConfig, group_inv, group_norm):
+    """HybridZeroOptimizer._step with several parameter groups: one overflow decision / scaler update over all of them, every group unscaled and
+    clipped by its OWN norm (hybrid_zero_optim.py:760-779,863-876).  sumsq_dev [n]; group_inv / group_norm [n] fp32 outputs on the device."""
+    n = sumsq_dev.numel()
+    if group_inv.numel() != n or group_norm.numel() != n:
+        raise ValueError("step_control_groups: size mismatch")
+    check(_L().ie_step_control_groups(_p(st), _p(sumsq_dev), n, ctypes.byref(cfg), _p(group_inv), _p(group_norm), _stream()), "ie_step_control_groups")
+
+
+def adamw_step_group(g, p32, m, v, p16, st, group_inv, lr, beta1, beta2, eps, weight_decay):
+    """adamw_step with the gradient factor of a parameter group (group_inv: ONE float on the device, an element of step_control_groups' output)."""
+    n = p32.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or (p16 is not None and p16.numel() != n) or group_inv.numel() != 1:
+        raise ValueError("adamw_step_group: size mismatch")
+    check(_L().ie_adamw_step_group(_p(g), _dt(g), _p(p32), _p(m), _p(v), _p(p16), n, _p(st), _p(group_inv), lr, beta1, beta2, eps, weight_decay, _stream()),
+          "ie_adamw_step_group")
+
+
 # ------------------------------------------------------------------------------------------ embedding / elementwise
 def embedding_fwd(weight, ids, out=None):
     V, dim = weight.shape
@@ -506,6 +524,15 @@ def gemm_batched(A, B, out, a_kmajor=False, b_kmajor=False, accumulate=False):
     if prof is not None:
         prof.end(2.0 * Z * M * N * K_, 2.0 * Z * (M * K_ + N * K_ + M * N))
     return out
+
+
+def bias_add(y, bias):
+    """y [rows, cols] += bias [cols] in place (bf16): the linear biases of the InternLM-1 block (multi_head_attention.py:371-408)."""
+    rows, cols, ld = _rows_ld(y)
+    if bias.numel() != cols:
+        raise ValueError("bias_add: size mismatch")
+    check(_L().ie_bias_add_bf16(_p(y), ld, _p(bias), rows, cols, _stream()), "ie_bias_add_bf16")
+    return y
 
 
 def colsum(x, out=None):

@@ -24,7 +24,7 @@ class ParamSpec:
     shape: Tuple[int, ...]
     offset: int      # element offset in the flat buffer
     bucket: int
-    kind: str        # "embed" | "norm" | "wqkv" | "wo" | "w1" | "w3" | "w2" | "head"
+    kind: str        # "embed" | "norm" | "wqkv" | "wo" | "w1" | "w3" | "w2" | "head" | "bqkv" | "bo" (the InternLM-1 block's attention biases)
     layer: int = -1
 
     @property
@@ -96,7 +96,11 @@ class FlatLayout:
             p = f"layers.{l}."
             add(cur, p + "attention_norm.weight", (h,), "norm", l)
             add(cur, p + "attention.wqkv.weight", (c.qkv_dim, h), "wqkv", l)
+            if getattr(c, "attn_bias", False):   # the InternLM-1 block (multi_head_attention.py:371-408): Wqkv and out_proj carry a bias
+                add(cur, p + "attention.wqkv.bias", (c.qkv_dim,), "bqkv", l)
             add(cur, p + "attention.wo.weight", (h, c.num_attention_heads * c.head_dim), "wo", l)  # = (h, h) unless tensor-parallel
+            if getattr(c, "attn_bias", False):
+                add(cur, p + "attention.wo.bias", (h,), "bo", l)
             add(cur, p + "ffn_norm.weight", (h,), "norm", l)
             add(cur, p + "feed_forward.w1.weight", (f, h), "w1", l)   # w1 and w3 adjacent: one [2F, h] GEMM operand
             add(cur, p + "feed_forward.w3.weight", (f, h), "w3", l)

@@ -120,10 +120,10 @@ class TensorParallel:
     # ---- shard <-> full parameter ------------------------------------------------------------------------------------
     def shard(self, kind, full):
         """This rank's part of a full parameter tensor (kind as in layout.ParamSpec.kind)."""
-        if self.tp == 1 or kind == "norm" or (kind == "embed" and not getattr(self, "embed_split", False)) or (kind == "head" and not self.vocab_parallel):
+        if self.tp == 1 or kind in ("norm", "bo") or (kind == "embed" and not getattr(self, "embed_split", False)) or (kind == "head" and not self.vocab_parallel):
             return full
         r, tp = self.tp_rank, self.tp
-        if kind in ("wqkv", "w1", "w3", "head"):  # column-parallel: output rows (wqkv rows are grouped by kv head: whole groups; head: vocabulary rows)
+        if kind in ("wqkv", "bqkv", "w1", "w3", "head"):  # column-parallel: output rows (wqkv rows / bias elements are grouped by kv head: whole groups; head: vocabulary rows)
             n = full.shape[0] // tp
             return full[r * n : (r + 1) * n]
         n = full.shape[1] // tp               # row-parallel (wo, w2): input columns; the hidden-split embedding: hidden columns
@@ -132,6 +132,6 @@ class TensorParallel:
     @staticmethod
     def unshard(kind, parts, vocab_parallel=True, embed_split=False):
         """Inverse of shard() given every rank's part in rank order."""
-        if kind == "norm" or (kind == "embed" and not embed_split) or (kind == "head" and not vocab_parallel) or len(parts) == 1:
+        if kind in ("norm", "bo") or (kind == "embed" and not embed_split) or (kind == "head" and not vocab_parallel) or len(parts) == 1:
             return parts[0]
-        return torch.cat(parts, dim=0 if kind in ("wqkv", "w1", "w3", "head") else 1)
+        return torch.cat(parts, dim=0 if kind in ("wqkv", "bqkv", "w1", "w3", "head") else 1)

@@ -71,6 +71,9 @@ class ZeroComm:
                 members = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
                 if len(members) != world_size:
                     raise ValueError(f"the data-parallel group has {len(members)} ranks, world_size says {world_size}")
+                if dp_groups is None and len(members) != dist.get_world_size():
+                    raise ValueError("hybrid ZeRO (zero_size < data-parallel size) over a SUB-group of the job needs dp_groups = every data-parallel group of the "
+                                     "job (zero.job_dp_groups): dist.new_group is collective over the default group, all ranks must create the same groups")
                 groups = [list(g) for g in dp_groups] if dp_groups is not None else [members]
                 if members not in groups:
                     raise ValueError(f"this rank's data-parallel group {members} is not among the job's {groups}")

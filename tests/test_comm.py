@@ -4,6 +4,7 @@ import os
 import sys
 
 import pytest
+from conftest import xport
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -27,7 +28,7 @@ def _spawn(fn, world, port, *args, timeout=200):
 
 def _staged_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.comm import StagedGlooBackend, backend_for
@@ -79,7 +80,7 @@ def test_staged_backend_lands_results_only_in_wait():
 
 def _hybrid_worker(rank, world, port, q, pp, tp, zero):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.config import tiny
@@ -140,7 +141,7 @@ def test_hybrid_zero_groups_for_every_data_parallel_group_of_the_job(pp, tp):
 
 def _rows_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.tensorpar import TensorParallel
@@ -179,7 +180,7 @@ def test_sequence_sharded_activation_exchanges_of_the_tensor_group():
 
 def _pp_tp_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.pipeline import PipeParallel

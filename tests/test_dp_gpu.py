@@ -10,6 +10,7 @@ import os
 import sys
 
 import pytest
+from conftest import xport
 import torch
 import torch.multiprocessing as mp
 
@@ -40,7 +41,7 @@ def _init_dist(rank, world, port):
     collectives staged through the host) or "nccl" (= RCCL over xGMI, one GPU per rank: the product path, exercised whenever the
     box has enough GPUs)."""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     backend = os.environ.get("IE_TEST_BACKEND", "gloo")
@@ -274,7 +275,7 @@ def test_two_rank_checkpoint_round_trip_and_reshard(dev, tmp_path, backend):
 
 def _rccl_worker(port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     torch.cuda.set_device(0)
@@ -320,7 +321,7 @@ def test_rccl_call_sequence_on_one_rank_group(dev):
 
 def _rccl_prims_worker(port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     torch.cuda.set_device(0)

@@ -309,6 +309,43 @@ def test_embedding(dev):
     close(dw, 2 * ref, 1.6e-2, 2e-3, "embedding bwd accumulate")
 
 
+def test_embedding_gradient_of_the_benchmark_batch_against_fp64(dev):
+    """Round-3 review: `oracle.ops.embedding_grad_in_fp32` (the oracle switched to the accelerator kernel's arithmetic for the 7B-width comparisons) must
+    rest on ground truth, not on the product.  The token ids of the BENCHMARK's step (SyntheticLoader, 4 x 4096 tokens: a handful of tokens, each thousands
+    of times) with an output gradient that has what makes bf16 accumulation swamp -- a common component of every row next to a noise part: the exact sum
+    in fp64 is the truth; embedding_bwd_k (fp32 sums per occurring token, rounded once) must sit at bf16 rounding from it and be closer to it than torch's
+    CPU kernel on bf16 (F.embedding's backward: rows added one by one into the bf16 gradient -- the arithmetic of the reference's CPU runs) by >= 10x in
+    relative l2; the oracle's fp32 switch must give the kernel's arithmetic, and the CPU-bf16 path must show the loss the 7B-width tests ran into."""
+    import torch.nn.functional as F
+
+    from internevo_amd.data import SyntheticLoader
+    from oracle import ops as O
+
+    batch, _ = next(iter(SyntheticLoader(4096, 1, 4, True, 4000)))
+    ids = batch["input_ids"].reshape(-1)
+    V, dim = 92544, 1024
+    assert ids.numel() == 16384 and int(torch.bincount(ids).max()) >= 500, "the benchmark's data: few tokens, hundreds to thousands of occurrences each"
+    dout = bf(torch.randn(ids.numel(), dim, generator=g(46)) * 0.05 + torch.randn(1, dim, generator=g(47)))
+    truth = torch.zeros(V, dim, dtype=torch.float64).index_add_(0, ids, dout.double())
+    dw = torch.zeros(V, dim, dtype=torch.bfloat16, device=dev)
+    K().embedding_bwd(dout.to(dev), ids.to(dev), dw, accumulate=False)
+    w = torch.zeros(V, dim, dtype=torch.bfloat16, requires_grad=True)
+    F.embedding(ids, w).backward(dout)                     # torch's CPU kernel on bf16
+    w32 = torch.zeros(V, dim, dtype=torch.bfloat16, requires_grad=True)
+    with O.embedding_grad_in_fp32():
+        O.embedding(ids, w32).backward(dout)               # the oracle's switch
+    err = lambda x: float((x.double().cpu() - truth).norm() / truth.norm())  # noqa: E731
+    e_hip, e_cpu, e_sw = err(dw), err(w.grad), err(w32.grad)
+    print(f"embedding gradient of the benchmark batch vs fp64: HIP kernel {e_hip:.2e}, CPU bf16 kernel {e_cpu:.2e}, oracle fp32 switch {e_sw:.2e}; "
+          f"CPU bf16 keeps {float(w.grad.double().norm() / truth.norm()):.3f} of the gradient's norm")
+    assert e_hip <= 3e-3, "fp32 sums rounded once: bf16 rounding of the result"
+    assert e_cpu >= 10 * e_hip, (e_cpu, e_hip)
+    # the oracle's fp32 switch is the kernel's arithmetic: fp32 sums rounded once (the order of an fp32 sum may move a rounding here and there)
+    differ = float((dw.cpu() != w32.grad).float().mean())
+    print(f"elements where the kernel and the oracle's fp32 switch differ: {differ:.2e}")
+    assert differ <= 1e-3 and float((dw.cpu().double() - w32.grad.double()).norm() / truth.norm()) <= 1e-3
+
+
 def test_add_and_cast(dev):
     a = bf(torch.randn(100003, generator=g(43)))
     b = bf(torch.randn(100003, generator=g(44)))

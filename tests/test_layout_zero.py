@@ -3,6 +3,7 @@ import os
 import sys
 
 import pytest
+from conftest import xport
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -131,7 +132,7 @@ def test_reference_config_files_map(tmp_path):
 
 def _worker(rank, world, port, q, zero=None):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.config import tiny
@@ -220,7 +221,7 @@ def test_checkpoint_fraction_maps_like_the_reference():
 
 def _sp_exchange_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.seqpar import SeqParallel
@@ -284,8 +285,10 @@ def test_shipped_reference_configs_map():
     from internevo_amd.moe_engine import ffn_dim as dense_ffn
 
     assert dense_ffn(c.model) == 11008   # int(4096 * 8/3) rounded up to a multiple of 256 (modules/mlp.py:52)
-    with pytest.raises(NotImplementedError, match="InternLM-1 family"):
-        load_reference_config("/root/reference/configs/7B_isp_sft.py")
+    # BASELINE configs[3] as shipped: the same model under tensor = dict(size=2, mode="isp"), weight = dict(size=4) (configs/7B_isp_sft.py:175-180)
+    i = load_reference_config("/root/reference/configs/7B_isp_sft.py")
+    assert (i.model.model_type, i.model.attn_bias, i.model.num_kv_attention_heads, i.model.ffn_dim, i.train.sp_size, i.train.wp_size, i.train.tp_size,
+            i.train.seq_len) == ("INTERNLM", True, 32, 11008, 2, 4, 1, 2048)
     # BASELINE configs[4]: model_type INTERNLM_MoE, 4 experts, top-2 (moe_engine.MoEEngine)
     d = load_reference_config("/root/reference/configs/7B_MoE4_sft.py")
     assert (d.model.model_type, d.model.num_experts, d.model.num_kv_attention_heads, d.model.moe_capacity_factor, d.model.moe_min_capacity,
@@ -297,7 +300,7 @@ def test_shipped_reference_configs_map():
 
 def _tp_group_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from internevo_amd.tensorpar import TensorParallel
@@ -454,14 +457,10 @@ def test_pure_python_style_config_loads_without_the_reference_installed(tmp_path
     ISP config's parallel section (tensor 2 / isp, weight 4)."""
     import subprocess
 
-    # configs/7B_isp_sft.py names no model_type = the dense InternLM-1 model (launch.py:78-79), which this engine runs data-parallel only: its
-    # parallel section is mapped through a config that re-exports the file for the InternLM2 model
-    isp = tmp_path / "isp_internlm2.py"
-    isp.write_text("import runpy\nglobals().update({k: v for k, v in runpy.run_path('/root/reference/configs/7B_isp_sft.py').items() if not k.startswith('__')})\n"
-                   "model_type = 'INTERNLM2_PUBLIC'\n")
+    isp = "/root/reference/configs/7B_isp_sft.py"   # (no model_type: the dense InternLM-1 model, launch.py:78-79)
     code = ("import sys, importlib.util; sys.path.insert(0, %r); assert importlib.util.find_spec('internlm') is None; "
             "from internevo_amd.config import load_reference_config as L; c = L('/root/reference/configs/demo.py'); "
             "i = L(%r); "
-            "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % (ROOT, str(isp))
+            "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.model.model_type, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % (ROOT, isp)
     out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["32", "4096", "92544", "2", "4", "False"], out
+    assert out == ["32", "4096", "92544", "INTERNLM", "2", "4", "False"], out

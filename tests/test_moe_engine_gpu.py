@@ -5,6 +5,7 @@ import json
 import os
 
 import pytest
+from conftest import xport
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -276,7 +277,7 @@ def _ep_engine_worker(rank, world, port, q, steps):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     dev = torch.device("cuda:0")

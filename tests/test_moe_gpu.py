@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import xport
 import torch
 
 from oracle import moe as MO  # tests may use the oracle; the product never does
@@ -176,7 +177,7 @@ def _ep_worker(rank, world, port, q):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     dev = torch.device("cuda:0")

@@ -19,8 +19,12 @@ lr_scheduler = dict(total_steps={steps}, init_steps=0, warmup_ratio=0.01, eta_mi
 model = dict(checkpoint=False, num_attention_heads=4, vocab_size=512, hidden_size=256, num_layers=2, no_bias=True, mlp_ratio=3.5,
              dtype="torch.bfloat16", layer_norm_epsilon=1e-5, num_kv_attention_heads=2, use_flash_attn=True)
 parallel = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=1), weight=dict(size=1))
-ckpt = dict(enable_save_ckpt={save}, save_ckpt_folder="local:{folder}", checkpoint_every=2, load_ckpt_info=dict(path="local:{load}", content=("all",), ckpt_type="internevo"))
+ckpt = dict(enable_save_ckpt={save}, save_ckpt_folder="local:{folder}", checkpoint_every=2, load_ckpt_info={load})
 """
+
+
+def _load_info(path):
+    return f'dict(path="local:{path}", content=("all",), ckpt_type="internevo")'
 
 
 def test_megatron_flops_and_tgs_windows_match_reference_golden():
@@ -57,7 +61,7 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
 
     folder = str(tmp_path / "ckpts")
     cfg1 = tmp_path / "cfg1.py"
-    cfg1.write_text(CFG.format(steps=4, save=True, folder=folder, load=str(tmp_path / "none")))
+    cfg1.write_text(CFG.format(steps=4, save=True, folder=folder, load="None"))
     lines = []
     run1 = train.main(["--config", str(cfg1), "--launcher", "torch"], log=lines.append)
     assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"]
@@ -69,7 +73,7 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
     assert run1[3]["num_consumed_tokens"] == 4 * 2 * 128 and run1[0]["loss"] > run1[3]["loss"]
     assert any(l.startswith("tflops=") for l in lines)
     cfg2 = tmp_path / "cfg2.py"
-    cfg2.write_text(CFG.format(steps=4, save=False, folder=folder, load=os.path.join(folder, "2")))
+    cfg2.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(os.path.join(folder, "2"))))
     run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
     assert [r["step"] for r in run2] == [2, 3]
     for a, b in zip(run1[2:], run2):
@@ -88,8 +92,8 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
 
 @pytest.mark.gpu
 def test_train_entry_default_model_type_is_the_dense_internlm1_model_and_resumes(dev, tmp_path):
-    """A config WITHOUT `model_type` (configs/7B_sft.py) is the reference's dense InternLM-1 model (launch.py:78-79): train.py runs it on the InternLM-1
-    engine, writes InternEvo checkpoints every 2 steps and a second run resumed from the step-2 folder reproduces steps 2 and 3 exactly."""
+    """A config WITHOUT `model_type` (configs/7B_sft.py) is the reference's dense InternLM-1 model (launch.py:78-79): train.py runs it on the dense
+    engine's InternLM-1 block, writes InternEvo checkpoints every 2 steps and a second run resumed from the step-2 folder reproduces steps 2 and 3 exactly."""
     sys.path.insert(0, ROOT)
     import train
 
@@ -97,15 +101,15 @@ def test_train_entry_default_model_type_is_the_dense_internlm1_model_and_resumes
     assert "model_type" not in v1
     folder = str(tmp_path / "ckpts")
     cfg1 = tmp_path / "cfg1.py"
-    cfg1.write_text(v1.format(steps=4, save=True, folder=folder, load=str(tmp_path / "none")))
+    cfg1.write_text(v1.format(steps=4, save=True, folder=folder, load="None"))
     lines = []
     run1 = train.main(["--config", str(cfg1), "--launcher", "torch"], log=lines.append)
-    assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"] and run1[0]["loss"] > run1[3]["loss"] and run1[0]["moe_loss"] == 0.0
+    assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"] and run1[0]["loss"] > run1[3]["loss"]
     assert sorted(os.listdir(os.path.join(folder, "2"))) == ["gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "optimizer_tp0_pp0_zo0.pt", "topo_tp0_pp0.json"]
     sd = torch.load(os.path.join(folder, "2", "model_tp0_pp0.pt"), weights_only=False)
     assert list(sd)[:3] == ["model.embedding.weight", "model.blocks.0.mixer.Wqkv.weight", "model.blocks.0.mixer.Wqkv.bias"]
     cfg2 = tmp_path / "cfg2.py"
-    cfg2.write_text(v1.format(steps=4, save=False, folder=folder, load=os.path.join(folder, "2")))
+    cfg2.write_text(v1.format(steps=4, save=False, folder=folder, load=_load_info(os.path.join(folder, "2"))))
     run2 = train.main(["--config", str(cfg2), "--launcher", "torch"], log=lines.append)
     assert [r["step"] for r in run2] == [2, 3]
     for a, b in zip(run1[2:], run2):
@@ -125,7 +129,7 @@ def test_train_entry_on_a_tokenized_folder(dev, tmp_path):
     root = str(tmp_path / "data")
     write_folder(root)
     cfg = tmp_path / "cfg.py"
-    text = CFG.format(steps=3, save=False, folder=str(tmp_path / "ck"), load=str(tmp_path / "none"))
+    text = CFG.format(steps=3, save=False, folder=str(tmp_path / "ck"), load="None")
     text = text.replace("seq_len=128, micro_num=2, micro_bsz=1,", "seq_len=64, micro_num=3, micro_bsz=2, min_length=5,").replace(
         "train_folder=None", f"train_folder={root!r}")
     cfg.write_text(text)
@@ -153,7 +157,7 @@ def test_train_entry_validates_every_n_steps(dev, tmp_path):
     import train
 
     cfg = tmp_path / "cfg.py"
-    text = CFG.format(steps=4, save=False, folder=str(tmp_path / "ck"), load=str(tmp_path / "none"))
+    text = CFG.format(steps=4, save=False, folder=str(tmp_path / "ck"), load="None")
     cfg.write_text(text.replace("train_folder=None,", "train_folder=None, valid_every=2, valid_micro_num=4, valid_folder=None,"))
     lines = []
     run = train.main(["--config", str(cfg), "--launcher", "torch"], log=lines.append)

@@ -71,30 +71,47 @@ def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
 def _train_moe(cfg, raw, dev, world, rank, args, log):
     """The hot loop for model_type INTERNLM_MoE (configs/7B_MoE4_sft.py) on internevo_amd.moe_engine.MoEEngine: synthetic RandomDataset batches,
     forward / backward with the moe loss, the three-group optimizer step, one log line per step with the reference's loss / moe_loss /
-    per-group grad_norm keys (train/pipeline.py:494-530).  The dense INTERNLM model (the reference's default model type) runs on the same engine and
-    saves / resumes InternEvo checkpoints (model + optimizer files); validation and tokenized folders are the InternLM2 engine's: refused."""
+    per-group grad_norm keys (train/pipeline.py:494-530); InternEvo checkpoints (model + expert + optimizer files and the run state: scheduler, sampler,
+    context) on one data-parallel rank.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
+    engine.InternLM2Engine like every other dense family.)"""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.moe_engine import MoEEngine
 
     data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
-    dense = cfg.model.model_type == "INTERNLM"
     load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
-    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and not dense and world > 1):
-        raise NotImplementedError("InternLM-1 family runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
-                                  "the InternLM2 / LLaMA engine); INTERNLM_MoE checkpoints cover one data-parallel rank (the dense INTERNLM model: any number)")
+    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and world > 1):
+        raise NotImplementedError("INTERNLM_MoE runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
+                                  "the dense engine); INTERNLM_MoE checkpoints cover one data-parallel rank")
     tc = cfg.train
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
     loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world)
-    first_step = 0
-    if load_folder and os.path.isdir(load_folder):   # model + optimizer files of the reference / of save_checkpoint, any ZeRO world; the batch stream moves on
+    first_step, run_state = 0, None
+    if load_folder:   # model + optimizer files of the reference / of save_checkpoint
+        from internevo_amd.checkpoint import load_run_state
+
+        if not os.path.isdir(load_folder):
+            raise FileNotFoundError(f"ckpt.load_ckpt_folder / load_ckpt_info.path: {load_folder} does not exist (refusing to start from scratch instead)")
         eng.load_checkpoint(load_folder)
-        first_step = eng.step_count
-        log(f"load_ckpt_folder: {load_folder} (resuming at batch {first_step})")
+        # the run state as the reference writes it (schedulder.pt / sampler.pt / context.pt).  The batch index comes from context.pt's batch_count, NOT
+        # from the count of successful optimizer steps: after a skipped (overflowed) step the two differ, and the data stream must move on exactly as an
+        # uninterrupted run's does (TrainState.load_state_dict, core/trainer.py:114-117)
+        run_state = load_run_state(load_folder)
+        ctx = run_state["context"]
+        first_step = ctx["batch_count"] + 1 if ctx else eng.step_count
+        if run_state["scheduler"] is not None:
+            eng.lr_sched.load_state_dict(run_state["scheduler"])
+        log(f"load_ckpt_folder: {load_folder} (resuming at batch {first_step}, step_count {eng.step_count})")
     loader = iter(loader_obj)
-    for _ in range(first_step):
-        next(loader)
+    if run_state and run_state["sampler"] is not None:
+        loader_obj.sampler.load_state_dict(run_state["sampler"])
+    else:
+        for _ in range(first_step):
+            next(loader)
+    ctx = run_state["context"] if run_state else None
+    consumed = ctx["num_consumed_tokens"] if ctx else 0
+    skipped_before = ctx["inf_nan_skip_batches"] if ctx else 0
     every = int(ck.get("checkpoint_every", 0) or 0)
     out = []
     for step in range(first_step, tc.total_steps):
@@ -104,7 +121,9 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
         eng.step()
         st = eng.read_state()
         infos = dict(step=step, loss=float(loss), moe_loss=float(moe_loss), grad_norm=dict(st.group_norms), loss_scale=st.loss_scale, lr=eng.lr_sched.lr(),
-                     tgs=round(labels.nelement() / (time.time() - start), 2), inf_nan_skip_batches=st.skipped_total)
+                     tgs=round(labels.nelement() / (time.time() - start), 2), inf_nan_skip_batches=skipped_before + st.skipped_total)
+        if not st.skip:
+            consumed += labels.nelement() * world
         out.append(infos)
         if rank % 8 == 0:
             if st.skip:
@@ -113,6 +132,11 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
         if save_folder and every > 0 and ((step + 1) % every == 0 or step + 1 == tc.total_steps):
             eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))   # collective: rank r writes the reference's ZeRO partition r
             if rank == 0:
+                from internevo_amd.checkpoint import save_run_state
+
+                save_run_state(os.path.join(save_folder, str(step + 1)), eng.lr_sched.state_dict(), loader_obj.sampler.state_dict(), batch_count=step,
+                               num_consumed_samples_in_epoch=loader_obj.sampler.consumed, num_consumed_tokens=consumed,
+                               inf_nan_skip_batches=skipped_before + st.skipped_total, step_count=st.adam_step)
                 log(f"Saving checkpoint to `{os.path.join(save_folder, str(step + 1))}` at batch count:{step + 1}")
     if world > 1:
         torch.distributed.barrier()
@@ -142,15 +166,17 @@ def main(argv=None, log=print):
     dev = torch.device("cuda", local_rank)
     if world > 1 and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL
-    if mc.model_type in ("INTERNLM_MoE", "INTERNLM"):   # the InternLM-1 families (MoE, or the dense model on the same engine)
+    if mc.model_type == "INTERNLM_MoE":   # (the dense InternLM-1 model, model_type INTERNLM, is a block variant of the engine below)
         return _train_moe(cfg, raw, dev, world, rank, args, log)
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
     ck = raw.get("ckpt", {}) or {}
     load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
     first_step, run_state = 0, None
-    if load_folder and os.path.isdir(load_folder):
+    if load_folder:
         from internevo_amd.checkpoint import load_run_state
 
+        if not os.path.isdir(load_folder):
+            raise FileNotFoundError(f"ckpt.load_ckpt_folder / load_ckpt_info.path: {load_folder} does not exist (refusing to start from scratch instead)")
         eng.load_checkpoint(load_folder)
         run_state = load_run_state(load_folder)  # schedulder.pt / sampler.pt / context.pt when the folder has them
         ctx = run_state["context"]
@@ -233,7 +259,7 @@ def main(argv=None, log=print):
         tk_per_gpu = round(labels.nelement() * dp_world / world, 4)
         infos = step_infos(tflops=flops(time.time() - start), step=step, loss=float(loss), tk_per_gpu=tk_per_gpu, start_time=start, tgs=tgs,
                            lr=eng.lr_sched.lr(),  # read after the scheduler stepped, like optimizer.param_groups[0]["lr"] (pipeline.py:494)
-                           loss_scale=st.loss_scale, grad_norm={"0_default": st.grad_norm}, batch=batch, labels=labels,
+                           loss_scale=st.loss_scale, grad_norm=getattr(st, "group_norms", None) or {"0_default": st.grad_norm}, batch=batch, labels=labels,
                            num_consumed_tokens=consumed, inf_nan_skip_batches=skipped_before + st.skipped_total, adam_beta2=eng.beta2_sched.beta2(),
                            fwd_bwd_time=fwd_bwd_time, metric=m)
         out.append(infos)
