@@ -288,11 +288,97 @@ def saved_zero_world(folder, tp_rank=0, pp_rank=0):
 
 
 def saved_tp_world(folder):
+    import re
+
     n = 0
     for fn in os.listdir(folder):
-        if fn.startswith("model_tp") and fn.endswith("_pp0.pt"):
-            n = max(n, int(fn[len("model_tp"):-len("_pp0.pt")]) + 1)
+        m = re.fullmatch(r"model_tp(\d+)_pp0\.pt", fn)
+        if m:
+            n = max(n, int(m.group(1)) + 1)
     return n
+
+
+# ---- model files of the ISP layout (tensor mode "isp" + weight parallelism; configs/7B_isp_sft.py) ---------------------------------------------------
+# save_model_checkpoint under ISP (checkpoint/components.py:221-226) writes `model_tp{t}_wp{w}_pp{p}.pt` = the state dict of a rank with tensor rank t and
+# weight rank w: the embedding cut over hidden COLUMNS and the head over vocabulary ROWS of the TENSOR group (modules/embedding.py:40-50, ops/linear.py:79-153),
+# every ISPLinear weight and bias cut over output ROWS of the WEIGHT group (ops/linear.py:357-378), norm weights whole.  Only the (t, w) pairs that occur on
+# ranks with weight-data rank 0 or data rank 0 are written (tensor 2 x weight 4: tp0_wp0, tp1_wp1, tp0_wp2, tp1_wp3).  Pinned on a real two-process
+# checkpoint (tests/golden/ckpt_ref_isp2v1/, make_golden.py --ckpt-isp).
+def isp_split(name):
+    """('tp' | 'wp' | None, dim) -- over which group and along which dimension the ISP layout cuts a parameter (both block families' names)."""
+    if name in ("tok_embeddings.weight", "embedding.weight"):
+        return "tp", 1
+    if name in ("output.weight", "head.weight"):
+        return "tp", 0
+    if name.endswith(("norm.weight", "norm1.weight", "norm2.weight")):
+        return None, None
+    return "wp", 0
+
+
+def isp_shard(name, full, tp_rank, tp_world, wp_rank, wp_world):
+    grp, d = isp_split(name)
+    if grp is None:
+        return full
+    r, w = (tp_rank, tp_world) if grp == "tp" else (wp_rank, wp_world)
+    n = full.shape[d] // w
+    return full.narrow(d, r * n, n)
+
+
+def saved_isp_layout(folder):
+    """-> {(t, w): file name} of the `model_tp{t}_wp{w}_pp0.pt` files of a folder (empty: not an ISP-layout folder)."""
+    import re
+
+    out = {}
+    for fn in os.listdir(folder):
+        m = re.fullmatch(r"model_tp(\d+)_wp(\d+)_pp(\d+)\.pt", fn)
+        if m:
+            if int(m.group(3)) != 0:
+                raise NotImplementedError("ISP-layout checkpoints with pipeline parallelism")
+            out[(int(m.group(1)), int(m.group(2)))] = fn
+    return out
+
+
+def load_isp_model(folder, model_cfg):
+    """The FULL parameters (reference names) out of an ISP-layout folder: tensor-group cuts taken from one file per tensor rank, weight-group cuts from one
+    file per weight rank (every rank of either group occurs in at least one file)."""
+    files = saved_isp_layout(folder)
+    tp_world, wp_world = max(t for t, _ in files) + 1, max(w for _, w in files) + 1
+    by_tp = {t: fn for (t, _), fn in sorted(files.items(), reverse=True)}
+    by_wp = {w: fn for (_, w), fn in sorted(files.items(), reverse=True)}
+    if sorted(by_tp) != list(range(tp_world)) or sorted(by_wp) != list(range(wp_world)):
+        raise FileNotFoundError(f"{folder}: the ISP-layout model files {sorted(files.values())} do not cover tensor ranks 0..{tp_world - 1} and weight ranks 0..{wp_world - 1}")
+    cache = {}
+
+    def sd(fn):
+        if fn not in cache:
+            cache[fn] = torch.load(os.path.join(folder, fn), map_location="cpu", weights_only=False)
+        return cache[fn]
+
+    def get(fn, n):
+        d = sd(fn)
+        return d["model." + n if "model." + n in d else n].detach()
+
+    out = {}
+    for n in state_dict_order(model_cfg):
+        grp, dim = isp_split(n)
+        if grp is None:
+            out[n] = get(next(iter(files.values())), n)
+        elif grp == "tp":
+            out[n] = torch.cat([get(by_tp[t], n) for t in range(tp_world)], dim=dim)
+        else:
+            out[n] = torch.cat([get(by_wp[w], n) for w in range(wp_world)], dim=dim)
+    return out, tp_world, wp_world
+
+
+def save_isp_model_shard(folder, model_cfg, full_params, tp_rank, tp_world, wp_rank, wp_world, param_dtype=torch.bfloat16):
+    """One rank's `model_tp{t}_wp{w}_pp0.pt` (+ the topology file) from the FULL parameters (reference names): what save_model_checkpoint writes on a
+    rank with tensor rank t and weight rank w."""
+    os.makedirs(folder, exist_ok=True)
+    sd = collections.OrderedDict()
+    for n in state_dict_order(model_cfg):
+        sd["model." + n] = isp_shard(n, full_params[n].detach().to("cpu"), tp_rank, tp_world, wp_rank, wp_world).to(param_dtype).contiguous().clone()
+    torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_wp{wp_rank}_pp0.pt"))
+    torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_wp{wp_rank}_pp0.json"))
 
 
 def saved_pp_world(folder):
@@ -314,7 +400,7 @@ def _stage_layers(sd):
     return max(idx) + 1 if idx else 0
 
 
-def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, sd=None):
+def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, sd=None, model_only=False):
     """One tensor rank's files (of one pipeline stage) -> its LOCAL named tensors (all its ZeRO shards merged).  want: the names (as this stage's files
     carry them) whose optimizer tensors are kept; sd: the stage's model state dict if the caller has read it already."""
     if sd is None:
@@ -327,7 +413,7 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, s
             raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
         params[n] = sd[key].detach()
     out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
-    zero_world = saved_zero_world(folder, t, pp_rank)
+    zero_world = 0 if model_only else saved_zero_world(folder, t, pp_rank)
     if zero_world == 0:
         return out
     flat_order = zero_flat_order([(n, tuple(params[n].shape)) for n in order])
@@ -375,10 +461,16 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, s
     return out
 
 
-def load_checkpoint(folder, model_cfg, want=None):
+def load_checkpoint(folder, model_cfg, want=None, model_only=False):
     """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, FULL tensors), adam_step, scaler, lr, zero_world, tp_world).
-    Optimizer entries are None when the folder holds model weights only.  Every shard in the folder is read and merged -- whatever
+    Optimizer entries are None when the folder holds model weights only, or with model_only (load_ckpt_info content = ("model",): the optimizer files are not read).  Every shard in the folder is read and merged -- whatever
     ZeRO world and tensor-parallel size wrote them; `want` (a set of names) limits the optimizer tensors kept in memory."""
+    if saved_isp_layout(folder):   # model files of the ISP layout (model_tp{t}_wp{w}_pp0.pt): weights only
+        if not model_only:
+            raise NotImplementedError(f"{folder} holds a checkpoint of the ISP layout (model_tp*_wp*_pp*.pt): its model weights load (load_ckpt_info content = "
+                                      "('model',)); the optimizer shards of that layout (optimizer_tp*_wp*_pp*_dp*.pt) are not implemented")
+        params, tp_world, _ = load_isp_model(folder, model_cfg)
+        return dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0, tp_world=tp_world)
     tp_world = saved_tp_world(folder)
     if tp_world == 0:
         raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")
@@ -394,7 +486,7 @@ def load_checkpoint(folder, model_cfg, want=None):
             n_layers = _stage_layers(sd)
             # (the optimizer tensors a caller does not want -- another stage's, another ZeRO rank's -- are dropped while the flat vectors are cut, not after)
             local_want = None if want is None else {n for n in stage_order(model_cfg, n_layers, p_ == 0, p_ == pp_world - 1) if stage_to_global(n, lo) in want}
-            st = _load_tp_rank(folder, model_cfg, 0, 1, local_want, p_, pp_world, sd=sd)
+            st = _load_tp_rank(folder, model_cfg, 0, 1, local_want, p_, pp_world, sd=sd, model_only=model_only)
             ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items()}  # noqa: E731
             named = {k: ren(st[k]) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
             if out is None:
@@ -410,7 +502,7 @@ def load_checkpoint(folder, model_cfg, want=None):
         if lo != model_cfg.num_layers:
             raise ValueError(f"the {pp_world} pipeline stages of the checkpoint hold {lo} layers, the model {model_cfg.num_layers}")
         return dict(out, tp_world=1, pp_world=pp_world)
-    ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want) for t in range(tp_world)]
+    ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want, model_only=model_only) for t in range(tp_world)]
     out = dict(ranks[0], tp_world=tp_world)
     if tp_world == 1:
         return out
@@ -531,6 +623,18 @@ def load_moe_checkpoint(folder, model_cfg):
     return out
 
 
+def latest_checkpoint(save_folder):
+    """CheckpointManager.query_latest_snapshot_step_local (checkpoint_manager.py:497-512): the folder under `save_folder` that holds the `{step}.step`
+    flag file with the largest step (the flag is written last, by the logging rank: a folder without it is incomplete) -> (folder or None, step)."""
+    best, where = 0, None
+    if save_folder and os.path.isdir(save_folder):
+        for root, _, files in os.walk(save_folder, followlinks=True):
+            for fn in files:
+                if fn.endswith(".step") and fn[: -len(".step")].isdigit() and int(fn[: -len(".step")]) > best:
+                    best, where = int(fn[: -len(".step")]), root
+    return where, best
+
+
 def save_run_state(folder, scheduler_state, sampler_state, batch_count, num_consumed_samples_in_epoch, num_consumed_tokens,
                    inf_nan_skip_batches, step_count, tensorboard_folder=None):
     """schedulder.pt / sampler.pt / context.pt as CheckpointManager.save_checkpoint writes them from the logging rank
@@ -544,6 +648,8 @@ def save_run_state(folder, scheduler_state, sampler_state, batch_count, num_cons
     torch.save({"batch_count": int(batch_count), "num_consumed_samples_in_epoch": int(num_consumed_samples_in_epoch),
                 "num_consumed_tokens": int(num_consumed_tokens), "inf_nan_skip_batches": int(inf_nan_skip_batches),
                 "step_count": int(step_count), "tensorboard_folder": tensorboard_folder}, os.path.join(folder, "context.pt"))
+    # the integrity flag the reference writes last (checkpoint_manager.py:633-637); `auto_resume` looks for the largest one
+    torch.save({"step": int(step_count)}, os.path.join(folder, f"{int(step_count)}.step"))
 
 
 def load_run_state(folder):

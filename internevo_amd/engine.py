@@ -79,6 +79,7 @@ class InternLM2Engine:
         self.mc, self.tc = cfg.model, cfg.train
         self.dev = device
         self.world, self.rank = world_size, rank
+        self.job_world, self.job_rank = world_size, rank   # (self.world / self.rank end up counting the ZeRO shards)
         mc, tc = self.mc, self.tc
         if mc.head_dim not in (64, 128):
             raise NotImplementedError("head dim must be 64 or 128")
@@ -1568,6 +1569,23 @@ class InternLM2Engine:
                     out[n] = C.tp_shard(n, out[n], self.tpar.tp_rank, self.tp)
         return out
 
+    def save_model_isp(self, folder):
+        """The MODEL files of the reference's ISP layout (checkpoint/components.py:221-226; checkpoint.save_isp_model_shard): `model_tp{t}_wp{w}_pp0.pt` with
+        the embedding's hidden columns / the head's vocabulary rows of tensor (= sequence) rank t and the ISPLinear rows of weight rank w, written by the
+        ranks the reference writes from (weight-data rank 0 or data rank 0); a reference job of the same tensor x weight sizes -- or this engine, in any
+        layout -- loads them with load_ckpt_info content = ("model",).  Collective.  (The optimizer shards of that layout are not written: a run under
+        sequence / weight parallelism cannot be RESUMED from its own checkpoint yet.)"""
+        from . import checkpoint as C
+
+        if self.tp != 1 or self.pp != 1:
+            raise NotImplementedError("save_model_isp: the ISP layout (tensor mode 'isp' + parallel.weight), without tensor mode mtp / msp / fsp or pipeline parallelism")
+        sp, wp = self.sp, max(int(getattr(self.tc, "wp_size", 1) or 1), 1)
+        named = {n: t.detach().to("cpu", copy=True) for n, t in self.named_parameters()}   # (collective under weight parallelism: every rank gathers)
+        r = self.job_rank
+        if r // wp == 0 or r // sp == 0:
+            C.save_isp_model_shard(folder, self.mc, named, r % sp, sp, r % wp, wp)
+        self.comm.barrier()
+
     def save_checkpoint(self, folder):
         """InternEvo's checkpoint files (checkpoint.py): per tensor rank (and pipeline stage) the model weights (written by its data-parallel
         rank 0) and one hybrid-ZeRO optimizer shard + partition plan per data-parallel rank, in the reference's whole-parameter partition
@@ -1629,12 +1647,19 @@ class InternLM2Engine:
                               scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t, **stage)
         everyone()  # the folder is complete when any rank returns
 
-    def load_checkpoint(self, folder):
+    def load_checkpoint(self, folder, model_only=False):
         """Resume from InternEvo checkpoint files (written by the reference or by save_checkpoint, by ANY ZeRO-1 world, ANY
         tensor-parallel size and ANY pipeline size: the shards are merged into full tensors under the model's own names and re-cut into this
-        engine's stage, tensor-parallel parts and bucket slices)."""
+        engine's stage, tensor-parallel parts and bucket slices).  model_only: load_ckpt_info content = ("model",) -- the weights only; the fp32 master
+        copy is rebuilt from them (reload_zero_fp32_buff, checkpoint_manager.py:553-557), optimizer moments, step and loss scale stay as they are."""
         from . import checkpoint as C
 
+        if model_only:   # nothing of the optimizer's layout is touched: also under sequence / weight parallelism, where full checkpoints are refused
+            if self._is_v1() and self.tp != 1:
+                self._checkpoint_guard()
+            ck = C.load_checkpoint(folder, self.mc, want=set(), model_only=True)
+            self.load_named_parameters(ck["params"])   # every rank keeps its stage's layers / its tensor-parallel cut / its weight-parallel shard
+            return
         self._checkpoint_guard()
         pieces = self._shard_pieces()
         want = set()

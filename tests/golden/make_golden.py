@@ -526,7 +526,7 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp=False):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
@@ -534,12 +534,19 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
     shard and one partition-plan file per rank (hybrid_zero_optim.py:254-284).
     model_type = "INTERNLM" (`--ckpt-v1`): the dense InternLM-1 model (modeling_internlm.py; the reference's default model type) -> ckpt_ref_v1/.
     pp = 2 (`--ckpt-pp`, two processes): two pipeline stages of a 4-layer model -> ckpt_ref_pp2/ with one model / optimizer / plan / topo file per stage
-    (`model_tp0_pp{s}.pt`: every stage numbers its layers from 0) and ckpt_pp2_rank{s}.json."""
+    (`model_tp0_pp{s}.pt`: every stage numbers its layers from 0) and ckpt_pp2_rank{s}.json.
+    isp (`--ckpt-isp`, two processes): the dense InternLM-1 model under tensor = dict(size=2, mode="isp"), weight = dict(size=2) -- configs/7B_isp_sft.py's layout in
+    small -> ckpt_ref_isp2v1/ with the MODEL files of that layout, `model_tp{t}_wp{w}_pp0.pt` (components.py:221-226: every rank's LOCAL shards -- embedding columns and
+    head rows of its tensor rank, ISPLinear rows of its weight rank) and ckpt_isp2v1.json (the optimizer files of the ISP layout are not part of the fixture)."""
     import shutil
 
     shim_cpu_accelerator()
     if world > 1:
         _patch_gloo_flat_collectives()
+        if isp:
+            import torch.distributed as dist
+
+            dist.all_to_all = _gloo_all_to_all
     import internlm  # noqa: F401
     import internlm.data.build_dataloader as bdl
     from internlm.checkpoint.components import save_model_checkpoint, save_optimizer_checkpoint
@@ -577,6 +584,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
             gl.gumbel_rsample = gumbel
     if pp > 1:
         kw = dict(kw, layers=4, micro_num=4, pp=pp)
+    if isp:
+        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=2, sp=2, wp=2, seq_len=128)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=1, tp=tp)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
@@ -602,8 +611,17 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
             for name, p in model.model.named_parameters():
                 gname = re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name)
                 p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
+        if isp:
+            from internevo_amd.config import ModelConfig
+            from oracle.moe_model import param_shapes as v1_shapes
+
+            full_shapes = v1_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
+                                                num_kv_attention_heads=kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
         for name, p in (model.model.named_parameters() if pp == 1 else ()):
-            if tp > 1:
+            if isp:
+                p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, gpc.get_local_rank(ParallelMode.TENSOR), 2, gpc.get_local_rank(ParallelMode.WEIGHT), 2,
+                                          full_shapes).to(p.dtype))
+            elif tp > 1:
                 part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw)
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
@@ -621,7 +639,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_isp2v1" if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -661,7 +679,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
             save_model_checkpoint("local:" + folder, model)
-            save_optimizer_checkpoint(optimizer, "local:" + folder)
+            if not isp:
+                save_optimizer_checkpoint(optimizer, "local:" + folder)
             if world == 1:
                 # the remaining files of CheckpointManager.save_checkpoint (checkpoint_manager.py:608-618), written the same way
                 from internlm.utils.storage_manager import llm_save
@@ -675,6 +694,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
                 rec["sampler_state"] = {k: (v if isinstance(v, (int, float, str, type(None))) else str(type(v))) for k, v in ss.items()}
             sd = model.state_dict()
             rec["model_keys"] = [[k, str(v.dtype), list(v.shape)] for k, v in sd.items()]
+            if isp:
+                continue
             osd = optimizer.state_dict()
             rec["optimizer_top_keys"] = list(osd.keys())
             rec["grad_scaler"] = {k: (float(v) if torch.is_tensor(v) else v) for k, v in osd["grad_scaler"].items()}
@@ -698,7 +719,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1):
         with open(os.path.join(HERE, f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
             json.dump(rec, f, indent=1, default=str)
         return
-    with open(os.path.join(HERE, "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
+    with open(os.path.join(HERE, "ckpt_isp2v1.json" if isp else "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
         json.dump(rec, f, indent=1, default=str)  # ParallelMode enums etc. as their repr
     print(rec["files"])
 
@@ -1314,6 +1335,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-isp-rank":
+        gen_checkpoint(port=29791, rank=int(sys.argv[2]), world=2, model_type="INTERNLM", isp=True)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe":
         gen_checkpoint(port=29792, model_type="INTERNLM_MoE")
         sys.exit(0)
@@ -1354,7 +1381,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--block-v1", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--block-v1", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-isp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

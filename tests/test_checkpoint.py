@@ -651,3 +651,61 @@ def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["moe_loss"] - w["moe_loss"]) <= 3e-2 * w["moe_loss"], (r, w)
         for k, v in w["grad_norm"].items():
             assert abs(r["grad_norm"][k] - v) <= 3e-2 * v, (k, r["grad_norm"], w["grad_norm"])
+
+
+def test_isp_layout_model_files_of_the_reference_load_and_are_reproduced(tmp_path):
+    """tests/golden/ckpt_ref_isp2v1/ = the MODEL files a real two-process ISP run of the reference wrote (tensor = dict(size=2, mode="isp"), weight =
+    dict(size=2), the dense InternLM-1 model -- configs/7B_isp_sft.py's layout in small; make_golden.py --ckpt-isp): `model_tp{t}_wp{w}_pp0.pt` with the
+    embedding's columns / the head's rows of tensor rank t and the ISPLinear rows (weights AND biases) of weight rank w.  The reader merges them into the
+    full model (the folder a user names in load_ckpt_info content=("model",) under that config); cutting the merged model again reproduces both files
+    tensor for tensor; the merged weights are the ISP run's after two steps: the oracle (oracle.isp, which retraces that run) holds the same weights and
+    sees the reference's step-2 loss on them."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.isp import OracleISPTrainer
+    from oracle.moe_model import OracleMoETrainer, param_shapes
+
+    gold = json.load(open(os.path.join(G, "ckpt_isp2v1.json")))
+    c = gold["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+    ref = os.path.join(G, "ckpt_ref_isp2v1")
+    assert sorted(C.saved_isp_layout(ref)) == [(0, 0), (1, 1)] and C.saved_tp_world(ref) == 0
+    with pytest.raises(NotImplementedError, match="ISP layout"):
+        C.load_checkpoint(ref, mc)                     # (its optimizer shards are not implemented: say so instead of resuming half a state)
+    ck = C.load_checkpoint(ref, mc, model_only=True)
+    assert {n: tuple(t.shape) for n, t in ck["params"].items()} == {n: tuple(s_) for n, s_ in param_shapes(mc).items()} and ck["master"] is None
+    # what rank 0 of the reference held: the shapes recorded from its own state dict
+    for key, dt, shape in gold["model_keys"]:
+        n = key[len("model."):]
+        assert list(C.isp_shard(n, ck["params"][n], 0, 2, 0, 2).shape) == shape, n
+    for t, w in ((0, 0), (1, 1)):
+        C.save_isp_model_shard(str(tmp_path), mc, ck["params"], t, 2, w, 2)
+        ours = torch.load(os.path.join(tmp_path, f"model_tp{t}_wp{w}_pp0.pt"), weights_only=False)
+        theirs = torch.load(os.path.join(ref, f"model_tp{t}_wp{w}_pp0.pt"), weights_only=False)
+        assert list(ours) == list(theirs)
+        for k in ours:
+            assert ours[k].dtype == theirs[k].dtype and torch.equal(ours[k], theirs[k]), (t, w, k)
+    assert sorted(os.listdir(tmp_path)) == gold["files"]
+    # the weights are the run's: the oracle retraces the two steps before the save, and the loss of step 2 follows from the loaded weights alone
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    tr = OracleISPTrainer(OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16), c["sp"])
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for k in range(2):
+        batch, labels = next(loader)
+        r = tr.train_step(batch, labels)
+        assert abs(r["loss"] - gold["steps"][k]["loss"]) <= 1e-3 * r["loss"]
+    worst = max(float((tr.base.params[n].detach().float() - ck["params"][n].float()).abs().max()) for n in ck["params"])
+    print("max |weight difference| oracle vs the reference's saved ISP shards after two steps:", worst)
+    assert worst <= 1.6e-2   # (bf16 weights of magnitude <= 1.2: one or two ulps where an Adam sign decision differs)
+    with torch.no_grad():
+        for n in ck["params"]:
+            tr.base.params[n].copy_(ck["params"][n])
+    batch, labels = next(loader)
+    M = batch["input_ids"].shape[0]
+    from oracle.isp import isp_positions
+
+    idx, cu = isp_positions(c["seq_len"], c["sp"], "INTERNLM")
+    loss = sum(float(tr._loss(batch["input_ids"][i], labels[i], idx, cu).detach()) for i in range(M)) / M
+    assert abs(loss - gold["steps"][2]["loss"]) <= 1e-3 * loss, (loss, gold["steps"][2]["loss"])

@@ -364,9 +364,6 @@ def test_engine_7b_shaped_layer_full_size_matches_oracle(dev, all_host_cores):
     assert worst <= 8e-3
 
 
-COS_MIN, AGREE_MIN = 0.98, 0.97   # step 1 of the 7B-width merged test (measured values in the test's output)
-
-
 @pytest.mark.timeout(2400)
 def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev, all_host_cores):
     """The step bench.py times, at the model's full WIDTH with one layer: micro_num = 4 micro-batches of ONE 4096-token sequence each
@@ -375,13 +372,11 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev, all_host_core
     segments, one weight gradient over all 16 384 tokens -- against the CPU oracle, which walks the four micro-batches one after the
     other with autograd's bf16 gradient accumulation.  Checked: loss and global gradient norm, EVERY parameter's gradient in relative l2
     (sharper than the norm), the trained weights.
-    The learning rate is the RECIPE's 1e-4 (round-3 review: the test used to run at 1e-5).  Step 0 (identical weights): loss 1e-3, norm 2e-2, every
-    gradient in relative l2.  Then the recipe's own first update is applied on both sides and step 1 is compared in the quantity that update leaves
-    well defined: Adam's first update is lr * sign(g) in every coordinate, so wherever |g| is at rounding level the sign -- and with it a 2 lr
-    difference in that weight -- is decided by bf16 summation order, and step 1's gradients differ element-wise by more than step 0's; what must
-    agree is the DIRECTION of every parameter's gradient: the cosine between the HIP and the oracle gradient, and the share of the oracle gradient's
-    mass |g| on which the two agree in sign (the direction of the next lr * sign-like update).  The loss of step 1 is asserted at 2.5e-2 (the
-    eight-step recipe test's bound)."""
+    The learning rate is the RECIPE's 1e-4 (round-3 review: the test used to run at 1e-5 for one step).  Step 0 (identical weights) and step 1 -- after
+    the recipe's own first update, lr * sign(g) in every coordinate -- are both held to loss 1e-3, norm 2e-2, every parameter's gradient 1.5e-2 in
+    relative l2, plus the share of each gradient's mass |g| on which HIP and oracle agree in sign (the direction of the NEXT sign-like update)
+    >= 0.999.  (Round 3 saw 11 % on step 1's norm at this learning rate: that was the CPU kernel's swamped bf16 embedding-gradient sum in the oracle,
+    not the update -- oracle.ops.embedding_grad_in_fp32, which rests on test_embedding_gradient_of_the_benchmark_batch_against_fp64.)"""
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
@@ -408,24 +403,28 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev, all_host_core
             ref = ora.train_step(batch, labels)   # test_embedding_gradient_of_the_benchmark_batch_against_fp64 in test_kernels_gpu.py)
         print(f"7B-width merged step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
         assert st.skip == 0
-        # the (loss-scaled, accumulated) gradients themselves: the engine's flat gradient buffer is untouched until the next backward
-        rel, cos, agree = {}, {}, {}
+        # the (loss-scaled, accumulated) gradients themselves: the engine's flat gradient buffer is untouched until the next backward.  (Compared on
+        # the GPU in fp64: the tensors hold up to 380 M elements.)
+        rel, agree = {}, {}
         for n, g_ in eng.g.items():
-            want = ora.params[n].grad.float()
-            got = g_.float().cpu()
+            want = ora.params[n].grad.to(dev).double()
+            got = g_.double()
             rel[n] = float((got - want).norm() / want.norm())
-            cos[n] = float((got * want).sum() / (got.norm() * want.norm()))
             agree[n] = float((want.abs() * (torch.sign(got) == torch.sign(want))).sum() / want.abs().sum())
-            print(f"   step {k} grad {n}: relative l2 difference {rel[n]:.2e}, cosine {cos[n]:.5f}, sign agreement weighted by |g| {agree[n]:.5f}")
-        if k == 0:
-            assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])            # the north star's loss tolerance
-            assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
-            bad = {n: r for n, r in rel.items() if r > 1.5e-2}
-            assert not bad, bad
-        else:   # after the recipe's own first update (lr 1e-4 * sign(g) in every coordinate): the direction of every gradient
-            assert abs(float(loss) - ref["loss"]) <= 2.5e-2 * abs(ref["loss"]) + 4e-3
-            bad = {n: (cos[n], agree[n]) for n in cos if cos[n] < COS_MIN or agree[n] < AGREE_MIN}
-            assert not bad, bad
+            print(f"   step {k} grad {n}: relative l2 difference {rel[n]:.2e}, share of |g| with the same sign {agree[n]:.5f}")
+            del want, got
+        # BOTH steps to the north star's tolerances -- step 1 AFTER the recipe's own first update (lr 1e-4 * sign(g) in every coordinate): measured
+        # 3.1e-4 / 2.4e-3 on loss / norm and <= 4.4e-3 on every gradient at step 1 (3e-5 / 2.6e-3 / <= 3.5e-3 at step 0)
+        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])
+        assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+        bad = {n: (rel[n], agree[n]) for n in rel if rel[n] > 1.5e-2 or agree[n] < 0.999}
+        assert not bad, bad
+    worst = 0.0
+    for n, p in eng.named_parameters():
+        if n in ("layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
+            worst = max(worst, float((p.float() - ora.params[n].detach().to(dev).float()).abs().max()))
+    print("max |param diff| after the two merged steps:", worst)
+    assert worst <= 8e-3
 
 
 @pytest.mark.timeout(900)

@@ -207,6 +207,60 @@ def test_isp_engine_retraces_the_reference_bf16_isp_runs(dev, backend, tag, wp_m
     assert res[0][2] == res[1][2], "both ranks hold (gather) the same parameters"
 
 
+def _isp_ckpt_worker(rank, world, port, q, out_folder):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+
+        gold = json.load(open(os.path.join(G, "ckpt_isp2v1.json")))
+        c = gold["config"]
+        cfg = _v1_cfg(c)
+        cfg.train.wp_size = c["wp"]
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, sp_size=c["sp"], weight_parallel=True)
+        with pytest.raises(NotImplementedError):
+            eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp2v1"))          # a full resume from the ISP layout is refused ...
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp2v1"), model_only=True)   # ... its model weights load (load_ckpt_info content = ("model",))
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        batch, labels = next(loader)
+        loss = float(eng.forward_backward(_isp_batch(batch, c["sp"], "INTERNLM"), labels))
+        eng.save_model_isp(out_folder)
+        q.put((rank, loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_isp_layout_model_files_load_into_the_engine_and_are_written_back(dev, backend, tmp_path):  # noqa: F811
+    """tests/golden/ckpt_ref_isp2v1/ (the MODEL files a real two-process ISP run of the reference wrote after two steps: model_tp{t}_wp{w}_pp0.pt) into
+    the HIP engine under the same layout (sp 2 x wp 2, every rank keeping its weight-parallel shard of the merged model): the loss of the NEXT batch is the
+    reference's step-2 loss (1e-3; it follows from the weights alone), and save_model_isp writes the reference's files back tensor for tensor."""
+    world = 2
+    out = str(tmp_path / "isp_out")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_isp_ckpt_worker, args=(r, world, 29797, q, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    gold = json.load(open(os.path.join(G, "ckpt_isp2v1.json")))
+    want = gold["steps"][gold["saved_after_step"]]["loss"]
+    print(f"loss on the loaded ISP shards: HIP {res[0][1]:.5f} | reference step {gold['saved_after_step']}: {want:.5f}")
+    assert res[0][1] == res[1][1] and abs(res[0][1] - want) <= 1e-3 * want
+    assert sorted(os.listdir(out)) == gold["files"]
+    for fn in gold["files"]:
+        if fn.startswith("model_"):
+            ours = torch.load(os.path.join(out, fn), weights_only=False)
+            theirs = torch.load(os.path.join(G, "ckpt_ref_isp2v1", fn), weights_only=False)
+            assert list(ours) == list(theirs) and all(torch.equal(ours[k], theirs[k]) for k in ours), fn
+
+
 # ---------------------------------------------------------------------------------------------------- configs[3]'s shape: tensor 2 x weight 4, InternLM-1 blocks
 def _small_v1(micro_num, layers=2, heads=4):
     return _v1_cfg(dict(vocab=512, hidden=64 * heads, layers=layers, heads=heads, seq_len=256, micro_num=micro_num, total_steps=6))

@@ -19,7 +19,7 @@ lr_scheduler = dict(total_steps={steps}, init_steps=0, warmup_ratio=0.01, eta_mi
 model = dict(checkpoint=False, num_attention_heads=4, vocab_size=512, hidden_size=256, num_layers=2, no_bias=True, mlp_ratio=3.5,
              dtype="torch.bfloat16", layer_norm_epsilon=1e-5, num_kv_attention_heads=2, use_flash_attn=True)
 parallel = dict(zero1=dict(size=-1), tensor=dict(size=1, mode="mtp"), pipeline=dict(size=1), weight=dict(size=1))
-ckpt = dict(enable_save_ckpt={save}, save_ckpt_folder="local:{folder}", checkpoint_every=2, load_ckpt_info={load})
+ckpt = dict(enable_save_ckpt={save}, save_ckpt_folder="local:{folder}", checkpoint_every=2, load_ckpt_info={load}, auto_resume=False)
 """
 
 
@@ -82,12 +82,31 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
     # the folder is a complete InternEvo checkpoint: model, optimizer shard + plan, and the logging rank's run state
     from internevo_amd import checkpoint as C
 
-    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["context.pt", "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt",
+    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["2.step", "context.pt", "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt",
                                                              "optimizer_tp0_pp0_zo0.pt", "sampler.pt", "schedulder.pt", "topo_tp0_pp0.json"]
     rs = C.load_run_state(os.path.join(folder, "2"))
     assert rs["context"] == dict(batch_count=1, num_consumed_samples_in_epoch=4, num_consumed_tokens=2 * 2 * 128, inf_nan_skip_batches=0,
                                  step_count=2, tensorboard_folder=None)
     assert rs["sampler"]["batch_count"] == 2 and rs["scheduler"]["after_scheduler_dict"]["last_epoch"] == 2
+    # auto_resume (the reference's DEFAULT, checkpoint_manager.py:296-305): load_ckpt_info is overridden by the latest complete checkpoint under
+    # save_ckpt_folder -- the folder with the largest {step}.step flag, here "4" -- and by nothing (a new run) when there is none
+    cfg3 = tmp_path / "cfg3.py"
+    cfg3.write_text(CFG.format(steps=6, save=False, folder=folder, load=_load_info(os.path.join(folder, "2"))).replace(", auto_resume=False", ""))
+    run3 = train.main(["--config", str(cfg3), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run3] == [4, 5] and any("Found latest ckpt" in ln and ln.rstrip(".").endswith("step: 4") for ln in lines)
+    cfg4 = tmp_path / "cfg4.py"
+    cfg4.write_text(CFG.format(steps=2, save=False, folder=str(tmp_path / "empty"), load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
+    run4 = train.main(["--config", str(cfg4), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run4] == [0, 1], "auto_resume with nothing saved yet: a new run (the shipped configs' load_ckpt_info placeholders are never opened)"
+    # auto_resume off: content = ("model",) takes the weights only -- step 0 of a fresh schedule on the trained weights; a missing folder is an error
+    cfg5 = tmp_path / "cfg5.py"
+    cfg5.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(os.path.join(folder, "4")).replace('("all",)', '("model",)')))
+    run5 = train.main(["--config", str(cfg5), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run5] == [0, 1, 2, 3] and run5[0]["loss"] < run1[1]["loss"] and run5[0]["lr"] == run1[0]["lr"]
+    cfg6 = tmp_path / "cfg6.py"
+    cfg6.write_text(CFG.format(steps=2, save=False, folder=folder, load=_load_info(str(tmp_path / "nowhere"))))
+    with pytest.raises(FileNotFoundError):
+        train.main(["--config", str(cfg6), "--launcher", "torch"], log=lines.append)
 
 
 @pytest.mark.gpu
@@ -105,7 +124,8 @@ def test_train_entry_default_model_type_is_the_dense_internlm1_model_and_resumes
     lines = []
     run1 = train.main(["--config", str(cfg1), "--launcher", "torch"], log=lines.append)
     assert len(run1) == 4 and sorted(os.listdir(folder)) == ["2", "4"] and run1[0]["loss"] > run1[3]["loss"]
-    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "optimizer_tp0_pp0_zo0.pt", "topo_tp0_pp0.json"]
+    assert sorted(os.listdir(os.path.join(folder, "2"))) == ["2.step", "context.pt", "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "model_tp0_pp0.pt", "optimizer_tp0_pp0_zo0.pt",
+                                                             "sampler.pt", "schedulder.pt", "topo_tp0_pp0.json"]
     sd = torch.load(os.path.join(folder, "2", "model_tp0_pp0.pt"), weights_only=False)
     assert list(sd)[:3] == ["model.embedding.weight", "model.blocks.0.mixer.Wqkv.weight", "model.blocks.0.mixer.Wqkv.bias"]
     cfg2 = tmp_path / "cfg2.py"

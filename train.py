@@ -42,6 +42,38 @@ def _local(path):
     return path
 
 
+def resolve_load(ck, log=lambda m: None):
+    """What a run starts from, as CheckpointManager.__init__ decides it (checkpoint_manager.py:296-305, initialize/legacy/launch.py:10-41):
+    `auto_resume` (default TRUE -- also when the key is absent and `load_given_ckpt` is not set) overrides `load_ckpt_info` with the LATEST complete checkpoint
+    under `save_ckpt_folder` (the folder holding the largest `{step}.step` flag), content "all" -- and with nothing when there is none: a new run;
+    otherwise `load_ckpt_info` = dict(path, content, ckpt_type), or the legacy `load_ckpt_folder` / `load_model_only_folder` keys.
+    -> (local folder or None, model_only)."""
+    from internevo_amd.checkpoint import latest_checkpoint
+
+    auto = ck.get("auto_resume", None)
+    if auto is None:
+        auto = not ck["load_given_ckpt"] if ck.get("load_given_ckpt", None) is not None else True
+    if auto:
+        folder, step = latest_checkpoint(_local(ck.get("save_ckpt_folder")))
+        log(f"Found latest ckpt {folder if folder else 'None'}, step: {step if folder else -1}...")
+        return folder, False
+    info = ck.get("load_ckpt_info", None)
+    if info is None:   # legacy keys
+        if ck.get("load_model_only_folder", None) is not None:
+            info = dict(path=ck["load_model_only_folder"], content=("model",), ckpt_type="internlm")
+        elif isinstance(ck.get("load_ckpt_folder", None), str):
+            info = dict(path=ck["load_ckpt_folder"], content=("model", "sampler", "optimizer"), ckpt_type="internlm")
+    if not info or info.get("path") is None:
+        return None, False
+    if info.get("ckpt_type", "internevo") not in ("internevo", "internlm", "normal"):
+        raise NotImplementedError(f"load_ckpt_info.ckpt_type {info.get('ckpt_type')!r}: InternEvo checkpoints only")
+    content = tuple(info.get("content", ("all",)))
+    folder = _local(info["path"])
+    if not os.path.isdir(folder):
+        raise FileNotFoundError(f"ckpt.load_ckpt_info.path: {folder} does not exist (auto_resume is off: refusing to start from scratch instead)")
+    return folder, "all" not in content and "optimizer" not in content
+
+
 def evaluate_on_val_dls(eng, val_loaders, step_count, dev, log):
     """eval/evaluation.py:45-147: a forward-only pass over every validation set with a fresh AccPerplex (no dataset types); the
     logging rank reports its own mean batch loss (divided by batches + 1e-6, as the reference does) and the all-reduced accuracy /
@@ -78,8 +110,10 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     from internevo_amd.moe_engine import MoEEngine
 
     data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
-    load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
+    load_folder, model_only = resolve_load(ck, log if rank == 0 else (lambda m: None))
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    if model_only:
+        raise NotImplementedError("INTERNLM_MoE: load_ckpt_info content = ('model',) (weights-only loads are the dense engine's)")
     if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and world > 1):
         raise NotImplementedError("INTERNLM_MoE runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
                                   "the dense engine); INTERNLM_MoE checkpoints cover one data-parallel rank")
@@ -91,8 +125,6 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     if load_folder:   # model + optimizer files of the reference / of save_checkpoint
         from internevo_amd.checkpoint import load_run_state
 
-        if not os.path.isdir(load_folder):
-            raise FileNotFoundError(f"ckpt.load_ckpt_folder / load_ckpt_info.path: {load_folder} does not exist (refusing to start from scratch instead)")
         eng.load_checkpoint(load_folder)
         # the run state as the reference writes it (schedulder.pt / sampler.pt / context.pt).  The batch index comes from context.pt's batch_count, NOT
         # from the count of successful optimizer steps: after a skipped (overflowed) step the two differ, and the data stream must move on exactly as an
@@ -170,13 +202,14 @@ def main(argv=None, log=print):
         return _train_moe(cfg, raw, dev, world, rank, args, log)
     eng = InternLM2Engine(cfg, dev, None, world, rank, seed=args.seed)
     ck = raw.get("ckpt", {}) or {}
-    load_folder = _local((ck.get("load_ckpt_info") or {}).get("path") if isinstance(ck.get("load_ckpt_info"), dict) else ck.get("load_ckpt_folder"))
+    load_folder, model_only = resolve_load(ck, log if rank == 0 else (lambda m: None))
     first_step, run_state = 0, None
-    if load_folder:
+    if load_folder and model_only:   # content = ("model",): the weights of another run; step count, optimizer, schedule and data stream start fresh
+        eng.load_checkpoint(load_folder, model_only=True)
+        log(f"load_ckpt_info: model weights from {load_folder}")
+    elif load_folder:
         from internevo_amd.checkpoint import load_run_state
 
-        if not os.path.isdir(load_folder):
-            raise FileNotFoundError(f"ckpt.load_ckpt_folder / load_ckpt_info.path: {load_folder} does not exist (refusing to start from scratch instead)")
         eng.load_checkpoint(load_folder)
         run_state = load_run_state(load_folder)  # schedulder.pt / sampler.pt / context.pt when the folder has them
         ctx = run_state["context"]
