@@ -17,24 +17,35 @@ def xport(port):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """Run the suite on four pytest-xdist workers by default (the GPU suite is host-bound: process spawns, imports, CPU oracles; one MI355X and
-    288 GB hold four tests at a time).  `-n N` on the command line wins; IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
+    """Run the suite on three pytest-xdist workers by default, `--dist loadgroup`: the two files of multi-process tests (up to eight ranks, each a
+    process with its own HIP context on the one GPU) are a group each, i.e. each runs serially on ONE worker -- many rank processes of several tests at
+    once oversubscribe the GPU's queues and every test slows down (measured: four free workers gained 15 % on the serial run) -- while the single-process
+    tests (kernels, engines against the CPU oracle, entry points) fill the third worker and the gaps.  `-n N` on the command line wins;
+    IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
     if (config.pluginmanager.hasplugin("xdist") and getattr(config.option, "numprocesses", None) is None and not os.environ.get("PYTEST_XDIST_WORKER")
             and os.environ.get("IE_TEST_SERIAL") != "1" and not getattr(config.option, "collectonly", False)):
-        config.option.numprocesses = 4
-        config.option.dist = "load"
+        config.option.numprocesses = 3
+        config.option.dist = "loadgroup"
 
 
-# the tests that hold the GPU / the host cores for minutes (7B-width shapes against the CPU oracle, eight ranks at 32 768 tokens): they go FIRST, one per
-# worker, so that the many small multi-process tests fill in around them instead of waiting behind them at the end of the run
-_LONGEST_FIRST = ("test_engine_7b_width_merged_benchmark_step_matches_oracle", "test_isp_config3_layout_seq32768_sp8_at_7b_width",
-                  "test_engine_7b_shaped_layer_full_size_matches_oracle", "test_sequence_parallel_sp4_sp8_equals_single_rank_step",
-                  "test_llama2_tensor_parallel_2_with_hybrid_zero_on_8_ranks", "test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width")
+# Order of the run: the two groups of multi-process tests first (one worker each, for minutes), then the single-process tests that hold the GPU / the
+# host cores longest (7B-width shapes against the CPU oracle), then everything else in file order.
+_GROUPS = {"test_multirank_gpu.py": "ranks_a", "test_dp_gpu.py": "ranks_b", "test_internlm1_gpu.py": "ranks_b"}
+_LONGEST_FIRST = ("test_engine_7b_width_merged_benchmark_step_matches_oracle", "test_engine_7b_shaped_layer_full_size_matches_oracle",
+                  "test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width", "test_flash_attention_benchmark_regime_matches_oracle")
 
 
 def pytest_collection_modifyitems(config, items):
     rank = {n: i for i, n in enumerate(_LONGEST_FIRST)}
-    items.sort(key=lambda it: rank.get(it.originalname or it.name, len(rank)))   # (stable: everything else keeps its order)
+
+    def key(it):
+        grp = _GROUPS.get(os.path.basename(str(it.fspath)))
+        if grp is not None and it.get_closest_marker("gpu") is not None:
+            it.add_marker(pytest.mark.xdist_group(grp))
+            return (0, grp, 0)
+        return (1, "", rank.get(getattr(it, "originalname", None) or it.name, len(rank)))
+
+    items.sort(key=key)   # (stable: inside a group and among the rest the file order stays)
 
 
 @pytest.fixture
