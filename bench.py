@@ -332,13 +332,24 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes): measured ratio to the algorithmic bytes x this run's algorithmic bytes
         traffic, traffic_note = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")) as f:
+            # round 4: measured on THIS workload -- two PMC passes of bench.py itself, every GEMM launch of the step as it runs (tools/gemm_traffic_in_step.py);
+            # falls back to the round-2 ratio of the 16 384-row shapes (kbench launches) when that file is absent
+            with open(os.path.join(ROOT, "profiles", "r04_gemm_hbm_traffic.json")) as f:
                 tj = json.load(f)
-            traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
-            traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
-                            "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes, a committed measurement -- not re-measured by this run; fabric-side L2 misses incl. Infinity-Cache hits: every block of 32 tiles of an XCD re-reads its 12 operand panels; the round-3 w1|w3 launch with the gate in its epilogue fetches the same and writes 0.47 GB more, profiles/r03_ffn_traffic.md)")
+            traffic = float(tj["traffic_bytes_per_launch"])
+            traffic_note = (f"{traffic / (s['bytes'] / max(s['launches'], 1)):.2f}x the algorithmic bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                            f"bench.py itself ({tj['gemm_launches']} GEMM launches of three steps, the kernels the step runs incl. the fused-gate w1|w3 product; "
+                            "profiles/r04_gemm_hbm_traffic.json -- a committed measurement of this workload, not re-measured by this run; fabric-side L2 misses "
+                            "incl. Infinity-Cache hits, FETCH_SIZE doubled per MI355X_MICROARCH.md)")
         except (OSError, KeyError, ValueError):
-            pass
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")) as f:
+                    tj = json.load(f)
+                traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
+                traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
+                                "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes, kbench launches -- a committed measurement, not re-measured by this run)")
+            except (OSError, KeyError, ValueError):
+                pass
         out["roofline"] = {
             "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM on v_mfma_f32_32x32x16_bf16; fwd and long dgrads: one wave per SIMD, operand-wise refill of two 64-deep stages; other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
             "bound": "mfma",

@@ -195,9 +195,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     wp_size = int(weight.get("size", 1) if isinstance(weight, dict) else weight)
     if wp_size > 1 and tensor.get("mode", "mtp") != "isp" and tensor.get("size", 1) != 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: parallel.weight.size > 1 outside tensor mode 'isp'")
-    if pp_size > 1 and (sp_size > 1 or (tp_size > 1 and tp_mode != "mtp")):
-        raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallelism together with sequence parallelism / the sequence-sharded tensor modes "
-                                  "(pipeline x tensor mode 'mtp' runs)")
+    if pp_size > 1 and wp_size > 1:
+        raise NotImplementedError(f"{_UNSUPPORTED}: pipeline parallelism together with parallel.weight.size > 1")
     model_type = cfg.get("model_type", "INTERNLM")   # the reference's default (initialize/launch.py:78-79)
     if model_type not in ("INTERNLM2_PUBLIC", "LLAMA2", "INTERNLM_MoE", "INTERNLM"):
         raise NotImplementedError(f"{_UNSUPPORTED}: model_type {model_type}")

@@ -90,9 +90,8 @@ class InternLM2Engine:
             raise NotImplementedError("tensor parallelism and sequence parallelism are alternatives (parallel.tensor has ONE mode)")
         pp_size = int(getattr(tc, "pp_size", 1) if pp_size is None else pp_size)
         tp_ss = tp_size > 1 and (getattr(tc, "tp_mode", "mtp") if tp_mode is None else tp_mode) in ("msp", "fsp")
-        if pp_size > 1 and (tp_ss or sp_size > 1 or mc.checkpoint_layers):
-            raise NotImplementedError("pipeline parallelism combines with data parallelism / ZeRO and Megatron tensor parallelism of mode 'mtp' (no "
-                                      "sequence-sharded tensor modes, no Ulysses / ISP sequence parallelism, no activation checkpointing)")
+        if pp_size > 1 and mc.checkpoint_layers:
+            raise NotImplementedError("pipeline parallelism without activation checkpointing (a stage keeps the activation sets of its in-flight micro-batches)")
         self.pp = pp_size
         # every data-parallel group of the job (hybrid ZeRO creates its sub-groups collectively over all of them); a caller-supplied
         # process group is taken as the job's only one
@@ -160,9 +159,9 @@ class InternLM2Engine:
         L = self.layout
         self.comm = ZeroComm(L, process_group, world_size, rank, force_collectives, zero_size=zs, dp_groups=dp_groups)
         self.sp = sp_size
-        self.seqpar = SeqParallel(sp_size, rank, world_size)
-        if pp_size > 1:  # every stage of a pipeline reads the same batches
-            self.seqpar.data_rank, self.seqpar.data_world = self.pipe.dp_rank, self.pipe.dp_world
+        # (rank / world_size are stage-local under pipeline parallelism: every stage of a pipeline reads the same batches, and inside a stage the ranks of a
+        # sequence group do)
+        self.seqpar = SeqParallel(sp_size, self.pipe.dp_rank if pp_size > 1 else rank, self.pipe.dp_world if pp_size > 1 else world_size, stages=pp_size, stage=self.pipe.stage)
         if tp_size > 1:  # ... and so does every rank of a tensor group (inside a stage, under pipeline parallelism)
             self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
         self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
@@ -657,7 +656,8 @@ class InternLM2Engine:
             self._layer_ready(l, l + 1 if l + 1 < lb else None)
             ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
         if not is_last:   # the output = the residual stream after the last layer; norm, head and loss live behind the model's last layer
-            torch.add(ffn_out, self.a_r2[self.slot[lb - 1]], out=self.t_send)
+            rl = self.rl    # (msp / fsp: this rank's token rows of it -- what travels to the same tensor rank of the next stage)
+            torch.add(ffn_out[rl], self.a_r2[self.slot[lb - 1]][rl], out=self.t_send[rl])
             return
         self._wait_bucket(L + 1)
         rl = self.rl
@@ -905,10 +905,10 @@ class InternLM2Engine:
                     self._rs_deferred = 1 + l
                 else:
                     self._reduce_bucket(1 + l)
-        if ss:   # the embedding's backward (or the previous pipeline stage) takes the whole sequence (embedding.py:57-58)
-            self.tpar.all_gather_rows_async(d_out).wait()
         if not is_first:
-            return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage
+            return d_out   # gradient of this stage's (chunk's) input: travels to the previous stage (msp / fsp: this rank's token rows of it are valid)
+        if ss:   # the embedding's backward takes the whole sequence (embedding.py:57-58)
+            self.tpar.all_gather_rows_async(d_out).wait()
         if mc.embed_grad_scale != 1.0:
             K.scale_bf16(d_out, mc.embed_grad_scale)   # d(s x + (1 - s) x.detach()) / dx = s
         if self.embed_split:   # ... split backward: this rank's columns of the gradient
@@ -965,7 +965,7 @@ class InternLM2Engine:
     _ACT_SETS = ("a_x", "a_n1", "a_rstd1", "a_q", "a_kv", "a_ctx", "a_lse", "a_r2", "a_n2", "a_rstd2", "a_w13")
 
     def _act_set_names(self):
-        return self._ACT_SETS + (("a_act",) if self.a_act is not None else ())
+        return self._ACT_SETS + (("a_act",) if self.a_act is not None else ()) + (("a_ctxl",) if self.sp > 1 else ())
 
     def _alloc_inflight_sets(self):
         """A stage keeps the saved activations of up to pp - stage micro-batches (forwarded, not yet backwarded): whole extra sets
@@ -979,7 +979,12 @@ class InternLM2Engine:
     def _bind_inflight(self, i):
         for name, lst in self._sets[i % len(self._sets)].items():
             setattr(self, name, lst)
-        self.a_ctxl = self.a_ctx   # (no sequence parallelism under pipeline parallelism: the attention output is the wo input)
+        if self.sp == 1:
+            self.a_ctxl = self.a_ctx   # (without sequence parallelism the attention output is the wo input)
+
+    def _p2p(self, t):
+        """What travels between stages of a [T, hidden] residual-stream tensor: all of it, or (msp / fsp) this rank's token rows."""
+        return t[self.rl] if self.ss else t
 
     def _forward_backward_pipeline(self, batch, labels):
         """One PipelineScheduler.forward_backward_step of this stage: warm-up forwards, one-forward-one-backward, cool-down backwards.
@@ -997,10 +1002,13 @@ class InternLM2Engine:
         if self.metric is not None and self.metric.ntypes:
             self.metric.set_current_type_ids(batch["type_ids"])
 
+        lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T   # this rank's tokens of every micro-batch (all of them without sp)
+        pr = self._p2p
+
         def args(i):
             cu_h = batch["cu_seqlens"][i]
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
-            return ids_d[i], lab_d[i], cu_h.to(self.dev, non_blocking=True), pos_d[i], int((cu_h[1:] - cu_h[:-1]).max())
+            return ids_d[i, lo:hi], lab_d[i, lo:hi], cu_h.to(self.dev, non_blocking=True), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
 
         def forward(i):
             self._bind_inflight(i)
@@ -1018,24 +1026,24 @@ class InternLM2Engine:
         warm = min(self.pp - P.stage - 1, M)
         rem = M - warm
         for i in range(warm):
-            P.exchange(recvs=[] if P.first else [(x_in(i), P.prev)])
+            P.exchange(recvs=[] if P.first else [(pr(x_in(i)), P.prev)])
             forward(i)
-            P.exchange(sends=[(self.t_send, P.next)])          # (warm > 0 only on stages before the last)
+            P.exchange(sends=[(pr(self.t_send), P.next)])          # (warm > 0 only on stages before the last)
         if rem > 0:
-            P.exchange(recvs=[] if P.first else [(x_in(warm), P.prev)])
+            P.exchange(recvs=[] if P.first else [(pr(x_in(warm)), P.prev)])
         for i in range(rem):
             forward(warm + i)
             if not P.last:                                      # send_forward_recv_backward
-                P.exchange(sends=[(self.t_send, P.next)], recvs=[(self.t_h1, P.next)])
+                P.exchange(sends=[(pr(self.t_send), P.next)], recvs=[(pr(self.t_h1), P.next)])
             g_in = backward(i)
             if i == rem - 1:
-                P.exchange(sends=[] if P.first else [(g_in, P.prev)])
+                P.exchange(sends=[] if P.first else [(pr(g_in), P.prev)])
             else:                                               # send_backward_recv_forward
-                P.exchange(sends=[] if P.first else [(g_in, P.prev)], recvs=[] if P.first else [(x_in(warm + i + 1), P.prev)])
+                P.exchange(sends=[] if P.first else [(pr(g_in), P.prev)], recvs=[] if P.first else [(pr(x_in(warm + i + 1)), P.prev)])
         for i in range(rem, M):
-            P.exchange(recvs=[(self.t_h1, P.next)])
+            P.exchange(recvs=[(pr(self.t_h1), P.next)])
             g_in = backward(i)
-            P.exchange(sends=[] if P.first else [(g_in, P.prev)])
+            P.exchange(sends=[] if P.first else [(pr(g_in), P.prev)])
         return P.broadcast_from_last(self.loss_acc)
 
     def _forward_backward_interleaved(self, batch, labels):
@@ -1080,10 +1088,13 @@ class InternLM2Engine:
         if self.metric is not None and self.metric.ntypes:
             self.metric.set_current_type_ids(batch["type_ids"])
 
+        lo, hi = self.seqpar.sp_rank * self.T, (self.seqpar.sp_rank + 1) * self.T
+        pr = self._p2p
+
         def args(i):
             cu_h = batch["cu_seqlens"][i]
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
-            return ids_d[i], lab_d[i], cu_h.to(self.dev, non_blocking=True), pos_d[i], int((cu_h[1:] - cu_h[:-1]).max())
+            return ids_d[i, lo:hi], lab_d[i, lo:hi], cu_h.to(self.dev, non_blocking=True), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
 
         def gbuf(m, c):
             key = (self._slot_of[m], c)
@@ -1106,8 +1117,8 @@ class InternLM2Engine:
                     if v != last_v:
                         self.t_h1.copy_(gbuf(m, c))
                     g_in = self._backward_micro(*args(m), m == M - 1, m == 0, chunk=c)
-            sends = [(self.t_send if k == "F" else g_in, P.stage_rank[to]) for k, m, c, to in tick["sends"]]
-            recvs = [(self._sets[self._slot_of[m]]["a_x"][self.chunks[c][0]] if k == "F" else gbuf(m, c), P.stage_rank[frm]) for k, m, c, frm in tick["recvs"]]
+            sends = [(pr(self.t_send if k == "F" else g_in), P.stage_rank[to]) for k, m, c, to in tick["sends"]]
+            recvs = [(pr(self._sets[self._slot_of[m]]["a_x"][self.chunks[c][0]] if k == "F" else gbuf(m, c)), P.stage_rank[frm]) for k, m, c, frm in tick["recvs"]]
             P.exchange(sends=sends, recvs=recvs)
         return P.broadcast_from_last(self.loss_acc)
 
@@ -1149,12 +1160,12 @@ class InternLM2Engine:
             try:
                 for i in range(npass):
                     self._bind_inflight(0)
-                    P.exchange(recvs=[] if P.first else [(self.a_x[0], P.prev)])
-                    self._forward_micro(ids_d[i], lab_d[i], cu, pos_d, S)
+                    P.exchange(recvs=[] if P.first else [(self._p2p(self.a_x[0]), P.prev)])
+                    self._forward_micro(ids_d[i, lo:hi], lab_d[i, lo:hi], cu, pos_d[lo:hi], S)
                     if P.last:
                         out.add_(self.t_loss[0:1], alpha=1.0 / M)
                     else:
-                        P.exchange(sends=[(self.t_send, P.next)])
+                        P.exchange(sends=[(self._p2p(self.t_send), P.next)])
             finally:
                 self.metric = train_metric
             return P.broadcast_from_last(out)
@@ -1263,7 +1274,7 @@ class InternLM2Engine:
         belongs to whichever piece it falls into)."""
         if getattr(self, "_pieces", None) is None:
             L, out = self.layout, []
-            head = L.params["output.weight"]
+            head = L.params.get("output.weight")   # (None on a pipeline stage other than the last: its last bucket is empty)
             for b in L.buckets:
                 s0, n = b.shard(self.rank, self.world)
                 if n == 0:
@@ -1286,8 +1297,13 @@ class InternLM2Engine:
         tc, L = self.tc, self.layout
         pieces = self._group_pieces()
         for grp in (0, 1):
-            K.sumsq([shards[b.index][o : o + n] for b, o, n, g_ in pieces if g_ == grp], self.sumsq_g[grp : grp + 1], False, self.sumsq_ws)
+            mine = [shards[b.index][o : o + n] for b, o, n, g_ in pieces if g_ == grp]
+            if mine:
+                K.sumsq(mine, self.sumsq_g[grp : grp + 1], False, self.sumsq_ws)
+            else:   # (a middle pipeline stage holds neither embedding nor head)
+                self.sumsq_g[grp : grp + 1].zero_()
         self.comm.all_reduce_sum(self.sumsq_g)
+        self.pipe.all_reduce_sum(self.sumsq_g)   # every group's norm (and the overflow decision) covers all stages of the pipeline
         K.step_control_groups(self.state, self.sumsq_g, self.scaler_cfg, self.group_inv, self.group_norm)
         lr, beta2 = self.lr_sched.lr(), self.beta2_sched.beta2()
         main = torch.cuda.current_stream(self.dev)
@@ -1348,7 +1364,9 @@ class InternLM2Engine:
             for sh in shards:
                 K.scale_bf16(sh, 1.0 / n_)
         for name in ("tok_embeddings.weight", "output.weight"):
-            spec = L.params[name]
+            spec = L.params.get(name)
+            if spec is None:   # (another pipeline stage holds it)
+                continue
             for b, sh in zip(L.buckets, shards):
                 s0, n0 = b.shard(self.rank, self.world)
                 a, z = max(s0, spec.offset), min(s0 + n0, spec.offset + spec.numel)

@@ -23,7 +23,9 @@ from .comm import backend_for
 
 
 class SeqParallel:
-    def __init__(self, sp_size, rank, world_size):
+    def __init__(self, sp_size, rank, world_size, stages=1, stage=0):
+        """rank / world_size: this rank inside ONE pipeline stage and the stage's size (the whole job without pipeline parallelism); stages / stage: the
+        pipeline size and this rank's stage (stage s = the global ranks s * world_size ...): every rank of the job creates every group of every stage."""
         if world_size % sp_size != 0:
             raise ValueError(f"world size {world_size} is not a multiple of the sequence-parallel size {sp_size}")
         self.sp = sp_size
@@ -38,11 +40,13 @@ class SeqParallel:
                 raise RuntimeError("torch.distributed must be initialised for sequence parallelism")
             # consecutive ranks share a sequence (parallel_context.py: the tensor group is the innermost dimension);
             # every rank has to take part in the creation of every group
-            for g in range(world_size // sp_size):
-                ranks = list(range(g * sp_size, (g + 1) * sp_size))
-                grp = dist.new_group(ranks)
-                if rank in ranks:
-                    self.group = grp
+            me = stage * world_size + rank
+            for s_ in range(stages):
+                for g in range(world_size // sp_size):
+                    ranks = [s_ * world_size + r for r in range(g * sp_size, (g + 1) * sp_size)]
+                    grp = dist.new_group(ranks)
+                    if me in ranks:
+                        self.group = grp
             self.be = backend_for(self.group)
             self.backend = self.be.name
 

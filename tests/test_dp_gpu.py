@@ -683,7 +683,7 @@ def _pp_worker(rank, world, port, q, pp, layers, micro_num, fixed, chunks=1, zer
         dist.destroy_process_group()
 
 
-def _pp_tp_worker(rank, world, port, q, chunks):
+def _pp_tp_worker(rank, world, port, q, chunks, mode="mtp"):
     import torch.distributed as dist
 
     dev = _init_dist(rank, world, port)
@@ -692,8 +692,10 @@ def _pp_tp_worker(rank, world, port, q, chunks):
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init
 
-        eng = InternLM2Engine(_pp_cfg(4, 4), dev, None, world, rank, init_fn=formula_init, pp_size=2, tp_size=2, num_chunks=chunks, vocab_parallel=True)
-        assert (eng.pipe.stage, eng.tpar.tp_rank, eng.dp_world) == (rank // 2, rank % 2, 1)
+        kw = dict(sp_size=2) if mode == "isp" else dict(tp_size=2, tp_mode=mode, vocab_parallel=True)
+        eng = InternLM2Engine(_pp_cfg(4, 4), dev, None, world, rank, init_fn=formula_init, pp_size=2, num_chunks=chunks, **kw)
+        assert (eng.pipe.stage, eng.seqpar.sp_rank if mode == "isp" else eng.tpar.tp_rank, eng.seqpar.data_world) == (rank // 2, rank % 2, 1)
+        assert eng.ss == (mode in ("msp", "fsp")) and eng.isp_groups == (mode == "isp")
         loader = iter(SyntheticLoader(128, 1, 4, False, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
         for _ in range(3):
@@ -709,31 +711,36 @@ def _pp_tp_worker(rank, world, port, q, chunks):
 
 @pytest.mark.timeout(600)
 @pytest.mark.ranks(4)
-@pytest.mark.parametrize("chunks", [1, 2], ids=["1f1b", "interleaved"])
-def test_pipeline_with_tensor_parallelism_equals_single_rank_step(dev, backend, chunks):
+@pytest.mark.parametrize("chunks,mode", [(1, "mtp"), (2, "mtp"), (1, "msp"), (1, "isp"), (2, "isp")],
+                         ids=["1f1b", "interleaved", "1f1b_msp", "1f1b_isp", "interleaved_isp"])
+def test_pipeline_with_tensor_parallelism_equals_single_rank_step(dev, backend, chunks, mode):
     """parallel.pipeline = dict(size=2) together with parallel.tensor = dict(size=2, mode="mtp") on four ranks (tensor groups inside a stage, a rank's
     pipeline peer holds the same tensor position; vocabulary-parallel loss on the last stage): loss on every rank, global gradient norm (tensor-replicated
-    parameters counted once, summed over the tensor group AND the stages) as ONE rank on the same micro-batches; norm weights stay equal inside a tensor group."""
+    parameters counted once, summed over the tensor group AND the stages) as ONE rank on the same micro-batches; norm weights stay equal inside a tensor group.
+    Round 4: also with the sequence-sharded tensor mode msp (between stages travel only a rank's T / tp token rows of the residual stream and of its
+    gradient; the all-gathers sit in front of the stage's first products) and with Ulysses / ISP sequence parallelism (mode "isp": every rank of a stage's
+    sequence group works on its tokens; the two ISP optimizer groups -- embedding on the first stage, head on the last -- are normed over the pipeline;
+    against one rank with the ISP gradient rule emulated)."""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_pp_tp_worker, args=(r, 4, 29841 + chunks, q, chunks)) for r in range(4)]
+    procs = [ctx.Process(target=_pp_tp_worker, args=(r, 4, 29841 + chunks + 3 * ["mtp", "msp", "isp"].index(mode), q, chunks, mode)) for r in range(4)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, 4), key=lambda x: x[0])
     for p in procs:
         p.join(60)
-    eng = InternLM2Engine(_pp_cfg(4, 4), dev, init_fn=formula_init)
+    eng = InternLM2Engine(_pp_cfg(4, 4), dev, init_fn=formula_init, emulate_isp_grad_rule=2 if mode == "isp" else 1)
     loader = iter(SyntheticLoader(128, 1, 4, False, 4000))
     for k in range(3):
         batch, labels = next(loader)
         loss = eng.forward_backward(batch, labels)
         eng.step()
         ref = (float(loss), float(eng.read_state().grad_norm))
-        print(f"step {k}: pp2 x tp2 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[0]:.5f} gn {ref[1]:.4f}")
+        print(f"step {k}: pp2 x {mode}2 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[0]:.5f} gn {ref[1]:.4f}")
         for r in res:
             assert r[1][k] == res[0][1][k], "every rank of the job reports the same loss and global norm"
         assert abs(res[0][1][k][0] - ref[0]) <= 1e-3 * ref[0] and abs(res[0][1][k][1] - ref[1]) <= 2e-2 * ref[1]

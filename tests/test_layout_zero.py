@@ -75,12 +75,16 @@ def test_reference_config_files_map(tmp_path):
     assert from_reference_dict(pp).train.pp_size == 4                       # non-interleaved 1F1B (pipeline.py)
     pp["parallel"]["tensor"] = dict(size=2, mode="mtp")                     # ... together with Megatron tensor parallelism of mode mtp
     assert (from_reference_dict(pp).train.pp_size, from_reference_dict(pp).train.tp_size) == (4, 2)
-    pp["parallel"]["tensor"] = dict(size=2, mode="msp")                     # ... but not with the sequence-sharded tensor modes / sequence parallelism
-    with pytest.raises(NotImplementedError):
-        from_reference_dict(pp)
+    pp["parallel"]["tensor"] = dict(size=2, mode="msp")                     # ... with the sequence-sharded tensor modes and with sequence parallelism (round 4)
+    t = from_reference_dict(pp).train
+    assert (t.pp_size, t.tp_size, t.tp_mode, t.sp_size) == (4, 2, "msp", 1)
     pp["parallel"]["tensor"] = dict(size=2, mode="isp")
+    t = from_reference_dict(pp).train
+    assert (t.pp_size, t.tp_size, t.sp_size) == (4, 1, 2)
+    pp["parallel"]["weight"] = dict(size=2)                                 # ... but not with weight parallelism
     with pytest.raises(NotImplementedError):
         from_reference_dict(pp)
+    pp["parallel"].pop("weight")
     pp["parallel"]["tensor"] = 1
     pp["model"]["num_chunks"] = 2                                           # interleaved 1F1B: two model chunks per stage
     pp["data"]["micro_num"] = 8
