@@ -172,7 +172,7 @@ class _RefEnumModule:
                 sys.modules[name] = types.ModuleType(name)
                 self.created.append(name)
         mod = sys.modules[_PM_MODULE]
-        pm = enum.Enum("ParallelMode", {"ZERO1": "zero1", "EXPERT_DATA": "expert_data"}, module=_PM_MODULE)
+        pm = enum.Enum("ParallelMode", {"ZERO1": "zero1", "EXPERT_DATA": "expert_data", "DATA": "data"}, module=_PM_MODULE)
         mod.ParallelMode = pm
         self.pm = pm
         return pm.ZERO1
@@ -370,6 +370,133 @@ def load_isp_model(folder, model_cfg):
     return out, tp_world, wp_world
 
 
+def isp_coords(rank, world, sp, wp):
+    """The group ranks of global rank `rank` in an ISP job of `world` ranks, tensor (= sequence) size sp, weight size wp, zero1.size -1
+    (process_group_initializer.py: tensor and weight groups are blocks of consecutive ranks; pinned by tests/golden/ckpt_isp4v1_rank*.json):
+    dict(t, w, d, z, data_world, zero_world) -- tensor rank, weight rank, data rank (= rank // sp), ZERO1 rank (= weight-data rank = rank // wp)."""
+    if world % sp or world % wp:
+        raise ValueError(f"an ISP job of {world} ranks with tensor size {sp} and weight size {wp}")
+    return dict(t=rank % sp, w=rank % wp, d=rank // sp, z=rank // wp, data_world=world // sp, zero_world=world // wp)
+
+
+def isp_groups(model_cfg):
+    """[(group name, parameter names in module order)] of an ISP run's optimizer groups (train/utils.py:11-80): "default" = the layers' ISPLinear weights and
+    biases + every norm weight, ZeRO over the weight-data group; "embed_head" = embedding + head, ZeRO over the DATA group; "fp32" (empty in a bf16 run)."""
+    order = state_dict_order(model_cfg)
+    eh = [n for n in order if isp_split(n)[0] == "tp"]
+    return [("default", [n for n in order if n not in eh]), ("embed_head", eh), ("fp32", [])]
+
+
+def _isp_group_layout(model_cfg, full_shapes, c, sp, wp):
+    """Per group: (flat order of (name, LOCAL shape) on a rank with coordinates c, partition over the group's zero world)."""
+    out = []
+    for g, (_, names) in enumerate(isp_groups(model_cfg)):
+        local = [(n, tuple(isp_shard(n, torch.empty(full_shapes[n], device="meta"), c["t"], sp, c["w"], wp).shape)) for n in names]
+        fo = zero_flat_order(local)
+        out.append((fo, zero_partition(fo, c["data_world"] if g == 1 else c["zero_world"])))
+    return out
+
+
+def save_isp_optimizer_shard(folder, model_cfg, rank, world, sp, wp, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16):
+    """What global rank `rank` of an ISP job writes (checkpoint/components.py:377-410): `optimizer_tp{t}_wp{w}_pp0_dp{d}.pt` -- three groups, the flat fp32
+    master weights / AdamW moments of the rank's partitions of ITS local shards (group "default": partition z of the weight-data group; "embed_head":
+    partition d of the data group), the reference's greedy whole-parameter partition of the LOCAL shapes -- and the plan file.  master / exp_avg /
+    exp_avg_sq: name -> FULL fp32 host tensor, at least for the parameters this rank's partitions hold (isp_rank_names)."""
+    os.makedirs(folder, exist_ok=True)
+    c = isp_coords(rank, world, sp, wp)
+    full_shapes = {n: tuple(t.shape) for n, t in master.items()} if len(master) == len(state_dict_order(model_cfg)) else None
+    if full_shapes is None:
+        raise ValueError("save_isp_optimizer_shard takes the shapes of ALL parameters from `master` (entries a rank does not own may be meta / empty tensors)")
+    layout = _isp_group_layout(model_cfg, full_shapes, c, sp, wp)
+    plan = [[_plan_ids(fo, idx) for idx in part] for fo, part in layout]
+
+    def flat(named, g):
+        fo, part = layout[g]
+        mine = part[c["d"] if g == 1 else c["z"]]
+        return torch.cat([isp_shard(fo[i][0], named[fo[i][0]].detach().to("cpu", torch.float32), c["t"], sp, c["w"], wp).reshape(-1) for i in mine])
+
+    with _RefEnumModule() as zero1:
+        pm = type(zero1)
+        tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
+                    differentiable=False, fused=True, decoupled_weight_decay=True)
+        wd, ilr = hyper["weight_decay"], hyper["initial_lr"]
+        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=[0]),
+               dict(name="embed_head", optimizer_mode=pm.DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=[1]),
+               dict(name="fp32", optimizer_mode=zero1, weight_decay=wd, **tail, dtype=None, initial_lr=ilr, params=[])]
+        states = {
+            "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]), "_hysteresis_step": int(scaler["hysteresis_step"])},
+            "base_optim_states": {"state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
+                                            for g in (0, 1)},
+                                  "param_groups": pgs},
+            "flat_fp32_weights": {g: flat(master, g) for g in (0, 1)},
+            "zero_devide_optim_plan": plan,
+        }
+        torch.save(states, os.path.join(folder, f"optimizer_tp{c['t']}_wp{c['w']}_pp0_dp{c['d']}.pt"))
+        torch.save(plan, os.path.join(folder, f"gpus-{world}_wp-{c['w']}_tp-{c['t']}_dp-{c['d']}_pp-0_zo-{c['z']}.pt"))
+
+
+def isp_rank_names(model_cfg, full_shapes, rank, world, sp, wp):
+    """The parameters (reference names) of which global rank `rank` of an ISP job holds optimizer state -- whole LOCAL shards, both groups."""
+    c = isp_coords(rank, world, sp, wp)
+    layout = _isp_group_layout(model_cfg, full_shapes, c, sp, wp)
+    return [layout[g][0][i][0] for g in (0, 1) for i in layout[g][1][c["d"] if g == 1 else c["z"]]]
+
+
+def load_isp_optimizer(folder, model_cfg, params):
+    """The FULL fp32 master weights and AdamW moments out of the optimizer shards of an ISP-layout folder (`optimizer_tp{t}_wp{w}_pp0_dp{d}.pt` of every
+    rank + the plan files, whose names carry the rank's zero1 position): every local shard is put back at its place in the full tensor.  params: the merged
+    model (load_isp_model) for the shapes.  -> dict(master, exp_avg, exp_avg_sq, adam_step, scaler, lr)."""
+    import re
+
+    files = {}
+    for fn in os.listdir(folder):
+        m = re.fullmatch(r"gpus-(\d+)_wp-(\d+)_tp-(\d+)_dp-(\d+)_pp-0_zo-(\d+)\.pt", fn)
+        if m:
+            world, w, t, d, z = (int(x) for x in m.groups())
+            files[(t, w, d)] = (world, z)
+    if not files:
+        raise FileNotFoundError(f"{folder}: no partition-plan files (gpus-*_wp-*_tp-*_dp-*_pp-0_zo-*.pt) next to the ISP optimizer shards")
+    world = next(iter(files.values()))[0]
+    sp, wp = max(t for t, _, _ in files) + 1, max(w for _, w, _ in files) + 1
+    full_shapes = {n: tuple(t.shape) for n, t in params.items()}
+    out = {k: {n: torch.zeros(full_shapes[n], dtype=torch.float32) for n in full_shapes} for k in ("master", "exp_avg", "exp_avg_sq")}
+    seen = {n: torch.zeros(full_shapes[n], dtype=torch.bool) for n in full_shapes}
+    meta = None
+    for (t, w, d), (wld, z) in sorted(files.items()):
+        st = _load(os.path.join(folder, f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt"))
+        c = dict(t=t, w=w, d=d, z=z, data_world=wld // sp, zero_world=wld // wp)
+        layout = _isp_group_layout(model_cfg, full_shapes, c, sp, wp)
+        for g in (0, 1):
+            fo, part = layout[g]
+            mine = part[d if g == 1 else z]
+            if list(st["zero_devide_optim_plan"][g][d if g == 1 else z]) != _plan_ids(fo, mine):
+                raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt: the partition plan of group {g} does not match this model / layout")
+            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
+                             ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
+                o = 0
+                for i in mine:
+                    n, shape = fo[i]
+                    k = 1
+                    for dd in shape:
+                        k *= dd
+                    isp_shard(n, out[key][n], t, sp, w, wp).copy_(vec.detach()[o : o + k].reshape(shape))
+                    if key == "master":
+                        isp_shard(n, seen[n], t, sp, w, wp).fill_(True)
+                    o += k
+                if o != vec.numel():
+                    raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt group {g}: {vec.numel()} elements, the partition holds {o}")
+        gs, base = st["grad_scaler"], st["base_optim_states"]
+        here = (int(float(base["state"][0]["step"])), float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
+        if meta is not None and here != meta:
+            raise ValueError("the ISP optimizer shards disagree on step / lr / loss scale")
+        meta = here
+    missing = [n for n, m_ in seen.items() if not bool(m_.all())]
+    if missing:
+        raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:4]} ... (files of some ranks are missing)")
+    return dict(out, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world // wp,
+                isp=dict(world=world, sp=sp, wp=wp))
+
+
 def save_isp_model_shard(folder, model_cfg, full_params, tp_rank, tp_world, wp_rank, wp_world, param_dtype=torch.bfloat16):
     """One rank's `model_tp{t}_wp{w}_pp0.pt` (+ the topology file) from the FULL parameters (reference names): what save_model_checkpoint writes on a
     rank with tensor rank t and weight rank w."""
@@ -465,12 +592,12 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
     """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, FULL tensors), adam_step, scaler, lr, zero_world, tp_world).
     Optimizer entries are None when the folder holds model weights only, or with model_only (load_ckpt_info content = ("model",): the optimizer files are not read).  Every shard in the folder is read and merged -- whatever
     ZeRO world and tensor-parallel size wrote them; `want` (a set of names) limits the optimizer tensors kept in memory."""
-    if saved_isp_layout(folder):   # model files of the ISP layout (model_tp{t}_wp{w}_pp0.pt): weights only
-        if not model_only:
-            raise NotImplementedError(f"{folder} holds a checkpoint of the ISP layout (model_tp*_wp*_pp*.pt): its model weights load (load_ckpt_info content = "
-                                      "('model',)); the optimizer shards of that layout (optimizer_tp*_wp*_pp*_dp*.pt) are not implemented")
+    if saved_isp_layout(folder):   # the ISP layout: model_tp{t}_wp{w}_pp0.pt + optimizer_tp{t}_wp{w}_pp0_dp{d}.pt, merged into FULL tensors
         params, tp_world, _ = load_isp_model(folder, model_cfg)
-        return dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0, tp_world=tp_world)
+        out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0, tp_world=tp_world)
+        if not model_only and any(fn.startswith("optimizer_tp") for fn in os.listdir(folder)):
+            out.update(load_isp_optimizer(folder, model_cfg, params))
+        return out
     tp_world = saved_tp_world(folder)
     if tp_world == 0:
         raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")

@@ -1562,16 +1562,24 @@ class InternLM2Engine:
                     out.append((n, a - spec.offset, e - a, lo + (a - s0)))
         return out
 
+    def _isp_layout(self):
+        """Sequence parallelism (tensor mode "isp") and / or weight parallelism: checkpoints take the reference's ISP layout."""
+        return self.sp != 1 or self.wp_mode
+
     def _checkpoint_guard(self):
-        if self.wp_mode:
-            raise NotImplementedError("checkpoints under weight parallelism are not implemented (the reference writes model_wp{w}_pp0.pt row shards)")
+        if self._isp_layout():
+            if self.pp != 1 or self.tp != 1:
+                raise NotImplementedError("checkpoints of the ISP layout (tensor mode 'isp' / parallel.weight) without pipeline parallelism")
+            zs_cfg = self.tc.zero1_size
+            wp = max(int(getattr(self.tc, "wp_size", 1) or 1), 1)
+            if self.job_world % wp or not (zs_cfg is None or zs_cfg <= 0 or zs_cfg >= self.job_world // wp):
+                raise NotImplementedError("checkpoints of the ISP layout with parallel.zero1.size below the weight-data size")
+            return
         if self.pp != 1 and (self.nch != 1 or self.tp != 1):
             raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule without tensor parallelism")
         if self._is_v1() and self.tp != 1:
             raise NotImplementedError("checkpoints of the InternLM-1 model under tensor parallelism are not implemented (a tensor rank's Wqkv rows are "
                                       "\"(three h/tp d)\": the ranks' files do not concatenate into the single-rank layout)")
-        if self.sp != 1:
-            raise NotImplementedError("checkpoints are not implemented under sequence parallelism (any data-parallel, tensor-parallel and pipeline size otherwise)")
 
     def _local_reference_named(self, named):
         """engine-named tensors of this rank -> the reference's names AND the reference's tensor-parallel cut: the layer weights are
@@ -1591,8 +1599,8 @@ class InternLM2Engine:
         """The MODEL files of the reference's ISP layout (checkpoint/components.py:221-226; checkpoint.save_isp_model_shard): `model_tp{t}_wp{w}_pp0.pt` with
         the embedding's hidden columns / the head's vocabulary rows of tensor (= sequence) rank t and the ISPLinear rows of weight rank w, written by the
         ranks the reference writes from (weight-data rank 0 or data rank 0); a reference job of the same tensor x weight sizes -- or this engine, in any
-        layout -- loads them with load_ckpt_info content = ("model",).  Collective.  (The optimizer shards of that layout are not written: a run under
-        sequence / weight parallelism cannot be RESUMED from its own checkpoint yet.)"""
+        layout -- loads them with load_ckpt_info content = ("model",).  Collective.  (save_checkpoint under sequence / weight parallelism writes these AND
+        the optimizer shards of the layout.)"""
         from . import checkpoint as C
 
         if self.tp != 1 or self.pp != 1:
@@ -1604,6 +1612,37 @@ class InternLM2Engine:
             C.save_isp_model_shard(folder, self.mc, named, r % sp, sp, r % wp, wp)
         self.comm.barrier()
 
+    def _save_checkpoint_isp(self, folder):
+        """save_checkpoint under sequence / weight parallelism: the reference's ISP layout (checkpoint.py: save_isp_model_shard / save_isp_optimizer_shard) --
+        every rank writes `optimizer_tp{t}_wp{w}_pp0_dp{d}.pt` (three groups: the partitions it would hold in a reference job of this size, of ITS local
+        shards) + its plan file, the ranks with weight-data rank 0 or data rank 0 the model files.  The engine's fp32 state lives in contiguous bucket slices
+        of the zero group, so every bucket is gathered once (collective) and every rank keeps the rows its partitions name.  Collective."""
+        from . import checkpoint as C
+
+        st = self.read_state()
+        tc, L = self.tc, self.layout
+        W, r = self.job_world, self.job_rank
+        sp, wp = self.sp, max(int(getattr(tc, "wp_size", 1) or 1), 1)
+        full_shapes = self.reference_param_shapes()
+        mine = {self._engine_name(n) for n in C.isp_rank_names(self.mc, full_shapes, r, W, sp, wp)}
+        state = {}
+        for key, flat in (("master", self.master), ("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            named = {}
+            for bi, (b, lo) in enumerate(zip(L.buckets, L.local_offsets())):   # every rank walks every bucket: the gather is collective
+                full = self.comm.gather_full_bucket(flat, lo, bi)
+                for n in b.params:
+                    spec = L.params[n]
+                    if n in mine:
+                        named[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape).to("cpu", copy=True)
+                    else:   # (only its shape is needed: the partition is computed from the shapes of ALL parameters)
+                        named[n] = torch.empty(spec.shape, dtype=torch.float32, device="meta")
+                del full
+            state[key] = self._to_reference_names(named)   # (the naming boundary's row permutations are views: fine on the shape-only meta tensors too)
+        hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
+        scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
+        C.save_isp_optimizer_shard(folder, self.mc, r, W, sp, wp, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step, scaler, self.lr_sched.lr(), hyper)
+        self.save_model_isp(folder)
+
     def save_checkpoint(self, folder):
         """InternEvo's checkpoint files (checkpoint.py): per tensor rank (and pipeline stage) the model weights (written by its data-parallel
         rank 0) and one hybrid-ZeRO optimizer shard + partition plan per data-parallel rank, in the reference's whole-parameter partition
@@ -1612,6 +1651,8 @@ class InternLM2Engine:
         from . import checkpoint as C
 
         self._checkpoint_guard()
+        if self._isp_layout():
+            return self._save_checkpoint_isp(folder)
         st = self.read_state()  # drains the optimizer stream
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
         tp, t = self.tp, self.tpar.tp_rank
@@ -1687,8 +1728,8 @@ class InternLM2Engine:
         self.drain()
         kind = lambda n: self.layout.params[n].kind  # noqa: E731
         for n, full in self._from_reference_names(ck["params"]).items():
-            if n in self.p:   # (a pipeline stage keeps its own layers)
-                self.p[n].copy_(self.tpar.shard(kind(n), full).to(self.dev, BF16))
+            if n in self.p:   # (a pipeline stage keeps its own layers; under weight parallelism a rank keeps its shard of a layer)
+                self._store_param(n, self.tpar.shard(kind(n), full).to(self.dev, BF16))
         if ck["master"] is None:
             self.sync_master_from_params()
             return

@@ -592,7 +592,10 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     cfg = tiny_config("torch.bfloat16", **kw)
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("IE_THREADS", "8")))
+    # CPU tensors are gathered over `gpc.get_cpu_group(mode)` (model/utils.py:101), which the reference only creates with use_cpu=True: every group of this
+    # harness is a gloo group already (harness only; with two ranks the missing group fell back to the world group, which WAS the tensor group)
+    gpc.get_cpu_group = gpc.get_group
     model = initialize_model()
     with torch.no_grad():
         if tp > 1:
@@ -639,7 +642,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_isp2v1" if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -679,7 +682,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
             save_model_checkpoint("local:" + folder, model)
-            if not isp:
+            if not isp or world == 4:   # (`--ckpt-isp4`: four processes = two weight-data / data replicas -> also the OPTIMIZER shards of the ISP layout)
                 save_optimizer_checkpoint(optimizer, "local:" + folder)
             if world == 1:
                 # the remaining files of CheckpointManager.save_checkpoint (checkpoint_manager.py:608-618), written the same way
@@ -694,7 +697,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                 rec["sampler_state"] = {k: (v if isinstance(v, (int, float, str, type(None))) else str(type(v))) for k, v in ss.items()}
             sd = model.state_dict()
             rec["model_keys"] = [[k, str(v.dtype), list(v.shape)] for k, v in sd.items()]
-            if isp:
+            if isp and world == 2:
                 continue
             osd = optimizer.state_dict()
             rec["optimizer_top_keys"] = list(osd.keys())
@@ -712,6 +715,14 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         import torch.distributed as dist
 
         dist.barrier()
+        if isp and world == 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
+            rec["files"] = sorted(os.listdir(folder))
+            rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.WEIGHT, ParallelMode.DATA,
+                                                                                            ParallelMode.WEIGHT_DATA, ParallelMode.ZERO1)}
+            rec["rank_unique_id"] = optimizer.rank_unique_id
+            with open(os.path.join(HERE, f"ckpt_isp4v1_rank{rank}.json"), "w") as f:
+                json.dump(rec, f, indent=1, default=str)
+            return
         if rank != 0 and pp == 1:
             return
     rec["files"] = sorted(os.listdir(folder))
@@ -1338,6 +1349,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-isp-rank":
         gen_checkpoint(port=29791, rank=int(sys.argv[2]), world=2, model_type="INTERNLM", isp=True)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-isp4-rank":
+        gen_checkpoint(port=29789, rank=int(sys.argv[2]), world=4, model_type="INTERNLM", isp=True)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp4":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp4-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))

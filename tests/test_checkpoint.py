@@ -672,8 +672,7 @@ def test_isp_layout_model_files_of_the_reference_load_and_are_reproduced(tmp_pat
                      mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
     ref = os.path.join(G, "ckpt_ref_isp2v1")
     assert sorted(C.saved_isp_layout(ref)) == [(0, 0), (1, 1)] and C.saved_tp_world(ref) == 0
-    with pytest.raises(NotImplementedError, match="ISP layout"):
-        C.load_checkpoint(ref, mc)                     # (its optimizer shards are not implemented: say so instead of resuming half a state)
+    assert C.load_checkpoint(ref, mc)["master"] is None   # (this fixture holds model files only; optimizer shards of the layout: the next test)
     ck = C.load_checkpoint(ref, mc, model_only=True)
     assert {n: tuple(t.shape) for n, t in ck["params"].items()} == {n: tuple(s_) for n, s_ in param_shapes(mc).items()} and ck["master"] is None
     # what rank 0 of the reference held: the shapes recorded from its own state dict
@@ -709,3 +708,82 @@ def test_isp_layout_model_files_of_the_reference_load_and_are_reproduced(tmp_pat
     idx, cu = isp_positions(c["seq_len"], c["sp"], "INTERNLM")
     loss = sum(float(tr._loss(batch["input_ids"][i], labels[i], idx, cu).detach()) for i in range(M)) / M
     assert abs(loss - gold["steps"][2]["loss"]) <= 1e-3 * loss, (loss, gold["steps"][2]["loss"])
+
+
+def _deep_equal(a, b, path=""):
+    if torch.is_tensor(a):
+        assert torch.is_tensor(b) and a.dtype == b.dtype and torch.equal(a, b), path
+    elif isinstance(a, dict):
+        assert list(a) == list(b), (path, list(a), list(b))
+        for k in a:
+            _deep_equal(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _deep_equal(x, y, f"{path}[{i}]")
+    else:
+        assert a == b or repr(a) == repr(b), (path, a, b)
+
+
+def test_isp_layout_optimizer_shards_of_the_reference_merge_are_reproduced_and_resume(tmp_path):
+    """tests/golden/ckpt_ref_isp4v1/ = what a real FOUR-process ISP run of the reference wrote after two steps (tensor 2 (isp) x weight 2 -> two weight-data /
+    data replicas; the dense InternLM-1 model; make_golden.py --ckpt-isp4): per rank `optimizer_tp{t}_wp{w}_pp0_dp{d}.pt` with THREE groups -- "default" (the
+    rank's local ISPLinear row shards + norms, partitioned over the weight-data group), "embed_head" (its embedding columns / head rows, partitioned over the
+    DATA group), "fp32" (empty) -- the reference's greedy whole-parameter partition of the LOCAL shapes, plus plan and model files.
+      * the reader merges all shards into FULL fp32 state: the master weights round to the merged bf16 model bit for bit;
+      * writing every rank's files from the merged state reproduces the reference's twelve files tensor for tensor (param_groups, plans, scaler included);
+      * the rank coordinates the writer assumes are the reference's (ckpt_isp4v1_rank*.json records gpc's);
+      * the oracle (oracle.isp over the union of the two data ranks' micro-batches) resumes from the merged state onto the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.isp import OracleISPTrainer
+    from oracle.moe_model import OracleMoETrainer
+
+    gold = [json.load(open(os.path.join(G, f"ckpt_isp4v1_rank{r}.json"))) for r in range(4)]
+    c = gold[0]["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+    ref = os.path.join(G, "ckpt_ref_isp4v1")
+    for r, g_ in enumerate(gold):
+        co = C.isp_coords(r, 4, c["sp"], c["wp"])
+        rk = g_["ranks"]
+        assert (co["t"], co["w"], co["d"], co["z"]) == (rk["TENSOR"][0], rk["WEIGHT"][0], rk["DATA"][0], rk["ZERO1"][0]) and rk["WEIGHT_DATA"][0] == co["z"]
+        assert (co["data_world"], co["zero_world"]) == (rk["DATA"][1], rk["ZERO1"][1])
+        assert g_["rank_unique_id"] == f"gpus-4_wp-{co['w']}_tp-{co['t']}_dp-{co['d']}_pp-0_zo-{co['z']}.pt"
+    ck = C.load_checkpoint(ref, mc)
+    assert ck["adam_step"] == 2 and ck["isp"] == dict(world=4, sp=2, wp=2) and ck["scaler"]["scale"] == gold[0]["grad_scaler"]["_scale"]
+    for n in ck["params"]:
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for r in range(4):
+        co = C.isp_coords(r, 4, 2, 2)
+        # (a rank only needs the tensors its partitions name; the others may be shape-only)
+        mine = set(C.isp_rank_names(mc, {n: tuple(t.shape) for n, t in ck["params"].items()}, r, 4, 2, 2))
+        part = lambda d: {n: (t if n in mine else torch.empty(t.shape, device="meta")) for n, t in d.items()}  # noqa: E731
+        C.save_isp_optimizer_shard(str(tmp_path), mc, r, 4, 2, 2, part(ck["master"]), part(ck["exp_avg"]), part(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"], hyper)
+        if r // 2 == 0:
+            C.save_isp_model_shard(str(tmp_path), mc, ck["params"], co["t"], 2, co["w"], 2)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(ref)) == gold[0]["files"]
+    for fn in gold[0]["files"]:
+        if not fn.endswith(".json"):
+            _deep_equal(C._load(os.path.join(tmp_path, fn)), C._load(os.path.join(ref, fn)), fn)
+    # resume: two data ranks x micro_num micro-batches = one process on their union (mean loss = mean of the ranks' losses, same averaged gradients)
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=2 * c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    base = OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16)
+    base.load_state(ck)
+    tr = OracleISPTrainer(base, c["sp"])
+    loaders = [iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold[0]["num_samples"], data_rank=d, data_world_size=2)) for d in range(2)]
+    for _ in range(gold[0]["saved_after_step"]):
+        for ld in loaders:
+            next(ld)
+    for k in range(2, 4):
+        bl = [next(ld) for ld in loaders]
+        batch = dict(input_ids=torch.cat([b["input_ids"] for b, _ in bl]))
+        r = tr.train_step(batch, torch.cat([y for _, y in bl]))
+        want_loss = (gold[0]["steps"][k]["loss"] + gold[2]["steps"][k]["loss"]) / 2     # ranks 0, 1 = data rank 0; ranks 2, 3 = data rank 1
+        w = gold[0]["steps"][k]
+        print(f"resumed step {k}: oracle loss {r['loss']:.5f} norms {r['grad_norm']} | reference {want_loss:.5f} {w['grad_norm']}")
+        assert abs(r["loss"] - want_loss) <= 1e-3 * want_loss and abs(r["lr"] - w["lr"]) <= 1e-12
+        for g_ in ("0_default", "1_embed_head"):
+            assert abs(r["grad_norm"][g_] - w["grad_norm"][g_]) <= 1e-2 * w["grad_norm"][g_], (k, g_)

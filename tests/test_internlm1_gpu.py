@@ -220,9 +220,7 @@ def _isp_ckpt_worker(rank, world, port, q, out_folder):
         cfg = _v1_cfg(c)
         cfg.train.wp_size = c["wp"]
         eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, sp_size=c["sp"], weight_parallel=True)
-        with pytest.raises(NotImplementedError):
-            eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp2v1"))          # a full resume from the ISP layout is refused ...
-        eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp2v1"), model_only=True)   # ... its model weights load (load_ckpt_info content = ("model",))
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp2v1"), model_only=True)   # load_ckpt_info content = ("model",)
         loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         for _ in range(gold["saved_after_step"]):
             next(loader)
@@ -259,6 +257,74 @@ def test_isp_layout_model_files_load_into_the_engine_and_are_written_back(dev, b
             ours = torch.load(os.path.join(out, fn), weights_only=False)
             theirs = torch.load(os.path.join(G, "ckpt_ref_isp2v1", fn), weights_only=False)
             assert list(ours) == list(theirs) and all(torch.equal(ours[k], theirs[k]) for k in ours), fn
+
+
+def _isp_resume_worker(rank, world, port, q, out_folder, wp_mode):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+
+        gold = json.load(open(os.path.join(G, f"ckpt_isp4v1_rank{rank}.json")))
+        c = gold["config"]
+        cfg = _v1_cfg(c)
+        cfg.train.wp_size = c["wp"]
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=11 + rank, sp_size=c["sp"], weight_parallel=wp_mode)
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_isp4v1"))
+        eng.save_checkpoint(out_folder)           # straight back out: must be the reference's files
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        out = []
+        for w in gold["steps"][gold["saved_after_step"]:]:
+            batch, labels = next(loader)
+            lr = eng.lr_sched.lr()
+            loss = float(eng.forward_backward(_isp_batch(batch, c["sp"], "INTERNLM"), labels))
+            eng.step()
+            st = eng.read_state()
+            out.append((loss, dict(st.group_norms), lr, st.loss_scale, st.skip, w["loss"], w["grad_norm"], w["lr"], w["loss_scale"]))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.ranks(4)
+@pytest.mark.parametrize("wp_mode", [True, False], ids=["weight_parallel", "resident"])
+def test_isp_layout_checkpoint_of_the_reference_resumes_and_is_written_back(dev, backend, tmp_path, wp_mode):  # noqa: F811
+    """tests/golden/ckpt_ref_isp4v1/ -- model AND optimizer files of a real four-process ISP run of the reference (tensor 2 (isp) x weight 2, two weight-data /
+    data replicas) after two steps -- into the HIP engine on four ranks of the same layout (layer weights sharded over the weight group or resident):
+      * save_checkpoint straight after the load writes the reference's twelve files back tensor for tensor (every rank its optimizer shard of three groups
+        in the reference's partition of its LOCAL shards, its plan file, the model files from the ranks the reference writes them from);
+      * the next two steps are the reference's: every rank's loss (1e-3), both group norms (2e-2), learning rate, loss scale."""
+    from test_checkpoint import _deep_equal
+
+    from internevo_amd import checkpoint as C
+
+    world = 4
+    out = str(tmp_path / "isp4_out")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_isp_resume_worker, args=(r, world, 29751 + wp_mode, q, out, wp_mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, world), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    ref = os.path.join(G, "ckpt_ref_isp4v1")
+    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+    for fn in sorted(os.listdir(ref)):
+        if not fn.endswith(".json"):
+            _deep_equal(C._load(os.path.join(out, fn)), C._load(os.path.join(ref, fn)), fn)
+    for rank, steps in res:
+        for k, (loss, norms, lr, scale, skip, w_loss, w_norms, w_lr, w_scale) in enumerate(steps):
+            print(f"rank {rank} resumed step {k}: HIP loss {loss:.5f} norms {norms} lr {lr:.3e} | reference {w_loss:.5f} {w_norms} {w_lr:.3e}")
+            assert skip == 0 and scale == w_scale and abs(lr - w_lr) <= 1e-12
+            assert abs(loss - w_loss) <= 1e-3 * w_loss, (rank, k, loss, w_loss)
+            for g in ("0_default", "1_embed_head"):
+                assert abs(norms[g] - w_norms[g]) <= 2e-2 * w_norms[g], (rank, k, g)
 
 
 # ---------------------------------------------------------------------------------------------------- configs[3]'s shape: tensor 2 x weight 4, InternLM-1 blocks

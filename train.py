@@ -300,7 +300,7 @@ def main(argv=None, log=print):
             log(line(infos))
         if val_loaders and st.adam_step % valid_every == 0:  # train.py:279-288: keyed on the count of successful steps
             out[-1].update(evaluate_on_val_dls(eng, val_loaders, st.adam_step, dev, log if rank == 0 else (lambda m: None)))
-        if save_folder and every and (step + 1) % every == 0 and eng.sp == 1:  # (sp > 1 with saving enabled is refused at start-up)
+        if save_folder and every and (step + 1) % every == 0:
             eng.save_checkpoint(os.path.join(save_folder, str(step + 1)))  # collective: every data-parallel rank writes its ZeRO shard
             if rank == 0:
                 from internevo_amd.checkpoint import save_run_state
