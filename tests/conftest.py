@@ -17,56 +17,43 @@ def xport(port):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """Run the suite on three pytest-xdist workers by default, `--dist loadgroup`: the two files of multi-process tests (up to eight ranks, each a
-    process with its own HIP context on the one GPU) are a group each, i.e. each runs serially on ONE worker -- many rank processes of several tests at
-    once oversubscribe the GPU's queues and every test slows down (measured: four free workers gained 15 % on the serial run) -- while the single-process
-    tests (kernels, engines against the CPU oracle, entry points) fill the third worker and the gaps.  `-n N` on the command line wins;
-    IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
+    """Run the suite on four pytest-xdist workers by default.  Two measured dead ends shaped this (profiles/r04_gpu_suite_timing.md): what made concurrent
+    tests crawl was not the GPU but CPU oracles at 7B width taking every host core (a 5-second two-rank test beside them took 150 s) -- those oracle
+    runs are committed records now (tools/gen_7bwidth_merged_fixture.py) -- and pinning the multi-process test files to one worker each (`loadgroup`)
+    made two 10-minute serial chains.  `-n N` on the command line wins; IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
     if (config.pluginmanager.hasplugin("xdist") and getattr(config.option, "numprocesses", None) is None and not os.environ.get("PYTEST_XDIST_WORKER")
             and os.environ.get("IE_TEST_SERIAL") != "1" and not getattr(config.option, "collectonly", False)):
-        config.option.numprocesses = 3
-        config.option.dist = "loadgroup"
+        config.option.numprocesses = 4
+        config.option.dist = "load"
 
 
-# Order of the run: the two groups of multi-process tests first (one worker each, for minutes), then the single-process tests that hold the GPU / the
-# host cores longest (7B-width shapes against the CPU oracle), then everything else in file order.
-_GROUPS = {"test_multirank_gpu.py": "ranks_a", "test_dp_gpu.py": "ranks_b", "test_internlm1_gpu.py": "ranks_b"}
-_LONGEST_FIRST = ("test_engine_7b_width_merged_benchmark_step_matches_oracle", "test_engine_7b_shaped_layer_full_size_matches_oracle",
-                  "test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width", "test_flash_attention_benchmark_regime_matches_oracle")
+# The longest tests first (eight ranks at 32 768 tokens / 7B width, the 8- and 4-rank layouts, the 7B-width engine runs), so that the short ones fill in
+# around them instead of one of them forming the tail of the run.
+_LONGEST_FIRST = ("test_isp_config3_layout_seq32768_sp8_at_7b_width", "test_sequence_parallel_sp4_sp8_equals_single_rank_step",
+                  "test_llama2_tensor_parallel_2_with_hybrid_zero_on_8_ranks", "test_config3_shape_tensor2_weight4_on_internlm1_blocks_equals_one_rank",
+                  "test_engine_7b_width_merged_benchmark_step_matches_oracle", "test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width",
+                  "test_engine_7b_shaped_layer_full_size_matches_oracle", "test_flash_attention_benchmark_regime_matches_oracle",
+                  "test_weight_parallel_step_equals_resident_step", "test_moe_engine_expert_parallel_on_two_ranks_matches_the_reference_rules")
 
 
 def pytest_collection_modifyitems(config, items):
     rank = {n: i for i, n in enumerate(_LONGEST_FIRST)}
-
-    def key(it):
-        grp = _GROUPS.get(os.path.basename(str(it.fspath)))
-        if grp is not None and it.get_closest_marker("gpu") is not None:
-            it.add_marker(pytest.mark.xdist_group(grp))
-            return (0, grp, 0)
-        return (1, "", rank.get(getattr(it, "originalname", None) or it.name, len(rank)))
-
-    items.sort(key=key)   # (stable: inside a group and among the rest the file order stays)
-
-
-@pytest.fixture
-def all_host_cores():
-    """A test whose CPU oracle works through a 7B-width step: all host cores for it, whatever share the xdist worker was given."""
-    import torch
-
-    before = torch.get_num_threads()
-    torch.set_num_threads(os.cpu_count() or before)
-    yield
-    torch.set_num_threads(before)
+    if os.environ.get("IE_TEST_FULL") != "1":   # parametrisations whose layout another test of the default run covers (each names it): IE_TEST_FULL=1 runs them too
+        for it in items:
+            if it.get_closest_marker("extended") is not None:
+                it.add_marker(pytest.mark.skip(reason="extended parametrisation (its layout is covered by another test of the default run); IE_TEST_FULL=1 runs it"))
+    items.sort(key=lambda it: rank.get(getattr(it, "originalname", None) or it.name, len(rank)))   # (stable: everything else keeps its file order)
 
 
 def pytest_configure(config):
     n = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "1"))
-    if n > 1:   # the CPU oracles of concurrent tests share the host's cores
+    if n > 1:   # the CPU oracles of concurrent tests share the host's cores (and tiny-model oracles gain nothing from 128 threads)
         import torch
 
-        torch.set_num_threads(max(1, (os.cpu_count() or n) // n))
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or n) // n)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ranks(n): GPUs a multi-rank test needs for its RCCL (nccl backend) variant")
+    config.addinivalue_line("markers", "extended: a parametrisation whose layout another default test covers; run with IE_TEST_FULL=1")
 
 
 @pytest.fixture(scope="session")

@@ -326,109 +326,122 @@ def test_merged_micro_batches_match_sequential_accumulation(dev):
         InternLM2Engine(cfg, dev, merge_micro=True)
 
 
-@pytest.mark.timeout(1500)
-def test_engine_7b_shaped_layer_full_size_matches_oracle(dev, all_host_cores):
+def _against_recorded_oracle(eng, fix, meta, k, loss, st, dev, loose=()):
+    """Step k of a 7B-width run against the CPU oracle's record of the same step (tools/gen_7bwidth_merged_fixture.py -> tests/golden/*_7bwidth_oracle.*;
+    the oracle needs 45-75 s per step at this width and, with all host cores, starves every test running beside it -- so it runs OFFLINE and its loss,
+    global norm, per-parameter gradient norms and a fixed strided SAMPLE of every gradient (~1e5 elements per tensor) are committed): loss 1e-3 and norm
+    2e-2 (north_star), and per parameter the gradient's l2 norm, the relative l2 difference on the sample and the share of the sample's mass |g| with the
+    same sign."""
+    ref = meta["steps"][k]
+    print(f"7B-width step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  recorded oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
+    assert st.skip == 0 and st.loss_scale == ref["loss_scale"]
+    assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])
+    assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
+    bad = {}
+    for n, g_ in eng.g.items():
+        stride = meta["stride"][n]
+        want = torch.from_numpy(fix[f"g{k}/{n}"]).to(dev).double()
+        got = g_.reshape(-1)[::stride].double()
+        rel = float((got - want).norm() / want.norm())
+        agree = float((want.abs() * (torch.sign(got) == torch.sign(want))).sum() / want.abs().sum())
+        l2 = float(g_.double().norm())
+        print(f"   step {k} grad {n}: |g| {l2:.4e} (oracle {ref['grad_l2'][n]:.4e}), sample of {want.numel()}: relative l2 difference {rel:.2e}, "
+              f"share of |g| with the same sign {agree:.5f}")
+        tol_rel, tol_l2, min_agree = (1e-1, 1e-1, 0.99) if n in loose else (1.5e-2, 2e-2, 0.999)
+        if rel > tol_rel or agree < min_agree or abs(l2 - ref["grad_l2"][n]) > tol_l2 * ref["grad_l2"][n]:
+            bad[n] = (rel, agree, l2, ref["grad_l2"][n])
+    assert not bad, bad
+
+
+def _params_against_recorded_oracle(eng, fix, meta, names, dev, tol=8e-3):
+    worst = 0.0
+    for n, p in eng.named_parameters():
+        if n in names:
+            worst = max(worst, float((p.reshape(-1)[:: meta["stride"][n]].float() - torch.from_numpy(fix[f"p/{n}"]).to(dev)).abs().max()))
+    print("max |param diff| on the recorded sample after training:", worst)
+    assert worst <= tol
+
+
+@pytest.mark.timeout(900)
+def test_engine_7b_shaped_layer_full_size_matches_oracle(dev):
     """BASELINE.json configs[1] at its FULL per-layer sizes (hidden 4096, 32/8 heads of 128, FFN 14336, vocab 92544, 4096 packed
-    tokens per micro-batch) with ONE transformer layer, so the CPU oracle finishes in under a minute: every kernel runs the code
-    path the 7B benchmark runs (256x256 GEMM tilings, flash attention at T = 4096 with several packed sequences, the 92544-wide
-    cross-entropy, the 218M / 379M-parameter AdamW buckets)."""
+    tokens per micro-batch) with ONE transformer layer: every kernel runs the code path the 7B benchmark runs (256x256 GEMM tilings, flash
+    attention at T = 4096 with several packed sequences, the 92544-wide cross-entropy, the 218M / 379M-parameter AdamW buckets).  One step against the
+    CPU oracle's committed record of the same step (tests/golden/single_7bwidth_oracle.*)."""
+    import json
+    import os
+
+    import numpy as np
+
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
-    from oracle.step import OracleTrainer
 
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta, fix = json.load(open(os.path.join(gdir, "single_7bwidth_oracle.json"))), np.load(os.path.join(gdir, "single_7bwidth_oracle.npz"))
     cfg = internlm2_7b(4096)
     cfg.model.num_layers = 1
     cfg.train.micro_num = 1
     cfg.train.total_steps = 4
+    assert (cfg.train.total_steps, cfg.train.micro_num, cfg.train.lr) == (meta["total_steps"], meta["micro_num"], meta["lr"])
     eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
-    ora = OracleTrainer(cfg, torch.bfloat16)
-    loader = iter(SyntheticLoader(4096, 1, 1, False, 4000))
-    for k in range(1):   # (one step: the CPU oracle needs half a minute per step at this width; multi-step behaviour at 7B width: the fixture-based test below)
-        batch, labels = next(loader)
-        loss = eng.forward_backward(batch, labels)
-        eng.step()
-        st = eng.read_state()
-        ref = ora.train_step(batch, labels)
-        print(f"7B-shaped layer, step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}  "
-              f"({len(batch['cu_seqlens'][0]) - 1} packed sequences)")
-        assert st.skip == 0
-        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])            # the north star's loss tolerance
-        assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
-    worst = 0.0
-    for n, p in eng.named_parameters():
-        if n in ("layers.0.attention.wqkv.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
-            worst = max(worst, float((p.float().cpu() - ora.params[n].detach().float()).abs().max()))
-    print("max |param diff| after the step:", worst)
-    assert worst <= 8e-3
+    batch, labels = next(iter(SyntheticLoader(4096, 1, 1, False, 4000)))
+    assert len(batch["cu_seqlens"][0]) - 1 > 1, "several packed sequences in the micro-batch"
+    loss = eng.forward_backward(batch, labels)
+    eng.step()
+    # (the embedding's gradient: this record holds the CPU kernel's row-by-row bf16 sum -- what this test always compared with -- which loses a few per
+    # cent on tokens that occur hundreds of times: its own, looser bound; every other gradient 1.5e-2.  The merged test below uses the fp32 arithmetic.)
+    _against_recorded_oracle(eng, fix, meta, 0, loss, eng.read_state(), dev, loose=("tok_embeddings.weight",))
+    _params_against_recorded_oracle(eng, fix, meta, ("layers.0.attention.wqkv.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"), dev)
 
 
-@pytest.mark.timeout(2400)
-def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev, all_host_cores):
+@pytest.mark.timeout(900)
+def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
     """The step bench.py times, at the model's full WIDTH with one layer: micro_num = 4 micro-batches of ONE 4096-token sequence each
     (fixed_random_dataset_seqlen=True, the benchmark's data) run as the merged 16 384-row pass -- the 16 384-row GEMM tile dispatch, the
     attention call of four 4096-token sequences (flash_fwd64_k, multi-round dK/dV grid with head split), the per-micro-batch cross-entropy
     segments, one weight gradient over all 16 384 tokens -- against the CPU oracle, which walks the four micro-batches one after the
-    other with autograd's bf16 gradient accumulation.  Checked: loss and global gradient norm, EVERY parameter's gradient in relative l2
-    (sharper than the norm), the trained weights.
+    other with autograd's bf16 gradient accumulation (its committed record: tests/golden/merged_7bwidth_oracle.*).
     The learning rate is the RECIPE's 1e-4 (round-3 review: the test used to run at 1e-5 for one step).  Step 0 (identical weights) and step 1 -- after
-    the recipe's own first update, lr * sign(g) in every coordinate -- are both held to loss 1e-3, norm 2e-2, every parameter's gradient 1.5e-2 in
-    relative l2, plus the share of each gradient's mass |g| on which HIP and oracle agree in sign (the direction of the NEXT sign-like update)
-    >= 0.999.  (Round 3 saw 11 % on step 1's norm at this learning rate: that was the CPU kernel's swamped bf16 embedding-gradient sum in the oracle,
-    not the update -- oracle.ops.embedding_grad_in_fp32, which rests on test_embedding_gradient_of_the_benchmark_batch_against_fp64.)"""
+    the recipe's own first update, lr * sign(g) in every coordinate -- are both held to loss 1e-3, norm 2e-2, every parameter's gradient norm 2e-2 and
+    1.5e-2 in relative l2 on the recorded sample, plus the share of each gradient's mass |g| on which HIP and oracle agree in sign (the direction of the
+    NEXT sign-like update) >= 0.999.  Measured against the live oracle on the GPU box (profiles/r04_7bwidth_merged_two_steps.log): step 1 agrees to 3.1e-4 /
+    2.4e-3 / <= 4.4e-3.  (Round 3 saw 11 % on step 1's norm at this learning rate: that was the CPU kernel's swamped bf16 embedding-gradient sum in the
+    oracle, not the update -- oracle.ops.embedding_grad_in_fp32, which rests on test_embedding_gradient_of_the_benchmark_batch_against_fp64.)"""
+    import json
+    import os
+
+    import numpy as np
+
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
-    from oracle import ops as O
     from oracle.model import formula_init
-    from oracle.step import OracleTrainer
 
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta, fix = json.load(open(os.path.join(gdir, "merged_7bwidth_oracle.json"))), np.load(os.path.join(gdir, "merged_7bwidth_oracle.npz"))
     cfg = internlm2_7b(4096)
     cfg.model.num_layers = 1
     cfg.train.micro_num = 4
     cfg.train.fixed_random_dataset_seqlen = True
-    assert cfg.train.lr == 1e-4 and cfg.train.total_steps == 20 and int(cfg.train.total_steps * cfg.train.warmup_ratio) == 0, "the benchmark's recipe: lr 1e-4 from step 0"
+    assert cfg.train.lr == 1e-4 == meta["lr"] and cfg.train.total_steps == 20 == meta["total_steps"] and int(cfg.train.total_steps * cfg.train.warmup_ratio) == 0, \
+        "the benchmark's recipe: lr 1e-4 from step 0"
     eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
     assert eng.mm == 4 and eng.Tg == 16384, "the merged pass must be the automatic choice here, as in bench.py"
-    ora = OracleTrainer(cfg, torch.bfloat16)
     loader = iter(SyntheticLoader(4096, 1, 4, True, 4000))
-    for k in range(2):   # (the oracle needs 75 s per 16 384-token step at this width)
+    for k in range(2):
         batch, labels = next(loader)
         assert all(len(c) == 2 for c in batch["cu_seqlens"])   # one 4096-token sequence per micro-batch
         loss = eng.forward_backward(batch, labels)
         eng.step()
-        st = eng.read_state()
-        with O.embedding_grad_in_fp32():   # the accelerator kernel's arithmetic for the embedding's weight gradient (oracle/ops.py; rests on fp64 ground truth:
-            ref = ora.train_step(batch, labels)   # test_embedding_gradient_of_the_benchmark_batch_against_fp64 in test_kernels_gpu.py)
-        print(f"7B-width merged step {k}: HIP {float(loss):.5f} / {st.grad_norm:.4f}  oracle {ref['loss']:.5f} / {ref['grad_norm']:.4f}")
-        assert st.skip == 0
-        # the (loss-scaled, accumulated) gradients themselves: the engine's flat gradient buffer is untouched until the next backward.  (Compared on
-        # the GPU in fp64: the tensors hold up to 380 M elements.)
-        rel, agree = {}, {}
-        for n, g_ in eng.g.items():
-            want = ora.params[n].grad.to(dev).double()
-            got = g_.double()
-            rel[n] = float((got - want).norm() / want.norm())
-            agree[n] = float((want.abs() * (torch.sign(got) == torch.sign(want))).sum() / want.abs().sum())
-            print(f"   step {k} grad {n}: relative l2 difference {rel[n]:.2e}, share of |g| with the same sign {agree[n]:.5f}")
-            del want, got
-        # BOTH steps to the north star's tolerances -- step 1 AFTER the recipe's own first update (lr 1e-4 * sign(g) in every coordinate): measured
-        # 3.1e-4 / 2.4e-3 on loss / norm and <= 4.4e-3 on every gradient at step 1 (3e-5 / 2.6e-3 / <= 3.5e-3 at step 0)
-        assert abs(float(loss) - ref["loss"]) <= 1e-3 * abs(ref["loss"])
-        assert abs(st.grad_norm - ref["grad_norm"]) <= 2e-2 * ref["grad_norm"]
-        bad = {n: (rel[n], agree[n]) for n in rel if rel[n] > 1.5e-2 or agree[n] < 0.999}
-        assert not bad, bad
-    worst = 0.0
-    for n, p in eng.named_parameters():
-        if n in ("layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight", "norm.weight", "layers.0.ffn_norm.weight"):
-            worst = max(worst, float((p.float() - ora.params[n].detach().to(dev).float()).abs().max()))
-    print("max |param diff| after the two merged steps:", worst)
-    assert worst <= 8e-3
+        _against_recorded_oracle(eng, fix, meta, k, loss, eng.read_state(), dev)   # (the gradient buffer is untouched until the next backward)
+    _params_against_recorded_oracle(eng, fix, meta, ("layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "layers.0.feed_forward.w2.weight",
+                                                     "norm.weight", "layers.0.ffn_norm.weight"), dev)
 
 
 @pytest.mark.timeout(900)
-def test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width(dev, all_host_cores):
+def test_first_steps_of_the_benchmark_recipe_retrace_the_oracle_at_7b_width(dev):
     """The 7B bench run's loss makes an excursion in its first steps (11.4 -> 27.7 at step 3 with grad norm 185 -> 0.9 -> 0.004: BENCH_r02).  The
     benchmark's recipe -- lr 1e-4 from step 0 (no warm-up inside 20 steps), AdamW, the synthetic RandomDataset batches -- at the 7B model's
     width with two layers was run through the CPU oracle (tools/loss_spike_oracle.py -> tests/golden/spike_7bwidth_oracle.json, committed);

@@ -90,17 +90,21 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
     assert rs["sampler"]["batch_count"] == 2 and rs["scheduler"]["after_scheduler_dict"]["last_epoch"] == 2
     # auto_resume (the reference's DEFAULT, checkpoint_manager.py:296-305): load_ckpt_info is overridden by the latest complete checkpoint under
     # save_ckpt_folder -- the folder with the largest {step}.step flag, here "4" -- and by nothing (a new run) when there is none
+    import shutil
+
+    shutil.rmtree(os.path.join(folder, "4"))       # ("2" is the latest complete checkpoint now)
     cfg3 = tmp_path / "cfg3.py"
-    cfg3.write_text(CFG.format(steps=6, save=False, folder=folder, load=_load_info(os.path.join(folder, "2"))).replace(", auto_resume=False", ""))
+    cfg3.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
     run3 = train.main(["--config", str(cfg3), "--launcher", "torch"], log=lines.append)
-    assert [r["step"] for r in run3] == [4, 5] and any("Found latest ckpt" in ln and ln.rstrip(".").endswith("step: 4") for ln in lines)
+    assert [r["step"] for r in run3] == [2, 3] and any("Found latest ckpt" in ln and ln.rstrip(".").endswith("step: 2") for ln in lines)
+    assert [(r["loss"], r["grad_norm"]) for r in run3] == [(r["loss"], r["grad_norm"]) for r in run2]
     cfg4 = tmp_path / "cfg4.py"
     cfg4.write_text(CFG.format(steps=2, save=False, folder=str(tmp_path / "empty"), load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
     run4 = train.main(["--config", str(cfg4), "--launcher", "torch"], log=lines.append)
     assert [r["step"] for r in run4] == [0, 1], "auto_resume with nothing saved yet: a new run (the shipped configs' load_ckpt_info placeholders are never opened)"
     # auto_resume off: content = ("model",) takes the weights only -- step 0 of a fresh schedule on the trained weights; a missing folder is an error
     cfg5 = tmp_path / "cfg5.py"
-    cfg5.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(os.path.join(folder, "4")).replace('("all",)', '("model",)')))
+    cfg5.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(os.path.join(folder, "2")).replace('("all",)', '("model",)')))
     run5 = train.main(["--config", str(cfg5), "--launcher", "torch"], log=lines.append)
     assert [r["step"] for r in run5] == [0, 1, 2, 3] and run5[0]["loss"] < run1[1]["loss"] and run5[0]["lr"] == run1[0]["lr"]
     cfg6 = tmp_path / "cfg6.py"
