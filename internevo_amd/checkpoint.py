@@ -651,13 +651,17 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
 #   optimizer_tp0_pp0_zo0.pt                       base_optim_states.state {0, 1, 2}, param_groups [default, fp32 (the gates), moe_ep_size_{ep} (the experts,
 #                                                  optimizer_mode EXPERT_DATA)], flat_fp32_weights {0, 1, 2}, the plan with one list per group
 # Covered here: one data-parallel rank (zero world 1, expert parallel size 1).
-def moe_groups(model_cfg):
-    """[(group name, parameter names in module order)] of the three optimizer groups."""
+def moe_groups(model_cfg, ep_world=1, ep_rank=0):
+    """[(group name, parameter names in module order)] of the three optimizer groups ON ONE RANK of an expert-parallel group of ep_world ranks: the dense
+    parameters and the gates whole, the experts this rank holds (global numbers ep_rank * E / ep ... -- the reference's automatic expert parallelism,
+    parallel_context.py:538-541)."""
     order = state_dict_order(model_cfg)
     gates = [n for n in order if n.endswith("gate.wg.weight")]
-    experts = [n for n in order if ".experts." in n]
-    dense = [n for n in order if n not in set(gates) | set(experts)]
-    return [("default", dense), ("fp32", gates), ("moe_ep_size_1", experts)]
+    El = max(model_cfg.num_experts, 1) // ep_world
+    mine = range(ep_rank * El, (ep_rank + 1) * El)
+    experts = [n for n in order if ".experts." in n and int(n.split(".")[6]) in mine]
+    dense = [n for n in order if ".experts." not in n and n not in set(gates)]
+    return [("default", dense), ("fp32", gates), (f"moe_ep_size_{ep_world}", experts)]
 
 
 def _expert_file(name):
@@ -665,29 +669,48 @@ def _expert_file(name):
     return f"model_moe_layer{parts[1]}_expert{parts[6]}_tp0.pt"
 
 
-def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16):
-    """params: name -> host tensor (gates fp32, the rest in the model dtype); master / exp_avg / exp_avg_sq: name -> fp32 host tensor; the rest as
-    save_checkpoint."""
-    os.makedirs(folder, exist_ok=True)
-    groups = moe_groups(model_cfg)
-    experts = set(groups[2][1])
-    sd = collections.OrderedDict()
-    per_expert = collections.OrderedDict()
-    for n in state_dict_order(model_cfg):
-        t = params[n].detach().to("cpu", torch.float32 if n.endswith("gate.wg.weight") else param_dtype).contiguous()
-        if n in experts:
-            per_expert.setdefault(_expert_file(n), collections.OrderedDict())["model." + n] = t
-        else:
-            sd["model." + n] = t
-    torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
-    for fn, esd in per_expert.items():
-        torch.save(esd, os.path.join(folder, fn))
-    torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
-    flat_orders = [zero_flat_order([(n, tuple(params[n].shape)) for n in names]) for _, names in groups]
-    plan = [[_plan_ids(fo, list(range(len(fo))))] for fo in flat_orders]
+def _moe_layout(model_cfg, shapes, world, rank):
+    """Per optimizer group on data-parallel rank `rank` of `world`: (flat order of (name, shape), partition over the group's zero world, this rank's position in
+    it).  default / fp32: ZeRO over the data-parallel group; the expert group: over the EXPERT_DATA group (the ranks holding the same experts: rank // ep)."""
+    ep = min(world, max(model_cfg.num_experts, 1))
+    if world % ep or max(model_cfg.num_experts, 1) % ep:
+        raise NotImplementedError(f"{world} data-parallel ranks with {model_cfg.num_experts} experts")
+    out = []
+    for g, (_, names) in enumerate(moe_groups(model_cfg, ep, rank % ep)):
+        fo = zero_flat_order([(n, tuple(shapes[n])) for n in names])
+        zw, zr = (world // ep, rank // ep) if g == 2 else (world, rank)
+        out.append((fo, zero_partition(fo, zw), zr))
+    return out, ep
 
-    def flat(named, fo):
-        return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n, _ in fo])
+
+def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16, world=1, rank=0):
+    """params: name -> host tensor (gates fp32, the rest in the model dtype); master / exp_avg / exp_avg_sq: name -> fp32 host tensor; the rest as
+    save_checkpoint.  world > 1 (round 4): what data-parallel rank `rank` of `world` writes in a reference job with its automatic expert parallelism
+    (ep = min(world, experts); pinned by tests/golden/ckpt_ref_moe_dp2/): its optimizer shard -- the dense parameters' and the gates' partition `rank` of the
+    data-parallel group, and its partition of ITS experts over the expert-data group --, its plan file, one model file per expert it holds (under the
+    expert's GLOBAL number; expert-data rank 0 only), and from rank 0 the model file without the experts.  The dicts need this rank's experts only."""
+    os.makedirs(folder, exist_ok=True)
+    shapes = {n: tuple(params[n].shape) for n in state_dict_order(model_cfg) if n in params}
+    layout, ep = _moe_layout(model_cfg, shapes, world, rank)
+    groups = moe_groups(model_cfg, ep, rank % ep)
+    if rank == 0:
+        sd = collections.OrderedDict()
+        for n in state_dict_order(model_cfg):
+            if ".experts." not in n:
+                sd["model." + n] = params[n].detach().to("cpu", torch.float32 if n.endswith("gate.wg.weight") else param_dtype).contiguous()
+        torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
+        torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
+    if rank // ep == 0:   # (tp_rank, expert_dp_rank) = (0, 0): components.py:270-277
+        per_expert = collections.OrderedDict()
+        for n in groups[2][1]:
+            per_expert.setdefault(_expert_file(n), collections.OrderedDict())["model." + n] = params[n].detach().to("cpu", param_dtype).contiguous()
+        for fn, esd in per_expert.items():
+            torch.save(esd, os.path.join(folder, fn))
+    plan = [[_plan_ids(fo, idx) for idx in part] for fo, part, _ in layout]
+
+    def flat(named, g):
+        fo, part, zr = layout[g]
+        return torch.cat([named[fo[i][0]].detach().to("cpu", torch.float32).reshape(-1) for i in part[zr]])
 
     with _RefEnumModule() as zero1:
         pm = type(zero1)
@@ -701,52 +724,63 @@ def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, 
         states = {
             "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]), "_hysteresis_step": int(scaler["hysteresis_step"])},
             "base_optim_states": {
-                "state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, fo), "exp_avg_sq": flat(exp_avg_sq, fo)}
-                          for g, fo in enumerate(flat_orders)},
+                "state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
+                          for g in range(3)},
                 "param_groups": pgs,
             },
-            "flat_fp32_weights": {g: flat(master, fo) for g, fo in enumerate(flat_orders)},
+            "flat_fp32_weights": {g: flat(master, g) for g in range(3)},
             "zero_devide_optim_plan": plan,
         }
-        torch.save(states, os.path.join(folder, "optimizer_tp0_pp0_zo0.pt"))
-        torch.save(plan, os.path.join(folder, "gpus-1_wp-0_tp-0_dp-0_pp-0_zo-0.pt"))
+        torch.save(states, os.path.join(folder, f"optimizer_tp0_pp0_zo{rank}.pt"))
+        torch.save(plan, os.path.join(folder, f"gpus-{world}_wp-0_tp-0_dp-{rank}_pp-0_zo-{rank}.pt"))
 
 
 def load_moe_checkpoint(folder, model_cfg):
-    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor), adam_step, scaler, lr) of a one-rank INTERNLM_MoE checkpoint (the reference's
-    or save_moe_checkpoint's); optimizer entries None when the folder holds weights only."""
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, ALL experts under their global numbers), adam_step, scaler, lr, zero_world) of an
+    INTERNLM_MoE checkpoint (the reference's or save_moe_checkpoint's) written by ANY number of data-parallel ranks: every rank's optimizer shard is read
+    and merged; optimizer entries None when the folder holds weights only."""
     order = state_dict_order(model_cfg)
     sd = dict(torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False))
     for n in order:
         if ".experts." in n and "model." + n not in sd:
             sd.update(torch.load(os.path.join(folder, _expert_file(n)), map_location="cpu", weights_only=False))
     params = {n: sd["model." + n].detach() for n in order}
-    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None)
-    opt = os.path.join(folder, "optimizer_tp0_pp0_zo0.pt")
-    if not os.path.exists(opt):
+    out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
+    world = saved_zero_world(folder)
+    if world == 0:
         return out
-    if os.path.exists(os.path.join(folder, "optimizer_tp0_pp0_zo1.pt")):
-        raise NotImplementedError("INTERNLM_MoE checkpoints of more than one data-parallel rank (expert shards per expert-parallel rank) are not implemented")
-    st = _load(opt)
+    shapes = {n: tuple(params[n].shape) for n in order}
     merged = dict(master={}, exp_avg={}, exp_avg_sq={})
-    for g, (_, names) in enumerate(moe_groups(model_cfg)):
-        fo = zero_flat_order([(n, tuple(params[n].shape)) for n in names])
-        if list(st["zero_devide_optim_plan"][g][0]) != _plan_ids(fo, list(range(len(fo)))):
-            raise ValueError(f"zero_devide_optim_plan of group {g} does not match this model")
-        for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
-                         ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
-            o = 0
-            for n, shape in fo:
-                k = 1
-                for d in shape:
-                    k *= d
-                merged[key][n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)
-                o += k
-            if o != vec.numel():
-                raise ValueError(f"group {g}: the flat vector holds {vec.numel()} elements, this model's group {o}")
-    gs, base = st["grad_scaler"], st["base_optim_states"]
-    out.update(merged, adam_step=int(float(base["state"][0]["step"])), lr=float(base["param_groups"][0]["lr"]),
-               scaler=dict(scale=float(gs["_scale"]), growth_step=int(gs["_growth_step"]), hysteresis_step=int(gs["_hysteresis_step"])))
+    meta = None
+    for r in range(world):
+        st = _load(os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt"))
+        layout, ep = _moe_layout(model_cfg, shapes, world, r)
+        if st["base_optim_states"]["param_groups"][2]["name"] != f"moe_ep_size_{ep}":
+            raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt: expert group {st['base_optim_states']['param_groups'][2]['name']!r}, this model on {world} ranks has moe_ep_size_{ep}")
+        for g, (fo, part, zr) in enumerate(layout):
+            if list(st["zero_devide_optim_plan"][g][zr]) != _plan_ids(fo, part[zr]):
+                raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt: zero_devide_optim_plan of group {g} does not match this model")
+            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
+                             ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
+                o = 0
+                for i in part[zr]:
+                    n, shape = fo[i]
+                    k = 1
+                    for d in shape:
+                        k *= d
+                    merged[key][n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)
+                    o += k
+                if o != vec.numel():
+                    raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt group {g}: the flat vector holds {vec.numel()} elements, this rank's partition {o}")
+        gs, base = st["grad_scaler"], st["base_optim_states"]
+        here = (int(float(base["state"][0]["step"])), float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
+        if meta is not None and here != meta:
+            raise ValueError("the optimizer shards disagree on step / lr / loss scale")
+        meta = here
+    missing = [n for n in order if n not in merged["master"]]
+    if missing:
+        raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:3]} ...")
+    out.update(merged, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world)
     return out
 
 

@@ -714,7 +714,7 @@ class InternLM2Engine:
         eps = self.tc.label_smoothing
         mine = [lse, torch.where(here, lse - rows, torch.zeros_like(rows))]
         if eps > 0:   # the smoothing term needs the mean logit over the WHOLE vocabulary (ce_loss.py:15-36 / flash-attn's smoothed parallel loss): one more statistic
-            mine.append(logits.float().sum(dim=1))
+            mine.append(logits.sum(dim=1, dtype=torch.float32))   # (fp32 accumulation inside the reduction: no [T, V / tp] fp32 copy of the logits)
         stats = self.tpar.all_gather(torch.stack(mine))   # [tp, 2 or 3, rows]
         lse.copy_(torch.logsumexp(stats[:, 0], dim=0))
         nll = torch.where(lab != -100, lse - stats[:, 1].sum(dim=0), torch.zeros_like(rows))

@@ -508,9 +508,7 @@ class MoEEngine:
 
     # ---- checkpoints (the dense model): InternEvo's files, internevo_amd/checkpoint.py -------------------------------------------------------
     def _checkpoint_guard(self):
-        if not self.dense and self.world != 1:
-            raise NotImplementedError("checkpoints of the MoE model cover one data-parallel rank (with more, the experts are sharded over the expert-parallel "
-                                      "group and the moe optimizer group over the expert-data group: not implemented)")
+        pass   # (any data-parallel size since round 4: checkpoint.save_moe_checkpoint / load_moe_checkpoint)
 
     def save_checkpoint(self, folder):
         """model_tp0_pp0.pt + the hybrid-ZeRO optimizer shards in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284): this
@@ -527,8 +525,16 @@ class MoEEngine:
             hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
             scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
             cpu = lambda views, gates: {n: t.detach().to("cpu", copy=True) for n, t in self.named_parameters(views, gates)}  # noqa: E731
+            # every data-parallel rank writes what the reference's rank would (this engine keeps the optimizer state of the dense parameters and the gates on
+            # every rank, and of its own experts: rank r cuts the reference's partition r out of it); collective
+            if r == 0:
+                C.remove_stale_shards(folder, W, 1)
+            if W > 1:
+                dist.barrier(group=self.group)
             C.save_moe_checkpoint(folder, self.mc, cpu(None, None), cpu(self._views(self.master), self.wg), cpu(self._views(self.exp_avg), self.wg_m),
-                                  cpu(self._views(self.exp_avg_sq), self.wg_v), st.adam_step, scaler, self.lr_sched.lr(), hyper)
+                                  cpu(self._views(self.exp_avg_sq), self.wg_v), st.adam_step, scaler, self.lr_sched.lr(), hyper, world=W, rank=r)
+            if W > 1:
+                dist.barrier(group=self.group)
             return
         if r == 0:
             C.remove_stale_shards(folder, W, 1)

@@ -543,7 +543,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     shim_cpu_accelerator()
     if world > 1:
         _patch_gloo_flat_collectives()
-        if isp:
+        if isp or model_type == "INTERNLM_MoE":
             import torch.distributed as dist
 
             dist.all_to_all = _gloo_all_to_all
@@ -577,9 +577,9 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             kw = dict(kw, num_experts=4, capacity_factor=1.0)
             calls = {"n": 0}
 
-            def gumbel(shape, device):
+            def gumbel(shape, device):   # (every data-parallel rank gates its own tokens: rank r draws seed 5000 + 1000 r + k, as the training fixtures do)
                 calls["n"] += 1
-                return MO.gumbel_noise(tuple(shape), 5000 + calls["n"] - 1).to(device)
+                return MO.gumbel_noise(tuple(shape), 5000 + 1000 * rank + calls["n"] - 1).to(device)
 
             gl.gumbel_rsample = gumbel
     if pp > 1:
@@ -620,8 +620,18 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
 
             full_shapes = v1_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
                                                 num_kv_attention_heads=kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
+        moe_mp = world > 1 and model_type == "INTERNLM_MoE"
         for name, p in (model.model.named_parameters() if pp == 1 else ()):
-            if isp:
+            if moe_mp:   # automatic expert parallelism (ep = min(dp, experts)): wrapped_experts.{j} on a rank = GLOBAL expert ep_rank * (E / ep) + j
+                import re
+
+                m_ = re.search(r"wrapped_experts\.(\d+)\.", name)
+                gname = name
+                if m_:
+                    El = kw["num_experts"] // gpc.get_world_size(ParallelMode.EXPERT)
+                    gname = name[: m_.start(1)] + str(gpc.get_local_rank(ParallelMode.EXPERT) * El + int(m_.group(1))) + name[m_.end(1):]
+                p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
+            elif isp:
                 p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, gpc.get_local_rank(ParallelMode.TENSOR), 2, gpc.get_local_rank(ParallelMode.WEIGHT), 2,
                                           full_shapes).to(p.dtype))
             elif tp > 1:
@@ -642,7 +652,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -715,6 +725,13 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         import torch.distributed as dist
 
         dist.barrier()
+        if world > 1 and model_type == "INTERNLM_MoE":   # `--ckpt-moe-mp`: every rank's record (each holds two of the four experts)
+            rec["files"] = sorted(os.listdir(folder))
+            rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.DATA, ParallelMode.ZERO1, ParallelMode.EXPERT, ParallelMode.EXPERT_DATA)}
+            rec["rank_unique_id"] = optimizer.rank_unique_id
+            with open(os.path.join(HERE, f"ckpt_moe_dp2_rank{rank}.json"), "w") as f:
+                json.dump(rec, f, indent=1, default=str)
+            return
         if isp and world == 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
             rec["files"] = sorted(os.listdir(folder))
             rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.WEIGHT, ParallelMode.DATA,
@@ -1358,6 +1375,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe-rank":
+        gen_checkpoint(port=29788, rank=int(sys.argv[2]), world=2, model_type="INTERNLM_MoE")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-mp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe":
         gen_checkpoint(port=29792, model_type="INTERNLM_MoE")
         sys.exit(0)
@@ -1398,7 +1421,7 @@ if __name__ == "__main__":
         shim_cpu_accelerator()
         gen_ops()
         sys.exit(0)
-    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--block-v1", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-isp", "--ckpt-load"):
+    for mode in ("--ops", "--data", "--data-folder", "--metrics", "--sched", "--eval", "--moe", "--moe-layer", "--block-v1", "--ckpt", "--ckpt-v1", "--ckpt-mp", "--ckpt-tp", "--ckpt-pp", "--ckpt-isp", "--ckpt-isp4", "--ckpt-moe-mp", "--ckpt-load"):
         subprocess.check_call([sys.executable, __file__, mode])
     for tag in RUNS:
         subprocess.check_call([sys.executable, __file__, "--run", tag])

@@ -787,3 +787,56 @@ def test_isp_layout_optimizer_shards_of_the_reference_merge_are_reproduced_and_r
         assert abs(r["loss"] - want_loss) <= 1e-3 * want_loss and abs(r["lr"] - w["lr"]) <= 1e-12
         for g_ in ("0_default", "1_embed_head"):
             assert abs(r["grad_norm"][g_] - w["grad_norm"][g_]) <= 1e-2 * w["grad_norm"][g_], (k, g_)
+
+
+def test_moe_two_rank_reference_checkpoint_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_moe_dp2/ = the files of a real TWO-rank run of the reference's INTERNLM_MoE model (its automatic expert parallelism: ep = 2, two
+    of the four experts per rank; make_golden.py --ckpt-moe-mp): the model file without the experts (rank 0), one file per expert under its GLOBAL number
+    (written by the rank that holds it), per rank an optimizer shard with three groups -- the dense parameters' and the gates' partition of the
+    data-parallel group, and in group `moe_ep_size_2` ALL of the rank's own experts (the expert-data group has one rank) -- and its plan.
+    The reader merges both ranks into the full state (master weights round to the model bit for bit); writing both ranks' files from it reproduces the
+    reference's sixteen files tensor for tensor; the expert-parallel oracle resumes onto the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoEDataParallel
+
+    gold = [json.load(open(os.path.join(G, f"ckpt_moe_dp2_rank{r}.json"))) for r in (0, 1)]
+    c = gold[0]["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+    ref = os.path.join(G, "ckpt_ref_moe_dp2")
+    assert gold[1]["ranks"] == {"DATA": [1, 2], "ZERO1": [1, 2], "EXPERT": [1, 2], "EXPERT_DATA": [0, 1]}
+    ck = C.load_moe_checkpoint(ref, mc)
+    assert ck["adam_step"] == 2 and ck["zero_world"] == 2 and len(ck["master"]) == len(C.state_dict_order(mc))
+    for n in ck["params"]:
+        assert torch.equal(ck["master"][n].to(ck["params"][n].dtype), ck["params"][n]), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for r in (0, 1):   # (a rank passes what it holds: everything dense, its own two experts)
+        mine = {n for _, names in C.moe_groups(mc, 2, r) for n in names}
+        part = lambda d: {n: t for n, t in d.items() if n in mine}  # noqa: E731
+        C.save_moe_checkpoint(str(tmp_path), mc, part(ck["params"]), part(ck["master"]), part(ck["exp_avg"]), part(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"],
+                              ck["lr"], hyper, world=2, rank=r)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(ref)) == gold[0]["files"]
+    for fn in gold[0]["files"]:
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(tmp_path, fn)), ld(os.path.join(ref, fn)), fn)
+    # resume: the expert-parallel oracle (both ranks in one process) from the merged state onto the reference's steps 2 and 3
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    ora = OracleMoEDataParallel(PathConfig(mc, tc), 2)
+    ora.load_state(ck)
+    ora.calls_of = [2 * c["layers"] * c["micro_num"]] * 2     # gating calls each rank's two saved steps consumed (rank r's call k draws seed 5000 + 1000 r + k)
+    loaders = [iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold[0]["num_samples"], data_rank=r, data_world_size=2)) for r in (0, 1)]
+    for _ in range(2):
+        for ld_ in loaders:
+            next(ld_)
+    for k in (2, 3):
+        bl = [next(ld_) for ld_ in loaders]
+        res = ora.train_step([b for b, _ in bl], [y for _, y in bl])
+        for r in (0, 1):
+            w = gold[r]["steps"][k]
+            print(f"resumed step {k} rank {r}: oracle loss {res[r]['loss']:.5f} {res[r]['grad_norm']} | reference {w['loss']:.5f} {w['grad_norm']}")
+            assert abs(res[r]["loss"] - w["loss"]) <= 1e-4 * w["loss"], (k, r)        # (measured 4e-6)
+            for (g_, v), gw in zip(res[r]["grad_norm"].items(), w["grad_norm"].values()):
+                assert abs(v - gw) <= 2e-3 * gw, (k, r, g_, v, gw)                     # (measured 2.5e-4)

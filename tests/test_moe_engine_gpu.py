@@ -365,3 +365,74 @@ def test_moe_engine_expert_parallel_on_two_ranks_matches_the_reference_rules(dev
     assert ex0 and not (ex0 & ex1), "the ranks hold different experts"
     assert all(".wrapped_experts.0." in n or ".wrapped_experts.1." in n for n in ex0), "rank 0 holds experts 0 and 1"
     assert all(".wrapped_experts.2." in n or ".wrapped_experts.3." in n for n in ex1), "rank 1 holds experts 2 and 3"
+
+
+def _moe_ckpt_worker(rank, world, port, q, out_folder):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.moe_engine import MoEEngine
+        from oracle import moe as MO
+
+        gold = json.load(open(os.path.join(G, f"ckpt_moe_dp2_rank{rank}.json")))
+        cfg = _cfg(gold)
+        calls0 = gold["saved_after_step"] * cfg.model.num_layers * cfg.train.micro_num    # gating calls the saved steps consumed on this rank
+        eng = MoEEngine(cfg, dev, None, world, rank, seed=21 + rank,
+                        noise_fn=lambda call, S, E: MO.gumbel_noise((S, E), 5000 + 1000 * rank + calls0 + call).to(dev))
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_moe_dp2"))
+        eng.save_checkpoint(out_folder)           # straight back out: must be the reference's files
+        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=rank, data_world_size=world))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        batch, labels = next(loader)
+        lr = eng.lr_sched.lr()
+        loss, moe_loss = eng.forward_backward(batch, labels)
+        eng.step()
+        st = eng.read_state()
+        q.put((rank, float(loss), float(moe_loss), dict(st.group_norms), lr, st.loss_scale, st.skip))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_moe_engine_two_rank_checkpoint_of_the_reference_loads_and_is_written_back(dev, tmp_path):
+    """tests/golden/ckpt_ref_moe_dp2/ (a real two-rank run of the reference's INTERNLM_MoE model with its automatic expert parallelism, after two steps) into
+    MoEEngine on two ranks: every rank takes the dense parameters, the gates and ITS two experts out of the merged state; save_checkpoint straight after the
+    load writes the reference's sixteen files back tensor for tensor (model file without the experts, one file per expert under its global number from the
+    rank that holds it, per rank the three-group optimizer shard + plan); the next step runs on the reference's batch: its loss within 5e-3 of the
+    reference's step 2 (the routing is free here: a near-tie of a gate logit may fall the other way), learning rate and loss scale equal."""
+    import torch.multiprocessing as mp
+    from test_checkpoint import _deep_equal
+
+    from internevo_amd import checkpoint as C
+
+    out = str(tmp_path / "moe_dp2_out")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moe_ckpt_worker, args=(r, 2, 29737, q, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    ref = os.path.join(G, "ckpt_ref_moe_dp2")
+    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+    for fn in sorted(os.listdir(ref)):
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(out, fn)), ld(os.path.join(ref, fn)), fn)
+    for rank, loss, moe_loss, norms, lr, scale, skip in res:
+        w = json.load(open(os.path.join(G, f"ckpt_moe_dp2_rank{rank}.json")))["steps"][2]
+        print(f"rank {rank} resumed step: HIP loss {loss:.5f} moe {moe_loss:.4f} norms {norms} | reference {w['loss']:.5f} {w['moe_loss']:.4f} {w['grad_norm']}")
+        assert skip == 0 and scale == w["loss_scale"] and abs(lr - w["lr"]) <= 1e-12
+        assert abs(loss - w["loss"]) <= 5e-3 * w["loss"]
+        for (g_, v), gw in zip(norms.items(), w["grad_norm"].values()):
+            assert abs(v - gw) <= 5e-2 * gw, (rank, g_, v, gw)

@@ -114,9 +114,9 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
     if model_only:
         raise NotImplementedError("INTERNLM_MoE: load_ckpt_info content = ('model',) (weights-only loads are the dense engine's)")
-    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0 or ((save_folder or load_folder) and world > 1):
+    if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0:
         raise NotImplementedError("INTERNLM_MoE runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
-                                  "the dense engine); INTERNLM_MoE checkpoints cover one data-parallel rank")
+                                  "the dense engine)")
     tc = cfg.train
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
