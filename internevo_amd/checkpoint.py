@@ -650,7 +650,7 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
 #   model_moe_layer{l}_expert{e}_tp0.pt            one expert's w1 / w2 / w3 under its GLOBAL expert number
 #   optimizer_tp0_pp0_zo0.pt                       base_optim_states.state {0, 1, 2}, param_groups [default, fp32 (the gates), moe_ep_size_{ep} (the experts,
 #                                                  optimizer_mode EXPERT_DATA)], flat_fp32_weights {0, 1, 2}, the plan with one list per group
-# Covered here: one data-parallel rank (zero world 1, expert parallel size 1).
+# Covered: any number of data-parallel ranks (the reference's automatic expert parallelism, ep = min(dp, experts); pinned on tests/golden/ckpt_ref_moe_dp2/ too).
 def moe_groups(model_cfg, ep_world=1, ep_rank=0):
     """[(group name, parameter names in module order)] of the three optimizer groups ON ONE RANK of an expert-parallel group of ep_world ranks: the dense
     parameters and the gates whole, the experts this rank holds (global numbers ep_rank * E / ep ... -- the reference's automatic expert parallelism,

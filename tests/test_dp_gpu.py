@@ -507,7 +507,8 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True, es=False):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("vp,es", [(True, False), (False, False), (True, True)], ids=["vocab_parallel_head", "whole_head", "hidden_split_embedding"])
+@pytest.mark.parametrize("vp,es", [(True, False), pytest.param(False, False, marks=pytest.mark.extended), (True, True)],   # (whole_head: the engine's non-default head layout)
+                         ids=["vocab_parallel_head", "whole_head", "hidden_split_embedding"])
 def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp, es):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
     same micro-batches: same loss, same grad norm (replicated parameters counted once), same AccPerplex metric, and the two ranks'

@@ -32,7 +32,8 @@ def _run_one_rank(dev, cfg, micro_num, fixed, steps=3, **kw):
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
 
-    eng = InternLM2Engine(cfg, dev, init_fn=formula_init, **kw)
+    kw.setdefault("init_fn", formula_init)
+    eng = InternLM2Engine(cfg, dev, **kw)
     loader = iter(SyntheticLoader(cfg.train.seq_len, 1, micro_num, fixed, 4000))
     ref = []
     for _ in range(steps):
@@ -190,7 +191,9 @@ def _sp_big_worker(rank, world, port, q, seq):
         cfg = internlm2_7b(seq)
         cfg.model.num_layers = 1
         cfg.train.micro_num, cfg.train.total_steps = 1, 4
-        eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=formula_init, sp_size=world)
+        # (the engine's own seeded initialisation: every rank draws the same full tensors on the GPU -- the closed-form numpy weights of the other tests cost
+        # each of the eight ranks half a minute of host time at this width)
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=77, sp_size=world)
         assert eng.a_kv[0].shape == (seq, 2, 1, 128) and eng.a_q[0].shape == (seq, 4, 128)   # all tokens, this rank's ONE kv head / 4 q heads
         loader = iter(SyntheticLoader(seq, 1, 1, True, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
@@ -226,7 +229,7 @@ def test_isp_config3_layout_seq32768_sp8_at_7b_width(dev, backend):  # noqa: F81
     cfg = internlm2_7b(seq)
     cfg.model.num_layers = 1
     cfg.train.micro_num, cfg.train.total_steps = 1, 4
-    eng, ref = _run_one_rank(dev, cfg, 1, True, steps=1, emulate_isp_grad_rule=world)
+    eng, ref = _run_one_rank(dev, cfg, 1, True, steps=1, emulate_isp_grad_rule=world, seed=77, init_fn=None)
     for k in range(1):
         print(f"step {k}: sp8 @ 32768 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
         for r in res:

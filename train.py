@@ -104,7 +104,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     """The hot loop for model_type INTERNLM_MoE (configs/7B_MoE4_sft.py) on internevo_amd.moe_engine.MoEEngine: synthetic RandomDataset batches,
     forward / backward with the moe loss, the three-group optimizer step, one log line per step with the reference's loss / moe_loss /
     per-group grad_norm keys (train/pipeline.py:494-530); InternEvo checkpoints (model + expert + optimizer files and the run state: scheduler, sampler,
-    context) on one data-parallel rank.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
+    context) at any data-parallel size.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
     engine.InternLM2Engine like every other dense family.)"""
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.moe_engine import MoEEngine
