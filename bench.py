@@ -38,6 +38,24 @@ def exact_flops_per_token(mc, seq_len, causal=True):
     return 3 * ((lin + attn) * mc.num_layers + 2 * v * h)
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one (the GPU boxes of this pool show 256 logical CPUs under a quota of 16
+    cores: 128 torch threads on them run the oracle SLOWER than 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(cfg, budget_note=True):
     """Time the CPU oracle on a bounded sample of the same workload: one 4096-token micro-batch through a
     7B-shaped model with 0 and with 1 transformer layer (fwd + bwd + optimizer), extrapolated linearly to
@@ -46,7 +64,8 @@ def cpu_baseline(cfg, budget_note=True):
 
     from oracle.step import OracleTrainer
 
-    threads = torch.get_num_threads()
+    threads = host_cores()
+    torch.set_num_threads(threads)   # (one thread per core the box grants; torch's own default follows the logical CPU count)
     tc = cfg.train
     gen = torch.Generator().manual_seed(0)
     ids = torch.randint(0, 30, (1, tc.packed_length), generator=gen)

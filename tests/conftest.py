@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The GPU boxes of this pool show 256 logical CPUs but run under a cgroup quota of 16 cores (`/sys/fs/cgroup/cpu.max` = 1600000 100000).  torch's default of 128
+# intra-op threads PER PROCESS -- the pytest process, every xdist worker, every spawned rank of the multi-process tests, each with its OpenMP workers
+# spinning between parallel regions -- gets the whole job throttled: measured on twelve multi-rank tests, 202 s with the defaults against 32 s with four
+# threads per process (`profiles/r04_gpu_suite_timing.md`).  Set before torch is imported anywhere, inherited by every child process.
+for _k, _v in (("OMP_NUM_THREADS", "4"), ("MKL_NUM_THREADS", "4"), ("OMP_WAIT_POLICY", "PASSIVE")):
+    os.environ.setdefault(_k, _v)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -46,11 +53,10 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_configure(config):
-    n = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "1"))
-    if n > 1:   # the CPU oracles of concurrent tests share the host's cores (and tiny-model oracles gain nothing from 128 threads)
+    if "torch" in sys.modules:   # (imported before this file by a plugin: the environment above came too late for this process)
         import torch
 
-        torch.set_num_threads(max(1, min(16, (os.cpu_count() or n) // n)))
+        torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ranks(n): GPUs a multi-rank test needs for its RCCL (nccl backend) variant")
     config.addinivalue_line("markers", "extended: a parametrisation whose layout another default test covers; run with IE_TEST_FULL=1")
