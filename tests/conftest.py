@@ -24,10 +24,8 @@ def xport(port):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """Run the suite on four pytest-xdist workers by default.  Two measured dead ends shaped this (profiles/r04_gpu_suite_timing.md): what made concurrent
-    tests crawl was not the GPU but CPU oracles at 7B width taking every host core (a 5-second two-rank test beside them took 150 s) -- those oracle
-    runs are committed records now (tools/gen_7bwidth_merged_fixture.py) -- and pinning the multi-process test files to one worker each (`loadgroup`)
-    made two 10-minute serial chains.  `-n N` on the command line wins; IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
+    """Run the suite on four pytest-xdist workers by default (with the thread cap above: the whole GPU suite in ~100 s on one MI355X box, 860 s in round 3;
+    the measurements behind it: profiles/r04_gpu_suite_timing.md).  `-n N` on the command line wins; IE_TEST_SERIAL=1 or a missing xdist plugin runs serially."""
     if (config.pluginmanager.hasplugin("xdist") and getattr(config.option, "numprocesses", None) is None and not os.environ.get("PYTEST_XDIST_WORKER")
             and os.environ.get("IE_TEST_SERIAL") != "1" and not getattr(config.option, "collectonly", False)):
         config.option.numprocesses = 4

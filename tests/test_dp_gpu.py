@@ -507,7 +507,7 @@ def _tp_worker(rank, world, port, q, folder=None, vp=True, es=False):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("vp,es", [(True, False), pytest.param(False, False, marks=pytest.mark.extended), (True, True)],   # (whole_head: the engine's non-default head layout)
+@pytest.mark.parametrize("vp,es", [(True, False), (False, False), (True, True)],
                          ids=["vocab_parallel_head", "whole_head", "hidden_split_embedding"])
 def test_tensor_parallel_step_equals_single_rank_step(dev, tmp_path, backend, vp, es):
     """Megatron tensor parallelism of the layers (parallel.tensor = dict(size=2, mode="mtp")) on two ranks vs ONE rank on the
@@ -712,7 +712,7 @@ def _pp_tp_worker(rank, world, port, q, chunks, mode="mtp"):
 
 @pytest.mark.timeout(600)
 @pytest.mark.ranks(4)
-@pytest.mark.parametrize("chunks,mode", [(1, "mtp"), (2, "mtp"), (1, "msp"), pytest.param(1, "isp", marks=pytest.mark.extended), (2, "isp")],
+@pytest.mark.parametrize("chunks,mode", [(1, "mtp"), (2, "mtp"), (1, "msp"), (1, "isp"), (2, "isp")],
                          ids=["1f1b", "interleaved", "1f1b_msp", "1f1b_isp", "interleaved_isp"])
 def test_pipeline_with_tensor_parallelism_equals_single_rank_step(dev, backend, chunks, mode):
     """parallel.pipeline = dict(size=2) together with parallel.tensor = dict(size=2, mode="mtp") on four ranks (tensor groups inside a stage, a rank's

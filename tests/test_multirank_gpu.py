@@ -70,8 +70,7 @@ def _sp_worker(rank, world, port, q, sp, heads, kv_heads, micro_num, fixed):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("sp,dp,heads,kv_heads", [
-    pytest.param(4, 1, 8, 4, marks=[pytest.mark.ranks(4), pytest.mark.extended]),   # (sp 4 also runs in sp4_x_dp2)
-    pytest.param(8, 1, 16, 8, marks=pytest.mark.ranks(8)), pytest.param(4, 2, 8, 4, marks=pytest.mark.ranks(8))],
+    pytest.param(4, 1, 8, 4, marks=pytest.mark.ranks(4)), pytest.param(8, 1, 16, 8, marks=pytest.mark.ranks(8)), pytest.param(4, 2, 8, 4, marks=pytest.mark.ranks(8))],
     ids=["sp4_one_kv_head_per_rank", "sp8_one_kv_head_per_rank", "sp4_x_dp2"])
 def test_sequence_parallel_sp4_sp8_equals_single_rank_step(dev, backend, sp, dp, heads, kv_heads):  # noqa: F811
     """configs[3]'s layout: the packed sequence cut into sp contiguous parts, attention on all tokens with Hkv / sp = 1 kv head (and
@@ -197,7 +196,7 @@ def _sp_big_worker(rank, world, port, q, seq):
         assert eng.a_kv[0].shape == (seq, 2, 1, 128) and eng.a_q[0].shape == (seq, 4, 128)   # all tokens, this rank's ONE kv head / 4 q heads
         loader = iter(SyntheticLoader(seq, 1, 1, True, 4000, data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
-        for _ in range(1):   # (one step: eight ranks x 4096 local tokens at the 7B width share one GPU here)
+        for _ in range(2):
             batch, labels = next(loader)
             loss = eng.forward_backward(batch, labels)
             eng.step()
@@ -229,8 +228,8 @@ def test_isp_config3_layout_seq32768_sp8_at_7b_width(dev, backend):  # noqa: F81
     cfg = internlm2_7b(seq)
     cfg.model.num_layers = 1
     cfg.train.micro_num, cfg.train.total_steps = 1, 4
-    eng, ref = _run_one_rank(dev, cfg, 1, True, steps=1, emulate_isp_grad_rule=world, seed=77, init_fn=None)
-    for k in range(1):
+    eng, ref = _run_one_rank(dev, cfg, 1, True, steps=2, emulate_isp_grad_rule=world, seed=77, init_fn=None)
+    for k in range(2):
         print(f"step {k}: sp8 @ 32768 loss {res[0][1][k][0]:.5f} gn {res[0][1][k][1]:.4f} | 1 rank loss {ref[k][0]:.5f} gn {ref[k][1]:.4f}")
         for r in res:
             assert r[1][k] == res[0][1][k], "every rank of the sequence group reports the same loss and global grad norm"
@@ -283,8 +282,7 @@ def _wp_worker(rank, world, port, q, sp, wp, micro_num):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,sp,wp,micro_num", [
-    (2, 1, 2, 1), pytest.param(4, 2, 2, 2, marks=[pytest.mark.ranks(4), pytest.mark.extended]),   # (sp 2 x wp 2 x two replicas: test_internlm1_gpu's ISP resume test)
-    pytest.param(4, 2, 4, 2, marks=pytest.mark.ranks(4))],
+    (2, 1, 2, 1), pytest.param(4, 2, 2, 2, marks=pytest.mark.ranks(4)), pytest.param(4, 2, 4, 2, marks=pytest.mark.ranks(4))],
     ids=["dp2_wp2_bit_identical", "sp2_wp2_two_replicas", "sp2_wp4"])
 def test_weight_parallel_step_equals_resident_step(dev, backend, world, sp, wp, micro_num):  # noqa: F811
     """ISP's weight parallelism (parallel.weight = dict(size=wp); isp.py:31-526, ops/linear.py:357-378, model/utils.py:466-586): every rank
