@@ -568,6 +568,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         // tile t+2 issued so far stay in flight: vmcnt(18)), barrier 4 those of A(t+1) (vmcnt(15)).  Per tile: 64 MFMAs, 32 LDS reads,
         // 16 DMA pieces, 4 barriers; one instruction per MFMA gap.
         static_assert(G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8, "written for 4 waves x 128x128");
+#ifndef IE_REFILL_ABL   // profiling builds only (tools/kbench/mkvariant.sh ... -DIE_REFILL_ABL=n; results are then WRONG): 1 no barriers, 2 no landing waits, 4 no LDS waits
+#define IE_REFILL_ABL 0
+#endif
+#define IE_RF_BARRIER() do { if (!(IE_REFILL_ABL & 1)) __builtin_amdgcn_s_barrier(); } while (0)
         s16x8 af[4][G::TM], bfr[4][G::TN];
         auto rdA = [&](const unsigned char* st, int ks, int i) {
             af[ks][i] = A_KM ? frag_km<BM>(st, wm * G::WM + i * 32, ks, lane) : frag_kc(st, wm * G::WM + i * 32, ks, lane);
@@ -610,24 +614,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                 if (m < 8) {
                     rdB(cur, 2 + (m >> 2), m & 3);                                   // B, k-steps 2 and 3
                 } else if (m == 8) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                                    // 1: every wave holds all of B(t)
+                    if (!(IE_REFILL_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    IE_RF_BARRIER();                                                 // 1: every wave holds all of B(t)
                 } else if (m < 14) {
                     if (more2) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
                 } else if (m < 22) {
                     rdA(cur, 2 + ((m - 14) >> 2), (m - 14) & 3);                     // A, k-steps 2 and 3
                 } else if (m == 22) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                                    // 2: every wave holds all of A(t)
+                    if (!(IE_REFILL_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    IE_RF_BARRIER();                                                 // 2: every wave holds all of A(t)
                 } else if (m < 26) {
                     if (more2) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
                 } else if (m < 28) {
                     if (more2) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
                 } else if (m == 28) {
                     if (more1) {
-                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
+                        if (IE_REFILL_ABL & 2) {
+                        } else if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();                                // 3: B(t+1) complete
+                        IE_RF_BARRIER();                                             // 3: B(t+1) complete
                     }
                 } else if (m < 37) {
                     if (more1) rdB(nxt, (m - 29) >> 2, (m - 29) & 3);                // B(t+1), k-steps 0 (registers free since MFMA 15) and 1 (since 31)
@@ -635,9 +640,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                     if (more2) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
                 } else if (m == 42) {
                     if (more1) {
-                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
+                        if (IE_REFILL_ABL & 2) {
+                        } else if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();                                // 4: A(t+1) complete
+                        IE_RF_BARRIER();                                             // 4: A(t+1) complete
                     }
                 } else if (m < 51) {
                     if (more1) rdA(nxt, (m - 43) >> 2, (m - 43) & 3);                // A(t+1), k-steps 0 and 1
