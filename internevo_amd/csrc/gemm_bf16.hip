@@ -333,7 +333,7 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, 
         // tiles ahead behind counted waits, four barriers per tile): the forward product +3 ... +10 % over 11 on every 7B shape; dgrad
         // level with the phased ring except on long / wide products (w1|w3 dgrad K = 28672: +8 %) -- profiles/r02_gemm_refill_ab.jsonl
         if (d256 <= d128) {
-            if (!any_kmajor) return 19;
+            if (!any_kmajor) return 20;   // round 4: the same schedule on v_mfma_f32_16x16x32_bf16, +4 ... +5 % on every 7B forward shape (profiles/r04_gemm_mfma16_ab.md)
             if (a_kmajor && b_kmajor) return 17;
             return (!a_kmajor && (K >= 6144 || N >= 8192)) ? 19 : 15;
         }
@@ -386,7 +386,7 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 19, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 20, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
@@ -460,7 +460,7 @@ extern "C" int ie_tune_ffn_fuse(int mode) {
 extern "C" int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K) {
     if (!(g_ffn_fuse & (bwd ? 2 : 1)) || K <= 0 || K % 64 != 0 || M < 8 || F < 8) return 0;
     if (bwd) return pick_variant(M, F, K, false, true) == 19 && !(g_tail_split && tail_split(M, F).on);
-    return F % 128 == 0 && pick_variant(M, 2 * F, K, false, false) == 19 && !(g_tail_split && tail_split(M, 2 * F).on);
+    return F % 128 == 0 && pick_variant(M, 2 * F, K, false, false) == 20 && !(g_tail_split && tail_split(M, 2 * F).on);
 }
 
 extern "C" int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, int64_t ldw, void* h13, int64_t ldh, void* act, int64_t ld_act, int64_t M,
@@ -472,7 +472,7 @@ extern "C" int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, i
     if (M == 0 || F == 0) return IE_OK;
     const bool fits32 = M * ldx * 2 < (1ll << 32) && 2 * F * ldw * 2 < (1ll << 32);
     const bool fuse = (g_ffn_fuse & 1) && K > 0 && K % 64 == 0 && F % 128 == 0 && M >= 8 && fits32 && aligned16(x) && aligned16(w13) && aligned16(h13) && ldx % 8 == 0 &&
-                      ldw % 8 == 0 && ldh % 8 == 0 && pick_variant(M, 2 * F, K, false, false) == 19 && !(g_tail_split && tail_split(M, 2 * F).on);
+                      ldw % 8 == 0 && ldh % 8 == 0 && pick_variant(M, 2 * F, K, false, false) == 20 && !(g_tail_split && tail_split(M, 2 * F).on);
     if (fuse) return ie_gemm_swiglu_dma_launch(0, x, ldx, w13, ldw, h13, ldh, nullptr, 0, act, ld_act, M, F, K, stream);
     const int rc = gemm_dispatch(-1, x, ldx, 0, w13, ldw, 0, h13, ldh, M, 2 * F, K, 0, stream);
     if (rc != IE_OK) return rc;

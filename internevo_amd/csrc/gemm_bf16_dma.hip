@@ -152,6 +152,14 @@ __device__ __forceinline__ s16x8 frag_kc(const unsigned char* tile, int rbase, i
     return *reinterpret_cast<const s16x8*>(tile + row * 128 + c * 16);
 }
 
+// the same image read for v_mfma_f32_16x16x32_bf16: rows rbase + (lane & 15), k = 32 * ks + 8 * (lane >> 4) .. + 7.  A 16-lane group reads one chunk
+// column of sixteen rows: eight swizzle values x the two 128-byte halves of a bank line -> all 64 banks once.
+__device__ __forceinline__ s16x8 frag_kc16(const unsigned char* tile, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 15);
+    const int c = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const s16x8*>(tile + row * 128 + c * 16);
+}
+
 // fragment (columns mbase + (lane & 31), k-step ks) of a k-major image [64][R]
 template <int R>
 __device__ __forceinline__ s16x8 frag_km(const unsigned char* tile, int mbase, int ks, int lane) {
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     const int pm = first_m + (id % width) % gsz;
     const int pn = (id % width) / gsz;
     // EPI 1 (w1 | w3 forward with the SwiGLU epilogue): tile column block pn = B rows pn*BN/2 .. +BN/2 of w1 AND the same rows of w3 (f rows further)
-    static_assert(EPI == 0 || (SPREAD == -4 && !A_KM && BM == 256 && BN == 256 && WAVES_M * WAVES_N == 4), "the fused epilogues ride on the refill schedule");
+    static_assert(EPI == 0 || ((SPREAD == -4 || (SPREAD == -5 && EPI == 1)) && !A_KM && BM == 256 && BN == 256 && WAVES_M * WAVES_N == 4), "the fused epilogues ride on the refill schedules");
     static_assert(EPI != 1 || !B_KM, "EPI 1: the forward product");
     const int m0 = pm * BM, n0 = EPI == 1 ? pn * (BN / 2) : pn * BN;
 
@@ -297,10 +305,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 acc16[SPREAD == -5 ? 2 * G::TM : 1][SPREAD == -5 ? 2 * G::TN : 1];   // the 16x16x32 schedule's accumulators (the other set is dead code there)
+#pragma unroll
+    for (auto& row : acc16)
+#pragma unroll
+        for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23;
     const int nk = K / BK;
-    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -11;
+    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -5 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
     if constexpr (!RING) {
@@ -663,6 +676,92 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         for (; t + 2 < nk; ++t) tile(t, std::true_type{});
         for (; t < nk; ++t) tile(t, std::false_type{});
         __syncthreads();
+    } else if constexpr (SPREAD == -5) {
+        // ---- the refill schedule of SPREAD -4 on v_mfma_f32_16x16x32_bf16 (what hipBLASLt's 256x256x64 kernel issues): 128 MFMAs of 8 passes per k-tile
+        // instead of 64 of 16, so the 52 companion instructions (LDS reads, DMA pieces, waits, barriers) sit behind every SECOND MFMA and each has a
+        // whole MFMA of issue slack behind it.  Same LDS image, same DMA order, same counted waits; a fragment is 16 rows x 32 k, a wave holds
+        // 2 k-steps x (8 + 8) fragments (128 VGPRs) and 8 x 8 accumulators of 4 registers (256 AGPRs).
+        static_assert(!A_KM && !B_KM && G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8 && EPI != 2, "written for 4 waves x 128x128, both operands k-contiguous");
+        s16x8 af[2][8], bfr[2][8];
+        // (asm form: the accumulators are pinned to AGPRs -- with the builtin the allocator parks some of the 64 four-register tiles in VGPRs and copies them
+        // through a temporary around their MFMAs, 120 to 480 v_accvgpr moves per k-tile; the waits on the fragments are still the compiler's)
+        auto mfma16 = [](f32x4& d, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); };
+        auto rdA = [&](const unsigned char* st, int ks, int i) { af[ks][i] = frag_kc16(st, wm * G::WM + i * 16, ks, lane); };
+        auto rdB = [&](const unsigned char* st, int ks, int j) { bfr[ks][j] = frag_kc16(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane); };
+        if (nk > 1) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) sb.issue_keep(q, smem + G::STAGE_BYTES + G::A_BYTES, wave);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) sa.issue_keep(q, smem + G::STAGE_BYTES, wave);
+            sa.advance_all();
+            sb.advance_all();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rdA(smem, 0, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rdB(smem, 0, j);
+        auto tile = [&](int t, auto fast_) {
+            constexpr bool FAST = decltype(fast_)::value;     // tiles t+1 and t+2 exist
+            const bool more1 = FAST || t + 1 < nk, more2 = FAST || t + 2 < nk;
+            unsigned char* cur = smem + (t & 1) * G::STAGE_BYTES;
+            const unsigned char* nxt = smem + ((t + 1) & 1) * G::STAGE_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {   // MFMAs 2m and 2m + 1 (k-step mm >> 6, A fragment (mm >> 3) & 7, B fragment mm & 7), the companion after the first
+                const int ks = m >> 5, i = (m >> 2) & 7, j = (2 * m) & 7;
+                mfma16(acc16[i][j], bfr[ks][j], af[ks][i]);  // D[n][m]
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 8) {
+                    rdB(cur, 1, m);                                                  // B, second half of the tile
+                } else if (m == 8) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                    // 1: every wave holds all of B(t)
+                } else if (m < 14) {
+                    if (more2) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
+                } else if (m < 22) {
+                    rdA(cur, 1, m - 14);                                             // A, second half
+                } else if (m == 22) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                    // 2: every wave holds all of A(t)
+                } else if (m < 26) {
+                    if (more2) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
+                } else if (m < 28) {
+                    if (more2) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
+                } else if (m == 28) {
+                    if (more1) {
+                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                // 3: B(t+1) complete
+                    }
+                } else if (m < 37) {
+                    if (more1) rdB(nxt, 0, m - 29);                                  // B(t+1), first half (fragment j is free since MFMA 56 + j; this is MFMA 58 + 2j)
+                } else if (m < 42) {
+                    if (more2) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
+                } else if (m == 42) {
+                    if (more1) {
+                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                // 4: A(t+1) complete
+                    }
+                } else if (m < 51) {
+                    if (more1) rdA(nxt, 0, m - 43);                                  // A(t+1), first half
+                } else if (m == 51) {
+                    if (more2) sa.issue_keep(7, cur, wave);                          // A(t+2) piece 7
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc16[i][j + 1], bfr[ks][j + 1], af[ks][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more2) {
+                sa.advance_all();
+                sb.advance_all();
+            }
+        };
+        int t = 0;
+        for (; t + 2 < nk; ++t) tile(t, std::true_type{});
+        for (; t < nk; ++t) tile(t, std::false_type{});
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: no hazard bookkeeping by the compiler) before the epilogue reads them
+        __syncthreads();
     } else if constexpr (SPREAD == -2 || SPREAD == -3) {
         // ---- one wave per SIMD (4 waves, 128x128 per wave: 0.5 LDS reads per MFMA), software-pipelined ACROSS k-tiles.
         // The single barrier of a k-tile sits between k-step 2 and k-step 3: by then every wave has requested all four
@@ -823,6 +922,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     // ---- epilogue (as gemm_bf16.hip): D^T accumulators -> LDS [m][n] bf16 -> 16-byte row stores
     if ((abl & 8) && !(abl & 4) && M != -12345) return;   // timing ablation: no epilogue at all
     auto stage = [&]() {
+    if constexpr (SPREAD == -5) {   // D[n][m] of a 16x16 block: lane = column m (lane & 15), registers = rows n 4 * (lane >> 4) .. + 3
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = wm * G::WM + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = wn * G::WN + j * 16 + 4 * (lane >> 4);
+                uint2 v;
+                v.x = pack2bf(acc16[i][j][0], acc16[i][j][1]);
+                v.y = pack2bf(acc16[i][j][2], acc16[i][j][3]);
+                st8(smem + m * G::CPITCH + n * 2, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int m = wm * G::WM + i * 32 + (lane & 31);
@@ -962,6 +1076,12 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 13) IE_SHAPE(256, 256, 2, 2, -23);
     else if (shape == 14) IE_SHAPE(256, 256, 2, 2, -3);
     else if (shape == 15) IE_SHAPE(256, 256, 2, 2, -4);
+    else if (shape == 16) {   // the refill schedule on 16x16x32 MFMAs: both operands k-contiguous only
+        if (a_kmajor || b_kmajor) return IE_ERR_UNSUPPORTED;
+        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
+                           (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt);
+    }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
@@ -979,7 +1099,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
     const int flags = (g_gemm_group << 8);
     if (!bwd) {
         const int tiles_n = (int)(F / 128);
-        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -4, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
+        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, bt);
     } else {
         const int tiles_n = (int)((F + 255) / 256);

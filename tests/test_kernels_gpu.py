@@ -389,6 +389,25 @@ def test_gemm_every_dma_tile_variant(dev, variant):
             close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, f"variant {variant} accumulate")
 
 
+def test_gemm_forward_schedule_on_16x16x32_mfma(dev):
+    """Variant 20 (the dispatcher's choice for the forward product since round 4: the operand-wise refill schedule issued as v_mfma_f32_16x16x32_bf16) on ragged
+    M/N edges, one, two, three and many k-tiles, a strided A view and accumulate; operands that are not k-contiguous are refused, not mis-read."""
+    for (M, N, Kd) in [(520, 392, 192), (264, 256, 64), (8, 520, 128), (304, 1000, 1024), (1024, 768, 4096)]:
+        Abig = bf(torch.randn(M, Kd + 64, generator=g(57)))
+        B = bf(torch.randn(N, Kd, generator=g(58)))
+        ref = Abig[:, :Kd].float() @ B.float().t()
+        C0 = bf(torch.randn(M, N, generator=g(59)))
+        Ad = Abig.to(dev)[:, :Kd]
+        C = K().gemm(Ad, B.to(dev), False, False, variant=20)
+        close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"variant 20 {M}x{N}x{Kd}")
+        Cd = C0.to(dev).clone()
+        K().gemm(Ad, B.to(dev), False, False, out=Cd, accumulate=True, variant=20)
+        close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, "variant 20 accumulate")
+    A = bf(torch.randn(256, 128, generator=g(57))).to(dev)
+    with pytest.raises(Exception):
+        K().gemm(A, bf(torch.randn(128, 256, generator=g(58))).to(dev), False, True, variant=20)
+
+
 @pytest.mark.parametrize("M,N", [(4096, 6144), (6144, 4096), (4096, 14336)])
 def test_gemm_tail_split_is_bit_identical(dev, M, N):
     """With ie_tune_gemm_tail_split on, the automatic GEMM cuts a half-empty last round of 256x256 tiles off into a launch of 128x256 tiles (wqkv: cut along N for
