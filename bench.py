@@ -370,7 +370,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         out["roofline"] = {
-            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM; fwd: one wave per SIMD, operand-wise refill of two 64-deep stages, v_mfma_f32_16x16x32_bf16; long dgrads: the same schedule on v_mfma_f32_32x32x16_bf16; other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
+            "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM; fwd: one wave per SIMD, operand-wise refill of two 64-deep stages, v_mfma_f32_16x16x32_bf16, also the long dgrads (B by transposing reads); other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
             "bound": "mfma",
             "achieved": ach / 1e12,
             "peak": MFMA_PEAK / 1e12,

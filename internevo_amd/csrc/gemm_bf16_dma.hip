@@ -94,16 +94,21 @@ struct DmaSrc {
 // into the descriptor base -- no per-piece address VGPRs to bump and no 64-bit per-lane addresses through the memory
 // front end.  The swizzle term of a piece depends on g only through g & 1 == wave & 1 (NW is even), so it is per-wave
 // constant.  Rows past the edge of the matrix fall outside num_records and read as zero (no clamping needed).
-template <bool KM, int R, int NW>
+// HALF (k-major image read as 16-column fragments for v_mfma_f32_16x16x32_bf16): k-rows k and k + 8 -- lanes l and l + 16 of a transposing read, one 32-lane bank
+// group -- additionally swap the 32-byte halves of their 64-byte blocks (slot ^ 2 for k & 8).  k & 8 of piece g = wave + NW q is q & 1 with two rows per piece and
+// NW = 4, so a lane has two byte offsets, one for the even and one for the odd pieces.
+template <bool KM, int R, int NW, bool HALF = false>
 struct BufSrc {
     static constexpr int LPR = R / 8;
     static constexpr int RPI = 64 / LPR;
     static constexpr int PERW = KM ? (64 / RPI) / NW : R / 8 / NW;
     static_assert(NW % 2 == 0 && (!KM || RPI == 2 || RPI % 4 == 0), "swizzle must be per-wave constant");
+    static_assert(!HALF || (KM && RPI == 2 && NW == 4), "the half swizzle is written for 256-column k-major images loaded by four waves");
     const bf16_t* base;   // tile origin at the current k-tile
     uint32_t bytes_left;  // bytes from `base` to the end of the matrix
     uint32_t step_bytes;
     int voff;
+    int voff_odd;         // HALF: the offset of the odd pieces
     int soff[PERW];
     __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int K, int wave, int lane) {
         const int ldb = (int)ld * 2;
@@ -112,6 +117,7 @@ struct BufSrc {
             const int kr3 = (RPI == 2 ? 2 * (wave & 1) + kr_in : kr_in) & 3;  // (g * RPI + kr_in) & 3
             const int cpos = (lane % LPR) ^ (kr3 << 2);
             voff = kr_in * ldb + cpos * 16;
+            voff_odd = kr_in * ldb + (cpos ^ 2) * 16;
             base = P + r0;
             bytes_left = (uint32_t)((int64_t)K * ldb - (int64_t)r0 * 2);
             step_bytes = 64u * (uint32_t)ldb;
@@ -131,7 +137,7 @@ struct BufSrc {
     __device__ __forceinline__ void issue_keep(int q, unsigned char* tile, int wave) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type does not exist in the host pass
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_left, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave + NW * q) * 1024), 16, voff, soff[q], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave + NW * q) * 1024), 16, (HALF && (q & 1)) ? voff_odd : voff, soff[q], 0, 0);
 #endif
     }
     __device__ __forceinline__ void advance_all() {
@@ -144,6 +150,22 @@ struct BufSrc {
         advance_all();
     }
 };
+
+// the output tile's 16-byte row stores: non-temporal, so that a round's 32 MB of C (256 tiles of 128 KB, all CUs reach their epilogues together) do not push
+// the A / B panels of the next round out of the L2s.  Same-box A/B (profiles/r04_gemm_mfma16_ab.md): +1 ... +2 % on the forward and input-gradient products,
+// 0 ... +6 % on the weight-gradient products, +0.35 % on the training step (A B A B).  -DIE_GEMM_NT_STORE=0 builds the plain stores.
+#ifndef IE_GEMM_NT_STORE
+#define IE_GEMM_NT_STORE 1
+#endif
+__device__ __forceinline__ void st16_c(void* p, const uint4& v) {
+#if IE_GEMM_NT_STORE
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
+#else
+    st16(p, v);
+#endif
+}
 
 // fragment (rows rbase + (lane & 31), k-step ks) of a k-contiguous image
 __device__ __forceinline__ s16x8 frag_kc(const unsigned char* tile, int rbase, int ks, int lane) {
@@ -186,15 +208,17 @@ __device__ __forceinline__ s16x8 frag_km(const unsigned char* tile, int mbase, i
 //   k-contiguous operand: stage image [R][32] bf16 (64-B rows); 16-B chunk c of row r sits at slot c ^ ((r >> 2) & 3) (16 rows x
 //     one chunk = 16 distinct 16-B slots of a 256-B bank row); a 1-KiB piece = 16 rows, 4 lanes per row;
 //   k-major operand: stage image [32][R] in natural layout, 64-B block b of k-row k at block b ^ (k & 3) exactly as above.
-template <bool KM, int R, int NW>
+template <bool KM, int R, int NW, bool HALF = false>   // HALF: as BufSrc (k-rows k and k + 8 swap the 32-byte halves of their 64-byte blocks; 16-column fragments)
 struct RingSrc {
     static constexpr int LPR = R / 8;                      // KM: 16-B slots per k-row
     static constexpr int RPI = 64 / LPR;                   // KM: k-rows per piece
     static constexpr int PERW = R / 16 / NW;               // pieces per wave and stage (a stage image is R * 64 bytes)
     static_assert(PERW >= 1 && NW % 2 == 0 && (!KM || RPI == 2 || RPI % 4 == 0), "piece mapping");
+    static_assert(!HALF || (KM && RPI == 2 && NW == 4), "the half swizzle is written for 256-column k-major images loaded by four waves");
     const bf16_t* base;
     uint32_t bytes_left, step_bytes;
     int voff;
+    int voff_odd;                                          // HALF: the offset of the odd pieces (k & 8 of piece wave + 4 q is q & 1)
     int soff[PERW];
     __device__ __forceinline__ void init(const bf16_t* __restrict__ P, int64_t ld, int r0, int nr, int K, int wave, int lane) {
         const int ldb = (int)ld * 2;
@@ -202,6 +226,7 @@ struct RingSrc {
             const int kr_in = lane / LPR;
             const int kr3 = (RPI == 2 ? 2 * (wave & 1) + kr_in : kr_in) & 3;
             voff = kr_in * ldb + (((lane % LPR) ^ (kr3 << 2)) * 16);
+            voff_odd = kr_in * ldb + (((lane % LPR) ^ (kr3 << 2) ^ 2) * 16);
             base = P + r0;
             bytes_left = (uint32_t)((int64_t)K * ldb - (int64_t)r0 * 2);
             step_bytes = 32u * (uint32_t)ldb;
@@ -220,7 +245,7 @@ struct RingSrc {
     __device__ __forceinline__ void issue_keep(int q, unsigned char* img, int wave) {
 #if defined(__HIP_DEVICE_COMPILE__)
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_left, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, voff, soff[q], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(img + (wave + NW * q) * 1024), 16, (HALF && (q & 1)) ? voff_odd : voff, soff[q], 0, 0);
 #endif
     }
     __device__ __forceinline__ void advance() {
@@ -245,6 +270,26 @@ __device__ __forceinline__ s16x8 frag_km_nowait(const unsigned char* tile, int m
     const int mcol = mbase + 16 * (gq & 1) + 4 * (p & 3);
     const int swz = (p >> 2) << 6;
     const int kb0 = ks * 16 + 8 * (lane >> 5) + (p >> 2);
+    const unsigned char* a0 = tile + kb0 * (2 * R) + ((mcol * 2) ^ swz);
+    const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a0;
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(l0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(l0), "n"(4 * 2 * R));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// the 16-column fragment of a k-major image [64][R] with the HALF swizzle (BufSrc), for v_mfma_f32_16x16x32_bf16: lane (p = lane & 15, gq = lane >> 4) gets column
+// mbase + p at k = 32 ks + 8 gq .. + 7.  Lanes l and l + 16 read k-rows eight apart: the other 32-byte half of the same 64-byte block, so a 32-lane group covers the
+// four block positions (k & 3) x both halves = all 64 banks.  Untracked asm reads as frag_km_nowait: the caller waits lgkmcnt itself.
+template <int R>
+__device__ __forceinline__ s16x8 frag_km16_nowait(const unsigned char* tile, int mbase, int ks, int lane) {
+    const int p = lane & 15, gq = lane >> 4;
+    const int mcol = mbase + 4 * (p & 3);
+    const int swz = ((p >> 2) << 6) ^ ((gq & 1) << 5);
+    const int kb0 = ks * 32 + 8 * gq + (p >> 2);
     const unsigned char* a0 = tile + kb0 * (2 * R) + ((mcol * 2) ^ swz);
     const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a0;
     s16x4 lo, hi;
@@ -305,17 +350,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 acc16[SPREAD == -5 ? 2 * G::TM : 1][SPREAD == -5 ? 2 * G::TN : 1];   // the 16x16x32 schedule's accumulators (the other set is dead code there)
+    constexpr bool MFMA16 = SPREAD == -5 || SPREAD == -24;   // the schedules on v_mfma_f32_16x16x32_bf16
+    f32x4 acc16[MFMA16 ? 2 * G::TM : 1][MFMA16 ? 2 * G::TN : 1];   // their accumulators (the other set is dead code there)
 #pragma unroll
     for (auto& row : acc16)
 #pragma unroll
         for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23;
+    constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23 || SPREAD == -24;
     const int nk = K / BK;
     constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -5 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
-    std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW>, DmaSrc<B_KM, BN, NW>> sb;
+    std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW, SPREAD == -5 && B_KM>, DmaSrc<B_KM, BN, NW>> sb;
     if constexpr (!RING) {
         sa.init(A, lda, m0, M, K, wave, lane);
         sb.init(B, ldb, n0, N, K, wave, lane);
@@ -333,9 +379,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     constexpr int NA = DmaSrc<A_KM, BM, NW>::PERW, NB = DmaSrc<B_KM, BN, NW>::PERW;
     constexpr int DMA_STRIDE = SPREAD > 0 ? (SPREAD * G::TM * G::TN) / (NA + NB) : 1;  // MFMAs between two DMA issues
     static_assert(SPREAD <= 0 || DMA_STRIDE >= 1, "more DMA slots than MFMAs in the spread window");
-    if constexpr (SPREAD == -21 || SPREAD == -22 || SPREAD == -23) {
-        using RA = RingSrc<A_KM, BM, NW>;
-        using RB = RingSrc<B_KM, BN, NW>;
+    if constexpr (RING) {
+        using RA = RingSrc<A_KM, BM, NW, SPREAD == -24>;
+        using RB = RingSrc<B_KM, BN, NW, SPREAD == -24>;
         constexpr int AB = BM * 64, ST = (BM + BN) * 64;     // bytes of A's stage image, of one stage
         static_assert(4 * ST <= G::SMEM_BYTES, "four k32 stages");
         constexpr int PPW = RA::PERW + RB::PERW;              // DMA pieces per wave and entry
@@ -361,7 +407,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         auto fragB = [&](const unsigned char* st, int j, int ks) {
             return B_KM ? frag_km_nowait<BN>(st + AB, wn * G::WN + j * 32, ks, lane) : frag_kc32(st + AB, wn * G::WN + j * 32, ks, lane);
         };
-        if constexpr (SPREAD == -21) {
+        if constexpr (SPREAD == -24) {
+            // ---- the one-wave-per-SIMD ring on v_mfma_f32_16x16x32_bf16, both operands k-major (the weight-gradient product).  An entry (32 k) is ONE k-step of
+            // 64 MFMAs of 4 passes; a wave holds the 8 + 8 sixteen-column fragments of two entries (128 VGPRs; 64 accumulator tiles of 4 registers in AGPRs).
+            // Entry u: its barrier first (this wave's reads of entry u, requested during entry u-1, are complete and its pieces of entry u+1 have landed: vmcnt
+            // leaves entries u+2, u+3 in flight) -- so every wave holds entry u in registers, stage u is free and entry u+1 is complete; then 64 MFMAs on set
+            // u & 1 with one companion per gap in the first half: the fragments of entry u+1 into the other set (even gaps, two transposing reads each) and
+            // the pieces of entry u+4 into stage u (odd gaps 1, 5, ...).  One barrier per 64 MFMAs, as the 32x32x16 ring has.
+            static_assert(A_KM && B_KM && G::TM == 4 && G::TN == 4 && PPW == 8 && EPI == 0, "written for 4 waves x 128x128, both operands k-major");
+            auto mfma16 = [](f32x4& d, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); };
+            s16x8 af[2][8], bfr[2][8];
+            auto rd = [&](const unsigned char* st, int set, int f) {
+                if (f < 8) af[set][f] = frag_km16_nowait<BM>(st, wm * G::WM + f * 16, 0, lane);
+                else bfr[set][f - 8] = frag_km16_nowait<BN>(st + AB, wn * G::WN + (f - 8) * 16, 0, lane);
+            };
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nk) issue_entry(e);
+            if (nk >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // (not __syncthreads: its fence would drain the three entries left in flight)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) rd(smem, 0, f);
+            auto entry = [&](int u, auto set_, auto fast_) {
+                constexpr int cur = decltype(set_)::value, nxt = cur ^ 1;
+                constexpr bool FAST = decltype(fast_)::value;     // entries u+1 .. u+4 exist
+                const bool more1 = FAST || u + 1 < nk, more4 = FAST || u + 4 < nk;
+                unsigned char* st = smem + (u & 3) * ST;
+                const unsigned char* nx = smem + ((u + 1) & 3) * ST;
+                if (FAST || u + 3 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+                else if (u + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 64; ++m) {
+                    const int i = m >> 3, j = m & 7;
+                    mfma16(acc16[i][j], bfr[cur][j], af[cur][i]);  // D[n][m]
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < 32 && !(m & 1)) {
+                        if (more1) rd(nx, nxt, m >> 1);
+                    } else if (m < 32 && (m & 3) == 1) {
+                        if (more4) issue_piece(m >> 2, st);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more4) {
+                    ra.advance();
+                    rb.advance();
+                }
+            };
+            int u = 0;
+            for (; u + 5 < nk; u += 2) {
+                entry(u, std::integral_constant<int, 0>{}, std::true_type{});
+                entry(u + 1, std::integral_constant<int, 1>{}, std::true_type{});
+            }
+            for (; u < nk; u += 2) {
+                entry(u, std::integral_constant<int, 0>{}, std::false_type{});
+                if (u + 1 < nk) entry(u + 1, std::integral_constant<int, 1>{}, std::false_type{});
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: no hazard bookkeeping by the compiler) before the epilogue reads them
+            __syncthreads();
+        } else if constexpr (SPREAD == -21) {
             // ---- 8 waves, role-split LOAD / COMPUTE phases as SPREAD -11; one phase pair = one ring entry (two k-steps).
             // LOAD(u) reads entry u's fragments, issues entry u+3 into the stage of entry u-1 (the lagging group, then in
             // COMPUTE(u-1), drained its reads of that stage before the barrier that closed its LOAD(u-1)) and waits until this
@@ -581,7 +689,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         // tile t+2 issued so far stay in flight: vmcnt(18)), barrier 4 those of A(t+1) (vmcnt(15)).  Per tile: 64 MFMAs, 32 LDS reads,
         // 16 DMA pieces, 4 barriers; one instruction per MFMA gap.
         static_assert(G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8, "written for 4 waves x 128x128");
-#ifndef IE_REFILL_ABL   // profiling builds only (tools/kbench/mkvariant.sh ... -DIE_REFILL_ABL=n; results are then WRONG): 1 no barriers, 2 no landing waits, 4 no LDS waits
+#ifndef IE_REFILL_ABL   // profiling builds only (tools/kbench/mkvariant.sh ... -DIE_REFILL_ABL=n; results are then WRONG): 1 no barriers, 2 no landing waits, 4 no LDS waits; on the 16x16x32 schedule also 8 no DMA pieces, 16 no fragment reads
 #define IE_REFILL_ABL 0
 #endif
 #define IE_RF_BARRIER() do { if (!(IE_REFILL_ABL & 1)) __builtin_amdgcn_s_barrier(); } while (0)
@@ -681,13 +789,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         // instead of 64 of 16, so the 52 companion instructions (LDS reads, DMA pieces, waits, barriers) sit behind every SECOND MFMA and each has a
         // whole MFMA of issue slack behind it.  Same LDS image, same DMA order, same counted waits; a fragment is 16 rows x 32 k, a wave holds
         // 2 k-steps x (8 + 8) fragments (128 VGPRs) and 8 x 8 accumulators of 4 registers (256 AGPRs).
-        static_assert(!A_KM && !B_KM && G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8 && EPI != 2, "written for 4 waves x 128x128, both operands k-contiguous");
+        // B k-major (the input-gradient product): 16-column fragments by transposing reads of the HALF-swizzled image, untracked (as SPREAD -4 does).
+        static_assert(!A_KM && G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8 && EPI != 2, "written for 4 waves x 128x128, A k-contiguous");
         s16x8 af[2][8], bfr[2][8];
         // (asm form: the accumulators are pinned to AGPRs -- with the builtin the allocator parks some of the 64 four-register tiles in VGPRs and copies them
         // through a temporary around their MFMAs, 120 to 480 v_accvgpr moves per k-tile; the waits on the fragments are still the compiler's)
         auto mfma16 = [](f32x4& d, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); };
         auto rdA = [&](const unsigned char* st, int ks, int i) { af[ks][i] = frag_kc16(st, wm * G::WM + i * 16, ks, lane); };
-        auto rdB = [&](const unsigned char* st, int ks, int j) { bfr[ks][j] = frag_kc16(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane); };
+        auto rdB = [&](const unsigned char* st, int ks, int j) {
+            if constexpr (B_KM) bfr[ks][j] = frag_km16_nowait<BN>(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane);
+            else bfr[ks][j] = frag_kc16(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane);
+        };
         if (nk > 1) {
 #pragma unroll
             for (int q = 0; q < NB; ++q) sb.issue_keep(q, smem + G::STAGE_BYTES + G::A_BYTES, wave);
@@ -700,6 +812,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         for (int i = 0; i < 8; ++i) rdA(smem, 0, i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) rdB(smem, 0, j);
+#ifndef IE_RF5_DMA   // 1: the DMA pieces of tile t+2 one every third MFMA pair behind the pair's SECOND MFMA (B at pairs 8 .. 29, A at 32 .. 53); 0: in the bursts of SPREAD -4
+#define IE_RF5_DMA 1
+#endif
+        constexpr bool EVEN_DMA = IE_RF5_DMA == 1;
         auto tile = [&](int t, auto fast_) {
             constexpr bool FAST = decltype(fast_)::value;     // tiles t+1 and t+2 exist
             const bool more1 = FAST || t + 1 < nk, more2 = FAST || t + 2 < nk;
@@ -712,51 +828,66 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                 mfma16(acc16[i][j], bfr[ks][j], af[ks][i]);  // D[n][m]
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 8) {
-                    rdB(cur, 1, m);                                                  // B, second half of the tile
+                    if (!(IE_REFILL_ABL & 16)) rdB(cur, 1, m);                                                  // B, second half of the tile
                 } else if (m == 8) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                                    // 1: every wave holds all of B(t)
+                    IE_RF_BARRIER();                                    // 1: every wave holds all of B(t)
                 } else if (m < 14) {
-                    if (more2) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
+                    if (more2 && !EVEN_DMA && !(IE_REFILL_ABL & 8)) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
                 } else if (m < 22) {
-                    rdA(cur, 1, m - 14);                                             // A, second half
+                    if (!(IE_REFILL_ABL & 16)) rdA(cur, 1, m - 14);                                             // A, second half
                 } else if (m == 22) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                                    // 2: every wave holds all of A(t)
+                    IE_RF_BARRIER();                                    // 2: every wave holds all of A(t)
                 } else if (m < 26) {
-                    if (more2) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
+                    if (more2 && !EVEN_DMA && !(IE_REFILL_ABL & 8)) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
                 } else if (m < 28) {
-                    if (more2) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
+                    if (more2 && !EVEN_DMA && !(IE_REFILL_ABL & 8)) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
                 } else if (m == 28) {
                     if (more1) {
-                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
+                        if (FAST || t + 2 < nk) {   // B(t+1) landed (this wave's pieces): A(t+1) and the pieces of tile t+2 issued so far stay in flight
+                            if constexpr (EVEN_DMA) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                        }
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();                                // 3: B(t+1) complete
+                        IE_RF_BARRIER();                                // 3: B(t+1) complete
                     }
                 } else if (m < 37) {
-                    if (more1) rdB(nxt, 0, m - 29);                                  // B(t+1), first half (fragment j is free since MFMA 56 + j; this is MFMA 58 + 2j)
+                    if (more1 && !(IE_REFILL_ABL & 16)) rdB(nxt, 0, m - 29);                                  // B(t+1), first half (fragment j is free since MFMA 56 + j; this is MFMA 58 + 2j)
                 } else if (m < 42) {
-                    if (more2) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
+                    if (more2 && !EVEN_DMA && !(IE_REFILL_ABL & 8)) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
                 } else if (m == 42) {
                     if (more1) {
-                        if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
+                        if (FAST || t + 2 < nk) {   // A(t+1) landed
+                            if constexpr (EVEN_DMA) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                        }
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();                                // 4: A(t+1) complete
+                        IE_RF_BARRIER();                                // 4: A(t+1) complete
                     }
                 } else if (m < 51) {
-                    if (more1) rdA(nxt, 0, m - 43);                                  // A(t+1), first half
+                    if (more1 && !(IE_REFILL_ABL & 16)) rdA(nxt, 0, m - 43);                                  // A(t+1), first half
                 } else if (m == 51) {
-                    if (more2) sa.issue_keep(7, cur, wave);                          // A(t+2) piece 7
+                    if (more2 && !EVEN_DMA && !(IE_REFILL_ABL & 8)) sa.issue_keep(7, cur, wave);                          // A(t+2) piece 7
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma16(acc16[i][j + 1], bfr[ks][j + 1], af[ks][i]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (EVEN_DMA && m >= 8 && m <= 53 && (m - 8) % 3 == 0) {
+                    if (more2 && !(IE_REFILL_ABL & 8)) {
+                        if (m < 32) sb.issue_keep((m - 8) / 3, cur + G::A_BYTES, wave);   // B(t+2): behind barrier 1
+                        else sa.issue_keep((m - 32) / 3, cur, wave);                       // A(t+2): behind barrier 2
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (more2) {
                 sa.advance_all();
                 sb.advance_all();
             }
+            if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (untracked reads: the next tile's first half of B)
         };
+        if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         int t = 0;
         for (; t + 2 < nk; ++t) tile(t, std::true_type{});
         for (; t < nk; ++t) tile(t, std::false_type{});
@@ -922,7 +1053,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     // ---- epilogue (as gemm_bf16.hip): D^T accumulators -> LDS [m][n] bf16 -> 16-byte row stores
     if ((abl & 8) && !(abl & 4) && M != -12345) return;   // timing ablation: no epilogue at all
     auto stage = [&]() {
-    if constexpr (SPREAD == -5) {   // D[n][m] of a 16x16 block: lane = column m (lane & 15), registers = rows n 4 * (lane >> 4) .. + 3
+    if constexpr (MFMA16) {   // D[n][m] of a 16x16 block: lane = column m (lane & 15), registers = rows n 4 * (lane >> 4) .. + 3
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = wm * G::WM + i * 16 + (lane & 15);
@@ -973,9 +1104,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(gv[e], uv[e]);
                 bf16_t* dst = C + (int64_t)gm * ldc + gn;
-                st16(dst, g);
-                st16(dst + F, u);
-                st16(ACT + (int64_t)gm * bt.ld_act + gn, pack8(o));
+                st16_c(dst, g);
+                st16_c(dst + F, u);
+                st16_c(ACT + (int64_t)gm * bt.ld_act + gn, pack8(o));
             }
         }
         return;
@@ -1002,8 +1133,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) swiglu_bwd1(gv[e], av[e], bv[e], oa[e], ob[e], oc);
                 bf16_t* dst = C + (int64_t)gm * ldc + gn;
-                st16(dst, pack8(oa));
-                st16(dst + F, pack8(ob));
+                st16_c(dst, pack8(oa));
+                st16_c(dst + F, pack8(ob));
             }
         }
         return;
@@ -1026,7 +1157,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
                 for (int e = 0; e < 8; ++e) o[e] += n[e];
                 v = pack8(o);
             }
-            st16(dst, v);
+            st16_c(dst, v);
         }
     }
 }
@@ -1076,10 +1207,18 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else if (shape == 13) IE_SHAPE(256, 256, 2, 2, -23);
     else if (shape == 14) IE_SHAPE(256, 256, 2, 2, -3);
     else if (shape == 15) IE_SHAPE(256, 256, 2, 2, -4);
-    else if (shape == 16) {   // the refill schedule on 16x16x32 MFMAs: both operands k-contiguous only
-        if (a_kmajor || b_kmajor) return IE_ERR_UNSUPPORTED;
+    else if (shape == 16) {   // the refill schedule on 16x16x32 MFMAs: A k-contiguous (forward and input-gradient products)
+        if (a_kmajor) return IE_ERR_UNSUPPORTED;
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
+        if (b_kmajor) hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, true, -5>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
+                                         (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt);
+        else hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
+                                (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt);
+    }
+    else if (shape == 17) {   // the one-wave-per-SIMD ring on 16x16x32 MFMAs: both operands k-major (the weight-gradient product)
+        if (!a_kmajor || !b_kmajor) return IE_ERR_UNSUPPORTED;
+        const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+        hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, true, true, -24>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
                            (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt);
     }
     else IE_SHAPE(256, 256, 2, 4, -11);

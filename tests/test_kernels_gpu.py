@@ -389,23 +389,28 @@ def test_gemm_every_dma_tile_variant(dev, variant):
             close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, f"variant {variant} accumulate")
 
 
-def test_gemm_forward_schedule_on_16x16x32_mfma(dev):
-    """Variant 20 (the dispatcher's choice for the forward product since round 4: the operand-wise refill schedule issued as v_mfma_f32_16x16x32_bf16) on ragged
-    M/N edges, one, two, three and many k-tiles, a strided A view and accumulate; operands that are not k-contiguous are refused, not mis-read."""
+@pytest.mark.parametrize("variant,akm,bkm", [(20, False, False), (20, False, True), (21, True, True)], ids=["fwd_refill", "dgrad_refill", "wgrad_ring"])
+def test_gemm_schedules_on_16x16x32_mfma(dev, variant, akm, bkm):
+    """The schedules issued as v_mfma_f32_16x16x32_bf16 (round 4): variant 20 = the operand-wise refill schedule, the dispatcher's choice for the forward product
+    and for the long input-gradient products (B k-major: 16-column fragments by transposing reads of an image whose k-rows k and k + 8 swap 32-byte halves);
+    variant 21 = the one-wave-per-SIMD ring for the weight-gradient product (measured 0.5-2 % behind variant 17, selectable only).  Ragged M/N edges, one, two,
+    three and many k-tiles, a strided A view and accumulate; layouts a schedule is not written for are refused, not mis-read."""
     for (M, N, Kd) in [(520, 392, 192), (264, 256, 64), (8, 520, 128), (304, 1000, 1024), (1024, 768, 4096)]:
-        Abig = bf(torch.randn(M, Kd + 64, generator=g(57)))
-        B = bf(torch.randn(N, Kd, generator=g(58)))
-        ref = Abig[:, :Kd].float() @ B.float().t()
+        Abig = bf(torch.randn((Kd, M + 8) if akm else (M, Kd + 64), generator=g(57)))
+        A = Abig[:, :M] if akm else Abig[:, :Kd]
+        B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(58)))
+        ref = (A.float().t() if akm else A.float()) @ (B.float() if bkm else B.float().t())
         C0 = bf(torch.randn(M, N, generator=g(59)))
-        Ad = Abig.to(dev)[:, :Kd]
-        C = K().gemm(Ad, B.to(dev), False, False, variant=20)
-        close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"variant 20 {M}x{N}x{Kd}")
+        Ad = Abig.to(dev)
+        Ad = Ad[:, :M] if akm else Ad[:, :Kd]
+        C = K().gemm(Ad, B.to(dev), akm, bkm, variant=variant)
+        close(C, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"variant {variant} {M}x{N}x{Kd} akm={akm} bkm={bkm}")
         Cd = C0.to(dev).clone()
-        K().gemm(Ad, B.to(dev), False, False, out=Cd, accumulate=True, variant=20)
-        close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, "variant 20 accumulate")
+        K().gemm(Ad, B.to(dev), akm, bkm, out=Cd, accumulate=True, variant=variant)
+        close(Cd, (C0.float() + ref.to(torch.bfloat16).float()), 1.6e-2, 2e-3 * math.sqrt(Kd) + 0.05, f"variant {variant} accumulate")
     A = bf(torch.randn(256, 128, generator=g(57))).to(dev)
-    with pytest.raises(Exception):
-        K().gemm(A, bf(torch.randn(128, 256, generator=g(58))).to(dev), False, True, variant=20)
+    with pytest.raises(Exception):   # the other layout
+        K().gemm(A, A, not akm, bkm, variant=variant)
 
 
 @pytest.mark.parametrize("M,N", [(4096, 6144), (6144, 4096), (4096, 14336)])
