@@ -39,14 +39,15 @@ import torch
 _PM_MODULE = "internlm.core.context.process_group_initializer"
 
 
-def state_dict_order(model_cfg):
-    """Parameter names in the reference's module order (PackedFlashLlama1D.state_dict())."""
+def state_dict_order(model_cfg, tp_rank=0):
+    """Parameter names in the reference's module order (PackedFlashLlama1D.state_dict()) on tensor-parallel rank tp_rank."""
     if getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "INTERNLM":   # PackedFlashInternLm1D (modeling_internlm.py; pinned by tests/golden/ckpt_v1.json)
         names = ["embedding.weight"]
         for l in range(model_cfg.num_layers):
             p = f"blocks.{l}."
-            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight", p + "mixer.out_proj.bias", p + "norm1.weight", p + "norm2.weight",
-                      p + "mlp.w1.weight", p + "mlp.w2.weight", p + "mlp.w3.weight"]
+            # (a row-parallel linear's bias exists on tensor rank 0 only, ops/linear.py:317-324; pinned by tests/golden/ckpt_v1tp2_rank1.json)
+            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight"] + ([p + "mixer.out_proj.bias"] if tp_rank == 0 else [])
+            names += [p + "norm1.weight", p + "norm2.weight", p + "mlp.w1.weight", p + "mlp.w2.weight", p + "mlp.w3.weight"]
         return names + ["norm.weight", "head.weight"]
     if getattr(model_cfg, "model_type", "INTERNLM2_PUBLIC") == "INTERNLM_MoE":   # PackedFlashInternLm1D of modeling_moe.py (pinned by tests/golden/ckpt_moe.json)
         names = ["embedding.weight"]
@@ -67,12 +68,12 @@ def state_dict_order(model_cfg):
     return names + ["norm.weight", "output.weight"]
 
 
-def stage_order(model_cfg, n_layers, first, last):
+def stage_order(model_cfg, n_layers, first, last, tp_rank=0):
     """Names in ONE pipeline stage's state dict (`model_tp{t}_pp{p}.pt`): the stage numbers its layers from 0 (modeling_internlm2.py:897-925), the
     embedding lives on the first stage, norm + head on the last (pinned by tests/golden/ckpt_pp2_rank*.json)."""
     import dataclasses
 
-    full = state_dict_order(dataclasses.replace(model_cfg, num_layers=n_layers))
+    full = state_dict_order(dataclasses.replace(model_cfg, num_layers=n_layers), tp_rank)
     head, tail = full[:1], full[-2:]
     return (head if first else []) + full[1:-2] + (tail if last else [])
 
@@ -105,27 +106,42 @@ def tp_split_dim(name):
     the hidden dim (embed_split_hidden), head and the column-parallel wqkv (wq / wk / wv) / w1 / w3 over output rows, the
     row-parallel wo / w2 over input columns; norms whole.  The layer rules are internevo_amd/tensorpar.py:shard's, pinned on a real
     2-rank mtp run (tests/golden/train_tp2_*.json) and on its checkpoint files (tests/golden/ckpt_ref_tp2/)."""
-    if name == "tok_embeddings.weight":
+    if name in ("tok_embeddings.weight", "embedding.weight"):   # (InternLM2 / InternLM-1 names)
         return 1
-    if name == "output.weight" or name.endswith(("attention.wqkv.weight", "attention.wq.weight", "attention.wk.weight", "attention.wv.weight",
-                                                 "feed_forward.w1.weight", "feed_forward.w3.weight")):
+    if name in ("output.weight", "head.weight") or name.endswith(("attention.wqkv.weight", "attention.wq.weight", "attention.wk.weight", "attention.wv.weight",
+                                                                  "feed_forward.w1.weight", "feed_forward.w3.weight", "mlp.w1.weight", "mlp.w3.weight",
+                                                                  "mixer.Wqkv.weight", "mixer.Wqkv.bias")):
         return 0
-    if name.endswith(("attention.wo.weight", "feed_forward.w2.weight")):
+    if name.endswith(("attention.wo.weight", "feed_forward.w2.weight", "mixer.out_proj.weight", "mlp.w2.weight")):
         return 1
     return None
 
 
-def tp_shard(name, full, tp_rank, tp_world):
+def _by_heads(name):
+    """The InternLM-1 block's packed Wqkv (weight and bias): rows "(three h d)" -- a tensor rank holds "(three h/tp d)" of ITS heads (multi_head_attention.py:
+    ColumnParallelLinear + rearrange with the local head count), so the ranks' parts interleave along the head axis instead of concatenating."""
+    return name.endswith(("mixer.Wqkv.weight", "mixer.Wqkv.bias"))
+
+
+def tp_shard(name, full, tp_rank, tp_world, head_dim=None):
     d = tp_split_dim(name)
     if tp_world == 1 or d is None:
         return full
+    if _by_heads(name):
+        v = full.reshape(3, -1, head_dim, *full.shape[1:])
+        n = v.shape[1] // tp_world
+        return v.narrow(1, tp_rank * n, n).reshape(-1, *full.shape[1:])
     n = full.shape[d] // tp_world
     return full.narrow(d, tp_rank * n, n)
 
 
-def tp_unshard(name, parts):
+def tp_unshard(name, parts, head_dim=None):
     d = tp_split_dim(name)
-    return parts[0] if len(parts) == 1 or d is None else torch.cat(list(parts), dim=d)
+    if len(parts) == 1 or d is None:
+        return parts[0]   # (replicated -- or, out_proj's bias of the InternLM-1 block, held by tensor rank 0 alone)
+    if _by_heads(name):
+        return torch.cat([p.reshape(3, -1, head_dim, *p.shape[1:]) for p in parts], dim=1).reshape(-1, *parts[0].shape[1:])
+    return torch.cat(list(parts), dim=d)
 
 
 def zero_partition(ordered, zero_world):
@@ -214,7 +230,7 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
     and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself.
     pp_world > 1: ONE pipeline stage's files (`..._pp{pp_rank}...`); `order` = the stage's local names (stage_order) and every dict is keyed by them."""
     os.makedirs(folder, exist_ok=True)
-    order = state_dict_order(model_cfg) if order is None else list(order)
+    order = state_dict_order(model_cfg, tp_rank) if order is None else list(order)
     if write_model:
         sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
         torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp{pp_rank}.pt"))
@@ -532,7 +548,7 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, s
     carry them) whose optimizer tensors are kept; sd: the stage's model state dict if the caller has read it already."""
     if sd is None:
         sd = torch.load(os.path.join(folder, f"model_tp{t}_pp{pp_rank}.pt"), map_location="cpu", weights_only=False)
-    order = state_dict_order(model_cfg) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1)
+    order = state_dict_order(model_cfg, t) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1, t)
     params = {}
     for n in order:
         key = "model." + n if "model." + n in sd else n
@@ -603,23 +619,28 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
         raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")
     pp_world = saved_pp_world(folder)
     if pp_world > 1:
-        # one set of files per pipeline stage, each numbering its layers from 0: merged into the whole model under its own names (so that ANY layout --
-        # another pipeline size, or none -- can resume from the folder)
-        if tp_world != 1:
-            raise NotImplementedError("checkpoints with pipeline AND tensor parallelism")
+        # one set of files per pipeline stage (and per tensor rank of the stage), each numbering its layers from 0: the tensor ranks of a stage are merged
+        # into full tensors, the stages into the whole model under its own names (so that ANY layout -- another pipeline or tensor size, or none -- can
+        # resume from the folder)
         out, lo = None, 0
+        hd = model_cfg.head_dim
+        same = ("adam_step", "lr", "scaler", "zero_world")
         for p_ in range(pp_world):
-            sd = torch.load(os.path.join(folder, f"model_tp0_pp{p_}.pt"), map_location="cpu", weights_only=False)
-            n_layers = _stage_layers(sd)
+            sds = [torch.load(os.path.join(folder, f"model_tp{t}_pp{p_}.pt"), map_location="cpu", weights_only=False) for t in range(tp_world)]
+            n_layers = _stage_layers(sds[0])
             # (the optimizer tensors a caller does not want -- another stage's, another ZeRO rank's -- are dropped while the flat vectors are cut, not after)
             local_want = None if want is None else {n for n in stage_order(model_cfg, n_layers, p_ == 0, p_ == pp_world - 1) if stage_to_global(n, lo) in want}
-            st = _load_tp_rank(folder, model_cfg, 0, 1, local_want, p_, pp_world, sd=sd, model_only=model_only)
+            ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, local_want, p_, pp_world, sd=sds[t], model_only=model_only) for t in range(tp_world)]
+            st = ranks[0]
+            for t, r in enumerate(ranks[1:], 1):
+                if {k: r[k] for k in same} != {k: st[k] for k in same}:
+                    raise ValueError(f"tensor rank {t} of pipeline stage {p_} disagrees with rank 0 on the step / scaler / lr / ZeRO world")
+            whole = lambda key: None if st[key] is None else {n: (tp_unshard(n, [r[key][n] for r in ranks if n in r[key]], hd) if tp_world > 1 else st[key][n]) for n in st[key]}  # noqa: E731
             ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items()}  # noqa: E731
-            named = {k: ren(st[k]) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+            named = {k: ren(whole(k)) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
             if out is None:
                 out = dict(st, **named)
             else:
-                same = ("adam_step", "lr", "scaler", "zero_world")
                 if {k: st[k] for k in same} != {k: out[k] for k in same}:
                     raise ValueError(f"pipeline stage {p_} disagrees with stage 0 on the step / scaler / lr / ZeRO world")
                 for k, d in named.items():
@@ -628,7 +649,7 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
             lo += n_layers
         if lo != model_cfg.num_layers:
             raise ValueError(f"the {pp_world} pipeline stages of the checkpoint hold {lo} layers, the model {model_cfg.num_layers}")
-        return dict(out, tp_world=1, pp_world=pp_world)
+        return dict(out, tp_world=tp_world, pp_world=pp_world)
     ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want, model_only=model_only) for t in range(tp_world)]
     out = dict(ranks[0], tp_world=tp_world)
     if tp_world == 1:
@@ -639,7 +660,7 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
             raise ValueError(f"tensor rank {t} disagrees with rank 0 on the step / scaler / lr / ZeRO world")
     for key in ("params", "master", "exp_avg", "exp_avg_sq"):
         if ranks[0][key] is not None:
-            out[key] = {n: tp_unshard(n, [r[key][n] for r in ranks]) for n in ranks[0][key]}
+            out[key] = {n: tp_unshard(n, [r[key][n] for r in ranks if n in r[key]], model_cfg.head_dim) for n in ranks[0][key]}
     return out
 
 

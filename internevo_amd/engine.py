@@ -1575,11 +1575,8 @@ class InternLM2Engine:
             if self.job_world % wp or not (zs_cfg is None or zs_cfg <= 0 or zs_cfg >= self.job_world // wp):
                 raise NotImplementedError("checkpoints of the ISP layout with parallel.zero1.size below the weight-data size")
             return
-        if self.pp != 1 and (self.nch != 1 or self.tp != 1):
-            raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule without tensor parallelism")
-        if self._is_v1() and self.tp != 1:
-            raise NotImplementedError("checkpoints of the InternLM-1 model under tensor parallelism are not implemented (a tensor rank's Wqkv rows are "
-                                      "\"(three h/tp d)\": the ranks' files do not concatenate into the single-rank layout)")
+        if self.pp != 1 and self.nch != 1:
+            raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule (with or without tensor parallelism)")
 
     def _local_reference_named(self, named):
         """engine-named tensors of this rank -> the reference's names AND the reference's tensor-parallel cut: the layer weights are
@@ -1589,10 +1586,13 @@ class InternLM2Engine:
 
         out = self._to_reference_names(named)
         if self.tp > 1:
-            whole = ([] if self.embed_split else ["tok_embeddings.weight"]) + ([] if self.vp else ["output.weight"])
+            emb, head = ("embedding.weight", "head.weight") if self._is_v1() else ("tok_embeddings.weight", "output.weight")
+            whole = ([] if self.embed_split else [emb]) + ([] if self.vp else [head])
             for n in whole:   # (what this engine keeps whole is cut the reference's way for its files; what it holds cut already is written as is)
                 if n in out:
                     out[n] = C.tp_shard(n, out[n], self.tpar.tp_rank, self.tp)
+            if self._is_v1() and self.tpar.tp_rank != 0:   # a row-parallel linear's bias lives on tensor rank 0 only (ops/linear.py:317-324); this engine keeps it replicated
+                out = {n: t for n, t in out.items() if not n.endswith("mixer.out_proj.bias")}
         return out
 
     def save_model_isp(self, folder):
@@ -1672,7 +1672,7 @@ class InternLM2Engine:
         scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
         # this stage's parameters under the reference's names, module order; inside the files a stage numbers its layers from 0
         lo_layer = self.gid[0] if pp > 1 else 0
-        glob = [n for n in C.state_dict_order(self.mc) if self._engine_name(n) in self.p]
+        glob = [n for n in C.state_dict_order(self.mc, t) if self._engine_name(n) in self.p]
         loc = lambda n: C.global_to_stage(n, lo_layer)  # noqa: E731
         stage = dict(pp_world=pp, pp_rank=ps, order=[loc(n) for n in glob]) if pp > 1 else {}
         cpu = lambda d: {loc(n): x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731

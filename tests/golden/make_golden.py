@@ -297,6 +297,26 @@ def _full_param_slice(name, shard_shape, formula_init, rank_in_tp, tp, rank_in_w
     return full[rank_in_wp * n : (rank_in_wp + 1) * n]
 
 
+def _mtp_part_v1(name, full, tp_rank, tp, head_dim):
+    """A tensor rank's part of a full parameter of the dense InternLM-1 model under Megatron tensor parallelism, as the reference's modules hold it: Wqkv (weight and
+    bias) = "(three h d)" rows of the rank's h / tp heads (multi_head_attention.py: ColumnParallelLinear + rearrange with the LOCAL head count), out_proj / w2 =
+    input columns (RowParallelLinear; out_proj's bias exists on tensor rank 0 only, ops/linear.py:317-324), w1 / w3 = output rows, embedding over the hidden
+    dim, head over the vocabulary, norms whole."""
+    cut = lambda t, dim: t.narrow(dim, tp_rank * (t.shape[dim] // tp), t.shape[dim] // tp)  # noqa: E731
+    if name == "embedding.weight":
+        return cut(full, 1)
+    if name == "head.weight":
+        return cut(full, 0)
+    if ".mixer.Wqkv." in name:
+        v = full.reshape(3, -1, head_dim, *full.shape[1:])
+        return cut(v, 1).reshape(-1, *full.shape[1:])
+    if name.endswith("mixer.out_proj.weight") or name.endswith("mlp.w2.weight"):
+        return cut(full, 1)
+    if name.endswith("mlp.w1.weight") or name.endswith("mlp.w3.weight"):
+        return cut(full, 0)
+    return full
+
+
 def _mtp_part(name, full, tp_rank, tp, cfg_kw):
     """A rank's part of a full parameter under Megatron tensor parallelism: the layer weights cut by THIS REPO's rule
     (internevo_amd/tensorpar.py:shard -- the run reproducing the single-rank trajectory is what pins it); embedding over the hidden
@@ -587,7 +607,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     if isp:
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=2, sp=2, wp=2, seq_len=128)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
-        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=1, tp=tp)
+        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=4 if pp > 1 else 2 if model_type == "INTERNLM" else 1, tp=tp)   # (`--ckpt-pptp`: tensor 2 x pipeline 2 on four processes -> ckpt_ref_pp2tp2/)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
@@ -602,8 +622,14 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             from internevo_amd.config import ModelConfig
             from oracle.model import param_shapes
 
-            full_shapes = param_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"],
-                                                   num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"]))
+            if model_type == "INTERNLM":   # `--ckpt-v1tp`
+                from oracle.moe_model import param_shapes as v1_shapes
+
+                full_shapes = v1_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
+                                                    num_kv_attention_heads=kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
+            else:
+                full_shapes = param_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"],
+                                                       num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"]))
             tp_rank = gpc.get_local_rank(ParallelMode.TENSOR)
         if pp > 1:   # a stage numbers its layers from 0: the closed-form weights go by the GLOBAL layer number (partition_uniform)
             import re
@@ -613,7 +639,12 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             (start, _end), = partition_uniform(kw["layers"], pp, 1)[gpc.get_local_rank(ParallelMode.PIPELINE)]
             for name, p in model.model.named_parameters():
                 gname = re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name)
-                p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
+                if tp > 1:
+                    part = _mtp_part(gname, formula_init(gname, full_shapes[gname]), tp_rank, tp, kw)
+                    assert tuple(part.shape) == tuple(p.shape), (gname, tuple(part.shape), tuple(p.shape))
+                    p.copy_(part.to(p.dtype))
+                else:
+                    p.copy_(formula_init(gname, tuple(p.shape)).to(p.dtype))
         if isp:
             from internevo_amd.config import ModelConfig
             from oracle.moe_model import param_shapes as v1_shapes
@@ -635,7 +666,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                 p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, gpc.get_local_rank(ParallelMode.TENSOR), 2, gpc.get_local_rank(ParallelMode.WEIGHT), 2,
                                           full_shapes).to(p.dtype))
             elif tp > 1:
-                part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw)
+                part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw["hidden"] // kw["heads"]) if model_type == "INTERNLM"
+                        else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw))
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
             else:
@@ -652,7 +684,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else f"ckpt_ref_pp{pp}" if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else "ckpt_ref_v1" if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -740,11 +772,17 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             with open(os.path.join(HERE, f"ckpt_isp4v1_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
+        if model_type == "INTERNLM" and tp > 1:   # `--ckpt-v1tp`: both tensor ranks' records (rank 1 has no out_proj.bias)
+            rec["files"] = sorted(os.listdir(folder))
+            with open(os.path.join(HERE, f"ckpt_v1tp2_rank{rank}.json"), "w") as f:
+                json.dump(rec, f, indent=1, default=str)
+            return
         if rank != 0 and pp == 1:
             return
     rec["files"] = sorted(os.listdir(folder))
     if pp > 1:
-        with open(os.path.join(HERE, f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
+        rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.PIPELINE, ParallelMode.DATA, ParallelMode.ZERO1)}
+        with open(os.path.join(HERE, f"ckpt_pp{pp}tp{tp}_rank{rank}.json" if tp > 1 else f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
             json.dump(rec, f, indent=1, default=str)
         return
     with open(os.path.join(HERE, "ckpt_isp2v1.json" if isp else "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
@@ -1360,6 +1398,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-pp-rank":
         gen_checkpoint(port=29793, rank=int(sys.argv[2]), world=2, pp=2)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-pptp-rank":
+        gen_checkpoint(port=29787, rank=int(sys.argv[2]), world=4, pp=2, tp=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pptp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pptp-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
@@ -1393,6 +1437,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-tp-rank":
         gen_checkpoint(port=29799, rank=int(sys.argv[2]), world=2, tp=2)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-v1tp-rank":
+        gen_checkpoint(port=29786, rank=int(sys.argv[2]), world=2, tp=2, model_type="INTERNLM")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-v1tp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-v1tp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-tp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-tp-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))

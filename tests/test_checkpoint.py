@@ -546,6 +546,60 @@ def test_dense_internlm1_reference_checkpoint_loads_saves_and_resumes(tmp_path):
         assert abs(r["lr"] - w["lr"]) <= 1e-12
 
 
+def test_dense_internlm1_tensor_parallel_checkpoint_of_the_reference_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_v1tp2/: the REAL reference's dense InternLM-1 model on two Megatron tensor-parallel ranks (make_golden.py --ckpt-v1tp).  Two things
+    differ from the InternLM2 layout (ckpt_ref_tp2/): a rank's packed Wqkv rows (weight and bias) are "(three h/tp d)" of ITS heads, so the ranks' parts
+    interleave along the head axis of the single-rank "(three h d)" instead of concatenating; and out_proj's bias (a row-parallel linear) exists on tensor rank 0
+    only -- rank 1's files hold 19 parameters, rank 0's 21.  The loader merges both ranks' files into the full tensors, the writer reproduces each rank's files
+    tensor for tensor from its cut, and the single-rank oracle resumed from the merge retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoETrainer, param_shapes
+
+    g0, g1 = (json.load(open(os.path.join(G, f"ckpt_v1tp2_rank{r}.json"))) for r in (0, 1))
+    ref = os.path.join(G, "ckpt_ref_v1tp2")
+    mc = _v1_model_cfg(g0)
+    hd = mc.head_dim
+    assert ["model." + n for n in C.state_dict_order(mc, 0)] == [k[0] for k in g0["model_keys"]] and ["model." + n for n in C.state_dict_order(mc, 1)] == [k[0] for k in g1["model_keys"]]
+    assert len(g0["model_keys"]) == len(g1["model_keys"]) + mc.num_layers   # (out_proj.bias)
+    ck = C.load_checkpoint(ref, mc)
+    assert ck["tp_world"] == 2 and ck["adam_step"] == 2 and list(ck["params"]) == C.state_dict_order(mc)
+    full = param_shapes(mc)
+    for n in ck["params"]:
+        assert tuple(ck["params"][n].shape) == tuple(full[n]) == tuple(ck["master"][n].shape) == tuple(ck["exp_avg_sq"][n].shape), n
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    # the head-wise cut and its inverse
+    w = ck["params"]["blocks.0.mixer.Wqkv.weight"]
+    parts = [C.tp_shard("blocks.0.mixer.Wqkv.weight", w, t, 2, hd) for t in (0, 1)]
+    assert torch.equal(C.tp_unshard("blocks.0.mixer.Wqkv.weight", parts, hd), w) and not torch.equal(torch.cat(parts), w)
+    assert torch.equal(parts[1], torch.load(os.path.join(ref, "model_tp1_pp0.pt"), weights_only=False)["model.blocks.0.mixer.Wqkv.weight"])
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    out = str(tmp_path / "ck")
+    for t in (0, 1):
+        cut = lambda d: {n: C.tp_shard(n, d[n], t, 2, hd).contiguous() for n in C.state_dict_order(mc, t)}  # noqa: E731
+        C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"], hyper,
+                          tp_world=2, tp_rank=t)
+    assert sorted(f for f in os.listdir(out) if not f.endswith(".step")) == g0["files"]
+    for t in (0, 1):
+        _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp{t}_pp0_zo0.pt"), os.path.join(out, f"optimizer_tp{t}_pp0_zo0.pt"))
+        x, y = (torch.load(os.path.join(f, f"model_tp{t}_pp0.pt"), weights_only=False) for f in (ref, out))
+        assert list(x) == list(y) and all(x[k].shape == y[k].shape and torch.equal(x[k], y[k]) for k in x)
+        fn = f"gpus-2_wp-0_tp-{t}_dp-0_pp-0_zo-0.pt"
+        assert C._load(os.path.join(ref, fn)) == C._load(os.path.join(out, fn))
+    c = g0["config"]
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    tr = OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, g0["num_samples"]))
+    for _ in range(g0["saved_after_step"]):
+        next(loader)
+    for w_ in g0["steps"][g0["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        total = sum(v * v for v in r["grad_norm"].values()) ** 0.5
+        assert abs(r["loss"] - w_["loss"]) <= 2e-3 * w_["loss"] and abs(total - w_["grad_norm"]["0_default"]) <= 1e-2 * total, (r, w_)
+
+
 def test_pipeline_stage_checkpoint_files_of_the_reference_load_save_and_resume(tmp_path):
     """tests/golden/ckpt_ref_pp2/: the REAL reference with parallel.pipeline = dict(size=2) on two processes (make_golden.py --ckpt-pp) wrote one model /
     optimizer / plan / topo file per STAGE after two steps; a stage numbers its layers from 0 (model_tp0_pp1.pt holds layers.0, layers.1 = the model's
@@ -596,6 +650,65 @@ def test_pipeline_stage_checkpoint_files_of_the_reference_load_save_and_resume(t
     for _ in range(g1["saved_after_step"]):
         next(loader)
     for w in g1["steps"][g1["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
+
+
+def test_pipeline_x_tensor_parallel_checkpoint_of_the_reference_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_pp2tp2/: the REAL reference with parallel.pipeline size 2 AND parallel.tensor size 2 (mtp) on FOUR processes (make_golden.py
+    --ckpt-pptp) wrote one model / optimizer / plan / topo file per (tensor rank, stage) after two steps.  The loader merges the tensor ranks of a stage into full
+    tensors and the stages into the whole model (any layout resumes from the folder), the writer reproduces all sixteen files tensor for tensor from the (stage,
+    tensor rank) cut of the merged state, and the single-rank oracle resumed from the merge retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.model import param_shapes
+    from oracle.step import OracleTrainer
+
+    ref = os.path.join(G, "ckpt_ref_pp2tp2")
+    gold = [json.load(open(os.path.join(G, f"ckpt_pp2tp2_rank{r}.json"))) for r in range(4)]
+    assert [(g["ranks"]["TENSOR"][0], g["ranks"]["PIPELINE"][0]) for g in gold] == [(0, 0), (1, 0), (0, 1), (1, 1)]   # tensor ranks innermost, stages = blocks of ranks
+    last = gold[2]   # (a last-stage rank reports the loss)
+    c = last["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    mc = cfg.model
+    assert C.saved_pp_world(ref) == 2 and C.saved_tp_world(ref) == 2 and C.saved_zero_world(ref, 1, 1) == 1
+    ck = C.load_checkpoint(ref, mc)
+    assert list(ck["params"]) == C.state_dict_order(mc) and ck["pp_world"] == 2 and ck["tp_world"] == 2 and ck["adam_step"] == 2
+    full = param_shapes(mc)
+    for n in C.state_dict_order(mc):
+        assert tuple(ck["params"][n].shape) == tuple(full[n]) == tuple(ck["exp_avg"][n].shape), n
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    some = {"layers.3.attention.wo.weight", "layers.0.ffn_norm.weight", "output.weight"}
+    part = C.load_checkpoint(ref, mc, want=some)
+    assert set(part["master"]) == some and all(torch.equal(part[k][n], ck[k][n]) for k in ("master", "exp_avg", "exp_avg_sq") for n in some)
+    only = C.load_checkpoint(ref, mc, model_only=True)
+    assert only["master"] is None and all(torch.equal(only["params"][n], ck["params"][n]) for n in ck["params"])
+    # every (stage, tensor rank)'s files again from its cut of the merged state
+    out = str(tmp_path / "ck")
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for p_, (lo, n) in enumerate([(0, 2), (2, 2)]):
+        order = C.stage_order(mc, n, p_ == 0, p_ == 1)
+        for t in (0, 1):
+            cut = lambda d: {k: C.tp_shard(k, d[C.stage_to_global(k, lo)], t, 2).contiguous() for k in order}  # noqa: E731
+            C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"],
+                              hyper, tp_world=2, tp_rank=t, pp_world=2, pp_rank=p_, order=order)
+    assert sorted(os.listdir(out)) == last["files"]
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    for p_ in (0, 1):
+        for t in (0, 1):
+            a, b = ld(ref, f"model_tp{t}_pp{p_}.pt"), ld(out, f"model_tp{t}_pp{p_}.pt")
+            assert list(a) == list(b) == [k[0] for k in gold[2 * p_ + t]["model_keys"]] and all(torch.equal(a[k], b[k]) for k in a)
+            _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp{t}_pp{p_}_zo0.pt"), os.path.join(out, f"optimizer_tp{t}_pp{p_}_zo0.pt"))
+            fn = f"gpus-4_wp-0_tp-{t}_dp-0_pp-{p_}_zo-0.pt"
+            assert C._load(os.path.join(ref, fn)) == C._load(os.path.join(out, fn))
+    # the single-rank oracle resumes where the four-process reference went on
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, last["num_samples"]))
+    for _ in range(last["saved_after_step"]):
+        next(loader)
+    for w in last["steps"][last["saved_after_step"]:]:
         r = tr.train_step(*next(loader))
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
 

@@ -806,7 +806,7 @@ def test_forward_only_pass_under_pipeline_parallelism(dev, backend):
     assert abs(l0 - want) <= 1e-3 * want and abs(m0["acc"] - wm["acc"]) <= 5e-3 and abs(m0["perplexity"] - wm["perplexity"]) <= 1e-2 * wm["perplexity"]
 
 
-def _pp_ckpt_worker(rank, world, port, q, folder, dp):
+def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1):
     import json
 
     import torch.distributed as dist
@@ -818,11 +818,14 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp):
         from internevo_amd.engine import InternLM2Engine
 
         G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-        gold = json.load(open(os.path.join(G, "ckpt_pp2_rank1.json")))
+        gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2_rank1.json")))
         c = gold["config"]
         cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
-        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, pp_size=2)
-        eng.load_checkpoint(os.path.join(G, "ckpt_ref_pp2"))    # the reference's two-stage files (merged, re-cut into this stage)
+        par = dict(pp_size=2, **({"tp_size": tp} if tp > 1 else {}))
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, **par)
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_pp2tp2" if tp > 1 else "ckpt_ref_pp2"))    # the reference's per-stage (and per-tensor-rank) files (merged, re-cut into this rank's part)
+        if tp > 1:
+            eng.save_checkpoint(folder + "_echo")                # ... written straight back: the reference's files again
         loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         for _ in range(gold["saved_after_step"]):
             next(loader)
@@ -835,7 +838,7 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp):
             st = eng.read_state()
             out.append((float(loss), float(st.grad_norm), lr, float(st.loss_scale)))
         eng.save_checkpoint(folder)                              # ... and this engine's own stage files
-        fresh = InternLM2Engine(cfg, dev, None, world, rank, seed=50 + rank, pp_size=2)
+        fresh = InternLM2Engine(cfg, dev, None, world, rank, seed=50 + rank, **par)
         fresh.load_checkpoint(folder)
         same = all(torch.equal(getattr(eng, k), getattr(fresh, k)) for k in ("params", "master", "exp_avg", "exp_avg_sq"))
         batch, labels = next(loader)
@@ -850,8 +853,8 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dp", [1, pytest.param(2, marks=pytest.mark.ranks(4))], ids=["pp2", "pp2_dp2"])
-def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, backend, tmp_path, dp):
+@pytest.mark.parametrize("dp,tp", [(1, 1), pytest.param(2, 1, marks=pytest.mark.ranks(4)), pytest.param(1, 2, marks=pytest.mark.ranks(4))], ids=["pp2", "pp2_dp2", "pp2_tp2"])
+def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, backend, tmp_path, dp, tp):
     """Checkpoints under pipeline parallelism (non-interleaved): one model / optimizer / plan / topo file per STAGE with the stage's layers numbered
     from 0, as the reference writes them (checkpoint/components.py:95-410, tests/golden/ckpt_ref_pp2/ from a real two-process run).  Two stages load the
     reference's files and their next two steps are the reference's (ckpt_pp2_rank1.json: loss on every stage -- this engine broadcasts it -- within 1e-3,
@@ -864,12 +867,12 @@ def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, back
     from internevo_amd.engine import InternLM2Engine
 
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    gold = json.load(open(os.path.join(G, "ckpt_pp2_rank1.json")))
+    gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2_rank1.json")))
     folder = str(tmp_path / "ck_pp2")
-    world = 2 * dp
+    world = 2 * dp * tp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_pp_ckpt_worker, args=(r, world, 29861 + dp, q, folder, dp)) for r in range(world)]
+    procs = [ctx.Process(target=_pp_ckpt_worker, args=(r, world, 29861 + dp + 4 * tp, q, folder, dp, tp)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, world), key=lambda x: x[0])
@@ -882,10 +885,24 @@ def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, back
                 print(f"stage {stage}: resumed loss {loss:.5f} gn {gn:.4f} | reference {w['loss'] if w['loss'] is not None else float('nan'):.5f} {w['grad_norm']['0_default']:.4f}")
                 assert abs(gn - w["grad_norm"]["0_default"]) <= 2e-2 * gn and abs(lr - w["lr"]) <= 1e-12 and scale == w["loss_scale"]
                 assert abs(loss - w["loss"]) <= 1e-3 * w["loss"]
-    want = sorted([f"model_tp0_pp{p}.pt" for p in (0, 1)] + [f"topo_tp0_pp{p}.json" for p in (0, 1)] + [f"optimizer_tp0_pp{p}_zo{z}.pt" for p in (0, 1) for z in range(dp)]
-                  + [f"gpus-{world}_wp-0_tp-0_dp-{z}_pp-{p}_zo-{z}.pt" for p in (0, 1) for z in range(dp)])
+    want = sorted([f"model_tp{t}_pp{p}.pt" for p in (0, 1) for t in range(tp)] + [f"topo_tp{t}_pp{p}.json" for p in (0, 1) for t in range(tp)]
+                  + [f"optimizer_tp{t}_pp{p}_zo{z}.pt" for p in (0, 1) for z in range(dp) for t in range(tp)]
+                  + [f"gpus-{world}_wp-0_tp-{t}_dp-{z}_pp-{p}_zo-{z}.pt" for p in (0, 1) for z in range(dp) for t in range(tp)])
     assert sorted(os.listdir(folder)) == want
-    if dp == 1:   # the same folder into an engine WITHOUT pipeline parallelism
+    if tp > 1:   # pipeline x tensor parallelism (tests/golden/ckpt_ref_pp2tp2/, a real four-process run): what the four ranks wrote straight after loading IS the reference's file set
+        from internevo_amd import checkpoint as C
+
+        ref = os.path.join(G, "ckpt_ref_pp2tp2")
+        assert sorted(os.listdir(folder + "_echo")) == gold["files"]
+        for p in (0, 1):
+            for t in range(tp):
+                a, b = (torch.load(os.path.join(f, f"model_tp{t}_pp{p}.pt"), weights_only=False) for f in (ref, folder + "_echo"))
+                assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a), (t, p)
+                oa, ob = (C._load(os.path.join(f, f"optimizer_tp{t}_pp{p}_zo0.pt")) for f in (ref, folder + "_echo"))
+                assert torch.equal(oa["flat_fp32_weights"][0].detach(), ob["flat_fp32_weights"][0]) and oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"]
+                for k in ("exp_avg", "exp_avg_sq"):
+                    assert torch.equal(oa["base_optim_states"]["state"][0][k], ob["base_optim_states"]["state"][0][k]), (t, p, k)
+    if dp == 1:   # the same folder into an engine WITHOUT pipeline (or tensor) parallelism
         c = gold["config"]
         cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
         one = InternLM2Engine(cfg, dev, seed=99)

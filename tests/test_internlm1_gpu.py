@@ -496,3 +496,85 @@ def test_internlm1_block_under_tensor_and_pipeline_parallelism_equals_single_ran
     worst = max(float(abs(got[n] - full[n]).max()) for n in full)
     print("max |param diff| vs one rank:", worst)
     assert worst <= 6e-3
+
+
+def _v1_tp_ckpt_worker(rank, world, port, q, folder):
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+
+        gold = json.load(open(os.path.join(G, "ckpt_v1tp2_rank0.json")))
+        c = gold["config"]
+        cfg = _v1_cfg(c)
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, tp_size=2)
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_v1tp2"))   # the reference's two tensor ranks' files, merged and re-cut by heads
+        eng.save_checkpoint(folder + "_echo")                   # ... written straight back
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        out = []
+        for _ in range(2):
+            batch, labels = next(loader)
+            lr = eng.lr_sched.lr()
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm), lr, float(st.loss_scale)))
+        eng.save_checkpoint(folder)
+        fresh = InternLM2Engine(cfg, dev, None, world, rank, seed=50 + rank, tp_size=2)
+        fresh.load_checkpoint(folder)
+        same = all(torch.equal(getattr(eng, k), getattr(fresh, k)) for k in ("params", "master", "exp_avg", "exp_avg_sq"))
+        q.put((rank, out, bool(same)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_internlm1_tensor_parallel_checkpoint_of_the_reference_resumes_and_is_written_back(dev, backend, tmp_path):  # noqa: F811
+    """Checkpoints of the InternLM-1 model under Megatron tensor parallelism (tests/golden/ckpt_ref_v1tp2/: the REAL reference on two tensor ranks, make_golden.py
+    --ckpt-v1tp): a rank's Wqkv rows are "(three h/tp d)" of its heads and out_proj's bias lives on tensor rank 0 only.  Two tensor ranks load the reference's
+    files, write them straight back tensor for tensor (21 parameters on rank 0, 19 on rank 1), train the reference's next two steps (loss 1e-3, norm 2e-2, lr and
+    loss scale equal), and fresh engines resume from their own files bit-identically; a ONE-rank engine resumes from the same folder onto the same next loss."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+
+    gold = json.load(open(os.path.join(G, "ckpt_v1tp2_rank0.json")))
+    folder = str(tmp_path / "ck_v1tp2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_v1_tp_ckpt_worker, args=(r, 2, 29881, q, folder)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 2), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for rank, out, same in res:
+        assert same, f"rank {rank}: a fresh tensor-parallel engine does not resume bit-identically"
+        for (loss, gn, lr, scale), w in zip(out, gold["steps"][gold["saved_after_step"]:]):
+            print(f"tensor rank {rank}: resumed loss {loss:.5f} gn {gn:.4f} | reference {w['loss']:.5f} {w['grad_norm']['0_default']:.4f}")
+            assert abs(loss - w["loss"]) <= 1e-3 * w["loss"] and abs(gn - w["grad_norm"]["0_default"]) <= 2e-2 * gn and abs(lr - w["lr"]) <= 1e-12 and scale == w["loss_scale"]
+    ref = os.path.join(G, "ckpt_ref_v1tp2")
+    assert sorted(f for f in os.listdir(folder + "_echo") if not f.endswith(".step")) == gold["files"]
+    for t in (0, 1):
+        a, b = (torch.load(os.path.join(f, f"model_tp{t}_pp0.pt"), weights_only=False) for f in (ref, folder + "_echo"))
+        assert list(a) == list(b) and len(a) == (21, 19)[t] and all(torch.equal(a[k], b[k]) for k in a), t
+        oa, ob = (C._load(os.path.join(f, f"optimizer_tp{t}_pp0_zo0.pt")) for f in (ref, folder + "_echo"))
+        assert torch.equal(oa["flat_fp32_weights"][0].detach(), ob["flat_fp32_weights"][0]) and oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"]
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa["base_optim_states"]["state"][0][k], ob["base_optim_states"]["state"][0][k]), (t, k)
+    c = gold["config"]
+    one = InternLM2Engine(_v1_cfg(c), dev, seed=99)
+    one.load_checkpoint(os.path.join(G, "ckpt_ref_v1tp2"))
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    batch, labels = next(loader)
+    loss = float(one.forward_backward(batch, labels))
+    one.step()
+    w = gold["steps"][gold["saved_after_step"]]
+    print("one rank from the two-tensor-rank folder:", loss, float(one.read_state().grad_norm), "| reference", w["loss"], w["grad_norm"]["0_default"])
+    assert abs(loss - w["loss"]) <= 1e-3 * w["loss"]
