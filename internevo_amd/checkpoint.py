@@ -90,6 +90,35 @@ def global_to_stage(name, layer_lo):
     return stage_to_global(name, -layer_lo)
 
 
+def stage_chunks(sd):
+    """Number of model chunks in a stage's state dict: 0 = one model (keys "model.<name>"), c > 0 = the interleaved pipeline schedule's ModuleList of c chunks
+    (keys "<chunk>.model.<name>", every chunk numbering its layers from 0; modeling_internlm2.py:1012-1050, pinned by tests/golden/ckpt_pp2i_rank*.json)."""
+    import re
+
+    idx = [int(m.group(1)) for m in (re.match(r"(\d+)\.model\.", k) for k in sd) if m]
+    return max(idx) + 1 if idx else 0
+
+
+def stage_naming(model_cfg, pp_world, pp_rank, chunks=0, tp_rank=0, layer_counts=None):
+    """[(name inside the stage's files, key of its model state dict, the model's own name)] of one pipeline stage, in the stage's module order (= the order the
+    stage's ZeRO partition is computed in).  chunks = 0: one model per stage, its layers numbered from 0 (partition_uniform with one chunk).  chunks >= 1
+    (interleaved schedule): chunk c of stage p holds the layers partition_chunks(...)[p][c]; inside the files its names carry the prefix "<c>.".
+    layer_counts: the layers found in the files (per chunk), checked against the partition."""
+    from .pipeline import partition_chunks, partition_uniform
+
+    L = model_cfg.num_layers
+    if pp_world == 1 and not chunks:
+        return [(n, "model." + n, n) for n in state_dict_order(model_cfg, tp_rank)]
+    parts = partition_chunks(L, pp_world, chunks)[pp_rank] if chunks else [partition_uniform(L, pp_world)[pp_rank]]
+    if layer_counts is not None and [hi - lo for lo, hi in parts] != list(layer_counts):
+        raise ValueError(f"pipeline stage {pp_rank} of the checkpoint holds {list(layer_counts)} layers per chunk, this model's partition gives {[hi - lo for lo, hi in parts]}")
+    out = []
+    for c, (lo, hi) in enumerate(parts):
+        for n in stage_order(model_cfg, hi - lo, lo == 0, hi == L, tp_rank):
+            out.append((f"{c}.{n}", f"{c}.model.{n}", stage_to_global(n, lo)) if chunks else (n, "model." + n, stage_to_global(n, lo)))
+    return out
+
+
 def zero_flat_order(named_shapes):
     """ZeRO rank-0 order of a parameter group on one rank: stable sort by numel, descending (hybrid_zero_optim.py:254-284)."""
     def numel(shape):
@@ -220,7 +249,7 @@ def _load(path):
 
 
 def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16,
-                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0, pp_world=1, pp_rank=0, order=None):
+                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0, pp_world=1, pp_rank=0, order=None, chunked=False):
     """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
     hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr").
     zero_world > 1: one optimizer + plan file per rank in `zero_ranks` (default: all); the state dicts then only need the
@@ -228,11 +257,16 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
     from data-parallel rank 0 only) and `params` may then be None if `shapes` (name -> shape, module order) is given.
     tp_world > 1: the tensors are tensor-parallel rank `tp_rank`'s LOCAL parts (tp_shard); the files carry that rank in their names
     and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself.
-    pp_world > 1: ONE pipeline stage's files (`..._pp{pp_rank}...`); `order` = the stage's local names (stage_order) and every dict is keyed by them."""
+    pp_world > 1: ONE pipeline stage's files (`..._pp{pp_rank}...`); `order` = the stage's local names (stage_order / stage_naming) and every dict is keyed by
+    them; chunked: the stage holds the interleaved schedule's model chunks (names "<chunk>.<name>")."""
     os.makedirs(folder, exist_ok=True)
     order = state_dict_order(model_cfg, tp_rank) if order is None else list(order)
     if write_model:
-        sd = collections.OrderedDict(("model." + n, params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
+        import re
+
+        # (a stage of the interleaved schedule: `order` carries "<chunk>.<name>", the ModuleList's state dict "<chunk>.model.<name>")
+        key = (lambda n: re.sub(r"^(\d+)\.", r"\1.model.", n)) if chunked else (lambda n: "model." + n)  # noqa: E731
+        sd = collections.OrderedDict((key(n), params[n].detach().to("cpu", param_dtype).contiguous()) for n in order)
         torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp{pp_rank}.pt"))
         torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_pp{pp_rank}.json"))
     if shapes is None:
@@ -543,15 +577,18 @@ def _stage_layers(sd):
     return max(idx) + 1 if idx else 0
 
 
-def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, sd=None, model_only=False):
+def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, sd=None, model_only=False, naming=None):
     """One tensor rank's files (of one pipeline stage) -> its LOCAL named tensors (all its ZeRO shards merged).  want: the names (as this stage's files
-    carry them) whose optimizer tensors are kept; sd: the stage's model state dict if the caller has read it already."""
+    carry them) whose optimizer tensors are kept; sd: the stage's model state dict if the caller has read it already; naming: stage_naming(...) of the stage."""
     if sd is None:
         sd = torch.load(os.path.join(folder, f"model_tp{t}_pp{pp_rank}.pt"), map_location="cpu", weights_only=False)
-    order = state_dict_order(model_cfg, t) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1, t)
+    if naming is None:
+        order = state_dict_order(model_cfg, t) if pp_world == 1 else stage_order(model_cfg, _stage_layers(sd), pp_rank == 0, pp_rank == pp_world - 1, t)
+        naming = [(n, "model." + n, n) for n in order]
+    order = [n for n, _, _ in naming]
     params = {}
-    for n in order:
-        key = "model." + n if "model." + n in sd else n
+    for n, key, _ in naming:
+        key = key if key in sd else n
         if key not in sd:
             raise KeyError(f"checkpoint has no parameter {n!r} (keys: {list(sd)[:4]} ...)")
         params[n] = sd[key].detach()
@@ -622,22 +659,31 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
         # one set of files per pipeline stage (and per tensor rank of the stage), each numbering its layers from 0: the tensor ranks of a stage are merged
         # into full tensors, the stages into the whole model under its own names (so that ANY layout -- another pipeline or tensor size, or none -- can
         # resume from the folder)
-        out, lo = None, 0
+        out, seen = None, 0
         hd = model_cfg.head_dim
         same = ("adam_step", "lr", "scaler", "zero_world")
+        chunks = None
         for p_ in range(pp_world):
             sds = [torch.load(os.path.join(folder, f"model_tp{t}_pp{p_}.pt"), map_location="cpu", weights_only=False) for t in range(tp_world)]
-            n_layers = _stage_layers(sds[0])
+            ch = stage_chunks(sds[0])
+            if chunks is not None and ch != chunks:
+                raise ValueError(f"pipeline stage {p_} holds {ch} model chunks, stage 0 holds {chunks}")
+            chunks = ch
+            if ch:   # (the interleaved schedule: the layers of every chunk, from the "<c>.model.layers.<k>." keys)
+                counts = [_stage_layers({k[len(f"{c}."):]: 0 for k in sds[0] if k.startswith(f"{c}.model.")}) for c in range(ch)]
+            else:
+                counts = [_stage_layers(sds[0])]
+            namings = [stage_naming(model_cfg, pp_world, p_, ch, t, counts) for t in range(tp_world)]
+            glob = {n: g for n, _, g in namings[0]}   # (tensor rank 0 holds every name of the stage)
             # (the optimizer tensors a caller does not want -- another stage's, another ZeRO rank's -- are dropped while the flat vectors are cut, not after)
-            local_want = None if want is None else {n for n in stage_order(model_cfg, n_layers, p_ == 0, p_ == pp_world - 1) if stage_to_global(n, lo) in want}
-            ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, local_want, p_, pp_world, sd=sds[t], model_only=model_only) for t in range(tp_world)]
+            local_want = None if want is None else {n for n, g in glob.items() if g in want}
+            ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, local_want, p_, pp_world, sd=sds[t], model_only=model_only, naming=namings[t]) for t in range(tp_world)]
             st = ranks[0]
             for t, r in enumerate(ranks[1:], 1):
                 if {k: r[k] for k in same} != {k: st[k] for k in same}:
                     raise ValueError(f"tensor rank {t} of pipeline stage {p_} disagrees with rank 0 on the step / scaler / lr / ZeRO world")
-            whole = lambda key: None if st[key] is None else {n: (tp_unshard(n, [r[key][n] for r in ranks if n in r[key]], hd) if tp_world > 1 else st[key][n]) for n in st[key]}  # noqa: E731
-            ren = lambda d: None if d is None else {stage_to_global(n, lo): v for n, v in d.items()}  # noqa: E731
-            named = {k: ren(whole(k)) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+            whole = lambda key: None if st[key] is None else {glob[n]: (tp_unshard(glob[n], [r[key][n] for r in ranks if n in r[key]], hd) if tp_world > 1 else st[key][n]) for n in st[key]}  # noqa: E731
+            named = {k: whole(k) for k in ("params", "master", "exp_avg", "exp_avg_sq")}
             if out is None:
                 out = dict(st, **named)
             else:
@@ -646,10 +692,14 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
                 for k, d in named.items():
                     if d is not None:
                         out[k].update(d)
-            lo += n_layers
-        if lo != model_cfg.num_layers:
-            raise ValueError(f"the {pp_world} pipeline stages of the checkpoint hold {lo} layers, the model {model_cfg.num_layers}")
-        return dict(out, tp_world=tp_world, pp_world=pp_world)
+            seen += sum(counts)
+        if seen != model_cfg.num_layers:
+            raise ValueError(f"the {pp_world} pipeline stages of the checkpoint hold {seen} layers, the model {model_cfg.num_layers}")
+        order = state_dict_order(model_cfg)   # (the model's own order: with interleaved chunks the stages do not hold consecutive layers)
+        for k in ("params", "master", "exp_avg", "exp_avg_sq"):
+            if out[k] is not None:
+                out[k] = {n: out[k][n] for n in order if n in out[k]}
+        return dict(out, tp_world=tp_world, pp_world=pp_world, chunks=chunks or 1)
     ranks = [_load_tp_rank(folder, model_cfg, t, tp_world, want, model_only=model_only) for t in range(tp_world)]
     out = dict(ranks[0], tp_world=tp_world)
     if tp_world == 1:

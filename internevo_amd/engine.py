@@ -1575,8 +1575,6 @@ class InternLM2Engine:
             if self.job_world % wp or not (zs_cfg is None or zs_cfg <= 0 or zs_cfg >= self.job_world // wp):
                 raise NotImplementedError("checkpoints of the ISP layout with parallel.zero1.size below the weight-data size")
             return
-        if self.pp != 1 and self.nch != 1:
-            raise NotImplementedError("checkpoints under pipeline parallelism cover the non-interleaved schedule (with or without tensor parallelism)")
 
     def _local_reference_named(self, named):
         """engine-named tensors of this rank -> the reference's names AND the reference's tensor-parallel cut: the layer weights are
@@ -1671,10 +1669,13 @@ class InternLM2Engine:
         hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
         scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
         # this stage's parameters under the reference's names, module order; inside the files a stage numbers its layers from 0
-        lo_layer = self.gid[0] if pp > 1 else 0
-        glob = [n for n in C.state_dict_order(self.mc, t) if self._engine_name(n) in self.p]
-        loc = lambda n: C.global_to_stage(n, lo_layer)  # noqa: E731
-        stage = dict(pp_world=pp, pp_rank=ps, order=[loc(n) for n in glob]) if pp > 1 else {}
+        # (under the interleaved schedule a stage's files hold its model chunks, "<chunk>.<name>", every chunk numbering its layers from 0: checkpoint.stage_naming)
+        naming = C.stage_naming(self.mc, pp, ps, self.nch if self.nch > 1 else 0, t)
+        assert all(self._engine_name(g) in self.p for _, _, g in naming), "this stage's parameters are not the ones its files are named for"
+        glob = [g for _, _, g in naming]
+        to_local, to_global = {g: n for n, _, g in naming}, {n: g for n, _, g in naming}
+        loc = to_local.__getitem__
+        stage = dict(pp_world=pp, pp_rank=ps, order=[loc(n) for n in glob], chunked=self.nch > 1) if pp > 1 else {}
         cpu = lambda d: {loc(n): x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
         if W == 1:
             if self.dp_rank == 0:
@@ -1688,7 +1689,7 @@ class InternLM2Engine:
             shapes[n] = tuple(x // tp if (tp > 1 and i == d) else x for i, x in enumerate(shp))
         shapes = {loc(n): shapes[n] for n in glob}
         mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole; stage-local names)
-        need = {self._engine_name(C.stage_to_global(n, lo_layer)) for n in mine}
+        need = {self._engine_name(to_global[n]) for n in mine}
         state = {}
         for key, flat in (("master", self.master), ("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             named = {}
@@ -1700,7 +1701,7 @@ class InternLM2Engine:
                         named[n] = full[spec.offset - b.start : spec.offset - b.start + spec.numel].view(spec.shape).to("cpu", copy=True)
                 del full
             ref_named = self._local_reference_named(named)
-            state[key] = {n: ref_named[C.stage_to_global(n, lo_layer)] for n in mine}
+            state[key] = {n: ref_named[to_global[n]] for n in mine}
         if self.comm.replica == 0:   # hybrid ZeRO: every zero group holds the same shards, the first one writes them
             C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
                               scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t, **stage)

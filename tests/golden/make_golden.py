@@ -546,7 +546,7 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp=False):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp=False, chunks=1):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
@@ -604,6 +604,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             gl.gumbel_rsample = gumbel
     if pp > 1:
         kw = dict(kw, layers=4, micro_num=4, pp=pp)
+        if chunks > 1:   # `--ckpt-ppi`: the interleaved schedule, two model chunks per stage (stage 0: layers 0, 2; stage 1: layers 1, 3) -> ckpt_ref_pp2i/
+            kw = dict(kw, chunks=chunks)
     if isp:
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=2, sp=2, wp=2, seq_len=128)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
@@ -636,8 +638,10 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
 
             from internlm.solver.pipeline_utils import partition_uniform
 
-            (start, _end), = partition_uniform(kw["layers"], pp, 1)[gpc.get_local_rank(ParallelMode.PIPELINE)]
-            for name, p in model.model.named_parameters():
+            parts = partition_uniform(kw["layers"], pp, chunks)[gpc.get_local_rank(ParallelMode.PIPELINE)]
+            chunk_models = list(model) if isinstance(model, torch.nn.ModuleList) else [model]
+            assert len(chunk_models) == len(parts)
+            for name, p, start in [(n_, p_, st_) for cm, (st_, _e) in zip(chunk_models, parts) for n_, p_ in cm.model.named_parameters()]:
                 gname = re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name)
                 if tp > 1:
                     part = _mtp_part(gname, formula_init(gname, full_shapes[gname]), tp_rank, tp, kw)
@@ -684,7 +688,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -752,7 +756,9 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             rec["zero_devide_optim_plan"] = osd["zero_devide_optim_plan"]
             groups = optimizer._fp16_param_groups
             groups = groups.items() if isinstance(groups, dict) else enumerate(groups)
-            rec["param_group_order"] = {str(gid): [name for p in pg for name, q in model.model.named_parameters() if q is p] for gid, pg in groups}
+            named_all = [(f"{ci}." + name if isinstance(model, torch.nn.ModuleList) else name, q) for ci, cm in enumerate(list(model) if isinstance(model, torch.nn.ModuleList) else [model])
+                         for name, q in cm.model.named_parameters()]
+            rec["param_group_order"] = {str(gid): [name for p in pg for name, q in named_all if q is p] for gid, pg in groups}
     if world > 1:
         import torch.distributed as dist
 
@@ -782,7 +788,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     rec["files"] = sorted(os.listdir(folder))
     if pp > 1:
         rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.PIPELINE, ParallelMode.DATA, ParallelMode.ZERO1)}
-        with open(os.path.join(HERE, f"ckpt_pp{pp}tp{tp}_rank{rank}.json" if tp > 1 else f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
+        with open(os.path.join(HERE, f"ckpt_pp{pp}tp{tp}_rank{rank}.json" if tp > 1 else f"ckpt_pp{pp}i_rank{rank}.json" if chunks > 1 else f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
             json.dump(rec, f, indent=1, default=str)
         return
     with open(os.path.join(HERE, "ckpt_isp2v1.json" if isp else "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
@@ -1403,6 +1409,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pptp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pptp-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-ppi-rank":
+        gen_checkpoint(port=29785, rank=int(sys.argv[2]), world=2, pp=2, chunks=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-ppi":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-ppi-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pp-rank", str(r)]) for r in range(2)]

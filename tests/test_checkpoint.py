@@ -713,6 +713,55 @@ def test_pipeline_x_tensor_parallel_checkpoint_of_the_reference_merges_is_reprod
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
 
 
+def test_interleaved_pipeline_checkpoint_of_the_reference_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_pp2i/: the REAL reference under the INTERLEAVED pipeline schedule (parallel.pipeline size 2, model.num_chunks = 2; make_golden.py
+    --ckpt-ppi).  A stage's model is a ModuleList of chunks: its state dict carries "<chunk>.model.<name>", every chunk numbers its layers from 0, and stage p holds
+    the layers partition_chunks gives it (stage 0: model layers 0 and 2, stage 1: layers 1 and 3, with norm + head in ITS last chunk); one optimizer group per stage
+    over all its chunks.  The loader merges the stages into the whole model in the model's own order, the writer reproduces every stage's files tensor for tensor, and
+    the single-rank oracle resumed from the merge retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    ref = os.path.join(G, "ckpt_ref_pp2i")
+    g0, g1 = (json.load(open(os.path.join(G, f"ckpt_pp2i_rank{r}.json"))) for r in (0, 1))
+    c = g1["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+    mc = cfg.model
+    namings = [C.stage_naming(mc, 2, p_, 2) for p_ in (0, 1)]
+    assert [k for _, k, _ in namings[0]] == [k[0] for k in g0["model_keys"]] and [k for _, k, _ in namings[1]] == [k[0] for k in g1["model_keys"]]
+    assert [n for n, _, _ in namings[1]] == g1["param_group_order"]["0"]   # (the names the stage's optimizer group is flattened in)
+    assert [g for _, _, g in namings[0]][:2] == ["tok_embeddings.weight", "layers.0.attention.wqkv.weight"] and [g for _, _, g in namings[0]][8] == "layers.2.attention.wqkv.weight"
+    ck = C.load_checkpoint(ref, mc)
+    assert list(ck["params"]) == C.state_dict_order(mc) and ck["pp_world"] == 2 and ck["chunks"] == 2 and ck["adam_step"] == 2
+    assert all(torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]) for n in ck["params"])
+    some = {"layers.2.attention.wo.weight", "layers.1.ffn_norm.weight", "norm.weight"}
+    part = C.load_checkpoint(ref, mc, want=some)
+    assert set(part["master"]) == some and all(torch.equal(part[k][n], ck[k][n]) for k in ("master", "exp_avg", "exp_avg_sq") for n in some)
+    out = str(tmp_path / "ck")
+    for p_ in (0, 1):
+        order = [n for n, _, _ in namings[p_]]
+        cut = lambda d: {n: d[g] for n, _, g in namings[p_]}  # noqa: E731
+        C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"],
+                          dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3), pp_world=2, pp_rank=p_, order=order, chunked=True)
+    assert sorted(os.listdir(out)) == g1["files"]
+    ld = lambda folder, fn: torch.load(os.path.join(folder, fn), weights_only=False)  # noqa: E731
+    for p_ in (0, 1):
+        a, b = ld(ref, f"model_tp0_pp{p_}.pt"), ld(out, f"model_tp0_pp{p_}.pt")
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+        _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp0_pp{p_}_zo0.pt"), os.path.join(out, f"optimizer_tp0_pp{p_}_zo0.pt"))
+        assert C._load(os.path.join(ref, f"gpus-2_wp-0_tp-0_dp-0_pp-{p_}_zo-0.pt")) == C._load(os.path.join(out, f"gpus-2_wp-0_tp-0_dp-0_pp-{p_}_zo-0.pt"))
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, g1["num_samples"]))
+    for _ in range(g1["saved_after_step"]):
+        next(loader)
+    for w in g1["steps"][g1["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
+
+
 def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
     """tests/golden/ckpt_ref_moe/: the REAL reference's INTERNLM_MoE checkpoint (4 experts, top-2; make_golden.py --ckpt-moe) after two steps: the model
     file without the experts, one `model_moe_layer{l}_expert{e}_tp0.pt` per expert, and an optimizer file with THREE groups (default / fp32 = the gates /

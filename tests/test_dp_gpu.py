@@ -806,7 +806,7 @@ def test_forward_only_pass_under_pipeline_parallelism(dev, backend):
     assert abs(l0 - want) <= 1e-3 * want and abs(m0["acc"] - wm["acc"]) <= 5e-3 and abs(m0["perplexity"] - wm["perplexity"]) <= 1e-2 * wm["perplexity"]
 
 
-def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1):
+def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1, chunks=1):
     import json
 
     import torch.distributed as dist
@@ -818,13 +818,13 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1):
         from internevo_amd.engine import InternLM2Engine
 
         G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-        gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2_rank1.json")))
+        gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2i_rank1.json" if chunks > 1 else "ckpt_pp2_rank1.json")))
         c = gold["config"]
         cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
-        par = dict(pp_size=2, **({"tp_size": tp} if tp > 1 else {}))
+        par = dict(pp_size=2, **({"tp_size": tp} if tp > 1 else {}), **({"num_chunks": chunks} if chunks > 1 else {}))
         eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, **par)
-        eng.load_checkpoint(os.path.join(G, "ckpt_ref_pp2tp2" if tp > 1 else "ckpt_ref_pp2"))    # the reference's per-stage (and per-tensor-rank) files (merged, re-cut into this rank's part)
-        if tp > 1:
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_pp2tp2" if tp > 1 else "ckpt_ref_pp2i" if chunks > 1 else "ckpt_ref_pp2"))    # the reference's per-stage (and per-tensor-rank) files (merged, re-cut into this rank's part)
+        if tp > 1 or chunks > 1:
             eng.save_checkpoint(folder + "_echo")                # ... written straight back: the reference's files again
         loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         for _ in range(gold["saved_after_step"]):
@@ -853,13 +853,16 @@ def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dp,tp", [(1, 1), pytest.param(2, 1, marks=pytest.mark.ranks(4)), pytest.param(1, 2, marks=pytest.mark.ranks(4))], ids=["pp2", "pp2_dp2", "pp2_tp2"])
-def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, backend, tmp_path, dp, tp):
-    """Checkpoints under pipeline parallelism (non-interleaved): one model / optimizer / plan / topo file per STAGE with the stage's layers numbered
+@pytest.mark.parametrize("dp,tp,chunks", [(1, 1, 1), pytest.param(2, 1, 1, marks=pytest.mark.ranks(4)), pytest.param(1, 2, 1, marks=pytest.mark.ranks(4)), (1, 1, 2)],
+                         ids=["pp2", "pp2_dp2", "pp2_tp2", "pp2_interleaved"])
+def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, backend, tmp_path, dp, tp, chunks):
+    """Checkpoints under pipeline parallelism: one model / optimizer / plan / topo file per STAGE with the stage's layers numbered
     from 0, as the reference writes them (checkpoint/components.py:95-410, tests/golden/ckpt_ref_pp2/ from a real two-process run).  Two stages load the
     reference's files and their next two steps are the reference's (ckpt_pp2_rank1.json: loss on every stage -- this engine broadcasts it -- within 1e-3,
     global norm within 2e-2, same lr and loss scale); their own save_checkpoint writes the same file set, from which fresh engines resume
-    bit-identically and a ONE-rank engine (no pipeline) resumes to the same next loss.  dp = 2: two pipelines, ZeRO-1 shards per stage."""
+    bit-identically and a ONE-rank engine (no pipeline) resumes to the same next loss.  dp = 2: two pipelines, ZeRO-1 shards per stage.
+    pp2_tp2 (round 4): pipeline x tensor parallelism on four ranks against the reference's four-process checkpoint (ckpt_ref_pp2tp2/); pp2_interleaved (round 4):
+    the interleaved schedule with two model chunks per stage against ckpt_ref_pp2i/ -- both also written straight back, tensor for tensor the reference's files."""
     import json
 
     from internevo_amd.config import tiny
@@ -867,12 +870,12 @@ def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, back
     from internevo_amd.engine import InternLM2Engine
 
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2_rank1.json")))
+    gold = json.load(open(os.path.join(G, "ckpt_pp2tp2_rank2.json" if tp > 1 else "ckpt_pp2i_rank1.json" if chunks > 1 else "ckpt_pp2_rank1.json")))
     folder = str(tmp_path / "ck_pp2")
     world = 2 * dp * tp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_pp_ckpt_worker, args=(r, world, 29861 + dp + 4 * tp, q, folder, dp, tp)) for r in range(world)]
+    procs = [ctx.Process(target=_pp_ckpt_worker, args=(r, world, 29861 + dp + 4 * tp + 16 * chunks, q, folder, dp, tp, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, world), key=lambda x: x[0])
@@ -889,10 +892,11 @@ def test_pipeline_checkpoints_resume_from_the_reference_and_round_trip(dev, back
                   + [f"optimizer_tp{t}_pp{p}_zo{z}.pt" for p in (0, 1) for z in range(dp) for t in range(tp)]
                   + [f"gpus-{world}_wp-0_tp-{t}_dp-{z}_pp-{p}_zo-{z}.pt" for p in (0, 1) for z in range(dp) for t in range(tp)])
     assert sorted(os.listdir(folder)) == want
-    if tp > 1:   # pipeline x tensor parallelism (tests/golden/ckpt_ref_pp2tp2/, a real four-process run): what the four ranks wrote straight after loading IS the reference's file set
+    if tp > 1 or chunks > 1:   # pipeline x tensor parallelism (tests/golden/ckpt_ref_pp2tp2/, a real four-process run) and the interleaved schedule (ckpt_ref_pp2i/: a stage's
+        # files hold its two model chunks, "<chunk>.model.<name>"): what the ranks wrote straight after loading IS the reference's file set
         from internevo_amd import checkpoint as C
 
-        ref = os.path.join(G, "ckpt_ref_pp2tp2")
+        ref = os.path.join(G, "ckpt_ref_pp2tp2" if tp > 1 else "ckpt_ref_pp2i")
         assert sorted(os.listdir(folder + "_echo")) == gold["files"]
         for p in (0, 1):
             for t in range(tp):
