@@ -174,6 +174,15 @@ __device__ __forceinline__ s16x8 frag_kc(const unsigned char* tile, int rbase, i
     return *reinterpret_cast<const s16x8*>(tile + row * 128 + c * 16);
 }
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+// frag_kc as four dwords (the fp8 schedule: one 16-byte chunk = sixteen e4m3 values, half of a v_mfma_f32_32x32x64_f8f6f4 operand)
+__device__ __forceinline__ i32x4 frag_kc_q(const unsigned char* tile, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 31);
+    const int c = (ks * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const i32x4*>(tile + row * 128 + c * 16);
+}
+
 // the same image read for v_mfma_f32_16x16x32_bf16: rows rbase + (lane & 15), k = 32 * ks + 8 * (lane >> 4) .. + 7.  A 16-lane group reads one chunk
 // column of sixteen rows: eight swizzle values x the two 128-byte halves of a bank line -> all 64 banks once.
 __device__ __forceinline__ s16x8 frag_kc16(const unsigned char* tile, int rbase, int ks, int lane) {
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 
     constexpr bool RING = SPREAD == -21 || SPREAD == -22 || SPREAD == -23 || SPREAD == -24;
     const int nk = K / BK;
-    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -5 || SPREAD == -11;
+    constexpr bool USE_BUF = SPREAD == -2 || SPREAD == -3 || SPREAD == -4 || SPREAD == -5 || SPREAD == -6 || SPREAD == -11;
     std::conditional_t<USE_BUF, BufSrc<A_KM, BM, NW>, DmaSrc<A_KM, BM, NW>> sa;
     std::conditional_t<USE_BUF, BufSrc<B_KM, BN, NW, SPREAD == -5 && B_KM>, DmaSrc<B_KM, BN, NW>> sb;
     if constexpr (!RING) {
@@ -893,6 +902,98 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         for (; t < nk; ++t) tile(t, std::false_type{});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: no hazard bookkeeping by the compiler) before the epilogue reads them
         __syncthreads();
+    } else if constexpr (SPREAD == -6) {
+        // ---- fp8 (OCP e4m3) operands on v_mfma_f32_32x32x64_f8f6f4: the refill schedule of SPREAD -4 with the matrices handed over as "bf16 matrices of half the
+        // width" -- a 128-byte LDS row is 128 fp8 values of k, the DMA, the image, its swizzle and the counted waits are byte-for-byte those of the bf16 kernel, and a
+        // k-tile is K = 128.  One MFMA consumes 64 k: a lane's 32-byte operand is TWO 16-byte chunks of its row, (chunk g, chunk 2 + g) of the tile half for lane
+        // half g = lane >> 5 -- the same permutation of k on both operands, which is all the instruction needs.  32 MFMAs of 16 passes per k-tile (behind every
+        // second companion slot), i.e. the matrix time of the bf16 tile for twice the k: same LDS reads and DMA pieces per MFMA cycle, twice the flops.
+        // A chunk pair = the fragments (2s, 2s + 1) of SPREAD -4's k-steps, so its register timing carries over: the second half of a tile is read early in the
+        // tile, the next tile's first half once MFMAs 0..15 have issued.
+        static_assert(!A_KM && !B_KM && G::TM == 4 && G::TN == 4 && NA == 8 && NB == 8 && EPI == 0, "written for 4 waves x 128x128, both operands k-contiguous");
+        i32x4 fa[4][4], fb[4][4];   // (chunk (ks, lane half) of a row: ks = 2 s, 2 s + 1 form the operand of MFMA step s)
+        auto rdA = [&](const unsigned char* st, int ks, int i) { fa[ks][i] = frag_kc_q(st, wm * G::WM + i * 32, ks, lane); };
+        auto rdB = [&](const unsigned char* st, int ks, int j) { fb[ks][j] = frag_kc_q(st + G::A_BYTES, wn * G::WN + j * 32, ks, lane); };
+        auto pair = [](const i32x4& lo, const i32x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+        if (nk > 1) {   // tile 1 into the second stage, B first (the order the counted waits assume)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) sb.issue_keep(q, smem + G::STAGE_BYTES + G::A_BYTES, wave);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) sa.issue_keep(q, smem + G::STAGE_BYTES, wave);
+            sa.advance_all();
+            sb.advance_all();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rdA(smem, ks, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rdB(smem, ks, j);
+        }
+        auto tile = [&](int t, auto fast_) {
+            constexpr bool FAST = decltype(fast_)::value;     // tiles t+1 and t+2 exist
+            const bool more1 = FAST || t + 1 < nk, more2 = FAST || t + 2 < nk;
+            unsigned char* cur = smem + (t & 1) * G::STAGE_BYTES;
+            const unsigned char* nxt = smem + ((t + 1) & 1) * G::STAGE_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
+            auto companion = [&](int m) {   // the slot's LDS read / DMA piece / wait + barrier (the table of SPREAD -4)
+                    if (m < 8) {
+                        rdB(cur, 2 + (m >> 2), m & 3);                                   // B, second half of the tile
+                    } else if (m == 8) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                    // 1: every wave holds all of B(t)
+                    } else if (m < 14) {
+                        if (more2) sb.issue_keep(m - 9, cur + G::A_BYTES, wave);         // B(t+2) pieces 0..4
+                    } else if (m < 22) {
+                        rdA(cur, 2 + ((m - 14) >> 2), (m - 14) & 3);                     // A, second half
+                    } else if (m == 22) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                                    // 2: every wave holds all of A(t)
+                    } else if (m < 26) {
+                        if (more2) sb.issue_keep(5 + m - 23, cur + G::A_BYTES, wave);    // B(t+2) pieces 5..7
+                    } else if (m < 28) {
+                        if (more2) sa.issue_keep(m - 26, cur, wave);                     // A(t+2) pieces 0..1
+                    } else if (m == 28) {
+                        if (more1) {
+                            if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // B(t+1) landed (this wave's pieces)
+                            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();                                // 3: B(t+1) complete
+                        }
+                    } else if (m < 37) {
+                        if (more1) rdB(nxt, (m - 29) >> 2, (m - 29) & 3);                // B(t+1), first half (chunk pair j is free since the MFMA behind slot 24 + 2j)
+                    } else if (m < 42) {
+                        if (more2) sa.issue_keep(2 + m - 37, cur, wave);                 // A(t+2) pieces 2..6
+                    } else if (m == 42) {
+                        if (more1) {
+                            if (FAST || t + 2 < nk) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // A(t+1) landed
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();                                // 4: A(t+1) complete
+                        }
+                    } else if (m < 51) {
+                        if (more1) rdA(nxt, (m - 43) >> 2, (m - 43) & 3);                // A(t+1), first half
+                    } else if (m == 51) {
+                        if (more2) sa.issue_keep(7, cur, wave);                          // A(t+2) piece 7
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {   // MFMA q (tile half q >> 4, A block (q >> 2) & 3, B block q & 3), then the companion slots 2q and 2q + 1
+                const int sx = q >> 4, i = (q >> 2) & 3, j = q & 3;
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pair(fb[2 * sx][j], fb[2 * sx + 1][j]), pair(fa[2 * sx][i], fa[2 * sx + 1][i]), acc[i][j],
+                                                                            0, 0, 0, 0, 0, 0);  // D[n][m]; e4m3 x e4m3, no block scales
+                __builtin_amdgcn_sched_barrier(0);
+                companion(2 * q);
+                companion(2 * q + 1);
+            }
+            if (more2) {
+                sa.advance_all();
+                sb.advance_all();
+            }
+        };
+        int t = 0;
+        for (; t + 2 < nk; ++t) tile(t, std::true_type{});
+        for (; t < nk; ++t) tile(t, std::false_type{});
+        __syncthreads();
     } else if constexpr (SPREAD == -2 || SPREAD == -3) {
         // ---- one wave per SIMD (4 waves, 128x128 per wave: 0.5 LDS reads per MFMA), software-pipelined ACROSS k-tiles.
         // The single barrier of a k-tile sits between k-step 2 and k-step 3: by then every wave has requested all four
@@ -1068,11 +1169,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         }
         return;
     }
+    float deq = 1.f;   // fp8 operands: the product of the two per-tensor dequantisation scales (device scalars: no host read between quantisation and product)
+    if constexpr (SPREAD == -6) deq = *reinterpret_cast<const float*>(bt.aux) * *reinterpret_cast<const float*>(bt.act);
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int m = wm * G::WM + i * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) {
+            if constexpr (SPREAD == -6) acc[i][j] *= deq;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = wn * G::WN + j * 32 + 8 * g + 4 * (lane >> 5);
@@ -1224,6 +1328,17 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
     return ie_launch_status("ie_gemm_bf16 (dma) launch");
+}
+
+// C[M, N] (bf16) = (A[M, K] e4m3) (B[N, K] e4m3)^T * scale_a * scale_b on v_mfma_f32_32x32x64_f8f6f4 (schedule -6).  Called from fp8.hip, which has validated the
+// arguments: K % 128 == 0, lda / ldb even multiples of 16 bytes, operands below 4 GiB, M, N >= 8.  The matrices are handed to the kernel as bf16 matrices of half the width.
+extern "C" int ie_gemm_fp8_dma_launch(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                      const float* scale_a, const float* scale_b, int accumulate, void* stream) {
+    IeGemmBatch bt{1, 0, 0, 0, 0, scale_a, 0, (void*)scale_b, 0};
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -6>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda / 2,
+                       (const bf16_t*)B, ldb / 2, (bf16_t*)C, ldc, (int)M, (int)N, (int)(K / 2), (accumulate ? 1 : 0) | (g_gemm_group << 8), tiles_m, tiles_n, bt);
+    return ie_launch_status("ie_gemm_fp8 launch");
 }
 
 // The two FFN products with the SwiGLU arithmetic in their epilogues (refill schedule, 256x256 tiles; the caller has checked K % 64 == 0,

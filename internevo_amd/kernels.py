@@ -415,6 +415,37 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False, varia
     return out
 
 
+def fp8_quantize(x):
+    """A contiguous bf16 tensor -> (q: uint8 tensor of the same shape holding OCP e4m3 bits, dequant: fp32 [1] on the device) with per-tensor dynamic scaling:
+    q = e4m3(x * 448 / max|x|), dequant = max|x| / 448 -- two launches (ie_fp8_amax, ie_fp8_quantize), the scale never leaves the device."""
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise ValueError("fp8_quantize: a contiguous bf16 tensor expected")
+    n = x.numel()
+    amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+    dequant = torch.empty(1, dtype=torch.float32, device=x.device)
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_L().ie_fp8_amax(_p(x), n, _p(amax), _stream()), "ie_fp8_amax")
+    check(_L().ie_fp8_quantize(_p(x), n, _p(amax), _p(q), _p(dequant), _stream()), "ie_fp8_quantize")
+    return q, dequant
+
+
+def gemm_fp8(Aq, a_dequant, Bq, b_dequant, out=None, accumulate=False):
+    """C[M, N] bf16 = (Aq[M, K] e4m3)(Bq[N, K] e4m3)^T * a_dequant * b_dequant (fp32 accumulation; ie_gemm_fp8).  K % 128 == 0."""
+    if Aq.dtype != torch.uint8 or Bq.dtype != torch.uint8 or Aq.dim() != 2 or Bq.dim() != 2 or Aq.stride(1) != 1 or Bq.stride(1) != 1:
+        raise ValueError("gemm_fp8: 2-D uint8 (e4m3) operands with unit column stride expected")
+    (M, K), (N, Kb) = Aq.shape, Bq.shape
+    if K != Kb:
+        raise ValueError(f"gemm_fp8: contraction mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=Aq.device)
+        accumulate = False
+    if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+        raise ValueError("gemm_fp8: bad output")
+    check(_L().ie_gemm_fp8(_p(Aq), Aq.stride(0), _p(Bq), Bq.stride(0), _p(out), out.stride(0), M, N, K, _p(a_dequant), _p(b_dequant), int(accumulate), _stream()),
+          "ie_gemm_fp8")
+    return out
+
+
 class KernelProfiler:
     """Times every launch of one kernel class with HIP events recorded on the launch stream (torch's
     current stream) and sums algorithmic flops / bytes.  Used by bench.py for the `roofline` object."""
