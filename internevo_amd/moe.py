@@ -33,9 +33,17 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity, top_k=2):
 
 class MoELayer:
     def __init__(self, hidden, ffn, num_experts, tokens, device, capacity_factor=1.0, min_capacity=4, seed=0, layer_index=0, ep_group=None,
-                 ep_size=1, ep_rank=0):
+                 ep_size=1, ep_rank=0, expert_fp8=False):
         """tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
-        backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F]."""
+        backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F].
+        expert_fp8 (opt-in; the reference has no fp8 linear): the two FORWARD products of every expert run on e4m3 operands
+        (ie_gemm_fp8: per-tensor dynamic scales per expert block and per expert weight, fp32 accumulation, bf16 results); the backward keeps the bf16 weights and
+        the saved bf16 activations (straight-through).  Needs hidden % 128 == 0 and ffn % 128 == 0.  An expert's quantised weights are kept until
+        invalidate_fp8() (the engine calls it after every optimizer step)."""
+        if expert_fp8 and (hidden % 128 or ffn % 128):
+            raise ValueError(f"expert_fp8: hidden ({hidden}) and ffn ({ffn}) must be multiples of 128 (one LDS row of e4m3 values)")
+        self.fp8 = bool(expert_fp8)
+        self._wq = {}
         if not 2 <= num_experts <= 16:
             raise NotImplementedError("2 <= num_experts <= 16")
         if num_experts % ep_size:
@@ -107,15 +115,32 @@ class MoELayer:
         El, ep = self.El, self.ep
         for g in range(ep):
             rows = slice(g * El * C, (g + 1) * El * C)
-            K.gemm_batched(ein[rows].view(El, C, M), w13, self.h13[rows].view(El, C, 2 * F))
+            self._products(ein[rows].view(El, C, M), w13, self.h13[rows].view(El, C, 2 * F), "w13")
         K.swiglu_fwd(self.h13[:, :F], self.h13[:, F:], self.act)
         for g in range(ep):
             rows = slice(g * El * C, (g + 1) * El * C)
-            K.gemm_batched(self.act[rows].view(El, C, F), w2, eo[rows].view(El, C, M))
+            self._products(self.act[rows].view(El, C, F), w2, eo[rows].view(El, C, M), "w2")
         if self.ep > 1:
             self._a2a(self.xout, self.eo)
         check(L.ie_moe_combine_fwd(K._p(self.eo), K._p(self.row), K._p(self.weight), S, M, K._p(out), out.stride(0), st()), "ie_moe_combine_fwd")
         return self.l_aux
+
+    def _products(self, a, w, out, which):
+        """out[j] = a[j] @ w[j]^T for the local experts j: one strided-batched bf16 launch, or (expert_fp8) per expert the e4m3 product of the block quantised
+        now and the weight quantised since the last invalidate_fp8()."""
+        if not self.fp8:
+            K.gemm_batched(a, w, out)
+            return
+        for j in range(a.shape[0]):
+            key = (which, j, w.data_ptr())
+            if key not in self._wq:
+                self._wq[key] = K.fp8_quantize(w[j])
+            qa, da = K.fp8_quantize(a[j])
+            K.gemm_fp8(qa, da, *self._wq[key], out=out[j])
+
+    def invalidate_fp8(self):
+        """The expert weights have changed (optimizer step, checkpoint load): quantise them again at the next forward."""
+        self._wq = {}
 
     def backward(self, dout, wg, w13, w2, dx, d_wg, d_w13, d_w2, accumulate, loss_scale_dev=None, aux_factor=0.0):
         """dout bf16 [S, M] -> dx bf16 [S, M] (overwritten).  d_wg fp32 [E, M], d_w13 / d_w2 bf16 like the weights: written, or added to
