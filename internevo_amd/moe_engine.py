@@ -57,6 +57,8 @@ class MoEEngine:
         # dense: the InternLM-1 model proper (modeling_internlm.py; INTERNLM_MoE with num_experts = 1 builds the same block, modeling_moe.py:120-140):
         # a plain SwiGLU FeedForward in place of the MoE -- no gate, no auxiliary loss, one optimizer group
         self.dense = mc.model_type == "INTERNLM" or mc.num_experts < 2
+        # expert_fp8 (opt-in; constructor argument or IE_EXPERT_FP8=1): the experts' two FORWARD products on e4m3 operands (moe.MoELayer)
+        self.expert_fp8 = (bool(int(os.environ.get("IE_EXPERT_FP8", "0"))) if expert_fp8 is None else bool(expert_fp8)) and not self.dense
         if mc.num_kv_attention_heads != mc.num_attention_heads:
             raise NotImplementedError("the InternLM-1 block has no grouped-query attention")
         K._L()
@@ -168,8 +170,6 @@ class MoEEngine:
             self.a_h13 = [e(T, 2 * F) for _ in range(L)]
             self.t_act, self.t_dact, self.t_dh13 = e(T, F), e(T, F), e(T, 2 * F)
         else:
-            # expert_fp8 (opt-in; constructor argument or IE_EXPERT_FP8=1): the experts' two FORWARD products on e4m3 operands (moe.MoELayer)
-            self.expert_fp8 = bool(int(os.environ.get("IE_EXPERT_FP8", "0"))) if expert_fp8 is None else bool(expert_fp8)
             self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * rank, layer_index=l, ep_group=self.ep_group,
                                  ep_size=self.ep, ep_rank=self.ep_rank, expert_fp8=self.expert_fp8) for l in range(L)]   # (every rank gates its own tokens with its own noise)
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
@@ -218,7 +218,7 @@ class MoEEngine:
         buffer of the same layout and the [L, E, h] fp32 tensor to fill instead of the bf16 parameters and the gate weights (checkpoints: master
         weights, moments)."""
         self._wait_optimizer()
-        for lay in self.moe or ():
+        for lay in getattr(self, "moe", None) or ():   # (the constructor initialises the weights before the layers exist)
             lay.invalidate_fp8()
         F = self.F
         P = self.p if views is None else views
