@@ -267,14 +267,19 @@ int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_
                  void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream);
 /* The same forward product on fp8 operands (OCP e4m3; csrc/fp8.hip, schedule -6 of csrc/gemm_bf16_dma.hip on v_mfma_f32_32x32x64_f8f6f4).  The reference has
  * no fp8 linear: per-tensor dynamic scaling, tolerance defined by tests/test_fp8_gpu.py.
- *   ie_fp8_amax:     *amax = max(*amax, max |x|) over n bf16 values (the caller zeroes *amax; device scalar).
- *   ie_fp8_quantize: q[i] = e4m3(x[i] * 448 / *amax), round-to-nearest-even, saturating; *dequant = *amax / 448 (1 when *amax == 0).
+ *   ie_fp8_amax:     amax[z] = max(amax[z], max |x_z|) over the n bf16 values of tensor z of `count` tensors laid out back to back (the caller zeroes amax;
+ *                    device scalars; count > 1 needs n % 8 == 0).
+ *   ie_fp8_quantize: q_z[i] = e4m3(x_z[i] * 448 / amax[z]), round-to-nearest-even, saturating; dequant[z] = amax[z] / 448 (1 when amax[z] == 0).
  *   ie_gemm_fp8:     C[M,N] bf16 = (A[M,K] e4m3)(B[N,K] e4m3)^T * *dequant_a * *dequant_b, fp32 accumulation (+ C if accumulate);
- *                    K % 128 == 0, lda / ldb (elements = bytes) multiples of 16, operands < 4 GiB: IE_ERR_UNSUPPORTED otherwise. */
-int ie_fp8_amax(const void* x, int64_t n, float* amax, void* stream);
-int ie_fp8_quantize(const void* x, int64_t n, const float* amax, void* q, float* dequant, void* stream);
+ *                    K % 128 == 0, lda / ldb (elements = bytes) multiples of 16, operands < 4 GiB: IE_ERR_UNSUPPORTED otherwise.
+ *   ie_gemm_fp8_batched: `count` such products in ONE launch (the experts of a MoE layer), product z at A + z stride_a, B + z stride_b, C + z stride_c
+ *                    (elements) with the scales dequant_a[z], dequant_b[z]. */
+int ie_fp8_amax(const void* x, int64_t n, int64_t count, float* amax, void* stream);
+int ie_fp8_quantize(const void* x, int64_t n, int64_t count, const float* amax, void* q, float* dequant, void* stream);
 int ie_gemm_fp8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                 const float* dequant_a, const float* dequant_b, int accumulate, void* stream);
+int ie_gemm_fp8_batched(const void* A, int64_t lda, int64_t stride_a, const void* B, int64_t ldb, int64_t stride_b, void* C, int64_t ldc, int64_t stride_c,
+                        int64_t count, int64_t M, int64_t N, int64_t K, const float* dequant_a, const float* dequant_b, int accumulate, void* stream);
 /* Same product with an explicit block-tile shape (tuning / A-B benchmarking; ie_gemm_bf16 picks one itself):
  * variant 0 = 128x128 (4 waves), 1 = 256x256 (8 waves), 2 = 256x128, 3 = 128x256 (register-staged);
  * 4 = 256x256 LDS-DMA, 5 = 128x128 LDS-DMA, 6 / 7 = 256x256 LDS-DMA with the DMA issue spread over 2 / 4 k-steps,

@@ -94,9 +94,10 @@ SIGNATURES = {
     "ie_cast": (I, [P, I, P, I, I64, P]),
     "ie_gemm_bf16": (I, [P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),
     "ie_gemm_bf16_tile": (I, [I, P, I64, I, P, I64, I, P, I64, I64, I64, I64, I, P]),
-    "ie_fp8_amax": (I, [P, I64, P, P]),
-    "ie_fp8_quantize": (I, [P, I64, P, P, P, P]),
+    "ie_fp8_amax": (I, [P, I64, I64, P, P]),
+    "ie_fp8_quantize": (I, [P, I64, I64, P, P, P, P]),
     "ie_gemm_fp8": (I, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I, P]),
+    "ie_gemm_fp8_batched": (I, [P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, I64, I64, P, P, I, P]),
     "ie_gemm_bf16_batched": (I, [P, I64, I64, I, P, I64, I64, I, P, I64, I64, I64, I64, I64, I, I, P]),
     "ie_colsum_bf16": (I, [P, I64, P, I64, I64, P]),
     "ie_flash_attn_fwd": (I, [P, I64, P, P, I64, P, I64, P, P, I, I64, I, I, I, I, F, I, P]),

@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
         return;
     }
     float deq = 1.f;   // fp8 operands: the product of the two per-tensor dequantisation scales (device scalars: no host read between quantisation and product)
-    if constexpr (SPREAD == -6) deq = *reinterpret_cast<const float*>(bt.aux) * *reinterpret_cast<const float*>(bt.act);
+    if constexpr (SPREAD == -6) deq = reinterpret_cast<const float*>(bt.aux)[bz] * reinterpret_cast<const float*>(bt.act)[bz];
 #pragma unroll
     for (int i = 0; i < G::TM; ++i) {
         const int m = wm * G::WM + i * 32 + (lane & 31);
@@ -1332,12 +1332,12 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
 
 // C[M, N] (bf16) = (A[M, K] e4m3) (B[N, K] e4m3)^T * scale_a * scale_b on v_mfma_f32_32x32x64_f8f6f4 (schedule -6).  Called from fp8.hip, which has validated the
 // arguments: K % 128 == 0, lda / ldb even multiples of 16 bytes, operands below 4 GiB, M, N >= 8.  The matrices are handed to the kernel as bf16 matrices of half the width.
-extern "C" int ie_gemm_fp8_dma_launch(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                      const float* scale_a, const float* scale_b, int accumulate, void* stream) {
-    IeGemmBatch bt{1, 0, 0, 0, 0, scale_a, 0, (void*)scale_b, 0};
+extern "C" int ie_gemm_fp8_dma_launch(const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb, void* C, int64_t ldc, int64_t sc, int64_t count,
+                                      int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b, int accumulate, void* stream) {
+    IeGemmBatch bt{(int)count, sa / 2, sb / 2, sc, 0, scale_a, 0, (void*)scale_b, 0};   // (a strided batch: product z reads scale_a[z], scale_b[z])
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -6>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda / 2,
-                       (const bf16_t*)B, ldb / 2, (bf16_t*)C, ldc, (int)M, (int)N, (int)(K / 2), (accumulate ? 1 : 0) | (g_gemm_group << 8), tiles_m, tiles_n, bt);
+    hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -6>), dim3((unsigned)(tiles_m * tiles_n * count)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
+                       lda / 2, (const bf16_t*)B, ldb / 2, (bf16_t*)C, ldc, (int)M, (int)N, (int)(K / 2), (accumulate ? 1 : 0) | (g_gemm_group << 8), tiles_m, tiles_n, bt);
     return ie_launch_status("ie_gemm_fp8 launch");
 }
 

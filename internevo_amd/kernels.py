@@ -415,17 +415,23 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, out=None, accumulate=False, varia
     return out
 
 
-def fp8_quantize(x):
-    """A contiguous bf16 tensor -> (q: uint8 tensor of the same shape holding OCP e4m3 bits, dequant: fp32 [1] on the device) with per-tensor dynamic scaling:
-    q = e4m3(x * 448 / max|x|), dequant = max|x| / 448 -- two launches (ie_fp8_amax, ie_fp8_quantize), the scale never leaves the device."""
+def fp8_quantize(x, per_slice=False, out=None):
+    """A contiguous bf16 tensor -> (q: uint8 tensor of the same shape holding OCP e4m3 bits, dequant: fp32 [count] on the device) with per-tensor dynamic scaling:
+    q = e4m3(x * 448 / max|x|), dequant = max|x| / 448 -- two launches (ie_fp8_amax, ie_fp8_quantize), the scale never leaves the device.
+    per_slice: x[z] for z in range(x.shape[0]) are `count` tensors with a scale each (the experts' blocks / weights).  out = (q, amax, dequant): buffers to use."""
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         raise ValueError("fp8_quantize: a contiguous bf16 tensor expected")
-    n = x.numel()
-    amax = torch.zeros(1, dtype=torch.float32, device=x.device)
-    dequant = torch.empty(1, dtype=torch.float32, device=x.device)
-    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    check(_L().ie_fp8_amax(_p(x), n, _p(amax), _stream()), "ie_fp8_amax")
-    check(_L().ie_fp8_quantize(_p(x), n, _p(amax), _p(q), _p(dequant), _stream()), "ie_fp8_quantize")
+    count = x.shape[0] if per_slice else 1
+    n = x.numel() // max(count, 1)
+    if out is None:
+        q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        amax = torch.zeros(count, dtype=torch.float32, device=x.device)
+        dequant = torch.empty(count, dtype=torch.float32, device=x.device)
+    else:
+        q, amax, dequant = out
+        amax.zero_()
+    check(_L().ie_fp8_amax(_p(x), n, count, _p(amax), _stream()), "ie_fp8_amax")
+    check(_L().ie_fp8_quantize(_p(x), n, count, _p(amax), _p(q), _p(dequant), _stream()), "ie_fp8_quantize")
     return q, dequant
 
 
@@ -443,6 +449,19 @@ def gemm_fp8(Aq, a_dequant, Bq, b_dequant, out=None, accumulate=False):
         raise ValueError("gemm_fp8: bad output")
     check(_L().ie_gemm_fp8(_p(Aq), Aq.stride(0), _p(Bq), Bq.stride(0), _p(out), out.stride(0), M, N, K, _p(a_dequant), _p(b_dequant), int(accumulate), _stream()),
           "ie_gemm_fp8")
+    return out
+
+
+def gemm_fp8_batched(Aq, a_dequant, Bq, b_dequant, out, accumulate=False):
+    """out[z] = (Aq[z] e4m3)(Bq[z] e4m3)^T * a_dequant[z] * b_dequant[z] for the Z products of a strided batch in ONE launch (ie_gemm_fp8_batched):
+    Aq [Z, M, K], Bq [Z, N, K] uint8, out [Z, M, N] bf16, the scales fp32 [Z]."""
+    if Aq.dim() != 3 or Bq.dim() != 3 or out.dim() != 3 or Aq.dtype != torch.uint8 or Bq.dtype != torch.uint8 or out.dtype != torch.bfloat16:
+        raise ValueError("gemm_fp8_batched: Aq [Z, M, K], Bq [Z, N, K] uint8 and out [Z, M, N] bf16 expected")
+    (Z, M, K), (Zb, N, Kb) = Aq.shape, Bq.shape
+    if Z != Zb or K != Kb or out.shape != (Z, M, N) or Aq.stride(2) != 1 or Bq.stride(2) != 1 or out.stride(2) != 1 or a_dequant.numel() < Z or b_dequant.numel() < Z:
+        raise ValueError("gemm_fp8_batched: shapes / strides do not match")
+    check(_L().ie_gemm_fp8_batched(_p(Aq), Aq.stride(1), Aq.stride(0), _p(Bq), Bq.stride(1), Bq.stride(0), _p(out), out.stride(1), out.stride(0), Z, M, N, K,
+                                   _p(a_dequant), _p(b_dequant), int(accumulate), _stream()), "ie_gemm_fp8_batched")
     return out
 
 

@@ -43,7 +43,7 @@ class MoELayer:
         if expert_fp8 and (hidden % 128 or ffn % 128):
             raise ValueError(f"expert_fp8: hidden ({hidden}) and ffn ({ffn}) must be multiples of 128 (one LDS row of e4m3 values)")
         self.fp8 = bool(expert_fp8)
-        self._wq = {}
+        self._wq, self._qa = {}, {}   # quantised weights (until invalidate_fp8) / the quantised-activation buffers
         if not 2 <= num_experts <= 16:
             raise NotImplementedError("2 <= num_experts <= 16")
         if num_experts % ep_size:
@@ -126,17 +126,21 @@ class MoELayer:
         return self.l_aux
 
     def _products(self, a, w, out, which):
-        """out[j] = a[j] @ w[j]^T for the local experts j: one strided-batched bf16 launch, or (expert_fp8) per expert the e4m3 product of the block quantised
-        now and the weight quantised since the last invalidate_fp8()."""
+        """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch: bf16, or (expert_fp8) the e4m3 products of the blocks quantised now (a scale
+        per expert block) and the weights quantised since the last invalidate_fp8() (a scale per expert)."""
         if not self.fp8:
             K.gemm_batched(a, w, out)
             return
-        for j in range(a.shape[0]):
-            key = (which, j, w.data_ptr())
-            if key not in self._wq:
-                self._wq[key] = K.fp8_quantize(w[j])
-            qa, da = K.fp8_quantize(a[j])
-            K.gemm_fp8(qa, da, *self._wq[key], out=out[j])
+        El, C, Kd = a.shape
+        key = (which, w.data_ptr())
+        if key not in self._wq:
+            self._wq[key] = K.fp8_quantize(w, per_slice=True)
+        buf = self._qa.get(which)
+        if buf is None or buf[0].shape != a.shape:
+            f32 = dict(dtype=torch.float32, device=a.device)
+            buf = self._qa[which] = (torch.empty(a.shape, dtype=torch.uint8, device=a.device), torch.empty(El, **f32), torch.empty(El, **f32))
+        qa, da = K.fp8_quantize(a, per_slice=True, out=buf)
+        K.gemm_fp8_batched(qa, da, *self._wq[key], out)
 
     def invalidate_fp8(self):
         """The expert weights have changed (optimizer step, checkpoint load): quantise them again at the next forward."""
