@@ -335,7 +335,10 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, 
         if (d256 <= d128) {
             if (!any_kmajor) return 20;   // round 4: the same schedule on v_mfma_f32_16x16x32_bf16, +4 ... +5 % on every 7B forward shape (profiles/r04_gemm_mfma16_ab.md)
             if (a_kmajor && b_kmajor) return 17;
-            return (!a_kmajor && (K >= 6144 || N >= 8192)) ? 20 : 15;   // (20 on a k-major B: +1 ... +2 % over 19, profiles/r04_gemm_mfma16_ab.md)
+#ifndef IE_DGRAD_REFILL   // (A/B builds: -DIE_DGRAD_REFILL=19 keeps the long input-gradient products on the 32x32x16 refill schedule)
+#define IE_DGRAD_REFILL 20
+#endif
+            return (!a_kmajor && (K >= 6144 || N >= 8192)) ? IE_DGRAD_REFILL : 15;   // (20 on a k-major B: +1 ... +2 % over 19, profiles/r04_gemm_mfma16_ab.md)
         }
         return any_kmajor ? 5 : 8;    // 128x128: spreading helps the k-contiguous product only
     }
@@ -459,7 +462,7 @@ extern "C" int ie_tune_ffn_fuse(int mode) {
 // 1 when the shape takes the one-launch path (contiguous, 16-byte aligned operands assumed), 0 when it takes two launches
 extern "C" int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K) {
     if (!(g_ffn_fuse & (bwd ? 2 : 1)) || K <= 0 || K % 64 != 0 || M < 8 || F < 8) return 0;
-    if (bwd) return pick_variant(M, F, K, false, true) == 20 && !(g_tail_split && tail_split(M, F).on);
+    if (bwd) return pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on);
     return F % 128 == 0 && pick_variant(M, 2 * F, K, false, false) == 20 && !(g_tail_split && tail_split(M, 2 * F).on);
 }
 
@@ -489,7 +492,7 @@ extern "C" int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, i
     if (M == 0 || F == 0) return IE_OK;
     const bool fits32 = M * ldy * 2 < (1ll << 32) && K * ldw * 2 < (1ll << 32);
     const bool fuse = (g_ffn_fuse & 2) && K > 0 && K % 64 == 0 && M >= 8 && F >= 8 && fits32 && aligned16(dy) && aligned16(w2) && ldy % 8 == 0 && ldw % 8 == 0 &&
-                      pick_variant(M, F, K, false, true) == 20 && !(g_tail_split && tail_split(M, F).on);
+                      pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on);
     if (fuse) return ie_gemm_swiglu_dma_launch(1, dy, ldy, w2, ldw, dh13, ldd, h13, ldh, nullptr, 0, M, F, K, stream);
     const int rc = gemm_dispatch(-1, dy, ldy, 0, w2, ldw, 1, dact_scratch, ld_scratch, M, F, K, 0, stream);
     if (rc != IE_OK) return rc;
