@@ -115,6 +115,7 @@ class TrainConfig:
     micro_num: int = 4
     total_steps: int = 20
     fixed_random_dataset_seqlen: bool = False
+    skip_batches: str = ""   # data.skip_batches, e.g. "1-3,5": batches drawn from the loader but not trained on (train.py:187,208-212; data.BatchSkipper)
     # adam (configs/7B_internlm2.py:92-99)
     lr: float = 1e-4
     adam_beta1: float = 0.9
@@ -258,8 +259,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         raise NotImplementedError(f"{_UNSUPPORTED}: model.multiple_of != 256")
     if not d.get("use_packed_dataset", True):
         raise NotImplementedError(f"{_UNSUPPORTED}: data.use_packed_dataset=False (the loaders build PackedDatasetWithCut batches only)")
-    if d.get("rampup_batch_size", "") or d.get("skip_batches", ""):
-        raise NotImplementedError(f"{_UNSUPPORTED}: data.rampup_batch_size / data.skip_batches")
+    if d.get("rampup_batch_size", ""):
+        raise NotImplementedError(f"{_UNSUPPORTED}: data.rampup_batch_size")
     zero1 = par.get("zero1", {})
     if isinstance(zero1, dict) and zero1.get("fsdp", False):
         raise NotImplementedError(f"{_UNSUPPORTED}: parallel.zero1.fsdp")
@@ -278,7 +279,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     hz = cfg["hybrid_zero_optimizer"]
     train = TrainConfig(
         seq_len=seq_len or d["seq_len"], micro_bsz=d["micro_bsz"], micro_num=d["micro_num"], total_steps=d["total_steps"],
-        fixed_random_dataset_seqlen=d.get("fixed_random_dataset_seqlen", False),
+        fixed_random_dataset_seqlen=d.get("fixed_random_dataset_seqlen", False), skip_batches=str(d.get("skip_batches", "") or ""),
         lr=adam["lr"], adam_beta1=adam["adam_beta1"], adam_beta2=adam["adam_beta2"], adam_beta2_c=adam.get("adam_beta2_c", 0),
         adam_eps=adam["adam_eps"], weight_decay=adam["weight_decay"],
         warmup_ratio=ls.get("warmup_ratio", 0.0), eta_min=ls.get("eta_min", 0.0), init_steps=ls.get("init_steps", 0),

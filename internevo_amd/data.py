@@ -429,3 +429,26 @@ class ValidLoader:
         bs = self.batch_size
         for b in range(len(self)):
             yield jsonl_collate([self.ds.tokens(i) for i in self.indices[b * bs : (b + 1) * bs]], self.seq_len)
+
+
+class BatchSkipper:
+    """data.skip_batches (utils/common.py:165-190, used at train.py:187,208-212): "a-b,c" names the batch counts whose batch is drawn from the loader -- the sampler
+    and the consumed-sample count move on -- but not trained on.  Intervals are inclusive and must come in ascending order (the reference asserts it)."""
+
+    def __init__(self, skip_batches=""):
+        spans = []
+        for interval in (str(skip_batches).split(",") if skip_batches else ()):
+            if "-" in interval:
+                start, end = map(int, interval.split("-"))
+            else:
+                start = end = int(interval)
+            if spans and spans[-1] > start:
+                raise AssertionError(f"data.skip_batches = {skip_batches!r}: the intervals must be in ascending order")
+            spans.extend((start, end + 1))
+        self.spans = spans
+
+    def __call__(self, batch_count):
+        import bisect
+
+        return bisect.bisect_right(self.spans, batch_count) % 2 == 1
+

@@ -1213,6 +1213,21 @@ def gen_moe_layer(port=29789):
         json.dump(meta, f, indent=1)
 
 
+def gen_skipper():
+    """The real BatchSkipper (utils/common.py:165-190) on a few data.skip_batches strings -> skipper.json: which of the batch counts 0..29 it skips.
+    Pins data.BatchSkipper."""
+    sys.path.insert(0, REF)
+    from internlm.utils.common import BatchSkipper
+
+    cases = []
+    for spec in ("", "3", "1-3,5", "0-0,7-9,20", "2,4,6-6,28-40"):
+        sk = BatchSkipper(spec)
+        cases.append({"skip_batches": spec, "spans": list(sk.spans), "skipped": [n for n in range(30) if sk(n)]})
+    with open(os.path.join(OUT, "skipper.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("skipper.json", len(cases))
+
+
 def gen_sched_state():
     """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
     wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
@@ -1475,6 +1490,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--sched":
         gen_sched_state()
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--skipper":
+        shim_cpu_accelerator()
+        gen_skipper()
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--metrics":
         gen_metrics()

@@ -107,7 +107,7 @@ def test_reference_config_files_map(tmp_path):
     # settings that would change the arithmetic are refused, not silently ignored
     for path, value in ((("use_fp32_norm",), True), (("model", "norm_type"), "layernorm"), (("model", "apply_post_layer_norm"), True),
                         (("model", "attn_drop_rate"), 0.1),
-                        (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"), (("data", "skip_batches"), "1-3"),
+                        (("model", "multiple_of"), 128), (("data", "rampup_batch_size"), "2 6 5"),
                         (("parallel", "zero1"), dict(size=8, fsdp=True)), (("model", "num_experts"), 4), (("model", "no_bias"), False),
                         (("data", "use_packed_dataset"), False)):
         c = copy.deepcopy(g)
@@ -117,6 +117,10 @@ def test_reference_config_files_map(tmp_path):
         node[path[-1]] = value
         with pytest.raises(NotImplementedError):
             from_reference_dict(c)
+    # data.skip_batches is honoured (train.py draws the batch and moves on; data.BatchSkipper)
+    sk = copy.deepcopy(g)
+    sk["data"]["skip_batches"] = "1-3,5"
+    assert from_reference_dict(sk).train.skip_batches == "1-3,5" and from_reference_dict(g).train.skip_batches == ""
     # ScaleColumnParallelLinearWithNormHead's options map (InternLM2 family, no pipeline stages)
     nh = copy.deepcopy(g)
     nh["model"].update(embed_grad_scale=0.1, norm_head=True)
@@ -468,3 +472,20 @@ def test_pure_python_style_config_loads_without_the_reference_installed(tmp_path
             "print(c.model.num_layers, c.model.hidden_size, c.model.vocab_size, i.model.model_type, i.train.sp_size, i.train.wp_size, 'internlm' in sys.modules)") % (ROOT, isp)
     out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, check=True).stdout.split()
     assert out == ["32", "4096", "92544", "INTERNLM", "2", "4", "False"], out
+
+
+def test_batch_skipper_equals_the_reference_class():
+    """data.BatchSkipper against the real utils/common.py BatchSkipper (tests/golden/skipper.json, make_golden.py --skipper): the parsed spans and which of the
+    batch counts 0..29 are skipped, for an empty string, a single count, intervals and open tails; descending intervals are refused as the reference asserts."""
+    import json
+    import os
+
+    from internevo_amd.data import BatchSkipper
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for case in json.load(open(os.path.join(G, "skipper.json"))):
+        sk = BatchSkipper(case["skip_batches"])
+        assert list(sk.spans) == case["spans"] and [n for n in range(30) if sk(n)] == case["skipped"], case["skip_batches"]
+    with pytest.raises(AssertionError):
+        BatchSkipper("5-7,2")
+

@@ -114,6 +114,27 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_train_entry_skips_the_batches_data_skip_batches_names(dev, tmp_path):
+    """data.skip_batches = "1" (train.py:187,208-212 of the reference): batch 1 is drawn from the loader and not trained on -- the run logs the reference's line,
+    reports steps 0 and 2 only, and step 2 sees the very batch an unskipped run sees at step 2 (the data stream moved on)."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    base = CFG.format(steps=3, save=False, folder=str(tmp_path / "none"), load="None")
+    plain, skip = tmp_path / "plain.py", tmp_path / "skip.py"
+    plain.write_text(base)
+    skip.write_text(base.replace("fixed_random_dataset_seqlen=True)", 'fixed_random_dataset_seqlen=True, skip_batches="1")'))
+    lines = []
+    run_plain = train.main(["--config", str(plain), "--launcher", "torch"], log=lines.append)
+    run_skip = train.main(["--config", str(skip), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run_plain] == [0, 1, 2] and [r["step"] for r in run_skip] == [0, 2]
+    assert sum(ln == "Skip batch count:`1`..." for ln in lines) == 1
+    data_keys = ("num_samples_in_batch", "largest_length", "largest_batch", "smallest_batch")
+    assert all(run_skip[1][k] == run_plain[2][k] for k in data_keys) and run_skip[0]["loss"] == run_plain[0]["loss"]
+    assert run_skip[1]["loss"] != run_plain[2]["loss"]    # (one optimizer step fewer)
+
+
+@pytest.mark.gpu
 def test_train_entry_default_model_type_is_the_dense_internlm1_model_and_resumes(dev, tmp_path):
     """A config WITHOUT `model_type` (configs/7B_sft.py) is the reference's dense InternLM-1 model (launch.py:78-79): train.py runs it on the dense
     engine's InternLM-1 block, writes InternEvo checkpoints every 2 steps and a second run resumed from the step-2 folder reproduces steps 2 and 3 exactly."""

@@ -106,7 +106,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     per-group grad_norm keys (train/pipeline.py:494-530); InternEvo checkpoints (model + expert + optimizer files and the run state: scheduler, sampler,
     context) at any data-parallel size.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
     engine.InternLM2Engine like every other dense family.)"""
-    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.data import BatchSkipper, SyntheticLoader
     from internevo_amd.moe_engine import MoEEngine
 
     data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
@@ -146,9 +146,13 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     skipped_before = ctx["inf_nan_skip_batches"] if ctx else 0
     every = int(ck.get("checkpoint_every", 0) or 0)
     out = []
+    skipper = BatchSkipper(tc.skip_batches)
     for step in range(first_step, tc.total_steps):
         start = time.time()
         batch, labels = next(loader)
+        if skipper(step):   # data.skip_batches (train.py:208-212): the batch is drawn -- sampler and consumed samples move on -- and not trained on
+            log(f"Skip batch count:`{step}`...")
+            continue
         loss, moe_loss = eng.forward_backward(batch, labels)
         eng.step()
         st = eng.read_state()
@@ -178,7 +182,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
 def main(argv=None, log=print):
     args = parse_args(argv)
     from internevo_amd.config import from_reference_dict, run_reference_config
-    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.data import BatchSkipper, SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from internevo_amd.metrics import AccPerplex
     from internevo_amd.trainlog import TgsStatistic, get_megatron_flops, line, step_infos
@@ -275,9 +279,13 @@ def main(argv=None, log=print):
     consumed = ctx["num_consumed_tokens"] if ctx else 0
     skipped_before = ctx["inf_nan_skip_batches"] if ctx else 0
     out = []
+    skipper = BatchSkipper(tc.skip_batches)
     for step in range(first_step, tc.total_steps):
         start = time.time()
         batch, labels = next(loader)
+        if skipper(step):   # data.skip_batches (train.py:208-212): the batch is drawn -- sampler and consumed samples move on -- and not trained on
+            log(f"Skip batch count:`{step}`...")
+            continue
         t0 = time.time()
         loss = eng.forward_backward(batch, labels)
         eng.step()
