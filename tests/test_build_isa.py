@@ -32,11 +32,47 @@ def test_kernels_with_untracked_lds_reads_use_no_scratch(tmp_path):
         assert m, name
         a_km, b_km = m.group(5) == "1", m.group(6) == "1"
         sched = -int(m.group(7)) if "ELin" in name else int(m.group(7))
-        nowait = (sched in (-21, -22, -23) and (a_km or b_km)) or (sched == -4 and b_km and not a_km)
+        nowait = (sched in (-21, -22, -23, -24) and (a_km or b_km)) or (sched in (-4, -5) and b_km and not a_km)
         if nowait:
             checked += 1
             assert int(scratch) == 0 and int(spills) == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs next to untracked LDS reads"
     assert checked >= 10, checked
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.timeout(300)
+def test_round4_gemm_schedules_keep_their_accumulators_in_agprs(tmp_path):
+    """The schedules added in round 4 -- the refill schedule on v_mfma_f32_16x16x32_bf16 (-5), its ring form (-24) and the e4m3 schedule on
+    v_mfma_f32_32x32x64_f8f6f4 (-6) -- use all 256 AGPRs for accumulators and nearly all VGPRs for fragments.  Twice while writing them hipcc answered a harmless
+    source change with a very different allocation: with the 16x16x32 builtin it parked accumulator tiles in VGPRs and copied them around their MFMAs (120 to 480
+    v_accvgpr moves per k-tile), and with the MFMA inside `if (!(m & 1))` it put accumulators AND fragments into scratch (1.7 KB per lane).  What the build must keep:
+    no scratch, no spills, and a steady-state k-tile loop with the full count of MFMAs, 32 LDS fragment reads, 16 DMA pieces (per two entries for the ring) and no
+    accumulator traffic between the register files."""
+    out = tmp_path / "gemm_dma.s"
+    src = os.path.join(ROOT, "internevo_amd", "csrc", "gemm_bf16_dma.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.dirname(src), src, "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    want = {"Lb0ELb0ELin5ELi0E": ("v_mfma_f32_16x16x32_bf16", 128, 32), "Lb0ELb0ELin5ELi1E": ("v_mfma_f32_16x16x32_bf16", 128, 32),
+            "Lb0ELb1ELin5ELi0E": ("v_mfma_f32_16x16x32_bf16", 128, 48), "Lb1ELb1ELin24ELi0E": ("v_mfma_f32_16x16x32_bf16", 128, 64),
+            "Lb0ELb0ELin6ELi0E": ("v_mfma_f32_32x32x64_f8f6f4", 32, 32)}
+    seen = set()
+    for m in re.finditer(r"^(_ZN\S*gemm_dma_kI\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        tag = next((t for t in want if t in m.group(1)), None)
+        if tag is None:
+            continue
+        mfma, n_mfma, n_reads = want[tag]
+        body = m.group(2)
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), f"{m.group(1)}: scratch in use"
+        # the steady-state loop: the basic block with the most MFMAs
+        blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+        loop = max(blocks, key=lambda b: b.count(mfma))
+        assert loop.count(mfma) == n_mfma, f"{m.group(1)}: {loop.count(mfma)} MFMAs in the k-tile loop, expected {n_mfma}"
+        assert len(re.findall(r"\bds_read_b(?:128|64_tr_b16)\b", loop)) == n_reads and loop.count("buffer_load_dwordx4") == 16, m.group(1)
+        own = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", loop, flags=re.S)
+        assert "v_accvgpr" not in own and "scratch_" not in own, f"{m.group(1)}: accumulator copies / scratch traffic inside the k-tile loop"
+        seen.add(tag)
+    assert seen == set(want), sorted(set(want) - seen)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
