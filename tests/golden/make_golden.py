@@ -432,7 +432,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                 else:
                     p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
             elif world > 1 and tp > 1:
-                part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw)
+                part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"]) if cfg_kw.get("model_type") == "INTERNLM"
+                        else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw))
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
             elif world > 1:
@@ -959,6 +960,16 @@ RUNS_MP = {
     "isp2v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2,
                                           model_type="INTERNLM"), 2),
     "isp2v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2,
+                                           model_type="INTERNLM"), 2),
+    # the dense InternLM-1 model on two Megatron tensor ranks, mtp and the sequence-sharded msp (same model / data as v1_*: the mtp run must retrace it; Wqkv and its
+    # bias cut by heads, out_proj's bias on tensor rank 0 only)
+    "tp2v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2,
+                                         model_type="INTERNLM"), 2),
+    "tp2v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2,
+                                          model_type="INTERNLM"), 2),
+    "msp2v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="msp",
+                                          model_type="INTERNLM"), 2),
+    "msp2v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="msp",
                                            model_type="INTERNLM"), 2),
     # two data-parallel ranks of the MoE family: the reference then runs expert parallel (ep = 2, two of the four experts per rank, all_to_all of the
     # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
