@@ -643,7 +643,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             chunk_models = list(model) if isinstance(model, torch.nn.ModuleList) else [model]
             assert len(chunk_models) == len(parts)
             for name, p, start in [(n_, p_, st_) for cm, (st_, _e) in zip(chunk_models, parts) for n_, p_ in cm.model.named_parameters()]:
-                gname = re.sub(r"layers\.(\d+)\.", lambda m_: f"layers.{int(m_.group(1)) + start}.", name)
+                gname = re.sub(r"(layers|blocks)\.(\d+)\.", lambda m_: f"{m_.group(1)}.{int(m_.group(2)) + start}.", name)   # (InternLM2 / InternLM-1 names)
                 if tp > 1:
                     part = _mtp_part(gname, formula_init(gname, full_shapes[gname]), tp_rank, tp, kw)
                     assert tuple(part.shape) == tuple(p.shape), (gname, tuple(part.shape), tuple(p.shape))
@@ -689,7 +689,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -789,7 +789,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     rec["files"] = sorted(os.listdir(folder))
     if pp > 1:
         rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.PIPELINE, ParallelMode.DATA, ParallelMode.ZERO1)}
-        with open(os.path.join(HERE, f"ckpt_pp{pp}tp{tp}_rank{rank}.json" if tp > 1 else f"ckpt_pp{pp}i_rank{rank}.json" if chunks > 1 else f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
+        with open(os.path.join(HERE, f"ckpt_pp{pp}tp{tp}_rank{rank}.json" if tp > 1 else f"ckpt_pp{pp}i_rank{rank}.json" if chunks > 1 else f"ckpt_pp{pp}v1_rank{rank}.json" if model_type == "INTERNLM" else f"ckpt_pp{pp}_rank{rank}.json"), "w") as f:
             json.dump(rec, f, indent=1, default=str)
         return
     with open(os.path.join(HERE, "ckpt_isp2v1.json" if isp else "ckpt_moe.json" if model_type == "INTERNLM_MoE" else "ckpt_v1.json" if model_type == "INTERNLM" else "ckpt.json" if world == 1 else f"ckpt_tp{tp}.json" if tp > 1 else f"ckpt_dp{world}.json"), "w") as f:
@@ -1435,6 +1435,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-pptp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-pptp-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-ppv1-rank":
+        gen_checkpoint(port=29783, rank=int(sys.argv[2]), world=2, pp=2, model_type="INTERNLM")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-ppv1":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-ppv1-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-ppi-rank":
         gen_checkpoint(port=29785, rank=int(sys.argv[2]), world=2, pp=2, chunks=2)

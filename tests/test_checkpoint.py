@@ -762,6 +762,47 @@ def test_interleaved_pipeline_checkpoint_of_the_reference_merges_is_reproduced_a
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
 
 
+def test_dense_internlm1_pipeline_checkpoint_of_the_reference_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_pp2v1/: the REAL reference's dense InternLM-1 model on two pipeline stages (make_golden.py --ckpt-ppv1): a stage's files carry
+    `blocks.<k>.` numbered from 0 (embedding on the first stage, norm + head on the last), biases with their block.  Merge, tensor-for-tensor rewrite of both stages'
+    files, and the single-rank oracle resumed from the merge retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import PathConfig, TrainConfig
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoETrainer
+
+    ref = os.path.join(G, "ckpt_ref_pp2v1")
+    g0, g1 = (json.load(open(os.path.join(G, f"ckpt_pp2v1_rank{r}.json"))) for r in (0, 1))
+    mc = _v1_model_cfg(g1)
+    namings = [C.stage_naming(mc, 2, p_) for p_ in (0, 1)]
+    assert [k for _, k, _ in namings[0]] == [k[0] for k in g0["model_keys"]] and [k for _, k, _ in namings[1]] == [k[0] for k in g1["model_keys"]]
+    assert namings[1][0][0] == "blocks.0.mixer.Wqkv.weight" and namings[1][0][2] == "blocks.2.mixer.Wqkv.weight"
+    ck = C.load_checkpoint(ref, mc)
+    assert list(ck["params"]) == C.state_dict_order(mc) and ck["pp_world"] == 2 and ck["adam_step"] == 2
+    assert all(torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]) for n in ck["params"])
+    out = str(tmp_path / "ck")
+    for p_ in (0, 1):
+        cut = lambda d: {n: d[g] for n, _, g in namings[p_]}  # noqa: E731
+        C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"],
+                          dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3), pp_world=2, pp_rank=p_, order=[n for n, _, _ in namings[p_]])
+    assert sorted(os.listdir(out)) == g1["files"]
+    for p_ in (0, 1):
+        a, b = (torch.load(os.path.join(f, f"model_tp0_pp{p_}.pt"), weights_only=False) for f in (ref, out))
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+        _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp0_pp{p_}_zo0.pt"), os.path.join(out, f"optimizer_tp0_pp{p_}_zo0.pt"))
+    c = g1["config"]
+    tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+    tr = OracleMoETrainer(PathConfig(mc, tc), torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, g1["num_samples"]))
+    for _ in range(g1["saved_after_step"]):
+        next(loader)
+    for w in g1["steps"][g1["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        total = sum(v * v for v in r["grad_norm"].values()) ** 0.5
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(total - w["grad_norm"]["0_default"]) <= 1e-2 * total, (r, w)
+
+
 def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
     """tests/golden/ckpt_ref_moe/: the REAL reference's INTERNLM_MoE checkpoint (4 experts, top-2; make_golden.py --ckpt-moe) after two steps: the model
     file without the experts, one `model_moe_layer{l}_expert{e}_tp0.pt` per expert, and an optimizer file with THREE groups (default / fp32 = the gates /
