@@ -391,6 +391,9 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
 
         full_shapes = param_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
                                                num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"]))
+        if cfg_kw.get("model_type") == "LLAMA2":
+            full_shapes = param_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"],
+                                                   num_attention_heads=cfg_kw["heads"], num_kv_attention_heads=cfg_kw["kv_heads"], model_type="LLAMA2"))
         if cfg_kw.get("model_type") == "INTERNLM":   # the InternLM-1 block's names and shapes (biases, mlp_ratio 8 / 3)
             from oracle.moe_model import param_shapes as v1_shapes
 
@@ -432,8 +435,14 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                 else:
                     p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
             elif world > 1 and tp > 1:
-                part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"]) if cfg_kw.get("model_type") == "INTERNLM"
-                        else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw))
+                if cfg_kw.get("model_type") == "INTERNLM":
+                    part = _mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"])
+                elif cfg_kw.get("model_type") == "LLAMA2":   # separate wq / wk / wv, each cut by rows: the rank's q heads and ITS kv heads (checkpoint.tp_shard)
+                    from internevo_amd.checkpoint import tp_shard
+
+                    part = tp_shard(name, formula_init(name, full_shapes[name]), tp_rank, tp)
+                else:
+                    part = _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw)
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
             elif world > 1:
@@ -971,6 +980,13 @@ RUNS_MP = {
                                           model_type="INTERNLM"), 2),
     "msp2v1_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="msp",
                                            model_type="INTERNLM"), 2),
+    "fsp2v1_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2, tp_mode="fsp",
+                                          model_type="INTERNLM"), 2),
+    # BASELINE configs[2]'s family on two tensor ranks (configs/7B_llama2.py: model_type LLAMA2, tensor size 2): same model / data as llama_*: must retrace them
+    "llama_tp2_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2,
+                                             model_type="LLAMA2"), 2),
+    "llama_tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, tp=2,
+                                              model_type="LLAMA2"), 2),
     # two data-parallel ranks of the MoE family: the reference then runs expert parallel (ep = 2, two of the four experts per rank, all_to_all of the
     # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
     "moe2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
