@@ -594,6 +594,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     from oracle.model import formula_init
 
     kw = dict(use_packed=False, seq_len=48, hidden=64, heads=1, kv_heads=1, vocab=512, layers=2, micro_num=2, total_steps=6)  # head dim 64: the smallest the HIP flash kernels take
+    if model_type == "LLAMA2":   # `--ckpt-llama-tp`: BASELINE configs[2]'s family on two tensor ranks -> ckpt_ref_llama_tp2/ (wq / wk / wv files per tensor rank)
+        kw = dict(kw, model_type=model_type)
     if model_type in ("INTERNLM", "INTERNLM_MoE"):
         from oracle.model import moe_formula_init as formula_init  # noqa: F811
 
@@ -641,7 +643,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                     num_kv_attention_heads=kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
             else:
                 full_shapes = param_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"],
-                                                       num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"]))
+                                                       num_attention_heads=kw["heads"], num_kv_attention_heads=kw["kv_heads"], **({"model_type": "LLAMA2"} if model_type == "LLAMA2" else {})))
             tp_rank = gpc.get_local_rank(ParallelMode.TENSOR)
         if pp > 1:   # a stage numbers its layers from 0: the closed-form weights go by the GLOBAL layer number (partition_uniform)
             import re
@@ -680,8 +682,13 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                 p.copy_(_full_param_slice(name, tuple(p.shape), formula_init, gpc.get_local_rank(ParallelMode.TENSOR), 2, gpc.get_local_rank(ParallelMode.WEIGHT), 2,
                                           full_shapes).to(p.dtype))
             elif tp > 1:
-                part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw["hidden"] // kw["heads"]) if model_type == "INTERNLM"
-                        else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw))
+                if model_type == "LLAMA2":
+                    from internevo_amd.checkpoint import tp_shard
+
+                    part = tp_shard(name, formula_init(name, full_shapes[name]), tp_rank, tp)
+                else:
+                    part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw["hidden"] // kw["heads"]) if model_type == "INTERNLM"
+                            else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw))
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
             else:
@@ -698,7 +705,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -787,6 +794,12 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             rec["rank_unique_id"] = optimizer.rank_unique_id
             with open(os.path.join(HERE, f"ckpt_isp4v1_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
+            return
+        if model_type == "LLAMA2":
+            if rank == 0:
+                rec["files"] = sorted(os.listdir(folder))
+                with open(os.path.join(HERE, "ckpt_llama_tp2.json"), "w") as f:
+                    json.dump(rec, f, indent=1, default=str)
             return
         if model_type == "INTERNLM" and tp > 1:   # `--ckpt-v1tp`: both tensor ranks' records (rank 1 has no out_proj.bias)
             rec["files"] = sorted(os.listdir(folder))
@@ -1497,6 +1510,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-tp-rank":
         gen_checkpoint(port=29799, rank=int(sys.argv[2]), world=2, tp=2)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-llama-tp-rank":
+        gen_checkpoint(port=29782, rank=int(sys.argv[2]), world=2, tp=2, model_type="LLAMA2")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-llama-tp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-llama-tp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-v1tp-rank":
         gen_checkpoint(port=29786, rank=int(sys.argv[2]), world=2, tp=2, model_type="INTERNLM")
         sys.exit(0)

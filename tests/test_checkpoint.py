@@ -803,6 +803,47 @@ def test_dense_internlm1_pipeline_checkpoint_of_the_reference_merges_is_reproduc
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(total - w["grad_norm"]["0_default"]) <= 1e-2 * total, (r, w)
 
 
+def test_llama2_tensor_parallel_checkpoint_of_the_reference_merges_is_reproduced_and_resumes(tmp_path):
+    """tests/golden/ckpt_ref_llama_tp2/: the REAL reference's LLAMA2 model (separate wq / wk / wv) on two tensor ranks -- BASELINE configs[2]'s family and layout
+    (make_golden.py --ckpt-llama-tp).  The loader merges the ranks' files (every projection by rows / columns as checkpoint.tp_split_dim says), the writer reproduces
+    them tensor for tensor, and the single-rank oracle (LLAMA2: adapt_hf False) resumed from the merge retraces the reference's next two steps."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from internevo_amd.data import SyntheticLoader
+    from oracle.model import param_shapes
+    from oracle.step import OracleTrainer
+
+    gold = json.load(open(os.path.join(G, "ckpt_llama_tp2.json")))
+    ref = os.path.join(G, "ckpt_ref_llama_tp2")
+    c = gold["config"]
+    cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"], model_type="LLAMA2")
+    mc = cfg.model
+    assert ["model." + n for n in C.state_dict_order(mc)] == [k[0] for k in gold["model_keys"]] and any(n.endswith("attention.wq.weight") for n in C.state_dict_order(mc))
+    ck = C.load_checkpoint(ref, mc)
+    full = param_shapes(mc)
+    assert ck["tp_world"] == 2 and ck["adam_step"] == 2 and all(tuple(ck["params"][n].shape) == tuple(full[n]) for n in C.state_dict_order(mc))
+    assert all(torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]) for n in ck["params"])
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    out = str(tmp_path / "ck")
+    for t in (0, 1):
+        cut = lambda d: {n: C.tp_shard(n, v, t, 2).contiguous() for n, v in d.items()}  # noqa: E731
+        C.save_checkpoint(out, mc, cut(ck["params"]), cut(ck["master"]), cut(ck["exp_avg"]), cut(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"], hyper,
+                          tp_world=2, tp_rank=t)
+    assert sorted(f for f in os.listdir(out) if not f.endswith(".step")) == gold["files"]
+    for t in (0, 1):
+        _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp{t}_pp0_zo0.pt"), os.path.join(out, f"optimizer_tp{t}_pp0_zo0.pt"))
+        x, y = (torch.load(os.path.join(f, f"model_tp{t}_pp0.pt"), weights_only=False) for f in (ref, out))
+        assert list(x) == list(y) and all(x[k].shape == y[k].shape and torch.equal(x[k], y[k]) for k in x)
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(ck)
+    loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"]))
+    for _ in range(gold["saved_after_step"]):
+        next(loader)
+    for w in gold["steps"][gold["saved_after_step"]:]:
+        r = tr.train_step(*next(loader))
+        assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
+
+
 def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
     """tests/golden/ckpt_ref_moe/: the REAL reference's INTERNLM_MoE checkpoint (4 experts, top-2; make_golden.py --ckpt-moe) after two steps: the model
     file without the experts, one `model_moe_layer{l}_expert{e}_tp0.pt` per expert, and an optimizer file with THREE groups (default / fp32 = the gates /
