@@ -556,7 +556,7 @@ def gen_metrics(port=29790):
     print(res)
 
 
-def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp=False, chunks=1):
+def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp=False, chunks=1, zero1=None):
     """Train a tiny bf16 InternLM2 for 2 steps with the real reference, save its model + optimizer checkpoints with the
     reference's own writers (checkpoint/components.py:199-283,377-410) into tests/golden/ckpt_ref/ (a "local:" folder), keep
     training 2 more steps and record that trajectory: a loader for this format must resume exactly there.
@@ -624,6 +624,8 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=4 if pp > 1 else 2 if model_type == "INTERNLM" else 1, tp=tp)   # (`--ckpt-pptp`: tensor 2 x pipeline 2 on four processes -> ckpt_ref_pp2tp2/)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
+    if zero1:   # `--ckpt-hz`: hybrid ZeRO (parallel.zero1.size < the data-parallel size): four data ranks, optimizer state sharded over groups of two -> ckpt_ref_dp4_zo2/
+        cfg["parallel"]["zero1"] = dict(size=zero1)
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
     torch.set_num_threads(int(os.environ.get("IE_THREADS", "8")))
@@ -705,7 +707,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -793,6 +795,13 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                                                             ParallelMode.WEIGHT_DATA, ParallelMode.ZERO1)}
             rec["rank_unique_id"] = optimizer.rank_unique_id
             with open(os.path.join(HERE, f"ckpt_isp4v1_rank{rank}.json"), "w") as f:
+                json.dump(rec, f, indent=1, default=str)
+            return
+        if zero1:   # every rank's record: which files exist, its rank_unique_id, its ranks in the DATA / ZERO1 groups
+            rec["files"] = sorted(os.listdir(folder))
+            rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.DATA, ParallelMode.ZERO1)}
+            rec["rank_unique_id"] = optimizer.rank_unique_id
+            with open(os.path.join(HERE, f"ckpt_dp{world}_zo{zero1}_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
         if model_type == "LLAMA2":
@@ -1510,6 +1519,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-tp-rank":
         gen_checkpoint(port=29799, rank=int(sys.argv[2]), world=2, tp=2)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-hz-rank":
+        gen_checkpoint(port=29781, rank=int(sys.argv[2]), world=4, zero1=2)
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-hz":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-hz-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-llama-tp-rank":
         gen_checkpoint(port=29782, rank=int(sys.argv[2]), world=2, tp=2, model_type="LLAMA2")
         sys.exit(0)

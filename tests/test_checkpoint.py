@@ -844,6 +844,45 @@ def test_llama2_tensor_parallel_checkpoint_of_the_reference_merges_is_reproduced
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
 
 
+def test_hybrid_zero_reference_checkpoint_loads_and_resumes():
+    """tests/golden/ckpt_ref_dp4_zo2/: the REAL reference on four data-parallel ranks with parallel.zero1.size = 2 (hybrid ZeRO; make_golden.py --ckpt-hz): the optimizer
+    state is sharded over groups of TWO ranks -- two optimizer files, written by the first zero group -- while every data rank writes its own plan file under the JOB's
+    world size (`gpus-4_..._dp-{d}_..._zo-{d % 2}.pt`, hybrid_zero_optim.py:133-140, components.py:396-407).  The loader takes the layout from the optimizer files (the
+    plan also sits inside them), merges the two shards, and the oracle resumed from the merge retraces the four-rank run's next two gradient norms.
+    (This repo's engine writes the same optimizer and model files under hybrid ZeRO but names its plan files after the zero world and writes them from the first zero
+    group only; the reference's loader treats a missing plan file as "use the default split", which is the same split -- INTEGRATION.md section 5.)"""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.data import SyntheticLoader
+    from oracle.step import OracleTrainer
+
+    ref = os.path.join(G, "ckpt_ref_dp4_zo2")
+    gold = [json.load(open(os.path.join(G, f"ckpt_dp4_zo2_rank{r}.json"))) for r in range(4)]
+    assert [g["ranks"]["ZERO1"] for g in gold] == [[0, 2], [1, 2], [0, 2], [1, 2]] and [g["ranks"]["DATA"][0] for g in gold] == [0, 1, 2, 3]
+    assert [g["rank_unique_id"] for g in gold] == [f"gpus-4_wp-0_tp-0_dp-{d}_pp-0_zo-{d % 2}.pt" for d in range(4)]
+    assert [f for f in gold[0]["files"] if f.startswith("optimizer")] == ["optimizer_tp0_pp0_zo0.pt", "optimizer_tp0_pp0_zo1.pt"]
+    cfg = _cfg()
+    c = gold[0]["config"]
+    assert C.saved_zero_world(ref) == 2
+    ck = C.load_checkpoint(ref, cfg.model)
+    assert ck["zero_world"] == 2 and ck["adam_step"] == 2 and all(torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]) for n in ck["params"])
+    shapes = {n: tuple(ck["params"][n].shape) for n in C.state_dict_order(cfg.model)}
+    flat = C.zero_flat_order(list(shapes.items()))
+    plan = [C._plan_ids(flat, idx) for idx in C.zero_partition(flat, 2)]
+    assert all(C._load(os.path.join(ref, g["rank_unique_id"]))[0] == plan for g in gold)   # every rank's plan file = the partition over the ZERO group
+    cfg.train.micro_num = 4 * c["micro_num"]
+    tr = OracleTrainer(cfg, torch.bfloat16)
+    tr.load_state(ck)
+    loaders = [iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold[0]["num_samples"], data_rank=r, data_world_size=4)) for r in range(4)]
+    for _ in range(gold[0]["saved_after_step"]):
+        [next(l) for l in loaders]
+    for w in gold[0]["steps"][gold[0]["saved_after_step"]:]:
+        parts = [next(l) for l in loaders]
+        batch = {k: (sum((p[0][k] for p in parts), []) if isinstance(parts[0][0][k], list) else torch.cat([p[0][k] for p in parts])) for k in parts[0][0]}
+        g = tr.train_step(batch, torch.cat([p[1] for p in parts]))
+        assert abs(g["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * w["grad_norm"]["0_default"], (g["grad_norm"], w["grad_norm"])
+        assert abs(g["lr"] - w["lr"]) <= 1e-9 * w["lr"] and g["loss_scale"] == w["loss_scale"]
+
+
 def test_moe_reference_checkpoint_loads_saves_and_resumes(tmp_path):
     """tests/golden/ckpt_ref_moe/: the REAL reference's INTERNLM_MoE checkpoint (4 experts, top-2; make_golden.py --ckpt-moe) after two steps: the model
     file without the experts, one `model_moe_layer{l}_expert{e}_tp0.pt` per expert, and an optimizer file with THREE groups (default / fp32 = the gates /
