@@ -249,7 +249,8 @@ def _load(path):
 
 
 def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16,
-                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0, pp_world=1, pp_rank=0, order=None, chunked=False):
+                    zero_world=1, zero_ranks=None, write_model=True, shapes=None, tp_world=1, tp_rank=0, pp_world=1, pp_rank=0, order=None, chunked=False,
+                    job_world=None, dp_ranks=None, plans_only=False):
     """params / master / exp_avg / exp_avg_sq: dict name -> host tensor (master and moments fp32).  scaler: dict(scale, growth_step,
     hysteresis_step).  hyper: dict(weight_decay, betas, eps, initial_lr).  lr: the learning rate in effect (param_groups' "lr").
     zero_world > 1: one optimizer + plan file per rank in `zero_ranks` (default: all); the state dicts then only need the
@@ -258,10 +259,15 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
     tp_world > 1: the tensors are tensor-parallel rank `tp_rank`'s LOCAL parts (tp_shard); the files carry that rank in their names
     and the ZeRO partition is computed from the local shapes, as every tensor rank of the reference does for itself.
     pp_world > 1: ONE pipeline stage's files (`..._pp{pp_rank}...`); `order` = the stage's local names (stage_order / stage_naming) and every dict is keyed by
-    them; chunked: the stage holds the interleaved schedule's model chunks (names "<chunk>.<name>")."""
+    them; chunked: the stage holds the interleaved schedule's model chunks (names "<chunk>.<name>").
+    Hybrid ZeRO (parallel.zero1.size = zero_world below the data-parallel size; pinned on tests/golden/ckpt_ref_dp4_zo2/): the optimizer files are those of ONE zero
+    group, but every data-parallel rank d writes a plan file, named after the JOB's world size and its own ranks: `gpus-{job_world}_..._dp-{d}_..._zo-{d % zero_world}.pt`
+    (hybrid_zero_optim.py:133-140).  job_world: the number of ranks in the job (default zero_world * tp_world * pp_world: no hybrid ZeRO); dp_ranks: the data-parallel
+    ranks whose plan files this call writes (default: the ranks of `zero_ranks`, as data ranks of the first zero group); plans_only: write nothing but those plan files
+    (the ranks outside the first zero group: the state dicts are not needed then)."""
     os.makedirs(folder, exist_ok=True)
     order = state_dict_order(model_cfg, tp_rank) if order is None else list(order)
-    if write_model:
+    if write_model and not plans_only:
         import re
 
         # (a stage of the interleaved schedule: `order` carries "<chunk>.<name>", the ModuleList's state dict "<chunk>.model.<name>")
@@ -274,6 +280,12 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
     flat_order = zero_flat_order([(n, tuple(shapes[n])) for n in order])
     partition = zero_partition(flat_order, zero_world)
     plan = [[_plan_ids(flat_order, idx) for idx in partition], [[] for _ in range(zero_world)]]
+    gpus = zero_world * tp_world * pp_world if job_world is None else int(job_world)
+    plan_file = lambda d: os.path.join(folder, f"gpus-{gpus}_wp-0_tp-{tp_rank}_dp-{d}_pp-{pp_rank}_zo-{d % zero_world}.pt")  # noqa: E731
+    if plans_only:
+        for d in dp_ranks:
+            torch.save(plan, plan_file(d))
+        return
 
     with _RefEnumModule() as zero1:
         tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
@@ -300,10 +312,13 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
                 "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
             }
             torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp{pp_rank}_zo{r}.pt"))
-            torch.save(plan, os.path.join(folder, f"gpus-{zero_world * tp_world * pp_world}_wp-0_tp-{tp_rank}_dp-{r}_pp-{pp_rank}_zo-{r}.pt"))
+            if dp_ranks is None:
+                torch.save(plan, plan_file(r))
+        for d in (dp_ranks or ()):
+            torch.save(plan, plan_file(d))
 
 
-def remove_stale_shards(folder, zero_world, tp_world, pp_world=1):
+def remove_stale_shards(folder, zero_world, tp_world, pp_world=1, job_world=None):
     """Before a save into an existing folder: drop the shard / plan / topology files of an earlier save by a LARGER layout.  The
     loaders infer the saved layout from the highest file index present (saved_zero_world / saved_tp_world, as the reference's
     components.py:294-306 does), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would be merged as if
@@ -320,8 +335,8 @@ def remove_stale_shards(folder, zero_world, tp_world, pp_world=1):
         m = re.fullmatch(r"(?:model_tp(\d+)_pp(\d+)\.pt|topo_tp(\d+)_pp(\d+)\.json)", fn)
         stale = stale or (bool(m) and (int(m.group(1) or m.group(3)) >= tp_world or int(m.group(2) or m.group(4)) >= pp_world))
         m = re.fullmatch(r"gpus-(\d+)_wp-0_tp-(\d+)_dp-(\d+)_pp-(\d+)_zo-(\d+)\.pt", fn)
-        stale = stale or (bool(m) and (int(m.group(1)) != zero_world * tp_world * pp_world or int(m.group(2)) >= tp_world or int(m.group(4)) >= pp_world
-                                       or int(m.group(5)) >= zero_world))
+        stale = stale or (bool(m) and (int(m.group(1)) != (zero_world * tp_world * pp_world if job_world is None else job_world) or int(m.group(2)) >= tp_world
+                                       or int(m.group(4)) >= pp_world or int(m.group(5)) >= zero_world))
         if stale:
             os.remove(os.path.join(folder, fn))
             removed.append(fn)

@@ -1655,8 +1655,9 @@ class InternLM2Engine:
         tc, L, W, r = self.tc, self.layout, self.world, self.rank
         tp, t = self.tp, self.tpar.tp_rank
         pp, ps = self.pp, self.pipe.stage
+        job = self.dp_world * tp * pp   # the ranks of the job: under hybrid ZeRO (W < dp_world) EVERY data-parallel rank writes a plan file named after it (ckpt_ref_dp4_zo2/)
         if self.dp_rank == 0 and t == 0 and ps == 0:   # shards of an earlier, larger layout in the same folder would be merged into this save by any loader
-            gone = C.remove_stale_shards(folder, W, tp, pp)
+            gone = C.remove_stale_shards(folder, W, tp, pp, job_world=job)
             if gone:
                 print(f"[internevo_amd] save_checkpoint({folder}): removed {len(gone)} shard files of an earlier, larger layout: {', '.join(gone)}", flush=True)
 
@@ -1677,17 +1678,21 @@ class InternLM2Engine:
         loc = to_local.__getitem__
         stage = dict(pp_world=pp, pp_rank=ps, order=[loc(n) for n in glob], chunked=self.nch > 1) if pp > 1 else {}
         cpu = lambda d: {loc(n): x.detach().to("cpu") for n, x in self._local_reference_named(d).items()}  # noqa: E731
-        if W == 1:
-            if self.dp_rank == 0:
-                C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
-                                  cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t, **stage)
-            everyone()
-            return
         shapes = {}
         for n, shp in self.reference_param_shapes().items():  # FULL shapes -> this tensor rank's local shapes
             d = C.tp_split_dim(n)
             shapes[n] = tuple(x // tp if (tp > 1 and i == d) else x for i, x in enumerate(shp))
         shapes = {loc(n): shapes[n] for n in glob}
+        plans = dict(job_world=job, dp_ranks=[self.dp_rank])   # this data-parallel rank's plan file, named after the job's world size and its ranks
+        if W == 1:
+            if self.dp_rank == 0:
+                C.save_checkpoint(folder, self.mc, cpu(self.p), cpu(self._named_shard_views(self.master)), cpu(self._named_shard_views(self.exp_avg)),
+                                  cpu(self._named_shard_views(self.exp_avg_sq)), st.adam_step, scaler, self.lr_sched.lr(), hyper, tp_world=tp, tp_rank=t, **stage, **plans)
+            else:   # (zero1.size = 1 under data parallelism: rank 0 holds and writes the state, every rank its plan file)
+                C.save_checkpoint(folder, self.mc, None, None, None, None, st.adam_step, scaler, self.lr_sched.lr(), hyper, shapes=shapes, tp_world=tp, tp_rank=t,
+                                  plans_only=True, **stage, **plans)
+            everyone()
+            return
         mine = C.zero_rank_names(shapes, W)[r]              # the parameters the reference's ZeRO rank r owns (whole; stage-local names)
         need = {self._engine_name(to_global[n]) for n in mine}
         state = {}
@@ -1704,7 +1709,10 @@ class InternLM2Engine:
             state[key] = {n: ref_named[to_global[n]] for n in mine}
         if self.comm.replica == 0:   # hybrid ZeRO: every zero group holds the same shards, the first one writes them
             C.save_checkpoint(folder, self.mc, cpu(self.p) if r == 0 else None, state["master"], state["exp_avg"], state["exp_avg_sq"], st.adam_step,
-                              scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t, **stage)
+                              scaler, self.lr_sched.lr(), hyper, zero_world=W, zero_ranks=[r], write_model=(r == 0), shapes=shapes, tp_world=tp, tp_rank=t, **stage, **plans)
+        else:                        # ... the others their plan files (hybrid_zero_optim.py:133-140: one per data-parallel rank)
+            C.save_checkpoint(folder, self.mc, None, None, None, None, st.adam_step, scaler, self.lr_sched.lr(), hyper, zero_world=W, shapes=shapes, tp_world=tp, tp_rank=t,
+                              plans_only=True, **stage, **plans)
         everyone()  # the folder is complete when any rank returns
 
     def load_checkpoint(self, folder, model_only=False):

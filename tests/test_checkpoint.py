@@ -844,13 +844,13 @@ def test_llama2_tensor_parallel_checkpoint_of_the_reference_merges_is_reproduced
         assert abs(r["loss"] - w["loss"]) <= 2e-3 * w["loss"] and abs(r["grad_norm"] - w["grad_norm"]["0_default"]) <= 1e-2 * r["grad_norm"], (r, w)
 
 
-def test_hybrid_zero_reference_checkpoint_loads_and_resumes():
+def test_hybrid_zero_reference_checkpoint_loads_and_resumes(tmp_path):
     """tests/golden/ckpt_ref_dp4_zo2/: the REAL reference on four data-parallel ranks with parallel.zero1.size = 2 (hybrid ZeRO; make_golden.py --ckpt-hz): the optimizer
     state is sharded over groups of TWO ranks -- two optimizer files, written by the first zero group -- while every data rank writes its own plan file under the JOB's
     world size (`gpus-4_..._dp-{d}_..._zo-{d % 2}.pt`, hybrid_zero_optim.py:133-140, components.py:396-407).  The loader takes the layout from the optimizer files (the
     plan also sits inside them), merges the two shards, and the oracle resumed from the merge retraces the four-rank run's next two gradient norms.
-    (This repo's engine writes the same optimizer and model files under hybrid ZeRO but names its plan files after the zero world and writes them from the first zero
-    group only; the reference's loader treats a missing plan file as "use the default split", which is the same split -- INTEGRATION.md section 5.)"""
+    The writer reproduces the whole file set the way the engine's ranks call it: the two ranks of the first zero group write model / optimizer / plan files, the other
+    two their plan files only (`plans_only`), all named after the job's four ranks."""
     from internevo_amd import checkpoint as C
     from internevo_amd.data import SyntheticLoader
     from oracle.step import OracleTrainer
@@ -869,6 +869,21 @@ def test_hybrid_zero_reference_checkpoint_loads_and_resumes():
     flat = C.zero_flat_order(list(shapes.items()))
     plan = [C._plan_ids(flat, idx) for idx in C.zero_partition(flat, 2)]
     assert all(C._load(os.path.join(ref, g["rank_unique_id"]))[0] == plan for g in gold)   # every rank's plan file = the partition over the ZERO group
+    out = str(tmp_path / "ck")
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for d in range(4):   # data-parallel rank d = zero rank d % 2 of zero group d // 2
+        if d < 2:
+            C.save_checkpoint(out, cfg.model, ck["params"] if d == 0 else None, ck["master"], ck["exp_avg"], ck["exp_avg_sq"], ck["adam_step"], ck["scaler"], ck["lr"], hyper,
+                              zero_world=2, zero_ranks=[d], write_model=(d == 0), shapes=shapes, job_world=4, dp_ranks=[d])
+        else:
+            C.save_checkpoint(out, cfg.model, None, None, None, None, ck["adam_step"], ck["scaler"], ck["lr"], hyper, zero_world=2, shapes=shapes, job_world=4, dp_ranks=[d],
+                              plans_only=True)
+    assert sorted(os.listdir(out)) == gold[0]["files"]
+    for g in gold:
+        assert C._load(os.path.join(ref, g["rank_unique_id"])) == C._load(os.path.join(out, g["rank_unique_id"]))
+    for z in (0, 1):
+        _cmp_optimizer_files(C, os.path.join(ref, f"optimizer_tp0_pp0_zo{z}.pt"), os.path.join(out, f"optimizer_tp0_pp0_zo{z}.pt"))
+    assert C.remove_stale_shards(out, 2, 1, job_world=4) == [] and len(C.remove_stale_shards(out, 2, 1)) == 4   # (the plan files name the job's world size)
     cfg.train.micro_num = 4 * c["micro_num"]
     tr = OracleTrainer(cfg, torch.bfloat16)
     tr.load_state(ck)

@@ -806,6 +806,80 @@ def test_forward_only_pass_under_pipeline_parallelism(dev, backend):
     assert abs(l0 - want) <= 1e-3 * want and abs(m0["acc"] - wm["acc"]) <= 5e-3 and abs(m0["perplexity"] - wm["perplexity"]) <= 1e-2 * wm["perplexity"]
 
 
+def _hz_ckpt_worker(rank, world, port, q, folder):
+    import json
+
+    import torch.distributed as dist
+
+    dev = _init_dist(rank, world, port)
+    try:
+        from internevo_amd.config import tiny
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.engine import InternLM2Engine
+
+        G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        gold = json.load(open(os.path.join(G, f"ckpt_dp4_zo2_rank{rank}.json")))
+        c = gold["config"]
+        cfg = tiny(c["hidden"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], c["seq_len"], c["micro_num"], 1e-3, c["total_steps"])
+        eng = InternLM2Engine(cfg, dev, None, world, rank, seed=3 + rank, zero_size=2)
+        eng.load_checkpoint(os.path.join(G, "ckpt_ref_dp4_zo2"))
+        eng.save_checkpoint(folder)            # straight back: the reference's file set
+        loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=rank, data_world_size=world))
+        for _ in range(gold["saved_after_step"]):
+            next(loader)
+        out = []
+        for _ in range(2):
+            batch, labels = next(loader)
+            lr = eng.lr_sched.lr()
+            loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            out.append((float(loss), float(st.grad_norm), lr, float(st.loss_scale)))
+        q.put((rank, out, [w["loss"] for w in gold["steps"][gold["saved_after_step"]:]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.ranks(4)
+def test_hybrid_zero_checkpoint_of_the_reference_resumes_and_is_written_back(dev, backend, tmp_path):
+    """Hybrid ZeRO (parallel.zero1.size = 2 under four data-parallel ranks) against a REAL four-process reference checkpoint (tests/golden/ckpt_ref_dp4_zo2/): the four
+    ranks load it, write it straight back -- two optimizer shards and the model from the first zero group, ONE plan file per data-parallel rank named after the job's
+    four ranks (`gpus-4_..._dp-{d}_..._zo-{d % 2}.pt`, hybrid_zero_optim.py:133-140) -- tensor for tensor the reference's eight files, and train the reference's next
+    two steps (every rank its own loss as the reference logs it, the global gradient norm, lr and loss scale)."""
+    import json
+
+    from internevo_amd import checkpoint as C
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(G, "ckpt_dp4_zo2_rank0.json")))
+    folder = str(tmp_path / "ck_hz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hz_ckpt_worker, args=(r, 4, 29857, q, folder)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(q, procs, 4), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    ref = os.path.join(G, "ckpt_ref_dp4_zo2")
+    assert sorted(os.listdir(folder)) == gold["files"]
+    for d in range(4):
+        fn = f"gpus-4_wp-0_tp-0_dp-{d}_pp-0_zo-{d % 2}.pt"
+        assert C._load(os.path.join(ref, fn)) == C._load(os.path.join(folder, fn))
+    a, b = (torch.load(os.path.join(f, "model_tp0_pp0.pt"), weights_only=False) for f in (ref, folder))
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    for z in (0, 1):
+        oa, ob = (C._load(os.path.join(f, f"optimizer_tp0_pp0_zo{z}.pt")) for f in (ref, folder))
+        assert torch.equal(oa["flat_fp32_weights"][0].detach(), ob["flat_fp32_weights"][0]) and oa["zero_devide_optim_plan"] == ob["zero_devide_optim_plan"]
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa["base_optim_states"]["state"][0][k], ob["base_optim_states"]["state"][0][k]), (z, k)
+    for rank, out, want_loss in res:
+        for (loss, gn, lr, scale), w, wl in zip(out, gold["steps"][gold["saved_after_step"]:], want_loss):
+            print(f"data rank {rank}: resumed loss {loss:.5f} gn {gn:.4f} | reference {wl:.5f} {w['grad_norm']['0_default']:.4f}")
+            assert abs(loss - wl) <= 1e-3 * wl and abs(gn - w["grad_norm"]["0_default"]) <= 2e-2 * gn and abs(lr - w["lr"]) <= 1e-12 and scale == w["loss_scale"]
+
+
 def _pp_ckpt_worker(rank, world, port, q, folder, dp, tp=1, chunks=1):
     import json
 
