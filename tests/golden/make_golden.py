@@ -1277,6 +1277,27 @@ def gen_skipper():
     print("skipper.json", len(cases))
 
 
+def gen_beta2():
+    """The real Beta2Scheduler (solver/schedulers/beta2_scheduler.py:7-33) stepping a torch AdamW's betas, for c = 0 (every shipped config), 0.8 (its default) and 0.5
+    -> beta2.json: the beta2 in effect at optimizer step k = 0, 1, ... (the trainer steps the scheduler AFTER the optimizer, core/trainer.py).  Pins schedule.Beta2Scheduler."""
+    sys.path.insert(0, REF)
+    from internlm.solver.schedulers.beta2_scheduler import Beta2Scheduler
+
+    cases = []
+    for init_beta2, c, n in ((0.95, 0.0, 12), (0.95, 0.8, 60), (0.5, 0.8, 12)):
+        p_ = torch.nn.Parameter(torch.zeros(2))
+        opt = torch.optim.AdamW([p_], lr=1e-3, betas=(0.9, init_beta2))
+        sch = Beta2Scheduler(opt, init_beta2=init_beta2, c=c, cur_iter=-1)
+        seq = []
+        for _ in range(n):
+            seq.append(opt.param_groups[0]["betas"][1])   # what the optimizer step about to run uses
+            sch.step()
+        cases.append({"init_beta2": init_beta2, "c": c, "beta2_at_step": seq})
+    with open(os.path.join(OUT, "beta2.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("beta2.json", len(cases))
+
+
 def gen_sched_state():
     """state_dict() of the real FineTuneCosineAnnealingWarmupLR (lr_scheduler.py:28-37,92-131: the __dict__ of torch's _LRScheduler
     wrapper + the after-scheduler's) after n steps, two parameter groups as in the reference's optimizer -> sched_state.json.
@@ -1557,6 +1578,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--sched":
         gen_sched_state()
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--beta2":
+        shim_cpu_accelerator()
+        gen_beta2()
         sys.exit(0)
     if len(sys.argv) >= 2 and sys.argv[1] == "--skipper":
         shim_cpu_accelerator()

@@ -489,3 +489,22 @@ def test_batch_skipper_equals_the_reference_class():
     with pytest.raises(AssertionError):
         BatchSkipper("5-7,2")
 
+
+def test_beta2_scheduler_equals_the_reference_class():
+    """schedule.Beta2Scheduler against the real solver/schedulers/beta2_scheduler.py class driving a torch AdamW (tests/golden/beta2.json, make_golden.py --beta2): the
+    beta2 the optimizer step k uses, for c = 0 (every shipped config), the class default c = 0.8 over 60 steps (it leaves 0.95 at step 43) and a small init value."""
+    import json
+    import os
+
+    from internevo_amd.schedule import Beta2Scheduler
+
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for case in json.load(open(os.path.join(G, "beta2.json"))):
+        sch = Beta2Scheduler(case["init_beta2"], case["c"])
+        got = []
+        for _ in case["beta2_at_step"]:
+            got.append(sch.beta2())
+            sch.step()
+        assert got == case["beta2_at_step"], (case["init_beta2"], case["c"])
+    assert any(b > 0.95 for b in json.load(open(os.path.join(G, "beta2.json")))[1]["beta2_at_step"])
+
