@@ -388,6 +388,13 @@ int ie_tune_flash_dkdv_split(int split);
 /* Tuning hooks (A/B benchmarking, tools/kbench): kernel variant of the attention forward / backward (0 = default). */
 int ie_tune_flash_fwd_variant(int variant);
 int ie_tune_flash_bwd_variant(int variant);
+/* The five-product attention backward (ie_tune_flash_bwd_variant bit 1; opt-in): the dK/dV kernel also writes dS^T (bf16, 2 bytes per visible
+ * (query, key) pair) and dQ is formed from it instead of recomputing S and dP a second time.  It needs a caller-owned buffer of
+ * ie_flash_attn_bwd_spill_bytes(nseq, max_seqlen, hq, causal) bytes, 1-KiB aligned, handed over (and taken back with NULL, 0) by
+ * ie_flash_attn_bwd_set_spill; without one that is large enough ie_flash_attn_bwd runs its default seven-product path.  Same results to
+ * bf16 rounding, deterministic; measured 2-4 % faster than the default at 4 x 4096 tokens and not the default: profiles/r05_flash_bwd_spill.md. */
+int64_t ie_flash_attn_bwd_spill_bytes(int nseq, int max_seqlen, int hq, int causal);
+int ie_flash_attn_bwd_set_spill(void* buf, int64_t bytes);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

@@ -124,6 +124,8 @@ SIGNATURES = {
     "ie_moe_gate_bwd": (I, [P, I64, P, P, P, P, P, P, P, F, I64, I, I, P, P, I64, P, I, P, P]),
     "ie_tune_flash_fwd_variant": (I, [I]),
     "ie_tune_flash_bwd_variant": (I, [I]),
+    "ie_flash_attn_bwd_spill_bytes": (I64, [I, I, I, I]),
+    "ie_flash_attn_bwd_set_spill": (I, [P, I64]),
     "ie_flash_attn_bwd_workspace": (I64, [I64, I, I, I]),
     "ie_mfma_probe": (I, [P, P, P, P]),
 }

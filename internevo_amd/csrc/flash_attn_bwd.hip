@@ -41,6 +41,10 @@
 #ifndef IE_FLASH_ABLATE
 #define IE_FLASH_ABLATE 0
 #endif
+// cache policy of the dS^T spill stores (A/B builds): "" default, " nt" non-temporal, " sc0 sc1" write-through
+#ifndef IE_SPILL_MOD
+#define IE_SPILL_MOD ""
+#endif
 #if IE_DKDV_TIMING
 __device__ unsigned long long g_dkdv_t[8];
 // (the wait makes the stamp's registers valid before hipcc may copy or reuse them -- without it the late result lands in whatever the register
@@ -203,18 +207,7 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
         if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
-    if (q_valid) {
-        bf16_t* op = dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D;
-#pragma unroll
-        for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack2bf(dqacc[db][4 * g + 0] * scale, dqacc[db][4 * g + 1] * scale);
-                w.y = pack2bf(dqacc[db][4 * g + 2] * scale, dqacc[db][4 * g + 3] * scale);
-                st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
-            }
-    }
+    store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,13 +222,28 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // to part[2][HS][T][hkv][D]; flash_dkdv_reduce_k sums them in a fixed order (deterministic, no atomics).  With all blocks
 // resident at once the kernel takes as long as its heaviest block (key block 0 sees every query tile: 2x the mean); HS x more,
 // HS x smaller blocks dispatched heavy-first let the light ones back-fill the tail.
-template <int D, bool CAUSAL, int HS, int DKV_WAVES>
+//
+// SPILL (round 5): the kernel also writes dS^T = P^T o (dP^T - delta), the bf16 fragments it feeds its own dK product with, to `ds_ws`, and
+// flash_dq_from_ds_k forms dQ = scale * dS K from them: five tile products for the whole backward instead of seven (flash_dq_k recomputes S and
+// dP), paid for with 2 bytes per visible (query, key) pair written here and read there.  Layout: per (sequence, q head) a triangle (causal) or
+// rectangle of 8-KiB IMAGES, one per (query tile of 64, key block of 64): image (qt, kb) at index qt (qt + 1) / 2 + kb (causal) or
+// qt * nq_max + kb, `ds_head_stride` bytes per (sequence, head).  An image is copied into LDS linearly by the reader and is laid out for BOTH
+// sides: (a) every store instruction of this kernel writes one contiguous KiB -- 8 whole cache lines; 32-byte pieces of 32 different lines, the
+// natural [key][query] image, quadrupled the L2's write requests and cost the kernel 19 % (profiles/r05_flash_bwd_spill.md) -- and (b) the
+// reader's transposing reads (ds_read_b64_tr_b16: every lane fetches 8 bytes = one key x four query columns) are bank-conflict free.  The 32
+// keys of a wave own 4 KiB (image half (key >> 5) & 1) in four 1-KiB chunks, one per packed fragment dsf[qs][gp] (registers 8 gp .. 8 gp + 7 of
+// sub-block qs: query rows 32 qs + 16 gp + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)); lane l's 16 bytes sit at position l ^ ((l >> 5) << 2) ^ (gp << 3)
+// of the chunk (the XORs spread the 32 lanes of a read over all banks; flash_dq_from_ds_k::DsOffs is the inverse map).  Four 16-byte stores per
+// wave and tile, from inline asm in the gaps of phase C1; the waits of the tile loop count them (vmcnt retires in order on gfx950: the
+// transfers they wait for are older than the stores).
+template <int D, bool CAUSAL, int HS, int DKV_WAVES, bool SPILL = false>
 __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
                                                                int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
                                                                const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale,
-                                                               float* __restrict__ part) {
+                                                               float* __restrict__ part, unsigned char* __restrict__ ds_ws,
+                                                               int64_t ds_head_stride, int nq_max) {
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, -lse/scale [64], -delta [64] (+ pad to keep 1 KiB alignment)
     // Pipeline stages.  Four waves (one block per CU: the registers allow one wave per SIMD) keep FOUR and work EARLY: the transfers of tile
@@ -288,12 +296,20 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     // Every transfer of a stage is issued from inline asm (flash_common.h: issue_piece_asm); the only vmcnt waits of the tile loop are the
     // explicit ones at the end of a tile.  lse2 / delta of the 64 rows: one buffer_load_dword ... lds each (lane = row), wave 0 / wave 1.
     struct Next { int soff_q, soff_do; i32x4 rs_ld; int soff_ld; };
-    // tiles are visited head by head, query tiles ascending; (pl_h, pl_qt) = the next tile to request, advanced without a division
-    int pl_h = h_first, pl_qt = qt_start;
+    // Tiles are visited query tile by query tile, from the LAST one down to the block's diagonal, the q heads of the group inside: every block of
+    // a (sequence, kv head) -- they share an XCD's L2: x % hkv = kv head -- then asks for the same Q / dO tiles in the same order and, dispatched
+    // together, at the same time; a block only stops earlier the later its keys are.  Head by head and upwards from the own diagonal, the order of
+    // rounds 2 - 4, no two blocks were on the same tile: 34 % of the tile requests missed the L2 (profiles/r05_flash_bwd_spill.md).
+    // (pl_h, pl_qt) = the next tile to request, advanced without a division
+#ifndef IE_DKDV_ORDER   // A/B builds: 0 = the old order
+#define IE_DKDV_ORDER 1
+#endif
+    constexpr bool QT_MAJOR = IE_DKDV_ORDER != 0;
+    int pl_h = h_first, pl_qt = QT_MAJOR ? nqt_all - 1 : qt_start;
     auto plan = [&]() {
         Next n;
         const int h = min(pl_h, hq - 1);   // the requests behind the last tile may name a head this block does not own: any valid address will do
-        const int q0 = pl_qt * 64;
+        const int q0 = max(pl_qt, qt_start) * 64;   // (likewise a query tile behind the block's last one)
         n.soff_q = q0 * qsrc.ts2 + h * D * 2;
         n.soff_do = q0 * dosrc.ts2 + h * D * 2;
         const float* lp = ((wave & 1) ? delta : lse) + (int64_t)h * T + tok0;   // even waves fetch -lse/scale, odd waves -delta (every wave one
@@ -302,7 +318,8 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         n.rs_ld[2] = len * 4;
         n.rs_ld[3] = 0x00020000;
         n.soff_ld = q0 * 4;
-        if (++pl_qt == nqt_all) { pl_qt = qt_start; ++pl_h; }
+        if (QT_MAJOR) { if (++pl_h == h_first + grp) { pl_h = h_first; --pl_qt; } }
+        else if (++pl_qt == nqt_all) { pl_qt = qt_start; ++pl_h; }
         return n;
     };
     auto issue_ld = [&](const Next& n, uint32_t stage_lds) {   // one buffer_load_dword ... lds (lane = row) per wave
@@ -381,13 +398,34 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     constexpr int SPAN = EARLY ? 2 * KS : KS;       // piece slots per image: EARLY Q over A0 + A1, dO over C0 + C1; else Q over A0, dO over A1
     // The head of a tile -- its first row fragments, the starting values of S0 / dP0 and their mask -- is state carried into step():
     // requested at the top of the tile (two stages) or under the previous tile's C1 MFMAs (EARLY).
-    struct TileInfo { int q0; bool need_mask; int first_rel; };
-    int cur_qt = qt_start;   // query tile the next tile_info() describes
+    struct TileInfo { int q0; bool need_mask; int first_rel; const unsigned char* sp; };   // sp: SPILL, the image of this tile for this wave's keys
+    int cur_qt = QT_MAJOR ? nqt_all - 1 : qt_start, cur_h = h_first;   // query tile / q head the next tile_info() describes
     const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
+    // SPILL: the image of (head, query tile) for this wave's keys.  (A four-wave block's upper key half above the diagonal tile is all zeros and has no
+    // image of its own: it goes to the spare image that ends every head's region -- the counted waits want the same number of stores from every wave
+    // and tile.)  Recomputed once per query tile, advanced by one head's region in between: the scalar instructions of an address per store cost
+    // the lone wave of a SIMD 8 % of the kernel (in-order issue: every one of them is a slot in front of the next MFMA).
+    const int sp_kb = (k0 + 32 * wave) >> 6;
+    auto sp_image = [&](int h, int qt) {
+        const int64_t img_off = (CAUSAL && sp_kb > qt) ? ds_head_stride - 8192
+                                                        : (CAUSAL ? (int64_t)qt * (qt + 1) / 2 + sp_kb : (int64_t)qt * nq_max + sp_kb) * 8192;
+        return (const unsigned char*)ds_ws + ((int64_t)seq * hq + h) * ds_head_stride + img_off;
+    };
+    const unsigned char* sp_cur = SPILL ? sp_image(cur_h, cur_qt) : nullptr;
     auto tile_info = [&]() {
         TileInfo ti;
         ti.q0 = cur_qt * 64;
-        if (++cur_qt == nqt_all) cur_qt = qt_start;
+        ti.sp = sp_cur;
+        if (QT_MAJOR) {
+            if (++cur_h == h_first + grp) {
+                cur_h = h_first;
+                cur_qt = max(cur_qt - 1, qt_start);
+                if (SPILL) sp_cur = sp_image(cur_h, cur_qt);
+            } else if (SPILL) sp_cur += ds_head_stride;
+        } else {
+            if (++cur_qt == nqt_all) { cur_qt = qt_start; ++cur_h; }
+            if (SPILL) sp_cur = sp_image(min(cur_h, hq - 1), cur_qt);
+        }
         ti.need_mask = (CAUSAL && kw0 + 31 > ti.q0) || (kw0 + 32 > len);   // wave-uniform: the diagonal tile, the last keys
         ti.first_rel = first_q - ti.q0 - rl_lane;                           // first visible row, tile-local, relative to this lane's registers 0 .. 3
         return ti;
@@ -400,6 +438,25 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     auto base = [&](int si) { return smem + (si % 2) * STAGE; };
     auto offs = [&](int si) -> const FragOffs<D>& { return si >= 2 ? foh : fo; };
     const int bias_lane[2] = {rl_lane * 4, rl_lane * 4 + 2 * STAGE};
+    // SPILL: this lane's four 16-byte slots inside an image, and the image of (head, query tile) for this wave's keys
+    int sp_off[2][2];
+    if (SPILL) {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+                sp_off[qs][gp] = ((my_k >> 5) & 1) * 4096 + (2 * qs + gp) * 1024 + ((lane ^ ((lane >> 5) << 2) ^ (gp << 3)) << 4);
+    }
+    // store i = 0 .. 3 of a tile: fragment gp = i & 1 of sub-block qs = i >> 1 (one store per MFMA gap: a 1-KiB store takes the wave's issue for
+    // about as long as a transfer piece does)
+    auto spill_one = [&](const TileInfo& t, const s16x8& frag, int i) {
+        if (!SPILL) return;
+        asm volatile("global_store_dwordx4 %0, %1, %2" IE_SPILL_MOD :: "v"(sp_off[i >> 1][i & 1]), "v"(frag), "s"(t.sp) : "memory");
+    };
+#ifndef IE_SPILL_NFRAG   // A/B builds (results wrong below 4): how many of the four fragments of a tile are stored
+#define IE_SPILL_NFRAG 4
+#endif
+    constexpr int NSPILL = (SPILL && !EARLY) ? IE_SPILL_NFRAG : 0;   // stores of this tile still counted at its wait (EARLY waits in front of C1, where they are issued)
     auto fetch_rows = [&](int si, int u) {   // u = 0 .. 2 KS - 1: k-step u % KS of sub-block u / KS
         if (IE_FLASH_ABLATE & 4) return;
         rq[u % R] = row_frag<D>(base(si), 32 * (u / KS), u % KS, offs(si));
@@ -577,7 +634,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         if (EARLY && !(IE_FLASH_ABLATE & 32)) {
             // EARLY: the next tile's pieces (requested a tile ago) have landed -- only this tile's, all younger, may still be in flight -- and
             // every wave is done with the previous tile's stage.  The next tile's head goes under the MFMAs of C1.
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(pieces_before(3 * KS)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(pieces_before(3 * KS) + NSPILL) : "memory");
             __syncthreads();
         }
         if (EARLY) ti = tile_info();
@@ -595,14 +652,18 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             MO(dvacc[m % G::DB], tfa[m % LT], pf1[m / G::DB]);
             MO(dkacc[m % G::DB], tfb[m % LT], dsf1[m / G::DB]);
             __builtin_amdgcn_sched_barrier(0);
+            if (SPILL && rep == 0 && m % (NTR / 4) == 0) {   // the four dS^T stores of this tile, spread over C1's gaps (they carry nothing else but fragment reads)
+                const int i = m / (NTR / 4);
+                if (i < IE_SPILL_NFRAG) spill_one(tc, i == 0 ? dsf0[0] : i == 1 ? dsf0[1] : i == 2 ? dsf1[0] : dsf1[1], i);
+            }
             if (m + LT < NTR) fetch_tr(m + LT, 1);
             if (EARLY && rep == 0 && m == NTR - 1) apply_mask(ti, s0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         IE_STAMP(5);
         if (!EARLY && !(IE_FLASH_ABLATE & 32)) {
-            // the next tile's pieces have landed; every wave is done with this tile's stage
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the next tile's pieces have landed (the spill stores behind them may still be on their way); every wave is done with this tile's stage
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSPILL) : "memory");
             __syncthreads();
         }
 #if IE_DKDV_TIMING
@@ -644,21 +705,9 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         for (int i = 0; i < 7; ++i) atomicAdd(&g_dkdv_t[i], (unsigned long long)tacc[i]);
 #endif
 
-    if (k_valid && HS == 1) {
-        bf16_t* dkp = dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
-        bf16_t* dvp = dv + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D;
-#pragma unroll
-        for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 a, b;
-                a.x = pack2bf(dkacc[db][4 * g + 0] * scale, dkacc[db][4 * g + 1] * scale);
-                a.y = pack2bf(dkacc[db][4 * g + 2] * scale, dkacc[db][4 * g + 3] * scale);
-                b.x = pack2bf(dvacc[db][4 * g + 0], dvacc[db][4 * g + 1]);
-                b.y = pack2bf(dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
-                st8(dkp + 32 * db + 8 * g + 4 * (lane >> 5), a);
-                st8(dvp + 32 * db + 8 * g + 4 * (lane >> 5), b);
-            }
+    if (HS == 1) {
+        store_row_block<D>(dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);
+        store_row_block<D>(dv + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D, dvacc, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
     }
     if (k_valid && HS > 1) {
         const int64_t row = (((int64_t)hsi * T + tok0 + my_k) * hkv + hk) * D;
@@ -706,12 +755,148 @@ __global__ __launch_bounds__(256) void flash_dkdv_reduce_k(const float* __restri
     st8(dv + tok * dkv_ts + (int64_t)hk * D + c4 * 4, vb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dQ from the spilled dS^T images (SPILL mode of flash_dkdv_k, which describes the layout): dQ^T[d][q] = scale * sum_keys K^T[d][key] dS^T[key][q].
+// One block = 4 waves = the (up to) four q heads of a kv head for one query tile of 64 rows (fewer heads per kv head: the waves split into
+// heads x consecutive query tiles), so one K tile per 64 keys, brought in by all four waves, serves four 8-KiB dS^T images, one per wave, which
+// nobody else ever reads: the kernel streams its operand exactly once and is bound by that stream (2 bytes per visible (query, key) pair;
+// its 8 MFMAs per wave, image and 16-key step are a quarter of what the matrix pipe could do in the time the bytes take).  Three LDS stages,
+// two tiles in flight; every transfer is inline asm (hipcc would drain a transfer it knows about in front of the next LDS read) and the
+// waits count them.  A operand = K^T fragment (lane = d), B operand = dS^T fragment (lane = query column), both by transposing reads with
+// the same key order, so the accumulators are dQ^T blocks in the layout store_row_block() writes (lane = row).
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void flash_dq_from_ds_k(const unsigned char* __restrict__ ds_ws, int64_t ds_head_stride, int nq_max,
+                                                             const bf16_t* __restrict__ k, int64_t kv_ts, bf16_t* __restrict__ dq, int64_t dq_ts,
+                                                             const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale, int gw) {
+    using G = Geo<D>;
+    constexpr int NST = 3;
+    constexpr int KIMG = G::IMG_BYTES, DIMG = 8192;
+    constexpr int STAGE = KIMG + 4 * DIMG;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int seq = blockIdx.z;
+    const int group = hq / hkv, qw = 4 / gw;
+    const int hk = blockIdx.x % hkv, gc = blockIdx.x / hkv;
+    const int qblk = gridDim.y - 1 - blockIdx.y;          // heaviest (last) query tiles first
+    const int tok0 = cu[seq];
+    const int len = cu[seq + 1] - tok0;
+    if (qblk * qw * 64 >= len) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = hk * group + gc * gw + (wave % gw);
+    const int qt = qblk * qw + wave / gw;
+    const int nkb_seq = (len + 63) / 64;
+    const bool wave_on = qt * 64 < len;
+    const int nkb_w = !wave_on ? 0 : (CAUSAL ? qt + 1 : nkb_seq);                          // key blocks this wave works on
+    const int nkb = CAUSAL ? min(qblk * qw + qw, nkb_seq) : nkb_seq;                        // key blocks the block streams
+
+    // (K tiles through registers instead -- buffer_load, ds_write_b128 behind the tile's products -- to take them off the LDS-DMA path did not make
+    // the kernel faster: 525 vs 520 us; profiles/r05_flash_bwd_spill.md)
+    TileSrc<D, 4> ksrc;
+    ksrc.init(k + (int64_t)tok0 * kv_ts + (int64_t)hk * D, kv_ts, T - tok0, D, wave, lane);
+    constexpr int PERW = TileSrc<D, 4>::PERW;
+    constexpr int NP = PERW + 8;                                                            // transfers per wave and tile
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    i32x4 rs;                                                                                // this wave's head: its images
+    {
+        const unsigned char* hb = ds_ws + ((int64_t)seq * hq + h) * ds_head_stride;
+        rs[0] = (int)(uint32_t)(uintptr_t)hb;
+        rs[1] = (int)(((uintptr_t)hb >> 32) & 0xffff);
+        rs[2] = (int)(uint32_t)ds_head_stride;
+        rs[3] = 0x00020000;
+    }
+    const int64_t img0 = CAUSAL ? (int64_t)qt * (qt + 1) / 2 : (int64_t)qt * nq_max;       // first image of this wave's query tile
+    const int lane16 = lane * 16;
+    auto issue_tile = [&](int kb, int st) {   // key block kb -> stage st: this wave's share of the K tile and, if it works on kb, its own dS^T image
+        const uint32_t sb = smem_lds + st * STAGE;
+        const int ksoff = kb * 64 * ksrc.ts2;
+#pragma unroll
+        for (int pq = 0; pq < PERW; ++pq) ksrc.issue_piece_asm(sb, ksoff, wave, pq);
+        if (kb < nkb_w) {
+            const int dsoff = (int)((img0 + kb) * DIMG);
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(sb + KIMG + wave * DIMG + pc * 1024), "v"(lane16), "s"(rs), "s"(dsoff + pc * 1024) : "memory");
+        }
+    };
+    issue_tile(0, 0);
+    if (nkb > 1) issue_tile(1, 1);
+
+    FragOffs<D> fk;
+    fk.init(lane);
+    // B fragment (lane = query column 32 X + (lane & 31), contraction over the keys of 16-key step st in the K^T fragment's order: slot e <-> key
+    // 16 st + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)) from a dS^T image: lane p of a 16-lane group fetches the 8 bytes (key kq = p >> 2; columns
+    // 4 u .. 4 u + 3 of the group's 16, u = p & 3) that writer lane kl + 32 hi stored as half g1 of its fragment gp = a -- see flash_dkdv_k
+    int ds_b0, ds_b1;
+    {
+        const int gq = lane >> 4, hh = gq >> 1, a = gq & 1, pp = lane & 15, kq = pp >> 2, u = pp & 3, g1 = u >> 1, hi = u & 1;
+        const int pos = kq | ((hh ^ hi) << 2) | (a << 3) | (hi << 5);
+        ds_b0 = a * 1024 + 16 * pos + 8 * g1;
+        ds_b1 = ds_b0 ^ 128;   // the second read's keys (+ 8): bit 3 of the position
+    }
+    auto ds_frag = [&](const unsigned char* img, int X, int st) {
+        const unsigned char* base = img + X * 2048 + (st & 1) * 256 + (st >> 1) * 4096;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + ds_b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + ds_b1));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    };
+    f32x16 acc[2][G::DB];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) acc[X][db] = zero16();
+
+    auto tile = [&](auto stage_c, int kb) {
+        constexpr int S = decltype(stage_c)::value;
+        // tile kb has landed (this wave's share); tile kb + 1, if there is one, may still be on its way: K pieces, and the image if the wave works on it
+        if (kb + 1 >= nkb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kb + 1 < nkb_w) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PERW) : "memory");
+        __syncthreads();                                               // ... everybody's share; and every wave is done with tile kb - 1's stage,
+        if (kb + 2 < nkb) issue_tile(kb + 2, (S + 2) % NST);           // which tile kb + 2 goes to
+        if (kb < nkb_w) {
+            const unsigned char* Kimg = smem + S * STAGE;
+            const unsigned char* Dimg = Kimg + KIMG + wave * DIMG;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const s16x8 b0 = ds_frag(Dimg, 0, st), b1 = ds_frag(Dimg, 1, st);
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db) {
+                    const s16x8 a = trans_frag<D>(Kimg, db, st, fk);
+                    acc[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0][db], 0, 0, 0);
+                    acc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1][db], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kb = 0; kb < nkb; kb += NST) {
+        tile(std::integral_constant<int, 0>{}, kb);
+        if (kb + 1 < nkb) tile(std::integral_constant<int, 1>{}, kb + 1);
+        if (kb + 2 < nkb) tile(std::integral_constant<int, 2>{}, kb + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer into this block's LDS may outlive the block
+
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const int qrow = qt * 64 + 32 * X + (lane & 31);
+        const bool valid = wave_on && qrow < len;
+        store_row_block<D>(dq + (int64_t)(tok0 + (valid ? qrow : 0)) * dq_ts + (int64_t)h * D, acc[X], scale, lane, valid, (dq_ts & 7) == 0);
+    }
+}
+
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 int g_dkdv_split = 0;  // 0 = automatic (see dkdv_split), else the forced head split of the dK/dV kernel
 int g_dkdv_waves = 2;  // waves (x 32 keys) per dK/dV block
 int g_dq_minw = 2;  // waves/SIMD the dQ kernel is compiled for (2: 256 VGPRs with a small spill; 1: no spill, half the occupancy)
+int g_bwd_spill = 0;  // 1: five-product backward (dS^T spilled by the dK/dV kernel, dQ formed from it): ie_tune_flash_bwd_variant bit 1, opt-in
+void* g_ds_ws = nullptr;     // the caller's spill buffer (ie_flash_attn_bwd_set_spill)
+int64_t g_ds_ws_bytes = 0;
 
 }  // namespace
 
@@ -784,7 +969,14 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
 #define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
                        (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
-                       softmax_scale, part)
+                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0)
+#define IE_DKDV_SPILL(DD, CA, NW_)                                                                                                 \
+    hipLaunchKernelGGL((flash_dkdv_k<DD, CA, 1, NW_, true>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
+                       softmax_scale, part, (unsigned char*)ds_ws, ds_head_stride, nq_max)
+#define IE_DQ_FROM_DS(DD, CA)                                                                                                      \
+    hipLaunchKernelGGL((flash_dq_from_ds_k<DD, CA>), gds, dim3(256), 0, st, (const unsigned char*)ds_ws, ds_head_stride, nq_max,      \
+                       (const bf16_t*)k, kv_ts, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, gw)
 #define IE_DKDV_HS(DD, CA, HS_)                                                                                                    \
     do {                                                                                                                           \
         if (DKV_WAVES == 4) IE_DKDV_W(DD, CA, HS_, 4);                                                                             \
@@ -813,8 +1005,26 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
                                softmax_scale);                                                                                      \
         IE_DKDV(DD, CA);                                                                                                           \
     } while (0)
-    if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
-    else          { if (causal) IE_L(64, true); else IE_L(64, false); }
+    // five-product path: dK/dV kernel with the dS^T spill, dQ from the spill.  Not with a head split (small problems, where the split is what matters).
+    const int nq_max = (max_seqlen + 63) / 64;
+    const int64_t ds_head_stride = ((causal ? (int64_t)nq_max * (nq_max + 1) / 2 : (int64_t)nq_max * nq_max) + 1) * 8192;
+    if (g_bwd_spill && hs == 1 && ds_head_stride < (1ll << 31) && g_ds_ws && (int64_t)nseq * hq * ds_head_stride <= g_ds_ws_bytes) {
+        void* ds_ws = g_ds_ws;
+        const int group = hq / hkv, gw = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1), qw = 4 / gw;
+        dim3 gds((unsigned)(hkv * (group / gw)), (unsigned)((nq_max + qw - 1) / qw), (unsigned)nseq);
+#define IE_SP(DD, CA)                                                                                                              \
+    do {                                                                                                                           \
+        if (DKV_WAVES == 4) IE_DKDV_SPILL(DD, CA, 4);                                                                              \
+        else IE_DKDV_SPILL(DD, CA, 2);                                                                                             \
+        IE_DQ_FROM_DS(DD, CA);                                                                                                     \
+    } while (0)
+        if (d == 128) { if (causal) IE_SP(128, true); else IE_SP(128, false); }
+        else          { if (causal) IE_SP(64, true); else IE_SP(64, false); }
+#undef IE_SP
+    } else {
+        if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
+        else          { if (causal) IE_L(64, true); else IE_L(64, false); }
+    }
 #undef IE_L
 #undef IE_DKDV
 #undef IE_DKDV_HS
@@ -833,9 +1043,24 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     return ie_launch_status("ie_flash_attn_bwd launch");
 }
 
-// tuning hook (A/B benchmarking only): bits 0-1: 0 = 2 waves x 32 keys per dK/dV block, 1 = 4 waves
+// Spill buffer of the five-product backward (ie_tune_flash_bwd_variant bit 1): bytes for a call with these shapes, and the hook that hands the
+// library a buffer of the caller's (it stays the caller's; NULL / 0 takes it back).  Without a large enough buffer the seven-product path runs.
+extern "C" int64_t ie_flash_attn_bwd_spill_bytes(int nseq, int max_seqlen, int hq, int causal) {
+    if (nseq < 0 || max_seqlen < 0 || hq <= 0) return -1;
+    const int64_t nq = (max_seqlen + 63) / 64;
+    return (int64_t)nseq * hq * ((causal ? nq * (nq + 1) / 2 : nq * nq) + 1) * 8192;
+}
+extern "C" int ie_flash_attn_bwd_set_spill(void* buf, int64_t bytes) {
+    IE_CHECK_ARG((buf == nullptr) == (bytes == 0) && bytes >= 0 && (((uintptr_t)buf) & 1023u) == 0, "ie_flash_attn_bwd_set_spill: a 1-KiB aligned buffer and its size, or NULL and 0");
+    g_ds_ws = buf;
+    g_ds_ws_bytes = bytes;
+    return IE_OK;
+}
+
+// tuning hook (A/B benchmarking only): bit 0: 0 = 2 waves x 32 keys per dK/dV block, 1 = 4 waves; bit 1: the five-product backward (needs a spill buffer)
 extern "C" int ie_tune_flash_bwd_variant(int variant) {
-    IE_CHECK_ARG(variant >= 0 && variant <= 1, "ie_tune_flash_bwd_variant: 0 or 1");
+    IE_CHECK_ARG(variant >= 0 && variant <= 3, "ie_tune_flash_bwd_variant: 0 .. 3");
     g_dkdv_waves = (variant & 1) ? 4 : 2;
+    g_bwd_spill = (variant >> 1) & 1;
     return IE_OK;
 }

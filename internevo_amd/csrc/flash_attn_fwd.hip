@@ -161,20 +161,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
         if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
-    if (q_valid) {
+    {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        bf16_t* op = out + (int64_t)(tok0 + my_q) * o_ts + (int64_t)h * D;
-#pragma unroll
-        for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack2bf(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
-                w.y = pack2bf(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-                st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
-            }
+        store_row_block<D>(out + (int64_t)(tok0 + my_q) * o_ts + (int64_t)h * D, oacc, inv, lane, q_valid, (o_ts & 7) == 0);
         // lse of the SCALED scores in natural log: scale * m + ln(l)
-        if (lane < 32) lse[(int64_t)h * T + tok0 + my_q] = (l_run > 0.f) ? m_run * scale + logf(l_run) : -INFINITY;
+        if (q_valid && lane < 32) lse[(int64_t)h * T + tok0 + my_q] = (l_run > 0.f) ? m_run * scale + logf(l_run) : -INFINITY;
     }
 }
 
@@ -454,21 +445,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_k(const bf16_t* __restrict
 #pragma unroll
         for (int db = 0; db < G::DB; db += 2) mfma_settle_acc(oacc[X][db], oacc[X][db + 1]);
 #pragma unroll
-    for (int X = 0; X < 2; ++X)
-        if (q_valid[X]) {
-            const float inv = l_run[X] > 0.f ? 1.f / l_run[X] : 0.f;
-            bf16_t* op = out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D;
-#pragma unroll
-            for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w;
-                    w.x = pack2bf(oacc[X][db][4 * g + 0] * inv, oacc[X][db][4 * g + 1] * inv);
-                    w.y = pack2bf(oacc[X][db][4 * g + 2] * inv, oacc[X][db][4 * g + 3] * inv);
-                    st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
-                }
-            if (lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_run[X] > 0.f) ? m_run[X] * scale + logf(l_run[X]) : -INFINITY;
-        }
+    for (int X = 0; X < 2; ++X) {
+        const float inv = l_run[X] > 0.f ? 1.f / l_run[X] : 0.f;
+        store_row_block<D>(out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D, oacc[X], inv, lane, q_valid[X], (o_ts & 7) == 0);
+        if (q_valid[X] && lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_run[X] > 0.f) ? m_run[X] * scale + logf(l_run[X]) : -INFINITY;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -808,23 +789,13 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
 #pragma unroll
         for (int db = 0; db < G::DB; db += 2) mfma_settle_acc(oacc[X][db], oacc[X][db + 1]);
 #pragma unroll
-    for (int X = 0; X < 2; ++X)
-        if (q_valid[X]) {
-            const float l_row = xhalf_sum(l_part[X][0] + l_part[X][1]);
-            const float inv = l_row > 0.f ? 1.f / l_row : 0.f;
-            bf16_t* op = out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D;
-#pragma unroll
-            for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w;
-                    w.x = pack2bf(oacc[X][db][4 * g + 0] * inv, oacc[X][db][4 * g + 1] * inv);
-                    w.y = pack2bf(oacc[X][db][4 * g + 2] * inv, oacc[X][db][4 * g + 3] * inv);
-                    st8(op + 32 * db + 8 * g + 4 * (lane >> 5), w);
-                }
-            // natural-log LSE from log2-unit scores: (mhat + log2 l) ln 2
-            if (lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_row > 0.f) ? (mhat[X] + __builtin_amdgcn_logf(l_row)) * kLn2 : -INFINITY;
-        }
+    for (int X = 0; X < 2; ++X) {
+        const float l_row = xhalf_sum(l_part[X][0] + l_part[X][1]);
+        const float inv = l_row > 0.f ? 1.f / l_row : 0.f;
+        store_row_block<D>(out + (int64_t)(tok0 + my_q[X]) * o_ts + (int64_t)h * D, oacc[X], inv, lane, q_valid[X], (o_ts & 7) == 0);
+        // natural-log LSE from log2-unit scores: (mhat + log2 l) ln 2
+        if (q_valid[X] && lane < 32) lse[(int64_t)h * T + tok0 + my_q[X]] = (l_row > 0.f) ? (mhat[X] + __builtin_amdgcn_logf(l_row)) * kLn2 : -INFINITY;
+    }
 }
 
 int g_fwd_variant = -1;  // -1: automatic; 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: 64 rows per wave, THR = 4;

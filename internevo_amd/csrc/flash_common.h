@@ -28,6 +28,7 @@ namespace fa {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -188,6 +189,40 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 __device__ __forceinline__ uint4 z4() { return make_uint4(0, 0, 0, 0); }
+
+// Epilogue store of a transposed 32-row accumulator block set (O^T, dQ^T: lane = row l & 31; dK, dV: lane = key), D / 32 accumulators of 16 registers:
+// registers 4 g .. 4 g + 3 of block db are columns 32 db + 8 g + 4 (l >> 5) + 0 .. 3 of the lane's row, so lanes l and l + 32 hold the two 8-byte halves
+// of every 16-byte group.  Stored as 8 bytes per lane that is D / 8 store instructions per row block and lane, and the store tail of a block is
+// bound by the NUMBER of store instructions (the waves of a block reach it together; cdna_hip_programming.md T21).  Exchanging the halves of two
+// neighbouring groups (g, g + 1) with v_permlane32_swap -- lanes 32 .. 63 of the first operand against lanes 0 .. 31 of the second -- leaves 16
+// contiguous bytes in every lane: lanes < 32 the whole group g, lanes >= 32 the whole group g + 1: half the store instructions, same bytes, same
+// addresses.  `row` = this lane's row (16-byte aligned when `wide`), `mul` = the factor applied before rounding; `valid` must agree between lanes
+// l and l + 32 (it does: they hold the same row); every lane of the wave must reach the call (the exchange runs unpredicated).
+template <int D>
+__device__ __forceinline__ void store_row_block(bf16_t* row, const f32x16 (&acc)[Geo<D>::DB], float mul, int lane, bool valid, bool wide) {
+    if (wide) {
+#pragma unroll
+        for (int db = 0; db < Geo<D>::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const unsigned a0 = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul), a1 = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+                const unsigned b0 = pack2bf(acc[db][4 * g + 4] * mul, acc[db][4 * g + 5] * mul), b1 = pack2bf(acc[db][4 * g + 6] * mul, acc[db][4 * g + 7] * mul);
+                const auto rx = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                if (valid) *reinterpret_cast<uint4*>(row + 32 * db + 8 * g + 8 * (lane >> 5)) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+    } else if (valid) {
+#pragma unroll
+        for (int db = 0; db < Geo<D>::DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+                w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+                st8(row + 32 * db + 8 * g + 4 * (lane >> 5), w);
+            }
+    }
+}
 
 // ---- MFMAs with an explicit register file for every operand (kernels with one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
 // hipcc allocates every MFMA accumulator of a > 256-register kernel in the accumulation file and then copies whatever the vector

@@ -651,6 +651,32 @@ def flash_attn_bwd(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scal
     return dq, dk, dv
 
 
+_spill_buf = None
+
+
+def flash_attn_bwd_spill(enable, nseq=0, max_seqlen=0, hq=0, causal=True, device=None, four_waves=True):
+    """Opt-in five-product attention backward (include/internevo_hip.h: ie_flash_attn_bwd_set_spill): hands the library a spill buffer large enough
+    for calls of this shape (kept alive here) and selects the variant; ``enable=False`` takes both back.  Calls whose shape needs more than the
+    buffer holds run the default path."""
+    global _spill_buf
+    L = _L()
+    if not enable:
+        check(L.ie_tune_flash_bwd_variant(0), "ie_tune_flash_bwd_variant")
+        check(L.ie_flash_attn_bwd_set_spill(None, 0), "ie_flash_attn_bwd_set_spill")
+        _spill_buf = None
+        return 0
+    need = L.ie_flash_attn_bwd_spill_bytes(int(nseq), int(max_seqlen), int(hq), int(bool(causal)))
+    if need < 0:
+        raise ValueError("flash_attn_bwd_spill: bad shape")
+    if _spill_buf is None or _spill_buf.numel() < need or _spill_buf.device != torch.device(device or "cuda"):
+        check(L.ie_flash_attn_bwd_set_spill(None, 0), "ie_flash_attn_bwd_set_spill")
+        _spill_buf = torch.empty(need + 1024, dtype=torch.uint8, device=device or "cuda")
+    off = (-_spill_buf.data_ptr()) % 1024
+    check(L.ie_flash_attn_bwd_set_spill(_spill_buf.data_ptr() + off, need), "ie_flash_attn_bwd_set_spill")
+    check(L.ie_tune_flash_bwd_variant(3 if four_waves else 2), "ie_tune_flash_bwd_variant")
+    return need
+
+
 def mfma_probe(a, b):
     c = torch.empty((32, 32), dtype=torch.float32, device=a.device)
     check(_L().ie_mfma_probe(_p(a), _p(b), _p(c), _stream()), "ie_mfma_probe")

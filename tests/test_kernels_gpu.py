@@ -739,6 +739,53 @@ def test_flash_bwd_four_wave_dkdv_blocks(dev, lens, hq, hkv, d, causal, split):
     assert torch.equal(got[0][1], dk) and torch.equal(got[0][2], dv), "the two block shapes must give bit-identical dK / dV"
 
 
+@pytest.mark.parametrize("lens,hq,hkv,d,causal,four", [
+    ([300, 700, 257], 4, 1, 128, True, False),          # ragged, one kv head for four q heads: a block of the dQ kernel = the four heads of one query tile
+    ([300, 700, 257], 4, 1, 128, True, True),           # ... with four-wave dK/dV blocks (the upper key half above the diagonal goes to the spare image)
+    ([1, 129, 64, 512], 4, 2, 64, True, False),         # a one-token sequence, head dim 64, two q heads per kv head: two query tiles per dQ block
+    ([333, 90], 3, 3, 128, False, True),                # full attention (rectangular image table), one q head per kv head: four query tiles per dQ block
+    ([2100], 8, 2, 128, True, True),                    # more key blocks than LDS stages in both kernels
+    ([64, 65, 127, 128, 129, 5], 2, 1, 128, True, False),
+])
+def test_flash_bwd_five_product_spill_path(dev, lens, hq, hkv, d, causal, four):
+    """The opt-in five-product backward (ie_flash_attn_bwd_set_spill + ie_tune_flash_bwd_variant bit 1): the dK/dV kernel writes dS^T, dQ is formed
+    from it by flash_dq_from_ds_k.  Against the oracle at the flash tests' bounds; dK / dV bit-identical to the default path (the spill changes
+    nothing in their arithmetic); without a buffer the same switch runs the default path."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32)
+    q = bf(torch.randn(T, hq, d, generator=g(190)))
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(191)))
+    do = bf(torch.randn(T, hq, d, generator=g(192)))
+    q32, kv32 = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(q32, kv32, cu, causal)
+    (ref * do.float()).sum().backward()
+    qd, kvd, cud = q.to(dev), kv.to(dev), cu.to(dev)
+    out, lse = K().flash_attn_fwd(qd, kvd[:, 0], kvd[:, 1], cud, max(lens), None, causal)
+    base = [t.clone() for t in K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cud, max(lens), None, causal)]
+    try:
+        assert L.ie_tune_flash_dkdv_split(1) == 0   # (the automatic head split of small problems takes the default path)
+        need = K().flash_attn_bwd_spill(True, len(lens), max(lens), hq, causal, dev, four_waves=four)
+        assert need == L.ie_flash_attn_bwd_spill_bytes(len(lens), max(lens), hq, int(causal)) > 0
+        dq = torch.full((T, hq, d), float("nan"), dtype=torch.bfloat16, device=dev)
+        dq, dk, dv = K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cud, max(lens), None, causal, dq=dq)
+        dq, dk, dv = dq.clone(), dk.clone(), dv.clone()
+        # no buffer: the switch alone must not change the path
+        assert L.ie_flash_attn_bwd_set_spill(None, 0) == 0
+        nobuf = [t.clone() for t in K().flash_attn_bwd(do.to(dev), qd, kvd[:, 0], kvd[:, 1], out, lse, cud, max(lens), None, causal)]
+    finally:
+        K().flash_attn_bwd_spill(False)
+        L.ie_tune_flash_dkdv_split(0)
+    close(dq, q32.grad, 2e-2, 3e-2, "dq (from the spilled dS^T)", rms=FLASH_RMS)
+    close(dk, kv32.grad[:, 0], 2e-2, 3e-2, "dk (spill path)", rms=FLASH_RMS)
+    close(dv, kv32.grad[:, 1], 2e-2, 3e-2, "dv (spill path)", rms=FLASH_RMS)
+    assert torch.isfinite(dq.float()).all()
+    assert torch.equal(nobuf[1], dk) and torch.equal(nobuf[2], dv), "the spill must not change dK / dV"
+    assert torch.equal(nobuf[0], base[0]), "without a buffer the default dQ kernel runs"
+
+
 @pytest.mark.parametrize("scale,norm_head", [(0.1, True), (1.0, True), (0.25, False)])
 @pytest.mark.parametrize("rows,cols,view", [(512, 256, False), (37, 1000, False), (64, 4096, True)])
 def test_head_weight_function_and_embedding_gradient_scale(dev, scale, norm_head, rows, cols, view):

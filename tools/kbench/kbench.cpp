@@ -113,10 +113,19 @@ static Diff diff_f32(const std::vector<float>& a, const std::vector<float>& ref)
 }
 
 static void* g_lib = nullptr;
+static void* g_ref_lib = nullptr;   // IE_REF_LIB=<path>: fwd / bwd reference outputs come from this library (default: the library under test)
 template <class F> static F sym(const char* name) {
     void* p = dlsym(g_lib, name);
     if (!p) {
         fprintf(stderr, "missing symbol %s\n", name);
+        exit(2);
+    }
+    return (F)p;
+}
+template <class F> static F ref_sym(const char* name) {
+    void* p = dlsym(g_ref_lib ? g_ref_lib : g_lib, name);
+    if (!p) {
+        fprintf(stderr, "missing symbol %s in the reference library\n", name);
         exit(2);
     }
     return (F)p;
@@ -241,8 +250,9 @@ static int run_fwd(const Args& a) {
         IE_OKAY(fwd(P.q, (int64_t)a.hq * a.d, P.kv, P.kv + (size_t)a.hkv * a.d, (int64_t)2 * a.hkv * a.d, out, (int64_t)a.hq * a.d, lse, P.cu_d,
                     a.seqs, P.T, P.max_len, a.hq, a.hkv, a.d, scale, a.causal, nullptr));
     };
-    IE_OKAY(tune(0));
-    call();
+    IE_OKAY(ref_sym<tune_t>("ie_tune_flash_fwd_variant")(0));
+    IE_OKAY(ref_sym<fwd_t>("ie_flash_attn_fwd")(P.q, (int64_t)a.hq * a.d, P.kv, P.kv + (size_t)a.hkv * a.d, (int64_t)2 * a.hkv * a.d, out, (int64_t)a.hq * a.d, lse,
+                                                P.cu_d, a.seqs, P.T, P.max_len, a.hq, a.hkv, a.d, scale, a.causal, nullptr));
     HIP_OK(hipDeviceSynchronize());
     const auto ref_o = to_host(out, no);
     const auto ref_l = to_host(lse, nl);
@@ -270,6 +280,18 @@ static int run_bwd(const Args& a) {
     auto bwd = sym<bwd_t>("ie_flash_attn_bwd");
     auto ws = sym<bwd_ws_t>("ie_flash_attn_bwd_workspace");
     auto tune = sym<tune_t>("ie_tune_flash_bwd_variant");
+    {   // variants with bit 1 (five-product backward) need a spill buffer
+        typedef int64_t (*spill_bytes_t)(int, int, int, int);
+        typedef int (*set_spill_t)(void*, int64_t);
+        auto sb = (spill_bytes_t)dlsym(g_lib, "ie_flash_attn_bwd_spill_bytes");
+        auto ss = (set_spill_t)dlsym(g_lib, "ie_flash_attn_bwd_set_spill");
+        if (sb && ss) {
+            const int64_t bytes = sb(a.seqs, P.max_len, a.hq, a.causal);
+            void* buf;
+            HIP_OK(hipMalloc(&buf, (size_t)bytes));
+            IE_OKAY(ss(buf, bytes));
+        }
+    }
     const size_t no = (size_t)P.T * a.hq * a.d, nl = (size_t)a.hq * P.T, nkv = (size_t)P.T * a.hkv * a.d;
     bf16_t* out = dev_alloc<bf16_t>(no);
     float* lse = dev_alloc<float>(nl);
@@ -284,8 +306,9 @@ static int run_bwd(const Args& a) {
         IE_OKAY(bwd(P.dout, qts, P.q, qts, P.kv, P.kv + (size_t)a.hkv * a.d, kvts, out, qts, lse, delta, dq, qts, dkv, dkv + (size_t)a.hkv * a.d, kvts,
                     P.cu_d, a.seqs, P.T, P.max_len, a.hq, a.hkv, a.d, scale, a.causal, nullptr));
     };
-    IE_OKAY(tune(0));
-    call();
+    IE_OKAY(ref_sym<tune_t>("ie_tune_flash_bwd_variant")(0));
+    IE_OKAY(ref_sym<bwd_t>("ie_flash_attn_bwd")(P.dout, qts, P.q, qts, P.kv, P.kv + (size_t)a.hkv * a.d, kvts, out, qts, lse, delta, dq, qts, dkv,
+                                                dkv + (size_t)a.hkv * a.d, kvts, P.cu_d, a.seqs, P.T, P.max_len, a.hq, a.hkv, a.d, scale, a.causal, nullptr));
     HIP_OK(hipDeviceSynchronize());
     const auto ref_dq = to_host(dq, no);
     const auto ref_dkv = to_host(dkv, 2 * nkv);
@@ -383,6 +406,13 @@ int main(int argc, char** argv) {
     if (!g_lib) {
         fprintf(stderr, "dlopen(%s): %s\n", lib.c_str(), dlerror());
         return 2;
+    }
+    if (const char* rp = getenv("IE_REF_LIB")) {
+        g_ref_lib = dlopen(rp, RTLD_NOW | RTLD_LOCAL);
+        if (!g_ref_lib) {
+            fprintf(stderr, "dlopen(%s): %s\n", rp, dlerror());
+            return 2;
+        }
     }
     g_last_error = sym<last_error_t>("ie_last_error");
     HIP_OK(hipSetDevice(0));
