@@ -351,24 +351,25 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes): measured ratio to the algorithmic bytes x this run's algorithmic bytes
         traffic, traffic_note = None, None
         try:
-            # round 4: measured on THIS workload -- two PMC passes of bench.py itself, every GEMM launch of the step as it runs (tools/gemm_traffic_in_step.py);
-            # falls back to the round-2 ratio of the 16 384-row shapes (kbench launches) when that file is absent
-            with open(os.path.join(ROOT, "profiles", "r04_gemm_hbm_traffic.json")) as f:
+            # measured on THIS workload -- two PMC passes of bench.py itself, every GEMM launch of the step as it runs (tools/gemm_traffic_in_step.py) --
+            # and only reported if the measurement is of the kernels THIS run launched (ie_gemm_last_kernel after every timed launch): a file of other
+            # schedules is refused (traffic: null), never passed on as this run's number
+            TRAFFIC_FILE = "r05_gemm_hbm_traffic.json"
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                 tj = json.load(f)
-            traffic = float(tj["traffic_bytes_per_launch"])
-            traffic_note = (f"{traffic / (s['bytes'] / max(s['launches'], 1)):.2f}x the algorithmic bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                            f"bench.py itself ({tj['gemm_launches']} GEMM launches of three steps, the kernels the step runs incl. the fused-gate w1|w3 product; "
-                            "profiles/r04_gemm_hbm_traffic.json -- a committed measurement of this workload, not re-measured by this run; fabric-side L2 misses "
-                            "incl. Infinity-Cache hits, FETCH_SIZE doubled per MI355X_MICROARCH.md)")
-        except (OSError, KeyError, ValueError):
-            try:
-                with open(os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")) as f:
-                    tj = json.load(f)
-                traffic = tj["traffic_over_algorithmic"] * s["bytes"] / max(s["launches"], 1)
-                traffic_note = (f"{tj['traffic_over_algorithmic']}x the algorithmic bytes per launch, from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE "
-                                "(profiles/r02_gemm_hbm_traffic.json, 16 384-row shapes, kbench launches -- a committed measurement, not re-measured by this run)")
-            except (OSError, KeyError, ValueError):
-                pass
+            measured = {k.replace("void ", "").strip() for k in tj["kernels"]}
+            seen = set(s["kernels"])
+            if measured != seen:
+                traffic_note = (f"profiles/{TRAFFIC_FILE} is not a measurement of this run's kernels (measured only: {sorted(measured - seen)}; launched only: "
+                                f"{sorted(seen - measured)}): no traffic reported -- re-measure with tools/gemm_traffic_in_step.py")
+            else:
+                traffic = float(tj["traffic_bytes_per_launch"])
+                traffic_note = (f"{traffic / (s['bytes'] / max(s['launches'], 1)):.2f}x the algorithmic bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                                f"bench.py itself ({tj['gemm_launches']} GEMM launches of three steps; profiles/{TRAFFIC_FILE}: the same {len(seen)} kernel instantiations this run "
+                                "launched, checked by name -- a committed measurement of this workload, not re-measured by this run; fabric-side L2 misses incl. "
+                                "Infinity-Cache hits, FETCH_SIZE doubled per MI355X_MICROARCH.md)")
+        except (OSError, KeyError, ValueError) as e:
+            traffic_note = f"no HBM-traffic measurement available ({type(e).__name__})"
         out["roofline"] = {
             "kernel": "gemm_dma_k<256,256,...> / <128,128,...> (LDS-DMA bf16 GEMM; fwd: one wave per SIMD, operand-wise refill of two 64-deep stages, v_mfma_f32_16x16x32_bf16, also the long dgrads (B by transposing reads); other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
             "bound": "mfma",
@@ -380,6 +381,7 @@ def main():
             "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": s["bytes"] / max(s["launches"], 1),
             "launches": s["launches"],
+            "kernels": s["kernels"],
             "avg_launch_us": s["avg_us"],
             "algorithmic_flops_per_launch": s["flops"] / max(s["launches"], 1),
             "share_of_step_time": s["seconds"] / dt,

@@ -376,6 +376,11 @@ int ie_moe_gate_bwd(const void* x, int64_t x_ld, const float* wg, const float* g
                     int M, int E, float* d_logits, void* dx, int64_t dx_ld, float* d_wg, int accumulate_d_wg, float* workspace,
                     void* stream);
 
+/* Diagnostic: the kernel instantiation the last GEMM launch of this process went to, spelled as rocprofv3 prints it ("gemm_dma_k<256, 256, 2, 2,
+ * false, true, -5, 0>"); bench.py compares the set it sees with the kernels of the committed HBM-traffic measurement.  ie_gemm_note_kernel is the
+ * library's own recorder (exported because two translation units share it). */
+int ie_gemm_last_kernel(char* buf, int n);
+int ie_gemm_note_kernel(int kind, int bm, int bn, int wm, int wn, int a_kmajor, int b_kmajor, int schedule, int epilogue);
 /* Tuning hook: tile rows per group of the LDS-DMA GEMMs' XCD-aware tile order (0 = default 4). */
 int ie_tune_gemm_group(int tile_rows_per_group);
 /* Tuning hook: the automatic GEMM's tail split (0 = off [default: neutral inside the training step], 1 = on: remainder tiles by

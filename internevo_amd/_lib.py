@@ -122,6 +122,8 @@ SIGNATURES = {
     "ie_moe_dispatch_bwd": (I, [P, P, P, I64, I, P, I64, P]),
     "ie_moe_dwg_workspace": (I64, [I, I]),
     "ie_moe_gate_bwd": (I, [P, I64, P, P, P, P, P, P, P, F, I64, I, I, P, P, I64, P, I, P, P]),
+    "ie_gemm_last_kernel": (I, [c_char_p, I]),
+    "ie_gemm_note_kernel": (I, [I, I, I, I, I, I, I, I, I]),
     "ie_tune_flash_fwd_variant": (I, [I]),
     "ie_tune_flash_bwd_variant": (I, [I]),
     "ie_flash_attn_bwd_spill_bytes": (I64, [I, I, I, I]),

@@ -27,6 +27,7 @@
 extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
                                   int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt);
 
+extern "C" int ie_gemm_note_kernel(int kind, int bm, int bn, int wm, int wn, int akm, int bkm, int sp, int epi);
 extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* h13,
                                          int64_t ld_h13, void* act, int64_t ld_act, int64_t M, int64_t F, int64_t K, void* stream);
 extern "C" int ie_swiglu_fwd(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, void* stream);
@@ -299,6 +300,7 @@ void launch_shape(int a_km, int b_km, hipStream_t st, const bf16_t* A, int64_t l
                   int M, int N, int K, int accumulate) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid((unsigned)(tiles_m * tiles_n)), block(64 * WM_ * WN_);
+    ie_gemm_note_kernel(2, BM, BN, WM_, WN_, a_km != 0, b_km != 0, 0, 0);
 #define IE_L(AK, BKM) \
     hipLaunchKernelGGL((gemm_bf16_k<BM, BN, WM_, WN_, AK, BKM>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, tiles_m, tiles_n)
     if (a_km) { if (b_km) IE_L(true, true); else IE_L(true, false); }

@@ -474,6 +474,8 @@ class KernelProfiler:
         self.flops = 0.0
         self.bytes = 0.0
         self._s = None
+        self.kernels = set()          # the kernel instantiations the timed launches went to (ie_gemm_last_kernel)
+        self._buf = ctypes.create_string_buffer(128)
 
     def begin(self):
         self._s = torch.cuda.Event(enable_timing=True)
@@ -485,12 +487,14 @@ class KernelProfiler:
         self.pairs.append((self._s, e))
         self.flops += flops
         self.bytes += nbytes
+        if _L().ie_gemm_last_kernel(self._buf, 128) == 0:
+            self.kernels.add(self._buf.value.decode())
 
     def summary(self):
         torch.cuda.synchronize()
         sec = sum(s.elapsed_time(e) for s, e in self.pairs) * 1e-3
         n = len(self.pairs)
-        return {"launches": n, "seconds": sec, "avg_us": sec / max(n, 1) * 1e6, "flops": self.flops, "bytes": self.bytes}
+        return {"launches": n, "seconds": sec, "avg_us": sec / max(n, 1) * 1e6, "flops": self.flops, "bytes": self.bytes, "kernels": sorted(self.kernels)}
 
 
 GEMM_PROFILER = None

@@ -33,17 +33,10 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity, top_k=2):
 
 class MoELayer:
     def __init__(self, hidden, ffn, num_experts, tokens, device, capacity_factor=1.0, min_capacity=4, seed=0, layer_index=0, ep_group=None,
-                 ep_size=1, ep_rank=0, expert_fp8=False):
+                 ep_size=1, ep_rank=0):
         """tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
         backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F].
-        expert_fp8 (opt-in; the reference has no fp8 linear): the two FORWARD products of every expert run on e4m3 operands
-        (ie_gemm_fp8: per-tensor dynamic scales per expert block and per expert weight, fp32 accumulation, bf16 results); the backward keeps the bf16 weights and
-        the saved bf16 activations (straight-through).  Needs hidden % 128 == 0 and ffn % 128 == 0.  An expert's quantised weights are kept until
-        invalidate_fp8() (the engine calls it after every optimizer step)."""
-        if expert_fp8 and (hidden % 128 or ffn % 128):
-            raise ValueError(f"expert_fp8: hidden ({hidden}) and ffn ({ffn}) must be multiples of 128 (one LDS row of e4m3 values)")
-        self.fp8 = bool(expert_fp8)
-        self._wq, self._qa = {}, {}   # quantised weights (until invalidate_fp8) / the quantised-activation buffers
+        (The fp8 expert route of round 4 was removed in round 5: it lost 3 % in the step; the e4m3 product itself stays in the library, kernels.gemm_fp8.)"""
         if not 2 <= num_experts <= 16:
             raise NotImplementedError("2 <= num_experts <= 16")
         if num_experts % ep_size:
@@ -126,25 +119,8 @@ class MoELayer:
         return self.l_aux
 
     def _products(self, a, w, out, which):
-        """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch: bf16, or (expert_fp8) the e4m3 products of the blocks quantised now (a scale
-        per expert block) and the weights quantised since the last invalidate_fp8() (a scale per expert)."""
-        if not self.fp8:
-            K.gemm_batched(a, w, out)
-            return
-        El, C, Kd = a.shape
-        key = (which, w.data_ptr())
-        if key not in self._wq:
-            self._wq[key] = K.fp8_quantize(w, per_slice=True)
-        buf = self._qa.get(which)
-        if buf is None or buf[0].shape != a.shape:
-            f32 = dict(dtype=torch.float32, device=a.device)
-            buf = self._qa[which] = (torch.empty(a.shape, dtype=torch.uint8, device=a.device), torch.empty(El, **f32), torch.empty(El, **f32))
-        qa, da = K.fp8_quantize(a, per_slice=True, out=buf)
-        K.gemm_fp8_batched(qa, da, *self._wq[key], out)
-
-    def invalidate_fp8(self):
-        """The expert weights have changed (optimizer step, checkpoint load): quantise them again at the next forward."""
-        self._wq = {}
+        """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch."""
+        K.gemm_batched(a, w, out)
 
     def backward(self, dout, wg, w13, w2, dx, d_wg, d_w13, d_w2, accumulate, loss_scale_dev=None, aux_factor=0.0):
         """dout bf16 [S, M] -> dx bf16 [S, M] (overwritten).  d_wg fp32 [E, M], d_w13 / d_w2 bf16 like the weights: written, or added to

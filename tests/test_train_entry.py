@@ -94,10 +94,15 @@ def test_train_entry_runs_saves_and_resumes(dev, tmp_path):
 
     shutil.rmtree(os.path.join(folder, "4"))       # ("2" is the latest complete checkpoint now)
     cfg3 = tmp_path / "cfg3.py"
-    cfg3.write_text(CFG.format(steps=4, save=False, folder=folder, load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
+    cfg3.write_text(CFG.format(steps=4, save=True, folder=folder, load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
     run3 = train.main(["--config", str(cfg3), "--launcher", "torch"], log=lines.append)
     assert [r["step"] for r in run3] == [2, 3] and any("Found latest ckpt" in ln and ln.rstrip(".").endswith("step: 2") for ln in lines)
     assert [(r["loss"], r["grad_norm"]) for r in run3] == [(r["loss"], r["grad_norm"]) for r in run2]
+    # ... and with saving disabled the reference drops save_ckpt_folder (initialize/launch.py:219-225): auto_resume finds nothing there and starts a new run
+    cfg3b = tmp_path / "cfg3b.py"
+    cfg3b.write_text(CFG.format(steps=2, save=False, folder=folder, load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
+    run3b = train.main(["--config", str(cfg3b), "--launcher", "torch"], log=lines.append)
+    assert [r["step"] for r in run3b] == [0, 1], "enable_save_ckpt=False: old checkpoints under save_ckpt_folder are not resumed from"
     cfg4 = tmp_path / "cfg4.py"
     cfg4.write_text(CFG.format(steps=2, save=False, folder=str(tmp_path / "empty"), load=_load_info(str(tmp_path / "nowhere"))).replace(", auto_resume=False", ""))
     run4 = train.main(["--config", str(cfg4), "--launcher", "torch"], log=lines.append)

@@ -45,7 +45,8 @@ def _local(path):
 def resolve_load(ck, log=lambda m: None):
     """What a run starts from, as CheckpointManager.__init__ decides it (checkpoint_manager.py:296-305, initialize/legacy/launch.py:10-41):
     `auto_resume` (default TRUE -- also when the key is absent and `load_given_ckpt` is not set) overrides `load_ckpt_info` with the LATEST complete checkpoint
-    under `save_ckpt_folder` (the folder holding the largest `{step}.step` flag), content "all" -- and with nothing when there is none: a new run;
+    under `save_ckpt_folder` (the folder holding the largest `{step}.step` flag), content "all" -- and with nothing when there is none or when
+    `enable_save_ckpt` is off (launch.py then drops the folder): a new run;
     otherwise `load_ckpt_info` = dict(path, content, ckpt_type), or the legacy `load_ckpt_folder` / `load_model_only_folder` keys.
     -> (local folder or None, model_only)."""
     from internevo_amd.checkpoint import latest_checkpoint
@@ -54,7 +55,10 @@ def resolve_load(ck, log=lambda m: None):
     if auto is None:
         auto = not ck["load_given_ckpt"] if ck.get("load_given_ckpt", None) is not None else True
     if auto:
-        folder, step = latest_checkpoint(_local(ck.get("save_ckpt_folder")))
+        # (initialize/launch.py:189-225: enable_save_ckpt defaults to True, and with saving disabled save_ckpt_folder is overwritten with None -- the
+        # latest-checkpoint query then finds nothing and auto_resume starts a NEW run, whatever an old folder of that name holds)
+        saving = bool(ck.get("enable_save_ckpt", True))
+        folder, step = latest_checkpoint(_local(ck.get("save_ckpt_folder")) if saving else None)
         log(f"Found latest ckpt {folder if folder else 'None'}, step: {step if folder else -1}...")
         return folder, False
     info = ck.get("load_ckpt_info", None)
