@@ -393,6 +393,23 @@ int ie_tune_flash_dkdv_split(int split);
 /* Tuning hooks (A/B benchmarking, tools/kbench): kernel variant of the attention forward / backward (0 = default). */
 int ie_tune_flash_fwd_variant(int variant);
 int ie_tune_flash_bwd_variant(int variant);
+/* Ring attention (the sequence-parallel attention whose K / V blocks travel around the ranks; internevo_amd/seqpar.py -- the reference has no
+ * such mode, the result to match is DistributedAttention's, multi_head_attention.py:56-135): the block = full attention of a rectangle of scores
+ * per sequence, queries cu_q[s] .. cu_q[s + 1] (of Tq rows) against keys cu_k[s] .. cu_k[s + 1] (of Tk rows); a sequence without keys gives out = 0,
+ * lse = -inf.  The backward takes the lse / out the probabilities are normalised with (for one block: the MERGED lse / out of the whole row, which
+ * makes its dq / dk / dv the block's additive share of the whole gradient); dq [Tq], dk / dv [Tk] are overwritten; Tq must be > 0; `delta` is a
+ * workspace of ie_flash_attn_bwd_workspace(Tq, hq, hkv, d) floats.  ie_attn_merge folds a block's (out_p bf16 [n, hq, d], lse_p [hq, Tp]) into the running
+ * fp32 result (acc [.., hq, d] contiguous, lse_acc [hq, Ta]) of its first n rows; ie_acc_bf16: dst (fp32) += src (bf16), n % 8 == 0. */
+int ie_flash_attn_fwd_x(const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts, void* out, int64_t o_ts, float* lse,
+                        const int32_t* cu_q, const int32_t* cu_k, int nseq, int64_t Tq, int64_t Tk, int max_seqlen_q, int hq, int hkv,
+                        int d, float softmax_scale, void* stream);
+int ie_flash_attn_bwd_x(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts,
+                        const void* out, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts, void* dk, void* dv,
+                        int64_t dkv_ts, const int32_t* cu_q, const int32_t* cu_k, int nseq, int64_t Tq, int64_t Tk, int max_seqlen_q,
+                        int max_seqlen_k, int hq, int hkv, int d, float softmax_scale, void* stream);
+int ie_attn_merge(float* acc, float* lse_acc, int64_t Ta, const void* out_p, int64_t p_ts, const float* lse_p, int64_t Tp, int64_t n, int hq,
+                  int d, void* stream);
+int ie_acc_bf16(float* dst, const void* src, int64_t n, void* stream);
 /* The five-product attention backward (ie_tune_flash_bwd_variant bit 1; opt-in): the dK/dV kernel also writes dS^T (bf16, 2 bytes per visible
  * (query, key) pair) and dQ is formed from it instead of recomputing S and dP a second time.  It needs a caller-owned buffer of
  * ie_flash_attn_bwd_spill_bytes(nseq, max_seqlen, hq, causal) bytes, 1-KiB aligned, handed over (and taken back with NULL, 0) by

@@ -126,6 +126,10 @@ SIGNATURES = {
     "ie_gemm_note_kernel": (I, [I, I, I, I, I, I, I, I, I]),
     "ie_tune_flash_fwd_variant": (I, [I]),
     "ie_tune_flash_bwd_variant": (I, [I]),
+    "ie_flash_attn_fwd_x": (I, [P, I64, P, P, I64, P, I64, P, P, P, I, I64, I64, I, I, I, I, F, P]),
+    "ie_flash_attn_bwd_x": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, I64, P, P, I64, P, P, I, I64, I64, I, I, I, I, I, F, P]),
+    "ie_attn_merge": (I, [P, P, I64, P, I64, P, I64, I64, I, I, P]),
+    "ie_acc_bf16": (I, [P, P, I64, P]),
     "ie_flash_attn_bwd_spill_bytes": (I64, [I, I, I, I]),
     "ie_flash_attn_bwd_set_spill": (I, [P, I64]),
     "ie_flash_attn_bwd_workspace": (I64, [I64, I, I, I]),

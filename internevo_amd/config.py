@@ -141,6 +141,9 @@ class TrainConfig:
     wp_size: int = 1                # parallel.weight = dict(size=wp): ISP weight parallelism -- the engine shards the layer weights over groups of wp ranks
                                     # only when they do not fit resident (engine.py, weight_parallel)
     sp_size: int = 1                # parallel.tensor = dict(size=sp, mode="isp"): Ulysses / ISP sequence parallelism (seqpar.py)
+    sp_attention: str = "auto"      # parallel.tensor = dict(..., attention="ulysses" | "ring" | "auto") -- an extension of this repo: how the attention of an isp
+                                    # run sees the whole sequence: the reference's head exchange (DistributedAttention), or K / V blocks travelling around the
+                                    # sequence group (seqpar.RingAttention: no limit on the kv head count); auto = ulysses where the kv heads divide, else ring
     tp_size: int = 1                # parallel.tensor = dict(size=tp, mode="mtp"): Megatron tensor parallelism of the layers (tensorpar.py)
     tp_mode: str = "mtp"            # "msp" / "fsp": the same shards with the activations between the linears sharded along the sequence
     pp_size: int = 1                # parallel.pipeline = dict(size=pp): 1F1B pipeline parallelism (pipeline.py)
@@ -175,6 +178,9 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
     tensor = tensor if isinstance(tensor, dict) else dict(size=tensor, mode="mtp")  # launch.py normalises an int the same way
     sp_size = tp_size = 1
     tp_mode = "mtp"
+    sp_attention = str(tensor.get("attention", "auto"))
+    if sp_attention not in ("auto", "ulysses", "ring"):
+        raise ValueError(f"parallel.tensor.attention = {sp_attention!r}: 'auto', 'ulysses' or 'ring'")
     if tensor.get("size", 1) != 1:
         mode = tensor.get("mode", "mtp")
         if mode == "isp":
@@ -287,7 +293,7 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         growth_factor=gs["growth_factor"], backoff_factor=gs["backoff_factor"], max_scale=gs.get("max_scale", 2**24), hysteresis=gs["hysteresis"],
         clip_grad_norm=hz["clip_grad_norm"], label_smoothing=cfg.get("loss", {}).get("label_smoothing", 0) or 0.0,
         zero1_size=par.get("zero1", {}).get("size", -1) if isinstance(par.get("zero1", {}), dict) else par.get("zero1", -1),
-        sp_size=sp_size, tp_size=tp_size, tp_mode=tp_mode, pp_size=pp_size, num_chunks=num_chunks, wp_size=wp_size,
+        sp_size=sp_size, tp_size=tp_size, tp_mode=tp_mode, pp_size=pp_size, num_chunks=num_chunks, wp_size=wp_size, sp_attention=sp_attention,
     )
     return PathConfig(model, train)
 

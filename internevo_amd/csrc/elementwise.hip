@@ -197,6 +197,49 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const bf16_t* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
+// ring attention (internevo_amd/seqpar.py): a block's partial result (out_p, lse_p) of n rows merged into the running fp32 result of the same rows:
+//   lse' = log(e^lse + e^lse_p),  acc' = e^(lse - lse') acc + e^(lse_p - lse') out_p.   One thread per 8 elements of a (row, head); a partial without keys
+// (lse_p = -inf) changes nothing.
+__global__ __launch_bounds__(256) void attn_merge_k(float* __restrict__ acc, float* __restrict__ lse_acc, int64_t Ta, const bf16_t* __restrict__ out_p,
+                                                    int64_t p_ts, const float* __restrict__ lse_p, int64_t Tp, int64_t n, int hq, int d) {
+    const int tpp = d / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pair = gid / tpp;
+    const int sub = (int)(gid % tpp);
+    if (pair >= n * hq) return;
+    const int64_t row = pair / hq;
+    const int h = (int)(pair % hq);
+    const float a = lse_acc[(int64_t)h * Ta + row], b = lse_p[(int64_t)h * Tp + row];
+    if (b == -INFINITY) return;
+    const float m = fmaxf(a, b);
+    const float ea = (a == -INFINITY) ? 0.f : __expf(a - m), eb = __expf(b - m);
+    const float inv = 1.f / (ea + eb);
+    const float wa = ea * inv, wb = eb * inv;
+    float* ap = acc + (row * hq + h) * (int64_t)d + sub * 8;
+    float pv[8];
+    unpack8(ld16(out_p + row * p_ts + (int64_t)h * d + sub * 8), pv);
+    float4 x0 = *reinterpret_cast<float4*>(ap), x1 = *reinterpret_cast<float4*>(ap + 4);
+    x0.x = wa * x0.x + wb * pv[0]; x0.y = wa * x0.y + wb * pv[1]; x0.z = wa * x0.z + wb * pv[2]; x0.w = wa * x0.w + wb * pv[3];
+    x1.x = wa * x1.x + wb * pv[4]; x1.y = wa * x1.y + wb * pv[5]; x1.z = wa * x1.z + wb * pv[6]; x1.w = wa * x1.w + wb * pv[7];
+    *reinterpret_cast<float4*>(ap) = x0;
+    *reinterpret_cast<float4*>(ap + 4) = x1;
+    // (the threads of a (row, head) are neighbouring lanes of one wave: all of them have read the old lse before this store is issued)
+    if (sub == 0) lse_acc[(int64_t)h * Ta + row] = m + __logf(ea + eb);
+}
+
+// dst (fp32) += src (bf16): the fp32 sums ring attention keeps of the blocks' dQ / dK / dV shares
+__global__ __launch_bounds__(256) void acc_bf16_k(float* __restrict__ dst, const bf16_t* __restrict__ src, int64_t n8) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n8) return;
+    float v[8];
+    unpack8(ld16(src + idx * 8), v);
+    float4 x0 = *reinterpret_cast<float4*>(dst + idx * 8), x1 = *reinterpret_cast<float4*>(dst + idx * 8 + 4);
+    x0.x += v[0]; x0.y += v[1]; x0.z += v[2]; x0.w += v[3];
+    x1.x += v[4]; x1.y += v[5]; x1.z += v[6]; x1.w += v[7];
+    *reinterpret_cast<float4*>(dst + idx * 8) = x0;
+    *reinterpret_cast<float4*>(dst + idx * 8 + 4) = x1;
+}
+
 __global__ __launch_bounds__(256) void add_bf16_k(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o,
                                                   int64_t n8, int64_t n) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,6 +578,25 @@ extern "C" int ie_add_bf16(const void* a, const void* b, void* out, int64_t n, v
     dim3 grid((unsigned)((n8 + 256) / 256));
     hipLaunchKernelGGL(add_bf16_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n8, n);
     return ie_launch_status("ie_add_bf16 launch");
+}
+
+extern "C" int ie_attn_merge(float* acc, float* lse_acc, int64_t Ta, const void* out_p, int64_t p_ts, const float* lse_p, int64_t Tp, int64_t n, int hq,
+                             int d, void* stream) {
+    IE_CHECK_ARG(acc && lse_acc && out_p && lse_p && n >= 0 && n <= Ta && n <= Tp && hq > 0 && d > 0 && d % 8 == 0 && p_ts % 8 == 0,
+                 "ie_attn_merge: bad argument");
+    IE_CHECK_ARG(aligned16(acc) && aligned16(out_p), "ie_attn_merge: pointers must be 16-byte aligned");
+    if (n == 0) return IE_OK;
+    const int64_t threads = n * hq * (d / 8);
+    hipLaunchKernelGGL(attn_merge_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, lse_acc, Ta, (const bf16_t*)out_p, p_ts,
+                       lse_p, Tp, n, hq, d);
+    return ie_launch_status("ie_attn_merge launch");
+}
+
+extern "C" int ie_acc_bf16(float* dst, const void* src, int64_t n, void* stream) {
+    IE_CHECK_ARG(dst && src && n >= 0 && n % 8 == 0 && aligned16(dst) && aligned16(src), "ie_acc_bf16: 16-byte aligned pointers and a multiple of 8 elements");
+    if (n == 0) return IE_OK;
+    hipLaunchKernelGGL(acc_bf16_k, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, (const bf16_t*)src, n / 8);
+    return ie_launch_status("ie_acc_bf16 launch");
 }
 
 extern "C" int ie_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {

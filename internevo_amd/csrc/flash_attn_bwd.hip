@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
                                                         int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                         int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
                                                         bf16_t* __restrict__ dq, int64_t dq_ts, const int32_t* __restrict__ cu, int64_t T,
-                                                        int hq, int hkv, float scale) {
+                                                        int hq, int hkv, float scale, const int32_t* __restrict__ cu_k, int64_t Tk) {
+    // cu_k / Tk (full attention only; ie_flash_attn_bwd_x): the keys of sequence s are rows cu_k[s] .. cu_k[s + 1] of K / V tensors of Tk rows
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES;  // K image, V image
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
@@ -119,15 +120,20 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     const int my_q = qw0 + (lane & 31);
     const bool q_valid = my_q < len;
 
-    const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
+    const int tok0k = (!CAUSAL && cu_k) ? cu_k[seq] : tok0;
+    const int lenk = (!CAUSAL && cu_k) ? cu_k[seq + 1] - tok0k : len;
+    const int64_t Tkk = (!CAUSAL && cu_k) ? Tk : T;
+    const int kv_end = CAUSAL ? min(len, q0 + 128) : lenk;
     const int ntiles = (kv_end + 63) / 64;
-    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
-    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* kbase = k + (int64_t)tok0k * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0k * kv_ts + (int64_t)hk * D;
     TileSrc<D, 4> ksrc, vsrc;
-    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
-    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
-    ksrc.issue(smem, 0, 0, wave);
-    vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
+    ksrc.init(kbase, kv_ts, Tkk - tok0k, D, wave, lane);
+    vsrc.init(vbase, kv_ts, Tkk - tok0k, D, wave, lane);
+    if (ntiles > 0) {   // (a sequence without keys: dQ = 0)
+        ksrc.issue(smem, 0, 0, wave);
+        vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
+    }
 
     FragOffs<D> fo;
     fo.init(lane);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
         }
         const bool active = !CAUSAL || kv0 <= qw0 + 31;
         if (active) {
-            const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > len);
+            const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > lenk);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 f32x16 s = zero16(), dp = zero16();
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, 32 * c, ks, fo), dof[ks], dp, 0, 0, 0);
                 }
                 if (need_mask) {  // wave-uniform; selects instead of per-element branches
-                    const int lim = CAUSAL ? min(len - 1, my_q) : len - 1;
+                    const int lim = CAUSAL ? min(len - 1, my_q) : lenk - 1;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + 32 * c + creg_row(r, lane);
@@ -243,7 +249,8 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
                                                                const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale,
                                                                float* __restrict__ part, unsigned char* __restrict__ ds_ws,
-                                                               int64_t ds_head_stride, int nq_max) {
+                                                               int64_t ds_head_stride, int nq_max, const int32_t* __restrict__ cu_k, int64_t Tk) {
+    // cu_k / Tk (full attention only; ie_flash_attn_bwd_x): the keys of sequence s are rows cu_k[s] .. cu_k[s + 1] of K / V / dK / dV tensors of Tk rows
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, -lse/scale [64], -delta [64] (+ pad to keep 1 KiB alignment)
     // Pipeline stages.  Four waves (one block per CU: the registers allow one wave per SIMD) keep FOUR and work EARLY: the transfers of tile
@@ -272,20 +279,32 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     const int kb = (HS > 1 || !one_round) ? j : (j < first ? j : nkb - 1 - (j - first));
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
+    const int tok0k = (!CAUSAL && cu_k) ? cu_k[seq] : tok0;
+    const int lenk = (!CAUSAL && cu_k) ? cu_k[seq + 1] - tok0k : len;
     const int k0 = kb * 32 * DKV_WAVES;
-    if (k0 >= len) return;
+    if (k0 >= lenk) return;
     const int grp = hq / hkv / HS;          // q heads handled by this block
     const int h_first = hk * (hq / hkv) + hsi * grp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kw0 = k0 + wave * 32;
     const int my_k = kw0 + (lane & 31);
-    const bool k_valid = my_k < len;
+    const bool k_valid = my_k < lenk;
 
     const int nqt_all = (len + 63) / 64;
     const int qt_start = CAUSAL ? (k0 / 64) : 0;
-    const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len
+    const int nqt = nqt_all - qt_start;  // >= 1 because k0 < len (0: a sequence without queries, ie_flash_attn_bwd_x only)
     const int nit = grp * nqt;
+    if (nqt <= 0) {   // nobody looks at these keys: dK = dV = 0, and nothing is requested (the descriptors of an empty sequence describe nothing)
+        if (HS == 1) {
+            f32x16 z[G::DB];
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db) z[db] = zero16();
+            store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
+            store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
+        }
+        return;
+    }
 
     // Q / dO descriptors end with this sequence: rows behind it arrive as zeros, and so do their lse2 / delta -- such a row gives S = 0,
     // P = exp2(0 - 0) = 1, dP = 0, dS = 1 * (0 - 0) = 0 and adds exact zeros to dV (P^T dO) and dK (dS^T Q), with no instruction spent on it
@@ -353,8 +372,8 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     // K, V fragments of this wave's 32 keys (B operands: lane = key)
     s16x8 kf[G::KS], vf[G::KS];
     {
-        const bf16_t* kp = k + (int64_t)(tok0 + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
-        const bf16_t* vp = v + (int64_t)(tok0 + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
+        const bf16_t* kp = k + (int64_t)(tok0k + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
+        const bf16_t* vp = v + (int64_t)(tok0k + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
             union { uint4 u; s16x8 s; } a, b;
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     // requested at the top of the tile (two stages) or under the previous tile's C1 MFMAs (EARLY).
     struct TileInfo { int q0; bool need_mask; int first_rel; const unsigned char* sp; };   // sp: SPILL, the image of this tile for this wave's keys
     int cur_qt = QT_MAJOR ? nqt_all - 1 : qt_start, cur_h = h_first;   // query tile / q head the next tile_info() describes
-    const int first_q = (my_k >= len) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
+    const int first_q = (my_k >= lenk) ? 0x3fffffff : (CAUSAL ? my_k : 0);  // first query row that sees this lane's key
     // SPILL: the image of (head, query tile) for this wave's keys.  (A four-wave block's upper key half above the diagonal tile is all zeros and has no
     // image of its own: it goes to the spare image that ends every head's region -- the counted waits want the same number of stores from every wave
     // and tile.)  Recomputed once per query tile, advanced by one head's region in between: the scalar instructions of an address per store cost
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             if (++cur_qt == nqt_all) { cur_qt = qt_start; ++cur_h; }
             if (SPILL) sp_cur = sp_image(min(cur_h, hq - 1), cur_qt);
         }
-        ti.need_mask = (CAUSAL && kw0 + 31 > ti.q0) || (kw0 + 32 > len);   // wave-uniform: the diagonal tile, the last keys
+        ti.need_mask = (CAUSAL && kw0 + 31 > ti.q0) || (kw0 + 32 > lenk);   // wave-uniform: the diagonal tile, the last keys
         ti.first_rel = first_q - ti.q0 - rl_lane;                           // first visible row, tile-local, relative to this lane's registers 0 .. 3
         return ti;
     };
@@ -706,8 +725,8 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
 #endif
 
     if (HS == 1) {
-        store_row_block<D>(dk + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);
-        store_row_block<D>(dv + (int64_t)(tok0 + my_k) * dkv_ts + (int64_t)hk * D, dvacc, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
+        store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);
+        store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dvacc, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
     }
     if (k_valid && HS > 1) {
         const int64_t row = (((int64_t)hsi * T + tok0 + my_k) * hkv + hk) * D;
@@ -933,10 +952,12 @@ extern "C" int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d
     return 3ll * hq * T + 2ll * 4 * T * hkv * d;  // delta, -lse / scale, -delta + the largest set of dK/dV partials
 }
 
-extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
-                                 int64_t kv_ts, const void* out, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts,
-                                 void* dk, void* dv, int64_t dkv_ts, const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen,
-                                 int hq, int hkv, int d, float softmax_scale, int causal, void* stream) {
+// cu_k == NULL: self-attention (ie_flash_attn_bwd); else the rectangle per sequence of ie_flash_attn_bwd_x (full attention; keys cu_k[s] .. cu_k[s + 1] of
+// Tk-row K / V / dK / dV tensors, at most max_seqlen_k per sequence): the seven-product path without a head split
+static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts, const void* out,
+                          int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
+                          const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv, int d, float softmax_scale, int causal,
+                          void* stream, const int32_t* cu_k, int64_t Tk, int max_seqlen_k) {
     IE_CHECK_ARG(dout && q && k && v && out && lse && delta && dq && dk && dv && cu_seqlens, "ie_flash_attn_bwd: null pointer");
     IE_CHECK_ARG(nseq >= 0 && T >= 0 && max_seqlen >= 0 && hq > 0 && hkv > 0 && hq % hkv == 0, "ie_flash_attn_bwd: bad shape");
     IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_flash_attn_bwd: head dim must be 64 or 128");
@@ -962,18 +983,18 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     const unsigned nt128 = (unsigned)((max_seqlen + 127) / 128);
     dim3 gq((unsigned)hq, nt128, (unsigned)nseq);
     const int DKV_WAVES = g_dkdv_waves;
-    const unsigned nkb = (unsigned)((max_seqlen + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
-    const int hs = dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
+    const unsigned nkb = (unsigned)(((cu_k ? max_seqlen_k : max_seqlen) + 32 * DKV_WAVES - 1) / (32 * DKV_WAVES));
+    const int hs = cu_k ? 1 : dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq);
     dim3 gk(nkb * (unsigned)hkv * (unsigned)hs, 1, (unsigned)nseq);
     float* part = ndelta + (int64_t)hq * T;
 #define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
                        (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
-                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0)
+                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0, cu_k, Tk)
 #define IE_DKDV_SPILL(DD, CA, NW_)                                                                                                 \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, 1, NW_, true>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
                        (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
-                       softmax_scale, part, (unsigned char*)ds_ws, ds_head_stride, nq_max)
+                       softmax_scale, part, (unsigned char*)ds_ws, ds_head_stride, nq_max, (const int32_t*)nullptr, (int64_t)0)
 #define IE_DQ_FROM_DS(DD, CA)                                                                                                      \
     hipLaunchKernelGGL((flash_dq_from_ds_k<DD, CA>), gds, dim3(256), 0, st, (const unsigned char*)ds_ws, ds_head_stride, nq_max,      \
                        (const bf16_t*)k, kv_ts, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, gw)
@@ -998,17 +1019,17 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
         if (g_dq_minw == 2)                                                                                                        \
             hipLaunchKernelGGL((flash_dq_k<DD, CA, 2>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
                                (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
-                               softmax_scale);                                                                                      \
+                               softmax_scale, cu_k, Tk);                                                                                      \
         else                                                                                                                       \
             hipLaunchKernelGGL((flash_dq_k<DD, CA, 1>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
                                (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
-                               softmax_scale);                                                                                      \
+                               softmax_scale, cu_k, Tk);                                                                                      \
         IE_DKDV(DD, CA);                                                                                                           \
     } while (0)
     // five-product path: dK/dV kernel with the dS^T spill, dQ from the spill.  Not with a head split (small problems, where the split is what matters).
     const int nq_max = (max_seqlen + 63) / 64;
     const int64_t ds_head_stride = ((causal ? (int64_t)nq_max * (nq_max + 1) / 2 : (int64_t)nq_max * nq_max) + 1) * 8192;
-    if (g_bwd_spill && hs == 1 && ds_head_stride < (1ll << 31) && g_ds_ws && (int64_t)nseq * hq * ds_head_stride <= g_ds_ws_bytes) {
+    if (g_bwd_spill && !cu_k && hs == 1 && ds_head_stride < (1ll << 31) && g_ds_ws && (int64_t)nseq * hq * ds_head_stride <= g_ds_ws_bytes) {
         void* ds_ws = g_ds_ws;
         const int group = hq / hkv, gw = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1), qw = 4 / gw;
         dim3 gds((unsigned)(hkv * (group / gw)), (unsigned)((nq_max + qw - 1) / qw), (unsigned)nseq);
@@ -1041,6 +1062,29 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
     }
 #endif
     return ie_launch_status("ie_flash_attn_bwd launch");
+}
+
+extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v,
+                                 int64_t kv_ts, const void* out, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts,
+                                 void* dk, void* dv, int64_t dkv_ts, const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen,
+                                 int hq, int hkv, int d, float softmax_scale, int causal, void* stream) {
+    return flash_bwd_impl(dout, do_ts, q, q_ts, k, v, kv_ts, out, o_ts, lse, delta, dq, dq_ts, dk, dv, dkv_ts, cu_seqlens, nseq, T, max_seqlen, hq, hkv, d,
+                          softmax_scale, causal, stream, nullptr, 0, 0);
+}
+
+// Backward of ie_flash_attn_fwd_x (full attention of queries cu_q[s] .. cu_q[s + 1] against keys cu_k[s] .. cu_k[s + 1]).  `lse` and `out` are what
+// the probabilities are normalised with and delta = rowsum(dout * out) is taken from -- for one block of ring attention the MERGED lse / out of the
+// whole row, which makes this block's dq / dk / dv its additive share of the whole gradient.  dq [Tq], dk / dv [Tk] are overwritten (rows of empty
+// sequences with zeros).  delta: workspace of ie_flash_attn_bwd_workspace(Tq, hq, hkv, d) floats.
+extern "C" int ie_flash_attn_bwd_x(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts,
+                                   const void* out, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts, void* dk, void* dv,
+                                   int64_t dkv_ts, const int32_t* cu_q, const int32_t* cu_k, int nseq, int64_t Tq, int64_t Tk, int max_seqlen_q,
+                                   int max_seqlen_k, int hq, int hkv, int d, float softmax_scale, void* stream) {
+    IE_CHECK_ARG(cu_k && Tk >= 0 && max_seqlen_k >= 0, "ie_flash_attn_bwd_x: cu_k, Tk, max_seqlen_k");
+    if (nseq == 0 || Tk == 0 || max_seqlen_k == 0) return IE_OK;
+    // (max_seqlen_q = 0 still runs the dK / dV kernel: keys nobody looks at get zeros)
+    return flash_bwd_impl(dout, do_ts, q, q_ts, k, v, kv_ts, out, o_ts, lse, delta, dq, dq_ts, dk, dv, dkv_ts, cu_q, nseq, Tq, max_seqlen_q > 0 ? max_seqlen_q : 1,
+                          hq, hkv, d, softmax_scale, 0, stream, cu_k, Tk, max_seqlen_k);
 }
 
 // Spill buffer of the five-product backward (ie_tune_flash_bwd_variant bit 1): bytes for a call with these shapes, and the hook that hands the

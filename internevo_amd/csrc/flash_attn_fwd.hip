@@ -23,7 +23,9 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
                                                       const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out,
                                                       int64_t o_ts, float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T,
-                                                      int hq, int hkv, float scale) {
+                                                      int hq, int hkv, float scale, const int32_t* __restrict__ cu_k, int64_t Tk) {
+    // cu_k (full attention only; ie_flash_attn_fwd_x): the keys of sequence s are rows cu_k[s] .. cu_k[s + 1] of a K / V tensor of Tk rows -- a
+    // rectangle of scores per sequence (ring attention: a rank's queries against another rank's keys); NULL: the queries' own rows
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES;                                       // K image, V image
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
@@ -46,16 +48,21 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
     const int my_q = qw0 + (lane & 31);        // this lane's query row (within the sequence)
     const bool q_valid = my_q < len;
 
-    const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
+    const int tok0k = (!CAUSAL && cu_k) ? cu_k[seq] : tok0;
+    const int lenk = (!CAUSAL && cu_k) ? cu_k[seq + 1] - tok0k : len;
+    const int64_t Tkk = (!CAUSAL && cu_k) ? Tk : T;
+    const int kv_end = CAUSAL ? min(len, q0 + 128) : lenk;
     const int ntiles = (kv_end + 63) / 64;
-    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
-    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* kbase = k + (int64_t)tok0k * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0k * kv_ts + (int64_t)hk * D;
 
     TileSrc<D, 4> ksrc, vsrc;
-    ksrc.init(kbase, kv_ts, T - tok0, D, wave, lane);
-    vsrc.init(vbase, kv_ts, T - tok0, D, wave, lane);
-    ksrc.issue(smem, 0, 0, wave);
-    vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
+    ksrc.init(kbase, kv_ts, Tkk - tok0k, D, wave, lane);
+    vsrc.init(vbase, kv_ts, Tkk - tok0k, D, wave, lane);
+    if (ntiles > 0) {   // (a sequence without keys -- ie_flash_attn_fwd_x only -- requests nothing: out = 0, lse = -inf)
+        ksrc.issue(smem, 0, 0, wave);
+        vsrc.issue(smem + G::IMG_BYTES, 0, 0, wave);
+    }
 
     FragOffs<D> fo;
     fo.init(lane);
@@ -102,10 +109,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_k(const bf16_t* __restrict__
                 for (int ks = 0; ks < G::KS; ++ks)
                     sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], sacc[c], 0, 0, 0);
             }
-            const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > len);
+            const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > lenk);
             float mx = -INFINITY;
             if (need_mask) {  // wave-uniform: only the diagonal / last tiles pay for the masks (selects, no per-element branches)
-                const int lim = CAUSAL ? min(len - 1, my_q) : len - 1;  // largest visible key of this lane's query
+                const int lim = CAUSAL ? min(len - 1, my_q) : lenk - 1;  // largest visible key of this lane's query
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -871,11 +878,34 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     dim3 grid((unsigned)hq, (unsigned)((max_seqlen + 127) / 128), (unsigned)nseq);
 #define IE_L(DD, CA)                                                                                                              \
     hipLaunchKernelGGL((flash_fwd_k<DD, CA>), grid, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
-                       (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
+                       (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale, (const int32_t*)nullptr, (int64_t)0)
     if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
     else          { if (causal) IE_L(64, true); else IE_L(64, false); }
 #undef IE_L
     return ie_launch_status("ie_flash_attn_fwd launch");
+}
+
+// Full attention of a rectangle of scores per sequence: queries cu_q[s] .. cu_q[s + 1] (of Tq rows) against keys cu_k[s] .. cu_k[s + 1] (of Tk rows).
+// A sequence without keys gives out = 0, lse = -inf.  The block of ring attention (internevo_amd/seqpar.py): a rank's queries of the sequence
+// that spans a rank boundary against the part of that sequence another rank holds.
+extern "C" int ie_flash_attn_fwd_x(const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts, void* out, int64_t o_ts, float* lse,
+                                   const int32_t* cu_q, const int32_t* cu_k, int nseq, int64_t Tq, int64_t Tk, int max_seqlen_q, int hq, int hkv,
+                                   int d, float softmax_scale, void* stream) {
+    IE_CHECK_ARG(q && k && v && out && lse && cu_q && cu_k, "ie_flash_attn_fwd_x: null pointer");
+    IE_CHECK_ARG(nseq >= 0 && Tq >= 0 && Tk >= 0 && max_seqlen_q >= 0 && hq > 0 && hkv > 0 && hq % hkv == 0, "ie_flash_attn_fwd_x: bad shape");
+    IE_CHECK_ARG(softmax_scale > 0.f, "ie_flash_attn_fwd_x: softmax_scale must be positive");
+    IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_flash_attn_fwd_x: head dim must be 64 or 128");
+    IE_CHECK_SUPPORTED(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && q_ts % 8 == 0 && kv_ts % 8 == 0 && o_ts % 4 == 0,
+                       "ie_flash_attn_fwd_x: pointers must be 16-byte aligned and token strides multiples of 8");
+    if (nseq == 0 || Tq == 0 || max_seqlen_q == 0) return IE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)hq, (unsigned)((max_seqlen_q + 127) / 128), (unsigned)nseq);
+#define IE_LX(DD)                                                                                                                      \
+    hipLaunchKernelGGL((flash_fwd_k<DD, false>), grid, dim3(256), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
+                       (bf16_t*)out, o_ts, lse, cu_q, Tq, hq, hkv, softmax_scale, cu_k, Tk)
+    if (d == 128) IE_LX(128); else IE_LX(64);
+#undef IE_LX
+    return ie_launch_status("ie_flash_attn_fwd_x launch");
 }
 
 // tuning hook (A/B benchmarking only): kernel variant of the forward

@@ -45,10 +45,13 @@ _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
-                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None, tp_mode=None, rs_under_w13=None):
+                 zero_size=None, vocab_parallel=None, pp_size=None, num_chunks=None, weight_parallel=None, scale_on_q=None, tp_mode=None, rs_under_w13=None,
+                 sp_attention=None):
         """zero_size (default: the config's parallel.zero1.size): hybrid ZeRO -- the fp32 state is sharded over groups of zero_size
         consecutive data-parallel ranks and replicated across the groups (zero.py); -1 / None-and-unset = the whole data-parallel group.
         sp_size > 1: Ulysses / ISP sequence parallelism over groups of sp_size consecutive ranks (seqpar.py).
+        sp_attention (default: the config's parallel.tensor.attention, "auto"): "ulysses" = the reference's head exchange around the attention,
+        "ring" = seqpar.RingAttention (K / V blocks travel around the group; any kv head count), "auto" = ulysses where the kv heads divide, else ring.
         emulate_isp_grad_rule = n on a run WITHOUT sequence parallelism applies the gradient averaging rule of an sp = n ISP
         run (test hook: an sp = n run must then match it step for step).
         tp_mode (default: the config's parallel.tensor mode): "msp" / "fsp" = tensor parallelism with the activations BETWEEN the linears sharded
@@ -165,8 +168,15 @@ class InternLM2Engine:
         if tp_size > 1:  # ... and so does every rank of a tensor group (inside a stage, under pipeline parallelism)
             self.seqpar.data_rank, self.seqpar.data_world = self.tpar.dp_rank, self.tpar.dp_world
         self.isp_rule = sp_size if sp_size > 1 else int(emulate_isp_grad_rule)
-        if sp_size > 1 and (mc.num_kv_attention_heads % sp_size or tc.packed_length % sp_size):
-            raise ValueError("sequence parallel size must divide the kv head count and the packed length")
+        mode = str(getattr(tc, "sp_attention", "auto") if sp_attention is None else sp_attention)
+        if mode not in ("auto", "ulysses", "ring"):
+            raise ValueError(f"sp_attention = {mode!r}: 'auto', 'ulysses' or 'ring'")
+        heads_divide = mc.num_kv_attention_heads % sp_size == 0 and mc.num_attention_heads % sp_size == 0
+        self.ring_mode = sp_size > 1 and (mode == "ring" or (mode == "auto" and not heads_divide))
+        if sp_size > 1 and tc.packed_length % sp_size:
+            raise ValueError("sequence parallel size must divide the packed length")
+        if sp_size > 1 and not self.ring_mode and not heads_divide:
+            raise ValueError("sequence parallel size must divide the head counts for the head exchange (parallel.tensor.attention = 'ring' has no such limit)")
 
         # ---- flat parameter / gradient buffers + ZeRO-1 fp32 state of this rank's shards
         # Physical placement of the buckets inside `params` / `grads`.  Resident: the layout's own offsets.  Weight parallel: a layer bucket
@@ -380,11 +390,13 @@ class InternLM2Engine:
         # attention works on ALL Tg tokens of the micro-batch with this rank's 1/sp of the heads (same element counts)
         sp, Tg = self.sp, self.Tg
         hql, hkvl = hq // sp, hkv // sp
+        if self.ring_mode:      # ring attention keeps the local tokens with ALL heads (same element counts where the heads divide)
+            Tg, hql, hkvl = T, hq, hkv
         self.a_q = [e(Tg, hql, d) for _ in range(S)]
         self.a_kv = [e(Tg, 2, hkvl, d) for _ in range(S)]
         self.a_ctx = [e(Tg, hql, d) for _ in range(S)]
         self.a_lse = [e(hql, Tg, dtype=torch.float32) for _ in range(S)]
-        self.a_ctxl = [e(T, hq, d) for _ in range(S)] if sp > 1 else self.a_ctx   # context of the local tokens, all heads (wo input)
+        self.a_ctxl = [e(T, hq, d) for _ in range(S)] if (sp > 1 and not self.ring_mode) else self.a_ctx   # context of the local tokens, all heads (wo input)
         self.a_r2 = [e(T, h) for _ in range(S)]
         self.a_n2 = [e(T, h) for _ in range(S)]
         self.a_rstd2 = [e(T, dtype=torch.float32) for _ in range(S)]
@@ -401,7 +413,13 @@ class InternLM2Engine:
         self.t_dw13 = e(T, 2 * F)
         self.t_dq = e(Tg, hql, d)
         self.t_dkv = e(Tg, 2, hkvl, d)
-        if sp > 1:  # local-token / all-head staging of the exchanges
+        self.ring = None
+        if self.ring_mode:
+            from .seqpar import RingAttention
+
+            self.ring = RingAttention(self.seqpar, hq, hkv, d, T, self.dev, None)   # (the scale is set below, with attn_scale)
+            self.t_loss_red = e(2, dtype=torch.float32)
+        elif sp > 1:  # local-token / all-head staging of the exchanges
             self.t_ql, self.t_kvl = e(T, hq, d), e(T, 2, hkv, d)
             self.t_xq, self.t_xkv = e(T, hq, d), e(T, 2, hkv, d)      # send / receive buffers
             self.t_dctx_full = e(Tg, hql, d)
@@ -476,8 +494,8 @@ class InternLM2Engine:
         self.a_n2 = [t[r] for t in self.st_n2]
         ctx = [t[r].view(T, mc.num_attention_heads, mc.head_dim) for t in self.st_ctx]
         self.a_ctxl = ctx
-        if self.sp == 1:
-            self.a_ctx = ctx  # without sequence parallelism the attention output IS the wo input
+        if self.sp == 1 or self.ring_mode:
+            self.a_ctx = ctx  # without the head exchange the attention output IS the wo input
         self.a_nf, self.t_logits = self.st_nf[r], self.st_logits[r]
 
     # ------------------------------------------------------------------------------------------ forward / backward
@@ -577,6 +595,12 @@ class InternLM2Engine:
         if rl.stop < T:
             product(slice(rl.stop, T))
 
+    def _dev_cu(self, cu_h):
+        """A micro-batch's sequence boundaries on the device; the host copy rides along (ring attention plans its blocks from it without a sync)."""
+        cu = cu_h.to(self.dev, non_blocking=True)
+        cu.host = cu_h
+        return cu
+
     def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
         """One PackedFlashLlamaLayer1D (modeling_internlm2.py:684-740) into activation slot slot[l].
         recompute=False: the forward proper; the layer input a_x[l] = prev_ffn_out + previous layer's r2 is produced
@@ -597,7 +621,7 @@ class InternLM2Engine:
         self._gathered_rows(self.a_n1[s], lambda r: K.linear_fwd(self.a_n1[s][r], p[pre + "attention.wqkv.weight"], self.t_qkv[r]))
         if self.bias:   # the InternLM-1 block (multi_head_attention.py:371-396): Wqkv carries a bias
             K.bias_add(self.t_qkv, p[pre + "attention.wqkv.bias"])
-        if self.sp == 1:
+        if self.sp == 1 or self.ring_mode:   # (ring attention: the local tokens keep all their heads)
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s], self.q_scale)
         else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl, self.q_scale)
@@ -605,8 +629,12 @@ class InternLM2Engine:
             xkv = self.seqpar.scatter_heads_gather_seq_async(self.t_kvl, 2, self.t_xkv, self.a_kv[s])  # and the two exchanges beside each other
             xq.wait()
             xkv.wait()
-        K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, self.attn_scale, True, self.a_ctx[s], self.a_lse[s])
-        if self.sp > 1:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
+        if self.ring_mode:   # K / V blocks travel around the sequence group instead of the heads (seqpar.RingAttention)
+            self.ring.scale = self.attn_scale
+            self.ring.forward(self.a_q[s], self.a_kv[s], self.ring.plan(cu.host), self.a_ctx[s], self.a_lse[s])
+        else:
+            K.flash_attn_fwd(self.a_q[s], self.a_kv[s][:, 0], self.a_kv[s][:, 1], cu, max_seqlen, self.attn_scale, True, self.a_ctx[s], self.a_lse[s])
+        if self.sp > 1 and not self.ring_mode:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
         K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
@@ -866,12 +894,16 @@ class InternLM2Engine:
             if self.bias:
                 bgrad(d_r2, g[pre + "attention.wo.bias"], self.st_dr2[l] if bw else None, acc_l)
             # _SeqAllToAll.backward: the mirrored exchanges (multi_head_attention.py:47-53); d_ctx travels under wo's weight gradient
-            xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if self.sp > 1 else None
+            head_x = self.sp > 1 and not self.ring_mode
+            xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if head_x else None
             wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None, acc_l)
-            d_ctx_full = d_ctx.view(T, -1, d) if self.sp == 1 else xc.wait()
-            K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
-                             max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
-            if self.sp == 1:
+            d_ctx_full = xc.wait() if head_x else d_ctx.view(T, -1, d)
+            if self.ring_mode:
+                self.ring.backward(d_ctx_full, self.a_q[sl], self.a_kv[sl], self.a_ctx[sl], self.a_lse[sl], self.ring.plan(cu.host), self.t_dq, self.t_dkv, self.t_delta)
+            else:
+                K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
+                                 max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+            if not head_x:
                 dq_l, dkv_l = self.t_dq, self.t_dkv
             else:
                 xq = self.seqpar.scatter_seq_gather_heads_async(self.t_dq, 1, self.t_xq, self.t_ql)
@@ -951,7 +983,7 @@ class InternLM2Engine:
             cu_h = batch["cu_seqlens"][i]
             max_seqlen = int((cu_h[1:] - cu_h[:-1]).max())  # host-side: no `.item()` sync (modeling_internlm2.py:989 syncs here)
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
-            cu = cu_h.to(self.dev, non_blocking=True)
+            cu = self._dev_cu(cu_h)
             ids_i, lab_i, pos_i = ids_d[i, lo:hi], lab_d[i, lo:hi], pos_d[i, lo:hi]
             self._bind_micro(i)
             if self.metric is not None and self.metric.ntypes and self.sp > 1:
@@ -965,7 +997,7 @@ class InternLM2Engine:
     _ACT_SETS = ("a_x", "a_n1", "a_rstd1", "a_q", "a_kv", "a_ctx", "a_lse", "a_r2", "a_n2", "a_rstd2", "a_w13")
 
     def _act_set_names(self):
-        return self._ACT_SETS + (("a_act",) if self.a_act is not None else ()) + (("a_ctxl",) if self.sp > 1 else ())
+        return self._ACT_SETS + (("a_act",) if self.a_act is not None else ()) + (("a_ctxl",) if (self.sp > 1 and not self.ring_mode) else ())
 
     def _alloc_inflight_sets(self):
         """A stage keeps the saved activations of up to pp - stage micro-batches (forwarded, not yet backwarded): whole extra sets
@@ -979,8 +1011,8 @@ class InternLM2Engine:
     def _bind_inflight(self, i):
         for name, lst in self._sets[i % len(self._sets)].items():
             setattr(self, name, lst)
-        if self.sp == 1:
-            self.a_ctxl = self.a_ctx   # (without sequence parallelism the attention output is the wo input)
+        if self.sp == 1 or self.ring_mode:
+            self.a_ctxl = self.a_ctx   # (without the head exchange the attention output is the wo input)
 
     def _p2p(self, t):
         """What travels between stages of a [T, hidden] residual-stream tensor: all of it, or (msp / fsp) this rank's token rows."""
@@ -1008,7 +1040,7 @@ class InternLM2Engine:
         def args(i):
             cu_h = batch["cu_seqlens"][i]
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
-            return ids_d[i, lo:hi], lab_d[i, lo:hi], cu_h.to(self.dev, non_blocking=True), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
+            return ids_d[i, lo:hi], lab_d[i, lo:hi], self._dev_cu(cu_h), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
 
         def forward(i):
             self._bind_inflight(i)
@@ -1094,7 +1126,7 @@ class InternLM2Engine:
         def args(i):
             cu_h = batch["cu_seqlens"][i]
             self._ensure_rotary(int(batch["indexes"][i].max()) + 1)
-            return ids_d[i, lo:hi], lab_d[i, lo:hi], cu_h.to(self.dev, non_blocking=True), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
+            return ids_d[i, lo:hi], lab_d[i, lo:hi], self._dev_cu(cu_h), pos_d[i, lo:hi], int((cu_h[1:] - cu_h[:-1]).max())
 
         def gbuf(m, c):
             key = (self._slot_of[m], c)
@@ -1145,7 +1177,7 @@ class InternLM2Engine:
         ids_d = input_ids.reshape(npass, -1).to(self.dev, non_blocking=True)
         lab_d = labels.reshape(npass, -1).to(self.dev, non_blocking=True)
         pos_d = torch.arange(S, dtype=torch.int64).repeat(rows).to(self.dev, non_blocking=True)
-        cu = (torch.arange(rows + 1, dtype=torch.int32) * S).to(self.dev, non_blocking=True)
+        cu = self._dev_cu(torch.arange(rows + 1, dtype=torch.int32) * S)
         self._ensure_rotary(S)
         out = torch.zeros(1, dtype=torch.float32, device=self.dev)
         train_metric = self.metric
@@ -1200,7 +1232,7 @@ class InternLM2Engine:
         self._ensure_rotary(int(batch["indexes"].max()) + 1)
         if self.metric is not None and self.metric.ntypes:
             self.metric.set_current_type_ids(batch["type_ids"])
-        cu = cu_h.to(self.dev, non_blocking=True)
+        cu = self._dev_cu(cu_h)
         self._forward_micro(ids_d, lab_d, cu, pos_d, max_seqlen)
         torch.sum(self.t_loss_seg[:, 0:1], dim=0, out=self.loss_acc)
         self.loss_acc.mul_(1.0 / M)

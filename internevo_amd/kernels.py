@@ -655,6 +655,70 @@ def flash_attn_bwd(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scal
     return dq, dk, dv
 
 
+def flash_attn_fwd_x(q, k, v, cu_q, cu_k, max_seqlen_q, softmax_scale=None, out=None, lse=None):
+    """Full attention of a rectangle of scores per sequence (ie_flash_attn_fwd_x): q [Tq, hq, d] rows cu_q[s] .. cu_q[s+1] against k / v [Tk, hkv, d] rows
+    cu_k[s] .. cu_k[s+1] -> (out [Tq, hq, d], lse [hq, Tq] fp32; a sequence without keys: 0 and -inf)."""
+    Tq, hq, d = q.shape
+    Tk, hkv = k.shape[0], k.shape[1]
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(d)
+    kv_ts = _tok_stride(k, d)
+    if _tok_stride(v, d) != kv_ts or v.shape[0] != Tk:
+        raise ValueError("k and v must share the token stride and the row count")
+    if out is None:
+        out = torch.empty((Tq, hq, d), dtype=q.dtype, device=q.device)
+    if lse is None:
+        lse = torch.empty((hq, Tq), dtype=torch.float32, device=q.device)
+    if cu_q.dtype != torch.int32 or cu_k.dtype != torch.int32 or cu_q.numel() != cu_k.numel():
+        raise ValueError("cu_q / cu_k must be int32 and of one length")
+    check(_L().ie_flash_attn_fwd_x(_p(q), _tok_stride(q, d), _p(k), _p(v), kv_ts, _p(out), _tok_stride(out, d), _p(lse), _p(cu_q), _p(cu_k),
+                                   cu_q.numel() - 1, Tq, Tk, int(max_seqlen_q), hq, hkv, d, float(softmax_scale), _stream()), "ie_flash_attn_fwd_x")
+    return out, lse
+
+
+def flash_attn_bwd_x(dout, q, k, v, out, lse, cu_q, cu_k, max_seqlen_q, max_seqlen_k, softmax_scale=None, dq=None, dk=None, dv=None, delta_ws=None):
+    """Backward of flash_attn_fwd_x with the lse / out the probabilities are normalised with (one block of ring attention: the merged ones) -> this
+    block's (dq [Tq, hq, d], dk, dv [Tk, hkv, d]); overwritten."""
+    Tq, hq, d = q.shape
+    Tk, hkv = k.shape[0], k.shape[1]
+    if Tq == 0:
+        raise ValueError("flash_attn_bwd_x: no query rows (the caller zeroes dk / dv)")
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(d)
+    if dq is None:
+        dq = torch.empty((Tq, hq, d), dtype=q.dtype, device=q.device)
+    if dk is None or dv is None:
+        dkv = torch.empty((Tk, 2, hkv, d), dtype=q.dtype, device=q.device)
+        dk, dv = dkv[:, 0], dkv[:, 1]
+    need = _L().ie_flash_attn_bwd_workspace(Tq, hq, hkv, d)
+    if delta_ws is None or delta_ws.numel() < need:
+        delta_ws = torch.empty(need, dtype=torch.float32, device=q.device)
+    kv_ts, dkv_ts = _tok_stride(k, d), _tok_stride(dk, d)
+    if _tok_stride(v, d) != kv_ts or _tok_stride(dv, d) != dkv_ts:
+        raise ValueError("k / v and dk / dv must share their token strides")
+    if tuple(lse.shape) != (hq, Tq) or not lse.is_contiguous():
+        raise ValueError("lse must be a contiguous [hq, Tq] tensor")
+    check(_L().ie_flash_attn_bwd_x(_p(dout), _tok_stride(dout, d), _p(q), _tok_stride(q, d), _p(k), _p(v), kv_ts, _p(out), _tok_stride(out, d), _p(lse),
+                                   _p(delta_ws), _p(dq), _tok_stride(dq, d), _p(dk), _p(dv), dkv_ts, _p(cu_q), _p(cu_k), cu_q.numel() - 1, Tq, Tk,
+                                   int(max_seqlen_q), int(max_seqlen_k), hq, hkv, d, float(softmax_scale), _stream()), "ie_flash_attn_bwd_x")
+    return dq, dk, dv
+
+
+def attn_merge(acc, lse_acc, out_p, lse_p, n):
+    """Fold a block's partial (out_p bf16 [>= n, hq, d], lse_p [hq, Tp]) into the running fp32 result of rows 0 .. n-1 (acc [Ta, hq, d], lse_acc [hq, Ta])."""
+    Ta, hq, d = acc.shape
+    if not (acc.is_contiguous() and lse_acc.is_contiguous() and lse_p.is_contiguous() and acc.dtype == torch.float32):
+        raise ValueError("attn_merge: contiguous fp32 accumulators expected")
+    check(_L().ie_attn_merge(_p(acc), _p(lse_acc), Ta, _p(out_p), _tok_stride(out_p, d), _p(lse_p), lse_p.shape[1], int(n), hq, d, _stream()), "ie_attn_merge")
+
+
+def acc_bf16(dst, src):
+    """dst (fp32, contiguous) += src (bf16, contiguous, same element count)"""
+    if dst.numel() != src.numel() or not (dst.is_contiguous() and src.is_contiguous()) or dst.dtype != torch.float32 or src.dtype != torch.bfloat16:
+        raise ValueError("acc_bf16: contiguous fp32 += bf16 of one size")
+    check(_L().ie_acc_bf16(_p(dst), _p(src), dst.numel(), _stream()), "ie_acc_bf16")
+
+
 _spill_buf = None
 
 
