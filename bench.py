@@ -99,7 +99,7 @@ def _self_launch(n):
     import subprocess
 
     have = torch.cuda.device_count()
-    if have < (1 if os.environ.get("IE_BENCH_BACKEND") == "gloo" else n):
+    if have < (1 if (os.environ.get("IE_BENCH_BACKEND") == "gloo" and "--staged-test" in sys.argv) else n):
         print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (one process per GPU over RCCL)", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--config", default="7B_internlm2", choices=["7B_internlm2", "7B_llama2", "tiny"])
     ap.add_argument("--seq-len", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--staged-test", action="store_true", help="TEST HOOK, together with IE_BENCH_BACKEND=gloo: every rank on cuda:0, collectives staged through "
+                    "the host (exercises the N-rank launch on a one-GPU box; the line it prints says it is not a measurement)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
     ap.add_argument("--merge-micro", type=int, default=None, help="A/B only: 1 = run the micro-batches of a step as one merged pass, 0 = sequentially")
@@ -170,7 +172,10 @@ def main():
     # IE_BENCH_BACKEND=gloo is a TEST HOOK for boxes with one GPU (RCCL refuses two ranks on one device): every rank on cuda:0, the
     # collectives staged through the host by comm.StagedGlooBackend -- it exercises the launch, the N-rank engine and this file's
     # reductions end to end; the line it prints says so and is not a measurement.
-    staged = os.environ.get("IE_BENCH_BACKEND") == "gloo" and world > 1
+    if os.environ.get("IE_BENCH_BACKEND") == "gloo" and world > 1 and not args.staged_test:
+        raise SystemExit("IE_BENCH_BACKEND=gloo is the one-GPU test hook of this file: it needs --staged-test on the command line as well (a stray "
+                         "environment variable must not turn a benchmark into a host-staged run)")
+    staged = args.staged_test and os.environ.get("IE_BENCH_BACKEND") == "gloo" and world > 1
     if staged:
         local_rank = 0
     if torch.cuda.device_count() <= local_rank:

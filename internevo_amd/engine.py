@@ -173,6 +173,7 @@ class InternLM2Engine:
             raise ValueError(f"sp_attention = {mode!r}: 'auto', 'ulysses' or 'ring'")
         heads_divide = mc.num_kv_attention_heads % sp_size == 0 and mc.num_attention_heads % sp_size == 0
         self.ring_mode = sp_size > 1 and (mode == "ring" or (mode == "auto" and not heads_divide))
+        self.overlap_gathered_rows = bool(int(os.environ.get("IE_OVERLAP_GATHERED_ROWS", "0")))   # msp / fsp: see _gathered_rows
         if sp_size > 1 and tc.packed_length % sp_size:
             raise ValueError("sequence parallel size must divide the packed length")
         if sp_size > 1 and not self.ring_mode and not heads_divide:
@@ -587,6 +588,10 @@ class InternLM2Engine:
             product(slice(None))
             return
         work = self.tpar.all_gather_rows_async(x)
+        if not self.overlap_gathered_rows:   # default: ONE product over all rows behind the all-gather -- the row slices of the overlapped form can fall off
+            work.wait()                      # the 256x256 / fused-epilogue schedules (pick_variant depends on the row count) and nothing on xGMI has shown
+            product(slice(None))             # the overlap to pay yet; `overlap_gathered_rows=True` / IE_OVERLAP_GATHERED_ROWS=1 is the A/B switch
+            return
         rl, T = self.rl, x.shape[0]
         product(rl)
         work.wait()
