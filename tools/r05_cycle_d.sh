@@ -1,0 +1,22 @@
+# round-5 final GPU cycle: the full GPU suite as the driver runs it, smoke(), the default bench line, the same under rocprofv3 --kernel-trace --stats,
+# and the two PMC traffic passes of the step
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r05d}
+O=gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+( time timeout 900 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -30 ) > $O/full.log 2>&1; tail -14 $O/full.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 300 python bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench_err.log; echo "bench rc=$?"; cut -c1-330 $O/bench_line.json
+rm -rf /tmp/prof_x
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_x -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_err.log
+DB=$(find /tmp/prof_x -name "*.db" | head -1)
+python3 tools/rocprof_summary.py "$DB" $O/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline" | head -18
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/tr_$C
+  timeout 400 rocprofv3 --pmc $C --kernel-trace -d /tmp/tr_$C -o r -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/bench_under_pmc_$C.json 2> $O/pmc_$C.err
+done
+python3 tools/gemm_traffic_in_step.py "$(find /tmp/tr_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/tr_WRITE_SIZE -name '*.db' | head -1)" $O/gemm_hbm_traffic.json | tail -4
+python3 -c "
+import json
+d=json.loads(open('$O/bench_line.json').read().strip().splitlines()[-1])
+r=d['roofline']; print('roofline', {k:r[k] for k in ('achieved','frac','traffic','avg_launch_us','launches')}); print(r['traffic_note'][:300]); print('cpu', {k:v for k,v in d['cpu_baseline'].items() if k in ('value','cores','kind')})"
