@@ -42,6 +42,33 @@ BF16 = torch.bfloat16
 _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 
 
+_HIP_RT = None
+
+
+def _optimizer_stream(device):
+    """The optimizer's HIP stream.  IE_ADAMW_CUS=n (A/B switch, default 0 = an ordinary stream): a stream whose kernels may only use n of the 256 CUs
+    (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD), so that the HBM-bound AdamW keeps to its CUs beside the next step's forward products instead of
+    taking turns with them for whole CUs (a GEMM workgroup needs a CU to itself: profiles/HISTORY.md section 3.4, profiles/r05_power_clock.md section 4).
+    Measured (profiles/r05_adamw_cu_mask_ab.log, A B A B on one box): 32 / 64 / 96 CUs -> 722-726 ms per step against 671-674 ms unmasked: the products
+    lose more to the CUs that are not theirs, for the longer update, than the update costs in turns.  Off."""
+    global _HIP_RT
+    n = int(os.environ.get("IE_ADAMW_CUS", "0") or 0)
+    if n <= 0 or device.type != "cuda":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+
+    if _HIP_RT is None:
+        _HIP_RT = ctypes.CDLL("libamdhip64.so")
+    per = max(1, min(32, n // 8))
+    words = (ctypes.c_uint32 * 8)(*([(1 << per) - 1 if per < 32 else 0xFFFFFFFF] * 8))
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP_RT.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(8), words)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n} CUs) failed with {rc}")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class InternLM2Engine:
     def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, init="normal", seed=1024, init_fn=None,
                  force_collectives=False, sp_size=None, emulate_isp_grad_rule=1, tp_size=None, batch_wgrad=None, merge_micro=None,
@@ -290,7 +317,7 @@ class InternLM2Engine:
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
         # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
         # GEMMs are MFMA-bound, so bucket b+1's update overlaps the forward of layer b; per-bucket events order the two.
-        self.opt_stream = torch.cuda.Stream(device=device)
+        self.opt_stream = _optimizer_stream(device)
         self._bucket_ready = [None] * len(self.layout.buckets)
         self._opt_done = None
         self.metric = None  # optional internevo_amd.metrics.AccPerplex (attach_metric)
