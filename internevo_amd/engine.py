@@ -201,6 +201,7 @@ class InternLM2Engine:
         heads_divide = mc.num_kv_attention_heads % sp_size == 0 and mc.num_attention_heads % sp_size == 0
         self.ring_mode = sp_size > 1 and (mode == "ring" or (mode == "auto" and not heads_divide))
         self.overlap_gathered_rows = bool(int(os.environ.get("IE_OVERLAP_GATHERED_ROWS", "0")))   # msp / fsp: see _gathered_rows
+        self.attn_bwd_spill = bool(int(os.environ.get("IE_ATTN_BWD_SPILL", "0")))
         if sp_size > 1 and tc.packed_length % sp_size:
             raise ValueError("sequence parallel size must divide the packed length")
         if sp_size > 1 and not self.ring_mode and not heads_divide:
@@ -933,6 +934,8 @@ class InternLM2Engine:
             if self.ring_mode:
                 self.ring.backward(d_ctx_full, self.a_q[sl], self.a_kv[sl], self.a_ctx[sl], self.a_lse[sl], self.ring.plan(cu.host), self.t_dq, self.t_dkv, self.t_delta)
             else:
+                if self.attn_bwd_spill:   # (A/B switch IE_ATTN_BWD_SPILL=1: the five-product backward, kernels.flash_attn_bwd_spill; a no-op once the buffer fits)
+                    K.flash_attn_bwd_spill(True, cu.numel() - 1, max_seqlen, self.a_q[sl].shape[1], True, self.dev)
                 K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
                                  max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
             if not head_x:
