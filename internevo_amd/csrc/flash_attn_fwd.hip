@@ -805,8 +805,267 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64f_k(const bf16_t* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K1 forward, EIGHT waves per block in two groups that take turns on the matrix pipe (round 5; variant 4).  flash_fwd64_k gives every SIMD one wave and
+// hides the softmax in the MFMA shadows of that same wave -- 9 issues per gap where 5 hide: the matrix pipe is 41 % busy
+// (profiles/r05_pmc_flash_fwd_SQ_pass*.md).  Here a SIMD holds TWO waves of 32 query rows (256 rows per block as before; waves 0-3 = group A, 4-7 =
+// group B: one of each per SIMD) and the block runs in HALF-STEPS closed by s_barrier: in a half-step one group is in its matrix phase
+//     M(k):  S(k+1) = K(k+1) Q^T  and  O += V(k)^T P(k)       (32 MFMAs + their LDS fragment reads, s_setprio 1)
+// while the other is in its vector phase
+//     V(k):  softmax of S(k): row maxima, (deferred) rescale, p = exp2(..), row sums, bf16 pack;  group B also requests K(k+2) / V(k+1)
+// and they swap in the next half-step: group A runs M(k) in half-step 2k and V(k) in 2k-1, group B one half-step later.  K and V tiles are
+// double-buffered 64-key images as in the other kernels; a tile requested in half-step 2k (by the group then in its vector phase: it issues no LDS read
+// in front of which hipcc would drain the request) is first read in half-step 2k+2.  Causal: a wave past its own diagonal tile keeps the barriers
+// and skips the work.
+template <int D, bool CAUSAL, int THR, int MODE>
+__global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict__ q, int64_t q_ts, const bf16_t* __restrict__ k,
+                                                       const bf16_t* __restrict__ v, int64_t kv_ts, bf16_t* __restrict__ out, int64_t o_ts,
+                                                       float* __restrict__ lse, const int32_t* __restrict__ cu, int64_t T, int hq, int hkv,
+                                                       float scale) {
+    using G = Geo<D>;
+    constexpr int IMG = G::IMG_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * IMG];  // K stage 0, K stage 1, V stage 0, V stage 1
+
+    const int seq = blockIdx.z;
+    const int h = ((int)blockIdx.x % hkv) * (hq / hkv) + (int)blockIdx.x / hkv;  // the q heads of one kv head share an XCD's L2
+    const int qt = gridDim.y - 1 - blockIdx.y;                                    // heaviest (last) query tiles first
+    const int tok0 = cu[seq];
+    const int len = cu[seq + 1] - tok0;
+    const int q0 = qt * 256;
+    if (q0 >= len) return;
+    const int hk = h / (hq / hkv);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    // rows: group A takes the even 32-row slices, group B the odd ones, so that the two waves of a SIMD see the same diagonal tile
+    const int qw0 = q0 + (2 * w4 + grp) * 32;
+    const int my_q = qw0 + (lane & 31);
+    const bool q_valid = my_q < len;
+    const int kv_end = CAUSAL ? min(len, q0 + 256) : len;
+    const int nt = (kv_end + 63) / 64;                                                    // tiles the block streams
+    const int ntw = qw0 >= len ? 0 : (CAUSAL ? min(nt, (qw0 + 31) / 64 + 1) : nt);        // tiles this wave computes on
+
+    const bf16_t* kbase = k + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    const bf16_t* vbase = v + (int64_t)tok0 * kv_ts + (int64_t)hk * D;
+    TileSrc<D, 4> ksrc, vsrc;          // a tile is requested by the four waves of ONE group
+    ksrc.init(kbase, kv_ts, T - tok0, D, w4, lane);
+    vsrc.init(vbase, kv_ts, T - tok0, D, w4, lane);
+    unsigned char* Kst = smem;
+    unsigned char* Vst = smem + 2 * IMG;
+    if (grp == 0) {                    // K(0), K(1), V(0) up front
+        ksrc.issue(Kst, 0, 0, w4);
+        if (nt > 1) ksrc.issue(Kst + IMG, 64, 0, w4);
+        vsrc.issue(Vst, 0, 0, w4);
+    }
+
+    FragOffs<D> fo;
+    fo.init(lane);
+    s16x8 qf[G::KS];
+    {
+        const bf16_t* qp = q + (int64_t)(tok0 + my_q) * q_ts + (int64_t)h * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            union { uint4 u; s16x8 s; } cv;
+            cv.u = q_valid ? ld16(qp + ks * 16) : z4();
+            qf[ks] = cv.s;
+        }
+    }
+    f32x16 oacc[G::DB];
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db) oacc[db] = zero16();
+    float m_ref = -INFINITY, l_part = 0.f;    // reference maximum of the row (raw score units); this lane's part of the row sum
+    const float sc2 = scale * kLog2e;
+    f32x16 sacc[2];                           // S^T of the tile whose softmax comes next: keys 0..31 / 32..63 of the tile x this lane's row
+    s16x8 pf[2][2];                           // P fragments of the tile whose P.V comes next
+
+    auto xhalf_max = [&](float x) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    // scores of tile t
+    auto scores = [&](int t) {
+        const unsigned char* Ks = Kst + (t & 1) * IMG;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            sacc[c] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+                sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], sacc[c], 0, 0, 0);
+        }
+    };
+    // O^T += V(t)^T P(t)^T
+    auto pv = [&](int t) {
+        const unsigned char* Vs = Vst + (t & 1) * IMG;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Vs, db, 2 * c + s2, fo), pf[c][s2], oacc[db], 0, 0, 0);
+    };
+    // softmax of tile t (scores in sacc) -> pf; the row's reference maximum moves only when some row of the wave rose more than THR log2 units
+    // above its own (p <= 2^THR then; exactly compensated: O and l are rescaled whenever it moves)
+    auto softmax = [&](int t) __attribute__((always_inline)) {
+        const int kv0 = t * 64;
+        const bool need_mask = (CAUSAL && kv0 + 63 > qw0) || (kv0 + 64 > len);
+        if (need_mask) {
+            const int lim = CAUSAL ? min(len - 1, my_q) : len - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * c + creg_row(r, lane);
+                    sacc[c][r] = key > lim ? -INFINITY : sacc[c][r];
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[c][r]);
+        mx = xhalf_max(mx);
+        const float m_new = fmaxf(m_ref, mx);
+        const bool keep = __all((m_new - m_ref) * sc2 <= (float)THR);   // (m_ref = -inf, the first tile: inf <= THR is false -> moves)
+        if (!keep) {
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * sc2);   // m_ref = -inf -> 0
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            l_part *= alpha;
+            m_ref = m_new;
+        }
+        const float moff = ((m_ref == -INFINITY) ? 0.f : m_ref) * sc2;
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[c][r], sc2, -moff));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[c][r + 1], sc2, -moff));
+                rs0 += p0;
+                rs1 += p1;
+                sacc[c][r] = p0;
+                sacc[c][r + 1] = p1;
+            }
+            pf[c][0] = pack_frag(sacc[c], 0);
+            pf[c][1] = pack_frag(sacc[c], 1);
+        }
+        l_part += rs0 + rs1;
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Half-steps -2 .. 2 nt, each closed by a barrier.  Group A: M(-1) | V(0) M(0) | V(1) M(1) | ... | V(nt) M(nt); group B one half-step later:
+    // idle | M(-1) | V(0) M(0) | ... | V(nt-1) M(nt-1) | V(nt).  Two straight-line loops (one per group: no phase branch inside).
+#ifndef IE_FWD8_ABL   // timing ablations (A/B builds, results wrong): 1 no softmax arithmetic, 2 no MFMAs, 4 no transfers in the loop
+#define IE_FWD8_ABL 0
+#endif
+    // (A hand-pipelined matrix phase -- fragments requested four MFMAs ahead, every MFMA pinned behind the request of its gap -- ran 688 us against
+    // 614 us for hipcc's own interleave of the two loops below: 256 registers with spills.  profiles/r05_flash_fwd8.md)
+    auto matrix_phase = [&](int kk) __attribute__((always_inline)) {          // M(kk): S(kk + 1), P.V(kk)
+        __builtin_amdgcn_s_setprio(1);
+        if (!(IE_FWD8_ABL & 2) && kk + 1 < ntw) scores(kk + 1);
+        if (!(IE_FWD8_ABL & 2) && kk >= 0 && kk < ntw) pv(kk);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    auto vector_phase = [&](int kk, bool requests) __attribute__((always_inline)) {   // V(kk): softmax(kk); group B requests K(kk + 2) / V(kk + 1) into the stages tiles kk / kk - 1 left
+        if (requests && !(IE_FWD8_ABL & 4)) {
+            if (kk + 2 < nt) ksrc.issue(Kst + (kk & 1) * IMG, (kk + 2) * 64, 0, w4);
+            if (kk + 1 < nt) vsrc.issue(Vst + ((kk + 1) & 1) * IMG, (kk + 1) * 64, 0, w4);
+        }
+        if (!(IE_FWD8_ABL & 1) && kk < ntw) softmax(kk);
+        if ((IE_FWD8_ABL & 1) && kk < ntw) {   // (the scores stay alive: packed as they are)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { pf[c][0] = pack_frag(sacc[c], 0); pf[c][1] = pack_frag(sacc[c], 1); }
+            l_part += sacc[0][0];
+        }
+        if (requests) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requested a whole half-step before anybody reads it
+        __builtin_amdgcn_s_barrier();
+    };
+    if (MODE == 0) {
+        if (grp == 0) {
+            matrix_phase(-1);
+            for (int kk = 0; kk <= nt; ++kk) {
+                vector_phase(kk, false);
+                matrix_phase(kk);
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();
+            matrix_phase(-1);
+            for (int kk = 0; kk < nt; ++kk) {
+                vector_phase(kk, true);
+                matrix_phase(kk);
+            }
+            __builtin_amdgcn_s_barrier();          // (V(nt): nothing left)
+        }
+    } else {
+        // MODE 1: QUARTERS.  The matrix work of a tile takes a lone wave three times as long as its softmax, so with strictly alternating phases the
+        // group in its vector phase waits two thirds of every half-step.  Here a wave's period is M1 (S(kk+1): 16 MFMAs) | M2 (P.V(kk), first key
+        // half: 8) | M3 (second half: 8) | V (softmax(kk+1)), a barrier behind each, and group B runs TWO quarters behind group A: A M1 + B M3,
+        // A M2 + B V, A M3 + B M1, A V + B M2 -- in every quarter at least one wave of the SIMD issues MFMAs, in two of four both do (the matrix pipe
+        // does not care whose).  Requests: group A asks for K(kk + 3) in its vector quarter, group B for V(kk + 2) in its own (asm pieces; each group
+        // waits for its requests at the end of its next M3, a barrier before anybody reads them).
+        const uint32_t Kst_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem, Vst_lds = Kst_lds + 2 * IMG;
+        constexpr int PERW = TileSrc<D, 4>::PERW;
+        auto pvc = [&](int t, int c) __attribute__((always_inline)) {
+            const unsigned char* Vs = Vst + (t & 1) * IMG;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < G::DB; ++db)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Vs, db, 2 * c + s2, fo), pf[c][s2], oacc[db], 0, 0, 0);
+        };
+        auto period = [&](int kk) __attribute__((always_inline)) {
+            const bool work = kk >= 0 && kk < ntw;
+            __builtin_amdgcn_s_setprio(1);
+            if (kk + 1 < ntw) scores(kk + 1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            if (work) pvc(kk, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            if (work) pvc(kk, 1);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this group's requests of a period ago have landed
+            __builtin_amdgcn_s_barrier();
+            if (grp == 0) {
+                if (kk + 3 < nt) {
+#pragma unroll
+                    for (int pq = 0; pq < PERW; ++pq) ksrc.issue_piece_asm(Kst_lds + ((kk + 3) & 1) * IMG, (kk + 3) * 64 * ksrc.ts2, w4, pq);
+                }
+            } else if (kk + 2 < nt) {
+#pragma unroll
+                for (int pq = 0; pq < PERW; ++pq) vsrc.issue_piece_asm(Vst_lds + ((kk + 2) & 1) * IMG, (kk + 2) * 64 * vsrc.ts2, w4, pq);
+            }
+            if (kk + 1 < ntw) softmax(kk + 1);
+            __builtin_amdgcn_s_barrier();
+        };
+        if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+        for (int kk = -1; kk < nt; ++kk) period(kk);
+        if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part), __float_as_uint(l_part), false, false);
+        const float l_row = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        const float inv = l_row > 0.f ? 1.f / l_row : 0.f;
+        store_row_block<D>(out + (int64_t)(tok0 + my_q) * o_ts + (int64_t)h * D, oacc, inv, lane, q_valid, (o_ts & 7) == 0);
+        if (q_valid && lane < 32) lse[(int64_t)h * T + tok0 + my_q] = (l_row > 0.f) ? m_ref * scale + logf(l_row) : -INFINITY;
+    }
+}
+
 int g_fwd_variant = -1;  // -1: automatic; 0: 32 rows per wave (flash_fwd_k); 1: 64 rows per wave, THR = 0; 2: 64 rows per wave, THR = 4;
-                         // 3: 64 rows per wave, folded softmax (flash_fwd64f_k), THR = 4
+                         // 3: 64 rows per wave, folded softmax (flash_fwd64f_k), THR = 4; 4: eight waves in two groups alternating on the matrix pipe
+                         // (flash_fwd8_k), THR = 4; 5: the same in quarter phases (slower: kept for the A/B)
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
@@ -830,7 +1089,9 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
     // scale * log2 e = 1: ie_qkv_rotary_fwd_scaled): scaling q inside the attention kernel costs one more bf16 rounding of q, which the
     // backward kernels (they recompute the scores from the q they are given) would not see
     const bool prescaled = fabsf(softmax_scale * kLog2e - 1.f) < 1e-6f;
-    const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? (prescaled ? 3 : 2) : 0);
+    // round 5: ... and there the eight-wave kernel whose two wave groups take turns on the matrix pipe (variant 4) measures 7-8 % faster still, causal
+    // and full, with the same results (profiles/r05_flash_fwd8.md)
+    const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : ((d == 128 && T >= (int64_t)nseq * 2048) ? (prescaled ? 3 : 4) : 0);
 #ifdef IE_ENABLE_ABLATIONS   // profiling builds only (hipcc -DIE_ENABLE_ABLATIONS): the shipped library holds no kernel with wrong results
     if (fwd_variant >= 10 && d == 128 && causal) {   // timing ablations of the folded kernel (results wrong)
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
@@ -853,6 +1114,18 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
         return ie_launch_status("ie_flash_attn_fwd launch");
     }
 #endif
+    if (fwd_variant == 4 || fwd_variant == 5) {   // eight waves in two groups that share the matrix pipe: 4 = alternating half-steps, 5 = quarters
+        dim3 grid8((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
+#define IE_L8M(DD, CA, MO)                                                                                                             \
+    hipLaunchKernelGGL((flash_fwd8_k<DD, CA, 4, MO>), grid8, dim3(512), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
+                       (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
+#define IE_L8(DD, CA) do { if (fwd_variant == 4) IE_L8M(DD, CA, 0); else IE_L8M(DD, CA, 1); } while (0)
+        if (d == 128) { if (causal) IE_L8(128, true); else IE_L8(128, false); }
+        else          { if (causal) IE_L8(64, true); else IE_L8(64, false); }
+#undef IE_L8
+#undef IE_L8M
+        return ie_launch_status("ie_flash_attn_fwd launch");
+    }
     if (fwd_variant >= 3) {
         dim3 grid64((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_LF(DD, CA)                                                                                                                 \
@@ -915,7 +1188,7 @@ extern "C" int ie_tune_flash_fwd_variant(int variant) {
 #else
     // (forcing 3 at a softmax_scale other than ln 2 scales q inside the kernel: one more bf16 rounding of q than the backward kernels see -- correct to
     // bf16 rounding, tested in tests/test_kernels_gpu.py, but not what the automatic dispatch ever picks)
-    IE_CHECK_ARG(variant >= -1 && variant <= 3, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 3");
+    IE_CHECK_ARG(variant >= -1 && variant <= 5, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 5");
 #endif
     g_fwd_variant = variant;
     return IE_OK;
