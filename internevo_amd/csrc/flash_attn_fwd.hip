@@ -886,6 +886,19 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
     // scores of tile t
     auto scores = [&](int t) {
         const unsigned char* Ks = Kst + (t & 1) * IMG;
+#ifndef IE_FWD8_ALT   // A/B: 1 = the two key halves' accumulation chains interleaved (consecutive MFMAs on different accumulators)
+#define IE_FWD8_ALT 0
+#endif
+        if (IE_FWD8_ALT) {
+            sacc[0] = zero16();
+            sacc[1] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], sacc[c], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             sacc[c] = zero16();
@@ -969,8 +982,38 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
     // 614 us for hipcc's own interleave of the two loops below: 256 registers with spills.  profiles/r05_flash_fwd8.md)
     auto matrix_phase = [&](int kk) __attribute__((always_inline)) {          // M(kk): S(kk + 1), P.V(kk)
         __builtin_amdgcn_s_setprio(1);
-        if (!(IE_FWD8_ABL & 2) && kk + 1 < ntw) scores(kk + 1);
-        if (!(IE_FWD8_ABL & 2) && kk >= 0 && kk < ntw) pv(kk);
+        const bool do_s = !(IE_FWD8_ABL & 2) && kk + 1 < ntw, do_pv = !(IE_FWD8_ABL & 2) && kk >= 0 && kk < ntw;
+#ifndef IE_FWD8_SGB   // 1: the common matrix phase (both products) as ONE scheduling region with a prescribed interleave (A/B switch)
+#define IE_FWD8_SGB 0
+#endif
+        if (IE_FWD8_SGB && do_s && do_pv) {
+            // the wave is alone on the matrix pipe: every LDS round trip it has to wait for is pipe idle time.  hipcc's own order keeps the reads about
+            // one MFMA ahead and drains them (lgkmcnt(0)) before most MFMAs of the second product; prescribed here: four fragments ahead throughout --
+            // 4 reads | 12 x (MFMA, read) | 4 x (MFMA, 2 transposing reads) | 12 x (MFMA, 2 transposing reads) | 4 MFMAs
+            scores(kk + 1);
+            pv(kk);
+            constexpr int NKF = 2 * G::KS, NVF = 4 * G::DB;   // fragments of the two products (one read / two reads each)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < NKF - 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NVF - 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+        } else {
+            if (do_s) scores(kk + 1);
+            if (do_pv) pv(kk);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
