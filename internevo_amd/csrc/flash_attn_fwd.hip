@@ -879,6 +879,9 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
     f32x16 sacc[2];                           // S^T of the tile whose softmax comes next: keys 0..31 / 32..63 of the tile x this lane's row
     s16x8 pf[2][2];                           // P fragments of the tile whose P.V comes next
 
+#ifndef IE_FWD8_ABL   // timing ablations (A/B builds, results wrong): 1 no softmax arithmetic, 2 no MFMAs, 4 no transfers in the loop, 8 / 16 / 32 below
+#define IE_FWD8_ABL 0
+#endif
     auto xhalf_max = [&](float x) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
         return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -904,7 +907,8 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
             sacc[c] = zero16();
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks)
-                sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], sacc[c], 0, 0, 0);
+                sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((IE_FWD8_ABL & 32) ? qf[(ks + 1) % G::KS] : row_frag<D>(Ks, 32 * c, ks, fo), qf[ks], sacc[c], 0,
+                                                                  0, 0);
         }
     };
     // O^T += V(t)^T P(t)^T
@@ -916,7 +920,13 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int db = 0; db < G::DB; ++db)
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag<D>(Vs, db, 2 * c + s2, fo), pf[c][s2], oacc[db], 0, 0, 0);
+                {
+                    const int idx = (2 * c + s2) * G::DB + db;   // (timing ablations: 8 = plain 16-byte reads in place of the transposing pairs, 16 = no reads)
+                    const s16x8 vf = (IE_FWD8_ABL & 16)  ? qf[idx % G::KS]
+                                     : (IE_FWD8_ABL & 8) ? row_frag<D>(Vs, 32 * (idx & 1), (idx >> 1) % G::KS, fo)
+                                                         : trans_frag<D>(Vs, db, 2 * c + s2, fo);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c][s2], oacc[db], 0, 0, 0);
+                }
     };
     // softmax of tile t (scores in sacc) -> pf; the row's reference maximum moves only when some row of the wave rose more than THR log2 units
     // above its own (p <= 2^THR then; exactly compensated: O and l are rescaled whenever it moves)
@@ -975,12 +985,78 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
 
     // Half-steps -2 .. 2 nt, each closed by a barrier.  Group A: M(-1) | V(0) M(0) | V(1) M(1) | ... | V(nt) M(nt); group B one half-step later:
     // idle | M(-1) | V(0) M(0) | ... | V(nt-1) M(nt-1) | V(nt).  Two straight-line loops (one per group: no phase branch inside).
-#ifndef IE_FWD8_ABL   // timing ablations (A/B builds, results wrong): 1 no softmax arithmetic, 2 no MFMAs, 4 no transfers in the loop
-#define IE_FWD8_ABL 0
-#endif
     // (A hand-pipelined matrix phase -- fragments requested four MFMAs ahead, every MFMA pinned behind the request of its gap -- ran 688 us against
     // 614 us for hipcc's own interleave of the two loops below: 256 registers with spills.  profiles/r05_flash_fwd8.md)
-    auto matrix_phase = [&](int kk) __attribute__((always_inline)) {          // M(kk): S(kk + 1), P.V(kk)
+    // MODE 2 (variant 6): the matrix phase as a prescribed order built on two measured rules (MI355X_MICROARCH.md, per-instruction constants; this
+    // kernel's ablations in profiles/r05_flash_fwd8.md): (1) any instruction between two MFMAs on the SAME accumulator costs ~43 cycles (the
+    // accumulator forwarding is lost) -- between MFMAs on different accumulators it costs its issue slot; (2) a lone wave pays the LDS round trips it
+    // waits for as matrix-pipe idle time.  So: S(kk+1) as the two key halves' chains INTERLEAVED (neighbouring MFMAs on different accumulators), its
+    // sixteen K fragments requested before the phase opens (end of the wave's vector phase: the tile is visible since the barrier that opened that
+    // phase, the registers are free once the scores are packed), the two transposing reads of P.V fragment m issued right behind S MFMA m into the
+    // ring slot that MFMA just read (sixteen MFMAs ahead of their use), and P.V as sixteen bare MFMAs, d-blocks rotating.  sched_barrier pins
+    // the order; the counted lgkmcnt waits are hipcc's own (in-order counters: exact for a pinned straight-line order).
+    constexpr bool PIPE = MODE == 2;
+    constexpr int NR = 2 * G::KS;                      // ring slots: S MFMA m = (k-step m / 2, key half m % 2); P.V MFMA m = (key step m / DB, d-block m % DB)
+    static_assert(4 * G::DB == 2 * G::KS, "one ring for the fragments of both products");
+    s16x8 ring[NR];
+    uint32_t va[2 * G::DB];                            // this phase's V fragment addresses (stage included; the key step is an immediate)
+    // Fragment addresses from THREE lane constants instead of FragOffs' sixteen: the XOR swizzle commutes with the k-step / d-block bits,
+    // row[ks] = row[0] ^ 32 ks and tr[db] = tr[0] ^ 64 db; 32-row blocks and key steps are immediates.
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const uint32_t a_row = smem_lds + fo.row[0], a_tr0 = smem_lds + 2 * IMG + fo.tr0[0], a_tr1 = smem_lds + 2 * IMG + fo.tr1[0];
+    auto kfrag = [&](uint32_t base, int half, int ks) __attribute__((always_inline)) {
+        if (IE_FWD8_ABL & 32) return qf[(ks + 1) % G::KS];
+        return *(const __attribute__((address_space(3))) s16x8*)((base ^ (32u * ks)) + half * 32 * (2 * D));
+    };
+    auto vfrag = [&](int db, int step) __attribute__((always_inline)) {
+        if (IE_FWD8_ABL & 16) return qf[(db + 4 * step) % G::KS];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va[2 * db] + step * 16 * (2 * D)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va[2 * db + 1] + step * 16 * (2 * D)));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    };
+#define IE_SB() __builtin_amdgcn_sched_barrier(0)
+    auto load_k = [&](int t) __attribute__((always_inline)) {          // ring <- the sixteen K fragments of tile t
+        uint32_t kb = a_row + (t & 1) * IMG;
+        asm volatile("" : "+v"(kb));   // (opaque: the per-fragment XORs stay here instead of becoming eight loop-invariant registers)
+#pragma unroll
+        for (int m = 0; m < NR; ++m) ring[m] = kfrag(kb, m & 1, m >> 1);
+    };
+    auto set_va = [&](int t) __attribute__((always_inline)) {          // V fragment addresses of tile t
+#pragma unroll
+        for (int db = 0; db < G::DB; ++db) {
+            va[2 * db] = (a_tr0 + (t & 1) * IMG) ^ (64u * db);
+            va[2 * db + 1] = (a_tr1 + (t & 1) * IMG) ^ (64u * db);
+            asm volatile("" : "+v"(va[2 * db]), "+v"(va[2 * db + 1]));
+        }
+    };
+    // Straight-line pieces, no branch inside (where paths join hipcc's waits take the worse of the two histories; the loops below are peeled instead:
+    // first half-step = S only, a wave's last tile = P.V only, both once per wave).
+    auto pipe_s = [&](bool then_pv) __attribute__((always_inline)) {   // S from the ring; ring <- the P.V fragments if P.V follows (va set)
+        IE_SB();
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            sacc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[m], qf[m >> 1], (m >> 1) ? sacc[m & 1] : zero16(), 0, 0, 0);
+            IE_SB();
+            if (then_pv) ring[m] = vfrag(m % G::DB, m / G::DB);
+            IE_SB();
+        }
+    };
+    auto pipe_pv = [&]() __attribute__((always_inline)) {              // O += V^T P from the ring
+        IE_SB();
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            oacc[m % G::DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[m], pf[(m / G::DB) >> 1][(m / G::DB) & 1], oacc[m % G::DB], 0, 0, 0);
+            IE_SB();
+        }
+    };
+#undef IE_SB
+#ifndef IE_FWD8_DEFER   // 1: group B requests its tiles from inline asm and waits for them at the end of its NEXT (matrix) phase, a half-step later
+#define IE_FWD8_DEFER 0
+#endif
+    auto matrix_phase = [&](int kk, bool waits = false) __attribute__((always_inline)) {          // M(kk): S(kk + 1), P.V(kk)
         __builtin_amdgcn_s_setprio(1);
         const bool do_s = !(IE_FWD8_ABL & 2) && kk + 1 < ntw, do_pv = !(IE_FWD8_ABL & 2) && kk >= 0 && kk < ntw;
 #ifndef IE_FWD8_SGB   // 1: the common matrix phase (both products) as ONE scheduling region with a prescribed interleave (A/B switch)
@@ -1015,12 +1091,27 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
             if (do_pv) pv(kk);
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
+        if (IE_FWD8_DEFER && waits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(IE_FWD8_ABL & 64)) __builtin_amdgcn_s_barrier();   // (64: the loop without its barriers -- what keeping the groups in step costs)
     };
     auto vector_phase = [&](int kk, bool requests) __attribute__((always_inline)) {   // V(kk): softmax(kk); group B requests K(kk + 2) / V(kk + 1) into the stages tiles kk / kk - 1 left
+        // (the fragment requests first: behind a transfer request hipcc would drain the transfer before any LDS read)
         if (requests && !(IE_FWD8_ABL & 4)) {
-            if (kk + 2 < nt) ksrc.issue(Kst + (kk & 1) * IMG, (kk + 2) * 64, 0, w4);
-            if (kk + 1 < nt) vsrc.issue(Vst + ((kk + 1) & 1) * IMG, (kk + 1) * 64, 0, w4);
+            if (IE_FWD8_DEFER) {
+                const uint32_t sl = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+                constexpr int PW = TileSrc<D, 4>::PERW;
+                if (kk + 2 < nt) {
+#pragma unroll
+                    for (int pq = 0; pq < PW; ++pq) ksrc.issue_piece_asm(sl + (kk & 1) * IMG, (kk + 2) * 64 * ksrc.ts2, w4, pq);
+                }
+                if (kk + 1 < nt) {
+#pragma unroll
+                    for (int pq = 0; pq < PW; ++pq) vsrc.issue_piece_asm(sl + 2 * IMG + ((kk + 1) & 1) * IMG, (kk + 1) * 64 * vsrc.ts2, w4, pq);
+                }
+            } else {
+                if (kk + 2 < nt) ksrc.issue(Kst + (kk & 1) * IMG, (kk + 2) * 64, 0, w4);
+                if (kk + 1 < nt) vsrc.issue(Vst + ((kk + 1) & 1) * IMG, (kk + 1) * 64, 0, w4);
+            }
         }
         if (!(IE_FWD8_ABL & 1) && kk < ntw) softmax(kk);
         if ((IE_FWD8_ABL & 1) && kk < ntw) {   // (the scores stay alive: packed as they are)
@@ -1028,10 +1119,73 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
             for (int c = 0; c < 2; ++c) { pf[c][0] = pack_frag(sacc[c], 0); pf[c][1] = pack_frag(sacc[c], 1); }
             l_part += sacc[0][0];
         }
-        if (requests) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requested a whole half-step before anybody reads it
-        __builtin_amdgcn_s_barrier();
+        if (requests && !IE_FWD8_DEFER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requested a whole half-step before anybody reads it
+        if (!(IE_FWD8_ABL & 64)) __builtin_amdgcn_s_barrier();
     };
-    if (MODE == 0) {
+    if (MODE == 2) {
+        // the same half-steps as MODE 0, the loops peeled by what a wave does in them: kk < ntw - 1 both products (the pipeline), kk = ntw - 1 its last
+        // P.V, then nothing (a wave above the block's last diagonal tile; group A's extra half-steps) -- barriers and group B's requests in all of them
+        auto requests = [&](int kk) __attribute__((always_inline)) {
+            if (kk + 2 < nt) ksrc.issue(Kst + (kk & 1) * IMG, (kk + 2) * 64, 0, w4);
+            if (kk + 1 < nt) vsrc.issue(Vst + ((kk + 1) & 1) * IMG, (kk + 1) * 64, 0, w4);
+        };
+        // (sched_barrier: hipcc otherwise sinks half of the softmax -- pure register arithmetic -- below the s_barrier into the wave's matrix phase)
+        auto phase_end = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto run = [&](auto is_b) __attribute__((always_inline)) {
+            constexpr bool B = decltype(is_b)::value;
+            const int ni = B ? nt : nt + 1;
+            if (B) phase_end();
+            __builtin_amdgcn_s_setprio(1);                                   // M(-1)
+            if (ntw > 0) { load_k(0); pipe_s(false); }
+            __builtin_amdgcn_s_setprio(0);
+            phase_end();
+            int kk = 0;
+            for (; kk < ntw - 1; ++kk) {
+                if (B) requests(kk);
+                if (!(IE_FWD8_ABL & 1)) softmax(kk);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) { pf[c][0] = pack_frag(sacc[c], 0); pf[c][1] = pack_frag(sacc[c], 1); }
+                    l_part += sacc[0][0];
+                }
+                if (B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(IE_FWD8_ABL & 128)) load_k(kk + 1);   // (behind the wait: hipcc drains every transfer it knows of in front of an LDS read anyway)
+                set_va(kk);
+                phase_end();
+                __builtin_amdgcn_s_setprio(1);
+                if (IE_FWD8_ABL & 128) load_k(kk + 1);
+                pipe_s(true);
+                pipe_pv();
+                __builtin_amdgcn_s_setprio(0);
+                phase_end();
+            }
+            if (kk < ntw) {
+                if (B) requests(kk);
+                softmax(kk);
+                if (B) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                set_va(kk);
+#pragma unroll
+                for (int m = 0; m < NR; ++m) ring[m] = vfrag(m % G::DB, m / G::DB);
+                phase_end();
+                __builtin_amdgcn_s_setprio(1);
+                pipe_pv();
+                __builtin_amdgcn_s_setprio(0);
+                phase_end();
+                ++kk;
+            }
+            for (; kk < ni; ++kk) {
+                if (B) { requests(kk); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                phase_end();
+                phase_end();
+            }
+            if (B) phase_end();
+        };
+        if (grp == 0) run(std::false_type{}); else run(std::true_type{});
+    } else if (MODE != 1) {
         if (grp == 0) {
             matrix_phase(-1);
             for (int kk = 0; kk <= nt; ++kk) {
@@ -1043,7 +1197,7 @@ __global__ __launch_bounds__(512, 2) void flash_fwd8_k(const bf16_t* __restrict_
             matrix_phase(-1);
             for (int kk = 0; kk < nt; ++kk) {
                 vector_phase(kk, true);
-                matrix_phase(kk);
+                matrix_phase(kk, true);
             }
             __builtin_amdgcn_s_barrier();          // (V(nt): nothing left)
         }
@@ -1157,12 +1311,12 @@ extern "C" int ie_flash_attn_fwd(const void* q, int64_t q_ts, const void* k, con
         return ie_launch_status("ie_flash_attn_fwd launch");
     }
 #endif
-    if (fwd_variant == 4 || fwd_variant == 5) {   // eight waves in two groups that share the matrix pipe: 4 = alternating half-steps, 5 = quarters
+    if (fwd_variant >= 4 && fwd_variant <= 6) {   // eight waves in two groups that share the matrix pipe: 4 = alternating half-steps, 5 = quarters, 6 = 4 with the pipelined matrix phase
         dim3 grid8((unsigned)hq, (unsigned)((max_seqlen + 255) / 256), (unsigned)nseq);
 #define IE_L8M(DD, CA, MO)                                                                                                             \
     hipLaunchKernelGGL((flash_fwd8_k<DD, CA, 4, MO>), grid8, dim3(512), 0, st, (const bf16_t*)q, q_ts, (const bf16_t*)k, (const bf16_t*)v, kv_ts, \
                        (bf16_t*)out, o_ts, lse, cu_seqlens, T, hq, hkv, softmax_scale)
-#define IE_L8(DD, CA) do { if (fwd_variant == 4) IE_L8M(DD, CA, 0); else IE_L8M(DD, CA, 1); } while (0)
+#define IE_L8(DD, CA) do { if (fwd_variant == 4) IE_L8M(DD, CA, 0); else if (fwd_variant == 5) IE_L8M(DD, CA, 1); else IE_L8M(DD, CA, 2); } while (0)
         if (d == 128) { if (causal) IE_L8(128, true); else IE_L8(128, false); }
         else          { if (causal) IE_L8(64, true); else IE_L8(64, false); }
 #undef IE_L8
@@ -1231,7 +1385,7 @@ extern "C" int ie_tune_flash_fwd_variant(int variant) {
 #else
     // (forcing 3 at a softmax_scale other than ln 2 scales q inside the kernel: one more bf16 rounding of q than the backward kernels see -- correct to
     // bf16 rounding, tested in tests/test_kernels_gpu.py, but not what the automatic dispatch ever picks)
-    IE_CHECK_ARG(variant >= -1 && variant <= 5, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 5");
+    IE_CHECK_ARG(variant >= -1 && variant <= 6, "ie_tune_flash_fwd_variant: -1 (automatic), 0 .. 6");
 #endif
     g_fwd_variant = variant;
     return IE_OK;

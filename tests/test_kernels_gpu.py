@@ -608,7 +608,7 @@ def test_flash_attention_lse_and_big_scores(dev):
     close(lse, torch.logsumexp(s, -1), 1e-3, 1e-2, "flash lse")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("lens,hq,hkv,d,causal", [
     ([300, 700, 257], 4, 2, 128, True),    # ragged: 256-row blocks with idle waves, a tail block of one row
     ([1, 129, 64, 512], 4, 1, 64, True),
@@ -616,7 +616,9 @@ def test_flash_attention_lse_and_big_scores(dev):
     ([1024], 8, 2, 128, True),
 ])
 def test_flash_forward_64_rows_per_wave(dev, variant, lens, hq, hkv, d, causal):
-    """The one-wave-per-SIMD forward (flash_fwd64_k; picked automatically for long head-dim-128 sequences) against the oracle, with
+    """(Variants 4 - 6: the eight-wave kernel flash_fwd8_k -- half-steps, quarters, half-steps with the pipelined matrix phase -- on the same ragged
+    packs: blocks with idle waves, one-row tails, one-tile sequences.)
+    The one-wave-per-SIMD forward (flash_fwd64_k; picked automatically for long head-dim-128 sequences) against the oracle, with
     the exact rescale (variant 1) and the deferred rescale (variant 2), and the folded-softmax kernel flash_fwd64f_k (variant 3: Q
     prescaled, the reference maximum subtracted by an extra MFMA k-step, per-lane partial row sums), including a late spiky key that
     forces the rescale branch of the deferred forms (guide section 5.4 rule 26) and the log-sum-exp the backward consumes."""
