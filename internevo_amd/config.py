@@ -226,8 +226,9 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
             raise NotImplementedError(f"{_UNSUPPORTED}: moe.top_k = {moe.get('top_k', 1)} (top-2 gating only)")
         if not moe.get("drop_tokens", True) or moe.get("noisy_gate_policy", None) not in (None, "None"):
             raise NotImplementedError(f"{_UNSUPPORTED}: moe.drop_tokens=False / moe.noisy_gate_policy")
-        if sp_size > 1 or tp_size > 1 or pp_size > 1:
-            raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with tensor / sequence / pipeline parallelism (data and expert parallelism only)")
+        if sp_size > 1 or pp_size > 1 or (tp_size > 1 and tp_mode != "mtp"):
+            raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with sequence / pipeline parallelism or the sequence-sharded tensor modes msp / fsp "
+                                      "(data, expert and Megatron 'mtp' tensor parallelism only)")
         if not m.get("use_swiglu", True) or m.get("residual_in_fp32", False):
             raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with use_swiglu=False / residual_in_fp32")
         moe_kw = dict(num_experts=int(m["num_experts"]), moe_capacity_factor=float(moe.get("capacity_factor", 1.0)),

@@ -33,8 +33,12 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity, top_k=2):
 
 class MoELayer:
     def __init__(self, hidden, ffn, num_experts, tokens, device, capacity_factor=1.0, min_capacity=4, seed=0, layer_index=0, ep_group=None,
-                 ep_size=1, ep_rank=0):
-        """tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
+                 ep_size=1, ep_rank=0, tpar=None):
+        """tpar (tensorpar.TensorParallel, tp > 1): every expert is a FeedForward over the TENSOR group (gshard_layer.py:421-433 -> modules/mlp.py:40-86):
+        `ffn` is then this rank's F / tp units (w1 / w3 cut by rows, w2 by columns), the experts' outputs are partial sums that are all-reduced over the
+        group before the combine (RowParallelLinearTorch), and so is the gradient of the dispatched tokens behind the w1 | w3 products
+        (ColumnParallelLinearTorch's backward); gate, routing, dispatch and combine run replicated on the same tokens with the same noise.
+        tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
         backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F].
         (The fp8 expert route of round 4 was removed in round 5: it lost 3 % in the step; the e4m3 product itself stays in the library, kernels.gemm_fp8.)"""
         if not 2 <= num_experts <= 16:
@@ -47,6 +51,7 @@ class MoELayer:
         self.cf, self.min_cap = capacity_factor, min_capacity
         self.C = capacity(tokens, num_experts, capacity_factor, min_capacity)
         self.ep_group, self.ep, self.ep_rank = ep_group, ep_size, ep_rank
+        self.tpar = tpar if tpar is not None and tpar.tp > 1 else None
         self.El = num_experts // ep_size
         self.seed, self.layer, self.calls = int(seed), int(layer_index), 0
         self.dev = device
@@ -113,6 +118,8 @@ class MoELayer:
         for g in range(ep):
             rows = slice(g * El * C, (g + 1) * El * C)
             self._products(self.act[rows].view(El, C, F), w2, eo[rows].view(El, C, M), "w2")
+        if self.tpar is not None:
+            self.tpar.all_reduce_sum(eo)          # w2 is row-parallel: every tensor rank holds a partial sum of the experts' outputs
         if self.ep > 1:
             self._a2a(self.xout, self.eo)
         check(L.ie_moe_combine_fwd(K._p(self.eo), K._p(self.row), K._p(self.weight), S, M, K._p(out), out.stride(0), st()), "ie_moe_combine_fwd")
@@ -141,8 +148,12 @@ class MoELayer:
         K.swiglu_bwd(self.d_act, self.h13[:, :F], self.h13[:, F:], self.d_h13[:, :F], self.d_h13[:, F:])
         for rows in blocks:
             K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), w13, d_ein[rows].view(El, C, M), b_kmajor=True)
+        if self.tpar is not None:                 # w1 | w3 are column-parallel: the input gradient is summed over the tensor group, under the weight gradient
+            h_ = self.tpar.all_reduce_sum_async(d_ein)
         for g, rows in enumerate(blocks):
             K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), ein[rows].view(El, C, M), d_w13, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
+        if self.tpar is not None:
+            h_.wait()
         if self.ep > 1:
             self._a2a(self.d_xin, self.d_ein)
         check(L.ie_moe_dispatch_bwd(K._p(self.d_ein), K._p(self.row), K._p(self.token_of), S, M, K._p(dx), dx.stride(0), st()), "ie_moe_dispatch_bwd")

@@ -13,8 +13,16 @@ data-parallel step with the reference's automatic expert parallelism: ep = min(w
 groups of ep CONSECUTIVE ranks each holding num_experts / ep experts, the [E, C, M] dispatch / combine buffers exchanged by one all_to_all per
 direction (moe.MoELayer), dense parameters and gates averaged by all-reduce over all ranks, an expert's gradient summed over its expert
 group's tokens and averaged over its expert-data group only, the moe group's norm scaled as solver/optimizer/utils.py:362-368; optimizer
-state replicated (`parallel.zero1.size = 1` semantics).  Tensor / sequence / pipeline parallelism, checkpoints and merged micro-batches
-are the dense engine's and are refused here (config.py).
+state replicated (`parallel.zero1.size = 1` semantics).
+Megatron tensor parallelism (parallel.tensor = dict(size=tp, mode="mtp"); round 5): tensor groups of tp CONSECUTIVE ranks that read the same
+micro-batches and draw the same gate noise; Wqkv (+ bias) cut by heads, out_proj by input columns (its bias added once, behind the all-reduce),
+every expert's w1 / w3 by rows and w2 by columns (gshard_layer.py:421-433: the experts are FeedForward modules over the TENSOR group), the head by
+vocabulary rows with the vocabulary-parallel loss of the dense engine; embedding, norms and gates whole on every rank.  Four all-reduces per layer
+and micro-batch (out_proj / expert outputs forward, Wqkv / w1|w3 input gradients backward), data and expert parallelism over the ranks that hold the
+same shard (expert groups = consecutive entries of a data-parallel group, process_group_initializer.py:493-524), group norms summed over the tensor
+group with the replicated parameters counted once (solver/optimizer/utils.py:225-262,330-352).  Pinned on a 2-process run of the reference
+(tests/golden/train_moe_tp2_bf16_rank*.json).  Sequence-sharded modes (msp / fsp), sequence and pipeline parallelism, and checkpoints under tensor
+parallelism are refused.
 Weights: Wqkv is kept in the [head][q, k, v][d] row order of the shared rotary / attention kernels and converted at the naming boundary
 (`named_parameters` / `load_named_parameters`), exactly like LLAMA2's wq / wk / wv in the dense engine.
 """
@@ -30,6 +38,7 @@ from .comm import backend_for
 from .config import PathConfig
 from .moe import MoELayer
 from .schedule import Beta2Scheduler, CosineWarmupLR
+from .tensorpar import TensorParallel
 
 BF16 = torch.bfloat16
 GROUPS = ("0_default", "1_fp32", "2_moe_ep_size_1")
@@ -47,8 +56,9 @@ def group_of(name):
 
 
 class MoEEngine:
-    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, seed=1024, init_fn=None, noise_fn=None):
-        """noise_fn(call_index, S, E) -> fp32 [S, E] device tensor: test hook that injects the Gumbel noise of the call-th gating call of the
+    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, seed=1024, init_fn=None, noise_fn=None, tp_size=None):
+        """tp_size: Megatron tensor-parallel size (default: cfg.train.tp_size).
+        noise_fn(call_index, S, E) -> fp32 [S, E] device tensor: test hook that injects the Gumbel noise of the call-th gating call of the
         run (layer-major inside a micro-batch); None = generated on the device from (seed, layer, call)."""
         self.cfg, self.mc, self.tc = cfg, cfg.model, cfg.train
         mc, tc = self.mc, self.tc
@@ -69,41 +79,61 @@ class MoEEngine:
         # ep CONSECUTIVE data-parallel ranks, expert-data groups = the ranks with the same position in their expert group): every rank holds
         # E / ep experts, its tokens visit the others through the all_to_all of the dispatch buffers (moe.MoELayer).
         E_ = max(mc.num_experts, 1)
+        tp = int(tp_size if tp_size is not None else getattr(tc, "tp_size", 1))
+        if tp > 1 and getattr(tc, "tp_mode", "mtp") != "mtp":
+            raise NotImplementedError("MoEEngine: tensor parallelism in mode 'mtp' only (msp / fsp shard the sequence in front of the gate)")
+        if tp > 1 and process_group is not None:
+            raise NotImplementedError("MoEEngine runs over the default group")
+        if tp > 1 and tc.label_smoothing > 0:
+            raise NotImplementedError("MoEEngine: label smoothing with the vocabulary-parallel loss (the dense engine has it)")
+        if mc.num_attention_heads % tp or ffn_dim(mc) % tp or mc.vocab_size % tp:
+            raise ValueError(f"heads {mc.num_attention_heads}, FFN units {ffn_dim(mc)} and vocabulary {mc.vocab_size} must split over {tp} tensor ranks")
+        self.tpar = TensorParallel(tp, rank, world_size, vocab_parallel=True, embed_split=False)   # (collective: creates the tensor / data groups)
+        self.tp, self.tp_rank = tp, self.tpar.tp_rank
+        dpw, dpr = self.tpar.dp_world, self.tpar.dp_rank           # the ranks that hold the same shard: data (and expert) parallelism runs over them
+        self.dp_world, self.dp_group = dpw, self.tpar.dp_group
         self.ep, self.ep_rank, self.ep_group, self.edp_group = 1, 0, None, None
-        if world_size > 1 and not self.dense:
+        if dpw > 1 and not self.dense:
             if process_group is not None:
                 raise NotImplementedError("MoEEngine runs over the default group (pure data parallelism + expert parallelism)")
-            ep = min(world_size, E_)
-            if world_size % ep or E_ % ep:
-                raise NotImplementedError(f"expert parallel size {ep} must divide the world size {world_size} and the number of experts {E_}")
-            for g in range(world_size // ep):          # collective: every rank creates every group, same order
-                ranks = list(range(g * ep, (g + 1) * ep))
-                grp = dist.new_group(ranks)
-                if rank in ranks:
-                    self.ep_group = grp
-            for j in range(ep):
-                ranks = list(range(j, world_size, ep))
-                grp = dist.new_group(ranks)
-                if rank in ranks:
-                    self.edp_group = grp
-            self.ep, self.ep_rank = ep, rank % ep
+            ep = min(dpw, E_)
+            if dpw % ep or E_ % ep:
+                raise NotImplementedError(f"expert parallel size {ep} must divide the data-parallel size {dpw} and the number of experts {E_}")
+            # process_group_initializer.py:493-524: expert groups = ep consecutive entries of a data-parallel group [t, t + tp, t + 2 tp, ...],
+            # expert-data groups = the entries with the same position in their expert group.  Collective: every rank creates every group, same order.
+            for t in range(tp):
+                dp_ranks = [t + k * tp for k in range(dpw)]
+                for g in range(dpw // ep):
+                    ranks = dp_ranks[g * ep : (g + 1) * ep]
+                    grp = dist.new_group(ranks)
+                    if rank in ranks:
+                        self.ep_group = grp
+                for j in range(ep):
+                    ranks = dp_ranks[j::ep]
+                    grp = dist.new_group(ranks)
+                    if rank in ranks:
+                        self.edp_group = grp
+            self.ep, self.ep_rank = ep, dpr % ep
         self.El = E_ // self.ep
         self.groups = ("0_default", "1_fp32", f"2_moe_ep_size_{self.ep}")   # the optimizer groups' names (train/utils.py:25-80)
         self.noise_fn, self.calls = noise_fn, 0
         self.keep_routes = None   # set to [] to record (expert choices, gate logits) of every micro-batch and layer
-        h, F, V, L, E = mc.hidden_size, ffn_dim(mc), mc.vocab_size, mc.num_layers, E_
-        self.F = F
-        H, d = mc.num_attention_heads, mc.head_dim
+        h, F, V, L, E = mc.hidden_size, ffn_dim(mc) // tp, mc.vocab_size, mc.num_layers, E_
+        self.F = F                                   # this rank's FFN units
+        self.Vl = Vl = V // tp                       # ... and vocabulary rows of the head
+        H, d = mc.num_attention_heads // tp, mc.head_dim
+        self.H = H                                   # ... and heads
+        hl = H * d
         if d not in (64, 128):
             raise NotImplementedError("head dim must be 64 or 128")
         # ---- parameters: one flat bf16 buffer (+ gradients), one flat fp32 buffer for the gates (fp32 modules)
         specs = [("embedding.weight", (V, h))]
         for l in range(L):
             p = f"blocks.{l}."
-            specs += [(p + "norm1.weight", (h,)), (p + "mixer.Wqkv.weight", (3 * h, h)), (p + "mixer.Wqkv.bias", (3 * h,)),
-                      (p + "mixer.out_proj.weight", (h, h)), (p + "mixer.out_proj.bias", (h,)), (p + "norm2.weight", (h,)),
+            specs += [(p + "norm1.weight", (h,)), (p + "mixer.Wqkv.weight", (3 * hl, h)), (p + "mixer.Wqkv.bias", (3 * hl,)),
+                      (p + "mixer.out_proj.weight", (h, hl)), (p + "mixer.out_proj.bias", (h,)), (p + "norm2.weight", (h,)),
                       (p + "mlp.w13", (self.El, 2 * F, h)), (p + "mlp.w2", (self.El, h, F))]   # this rank's experts: w1 | w3 fused per expert, adjacent
-        specs += [("norm.weight", (h,)), ("head.weight", (V, h))]
+        specs += [("norm.weight", (h,)), ("head.weight", (Vl, h))]
         off, self.spec = 0, {}
         for n, shp in specs:
             numel = math.prod(shp)
@@ -127,6 +157,14 @@ class MoEEngine:
                 self.runs[g][-1] = (self.runs[g][-1][0], o + numel)
             else:
                 self.runs[g].append((o, o + numel))
+        # group 0 under tensor parallelism: what is cut over the tensor group (its squared norm is summed over the group) and what every rank holds whole
+        # (counted once: reduce_grads, solver/optimizer/utils.py:225-262)
+        self.cut0, self.whole0 = [], []
+        for n, (o, s_) in self.spec.items():
+            if n.endswith(("mlp.w13", "mlp.w2")) and not self.dense:
+                continue
+            cut = n.endswith(("Wqkv.weight", "Wqkv.bias", "out_proj.weight", "head.weight", "mlp.w13", "mlp.w2"))
+            (self.cut0 if cut else self.whole0).append(self.grads[o : o + math.prod(s_)])
         # AdamW of the previous step runs on its own stream under the next forward pass (as in the dense engine): one event per run, and the
         # forward waits for the runs that hold the layer it is about to use
         self.opt_stream = torch.cuda.Stream(device=device)
@@ -168,16 +206,18 @@ class MoEEngine:
             self.a_h13 = [e(T, 2 * F) for _ in range(L)]
             self.t_act, self.t_dact, self.t_dh13 = e(T, F), e(T, F), e(T, 2 * F)
         else:
-            self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * rank, layer_index=l, ep_group=self.ep_group,
-                                 ep_size=self.ep, ep_rank=self.ep_rank) for l in range(L)]   # (every rank gates its own tokens with its own noise)
+            self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * dpr, layer_index=l, ep_group=self.ep_group,
+                                 ep_size=self.ep, ep_rank=self.ep_rank, tpar=self.tpar) for l in range(L)]
+            # (every DATA-parallel rank gates its own tokens with its own noise; the ranks of a tensor group gate the same tokens with the same noise)
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
-        self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * h), e(T, h), e(T, h), e(T, h)
+        self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * hl), e(T, h), e(T, h), e(T, h)
         self.t_dq, self.t_dkv = e(T, H, d), e(T, 2, H, d)
-        self.t_logits, self.t_loss_rows, self.t_lse, self.t_loss = e(T, V), e(T, dtype=torch.float32), e(T, dtype=torch.float32), e(2, dtype=torch.float32)
+        self.t_logits, self.t_loss_rows, self.t_lse, self.t_loss = e(T, Vl), e(T, dtype=torch.float32), e(T, dtype=torch.float32), e(2, dtype=torch.float32)
+        self.t_lab_local = torch.empty(T, dtype=torch.int64, device=device) if tp > 1 else None
         self.t_delta = e(K._L().ie_flash_attn_bwd_workspace(T, H, H, d), dtype=torch.float32)
         self.t_norm_ws = e(K._L().ie_rmsnorm_bwd_partials(T) * h, dtype=torch.float32)
         self.t_emb_ws = e(V + 1 + T, dtype=torch.int32)
-        self.t_bias3, self.t_bias1 = e(3 * h), e(h)
+        self.t_bias3, self.t_bias1 = e(3 * hl), e(h)
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)
         self.moe_acc = torch.zeros(1, dtype=torch.float32, device=device)
         self.step_count = 0
@@ -185,7 +225,7 @@ class MoEEngine:
     # ------------------------------------------------------------------------------------------ parameters
     def reference_param_shapes(self):
         mc, out = self.mc, {}
-        h, F, V, E = mc.hidden_size, self.F, mc.vocab_size, max(mc.num_experts, 1)
+        h, F, V, E = mc.hidden_size, self.F * self.tp, mc.vocab_size, max(mc.num_experts, 1)   # (the FULL shapes: a one-rank job's)
         out["embedding.weight"] = (V, h)
         for l in range(mc.num_layers):
             p = f"blocks.{l}."
@@ -203,16 +243,27 @@ class MoEEngine:
         return out
 
     def _qkv_to_engine(self, t):
-        """reference "(three h d)" rows -> [h][three][d] rows (weights [3h, h] or biases [3h])"""
-        H, d = self.mc.num_attention_heads, self.mc.head_dim
-        return t.reshape(3, H, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
+        """the FULL reference tensor, "(three h d)" rows -> this rank's heads as [h][three][d] rows (weights [3h, h] or biases [3h])"""
+        Hf, H, d, r = self.mc.num_attention_heads, self.H, self.mc.head_dim, self.tp_rank
+        v = t.reshape(3, Hf, d, -1)[:, r * H : (r + 1) * H]
+        return v.permute(1, 0, 2, 3).reshape((3 * H * d,) + tuple(t.shape[1:]))
 
     def _qkv_to_reference(self, t):
-        H, d = self.mc.num_attention_heads, self.mc.head_dim
+        """this rank's [h][three][d] rows -> "(three h d)" rows of its heads: what the reference's tensor rank holds (multi_head_attention.py: the
+        rearrange runs with the LOCAL head count)"""
+        H, d = self.H, self.mc.head_dim
         return t.reshape(H, 3, d, -1).permute(1, 0, 2, 3).reshape(t.shape)
 
+    def _cut(self, t, dim):
+        """this tensor rank's 1 / tp of a full parameter along `dim`"""
+        if self.tp == 1:
+            return t
+        n = t.shape[dim] // self.tp
+        return t.narrow(dim, self.tp_rank * n, n)
+
     def load_named_parameters(self, named, sync_master=True, views=None, gates=None):
-        """named: the reference's parameter tensors by name (PackedFlashInternLm1D.named_parameters()).  views / gates: `_views(flat)` of another
+        """named: the reference's FULL parameter tensors by name (PackedFlashInternLm1D.named_parameters() of a one-rank job; a tensor rank keeps its
+        part: tensorpar.py's rule).  views / gates: `_views(flat)` of another
         buffer of the same layout and the [L, E, h] fp32 tensor to fill instead of the bf16 parameters and the gate weights (checkpoints: master
         weights, moments)."""
         self._wait_optimizer()
@@ -230,17 +281,21 @@ class MoEEngine:
                 if not 0 <= e_ < self.El:
                     continue                                                                 # another rank's expert
                 if w == "w2":
-                    P[f"blocks.{l}.mlp.w2"][e_].copy_(t)
+                    P[f"blocks.{l}.mlp.w2"][e_].copy_(self._cut(t, 1))
                 else:
-                    P[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
+                    P[f"blocks.{l}.mlp.w13"][e_][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(self._cut(t, 0))
             elif "mixer.Wqkv" in n:
                 P[n].copy_(self._qkv_to_engine(t))
+            elif n.endswith("mixer.out_proj.weight"):
+                P[n].copy_(self._cut(t, 1))
+            elif n == "head.weight":
+                P[n].copy_(self._cut(t, 0))
             elif self.dense and ".mlp.w" in n:   # blocks.{l}.mlp.w1 / w2 / w3.weight -> the fused [1, 2F, h] / [1, h, F] tensors
                 l, w = int(n.split(".")[1]), n.split(".")[3]
                 if w == "w2":
-                    P[f"blocks.{l}.mlp.w2"][0].copy_(t)
+                    P[f"blocks.{l}.mlp.w2"][0].copy_(self._cut(t, 1))
                 else:
-                    P[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(t)
+                    P[f"blocks.{l}.mlp.w13"][0][(0 if w == "w1" else F) : (F if w == "w1" else 2 * F)].copy_(self._cut(t, 0))
             else:
                 P[n].copy_(t)
         if sync_master:
@@ -251,7 +306,8 @@ class MoEEngine:
         return {n: flat[o : o + math.prod(s)].view(s) for n, (o, s) in self.spec.items()}
 
     def named_parameters(self, views=None, gates=None):
-        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors).  views / gates: `_views(flat)` of another buffer of the same
+        """(reference name, tensor) pairs (copies for the re-ordered / fused tensors); under tensor parallelism the tensors are this rank's parts, laid
+        out as the reference's tensor rank holds them.  views / gates: `_views(flat)` of another buffer of the same
         layout and an [L, E, h] fp32 tensor (the fp32 master weights / moments, for checkpoints) instead of the bf16 parameters and the gate weights."""
         self._wait_optimizer()
         F, out = self.F, {}
@@ -308,7 +364,8 @@ class MoEEngine:
 
     def _forward_micro(self, ids, labels, cu, pos, max_seqlen):
         mc, p = self.mc, self.p
-        L, eps, H, d = mc.num_layers, mc.layer_norm_epsilon, mc.num_attention_heads, mc.head_dim
+        L, eps, H, d = mc.num_layers, mc.layer_norm_epsilon, self.H, mc.head_dim
+        tpar = self.tpar
         self._wait_runs([self._embed_run, "gate"])
         K.embedding_fwd(p["embedding.weight"], ids, self.a_x[0])
         moe_out = None
@@ -325,6 +382,7 @@ class MoEEngine:
             K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, H, 1, d, False, self.a_q[l], self.a_kv[l])
             K.flash_attn_fwd(self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], cu, max_seqlen, None, True, self.a_ctx[l], self.a_lse[l])
             K.linear_fwd(self.a_ctx[l].view(self.T, -1), p[pre + "mixer.out_proj.weight"], self.t_h0)
+            tpar.all_reduce_sum(self.t_h0)     # row-parallel: partial sums over the tensor group (no-op at tp = 1); the bias once, behind the sum
             self._bias_add(self.t_h0, p[pre + "mixer.out_proj.bias"])
             K.add_rmsnorm_fwd(self.t_h0, self.a_x[l], p[pre + "norm2.weight"], eps, self.a_r2[l], self.a_n2[l], self.a_rstd2[l])
             moe_out = self.t_h1
@@ -333,21 +391,39 @@ class MoEEngine:
                 K.linear_fwd(self.a_n2[l], p[pre + "mlp.w13"][0], self.a_h13[l])
                 K.swiglu_fwd(self.a_h13[l][:, :F_], self.a_h13[l][:, F_:], self.t_act)
                 K.linear_fwd(self.t_act, p[pre + "mlp.w2"][0], moe_out)
+                tpar.all_reduce_sum(moe_out)
                 continue
             self.l_aux.append(self.moe[l].forward(self.a_n2[l], self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], moe_out, noise=self._noise(self.T, mc.num_experts)).clone())
         self._wait_runs(self._head_runs)
         K.add_rmsnorm_fwd(moe_out, self.a_r2[L - 1], p["norm.weight"], eps, self.a_xf, self.a_nf, self.a_rstdf)
         K.linear_fwd(self.a_nf, p["head.weight"], self.t_logits)
-        K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+        if self.tp == 1:
+            K.ce_fwd(self.t_logits, labels, -100, self.tc.label_smoothing, self.t_loss_rows, self.t_lse, self.t_loss)
+            return
+        # vocabulary-parallel head (ScaleColumnParallelLinear + the parallel loss; engine.InternLM2Engine._cross_entropy): the fused kernel on this rank's
+        # [T, V / tp] columns with the labels mapped into its range (-1 = valid, another rank's column), then ONE all-gather of (local log-sum-exp,
+        # local target logit) per token gives the global log-sum-exp (kept for the backward) and the loss
+        v0 = self.tp_rank * self.Vl
+        here = (labels >= v0) & (labels < v0 + self.Vl)
+        self.t_lab_local.copy_(torch.where(labels == -100, labels, torch.where(here, labels - v0, torch.full_like(labels, -1))))
+        K.ce_fwd(self.t_logits, self.t_lab_local, -100, 0.0, self.t_loss_rows, self.t_lse, self.t_loss)
+        stats = tpar.all_gather(torch.stack([self.t_lse, torch.where(here, self.t_lse - self.t_loss_rows, torch.zeros_like(self.t_loss_rows))]))   # [tp, 2, T]
+        self.t_lse.copy_(torch.logsumexp(stats[:, 0], dim=0))
+        self.t_loss_rows.copy_(torch.where(labels != -100, self.t_lse - stats[:, 1].sum(dim=0), torch.zeros_like(self.t_loss_rows)))
+        K.ce_mean(self.t_loss_rows, labels, -100, self.t_loss)
 
     def _backward_micro(self, ids, labels, cu, pos, max_seqlen, acc, inv_m):
         mc, tc, p, g = self.mc, self.tc, self.p, self.g
         self._wait_optimizer()   # the backward overwrites the gradients the last step's AdamW reads
-        L, H, d, T = mc.num_layers, mc.num_attention_heads, mc.head_dim, self.T
+        L, H, d, T = mc.num_layers, self.H, mc.head_dim, self.T
         ws = self.t_norm_ws
-        K.ce_bwd(self.t_logits, labels, self.t_lse, self.scale_view, self.t_loss[1:2], inv_m, -100, tc.label_smoothing)
+        tpar = self.tpar
+        # (vocabulary-parallel head: t_lse is the GLOBAL log-sum-exp, the labels the ones mapped into this rank's range)
+        K.ce_bwd(self.t_logits, labels if self.tp == 1 else self.t_lab_local, self.t_lse, self.scale_view, self.t_loss[1:2], inv_m, -100, tc.label_smoothing)
         K.linear_dgrad(self.t_logits, p["head.weight"], self.t_h0)
+        ar = tpar.all_reduce_sum_async(self.t_h0)    # column-parallel head: its input gradient is a partial sum; summed under the weight gradient
         K.linear_wgrad(self.t_logits, self.a_nf, g["head.weight"], acc)
+        ar.wait()
         d_h = self.t_h1
         K.rmsnorm_bwd(self.t_h0, self.a_xf, p["norm.weight"], self.a_rstdf, None, g["norm.weight"], acc, ws, d_h)
         spare = [self.t_h0, self.t_h2]
@@ -360,14 +436,16 @@ class MoEEngine:
                 K.swiglu_bwd(self.t_dact, self.a_h13[l][:, :F_], self.a_h13[l][:, F_:], self.t_dh13[:, :F_], self.t_dh13[:, F_:], self.t_act)
                 K.linear_wgrad(d_h, self.t_act, g[pre + "mlp.w2"][0], acc)
                 K.linear_dgrad(self.t_dh13, p[pre + "mlp.w13"][0], d_n2)
+                ar = tpar.all_reduce_sum_async(d_n2)
                 K.linear_wgrad(self.t_dh13, self.a_n2[l], g[pre + "mlp.w13"][0], acc)
+                ar.wait()
             else:
                 self.moe[l].backward(d_h, self.wg[l], p[pre + "mlp.w13"], p[pre + "mlp.w2"], d_n2, self.d_wg[l], g[pre + "mlp.w13"], g[pre + "mlp.w2"],
                                      accumulate=acc, loss_scale_dev=self.scale_view, aux_factor=mc.moe_loss_coeff * inv_m)
             d_r2 = spare[1]
             K.rmsnorm_bwd(d_n2, self.a_r2[l], p[pre + "norm2.weight"], self.a_rstd2[l], d_h, g[pre + "norm2.weight"], acc, ws, d_r2)
             self._bias_grad(d_r2, g[pre + "mixer.out_proj.bias"], self.t_bias1, acc)
-            d_ctx = d_n2
+            d_ctx = d_n2.view(-1)[: T * H * d].view(T, H * d)   # (row-parallel backward: this rank's heads' columns, no exchange)
             K.linear_dgrad(d_r2, p[pre + "mixer.out_proj.weight"], d_ctx)
             K.linear_wgrad(d_r2, self.a_ctx[l].view(T, -1), g[pre + "mixer.out_proj.weight"], acc)
             K.flash_attn_bwd(d_ctx.view(T, H, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu, max_seqlen, None, True,
@@ -376,7 +454,9 @@ class MoEEngine:
             self._bias_grad(self.t_qkv, g[pre + "mixer.Wqkv.bias"], self.t_bias3, acc)
             d_n1 = d_n2
             K.linear_dgrad(self.t_qkv, p[pre + "mixer.Wqkv.weight"], d_n1)
+            ar = tpar.all_reduce_sum_async(d_n1)
             K.linear_wgrad(self.t_qkv, self.a_n1[l], g[pre + "mixer.Wqkv.weight"], acc)
+            ar.wait()
             d_x = d_h
             K.rmsnorm_bwd(d_n1, self.a_x[l], p[pre + "norm1.weight"], self.a_rstd1[l], d_r2, g[pre + "norm1.weight"], acc, ws, d_x)
             spare = [d_n2, d_r2]
@@ -451,12 +531,15 @@ class MoEEngine:
         def bcast(t, src, group):
             self.be.broadcast(t, src, group).wait()
 
-        for a, b in self.runs[0]:
-            bcast(self.params[a:b], 0, None)
-        bcast(self.wg, 0, None)
-        if self.world > self.ep:
+        # (tensor parallelism: a shard is replicated over the ranks of its data-parallel group, whose first rank is the global rank tp_rank; an expert
+        # over its expert-data group, whose first rank holds the same position in the first expert group)
+        if self.dp_world > 1:
+            for a, b in self.runs[0]:
+                bcast(self.params[a:b], self.tp_rank, self.dp_group)
+            bcast(self.wg, self.tp_rank, self.dp_group)
+        if self.dp_world > self.ep:
             for a, b in self.runs[2]:
-                bcast(self.params[a:b], self.ep_rank, self.edp_group)
+                bcast(self.params[a:b], self.tp_rank + self.ep_rank * self.tp, self.edp_group)
         self.master.copy_(self.params)
 
     def step(self):
@@ -465,19 +548,27 @@ class MoEEngine:
         # data parallel, every rank keeps the (replicated) optimizer state of what it holds.  Dense parameters and gates: AVG over all ranks.
         # Experts: an expert's gradient already sums what the tokens of every rank of its expert group contributed (one copy, one backward);
         # the reference averages it over the expert-data group only (hybrid_zero_optim.py:166-167) -- no 1 / ep.
+        dpw = self.dp_world
         for a, b in self.runs[0]:
-            self._all_reduce(self.grads[a:b], None, self.world)
-        self._all_reduce(self.d_wg, None, self.world)
+            self._all_reduce(self.grads[a:b], self.dp_group, dpw)
+        self._all_reduce(self.d_wg, self.dp_group, dpw)
         for a, b in self.runs[2]:
-            self._all_reduce(self.grads[a:b], self.edp_group, self.world // self.ep)
-        K.sumsq([self.grads[a:b] for a, b in self.runs[0]], self.sumsq[0:1])
-        K.sumsq(self.d_wg, self.sumsq[1:2])
+            self._all_reduce(self.grads[a:b], self.edp_group, dpw // self.ep)
+        if self.tp == 1:
+            K.sumsq([self.grads[a:b] for a, b in self.runs[0]], self.sumsq[0:1])
+        else:   # what is cut over the tensor group: summed over it; what every rank holds whole: once (solver/optimizer/utils.py:225-262,330-352)
+            K.sumsq(self.cut0, self.sumsq[0:1])
         if self.runs[2]:
             K.sumsq([self.grads[a:b] for a, b in self.runs[2]], self.sumsq[2:3])
         else:
             self.sumsq[2:3].zero_()   # (the dense model has no expert group)
+        if self.tp > 1:
+            self.sumsq[1:2].zero_()
+            self.tpar.all_reduce_sum(self.sumsq)
+            K.sumsq(self.whole0, self.sumsq[0:1], accumulate=True)
+        K.sumsq(self.d_wg, self.sumsq[1:2])
         if self.ep > 1:   # the moe group's squared norm: local sum of squares / dp, summed over the expert group (solver/optimizer/utils.py:362-368)
-            self.sumsq[2:3].div_(self.world)
+            self.sumsq[2:3].div_(dpw)
             self._all_reduce(self.sumsq[2:3], self.ep_group, self.ep, avg=False)
         check(K._L().ie_step_control_groups(K._p(self.state), K._p(self.sumsq), 3, self.scaler_cfg, K._p(self.group_inv), K._p(self.group_norm), K._stream()),
               "ie_step_control_groups")
@@ -509,7 +600,9 @@ class MoEEngine:
 
     # ---- checkpoints (the dense model): InternEvo's files, internevo_amd/checkpoint.py -------------------------------------------------------
     def _checkpoint_guard(self):
-        pass   # (any data-parallel size since round 4: checkpoint.save_moe_checkpoint / load_moe_checkpoint)
+        # (any data-parallel size since round 4: checkpoint.save_moe_checkpoint / load_moe_checkpoint)
+        if self.tp > 1:
+            raise NotImplementedError("MoEEngine: checkpoints under tensor parallelism (the tensor-rank files of the MoE model) are not written / read")
 
     def save_checkpoint(self, folder):
         """model_tp0_pp0.pt + the hybrid-ZeRO optimizer shards in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284): this

@@ -310,9 +310,9 @@ def _mtp_part_v1(name, full, tp_rank, tp, head_dim):
     if ".mixer.Wqkv." in name:
         v = full.reshape(3, -1, head_dim, *full.shape[1:])
         return cut(v, 1).reshape(-1, *full.shape[1:])
-    if name.endswith("mixer.out_proj.weight") or name.endswith("mlp.w2.weight"):
+    if name.endswith("mixer.out_proj.weight") or name.endswith(".w2.weight"):   # (mlp.w2 of the dense block; experts.wrapped_experts.{e}.w2 of the MoE block)
         return cut(full, 1)
-    if name.endswith("mlp.w1.weight") or name.endswith("mlp.w3.weight"):
+    if name.endswith(".w1.weight") or name.endswith(".w3.weight"):
         return cut(full, 0)
     return full
 
@@ -368,8 +368,8 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
         calls = [0]
 
         def _noise(shape, device):  # the k-th gating call of the run (layer-major inside a micro-batch) gets gumbel_noise(seed = 5000 + k)
-            calls[0] += 1          # (every data-parallel rank gates its own tokens: rank r draws seed 5000 + 1000 r + k)
-            return gumbel_noise(tuple(shape), 5000 + 1000 * rank + calls[0] - 1)
+            calls[0] += 1          # (every data-parallel rank gates its own tokens: rank r draws seed 5000 + 1000 r + k; the ranks of a tensor group
+            return gumbel_noise(tuple(shape), 5000 + 1000 * (rank // cfg_kw.get("tp", 1)) + calls[0] - 1)   # gate the same tokens with the same noise)
 
         gl.gumbel_rsample = _noise
 
@@ -384,8 +384,16 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
     inner = model.model if not isinstance(model, torch.nn.ModuleList) else None   # (a pipeline stage with several chunks: a list of wrapped models)
     sp, wp = cfg_kw.get("sp", 1), cfg_kw.get("wp", 1)
-    moe_mp = world > 1 and cfg_kw.get("model_type") == "INTERNLM_MoE"
-    if world > 1 and not moe_mp and cfg_kw.get("pp", 1) == 1:
+    moe_mp = world > 1 and cfg_kw.get("model_type") == "INTERNLM_MoE" and cfg_kw.get("tp", 1) == 1
+    moe_tp = world > 1 and cfg_kw.get("model_type") == "INTERNLM_MoE" and cfg_kw.get("tp", 1) > 1
+    if moe_tp:   # experts = FeedForward modules over the TENSOR group (gshard_layer.py:421-433): w1 / w3 cut by rows, w2 by columns; the gate whole
+        from internevo_amd.config import ModelConfig
+        from oracle.moe_model import param_shapes as moe_shapes
+
+        full_shapes = moe_shapes(ModelConfig(vocab_size=cfg_kw["vocab"], hidden_size=cfg_kw["hidden"], num_layers=cfg_kw["layers"], num_attention_heads=cfg_kw["heads"],
+                                             num_kv_attention_heads=cfg_kw["heads"], mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=cfg_kw["num_experts"]))
+        tp_rank = gpc.get_local_rank(ParallelMode.TENSOR)
+    if world > 1 and not moe_mp and not moe_tp and cfg_kw.get("pp", 1) == 1:
         from internevo_amd.config import ModelConfig
         from oracle.model import param_shapes
 
@@ -435,7 +443,7 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                 else:
                     p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
             elif world > 1 and tp > 1:
-                if cfg_kw.get("model_type") == "INTERNLM":
+                if cfg_kw.get("model_type") in ("INTERNLM", "INTERNLM_MoE"):
                     part = _mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"])
                 elif cfg_kw.get("model_type") == "LLAMA2":   # separate wq / wk / wv, each cut by rows: the rank's q heads and ITS kv heads (checkpoint.tp_shard)
                     from internevo_amd.checkpoint import tp_shard
@@ -1013,6 +1021,10 @@ RUNS_MP = {
     # dispatch buffers) with its own gradient / norm rules for the expert group (hybrid_zero_optim.py:166-167, solver/optimizer/utils.py:362-368)
     "moe2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
                                          model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0), 2),
+    # the MoE family on two Megatron tensor ranks (gshard_layer.py:421-433: every expert is a FeedForward over the TENSOR group; one data-parallel rank, so no
+    # expert parallelism): same model / data / noise as moe_bf16, which it must retrace
+    "moe_tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                            model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0, tp=2), 2),
     # two pipeline stages (parallel.pipeline = dict(size=2)): PipelineScheduler (1F1B, pipeline_scheduler.py:111-709) on the 4-layer model of
     # pin4_* with 4 micro-batches (warm-up, steady state and cool-down all occur), and InterleavedPipelineScheduler (:711-1430) with two model
     # chunks per stage; both must retrace the single-rank pin4_* runs

@@ -1,0 +1,100 @@
+"""Host logic of MoEEngine under Megatron tensor parallelism, on CPU: two gloo ranks run one forward / backward / optimizer step with every kernel launch
+stubbed out (the library refuses host tensors -- that refusal is part of the product and is asserted first), so that what runs is exactly the engine's own
+Python: process groups, shard shapes and views, buffer aliasing, the order and the shapes of the collectives on both ranks (a mismatch deadlocks or raises
+here instead of on a GPU box), the shapes named_parameters() reports.  The numbers are the GPU test's business
+(tests/test_moe_engine_gpu.py::test_moe_engine_tensor_parallel_on_two_ranks_matches_the_reference_rules)."""
+import contextlib
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Stub:
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, *a):
+        pass
+
+    wait_event = record = synchronize = wait_stream
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import internevo_amd.kernels as K
+        import internevo_amd.moe as M
+        import internevo_amd.moe_engine as ME
+        from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
+        from internevo_amd.data import SyntheticLoader
+        from oracle.model import moe_formula_init
+
+        gold = json.load(open(os.path.join(HERE, "golden", "train_moe_tp2_bf16_rank0.json")))
+        c = gold["config"]
+        mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                         mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+        tc = TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True)
+        cfg = PathConfig(mc, tc)
+        refused = False
+        try:
+            K.rmsnorm_fwd(torch.zeros(4, 8, dtype=torch.bfloat16), torch.ones(8, dtype=torch.bfloat16), 1e-5, torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(4))
+        except (ValueError, RuntimeError):
+            refused = True
+        assert refused, "the kernels must refuse host tensors (no CPU fallback)"
+        # from here on: no launches (null pointers, ignored status), streams and events stubbed
+        torch.cuda.Stream = torch.cuda.Event = _Stub
+        torch.cuda.current_stream = lambda *a, **k: _Stub()
+        torch.cuda.stream = lambda s: contextlib.nullcontext()
+        torch.cuda.synchronize = lambda *a, **k: None
+        K.check = M.check = ME.check = lambda *a, **k: None
+        K._stream = lambda: None
+        K._contig = lambda t, n: t
+        K._p = lambda t: None
+        eng = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=2)
+        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"]))
+        batch, labels = next(loader)
+        eng.forward_backward(batch, labels)
+        eng.step()
+        q.put((rank, {n: tuple(p.shape) for n, p in eng.named_parameters()}, (eng.tp, eng.tp_rank, eng.dp_world, eng.ep, eng.H, eng.F, eng.Vl)))
+    except Exception:
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29931, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, shapes, meta = q.get(timeout=200)
+        assert meta is not None, f"rank {r} failed:\n{shapes}"
+        res[r] = (shapes, meta)
+    for p in procs:
+        p.join(30)
+    assert res[0][1] == (2, 0, 1, 1, 2, 256, 256) and res[1][1] == (2, 1, 1, 1, 2, 256, 256)
+    s0, s1 = res[0][0], res[1][0]
+    assert s0 == s1 and len(s0) == 41
+    # the parts a tensor rank of the reference holds (tests/golden/make_golden.py:_mtp_part_v1): heads, FFN units and vocabulary rows cut in two
+    assert s0["blocks.0.mixer.Wqkv.weight"] == (384, 256) and s0["blocks.0.mixer.Wqkv.bias"] == (384,) and s0["blocks.0.mixer.out_proj.weight"] == (256, 128)
+    assert s0["blocks.1.mlp.moe_layer.experts.wrapped_experts.3.w1.weight"] == (256, 256) and s0["blocks.1.mlp.moe_layer.experts.wrapped_experts.3.w2.weight"] == (256, 256)
+    assert s0["head.weight"] == (256, 256) and s0["embedding.weight"] == (512, 256) and s0["blocks.0.mlp.moe_layer.gate.wg.weight"] == (4, 256)
+    assert s0["blocks.0.mixer.out_proj.bias"] == (256,) and s0["norm.weight"] == (256,)
