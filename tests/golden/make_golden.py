@@ -379,6 +379,10 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     launch(config=cfg, rank=rank, world_size=world, host="::1", port=port, backend="gloo", local_rank=rank, seed=1024)
     args_sanity_check()
     torch.set_num_threads(int(os.environ.get("IE_THREADS", "8")))
+    # harness only: on CPU tensors model/utils.py:_gather asks for the mode's "cpu group", which launch() creates only with use_cpu=True (None otherwise = the
+    # WORLD group: right by accident when the tensor group is the whole job).  The groups are gloo groups here: hand out the mode's own group.
+    _cpu_group = gpc.get_cpu_group
+    gpc.get_cpu_group = lambda mode: (_cpu_group(mode) if gpc._cpu_groups.get(mode) is not None else gpc.get_group(mode))
 
     model = initialize_model()
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
@@ -444,7 +448,15 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
                     p.copy_(formula_init(name, tuple(p.shape)).to(p.dtype))
             elif world > 1 and tp > 1:
                 if cfg_kw.get("model_type") in ("INTERNLM", "INTERNLM_MoE"):
-                    part = _mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"])
+                    gname = name
+                    if moe_tp:   # (with data-parallel ranks beside the tensor group: expert parallelism inside the data-parallel group; local -> GLOBAL expert index)
+                        import re
+
+                        m_ = re.search(r"wrapped_experts\.(\d+)\.", name)
+                        if m_:
+                            El = cfg_kw["num_experts"] // gpc.get_world_size(ParallelMode.EXPERT)
+                            gname = name[: m_.start(1)] + str(gpc.get_local_rank(ParallelMode.EXPERT) * El + int(m_.group(1))) + name[m_.end(1):]
+                    part = _mtp_part_v1(gname, formula_init(gname, full_shapes[gname]), tp_rank, tp, cfg_kw["hidden"] // cfg_kw["heads"])
                 elif cfg_kw.get("model_type") == "LLAMA2":   # separate wq / wk / wv, each cut by rows: the rank's q heads and ITS kv heads (checkpoint.tp_shard)
                     from internevo_amd.checkpoint import tp_shard
 
@@ -1025,6 +1037,10 @@ RUNS_MP = {
     # expert parallelism): same model / data / noise as moe_bf16, which it must retrace
     "moe_tp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
                                             model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0, tp=2), 2),
+    # ... and two such tensor groups side by side (4 processes: data parallel 2 x tensor 2): expert parallelism (ep = 2) INSIDE the data-parallel groups
+    # [0, 2] and [1, 3] (process_group_initializer.py:493-524), every expert's shard on one rank; same data / noise per data-parallel rank as moe2_bf16
+    "moe_tp2dp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=4, vocab=512, layers=2, micro_num=2, total_steps=6,
+                                               model_type="INTERNLM_MoE", num_experts=4, capacity_factor=1.0, tp=2), 4),
     # two pipeline stages (parallel.pipeline = dict(size=2)): PipelineScheduler (1F1B, pipeline_scheduler.py:111-709) on the 4-layer model of
     # pin4_* with 4 micro-batches (warm-up, steady state and cool-down all occur), and InterleavedPipelineScheduler (:711-1430) with two model
     # chunks per stage; both must retrace the single-rank pin4_* runs

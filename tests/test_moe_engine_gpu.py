@@ -562,3 +562,109 @@ def test_moe_engine_tensor_parallel_on_two_ranks_matches_the_reference_rules(dev
         worst = max(worst, float(np.abs(got - full).max()))
     print("max |param diff| of the re-assembled shards vs the forced one-rank oracle after training:", worst)
     assert worst <= 1e-1
+
+
+def _tp_dp_engine_worker(rank, world, port, q, steps):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(xport(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from internevo_amd.data import SyntheticLoader
+        from internevo_amd.moe_engine import MoEEngine
+        from oracle import moe as MO
+        from oracle.model import moe_formula_init
+
+        gold = json.load(open(os.path.join(G, f"train_moe_tp2dp2_bf16_rank{rank}.json")))
+        cfg = _cfg(gold)
+        dp_rank = rank // 2
+        eng = MoEEngine(cfg, dev, None, world, rank, init_fn=moe_formula_init, tp_size=2,
+                        noise_fn=lambda call, S, E: MO.gumbel_noise((S, E), 5000 + 1000 * dp_rank + call).to(dev))
+        assert eng.tp == 2 and eng.dp_world == 2 and eng.ep == 2 and eng.ep_rank == dp_rank and eng.groups[2] == "2_moe_ep_size_2"
+        assert eng.p["blocks.0.mlp.w13"].shape == (2, 512, 256) and eng.p["blocks.0.mlp.w2"].shape == (2, 256, 256)
+        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=dp_rank, data_world_size=2))
+        out = []
+        for _ in range(steps):
+            batch, labels = next(loader)
+            eng.keep_routes = []
+            loss, moe_loss = eng.forward_backward(batch, labels)
+            eng.step()
+            st = eng.read_state()
+            routes = [[r[0].cpu().long().numpy() for r in micro] for micro in eng.keep_routes]
+            out.append((float(loss), float(moe_loss), dict(st.group_norms), st.skip, st.loss_scale, routes))
+        q.put((rank, out, {n: p.float().cpu().numpy() for n, p in eng.named_parameters()}))
+    except Exception:
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_moe_engine_tensor_parallel_2_x_expert_parallel_2_on_four_ranks(dev):
+    """Two tensor groups side by side (data parallel 2 x tensor 2, four staged ranks): the expert groups live INSIDE the data-parallel groups [0, 2] and
+    [1, 3] (process_group_initializer.py:493-524), so every rank holds its tensor part of two of the four experts; the dispatch buffers cross the data-parallel
+    ranks by all_to_all, the experts' partial outputs are summed over the tensor group.  Against the two-data-rank oracle (OracleMoEDataParallel, pinned on the
+    reference's ep-2 run) teacher-forced onto the engine's routing, and against the unmodified reference's own 4-process run at step 0
+    (tests/golden/train_moe_tp2dp2_bf16_rank*.json)."""
+    import torch.multiprocessing as mp
+
+    from internevo_amd.data import SyntheticLoader
+    from oracle.moe_model import OracleMoEDataParallel
+
+    steps = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_dp_engine_worker, args=(r, 4, 29899, q, steps)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(4):
+        r, out, params = q.get(timeout=300)
+        assert params is not None, f"rank {r} failed:\n{out}"
+        res[r] = (out, params)
+    for p in procs:
+        p.join(60)
+    gold = [json.load(open(os.path.join(G, f"train_moe_tp2dp2_bf16_rank{r}.json"))) for r in range(4)]
+    cfg = _cfg(gold[0])
+    ora = OracleMoEDataParallel(cfg, 2)
+    loaders = [iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold[0]["num_samples"], data_rank=r, data_world_size=2)) for r in (0, 1)]
+    for k in range(steps):
+        bl = [next(ld) for ld in loaders]
+        for a, b in ((0, 1), (2, 3)):   # the ranks of a tensor group agree on everything
+            x, y = res[a][0][k], res[b][0][k]
+            assert x[:5] == y[:5], (k, a, b, x[:5], y[:5])
+            assert all((u == v).all() for mu, mv in zip(x[5], y[5]) for u, v in zip(mu, mv))
+        forced = [[[torch.from_numpy(x) for x in micro] for micro in res[r][0][k][5]] for r in (0, 2)]
+        ref = ora.train_step([b for b, _ in bl], [y for _, y in bl], forced)
+        for dp, r in enumerate((0, 2)):
+            loss, moe_loss, norms, skip, scale, _ = res[r][0][k]
+            w = gold[r]["steps"][k]
+            print(f"step {k} data rank {dp}: HIP loss {loss:.5f} moe {moe_loss:.5f} norms {norms} | forced oracle {ref[dp]['loss']:.5f} {ref[dp]['moe_loss']:.5f} "
+                  f"{ref[dp]['grad_norm']} | reference {w['loss']:.5f} {w['moe_loss']:.5f} {w['grad_norm']}")
+            assert skip == 0 and scale == w["loss_scale"]
+            assert abs(loss - ref[dp]["loss"]) <= 1e-3 * ref[dp]["loss"], (k, dp, loss, ref[dp]["loss"])
+            assert abs(moe_loss - ref[dp]["moe_loss"]) <= 3e-2 * ref[dp]["moe_loss"]
+            for (g, v), (g2, v2) in zip(norms.items(), ref[dp]["grad_norm"].items()):
+                assert abs(v - v2) <= 3e-2 * v2, (k, dp, g, v, v2)
+            if k == 0:
+                assert abs(loss - w["loss"]) <= 2e-3 * w["loss"], (dp, loss, w["loss"])
+                for (g, v), gw in zip(norms.items(), w["grad_norm"].values()):
+                    assert abs(v - gw) <= 3e-2 * gw, (dp, g, v, gw)
+        assert res[0][0][k][2] == res[2][0][k][2], "every rank reports the same global group norms"
+    names = [set(res[r][1]) for r in range(4)]
+    assert names[0] == names[1] and names[2] == names[3]
+    ex0, ex2 = {n for n in names[0] if ".experts." in n}, {n for n in names[2] if ".experts." in n}
+    assert ex0 and not (ex0 & ex2) and all(".wrapped_experts.0." in n or ".wrapped_experts.1." in n for n in ex0)
+    assert all(".wrapped_experts.2." in n or ".wrapped_experts.3." in n for n in ex2)
+    dense = [n for n in names[0] if ".experts." not in n]
+    assert all((res[0][1][n] == res[2][1][n]).all() and (res[1][1][n] == res[3][1][n]).all() for n in dense), "a shard stays replicated over its data-parallel group"
+    n = "blocks.0.mlp.moe_layer.experts.wrapped_experts.0.w1.weight"
+    assert res[0][1][n].shape == (256, 256) and not (res[0][1][n] == res[1][1][n]).all(), "the tensor ranks hold different rows of an expert"

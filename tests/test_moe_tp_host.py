@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
         K._contig = lambda t, n: t
         K._p = lambda t: None
         eng = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=2)
-        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"]))
+        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=rank // 2, data_world_size=world // 2))
         batch, labels = next(loader)
         eng.forward_backward(batch, labels)
         eng.step()
@@ -74,22 +74,38 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
+def _run(world, port):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29931, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
+    for _ in range(world):
         r, shapes, meta = q.get(timeout=200)
         assert meta is not None, f"rank {r} failed:\n{shapes}"
         res[r] = (shapes, meta)
     for p in procs:
         p.join(30)
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_tensor_2_x_expert_parallel_2_host_logic_on_four_gloo_ranks():
+    """data parallel 2 x tensor 2: expert groups inside the data-parallel groups [0, 2] / [1, 3] (process_group_initializer.py:493-524)."""
+    res = _run(4, 29933)
+    #                      tp, tp_rank, dp_world, ep, heads, FFN units, vocabulary rows
+    assert [res[r][1] for r in range(4)] == [(2, 0, 2, 2, 2, 256, 256), (2, 1, 2, 2, 2, 256, 256), (2, 0, 2, 2, 2, 256, 256), (2, 1, 2, 2, 2, 256, 256)]
+    assert res[0][0] == res[1][0] and res[2][0] == res[3][0] and len(res[0][0]) == 41 - 2 * 2 * 3   # two of the four experts of each layer
+    held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
+    assert held(0) == held(1) == ["0", "1"] and held(2) == held(3) == ["2", "3"]
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
+    res = _run(2, 29931)
     assert res[0][1] == (2, 0, 1, 1, 2, 256, 256) and res[1][1] == (2, 1, 1, 1, 2, 256, 256)
     s0, s1 = res[0][0], res[1][0]
     assert s0 == s1 and len(s0) == 41
