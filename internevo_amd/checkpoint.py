@@ -318,25 +318,49 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
             torch.save(plan, plan_file(d))
 
 
-def remove_stale_shards(folder, zero_world, tp_world, pp_world=1, job_world=None):
-    """Before a save into an existing folder: drop the shard / plan / topology files of an earlier save by a LARGER layout.  The
-    loaders infer the saved layout from the highest file index present (saved_zero_world / saved_tp_world, as the reference's
-    components.py:294-306 does), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would be merged as if
-    they belonged to it.  Called by ONE rank, before anyone writes.  Returns the names of the files it removed (the engine logs
-    them: this DELETES files in the user's checkpoint folder -- only names this module itself writes, only out-of-range indices)."""
+def remove_stale_shards(folder, zero_world, tp_world, pp_world=1, job_world=None, layout="plain", wp_world=1, dp_world=None, num_experts=0, num_layers=0):
+    """Before a save into an existing folder: drop the files of an earlier save that the loaders would merge into this one.  The loaders infer the
+    saved layout from the files present (saved_zero_world / saved_tp_world as the reference's components.py:294-306 does; saved_isp_layout: ANY
+    `model_tp{t}_wp{w}_pp0.pt` makes the folder an ISP-layout folder), so left-over `optimizer_tp0_pp0_zo3.pt` files next to a fresh 2-rank save would
+    be merged as if they belonged to it, and left-over ISP files next to a plain save would be loaded INSTEAD of it.  Removed:
+      * files of this save's own layout with an out-of-range index (a LARGER earlier layout);
+      * every file of the OTHER layouts: layout = "plain" (model_tp{t}_pp{p}.pt, optimizer_tp{t}_pp{p}_zo{z}.pt, topo_*.json, plans with wp-0),
+        "isp" (model_tp{t}_wp{w}_pp0.pt, optimizer_tp{t}_wp{w}_pp0_dp{d}.pt, plans gpus-{W}_wp-{w}_...; tp_world = the sequence-parallel size, dp_world the
+        data-parallel ranks per (t, w)), "moe" (= plain + model_moe_layer{l}_expert{e}_tp0.pt: experts >= num_experts / layers >= num_layers go).
+    Called by ONE rank, before anyone writes.  Returns the names of the files it removed (the engine logs them: this DELETES files in the user's
+    checkpoint folder -- only names this module itself writes)."""
     removed = []
     if not os.path.isdir(folder):
         return removed
     import re
 
+    isp = layout == "isp"
+    job = (zero_world * tp_world * pp_world) if job_world is None else job_world
     for fn in sorted(os.listdir(folder)):
+        stale = False
         m = re.fullmatch(r"optimizer_tp(\d+)_pp(\d+)_zo(\d+)\.pt", fn)
-        stale = bool(m) and (int(m.group(1)) >= tp_world or int(m.group(2)) >= pp_world or int(m.group(3)) >= zero_world)
+        if m:
+            stale = isp or int(m.group(1)) >= tp_world or int(m.group(2)) >= pp_world or int(m.group(3)) >= zero_world
         m = re.fullmatch(r"(?:model_tp(\d+)_pp(\d+)\.pt|topo_tp(\d+)_pp(\d+)\.json)", fn)
-        stale = stale or (bool(m) and (int(m.group(1) or m.group(3)) >= tp_world or int(m.group(2) or m.group(4)) >= pp_world))
-        m = re.fullmatch(r"gpus-(\d+)_wp-0_tp-(\d+)_dp-(\d+)_pp-(\d+)_zo-(\d+)\.pt", fn)
-        stale = stale or (bool(m) and (int(m.group(1)) != (zero_world * tp_world * pp_world if job_world is None else job_world) or int(m.group(2)) >= tp_world
-                                       or int(m.group(4)) >= pp_world or int(m.group(5)) >= zero_world))
+        if m:
+            stale = isp or int(m.group(1) or m.group(3)) >= tp_world or int(m.group(2) or m.group(4)) >= pp_world
+        m = re.fullmatch(r"model_tp(\d+)_wp(\d+)_pp(\d+)\.pt", fn)
+        if m:
+            stale = not isp or int(m.group(1)) >= tp_world or int(m.group(2)) >= wp_world or int(m.group(3)) >= pp_world
+        m = re.fullmatch(r"optimizer_tp(\d+)_wp(\d+)_pp(\d+)_dp(\d+)\.pt", fn)
+        if m:
+            stale = (not isp or int(m.group(1)) >= tp_world or int(m.group(2)) >= wp_world or int(m.group(3)) >= pp_world
+                     or (dp_world is not None and int(m.group(4)) >= dp_world))
+        m = re.fullmatch(r"gpus-(\d+)_wp-(\d+)_tp-(\d+)_dp-(\d+)_pp-(\d+)_zo-(\d+)\.pt", fn)
+        if m:
+            g, w, t, d, p_, z = (int(x) for x in m.groups())
+            if isp:
+                stale = g != job or w >= wp_world or t >= tp_world or p_ >= pp_world or (dp_world is not None and d >= dp_world)
+            else:
+                stale = w > 0 or g != job or t >= tp_world or p_ >= pp_world or z >= zero_world
+        m = re.fullmatch(r"model_moe_layer(\d+)_expert(\d+)_tp(\d+)\.pt", fn)
+        if m:
+            stale = layout != "moe" or int(m.group(1)) >= num_layers or int(m.group(2)) >= num_experts or int(m.group(3)) >= tp_world
         if stale:
             os.remove(os.path.join(folder, fn))
             removed.append(fn)

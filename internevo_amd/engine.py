@@ -1688,6 +1688,14 @@ class InternLM2Engine:
         tc, L = self.tc, self.layout
         W, r = self.job_world, self.job_rank
         sp, wp = self.sp, max(int(getattr(tc, "wp_size", 1) or 1), 1)
+        if r == 0:   # files of another layout (or of a larger ISP job) in the folder would be loaded instead of / merged into this save
+            gone = C.remove_stale_shards(folder, 1, sp, 1, job_world=W, layout="isp", wp_world=wp)
+            if gone:
+                print(f"[internevo_amd] save_checkpoint({folder}): removed {len(gone)} files of an earlier layout: {', '.join(gone)}", flush=True)
+        if W > 1:                # (the job is the default group under ISP: behind this barrier every rank has been here, nobody writes before the cleanup)
+            import torch.distributed as dist
+
+            dist.barrier()
         full_shapes = self.reference_param_shapes()
         mine = {self._engine_name(n) for n in C.isp_rank_names(self.mc, full_shapes, r, W, sp, wp)}
         state = {}

@@ -622,7 +622,7 @@ class MoEEngine:
             # every data-parallel rank writes what the reference's rank would (this engine keeps the optimizer state of the dense parameters and the gates on
             # every rank, and of its own experts: rank r cuts the reference's partition r out of it); collective
             if r == 0:
-                C.remove_stale_shards(folder, W, 1)
+                C.remove_stale_shards(folder, W, 1, layout="moe", num_experts=self.mc.num_experts, num_layers=self.mc.num_layers)
             if W > 1:
                 dist.barrier(group=self.group)
             C.save_moe_checkpoint(folder, self.mc, cpu(None, None), cpu(self._views(self.master), self.wg), cpu(self._views(self.exp_avg), self.wg_m),

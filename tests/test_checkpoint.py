@@ -1138,3 +1138,29 @@ def test_moe_two_rank_reference_checkpoint_merges_is_reproduced_and_resumes(tmp_
             assert abs(res[r]["loss"] - w["loss"]) <= 1e-4 * w["loss"], (k, r)        # (measured 4e-6)
             for (g_, v), gw in zip(res[r]["grad_norm"].items(), w["grad_norm"].values()):
                 assert abs(v - gw) <= 2e-3 * gw, (k, r, g_, v, gw)                     # (measured 2.5e-4)
+
+
+def test_stale_files_of_another_layout_are_removed_before_a_save(tmp_path):
+    """A folder that held an ISP-layout save (or the expert files of a MoE save) and is written again in the plain layout must not keep the old files: load_checkpoint
+    takes the ISP branch as soon as ANY model_tp*_wp* file is present and would load the stale weights (and the other way round)."""
+    from internevo_amd import checkpoint as C
+
+    def touch(*names):
+        for n in names:
+            open(os.path.join(tmp_path, n), "w").close()
+
+    isp = ["model_tp0_wp0_pp0.pt", "model_tp1_wp1_pp0.pt", "optimizer_tp0_wp0_pp0_dp0.pt", "optimizer_tp1_wp1_pp0_dp0.pt", "gpus-4_wp-1_tp-1_dp-0_pp-0_zo-0.pt",
+           "gpus-4_wp-0_tp-0_dp-0_pp-0_zo-0.pt"]
+    plain = ["model_tp0_pp0.pt", "topo_tp0_pp0.json", "optimizer_tp0_pp0_zo0.pt", "optimizer_tp0_pp0_zo1.pt", "gpus-2_wp-0_tp-0_dp-0_pp-0_zo-0.pt", "gpus-2_wp-0_tp-0_dp-1_pp-0_zo-1.pt"]
+    moe = ["model_moe_layer0_expert0_tp0.pt", "model_moe_layer1_expert3_tp0.pt"]
+    keep = ["context.pt", "notes.txt"]
+    touch(*isp, *plain, *moe, *keep)
+    gone = C.remove_stale_shards(str(tmp_path), 2, 1)                                 # a plain 2-rank save
+    assert sorted(gone) == sorted(isp + moe) and sorted(os.listdir(tmp_path)) == sorted(plain + keep)
+    touch(*isp, *moe)
+    gone = C.remove_stale_shards(str(tmp_path), 1, 2, 1, job_world=4, layout="isp", wp_world=2)   # an ISP save, sp 2 x wp 2 on 4 ranks
+    assert sorted(gone) == sorted(plain + moe) and sorted(os.listdir(tmp_path)) == sorted(isp + keep)
+    touch(*plain, *moe, "model_moe_layer2_expert0_tp0.pt", "model_moe_layer0_expert4_tp0.pt")
+    gone = C.remove_stale_shards(str(tmp_path), 2, 1, layout="moe", num_experts=4, num_layers=2)  # a MoE save on 2 ranks: 2 layers, 4 experts
+    assert sorted(gone) == sorted(isp + ["model_moe_layer2_expert0_tp0.pt", "model_moe_layer0_expert4_tp0.pt"])
+    assert sorted(os.listdir(tmp_path)) == sorted(plain + moe + keep)
