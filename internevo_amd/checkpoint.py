@@ -531,10 +531,12 @@ def isp_rank_names(model_cfg, full_shapes, rank, world, sp, wp):
     return [layout[g][0][i][0] for g in (0, 1) for i in layout[g][1][c["d"] if g == 1 else c["z"]]]
 
 
-def load_isp_optimizer(folder, model_cfg, params):
+def load_isp_optimizer(folder, model_cfg, params, want=None):
     """The FULL fp32 master weights and AdamW moments out of the optimizer shards of an ISP-layout folder (`optimizer_tp{t}_wp{w}_pp0_dp{d}.pt` of every
     rank + the plan files, whose names carry the rank's zero1 position): every local shard is put back at its place in the full tensor.  params: the merged
-    model (load_isp_model) for the shapes.  -> dict(master, exp_avg, exp_avg_sq, adam_step, scaler, lr)."""
+    model (load_isp_model) for the shapes.  want (a set of reference names, or None = all): only these are allocated and copied -- a rank of a large job asks
+    for what it holds, not 3 x fp32 of the whole model -- while coverage (every element of every parameter present in some shard) is still checked for ALL
+    names, with one element counter per name.  -> dict(master, exp_avg, exp_avg_sq, adam_step, scaler, lr)."""
     import re
 
     files = {}
@@ -548,8 +550,9 @@ def load_isp_optimizer(folder, model_cfg, params):
     world = next(iter(files.values()))[0]
     sp, wp = max(t for t, _, _ in files) + 1, max(w for _, w, _ in files) + 1
     full_shapes = {n: tuple(t.shape) for n, t in params.items()}
-    out = {k: {n: torch.zeros(full_shapes[n], dtype=torch.float32) for n in full_shapes} for k in ("master", "exp_avg", "exp_avg_sq")}
-    seen = {n: torch.zeros(full_shapes[n], dtype=torch.bool) for n in full_shapes}
+    keep = set(full_shapes) if want is None else set(want) & set(full_shapes)
+    out = {k: {n: torch.zeros(full_shapes[n], dtype=torch.float32) for n in full_shapes if n in keep} for k in ("master", "exp_avg", "exp_avg_sq")}
+    seen = {n: 0 for n in full_shapes}           # elements of the parameter found in the shards (disjoint by construction: isp_shard cuts, the plans partition)
     meta = None
     for (t, w, d), (wld, z) in sorted(files.items()):
         st = _load(os.path.join(folder, f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt"))
@@ -568,9 +571,10 @@ def load_isp_optimizer(folder, model_cfg, params):
                     k = 1
                     for dd in shape:
                         k *= dd
-                    isp_shard(n, out[key][n], t, sp, w, wp).copy_(vec.detach()[o : o + k].reshape(shape))
+                    if n in keep:
+                        isp_shard(n, out[key][n], t, sp, w, wp).copy_(vec.detach()[o : o + k].reshape(shape))
                     if key == "master":
-                        isp_shard(n, seen[n], t, sp, w, wp).fill_(True)
+                        seen[n] += k
                     o += k
                 if o != vec.numel():
                     raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt group {g}: {vec.numel()} elements, the partition holds {o}")
@@ -579,7 +583,11 @@ def load_isp_optimizer(folder, model_cfg, params):
         if meta is not None and here != meta:
             raise ValueError("the ISP optimizer shards disagree on step / lr / loss scale")
         meta = here
-    missing = [n for n, m_ in seen.items() if not bool(m_.all())]
+    numel = lambda shp: int(torch.Size(shp).numel())  # noqa: E731
+    over = [n for n, k_ in seen.items() if k_ > numel(full_shapes[n])]
+    if over:
+        raise ValueError(f"{folder}: the optimizer shards hold {over[:4]} ... more than once (files of two different jobs in one folder?)")
+    missing = [n for n, k_ in seen.items() if k_ != numel(full_shapes[n])]
     if missing:
         raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:4]} ... (files of some ranks are missing)")
     return dict(out, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world // wp,
@@ -688,7 +696,7 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
         params, tp_world, _ = load_isp_model(folder, model_cfg)
         out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0, tp_world=tp_world)
         if not model_only and any(fn.startswith("optimizer_tp") for fn in os.listdir(folder)):
-            out.update(load_isp_optimizer(folder, model_cfg, params))
+            out.update(load_isp_optimizer(folder, model_cfg, params, want=want))
         return out
     tp_world = saved_tp_world(folder)
     if tp_world == 0:

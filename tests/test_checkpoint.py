@@ -1053,6 +1053,11 @@ def test_isp_layout_optimizer_shards_of_the_reference_merge_are_reproduced_and_r
     assert ck["adam_step"] == 2 and ck["isp"] == dict(world=4, sp=2, wp=2) and ck["scaler"]["scale"] == gold[0]["grad_scaler"]["_scale"]
     for n in ck["params"]:
         assert torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    # `want`: a rank asks for the optimizer tensors it holds -- only those are allocated and copied (coverage is still checked for every name)
+    some = {"blocks.1.mixer.Wqkv.weight", "norm.weight", "head.weight"}
+    part = C.load_checkpoint(ref, mc, want=some)
+    assert set(part["master"]) == set(part["exp_avg"]) == set(part["exp_avg_sq"]) == some and set(part["params"]) == set(ck["params"])
+    assert all(torch.equal(part[k][n], ck[k][n]) for k in ("master", "exp_avg", "exp_avg_sq") for n in some) and part["adam_step"] == 2
     hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
     for r in range(4):
         co = C.isp_coords(r, 4, 2, 2)
