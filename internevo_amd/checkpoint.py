@@ -552,7 +552,10 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
     full_shapes = {n: tuple(t.shape) for n, t in params.items()}
     keep = set(full_shapes) if want is None else set(want) & set(full_shapes)
     out = {k: {n: torch.zeros(full_shapes[n], dtype=torch.float32) for n in full_shapes if n in keep} for k in ("master", "exp_avg", "exp_avg_sq")}
-    seen = {n: 0 for n in full_shapes}           # elements of the parameter found in the shards (disjoint by construction: isp_shard cuts, the plans partition)
+    # coverage without a mask per element: the region of a parameter a (t, w) rank holds is a view (isp_shard) -- identified by its offset / shape / strides on a
+    # storage-less tensor; the regions of different ranks are identical (replicated parameters: norms) or disjoint (cut ones)
+    seen = {n: {} for n in full_shapes}
+    probe = {n: torch.empty(full_shapes[n], device="meta") for n in full_shapes}
     meta = None
     for (t, w, d), (wld, z) in sorted(files.items()):
         st = _load(os.path.join(folder, f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt"))
@@ -574,7 +577,8 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
                     if n in keep:
                         isp_shard(n, out[key][n], t, sp, w, wp).copy_(vec.detach()[o : o + k].reshape(shape))
                     if key == "master":
-                        seen[n] += k
+                        reg = isp_shard(n, probe[n], t, sp, w, wp)
+                        seen[n][(reg.storage_offset(), tuple(reg.shape), tuple(reg.stride()))] = k
                     o += k
                 if o != vec.numel():
                     raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt group {g}: {vec.numel()} elements, the partition holds {o}")
@@ -583,11 +587,7 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
         if meta is not None and here != meta:
             raise ValueError("the ISP optimizer shards disagree on step / lr / loss scale")
         meta = here
-    numel = lambda shp: int(torch.Size(shp).numel())  # noqa: E731
-    over = [n for n, k_ in seen.items() if k_ > numel(full_shapes[n])]
-    if over:
-        raise ValueError(f"{folder}: the optimizer shards hold {over[:4]} ... more than once (files of two different jobs in one folder?)")
-    missing = [n for n, k_ in seen.items() if k_ != numel(full_shapes[n])]
+    missing = [n for n, regs in seen.items() if sum(regs.values()) != int(torch.Size(full_shapes[n]).numel())]
     if missing:
         raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:4]} ... (files of some ranks are missing)")
     return dict(out, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world // wp,
