@@ -22,7 +22,11 @@ import os
 import sys
 import time
 
-import torch
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL's peer mappings fail (hipIpcGetMemHandle: invalid argument).  Exported on the
+# GPU boxes already; set here as well, before the HIP runtime loads, so that a launcher with a scrubbed environment still gets a working N > 1 run
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

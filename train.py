@@ -15,6 +15,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC only on these hosts: RCCL peer mappings need it; before the HIP runtime loads)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
