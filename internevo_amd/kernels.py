@@ -505,6 +505,10 @@ LINEAR_FWD_VARIANT = -1  # tile variant forced on the forward product (A/B runs 
 
 def linear_fwd(x, w, out=None):
     """y[T,N] = x[T,K] @ w[N,K]^T"""
+    if LINEAR_FWD_VARIANT == -100:
+        # YARDSTICK ONLY (bench.py --fwd-variant -100, never a default): the forward products through torch.mm = hipBLASLt, to price this repo's forward
+        # kernel against the library's INSIDE the training step (tools/hipblaslt_probe.py compares them in isolation).  Not a product path, not a fallback.
+        return torch.mm(x, w.t(), out=out) if out is not None else torch.mm(x, w.t())
     return gemm(x, w, False, False, out, False, LINEAR_FWD_VARIANT)
 
 
