@@ -386,6 +386,12 @@ int ie_tune_gemm_group(int tile_rows_per_group);
 /* Tuning hook: the automatic GEMM's tail split (0 = off [default: neutral inside the training step], 1 = on: remainder tiles by
  * variant 14 when an operand is k-major, else 12; 2 / 3 = always 14 / 12). */
 int ie_tune_gemm_tail_split(int mode);
+/* Tuning hook: 1 (default) = the forward / input-gradient products on the 16x16x32 refill schedule run in its PERSISTENT frame where that applies (whole
+ * 256x256 tiles, an even number of 64-deep k-tiles, more tiles than blocks): 256 blocks walk their tiles, the transfers continue through the tile boundary, the
+ * accumulators leave through a wave-private LDS turn.  n >= 8 (a multiple of 8) = the same on n blocks (tests).  Same results bit for bit; 0 = the plain launch. */
+int ie_tune_gemm_persistent(int mode);
+/* (internal: the block count behind ie_tune_gemm_persistent; exported because two translation units share it) */
+int ie_gemm_dma_set_persistent_grid(int blocks);
 /* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
 /* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */

@@ -109,6 +109,8 @@ SIGNATURES = {
     "ie_gemm_swiglu_fwd": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "ie_gemm_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "ie_tune_gemm_tail_split": (I, [I]),
+    "ie_tune_gemm_persistent": (I, [I]),
+    "ie_gemm_dma_set_persistent_grid": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
     "ie_bias_add_bf16": (I, [P, I64, P, I64, I64, P]),
     "ie_step_control_groups": (I, [P, P, I, POINTER(IeScalerConfig), P, P, P]),

@@ -364,6 +364,10 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, 
 // wgrad), +3 % (w2 dgrad), +2 % (w2 wgrad); inside the training step the GEMM average improves 0.7 % and tokens/s does not move
 // (same-box A/B, 2 x 2 runs: 19.68 / 19.70 k off, 19.73 / 19.67 k on) -- the idle half round was already giving the busy CUs a
 // higher clock under the power limit, and the extra launch has its own ramp.  Hence OFF by default; kept as a tuning hook.
+// 1 (default since round 5): eligible products of the 16x16x32 refill schedule run in the persistent frame (gemm_p5_k) on 256 blocks; n >= 8, a multiple of 8:
+// on n blocks (tests: small products then walk several tiles per block); 0: the plain launch.  In the training step (same box, A B A B under rocprofv3,
+// profiles/r05_step_gemm_persistent_abab.log): the plain forward products 800 -> 758 us per launch (-5.3 %), the step 676.8 -> 673.8 ms, the same loss bit for bit.
+int g_gemm_persistent = 1;
 int g_tail_split = 0;  // 0 = off, 1 = remainder by variant 14 if an operand is k-major else 12 (as measured), 2 = always 14, 3 = always 12
 struct TailSplit {
     bool on, along_n;
@@ -391,13 +395,18 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
                        "ie_gemm_bf16: pointers must be 16-byte aligned and leading dimensions multiples of 8");
     IE_CHECK_SUPPORTED(N % 8 == 0 && (a_kmajor ? M % 8 == 0 : K % 8 == 0) && (b_kmajor ? true : K % 8 == 0),
                        "ie_gemm_bf16: N (and the contiguous extent of each operand) must be a multiple of 8");
-    IE_CHECK_ARG(variant >= -1 && variant <= 21, "ie_gemm_bf16: unknown tile variant");
+    IE_CHECK_ARG(variant >= -1 && variant <= 22, "ie_gemm_bf16: unknown tile variant");
     if (M == 0 || N == 0) return IE_OK;
     // variant 11 addresses its operands through 32-bit buffer offsets: each operand must span < 4 GiB
     const bool fits32 = /* also needed by variants 13, 14 */ (a_kmajor ? K : M) * lda * 2 < (1ll << 32) && (b_kmajor ? K : N) * ldb * 2 < (1ll << 32);
     if (variant < 0) {
         variant = pick_variant(M, N, K, a_kmajor != 0, b_kmajor != 0, bt.count);
         if ((variant == 11 || variant == 13 || variant >= 15) && !fits32) variant = 9;
+        // the 16x16x32 refill schedule in its persistent frame (variant 22, gemm_p5_k) where it applies: whole 256x256 tiles, an even number of k-tiles, one
+        // product, more tiles than one round (ie_tune_gemm_persistent; same results bit for bit)
+        if (g_gemm_persistent && variant == 20 && bt.count == 1 && M % 256 == 0 && N % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 &&
+            (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent))
+            variant = 22;
         const TailSplit ts = (g_tail_split && bt.count == 1 && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
             const int tail_variant = g_tail_split == 2 ? 14 : g_tail_split == 3 ? 12 : ((a_kmajor || b_kmajor) ? 14 : 12);
@@ -511,6 +520,13 @@ extern "C" int ie_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride_a
                                     void* stream) {
     IE_CHECK_ARG(batch >= 1, "ie_gemm_bf16_batched: batch must be >= 1");
     return gemm_dispatch(-1, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream, IeGemmBatch{batch, stride_a, stride_b, stride_c});
+}
+
+extern "C" int ie_gemm_dma_set_persistent_grid(int blocks);
+extern "C" int ie_tune_gemm_persistent(int mode) {
+    if (mode < 0 || mode > 1024 || (mode > 1 && mode % 8)) return IE_ERR_INVALID;
+    g_gemm_persistent = mode;
+    return ie_gemm_dma_set_persistent_grid(mode > 1 ? mode : 256);
 }
 
 extern "C" int ie_tune_gemm_tail_split(int mode) {

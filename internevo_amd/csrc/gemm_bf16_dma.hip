@@ -18,6 +18,7 @@
 // Block tile 256x256x64, 8 wave64 as 2(M) x 4(N), 128x64 per wave (8 accumulator tiles, 0.75 LDS reads/MFMA).
 #include "ie_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1266,6 +1267,204 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT frame around the 16x16x32 refill schedule (round 5; schedule id -7 = -5 in a persistent frame; forward and input-gradient layouts).
+// Measured on the plain kernel (profiles/r05_gemm_forward_k_sweep.log, r05_gemm_frame_ablation.log): a 16 384 x 4096 forward product costs 71 us + 0.0906 us x K,
+// i.e. 17.8 us per tile ROUND that is not the k-loop -- 16 % of a K = 4096 product: a block's dispatch, its first k-tile's transfer with nothing to hide it
+// (all 256 CUs fetch 16 MB together), the LDS-staged epilogue (4-5 us) -- and the library's persistent stream-K kernel on the same tile, MFMA and per-k-tile
+// instruction mix keeps the matrix pipe 87.5 % busy in the training step where gemm_dma_k<..., -5, 0> reaches 75.4 %.  Here a block WALKS its tiles (block b:
+// tiles b, b + grid, ... -- the order of the plain launch's rounds, so the XCD-aware numbering and the lockstep of a round are kept); the k-loop runs THROUGH the
+// tile boundary: the last two k-tiles of an output tile request the first two k-tiles of the next one (the transfer sources are re-based, nothing else changes: the
+// stages, their barriers and the counted waits continue), the last k-tile reads the next tile's first fragments; the accumulators go to memory FROM REGISTERS
+// (8-byte row pieces: a lane of a 16x16 D^T block holds four consecutive columns of one row; the LDS image of C would need the LDS the next tile's k-tiles are
+// landing in, and two barriers).  The stores share vmcnt with the counted landing waits: in the first k-tile behind an epilogue those waits also cover the
+// stores issued in front of them (over-waiting is safe; the stores are acknowledged by the L2).  K / 64 must be even (the stage parity continues across tiles).
+template <bool B_KM>
+__global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C,
+                                                 int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n) {
+    using G = DCfg<256, 256, 2, 2>;
+    constexpr int NW = 4;
+    constexpr int EP = 256 + 16;                      // pitch of a wave's private epilogue rows (16 rows x 128 bf16 columns)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G::STAGE_BYTES + NW * 16 * EP];
+    const int nblk = tiles_m * tiles_n;
+    const int GM = (accumulate >> 8) ? (accumulate >> 8) : 4;
+    const int abl = (accumulate >> 4) & 15;   // timing ablations (IE_GEMM_ABLATE; results then wrong): 8 = no stores
+    accumulate &= 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / 2, wn = wave % 2;
+    const int nk = K / 64;
+    // tile b of the launch order -> (m0, n0): gemm_dma_k's XCD-contiguous numbering and its GM x tiles_n groups
+    auto coords = [&](int b, int& m0, int& n0) {
+        const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const int width = GM * tiles_n, group = id / width, first_m = group * GM, gsz = min(tiles_m - first_m, GM);
+        m0 = (first_m + (id % width) % gsz) * 256;
+        n0 = ((id % width) / gsz) * 256;
+    };
+    int b = blockIdx.x;
+    if (b >= nblk) return;
+    int m0, n0;
+    coords(b, m0, n0);
+
+    f32x4 acc16[8][8];
+    BufSrc<false, 256, NW> sa;
+    BufSrc<B_KM, 256, NW, B_KM> sb;
+    sa.init(A, lda, m0, M, K, wave, lane);
+    sb.init(B, ldb, n0, N, K, wave, lane);
+    sa.issue(smem, wave);
+    sb.issue(smem + G::A_BYTES, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sb.issue_keep(q, smem + G::STAGE_BYTES + G::A_BYTES, wave);   // k-tile 1 into the second stage, B first (the order the counted waits assume)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sa.issue_keep(q, smem + G::STAGE_BYTES, wave);
+    sa.advance_all();
+    sb.advance_all();
+
+    s16x8 af[2][8], bfr[2][8];
+    auto mfma16 = [](f32x4& d, const s16x8& a, const s16x8& bb) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(bb)); };
+    // (the first k-step of an output tile starts its accumulators from the literal 0: no zeroing pass, and the 256 accumulator registers are never anything
+    // but asm outputs in AGPRs -- assigned from C++ they are parked in VGPRs around the tile loop and spill)
+    auto mfma16z = [](f32x4& d, const s16x8& a, const s16x8& bb) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(d) : "v"(a), "v"(bb)); };
+    auto rdA = [&](const unsigned char* st, int ks, int i) { af[ks][i] = frag_kc16(st, wm * G::WM + i * 16, ks, lane); };
+    auto rdB = [&](const unsigned char* st, int ks, int j) {
+        if constexpr (B_KM) bfr[ks][j] = frag_km16_nowait<256>(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane);
+        else bfr[ks][j] = frag_kc16(st + G::A_BYTES, wn * G::WN + j * 16, ks, lane);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rdA(smem, 0, i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rdB(smem, 0, j);
+    if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // one k-tile (the table of SPREAD -5, its evenly spread transfer pieces).  more1 / more2: the k-tiles one / two ahead exist -- of this output tile or of the next
+    bool behind_stores = false;   // this k-tile follows an epilogue: 32 stores of this wave sit between the transfers the counted waits name and the younger ones
+    auto tile = [&](int t, auto fast_, bool more1_, bool more2_, auto zero_) {
+        constexpr bool FAST = decltype(fast_)::value;
+        constexpr bool ZERO = decltype(zero_)::value;   // the output tile's first k-tile
+        const bool more1 = FAST || more1_, more2 = FAST || more2_;
+        unsigned char* cur = smem + (t & 1) * G::STAGE_BYTES;
+        const unsigned char* nxt = smem + ((t + 1) & 1) * G::STAGE_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int ks = m >> 5, i = (m >> 2) & 7, j = (2 * m) & 7;
+            if (ZERO && ks == 0) mfma16z(acc16[i][j], bfr[ks][j], af[ks][i]);
+            else mfma16(acc16[i][j], bfr[ks][j], af[ks][i]);  // D[n][m]
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < 8) {
+                rdB(cur, 1, m);
+            } else if (m == 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // 1: every wave holds all of B(t)
+            } else if (m >= 14 && m < 22) {
+                rdA(cur, 1, m - 14);
+            } else if (m == 22) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // 2: every wave holds all of A(t)
+            } else if (m == 28) {
+                if (more1) {
+                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(47)" ::: "memory");   // (15 + the 32 stores issued behind B(t+1))
+                    else if (more2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // B(t+1) landed: A(t+1) and the pieces of tile t+2 issued so far stay in flight
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                   // 3: B(t+1) complete
+                }
+            } else if (m >= 29 && m < 37) {
+                if (more1) rdB(nxt, 0, m - 29);
+            } else if (m == 42) {
+                if (more1) {
+                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+                    else if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // A(t+1) landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                   // 4: A(t+1) complete
+                }
+            } else if (m >= 43 && m < 51) {
+                if (more1) rdA(nxt, 0, m - 43);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ZERO && ks == 0) mfma16z(acc16[i][j + 1], bfr[ks][j + 1], af[ks][i]);
+            else mfma16(acc16[i][j + 1], bfr[ks][j + 1], af[ks][i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m >= 8 && m <= 53 && (m - 8) % 3 == 0) {
+                if (more2) {
+                    if (m < 32) sb.issue_keep((m - 8) / 3, cur + G::A_BYTES, wave);   // B(t+2): behind barrier 1
+                    else sa.issue_keep((m - 32) / 3, cur, wave);                       // A(t+2): behind barrier 2
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more2) {
+            sa.advance_all();
+            sb.advance_all();
+        }
+        if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    for (;;) {
+        const int bn = b + (int)gridDim.x;
+        const bool has_next = bn < nblk;
+        int m0n = 0, n0n = 0;
+        if (has_next) coords(bn, m0n, n0n);
+        constexpr std::true_type yes{};
+        constexpr std::false_type no{};
+        tile(0, yes, true, true, yes);
+        int t = 1;
+        for (; t + 2 < nk; ++t) tile(t, yes, true, true, no);
+        if (has_next) {   // the transfers continue into the next output tile: its k-tiles 0 and 1 are "t + 2" of this tile's last two k-tiles
+            sa.init(A, lda, m0n, M, K, wave, lane);
+            sb.init(B, ldb, n0n, N, K, wave, lane);
+        }
+        // (ONE copy of the last two k-tiles with run-time flags: a second copy in another branch would merge 256 accumulator registers where the paths join)
+        tile(t, no, true, has_next, no);
+        tile(t + 1, no, has_next, has_next, no);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: no hazard bookkeeping by the compiler) before they are read
+        // ---- this tile's accumulators to memory.  Straight from the registers a lane has 8-byte pieces of sixteen different rows per store (measured: 9 us per
+        // tile round, twice the plain kernel's LDS-staged epilogue -- it ate what the continued transfers gain); so every WAVE turns one 16-row block at a time
+        // through 4 KB of LDS of its own, beside the stages the next tile is landing in: eight 8-byte writes (its eight 16x16 blocks of the row block), then four
+        // 16-byte pieces per lane read back ALONG the rows and stored -- 256 contiguous bytes per row.  No barrier: the region is the wave's own, LDS operations
+        // of a wave complete in order.
+        if (!((abl & 8) && M != -12345)) {
+            unsigned char* ep = smem + 2 * G::STAGE_BYTES + wave * 16 * EP;
+            unsigned char* wr = ep + (lane & 15) * EP + 8 * (lane >> 4);                 // row m = lane & 15, columns 4 (lane >> 4) .. + 3 of a 16-column block
+            const unsigned char* rd = ep + (lane >> 4) * EP + (lane & 15) * 16;          // piece p = lane + 64 q: row p / 16, 16-byte column p % 16
+            bf16_t* cdst = C + (int64_t)(m0 + wm * G::WM + (lane >> 4)) * ldc + n0 + wn * G::WN + (lane & 15) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint2 v;
+                    v.x = pack2bf(acc16[i][j][0], acc16[i][j][1]);
+                    v.y = pack2bf(acc16[i][j][2], acc16[i][j][3]);
+                    *reinterpret_cast<uint2*>(wr + j * 32) = v;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint4 v = *reinterpret_cast<const uint4*>(rd + q * 4 * EP);
+                    bf16_t* dst = cdst + (int64_t)(i * 16 + q * 4) * ldc;
+                    if (accumulate) {
+                        float o[8], n[8];
+                        unpack8(ld16(dst), o);
+                        unpack8(v, n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += n[e];
+                        v = pack8(o);
+                    }
+                    if (abl & 4) st16(dst, v);   // (A/B: plain instead of non-temporal stores)
+                    else st16_c(dst, v);
+                }
+            }
+        }
+        if (!has_next) break;
+        behind_stores = !accumulate && !((abl & 8) && M != -12345);   // (accumulating epilogues read C: their waits have drained everything)
+        b = bn;
+        m0 = m0n;
+        n0 = n0n;
+    }
+}
+
 }  // namespace
 
 // called from gemm_bf16.hip's dispatcher; arguments already validated there (K % 64 == 0, N % 8 == 0, ...)
@@ -1286,6 +1485,12 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
     return IE_OK;
 }
 
+static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
+extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent; a multiple of 8)
+    if (blocks < 8 || blocks % 8) return IE_ERR_INVALID;
+    g_gemm_persistent_grid = blocks;
+    return IE_OK;
+}
 static int g_gemm_group = 0;  // 0 = the kernel's default (4 tile rows per group)
 extern "C" int ie_tune_gemm_group(int gm) {
     if (gm < 0 || gm > 64) return IE_ERR_INVALID;
@@ -1344,6 +1549,14 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
         const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, true, true, -24>), dim3((unsigned)(tiles_m * tiles_n * bt.count)), dim3(256), 0, st, a, lda, b, ldb, c, ldc,
                            (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n, bt);
+    }
+    else if (shape == 18) {   // the same schedule in the persistent frame (gemm_p5_k): whole 256x256 tiles, an even number of k-tiles, one product
+        if (a_kmajor || bt.count != 1 || M % 256 || N % 256 || (K / 64) % 2 || K < 256) return IE_ERR_UNSUPPORTED;
+        ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, b_kmajor != 0, -7, 0);
+        const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
+        const unsigned grid = (unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid);
+        if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((gemm_p5_k<false>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n);
     }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE

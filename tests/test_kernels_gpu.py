@@ -443,6 +443,38 @@ def test_gemm_tail_split_is_bit_identical(dev, M, N):
     assert lib().ie_tune_gemm_tail_split(4) != 0
 
 
+@pytest.mark.parametrize("M,N,Kd,grid", [(1024, 1024, 512, 8), (2048, 1280, 256, 8), (1536, 2560, 1152, 16), (4096, 4096, 1024, 1)])
+def test_gemm_persistent_frame_is_bit_identical(dev, M, N, Kd, grid):
+    """gemm_p5_k (variant 22; the dispatcher's choice for the eligible forward / input-gradient products since round 5): the 16x16x32 refill schedule in its
+    persistent frame -- blocks that walk their tiles, the transfers continued through the tile boundary, the accumulators out through a wave-private LDS turn --
+    against the plain launch of the same schedule (variant 20): the k order per element is the same, so not one bit may differ; both layouts (B k-contiguous /
+    k-major), with and without accumulate, on strided operands, with blocks that walk 2 - 10 tiles (uneven counts: some blocks one tile more) and with the
+    production block count (grid 1 = 256 blocks, one tile each on this shape); plus the oracle product, and the automatic dispatch taking the frame."""
+    from internevo_amd._lib import load as lib
+    try:
+        assert lib().ie_tune_gemm_persistent(grid) == 0
+        for bkm in (False, True):
+            Abig = bf(torch.randn(M, Kd + 64, generator=g(70))).to(dev)
+            A = Abig[:, :Kd]
+            B = bf(torch.randn((Kd, N) if bkm else (N, Kd), generator=g(71))).to(dev)
+            C0 = bf(torch.randn(M, N, generator=g(72))).to(dev)
+            ref = A.float() @ (B.float() if bkm else B.float().t())
+            plain = K().gemm(A, B, False, bkm, variant=20)
+            pers = K().gemm(A, B, False, bkm, variant=22)
+            close(plain, ref, 8e-3, 2e-3 * math.sqrt(Kd), f"variant 20 {M}x{N}x{Kd} bkm={bkm}")
+            assert torch.equal(pers, plain), f"persistent frame differs from the plain launch: {M}x{N}x{Kd} bkm={bkm} grid={grid}"
+            a20, a22 = C0.clone(), C0.clone()
+            K().gemm(A, B, False, bkm, out=a20, accumulate=True, variant=20)
+            K().gemm(A, B, False, bkm, out=a22, accumulate=True, variant=22)
+            assert torch.equal(a22, a20), f"persistent frame, accumulate: {M}x{N}x{Kd} bkm={bkm} grid={grid}"
+            auto = K().gemm(A, B, False, bkm)     # (the automatic choice: the frame when the product has more tiles than blocks; the same bits either way)
+            assert torch.equal(auto, plain)
+        assert K().gemm(bf(torch.randn(512, 320, generator=g(73))).to(dev), bf(torch.randn(512, 320, generator=g(74))).to(dev), False, False).shape == (512, 512)
+    finally:
+        lib().ie_tune_gemm_persistent(1)
+    assert lib().ie_tune_gemm_persistent(12) != 0 and lib().ie_tune_gemm_persistent(-1) != 0
+
+
 def test_gemm_accumulate_and_strided(dev):
     M, N, Kd = 256, 384, 320
     Abig = bf(torch.randn(M, Kd + 64, generator=g(52)))
