@@ -404,8 +404,10 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
         if ((variant == 11 || variant == 13 || variant >= 15) && !fits32) variant = 9;
         // the 16x16x32 refill schedule in its persistent frame (variant 22, gemm_p5_k) where it applies: whole 256x256 tiles, an even number of k-tiles, one
         // product, more tiles than one round (ie_tune_gemm_persistent; same results bit for bit)
+        // (measured at 16 384 rows, profiles/r05_gemm_persistent_kbench.log, r05_gemm_persistent_k_rule.log: K = 2048 / 4096 -2 ... -2.4 %, 14 336 -1.2 %, 28 672 level,
+        // but K = 6144 +1 % and 8192 level on both layouts: the frame is taken where it was seen to pay)
         if (g_gemm_persistent && variant == 20 && bt.count == 1 && M % 256 == 0 && N % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 &&
-            (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent))
+            (g_gemm_persistent > 1 || K <= 4096 || K >= 12288) && (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent))
             variant = 22;
         const TailSplit ts = (g_tail_split && bt.count == 1 && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
