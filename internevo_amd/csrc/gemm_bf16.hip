@@ -528,7 +528,7 @@ extern "C" int ie_gemm_dma_set_persistent_grid(int blocks);
 extern "C" int ie_tune_gemm_persistent(int mode) {
     if (mode < 0 || mode > 1024 || (mode > 1 && mode % 8)) return IE_ERR_INVALID;
     g_gemm_persistent = mode;
-    return ie_gemm_dma_set_persistent_grid(mode > 1 ? mode : 256);
+    return ie_gemm_dma_set_persistent_grid(mode == 0 ? 0 : mode > 1 ? mode : 256);
 }
 
 extern "C" int ie_tune_gemm_tail_split(int mode) {

@@ -1280,9 +1280,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 // (8-byte row pieces: a lane of a 16x16 D^T block holds four consecutive columns of one row; the LDS image of C would need the LDS the next tile's k-tiles are
 // landing in, and two barriers).  The stores share vmcnt with the counted landing waits: in the first k-tile behind an epilogue those waits also cover the
 // stores issued in front of them (over-waiting is safe; the stores are acknowledged by the L2).  K / 64 must be even (the stage parity continues across tiles).
-template <bool B_KM>
+// EPI 1 (the w1 | w3 forward product with the SwiGLU gate): B = (w1 | w3) [2F, K]; an output tile is 128 gate columns + the SAME 128 up columns, laid out so
+// that every wave holds both for its 64 columns: tile rows [0, 64) = w1 rows n0 .. + 64, [64, 128) = w3 rows n0 .. + 64, [128, 192) = w1 rows n0 + 64 .. + 128,
+// [192, 256) = w3 rows n0 + 64 .. + 128 (a row offset on B's transfer pieces, as in gemm_dma_k's EPI 1) -- accumulator blocks j = 0 .. 3 are gate, 4 .. 7 up
+// columns of one lane's rows.  The epilogue writes h13 (both halves) and act = silu(gate) * up, computed from the bf16-rounded gate / up exactly as the
+// separate kernel and gemm_dma_k's fused epilogue do.  N = 2F; tiles_n = F / 128.
+template <bool B_KM, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C,
-                                                 int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n) {
+                                                 int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n, bf16_t* __restrict__ ACT,
+                                                 int64_t ld_act, int F) {
+    static_assert(EPI == 0 || !B_KM, "EPI 1: the forward product");
     using G = DCfg<256, 256, 2, 2>;
     constexpr int NW = 4;
     constexpr int EP = 256 + 16;                      // pitch of a wave's private epilogue rows (16 rows x 128 bf16 columns)
@@ -1301,7 +1308,15 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
         const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
         const int width = GM * tiles_n, group = id / width, first_m = group * GM, gsz = min(tiles_m - first_m, GM);
         m0 = (first_m + (id % width) % gsz) * 256;
-        n0 = ((id % width) / gsz) * 256;
+        n0 = ((id % width) / gsz) * (EPI == 1 ? 128 : 256);
+    };
+    auto init_b = [&](BufSrc<B_KM, 256, NW, B_KM>& sb_, int n0_) {
+        sb_.init(B, ldb, n0_, N, K, wave, lane);
+        if constexpr (EPI == 1) {   // piece p = wave + 4 q carries tile rows 8 p .. + 7: their source rows (see above)
+            const int64_t rb = ldb * 2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sb_.soff[q] += (int)(((q & 2) ? (int64_t)F : 0) * rb - (int64_t)(q < 2 ? 0 : q < 4 ? 64 : q < 6 ? 64 : 128) * rb);
+        }
     };
     int b = blockIdx.x;
     if (b >= nblk) return;
@@ -1312,7 +1327,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
     BufSrc<false, 256, NW> sa;
     BufSrc<B_KM, 256, NW, B_KM> sb;
     sa.init(A, lda, m0, M, K, wave, lane);
-    sb.init(B, ldb, n0, N, K, wave, lane);
+    init_b(sb, n0);
     sa.issue(smem, wave);
     sb.issue(smem + G::A_BYTES, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1341,6 +1356,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
     if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // one k-tile (the table of SPREAD -5, its evenly spread transfer pieces).  more1 / more2: the k-tiles one / two ahead exist -- of this output tile or of the next
+    constexpr int NST = EPI == 1 ? 48 : 32;   // stores of a wave's epilogue
     bool behind_stores = false;   // this k-tile follows an epilogue: 32 stores of this wave sit between the transfers the counted waits name and the younger ones
     auto tile = [&](int t, auto fast_, bool more1_, bool more2_, auto zero_) {
         constexpr bool FAST = decltype(fast_)::value;
@@ -1367,7 +1383,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                 __builtin_amdgcn_s_barrier();                       // 2: every wave holds all of A(t)
             } else if (m == 28) {
                 if (more1) {
-                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(47)" ::: "memory");   // (15 + the 32 stores issued behind B(t+1))
+                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(15 + NST) : "memory");   // (15 + the stores issued behind B(t+1))
                     else if (more2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // B(t+1) landed: A(t+1) and the pieces of tile t+2 issued so far stay in flight
                     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                   // 3: B(t+1) complete
@@ -1376,7 +1392,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                 if (more1) rdB(nxt, 0, m - 29);
             } else if (m == 42) {
                 if (more1) {
-                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+                    if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + NST) : "memory");
                     else if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // A(t+1) landed
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                   // 4: A(t+1) complete
@@ -1415,7 +1431,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
         for (; t + 2 < nk; ++t) tile(t, yes, true, true, no);
         if (has_next) {   // the transfers continue into the next output tile: its k-tiles 0 and 1 are "t + 2" of this tile's last two k-tiles
             sa.init(A, lda, m0n, M, K, wave, lane);
-            sb.init(B, ldb, n0n, N, K, wave, lane);
+            init_b(sb, n0n);
         }
         // (ONE copy of the last two k-tiles with run-time flags: a second copy in another branch would merge 256 accumulator registers where the paths join)
         tile(t, no, true, has_next, no);
@@ -1439,6 +1455,26 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                     v.x = pack2bf(acc16[i][j][0], acc16[i][j][1]);
                     v.y = pack2bf(acc16[i][j][2], acc16[i][j][3]);
                     *reinterpret_cast<uint2*>(wr + j * 32) = v;
+                }
+                if constexpr (EPI == 1) {   // a row = [gate 64 | up 64]; pair p = lane + 64 q: row p / 8, 8-column piece p % 8
+#pragma unroll 1
+                    for (int q = 0; q < 2; ++q) {
+                        const int prow = (lane >> 3) + 8 * q, pc = lane & 7;
+                        const uint4 gv4 = *reinterpret_cast<const uint4*>(ep + prow * EP + pc * 16), uv4 = *reinterpret_cast<const uint4*>(ep + prow * EP + 128 + pc * 16);
+                        float gv[8], uv[8], o[8];
+                        unpack8(gv4, gv);
+                        unpack8(uv4, uv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd1(gv[e], uv[e]);
+                        const int64_t gm = m0 + wm * G::WM + i * 16 + prow;
+                        const int gn = n0 + wn * 64 + pc * 8;
+                        bf16_t* dst = C + gm * ldc + gn;
+                        st16_c(dst, gv4);
+                        st16_c(dst + F, uv4);
+                        st16_c(ACT + gm * ld_act + gn, pack8(o));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // (keeps the accumulator reads of the next row block behind this one's arithmetic: 256 live registers otherwise)
+                    continue;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1486,8 +1522,11 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
 }
 
 static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
-extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent; a multiple of 8)
+static int g_gemm_persistent_on = 1;        // ie_tune_gemm_persistent's mode (the fused w1 | w3 product is launched from this file)
+extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent: 0 = off, 8 .. 1024 = that many blocks (mode > 1), 256 + on for mode 1)
+    if (blocks == 0) { g_gemm_persistent_on = 0; return IE_OK; }
     if (blocks < 8 || blocks % 8) return IE_ERR_INVALID;
+    g_gemm_persistent_on = blocks == 256 ? 1 : blocks;
     g_gemm_persistent_grid = blocks;
     return IE_OK;
 }
@@ -1555,8 +1594,10 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
         ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, b_kmajor != 0, -7, 0);
         const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
         const unsigned grid = (unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid);
-        if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((gemm_p5_k<false>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n);
+        if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
+                                         (bf16_t*)nullptr, (int64_t)0, 0);
+        else hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
+                                (bf16_t*)nullptr, (int64_t)0, 0);
     }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
@@ -1588,6 +1629,14 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
     ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, bwd ? 1 : 0, bwd ? -4 : -5, bwd ? 2 : 1);
     if (!bwd) {
         const int tiles_n = (int)(F / 128);
+        // the same product in the persistent frame (gemm_p5_k<false, 1>): whole tiles, an even number of k-tiles, more tiles than blocks, K as in gemm_bf16.hip's rule
+        if (g_gemm_persistent_on && M % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 && (K <= 4096 || K >= 12288 || g_gemm_persistent_on > 1) &&
+            tiles_m * tiles_n > g_gemm_persistent_grid) {
+            ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 0, -7, 1);
+            hipLaunchKernelGGL((gemm_p5_k<false, 1>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
+                               (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F);
+            return ie_launch_status("ie_gemm_swiglu (persistent) launch");
+        }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, bt);
     } else {

@@ -470,6 +470,22 @@ def test_gemm_persistent_frame_is_bit_identical(dev, M, N, Kd, grid):
             auto = K().gemm(A, B, False, bkm)     # (the automatic choice: the frame when the product has more tiles than blocks; the same bits either way)
             assert torch.equal(auto, plain)
         assert K().gemm(bf(torch.randn(512, 320, generator=g(73))).to(dev), bf(torch.randn(512, 320, generator=g(74))).to(dev), False, False).shape == (512, 512)
+        # the w1 | w3 forward product with the SwiGLU gate in the same frame (gemm_p5_k<false, 1>: every wave holds gate and up of its 64 columns): identical to
+        # the plain fused launch and to the two-launch path, blocks walking several tiles
+        F = N
+        x = bf(torch.randn(M, Kd, generator=g(75))).to(dev)
+        w13 = bf(torch.randn(2 * F, Kd, generator=g(76)) * 0.05).to(dev)
+        res = {}
+        for mode in (0, grid):
+            assert lib().ie_tune_gemm_persistent(mode) == 0
+            h13 = torch.full((M, 2 * F), 7.0, device=dev, dtype=torch.bfloat16)
+            act = torch.full((M, F), 7.0, device=dev, dtype=torch.bfloat16)
+            K().linear_swiglu_fwd(x, w13, h13, act)
+            res[mode] = (h13, act)
+        assert torch.equal(res[grid][0], res[0][0]) and torch.equal(res[grid][1], res[0][1]), "fused w1 | w3 product: persistent frame differs from the plain launch"
+        lib().ie_tune_gemm_persistent(0)
+        ref = K().linear_fwd(x, w13)
+        assert torch.equal(res[0][0], ref) and torch.equal(res[0][1], K().swiglu_fwd(ref[:, :F], ref[:, F:]))
     finally:
         lib().ie_tune_gemm_persistent(1)
     assert lib().ie_tune_gemm_persistent(12) != 0 and lib().ie_tune_gemm_persistent(-1) != 0
