@@ -1515,7 +1515,8 @@ extern "C" int ie_gemm_note_kernel(int kind, int bm, int bn, int wm, int wn, int
 extern "C" int ie_gemm_last_kernel(char* buf, int n) {
     if (!buf || n <= 0) return IE_ERR_INVALID;
     const int* k = g_last_k;
-    if (k[0] == 1) snprintf(buf, (size_t)n, "gemm_dma_k<%d, %d, %d, %d, %s, %s, %d, %d>", k[1], k[2], k[3], k[4], k[5] ? "true" : "false", k[6] ? "true" : "false", k[7], k[8]);
+    if (k[0] == 1 && k[7] == -7) snprintf(buf, (size_t)n, "gemm_p5_k<%s, %d>", k[6] ? "true" : "false", k[8]);   // (the persistent frame: its own kernel)
+    else if (k[0] == 1) snprintf(buf, (size_t)n, "gemm_dma_k<%d, %d, %d, %d, %s, %s, %d, %d>", k[1], k[2], k[3], k[4], k[5] ? "true" : "false", k[6] ? "true" : "false", k[7], k[8]);
     else if (k[0] == 2) snprintf(buf, (size_t)n, "gemm_bf16_k<%d, %d, %d, %d, %s, %s>", k[1], k[2], k[3], k[4], k[5] ? "true" : "false", k[6] ? "true" : "false");
     else snprintf(buf, (size_t)n, "none");
     return IE_OK;

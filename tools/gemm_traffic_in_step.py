@@ -16,7 +16,7 @@ import sys
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    return {n: (v, k) for n, v, k in rows if "gemm_dma_k" in n or "gemm_bf16_k" in n}
+    return {n: (v, k) for n, v, k in rows if "gemm_dma_k" in n or "gemm_bf16_k" in n or "gemm_p5_k" in n}
 
 
 def main():
