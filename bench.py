@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--fwd-variant", type=int, default=-1, help="A/B only: force a GEMM tile variant on the forward products")
     ap.add_argument("--merge-micro", type=int, default=None, help="A/B only: 1 = run the micro-batches of a step as one merged pass, 0 = sequentially")
     ap.add_argument("--no-batch-wgrad", action="store_true", help="A/B only: one weight-gradient GEMM per micro-batch (engine batch_wgrad=False)")
+    ap.add_argument("--attn-fwd-variant", type=int, default=None, help="A/B only: ie_tune_flash_fwd_variant (library default when omitted)")
     ap.add_argument("--gemm-persistent", type=int, default=None, help="A/B only: ie_tune_gemm_persistent mode (library default when omitted)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B only: ie_tune_gemm_tail_split mode (library default when omitted)")
     ap.add_argument("--checkpoint", type=float, default=0.0, help="model.checkpoint: fraction of layers under activation checkpointing "
@@ -167,6 +168,8 @@ def main():
         assert K._L().ie_tune_gemm_tail_split(args.gemm_tail_split) == 0
     if args.gemm_persistent is not None:
         assert K._L().ie_tune_gemm_persistent(args.gemm_persistent) == 0
+    if args.attn_fwd_variant is not None:
+        assert K._L().ie_tune_flash_fwd_variant(args.attn_fwd_variant) == 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over RCCL) and hand their
         # single JSON line through.  Under torch.distributed.run (the driver's N > 1 command) WORLD_SIZE is set and this is skipped.

@@ -1288,12 +1288,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 template <bool B_KM, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C,
                                                  int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n, bf16_t* __restrict__ ACT,
-                                                 int64_t ld_act, int F) {
+                                                 int64_t ld_act, int F, unsigned* __restrict__ queue) {
     static_assert(EPI == 0 || !B_KM, "EPI 1: the forward product");
     using G = DCfg<256, 256, 2, 2>;
     constexpr int NW = 4;
     constexpr int EP = 256 + 16;                      // pitch of a wave's private epilogue rows (16 rows x 128 bf16 columns)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G::STAGE_BYTES + NW * 16 * EP];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G::STAGE_BYTES + NW * 16 * EP + 16];
     const int nblk = tiles_m * tiles_n;
     const int GM = (accumulate >> 8) ? (accumulate >> 8) : 4;
     const int abl = (accumulate >> 4) & 15;   // timing ablations (IE_GEMM_ABLATE; results then wrong): 8 = no stores
@@ -1318,8 +1318,29 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
             for (int q = 0; q < 8; ++q) sb_.soff[q] += (int)(((q & 2) ? (int64_t)F : 0) * rb - (int64_t)(q < 2 ? 0 : q < 4 ? 64 : q < 6 ? 64 : 128) * rb);
         }
     };
-    int b = blockIdx.x;
-    if (b >= nblk) return;
+    // Which tile next: a block does NOT own the tiles b, b + grid, ... -- if a collective's kernels hold some CUs, the blocks that cannot start until a running block
+    // has finished would leave their whole share for the end (2 x for a 4-round product).  Tiles are handed out by eight counters, one per XCD (block b runs on
+    // XCD b & 7 and takes the tiles x + 8 i of the launch order, i from the XCD's counter: on a free chip the same tiles in the same rounds as the static walk, the
+    // XCD-aware numbering intact); the first tile too.  queue[0..7] the counters, queue[8] the blocks that are done: the last one zeroes them for the launch that
+    // uses this slot next (gemm_bf16_dma.hip hands out 64 slots round-robin).  One lane asks; the answer travels through an LDS word behind the next barrier.
+    unsigned* nextw = reinterpret_cast<unsigned*>(smem + 2 * G::STAGE_BYTES + NW * 16 * EP);
+    const int xcd_ = blockIdx.x & 7;
+    const int per_xcd = (nblk - xcd_ + 7) >> 3;             // tiles x, x + 8, ... below nblk
+    auto grab = [&]() -> int {                              // (wave 0, lane 0)
+        const unsigned i = atomicAdd(queue + xcd_, 1u);
+        return (int)i < per_xcd ? xcd_ + 8 * (int)i : -1;
+    };
+    if (threadIdx.x == 0) nextw[0] = (unsigned)grab();
+    __syncthreads();
+    int b = (int)nextw[0];
+    if (b < 0) {
+        if (threadIdx.x == 0 && atomicAdd(queue + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) queue[i] = 0;
+        }
+        return;
+    }
+    __syncthreads();                                        // (everybody has read the word before the next answer is written)
     int m0, n0;
     coords(b, m0, n0);
 
@@ -1420,14 +1441,19 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
     };
 
     for (;;) {
-        const int bn = b + (int)gridDim.x;
-        const bool has_next = bn < nblk;
-        int m0n = 0, n0n = 0;
-        if (has_next) coords(bn, m0n, n0n);
+        // the next tile: asked for now (the atomic's round trip runs under the first k-tile), published behind it, read behind the second k-tile's barriers
+        int asked = -1;
+        if (threadIdx.x == 0) asked = grab();
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
         tile(0, yes, true, true, yes);
-        int t = 1;
+        if (threadIdx.x == 0) nextw[0] = (unsigned)asked;
+        tile(1, yes, true, true, no);
+        const int bn = (int)nextw[0];
+        const bool has_next = bn >= 0;
+        int m0n = 0, n0n = 0;
+        if (has_next) coords(bn, m0n, n0n);
+        int t = 2;
         for (; t + 2 < nk; ++t) tile(t, yes, true, true, no);
         if (has_next) {   // the transfers continue into the next output tile: its k-tiles 0 and 1 are "t + 2" of this tile's last two k-tiles
             sa.init(A, lda, m0n, M, K, wave, lane);
@@ -1493,7 +1519,13 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                 }
             }
         }
-        if (!has_next) break;
+        if (!has_next) {
+            if (threadIdx.x == 0 && atomicAdd(queue + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) queue[i] = 0;
+            }
+            break;
+        }
         behind_stores = !accumulate && !((abl & 8) && M != -12345);   // (accumulating epilogues read C: their waits have drained everything)
         b = bn;
         m0 = m0n;
@@ -1523,6 +1555,15 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
 }
 
 static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
+// tile queues of the persistent kernel: 64 slots of 16 words handed out round-robin (a launch's last block zeroes its slot; 64 launches later the slot is
+// taken again -- stream order, or far apart in time on different streams); module-global device memory, zero at load: no allocation
+__device__ unsigned g_p5_queues[64 * 16];
+static unsigned* p5_queue_slot() {
+    static unsigned* base = nullptr;
+    static unsigned n = 0;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
+    return base + 16 * (n++ & 63);
+}
 static int g_gemm_persistent_on = 1;        // ie_tune_gemm_persistent's mode (the fused w1 | w3 product is launched from this file)
 extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent: 0 = off, 8 .. 1024 = that many blocks (mode > 1), 256 + on for mode 1)
     if (blocks == 0) { g_gemm_persistent_on = 0; return IE_OK; }
@@ -1595,10 +1636,12 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
         ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, b_kmajor != 0, -7, 0);
         const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
         const unsigned grid = (unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid);
+        unsigned* qslot = p5_queue_slot();
+        if (!qslot) return IE_ERR_LAUNCH;
         if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
-                                         (bf16_t*)nullptr, (int64_t)0, 0);
+                                         (bf16_t*)nullptr, (int64_t)0, 0, qslot);
         else hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
-                                (bf16_t*)nullptr, (int64_t)0, 0);
+                                (bf16_t*)nullptr, (int64_t)0, 0, qslot);
     }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
@@ -1634,8 +1677,10 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
         if (g_gemm_persistent_on && M % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 && (K <= 4096 || K >= 12288 || g_gemm_persistent_on > 1) &&
             tiles_m * tiles_n > g_gemm_persistent_grid) {
             ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 0, -7, 1);
+            unsigned* qslot = p5_queue_slot();
+            if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<false, 1>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
-                               (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F);
+                               (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F, qslot);
             return ie_launch_status("ie_gemm_swiglu (persistent) launch");
         }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
