@@ -1559,10 +1559,12 @@ static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (o
 // taken again -- stream order, or far apart in time on different streams); module-global device memory, zero at load: no allocation
 __device__ unsigned g_p5_queues[64 * 16];
 static unsigned* p5_queue_slot() {
-    static unsigned* base = nullptr;
+    static unsigned* base[16] = {};   // per device: a module-global has one address on every device of the process
     static unsigned n = 0;
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
-    return base + 16 * (n++ & 63);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
+    return base[dev] + 16 * (n++ & 63);
 }
 static int g_gemm_persistent_on = 1;        // ie_tune_gemm_persistent's mode (the fused w1 | w3 product is launched from this file)
 extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent: 0 = off, 8 .. 1024 = that many blocks (mode > 1), 256 + on for mode 1)
