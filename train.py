@@ -123,9 +123,12 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
         raise NotImplementedError("INTERNLM_MoE runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
                                   "the dense engine)")
     tc = cfg.train
+    if getattr(tc, "tp_size", 1) > 1 and (load_folder or save_folder):
+        raise NotImplementedError("INTERNLM_MoE under tensor parallelism: checkpoints are not written / read (set ckpt.enable_save_ckpt=False and no load folder)")
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
-    loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=rank, data_world_size=world)
+    # (the ranks of a tensor group read the same micro-batches: the data stream is split over the data-parallel ranks)
+    loader_obj = SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, tc.fixed_random_dataset_seqlen, data_rank=eng.tpar.dp_rank, data_world_size=eng.dp_world)
     first_step, run_state = 0, None
     if load_folder:   # model + optimizer files of the reference / of save_checkpoint
         from internevo_amd.checkpoint import load_run_state
@@ -162,9 +165,9 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
         eng.step()
         st = eng.read_state()
         infos = dict(step=step, loss=float(loss), moe_loss=float(moe_loss), grad_norm=dict(st.group_norms), loss_scale=st.loss_scale, lr=eng.lr_sched.lr(),
-                     tgs=round(labels.nelement() / (time.time() - start), 2), inf_nan_skip_batches=skipped_before + st.skipped_total)
+                     tgs=round(labels.nelement() * eng.dp_world / world / (time.time() - start), 2), inf_nan_skip_batches=skipped_before + st.skipped_total)
         if not st.skip:
-            consumed += labels.nelement() * world
+            consumed += labels.nelement() * eng.dp_world
         out.append(infos)
         if rank % 8 == 0:
             if st.skip:
