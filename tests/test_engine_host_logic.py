@@ -1,0 +1,101 @@
+"""Host logic of the training engine under every multi-rank layout, on CPU: gloo ranks run one forward / backward / optimizer step of the tiny model with every
+kernel launch stubbed out (the library refuses host tensors; that refusal is asserted in tests/test_moe_tp_host.py), so that what runs is exactly the engine's own
+Python -- process groups, shard shapes and views, buffer aliasing, bucket bookkeeping, and the ORDER and shapes of the collectives on all ranks: a mismatch
+deadlocks or raises here instead of on a multi-GPU node.  This is the N > 1 path `bench.py --gpus N` takes (data parallel + ZeRO-1), and the tensor / sequence /
+pipeline layouts of the BASELINE configs.  The numbers are the GPU tests' business (tests/test_dp_gpu.py, test_multirank_gpu.py, ... on staged ranks)."""
+import contextlib
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Stub:
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, *a):
+        pass
+
+    wait_event = record = synchronize = wait_stream
+
+    def query(self):
+        return True
+
+
+def _worker(rank, world, port, kw, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import internevo_amd.engine as E
+        import internevo_amd.kernels as K
+        from internevo_amd.config import tiny
+        from internevo_amd.data import SyntheticLoader
+
+        torch.cuda.Stream = torch.cuda.Event = _Stub
+        torch.cuda.current_stream = lambda *a, **k: _Stub()
+        torch.cuda.stream = lambda s: contextlib.nullcontext()
+        torch.cuda.synchronize = lambda *a, **k: None
+        K.check = E.check = lambda *a, **k: None   # no launches: null pointers, ignored status
+        K._stream = lambda: None
+        K._contig = lambda t, n: t
+        K._p = lambda t: None
+        cfg = tiny()
+        eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=3, **kw)
+        tc = cfg.train
+        dpw = world // (kw.get("tp_size", 1) * kw.get("sp_size", 1) * kw.get("pp_size", 1))
+        loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, True, data_rank=eng.dp_rank % dpw, data_world_size=dpw))
+        for _ in range(2):   # two steps: the second one runs with the optimizer events / bucket state of the first in place
+            batch, labels = next(loader)
+            eng.forward_backward(batch, labels)
+            eng.step()
+        q.put((rank, "ok", (eng.dp_world, eng.tp, eng.sp, eng.pp)))
+    except Exception:
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+LAYOUTS = {
+    "dp2_zero1": (2, {}),                                   # what `bench.py --gpus 2` runs
+    "dp4_zero1": (4, {}),
+    "tp2_mtp": (2, dict(tp_size=2)),
+    "tp2_msp": (2, dict(tp_size=2, tp_mode="msp")),
+    "dp2_x_tp2": (4, dict(tp_size=2)),                      # BASELINE configs[2]'s layout in small
+    "sp2_ulysses": (2, dict(sp_size=2)),
+    "sp2_ring": (2, dict(sp_size=2, sp_attention="ring")),
+    "pp2_1f1b": (2, dict(pp_size=2)),
+}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name", list(LAYOUTS))
+def test_engine_host_logic_on_gloo_ranks(name):
+    import torch.multiprocessing as mp
+
+    world, kw = LAYOUTS[name]
+    port = 29940 + list(LAYOUTS).index(name) + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, status, meta = q.get(timeout=200)
+        assert meta is not None, f"{name}: rank {r} failed:\n{status}"
+        got[r] = meta
+    for p in procs:
+        p.join(30)
+    tp, sp, pp = kw.get("tp_size", 1), kw.get("sp_size", 1), kw.get("pp_size", 1)
+    # (under ISP sequence parallelism the parameters are replicated over the sequence group too: its ranks belong to the gradient / ZeRO group)
+    assert all(m == (world // (tp * pp), tp, sp, pp) for m in got.values()), got
