@@ -74,6 +74,9 @@ LAYOUTS = {
     "sp2_ulysses": (2, dict(sp_size=2)),
     "sp2_ring": (2, dict(sp_size=2, sp_attention="ring")),
     "pp2_1f1b": (2, dict(pp_size=2)),
+    "dp4_hybrid_zero2": (4, dict(zero_size=2)),             # parallel.zero1.size below the data-parallel size
+    "sp2_weight_parallel": (2, dict(sp_size=2, weight_parallel=True)),   # BASELINE configs[3]'s ISP layout in small
+    "tp2_fsp": (2, dict(tp_size=2, tp_mode="fsp")),
 }
 
 
