@@ -46,7 +46,8 @@ def _worker(rank, world, port, kw, q):
         K._stream = lambda: None
         K._contig = lambda t, n: t
         K._p = lambda t: None
-        cfg = tiny()
+        kw = dict(kw)
+        cfg = tiny(**kw.pop("cfg", {}))
         eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=3, **kw)
         tc = cfg.train
         dpw = world // (kw.get("tp_size", 1) * kw.get("sp_size", 1) * kw.get("pp_size", 1))
@@ -77,6 +78,9 @@ LAYOUTS = {
     "dp4_hybrid_zero2": (4, dict(zero_size=2)),             # parallel.zero1.size below the data-parallel size
     "sp2_weight_parallel": (2, dict(sp_size=2, weight_parallel=True)),   # BASELINE configs[3]'s ISP layout in small
     "tp2_fsp": (2, dict(tp_size=2, tp_mode="fsp")),
+    "pp2_interleaved": (2, dict(pp_size=2, num_chunks=2, cfg=dict(layers=4, micro_num=4))),
+    "llama2_tp2": (2, dict(tp_size=2, cfg=dict(model_type="LLAMA2"))),
+    "internlm1_dp2": (2, dict(cfg=dict(model_type="INTERNLM", kv_heads=8))),
 }
 
 
