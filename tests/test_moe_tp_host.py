@@ -24,7 +24,7 @@ class _Stub:
     wait_event = record = synchronize = wait_stream
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, tp=2):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -59,8 +59,8 @@ def _worker(rank, world, port, q):
         K._stream = lambda: None
         K._contig = lambda t, n: t
         K._p = lambda t: None
-        eng = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=2)
-        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=rank // 2, data_world_size=world // 2))
+        eng = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=tp)
+        loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=rank // tp, data_world_size=world // tp))
         batch, labels = next(loader)
         eng.forward_backward(batch, labels)
         eng.step()
@@ -74,12 +74,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run(world, port):
+def _run(world, port, tp=2):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -114,3 +114,14 @@ def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
     assert s0["blocks.1.mlp.moe_layer.experts.wrapped_experts.3.w1.weight"] == (256, 256) and s0["blocks.1.mlp.moe_layer.experts.wrapped_experts.3.w2.weight"] == (256, 256)
     assert s0["head.weight"] == (256, 256) and s0["embedding.weight"] == (512, 256) and s0["blocks.0.mlp.moe_layer.gate.wg.weight"] == (4, 256)
     assert s0["blocks.0.mixer.out_proj.bias"] == (256,) and s0["norm.weight"] == (256,)
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_expert_parallel_host_logic_on_two_and_four_gloo_ranks():
+    """plain data + expert parallelism (BASELINE configs[4]'s layout): ep = min(dp, experts) -- two ranks with two experts each, four ranks with one each."""
+    res = _run(2, 29935, tp=1)
+    assert [res[r][1] for r in range(2)] == [(1, 0, 2, 2, 4, 512, 512)] * 2
+    res = _run(4, 29937, tp=1)
+    assert [res[r][1] for r in range(4)] == [(1, 0, 4, 4, 4, 512, 512)] * 4
+    held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
+    assert [held(r) for r in range(4)] == [["0"], ["1"], ["2"], ["3"]]
