@@ -69,6 +69,7 @@ def _worker(rank, world, port, kw, q):
 LAYOUTS = {
     "dp2_zero1": (2, {}),                                   # what `bench.py --gpus 2` runs
     "dp4_zero1": (4, {}),
+    "dp8_zero1": (8, {}),                                   # ... and `--gpus 8`: the layout of the driver's scaling run
     "tp2_mtp": (2, dict(tp_size=2)),
     "tp2_msp": (2, dict(tp_size=2, tp_mode="msp")),
     "dp2_x_tp2": (4, dict(tp_size=2)),                      # BASELINE configs[2]'s layout in small
