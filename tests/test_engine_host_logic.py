@@ -48,7 +48,7 @@ def _worker(rank, world, port, kw, q):
         K._p = lambda t: None
         kw = dict(kw)
         cfg = tiny(**kw.pop("cfg", {}))
-        eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=3, **kw)
+        eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=3, **{k: v for k, v in kw.items() if k != "_ckpt"})
         tc = cfg.train
         dpw = world // (kw.get("tp_size", 1) * kw.get("sp_size", 1) * kw.get("pp_size", 1))
         loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, True, data_rank=eng.dp_rank % dpw, data_world_size=dpw))
@@ -56,11 +56,28 @@ def _worker(rank, world, port, kw, q):
             batch, labels = next(loader)
             eng.forward_backward(batch, labels)
             eng.step()
+        ck = kw.get("_ckpt")
+        if ck:   # the checkpoint round trip of this layout (collective save, every rank's files; a fresh engine resumes from them): the stubbed kernels
+            #      leave the state as initialised, so what is checked is the host side -- names, shards, partitions, files of every rank, the merge on load
+            probe = torch.empty(4 * eng.tp, 4 * eng.tp)
+            for j, t in enumerate((eng.master, eng.exp_avg, eng.exp_avg_sq)):   # a value per (tensor, parameter, position inside it, tensor rank if it is cut there):
+                for n, a, k, lo in eng._shard_pieces():                          # replicas agree, no two shards do
+                    cut = eng.tpar.shard(eng.layout.params[n].kind, probe).shape != probe.shape
+                    t[lo : lo + k] = torch.arange(a, a + k, dtype=torch.float32) * 1e-3 + (sum(map(ord, n)) % 97) + 100 * j + (0.5 * eng.tpar.tp_rank if cut else 0.0)
+            eng.save_checkpoint(ck)
+            dist.barrier()
+            fresh = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=11, **{k: v for k, v in kw.items() if k != "_ckpt"})
+            fresh.load_checkpoint(ck)
+            for name in ("params", "master", "exp_avg", "exp_avg_sq"):
+                a, b = getattr(eng, name), getattr(fresh, name)
+                assert torch.equal(a, b), f"{name} differs after save -> load on rank {rank}"
         q.put((rank, "ok", (eng.dp_world, eng.tp, eng.sp, eng.pp)))
     except Exception:
         import traceback
 
         q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()   # the report is on the pipe before this rank goes (its peers may be waiting in a collective: no clean shutdown)
         os._exit(1)
     finally:
         dist.destroy_process_group()
@@ -85,12 +102,17 @@ LAYOUTS = {
 }
 
 
+CKPT_LAYOUTS = tuple(LAYOUTS)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("name", list(LAYOUTS))
-def test_engine_host_logic_on_gloo_ranks(name):
+def test_engine_host_logic_on_gloo_ranks(name, tmp_path):
     import torch.multiprocessing as mp
 
     world, kw = LAYOUTS[name]
+    if name in CKPT_LAYOUTS:
+        kw = dict(kw, _ckpt=str(tmp_path / "ckpt"))
     port = 29940 + list(LAYOUTS).index(name) + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -479,6 +479,8 @@ def _tp_engine_worker(rank, world, port, q, steps):
         import traceback
 
         q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()   # the report is on the pipe before this rank goes
         os._exit(1)
     finally:
         dist.destroy_process_group()
@@ -602,6 +604,8 @@ def _tp_dp_engine_worker(rank, world, port, q, steps):
         import traceback
 
         q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()   # the report is on the pipe before this rank goes
         os._exit(1)
     finally:
         dist.destroy_process_group()

@@ -69,6 +69,8 @@ def _worker(rank, world, port, q, tp=2):
         import traceback
 
         q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()   # the report is on the pipe before this rank goes
         os._exit(1)
     finally:
         dist.destroy_process_group()
