@@ -83,6 +83,96 @@ def _worker(rank, world, port, kw, q):
         dist.destroy_process_group()
 
 
+def _stub_launches():
+    import internevo_amd.engine as E
+    import internevo_amd.kernels as K
+
+    torch.cuda.Stream = torch.cuda.Event = _Stub
+    torch.cuda.current_stream = lambda *a, **k: _Stub()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.synchronize = lambda *a, **k: None
+    K.check = E.check = lambda *a, **k: None
+    K._stream = lambda: None
+    K._contig = lambda t, n: t
+    K._p = lambda t: None
+    return E
+
+
+def _chain_worker(rank, world, port, chain, folder, q):
+    """The checkpoint files as the exchange format BETWEEN layouts: the first layout saves a recognisable state, every next one resumes from the
+    previous folder and saves its own; whatever layout wrote a folder, the loader's merged FULL tensors must be the first folder's."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        E = _stub_launches()
+        from internevo_amd import checkpoint as C
+        from internevo_amd.config import tiny
+
+        first = None
+        for i, kw in enumerate(chain):
+            kw = dict(kw)
+            cfg = tiny(**kw.pop("cfg", {}))
+            eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=3 + i, **kw)
+            here = os.path.join(folder, f"hop{i}")
+            if i == 0:
+                probe = torch.empty(4 * eng.tp, 4 * eng.tp)
+                for j, t in enumerate((eng.master, eng.exp_avg, eng.exp_avg_sq)):
+                    for n, a, k, lo in eng._shard_pieces():
+                        cut = eng.tpar.shard(eng.layout.params[n].kind, probe).shape != probe.shape
+                        t[lo : lo + k] = torch.arange(a, a + k, dtype=torch.float32) * 1e-3 + (sum(map(ord, n)) % 97) + 100 * j + (0.5 * eng.tpar.tp_rank if cut else 0.0)
+            else:
+                eng.load_checkpoint(os.path.join(folder, f"hop{i - 1}"))
+            eng.save_checkpoint(here)
+            dist.barrier()
+            if rank == 0:
+                ck = C.load_checkpoint(here, cfg.model)
+                if first is None:
+                    first = ck
+                else:
+                    for key in ("params", "master", "exp_avg", "exp_avg_sq"):
+                        assert set(ck[key]) == set(first[key]), f"hop {i} ({kw}): the names of {key} changed"
+                        for n, t in first[key].items():
+                            assert torch.equal(t.float(), ck[key][n].float()), f"hop {i} ({kw}): {key}[{n}] is not what hop 0 saved"
+                    assert ck["adam_step"] == first["adam_step"] and ck["scaler"] == first["scaler"], f"hop {i}: step / scaler changed"
+            dist.barrier()
+        q.put((rank, "ok", len(chain)))
+    except Exception:
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+CHAIN = [dict(tp_size=2), {}, dict(pp_size=2), dict(zero_size=2), dict(sp_size=2, weight_parallel=True), dict(tp_size=2, tp_mode="msp"), dict(pp_size=2, tp_size=2),
+         dict(sp_size=2), dict(tp_size=2, tp_mode="fsp"), dict(pp_size=2, num_chunks=2), dict(sp_size=4, weight_parallel=True), dict(pp_size=4)]
+CHAIN = [dict(kw, cfg=dict(layers=4, micro_num=4)) for kw in CHAIN]   # (one model for every hop; four layers / four micro-batches: what the interleaved and the 4-stage hops need)
+
+
+@pytest.mark.timeout(300)
+def test_checkpoints_carry_the_state_from_layout_to_layout_on_four_gloo_ranks(tmp_path):
+    import torch.multiprocessing as mp
+
+    world = 4
+    port = 29990 + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_chain_worker, args=(r, world, port, CHAIN, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        r, status, meta = q.get(timeout=240)
+        assert meta is not None, f"rank {r} failed:\n{status}"
+    for p in procs:
+        p.join(30)
+
+
 LAYOUTS = {
     "dp2_zero1": (2, {}),                                   # what `bench.py --gpus 2` runs
     "dp4_zero1": (4, {}),
