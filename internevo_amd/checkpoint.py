@@ -297,18 +297,20 @@ def save_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam
                 return torch.cat([named[n].detach().to("cpu", torch.float32).reshape(-1) for n in names])
 
             # key order as the reference's groups carry it (train/utils.py:create_param_groups + torch.optim.AdamW defaults)
+            # (a rank with an EMPTY partition -- more ZeRO ranks than parameters -- keeps the group's own parameters in the base optimizer, without state and without
+            #  flat weights: hybrid_zero_optim.py:210-222,880-895; the rule is pinned on the MoE model's gate group, tests/golden/ckpt_ref_moe_dp4/)
             g_default = dict(name="default", weight_decay=hyper["weight_decay"], optimizer_mode=zero1, **tail, dtype=param_dtype,
-                             initial_lr=hyper["initial_lr"], params=[0])
+                             initial_lr=hyper["initial_lr"], params=[0] if names else list(range(len(flat_order))))
             g_fp32 = dict(name="fp32", optimizer_mode=zero1, weight_decay=hyper["weight_decay"], **tail, dtype=None,
                           initial_lr=hyper["initial_lr"], params=[])
             states = {
                 "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]),
                                 "_hysteresis_step": int(scaler["hysteresis_step"])},
                 "base_optim_states": {
-                    "state": {0: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg), "exp_avg_sq": flat(exp_avg_sq)}},
+                    "state": {0: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg), "exp_avg_sq": flat(exp_avg_sq)}} if names else {},
                     "param_groups": [g_default, g_fp32],
                 },
-                "flat_fp32_weights": {0: flat(master)},
+                "flat_fp32_weights": {0: flat(master)} if names else {},
                 "zero_devide_optim_plan": plan,  # the reference writes the state file BEFORE popping the plan (components.py:398-407)
             }
             torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp{pp_rank}_zo{r}.pt"))
@@ -672,6 +674,10 @@ def _load_tp_rank(folder, model_cfg, t, tp_world, want, pp_rank=0, pp_world=1, s
                 raise ValueError(f"flat optimizer vector of tp{t} zo{r} holds {vec.numel()} elements, this model's partition {o}")
 
         base = st["base_optim_states"]
+        if not partition[r]:   # a ZeRO rank without parameters: its file carries the scaler and the groups only
+            if base["state"] or st["flat_fp32_weights"]:
+                raise ValueError(f"optimizer shard tp{t} zo{r} holds state, this model's partition over {zero_world} ranks gives that rank no parameter")
+            continue
         s0 = base["state"][0]
         unflat(st["flat_fp32_weights"][0], merged["master"])
         unflat(s0["exp_avg"], merged["exp_avg"])
@@ -835,18 +841,28 @@ def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, 
         tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
                     differentiable=False, fused=True, decoupled_weight_decay=True)
         wd, ilr = hyper["weight_decay"], hyper["initial_lr"]
+        # A rank whose partition of a group is EMPTY (more ranks than parameters: the gates of a shallow model on many ranks; hybrid_zero_optim.py:254-284
+        # no_params_ranks) keeps the group's own parameters in the base optimizer (:210-222 replaces them by the flat fp32 shard only where there is one): the
+        # group lists ALL its parameters' ids, none of them has optimizer state, the group has no flat fp32 weights, and the ids behind it move up
+        # (pinned on ranks 2 and 3 of tests/golden/ckpt_ref_moe_dp4/).
+        held = [bool(part[zr]) for _, part, zr in layout]
+        ids, nxt = [], 0
+        for g in range(3):
+            k = 1 if held[g] else len(groups[g][1])
+            ids.append(list(range(nxt, nxt + k)))
+            nxt += k
         # key order as the reference's groups carry it
-        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=[0]),
-               dict(name="fp32", optimizer_mode=zero1, weight_decay=wd, **tail, dtype=torch.float32, initial_lr=ilr, params=[1]),
-               dict(name=groups[2][0], moe=True, optimizer_mode=pm.EXPERT_DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=[2])]
+        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=ids[0]),
+               dict(name="fp32", optimizer_mode=zero1, weight_decay=wd, **tail, dtype=torch.float32, initial_lr=ilr, params=ids[1]),
+               dict(name=groups[2][0], moe=True, optimizer_mode=pm.EXPERT_DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=ids[2])]
         states = {
             "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]), "_hysteresis_step": int(scaler["hysteresis_step"])},
             "base_optim_states": {
-                "state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
-                          for g in range(3)},
+                "state": {ids[g][0]: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
+                          for g in range(3) if held[g]},
                 "param_groups": pgs,
             },
-            "flat_fp32_weights": {g: flat(master, g) for g in range(3)},
+            "flat_fp32_weights": {g: flat(master, g) for g in range(3) if held[g]},
             "zero_devide_optim_plan": plan,
         }
         torch.save(states, os.path.join(folder, f"optimizer_tp0_pp0_zo{rank}.pt"))
@@ -878,8 +894,11 @@ def load_moe_checkpoint(folder, model_cfg):
         for g, (fo, part, zr) in enumerate(layout):
             if list(st["zero_devide_optim_plan"][g][zr]) != _plan_ids(fo, part[zr]):
                 raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt: zero_devide_optim_plan of group {g} does not match this model")
-            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
-                             ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
+            if not part[zr]:   # this rank holds no parameter of the group: no state, no flat weights, the group lists its own parameters (see save_moe_checkpoint)
+                continue
+            sid = st["base_optim_states"]["param_groups"][g]["params"][0]
+            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][sid]["exp_avg"]),
+                             ("exp_avg_sq", st["base_optim_states"]["state"][sid]["exp_avg_sq"])):
                 o = 0
                 for i in part[zr]:
                     n, shape = fo[i]

@@ -727,7 +727,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, "ckpt_ref_moe_dp2" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, f"ckpt_ref_moe_dp{world}" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -806,7 +806,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             rec["files"] = sorted(os.listdir(folder))
             rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.DATA, ParallelMode.ZERO1, ParallelMode.EXPERT, ParallelMode.EXPERT_DATA)}
             rec["rank_unique_id"] = optimizer.rank_unique_id
-            with open(os.path.join(HERE, f"ckpt_moe_dp2_rank{rank}.json"), "w") as f:
+            with open(os.path.join(HERE, f"ckpt_moe_dp{world}_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
         if isp and world == 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
@@ -1553,6 +1553,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe-rank":
         gen_checkpoint(port=29788, rank=int(sys.argv[2]), world=2, model_type="INTERNLM_MoE")
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe4-rank":   # four ranks, two gate parameters: two ranks hold NO parameter of the fp32 group (hybrid_zero_optim.py:254-284)
+        gen_checkpoint(port=29786, rank=int(sys.argv[2]), world=4, model_type="INTERNLM_MoE")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-mp4":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe4-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-mp":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe-rank", str(r)]) for r in range(2)]
         sys.exit(max(p.wait() for p in procs))

@@ -434,6 +434,41 @@ def test_checkpoint_layouts_round_trip(tmp_path, tp, zw):
     assert set(part["master"]) == some and all(torch.equal(part["exp_avg"][n], full["exp_avg"][n]) for n in some)
 
 
+def test_more_zero_ranks_than_parameters(tmp_path):
+    """ZeRO ranks that hold NO parameter (the greedy whole-parameter partition over more ranks than parameters, hybrid_zero_optim.py:254-284) write what the
+    reference's do -- the group's own parameter ids, no optimizer state, no flat weights (the rule pinned on tests/golden/ckpt_ref_moe_dp4/) -- and the reader
+    merges the folder without them."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import tiny
+    from oracle.model import param_shapes
+
+    cfg = tiny(128, 2, 4, 4, 256, 32, 2, 1e-3, 4)
+    order = C.state_dict_order(cfg.model)
+    zw = len(order) + 3
+    shapes = param_shapes(cfg.model)
+    g = torch.Generator().manual_seed(5)
+    full = {k: {n: torch.randn(shapes[n], generator=g) for n in order} for k in ("params", "master", "exp_avg", "exp_avg_sq")}
+    full["params"] = {n: v.to(torch.bfloat16) for n, v in full["params"].items()}
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    scaler = dict(scale=1024.0, growth_step=7, hysteresis_step=1)
+    owners = C.zero_rank_names({n: tuple(shapes[n]) for n in order}, zw)
+    assert sum(1 for o in owners if not o) == 3
+    out = str(tmp_path / "ck")
+    for r in range(zw):
+        own = lambda d: {n: d[n] for n in owners[r]}  # noqa: E731
+        C.save_checkpoint(out, cfg.model, full["params"] if r == 0 else None, own(full["master"]), own(full["exp_avg"]), own(full["exp_avg_sq"]), 5, scaler, 3e-4, hyper,
+                          zero_world=zw, zero_ranks=[r], write_model=(r == 0), shapes={n: tuple(shapes[n]) for n in order})
+    empty = next(r for r in range(zw) if not owners[r])
+    st = C._load(os.path.join(out, f"optimizer_tp0_pp0_zo{empty}.pt"))
+    assert st["base_optim_states"]["state"] == {} and st["flat_fp32_weights"] == {} and st["zero_devide_optim_plan"][0][empty] == []
+    assert [g_["params"] for g_ in st["base_optim_states"]["param_groups"]] == [list(range(len(order))), []]
+    ck = C.load_checkpoint(out, cfg.model)
+    assert (ck["zero_world"], ck["adam_step"], ck["lr"], ck["scaler"]) == (zw, 5, 3e-4, scaler)
+    for k in ("params", "master", "exp_avg", "exp_avg_sq"):
+        for n in order:
+            assert torch.equal(ck[k][n], full[k][n]), (k, n)
+
+
 @pytest.mark.gpu
 def test_engine_resumes_from_reference_checkpoint_and_round_trips(dev, tmp_path):
     """The HIP engine loads the reference's checkpoint and reproduces the 2 steps the reference trained after saving; a checkpoint
@@ -1143,6 +1178,39 @@ def test_moe_two_rank_reference_checkpoint_merges_is_reproduced_and_resumes(tmp_
             assert abs(res[r]["loss"] - w["loss"]) <= 1e-4 * w["loss"], (k, r)        # (measured 4e-6)
             for (g_, v), gw in zip(res[r]["grad_norm"].items(), w["grad_norm"].values()):
                 assert abs(v - gw) <= 2e-3 * gw, (k, r, g_, v, gw)                     # (measured 2.5e-4)
+
+
+def test_moe_four_rank_reference_checkpoint_with_ranks_that_hold_no_gate(tmp_path):
+    """tests/golden/ckpt_ref_moe_dp4/ = a real FOUR-rank run of the reference's INTERNLM_MoE model (make_golden.py --ckpt-moe-mp4): ep = 4, one expert per rank, and
+    the two gate parameters of the fp32 group go to ZeRO ranks 0 and 1 -- ranks 2 and 3 hold NO parameter of that group (hybrid_zero_optim.py:254-284): their files
+    carry no flat weights and no optimizer state for it, the group lists the gates themselves (ids 1, 2) and the expert group's id moves to 3.  The reader merges the four
+    ranks; writing them again reproduces the reference's files tensor for tensor."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig
+
+    gold = [json.load(open(os.path.join(G, f"ckpt_moe_dp4_rank{r}.json"))) for r in range(4)]
+    c = gold[0]["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+    ref = os.path.join(G, "ckpt_ref_moe_dp4")
+    st3 = C._load(os.path.join(ref, "optimizer_tp0_pp0_zo3.pt"))
+    assert [g["params"] for g in st3["base_optim_states"]["param_groups"]] == [[0], [1, 2], [3]] and sorted(st3["base_optim_states"]["state"]) == [0, 3]
+    assert sorted(st3["flat_fp32_weights"]) == [0, 2] and st3["zero_devide_optim_plan"][1][2:] == [[], []]
+    ck = C.load_moe_checkpoint(ref, mc)
+    assert ck["adam_step"] == 2 and ck["zero_world"] == 4 and len(ck["master"]) == len(C.state_dict_order(mc))
+    for n in ck["params"]:
+        assert torch.equal(ck["master"][n].to(ck["params"][n].dtype), ck["params"][n]), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for r in range(4):
+        mine = {n for _, names in C.moe_groups(mc, 4, r) for n in names}
+        part = lambda d: {n: t for n, t in d.items() if n in mine}  # noqa: E731
+        C.save_moe_checkpoint(str(tmp_path), mc, part(ck["params"]), part(ck["master"]), part(ck["exp_avg"]), part(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"],
+                              ck["lr"], hyper, world=4, rank=r)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(ref)) == gold[0]["files"]
+    for fn in gold[0]["files"]:
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(tmp_path, fn)), ld(os.path.join(ref, fn)), fn)
 
 
 def test_stale_files_of_another_layout_are_removed_before_a_save(tmp_path):

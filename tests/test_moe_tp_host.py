@@ -24,7 +24,7 @@ class _Stub:
     wait_event = record = synchronize = wait_stream
 
 
-def _worker(rank, world, port, q, tp=2):
+def _worker(rank, world, port, q, tp=2, ckpt=None):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -64,6 +64,33 @@ def _worker(rank, world, port, q, tp=2):
         batch, labels = next(loader)
         eng.forward_backward(batch, labels)
         eng.step()
+        if tp == 1 and ckpt:   # the checkpoint round trip of the expert-parallel layout: model file without experts, one file per expert, the optimizer partitions of every rank
+            import internevo_amd.checkpoint as C
+
+            def fill(flat, gates, j):   # a value per (buffer, position): the replicated parameters agree between the ranks; a rank's own experts carry its expert rank
+                flat.copy_((torch.arange(flat.numel()) % 251).float() / 256 + j)
+                for n, v in eng._views(flat).items():
+                    if n.endswith(("mlp.w13", "mlp.w2")):
+                        v += 0.25 * (eng.ep_rank + 1)
+                if gates is not None:
+                    gates.copy_((torch.arange(gates.numel()) % 83).float().view_as(gates) / 128 + j)
+
+            fill(eng.params, eng.wg, 0)
+            fill(eng.master, None, 0)
+            fill(eng.exp_avg, eng.wg_m, 1)
+            fill(eng.exp_avg_sq, eng.wg_v, 2)
+            eng.save_checkpoint(ckpt)
+            dist.barrier()
+            fresh = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=tp)
+            fresh.load_checkpoint(ckpt)
+            for name in ("params", "wg", "master", "exp_avg", "exp_avg_sq", "wg_m", "wg_v"):
+                a, b = getattr(eng, name), getattr(fresh, name)
+                assert torch.equal(a.float(), b.float()), f"{name} differs after save -> load on rank {rank}"
+            if rank == 0:   # ... and the folder holds every expert of every layer once, under the reference's names
+                ck = C.load_moe_checkpoint(ckpt, mc)
+                experts = {n for n in ck["params"] if ".experts." in n}
+                assert len(experts) == mc.num_layers * mc.num_experts * 3, sorted(experts)
+                assert set(ck["master"]) == set(ck["params"]) == set(ck["exp_avg"]) == set(ck["exp_avg_sq"])
         q.put((rank, {n: tuple(p.shape) for n, p in eng.named_parameters()}, (eng.tp, eng.tp_rank, eng.dp_world, eng.ep, eng.H, eng.F, eng.Vl)))
     except Exception:
         import traceback
@@ -76,12 +103,12 @@ def _worker(rank, world, port, q, tp=2):
         dist.destroy_process_group()
 
 
-def _run(world, port, tp=2):
+def _run(world, port, tp=2, ckpt=None):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -119,11 +146,11 @@ def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
 
 
 @pytest.mark.timeout(300)
-def test_moe_engine_expert_parallel_host_logic_on_two_and_four_gloo_ranks():
+def test_moe_engine_expert_parallel_host_logic_on_two_and_four_gloo_ranks(tmp_path):
     """plain data + expert parallelism (BASELINE configs[4]'s layout): ep = min(dp, experts) -- two ranks with two experts each, four ranks with one each."""
-    res = _run(2, 29935, tp=1)
+    res = _run(2, 29935, tp=1, ckpt=str(tmp_path / "ep2"))
     assert [res[r][1] for r in range(2)] == [(1, 0, 2, 2, 4, 512, 512)] * 2
-    res = _run(4, 29937, tp=1)
+    res = _run(4, 29937, tp=1, ckpt=str(tmp_path / "ep4"))
     assert [res[r][1] for r in range(4)] == [(1, 0, 4, 4, 4, 512, 512)] * 4
     held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
     assert [held(r) for r in range(4)] == [["0"], ["1"], ["2"], ["3"]]
