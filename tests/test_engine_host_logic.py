@@ -189,6 +189,9 @@ LAYOUTS = {
     "pp2_interleaved": (2, dict(pp_size=2, num_chunks=2, cfg=dict(layers=4, micro_num=4))),
     "llama2_tp2": (2, dict(tp_size=2, cfg=dict(model_type="LLAMA2"))),
     "internlm1_dp2": (2, dict(cfg=dict(model_type="INTERNLM", kv_heads=8))),
+    "dp2_x_tp2_x_pp2": (8, dict(tp_size=2, pp_size=2)),    # the three axes at once on eight ranks
+    "dp8_hybrid_zero4": (8, dict(zero_size=4)),
+    "dp2_x_sp2_x_wp": (4, dict(sp_size=2, weight_parallel=True)),
 }
 
 

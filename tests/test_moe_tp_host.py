@@ -154,3 +154,13 @@ def test_moe_engine_expert_parallel_host_logic_on_two_and_four_gloo_ranks(tmp_pa
     assert [res[r][1] for r in range(4)] == [(1, 0, 4, 4, 4, 512, 512)] * 4
     held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
     assert [held(r) for r in range(4)] == [["0"], ["1"], ["2"], ["3"]]
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_eight_ranks_four_experts_host_logic(tmp_path):
+    """eight data-parallel ranks, four experts: ep = 4, every expert on TWO ranks (the expert-data groups {r, r + 4}: process_group_initializer.py:493-524) --
+    the expert gradients reduce over those, the expert group's optimizer partition is cut over them, the checkpoint's expert files come from expert-data rank 0."""
+    res = _run(8, 29939, tp=1, ckpt=str(tmp_path / "ep4x2"))
+    assert [res[r][1] for r in range(8)] == [(1, 0, 8, 4, 4, 512, 512)] * 8
+    held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
+    assert [held(r) for r in range(8)] == [["0"], ["1"], ["2"], ["3"]] * 2
