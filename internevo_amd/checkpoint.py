@@ -511,15 +511,23 @@ def save_isp_optimizer_shard(folder, model_cfg, rank, world, sp, wp, master, exp
         tail = dict(lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False,
                     differentiable=False, fused=True, decoupled_weight_decay=True)
         wd, ilr = hyper["weight_decay"], hyper["initial_lr"]
-        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=[0]),
-               dict(name="embed_head", optimizer_mode=pm.DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=[1]),
+        # (a rank whose partition of a group is EMPTY -- embedding + head over three or more data ranks -- lists the group's own parameters, without state and without
+        #  flat weights, and the ids behind them move up: see save_moe_checkpoint; pinned on data rank 2 of tests/golden/ckpt_ref_isp6v1/)
+        held = [bool(layout[g][1][c["d"] if g == 1 else c["z"]]) for g in (0, 1)]
+        ids, nxt = [], 0
+        for g in (0, 1):
+            k = 1 if held[g] else len(layout[g][0])
+            ids.append(list(range(nxt, nxt + k)))
+            nxt += k
+        pgs = [dict(name="default", weight_decay=wd, optimizer_mode=zero1, **tail, dtype=param_dtype, initial_lr=ilr, params=ids[0]),
+               dict(name="embed_head", optimizer_mode=pm.DATA, weight_decay=wd, **tail, dtype=param_dtype, initial_lr=ilr, params=ids[1]),
                dict(name="fp32", optimizer_mode=zero1, weight_decay=wd, **tail, dtype=None, initial_lr=ilr, params=[])]
         states = {
             "grad_scaler": {"_scale": float(scaler["scale"]), "_growth_step": int(scaler["growth_step"]), "_hysteresis_step": int(scaler["hysteresis_step"])},
-            "base_optim_states": {"state": {g: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
-                                            for g in (0, 1)},
+            "base_optim_states": {"state": {ids[g][0]: {"step": torch.tensor(float(adam_step), dtype=torch.float32), "exp_avg": flat(exp_avg, g), "exp_avg_sq": flat(exp_avg_sq, g)}
+                                            for g in (0, 1) if held[g]},
                                   "param_groups": pgs},
-            "flat_fp32_weights": {g: flat(master, g) for g in (0, 1)},
+            "flat_fp32_weights": {g: flat(master, g) for g in (0, 1) if held[g]},
             "zero_devide_optim_plan": plan,
         }
         torch.save(states, os.path.join(folder, f"optimizer_tp{c['t']}_wp{c['w']}_pp0_dp{c['d']}.pt"))
@@ -558,7 +566,7 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
     # storage-less tensor; the regions of different ranks are identical (replicated parameters: norms) or disjoint (cut ones)
     seen = {n: {} for n in full_shapes}
     probe = {n: torch.empty(full_shapes[n], device="meta") for n in full_shapes}
-    meta = None
+    meta = step = None
     for (t, w, d), (wld, z) in sorted(files.items()):
         st = _load(os.path.join(folder, f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt"))
         c = dict(t=t, w=w, d=d, z=z, data_world=wld // sp, zero_world=wld // wp)
@@ -568,8 +576,11 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
             mine = part[d if g == 1 else z]
             if list(st["zero_devide_optim_plan"][g][d if g == 1 else z]) != _plan_ids(fo, mine):
                 raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt: the partition plan of group {g} does not match this model / layout")
-            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][g]["exp_avg"]),
-                             ("exp_avg_sq", st["base_optim_states"]["state"][g]["exp_avg_sq"])):
+            if not mine:   # this rank holds no parameter of the group: no state, no flat weights (see save_isp_optimizer_shard)
+                continue
+            sid = st["base_optim_states"]["param_groups"][g]["params"][0]
+            for key, vec in (("master", st["flat_fp32_weights"][g]), ("exp_avg", st["base_optim_states"]["state"][sid]["exp_avg"]),
+                             ("exp_avg_sq", st["base_optim_states"]["state"][sid]["exp_avg_sq"])):
                 o = 0
                 for i in mine:
                     n, shape = fo[i]
@@ -585,14 +596,19 @@ def load_isp_optimizer(folder, model_cfg, params, want=None):
                 if o != vec.numel():
                     raise ValueError(f"optimizer_tp{t}_wp{w}_pp0_dp{d}.pt group {g}: {vec.numel()} elements, the partition holds {o}")
         gs, base = st["grad_scaler"], st["base_optim_states"]
-        here = (int(float(base["state"][0]["step"])), float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
+        some = next(iter(base["state"].values()), None)   # (a rank without any parameter carries no step: the scaler and lr only)
+        if some is not None:
+            if step not in (None, int(float(some["step"]))):
+                raise ValueError("the ISP optimizer shards disagree on the step")
+            step = int(float(some["step"]))
+        here = (float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
         if meta is not None and here != meta:
-            raise ValueError("the ISP optimizer shards disagree on step / lr / loss scale")
+            raise ValueError("the ISP optimizer shards disagree on lr / loss scale")
         meta = here
     missing = [n for n, regs in seen.items() if sum(regs.values()) != int(torch.Size(full_shapes[n]).numel())]
     if missing:
         raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:4]} ... (files of some ranks are missing)")
-    return dict(out, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world // wp,
+    return dict(out, adam_step=step, lr=meta[0], scaler=dict(scale=meta[1], growth_step=meta[2], hysteresis_step=meta[3]), zero_world=world // wp,
                 isp=dict(world=world, sp=sp, wp=wp))
 
 

@@ -727,7 +727,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, f"ckpt_ref_moe_dp{world}" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else "ckpt_ref_isp4v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, f"ckpt_ref_moe_dp{world}" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else f"ckpt_ref_isp{world}v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -767,7 +767,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         print("ckpt", step, rec["steps"][-1], flush=True)
         if step == 1:
             save_model_checkpoint("local:" + folder, model)
-            if not isp or world == 4:   # (`--ckpt-isp4`: four processes = two weight-data / data replicas -> also the OPTIMIZER shards of the ISP layout)
+            if not isp or world >= 4:   # (`--ckpt-isp4`: four processes = two weight-data / data replicas -> also the OPTIMIZER shards of the ISP layout)
                 save_optimizer_checkpoint(optimizer, "local:" + folder)
             if world == 1:
                 # the remaining files of CheckpointManager.save_checkpoint (checkpoint_manager.py:608-618), written the same way
@@ -809,12 +809,12 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             with open(os.path.join(HERE, f"ckpt_moe_dp{world}_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
-        if isp and world == 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
+        if isp and world >= 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
             rec["files"] = sorted(os.listdir(folder))
             rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.TENSOR, ParallelMode.WEIGHT, ParallelMode.DATA,
                                                                                             ParallelMode.WEIGHT_DATA, ParallelMode.ZERO1)}
             rec["rank_unique_id"] = optimizer.rank_unique_id
-            with open(os.path.join(HERE, f"ckpt_isp4v1_rank{rank}.json"), "w") as f:
+            with open(os.path.join(HERE, f"ckpt_isp{world}v1_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
         if zero1:   # every rank's record: which files exist, its rank_unique_id, its ranks in the DATA / ZERO1 groups
@@ -1544,6 +1544,12 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-isp4-rank":
         gen_checkpoint(port=29789, rank=int(sys.argv[2]), world=4, model_type="INTERNLM", isp=True)
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-isp6-rank":   # six ranks = THREE data replicas of the sp 2 x wp 2 block: the embed_head group's two parameters
+        gen_checkpoint(port=29784, rank=int(sys.argv[2]), world=6, model_type="INTERNLM", isp=True)   # go to data ranks 0 and 1, data rank 2 holds none of them
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp6":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp6-rank", str(r)]) for r in range(6)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-isp4":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-isp4-rank", str(r)]) for r in range(4)]
         sys.exit(max(p.wait() for p in procs))

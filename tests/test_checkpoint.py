@@ -1180,6 +1180,45 @@ def test_moe_two_rank_reference_checkpoint_merges_is_reproduced_and_resumes(tmp_
                 assert abs(v - gw) <= 2e-3 * gw, (k, r, g_, v, gw)                     # (measured 2.5e-4)
 
 
+def test_isp_layout_on_six_ranks_with_a_data_rank_that_holds_neither_embedding_nor_head(tmp_path):
+    """tests/golden/ckpt_ref_isp6v1/ = a real SIX-process ISP run of the reference (tensor 2 (isp) x weight 2, THREE data replicas; make_golden.py --ckpt-isp6): the
+    "embed_head" group's two parameters go to data ranks 0 and 1, data rank 2 holds none (hybrid_zero_optim.py:254-284) -- its files list the group's own
+    parameters (ids 1, 2), carry no state and no flat weights for it.  The reader merges the six ranks; writing them again reproduces the reference's files tensor for tensor."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig
+
+    gold = [json.load(open(os.path.join(G, f"ckpt_isp6v1_rank{r}.json"))) for r in range(6)]
+    c = gold[0]["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+    ref = os.path.join(G, "ckpt_ref_isp6v1")
+    for r, g_ in enumerate(gold):
+        co = C.isp_coords(r, 6, c["sp"], c["wp"])
+        rk = g_["ranks"]
+        assert (co["t"], co["w"], co["d"], co["z"]) == (rk["TENSOR"][0], rk["WEIGHT"][0], rk["DATA"][0], rk["ZERO1"][0]) and rk["WEIGHT_DATA"][0] == co["z"]
+        assert (co["data_world"], co["zero_world"]) == (rk["DATA"][1], rk["ZERO1"][1]) == (3, 3)
+        assert g_["rank_unique_id"] == f"gpus-6_wp-{co['w']}_tp-{co['t']}_dp-{co['d']}_pp-0_zo-{co['z']}.pt"
+    st2 = C._load(os.path.join(ref, "optimizer_tp1_wp1_pp0_dp2.pt"))
+    assert [g_["params"] for g_ in st2["base_optim_states"]["param_groups"]] == [[0], [1, 2], []] and sorted(st2["base_optim_states"]["state"]) == [0]
+    assert sorted(st2["flat_fp32_weights"]) == [0] and st2["zero_devide_optim_plan"][1][2] == []
+    ck = C.load_checkpoint(ref, mc)
+    assert ck["adam_step"] == 2 and ck["isp"] == dict(world=6, sp=2, wp=2) and ck["scaler"]["scale"] == gold[0]["grad_scaler"]["_scale"]
+    for n in ck["params"]:
+        assert torch.equal(ck["master"][n].to(torch.bfloat16), ck["params"][n]), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for r in range(6):
+        co = C.isp_coords(r, 6, 2, 2)
+        mine = set(C.isp_rank_names(mc, {n: tuple(t.shape) for n, t in ck["params"].items()}, r, 6, 2, 2))
+        part = lambda d: {n: (t if n in mine else torch.empty(t.shape, device="meta")) for n, t in d.items()}  # noqa: E731
+        C.save_isp_optimizer_shard(str(tmp_path), mc, r, 6, 2, 2, part(ck["master"]), part(ck["exp_avg"]), part(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"], ck["lr"], hyper)
+        if r // 2 == 0:
+            C.save_isp_model_shard(str(tmp_path), mc, ck["params"], co["t"], 2, co["w"], 2)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(ref)) == gold[0]["files"]
+    for fn in gold[0]["files"]:
+        if not fn.endswith(".json"):
+            _deep_equal(C._load(os.path.join(tmp_path, fn)), C._load(os.path.join(ref, fn)), fn)
+
+
 def test_moe_four_rank_reference_checkpoint_with_ranks_that_hold_no_gate(tmp_path):
     """tests/golden/ckpt_ref_moe_dp4/ = a real FOUR-rank run of the reference's INTERNLM_MoE model (make_golden.py --ckpt-moe-mp4): ep = 4, one expert per rank, and
     the two gate parameters of the fp32 group go to ZeRO ranks 0 and 1 -- ranks 2 and 3 hold NO parameter of that group (hybrid_zero_optim.py:254-284): their files

@@ -192,6 +192,8 @@ LAYOUTS = {
     "dp2_x_tp2_x_pp2": (8, dict(tp_size=2, pp_size=2)),    # the three axes at once on eight ranks
     "dp8_hybrid_zero4": (8, dict(zero_size=4)),
     "dp2_x_sp2_x_wp": (4, dict(sp_size=2, weight_parallel=True)),
+    "wp4": (4, dict(weight_parallel=True)),                 # four data ranks in the ISP layout: two of them hold neither the embedding's nor the head's optimizer state
+    "dp4_x_sp2": (8, dict(sp_size=2)),
 }
 
 
