@@ -53,8 +53,8 @@ def state_dict_order(model_cfg, tp_rank=0):
         names = ["embedding.weight"]
         for l in range(model_cfg.num_layers):
             p = f"blocks.{l}."
-            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight", p + "mixer.out_proj.bias", p + "norm1.weight", p + "norm2.weight",
-                      p + "mlp.moe_layer.gate.wg.weight"]
+            names += [p + "mixer.Wqkv.weight", p + "mixer.Wqkv.bias", p + "mixer.out_proj.weight"] + ([p + "mixer.out_proj.bias"] if tp_rank == 0 else [])
+            names += [p + "norm1.weight", p + "norm2.weight", p + "mlp.moe_layer.gate.wg.weight"]
             for e in range(model_cfg.num_experts):
                 names += [p + f"mlp.moe_layer.experts.wrapped_experts.{e}.w{k}.weight" for k in (1, 2, 3)]
         return names + ["norm.weight", "head.weight"]
@@ -143,6 +143,8 @@ def tp_split_dim(name):
         return 0
     if name.endswith(("attention.wo.weight", "feed_forward.w2.weight", "mixer.out_proj.weight", "mlp.w2.weight")):
         return 1
+    if ".experts.wrapped_experts." in name:   # every expert of the MoE model is a FeedForward over the tensor group (gshard_layer.py:421-433; tests/golden/ckpt_ref_moe_tp2dp2/)
+        return 1 if name.endswith(".w2.weight") else 0
     return None
 
 
@@ -791,11 +793,11 @@ def load_checkpoint(folder, model_cfg, want=None, model_only=False):
 #   optimizer_tp0_pp0_zo0.pt                       base_optim_states.state {0, 1, 2}, param_groups [default, fp32 (the gates), moe_ep_size_{ep} (the experts,
 #                                                  optimizer_mode EXPERT_DATA)], flat_fp32_weights {0, 1, 2}, the plan with one list per group
 # Covered: any number of data-parallel ranks (the reference's automatic expert parallelism, ep = min(dp, experts); pinned on tests/golden/ckpt_ref_moe_dp2/ too).
-def moe_groups(model_cfg, ep_world=1, ep_rank=0):
+def moe_groups(model_cfg, ep_world=1, ep_rank=0, tp_rank=0):
     """[(group name, parameter names in module order)] of the three optimizer groups ON ONE RANK of an expert-parallel group of ep_world ranks: the dense
     parameters and the gates whole, the experts this rank holds (global numbers ep_rank * E / ep ... -- the reference's automatic expert parallelism,
     parallel_context.py:538-541)."""
-    order = state_dict_order(model_cfg)
+    order = state_dict_order(model_cfg, tp_rank)
     gates = [n for n in order if n.endswith("gate.wg.weight")]
     El = max(model_cfg.num_experts, 1) // ep_world
     mine = range(ep_rank * El, (ep_rank + 1) * El)
@@ -804,46 +806,50 @@ def moe_groups(model_cfg, ep_world=1, ep_rank=0):
     return [("default", dense), ("fp32", gates), (f"moe_ep_size_{ep_world}", experts)]
 
 
-def _expert_file(name):
+def _expert_file(name, tp_rank=0):
     parts = name.split(".")   # blocks.{l}.mlp.moe_layer.experts.wrapped_experts.{e}.w1.weight
-    return f"model_moe_layer{parts[1]}_expert{parts[6]}_tp0.pt"
+    return f"model_moe_layer{parts[1]}_expert{parts[6]}_tp{tp_rank}.pt"
 
 
-def _moe_layout(model_cfg, shapes, world, rank):
+def _moe_layout(model_cfg, shapes, world, rank, tp_rank=0):
     """Per optimizer group on data-parallel rank `rank` of `world`: (flat order of (name, shape), partition over the group's zero world, this rank's position in
     it).  default / fp32: ZeRO over the data-parallel group; the expert group: over the EXPERT_DATA group (the ranks holding the same experts: rank // ep)."""
     ep = min(world, max(model_cfg.num_experts, 1))
     if world % ep or max(model_cfg.num_experts, 1) % ep:
         raise NotImplementedError(f"{world} data-parallel ranks with {model_cfg.num_experts} experts")
     out = []
-    for g, (_, names) in enumerate(moe_groups(model_cfg, ep, rank % ep)):
+    for g, (_, names) in enumerate(moe_groups(model_cfg, ep, rank % ep, tp_rank)):
         fo = zero_flat_order([(n, tuple(shapes[n])) for n in names])
         zw, zr = (world // ep, rank // ep) if g == 2 else (world, rank)
         out.append((fo, zero_partition(fo, zw), zr))
     return out, ep
 
 
-def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16, world=1, rank=0):
+def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, adam_step, scaler, lr, hyper, param_dtype=torch.bfloat16, world=1, rank=0,
+                        tp_world=1, tp_rank=0):
     """params: name -> host tensor (gates fp32, the rest in the model dtype); master / exp_avg / exp_avg_sq: name -> fp32 host tensor; the rest as
     save_checkpoint.  world > 1 (round 4): what data-parallel rank `rank` of `world` writes in a reference job with its automatic expert parallelism
     (ep = min(world, experts); pinned by tests/golden/ckpt_ref_moe_dp2/): its optimizer shard -- the dense parameters' and the gates' partition `rank` of the
     data-parallel group, and its partition of ITS experts over the expert-data group --, its plan file, one model file per expert it holds (under the
-    expert's GLOBAL number; expert-data rank 0 only), and from rank 0 the model file without the experts.  The dicts need this rank's experts only."""
+    expert's GLOBAL number; expert-data rank 0 only), and from rank 0 the model file without the experts.  The dicts need this rank's experts only.
+    tp_world > 1 (Megatron tensor parallelism; pinned by tests/golden/ckpt_ref_moe_tp2dp2/): `world` / `rank` are the DATA-parallel size and rank, the tensors tensor
+    rank tp_rank's LOCAL parts as the reference's modules hold them (tp_shard: embedding columns, head rows, the heads' Wqkv rows, out_proj / w2 columns, w1 / w3
+    rows -- the experts' too; out_proj's bias on tensor rank 0 only); every file carries the tensor rank in its name, the partitions are computed from the local shapes."""
     os.makedirs(folder, exist_ok=True)
-    shapes = {n: tuple(params[n].shape) for n in state_dict_order(model_cfg) if n in params}
-    layout, ep = _moe_layout(model_cfg, shapes, world, rank)
-    groups = moe_groups(model_cfg, ep, rank % ep)
-    if rank == 0:
+    shapes = {n: tuple(params[n].shape) for n in state_dict_order(model_cfg, tp_rank) if n in params}
+    layout, ep = _moe_layout(model_cfg, shapes, world, rank, tp_rank)
+    groups = moe_groups(model_cfg, ep, rank % ep, tp_rank)
+    if rank == 0:   # (the reference: tensor rank t's file from data rank t % dp, components.py:256-262 -- the same content on every data rank)
         sd = collections.OrderedDict()
-        for n in state_dict_order(model_cfg):
+        for n in state_dict_order(model_cfg, tp_rank):
             if ".experts." not in n:
                 sd["model." + n] = params[n].detach().to("cpu", torch.float32 if n.endswith("gate.wg.weight") else param_dtype).contiguous()
-        torch.save(sd, os.path.join(folder, "model_tp0_pp0.pt"))
-        torch.save({}, os.path.join(folder, "topo_tp0_pp0.json"))
-    if rank // ep == 0:   # (tp_rank, expert_dp_rank) = (0, 0): components.py:270-277
+        torch.save(sd, os.path.join(folder, f"model_tp{tp_rank}_pp0.pt"))
+        torch.save({}, os.path.join(folder, f"topo_tp{tp_rank}_pp0.json"))
+    if rank // ep == 0:   # expert-data rank 0 (the reference: (tp_rank, expert_dp_rank) = (t, t % edp), components.py:270-277 -- the same content again)
         per_expert = collections.OrderedDict()
         for n in groups[2][1]:
-            per_expert.setdefault(_expert_file(n), collections.OrderedDict())["model." + n] = params[n].detach().to("cpu", param_dtype).contiguous()
+            per_expert.setdefault(_expert_file(n, tp_rank), collections.OrderedDict())["model." + n] = params[n].detach().to("cpu", param_dtype).contiguous()
         for fn, esd in per_expert.items():
             torch.save(esd, os.path.join(folder, fn))
     plan = [[_plan_ids(fo, idx) for idx in part] for fo, part, _ in layout]
@@ -881,35 +887,35 @@ def save_moe_checkpoint(folder, model_cfg, params, master, exp_avg, exp_avg_sq, 
             "flat_fp32_weights": {g: flat(master, g) for g in range(3) if held[g]},
             "zero_devide_optim_plan": plan,
         }
-        torch.save(states, os.path.join(folder, f"optimizer_tp0_pp0_zo{rank}.pt"))
-        torch.save(plan, os.path.join(folder, f"gpus-{world}_wp-0_tp-0_dp-{rank}_pp-0_zo-{rank}.pt"))
+        torch.save(states, os.path.join(folder, f"optimizer_tp{tp_rank}_pp0_zo{rank}.pt"))
+        torch.save(plan, os.path.join(folder, f"gpus-{world * tp_world}_wp-0_tp-{tp_rank}_dp-{rank}_pp-0_zo-{rank}.pt"))
 
 
-def load_moe_checkpoint(folder, model_cfg):
-    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, ALL experts under their global numbers), adam_step, scaler, lr, zero_world) of an
-    INTERNLM_MoE checkpoint (the reference's or save_moe_checkpoint's) written by ANY number of data-parallel ranks: every rank's optimizer shard is read
-    and merged; optimizer entries None when the folder holds weights only."""
-    order = state_dict_order(model_cfg)
-    sd = dict(torch.load(os.path.join(folder, "model_tp0_pp0.pt"), map_location="cpu", weights_only=False))
+def _load_moe_tp_rank(folder, model_cfg, t):
+    """One tensor rank's files of an INTERNLM_MoE checkpoint -> dict(params, master, exp_avg, exp_avg_sq (name -> LOCAL host tensor, all experts under their global
+    numbers; optimizer entries None when the folder holds weights only), adam_step, scaler, lr, zero_world): every data-parallel rank's optimizer shard read and merged."""
+    order = state_dict_order(model_cfg, t)
+    sd = dict(torch.load(os.path.join(folder, f"model_tp{t}_pp0.pt"), map_location="cpu", weights_only=False))
     for n in order:
         if ".experts." in n and "model." + n not in sd:
-            sd.update(torch.load(os.path.join(folder, _expert_file(n)), map_location="cpu", weights_only=False))
+            sd.update(torch.load(os.path.join(folder, _expert_file(n, t)), map_location="cpu", weights_only=False))
     params = {n: sd["model." + n].detach() for n in order}
     out = dict(params=params, master=None, exp_avg=None, exp_avg_sq=None, adam_step=None, scaler=None, lr=None, zero_world=0)
-    world = saved_zero_world(folder)
+    world = saved_zero_world(folder, t)
     if world == 0:
         return out
     shapes = {n: tuple(params[n].shape) for n in order}
     merged = dict(master={}, exp_avg={}, exp_avg_sq={})
     meta = None
     for r in range(world):
-        st = _load(os.path.join(folder, f"optimizer_tp0_pp0_zo{r}.pt"))
-        layout, ep = _moe_layout(model_cfg, shapes, world, r)
+        fn = f"optimizer_tp{t}_pp0_zo{r}.pt"
+        st = _load(os.path.join(folder, fn))
+        layout, ep = _moe_layout(model_cfg, shapes, world, r, t)
         if st["base_optim_states"]["param_groups"][2]["name"] != f"moe_ep_size_{ep}":
-            raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt: expert group {st['base_optim_states']['param_groups'][2]['name']!r}, this model on {world} ranks has moe_ep_size_{ep}")
+            raise ValueError(f"{fn}: expert group {st['base_optim_states']['param_groups'][2]['name']!r}, this model on {world} data-parallel ranks has moe_ep_size_{ep}")
         for g, (fo, part, zr) in enumerate(layout):
             if list(st["zero_devide_optim_plan"][g][zr]) != _plan_ids(fo, part[zr]):
-                raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt: zero_devide_optim_plan of group {g} does not match this model")
+                raise ValueError(f"{fn}: zero_devide_optim_plan of group {g} does not match this model")
             if not part[zr]:   # this rank holds no parameter of the group: no state, no flat weights, the group lists its own parameters (see save_moe_checkpoint)
                 continue
             sid = st["base_optim_states"]["param_groups"][g]["params"][0]
@@ -924,7 +930,7 @@ def load_moe_checkpoint(folder, model_cfg):
                     merged[key][n] = vec.detach()[o : o + k].reshape(shape).to(torch.float32)
                     o += k
                 if o != vec.numel():
-                    raise ValueError(f"optimizer_tp0_pp0_zo{r}.pt group {g}: the flat vector holds {vec.numel()} elements, this rank's partition {o}")
+                    raise ValueError(f"{fn} group {g}: the flat vector holds {vec.numel()} elements, this rank's partition {o}")
         gs, base = st["grad_scaler"], st["base_optim_states"]
         here = (int(float(base["state"][0]["step"])), float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
         if meta is not None and here != meta:
@@ -934,6 +940,28 @@ def load_moe_checkpoint(folder, model_cfg):
     if missing:
         raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:3]} ...")
     out.update(merged, adam_step=meta[0], lr=meta[1], scaler=dict(scale=meta[2], growth_step=meta[3], hysteresis_step=meta[4]), zero_world=world)
+    return out
+
+
+def load_moe_checkpoint(folder, model_cfg):
+    """-> dict(params, master, exp_avg, exp_avg_sq (name -> host tensor, FULL tensors, ALL experts under their global numbers), adam_step, scaler, lr, zero_world,
+    tp_world) of an INTERNLM_MoE checkpoint (the reference's or save_moe_checkpoint's) written by ANY number of data-parallel ranks and ANY tensor-parallel size:
+    every rank's optimizer shard is read and merged, the tensor ranks' parts put together (tp_unshard); optimizer entries None when the folder holds weights only."""
+    tp_world = saved_tp_world(folder)
+    if tp_world == 0:
+        raise FileNotFoundError(f"{folder}: no model_tp*_pp0.pt")
+    ranks = [_load_moe_tp_rank(folder, model_cfg, t) for t in range(tp_world)]
+    out = dict(ranks[0], tp_world=tp_world)
+    if tp_world == 1:
+        return out
+    same = ("adam_step", "lr", "scaler", "zero_world")
+    for t, r in enumerate(ranks[1:], 1):
+        if {k: r[k] for k in same} != {k: out[k] for k in same}:
+            raise ValueError(f"tensor rank {t} disagrees with rank 0 on the step / scaler / lr / ZeRO world")
+    hd = model_cfg.head_dim
+    for key in ("params", "master", "exp_avg", "exp_avg_sq"):
+        if out[key] is not None:
+            out[key] = {n: tp_unshard(n, [r[key][n] for r in ranks if n in r[key]], hd).contiguous() for n in ranks[0][key]}
     return out
 
 

@@ -21,8 +21,8 @@ vocabulary rows with the vocabulary-parallel loss of the dense engine; embedding
 and micro-batch (out_proj / expert outputs forward, Wqkv / w1|w3 input gradients backward), data and expert parallelism over the ranks that hold the
 same shard (expert groups = consecutive entries of a data-parallel group, process_group_initializer.py:493-524), group norms summed over the tensor
 group with the replicated parameters counted once (solver/optimizer/utils.py:225-262,330-352).  Pinned on a 2-process run of the reference
-(tests/golden/train_moe_tp2_bf16_rank*.json).  Sequence-sharded modes (msp / fsp), sequence and pipeline parallelism, and checkpoints under tensor
-parallelism are refused.
+(tests/golden/train_moe_tp2_bf16_rank*.json).  Sequence-sharded modes (msp / fsp), sequence and pipeline parallelism are refused.  Checkpoints under tensor
+parallelism: every tensor rank its own model / expert / optimizer files (pinned on tests/golden/ckpt_ref_moe_tp2dp2/).
 Weights: Wqkv is kept in the [head][q, k, v][d] row order of the shared rotary / attention kernels and converted at the naming boundary
 (`named_parameters` / `load_named_parameters`), exactly like LLAMA2's wq / wk / wv in the dense engine.
 """
@@ -601,8 +601,22 @@ class MoEEngine:
     # ---- checkpoints (the dense model): InternEvo's files, internevo_amd/checkpoint.py -------------------------------------------------------
     def _checkpoint_guard(self):
         # (any data-parallel size since round 4: checkpoint.save_moe_checkpoint / load_moe_checkpoint)
-        if self.tp > 1:
-            raise NotImplementedError("MoEEngine: checkpoints under tensor parallelism (the tensor-rank files of the MoE model) are not written / read")
+        if self.tp > 1 and self.dense:
+            raise NotImplementedError("MoEEngine: checkpoints of the dense InternLM-1 model under tensor parallelism go through InternLM2Engine (model_type INTERNLM)")
+
+    def _reference_local(self, named):
+        """named_parameters() output -> what tensor rank tp_rank of the reference holds: this engine keeps the embedding whole on every tensor rank (the reference
+        cuts its hidden columns) and out_proj's bias on every rank (the reference: tensor rank 0 only, ops/linear.py:317-324)."""
+        if self.tp == 1:
+            return dict(named)
+        out = {}
+        for n, t in named:
+            if n == "embedding.weight":
+                t = self._cut(t, 1)
+            elif n.endswith("mixer.out_proj.bias") and self.tp_rank:
+                continue
+            out[n] = t
+        return out
 
     def save_checkpoint(self, folder):
         """model_tp0_pp0.pt + the hybrid-ZeRO optimizer shards in the reference's whole-parameter partition (hybrid_zero_optim.py:254-284): this
@@ -618,15 +632,18 @@ class MoEEngine:
         if not self.dense:   # the MoE model: the model file without the experts, one file per expert, three optimizer groups (checkpoint.save_moe_checkpoint)
             hyper = dict(weight_decay=tc.weight_decay, betas=(tc.adam_beta1, tc.adam_beta2), eps=tc.adam_eps, initial_lr=tc.lr)
             scaler = dict(scale=st.loss_scale, growth_step=st.growth_step, hysteresis_step=st.hysteresis_step)
-            cpu = lambda views, gates: {n: t.detach().to("cpu", copy=True) for n, t in self.named_parameters(views, gates)}  # noqa: E731
+            cpu = lambda views, gates: {n: t.detach().to("cpu", copy=True) for n, t in self._reference_local(self.named_parameters(views, gates)).items()}  # noqa: E731
             # every data-parallel rank writes what the reference's rank would (this engine keeps the optimizer state of the dense parameters and the gates on
-            # every rank, and of its own experts: rank r cuts the reference's partition r out of it); collective
+            # every rank, and of its own experts: data rank d cuts the reference's partition d out of it), under tensor parallelism every tensor rank its own files
+            # (round 5; pinned on tests/golden/ckpt_ref_moe_tp2dp2/); collective
+            dpw, dpr = self.dp_world, self.tpar.dp_rank
             if r == 0:
-                C.remove_stale_shards(folder, W, 1, layout="moe", num_experts=self.mc.num_experts, num_layers=self.mc.num_layers)
+                C.remove_stale_shards(folder, dpw, self.tp, layout="moe", num_experts=self.mc.num_experts, num_layers=self.mc.num_layers)
             if W > 1:
                 dist.barrier(group=self.group)
             C.save_moe_checkpoint(folder, self.mc, cpu(None, None), cpu(self._views(self.master), self.wg), cpu(self._views(self.exp_avg), self.wg_m),
-                                  cpu(self._views(self.exp_avg_sq), self.wg_v), st.adam_step, scaler, self.lr_sched.lr(), hyper, world=W, rank=r)
+                                  cpu(self._views(self.exp_avg_sq), self.wg_v), st.adam_step, scaler, self.lr_sched.lr(), hyper, world=dpw, rank=dpr,
+                                  tp_world=self.tp, tp_rank=self.tp_rank)
             if W > 1:
                 dist.barrier(group=self.group)
             return

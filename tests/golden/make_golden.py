@@ -631,7 +631,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
 
             def gumbel(shape, device):   # (every data-parallel rank gates its own tokens: rank r draws seed 5000 + 1000 r + k, as the training fixtures do)
                 calls["n"] += 1
-                return MO.gumbel_noise(tuple(shape), 5000 + 1000 * rank + calls["n"] - 1).to(device)
+                return MO.gumbel_noise(tuple(shape), 5000 + 1000 * (rank // tp) + calls["n"] - 1).to(device)   # (the ranks of a tensor group gate the same tokens with the same noise)
 
             gl.gumbel_rsample = gumbel
     if pp > 1:
@@ -641,7 +641,9 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
     if isp:
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=2, sp=2, wp=2, seq_len=128)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
-        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=4 if pp > 1 else 2 if model_type == "INTERNLM" else 1, tp=tp)   # (`--ckpt-pptp`: tensor 2 x pipeline 2 on four processes -> ckpt_ref_pp2tp2/)
+        kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=4 if pp > 1 else 2 if model_type in ("INTERNLM", "INTERNLM_MoE") else 1, tp=tp)   # (`--ckpt-pptp`: tensor 2 x pipeline 2 on four processes -> ckpt_ref_pp2tp2/)
+        if model_type == "INTERNLM_MoE":   # (file-format fixtures, read and written on the host only: the smallest shapes the model takes)
+            kw = dict(kw, hidden=64)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
     if zero1:   # `--ckpt-hz`: hybrid ZeRO (parallel.zero1.size < the data-parallel size): four data ranks, optimizer state sharded over groups of two -> ckpt_ref_dp4_zo2/
@@ -658,7 +660,12 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
             from internevo_amd.config import ModelConfig
             from oracle.model import param_shapes
 
-            if model_type == "INTERNLM":   # `--ckpt-v1tp`
+            if model_type == "INTERNLM_MoE":   # `--ckpt-moe-tp`: every expert a FeedForward over the tensor group
+                from oracle.moe_model import param_shapes as moe_shapes
+
+                full_shapes = moe_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
+                                                     num_kv_attention_heads=kw["heads"], mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=kw["num_experts"]))
+            elif model_type == "INTERNLM":   # `--ckpt-v1tp`
                 from oracle.moe_model import param_shapes as v1_shapes
 
                 full_shapes = v1_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
@@ -689,7 +696,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
 
             full_shapes = v1_shapes(ModelConfig(vocab_size=kw["vocab"], hidden_size=kw["hidden"], num_layers=kw["layers"], num_attention_heads=kw["heads"],
                                                 num_kv_attention_heads=kw["heads"], mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1))
-        moe_mp = world > 1 and model_type == "INTERNLM_MoE"
+        moe_mp = world > 1 and model_type == "INTERNLM_MoE" and tp == 1
         for name, p in (model.model.named_parameters() if pp == 1 else ()):
             if moe_mp:   # automatic expert parallelism (ep = min(dp, experts)): wrapped_experts.{j} on a rank = GLOBAL expert ep_rank * (E / ep) + j
                 import re
@@ -709,7 +716,15 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
 
                     part = tp_shard(name, formula_init(name, full_shapes[name]), tp_rank, tp)
                 else:
-                    part = (_mtp_part_v1(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw["hidden"] // kw["heads"]) if model_type == "INTERNLM"
+                    gname = name
+                    if model_type == "INTERNLM_MoE":   # (expert parallelism inside the data-parallel group: local -> GLOBAL expert number)
+                        import re
+
+                        m_ = re.search(r"wrapped_experts\.(\d+)\.", name)
+                        if m_:
+                            El = kw["num_experts"] // gpc.get_world_size(ParallelMode.EXPERT)
+                            gname = name[: m_.start(1)] + str(gpc.get_local_rank(ParallelMode.EXPERT) * El + int(m_.group(1))) + name[m_.end(1):]
+                    part = (_mtp_part_v1(gname, formula_init(gname, full_shapes[gname]), tp_rank, tp, kw["hidden"] // kw["heads"]) if model_type in ("INTERNLM", "INTERNLM_MoE")
                             else _mtp_part(name, formula_init(name, full_shapes[name]), tp_rank, tp, kw))
                 assert tuple(part.shape) == tuple(p.shape), (name, tuple(part.shape), tuple(p.shape))
                 p.copy_(part.to(p.dtype))
@@ -727,7 +742,7 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
                                                           scheduler_hooks=get_scheduler_hooks(metric, optimizer, isp))
     trainer.train()
     train_iter = iter(train_dl)
-    folder = os.path.join(HERE, f"ckpt_ref_moe_dp{world}" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else f"ckpt_ref_isp{world}v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
+    folder = os.path.join(HERE, (f"ckpt_ref_moe_tp{tp}" + (f"dp{world // tp}" if world > tp else "")) if (tp > 1 and model_type == "INTERNLM_MoE") else f"ckpt_ref_moe_dp{world}" if (world > 1 and model_type == "INTERNLM_MoE") else ("ckpt_ref_isp2v1" if world == 2 else f"ckpt_ref_isp{world}v1") if isp else (f"ckpt_ref_pp{pp}tp{tp}" if tp > 1 else f"ckpt_ref_pp{pp}i" if chunks > 1 else f"ckpt_ref_pp{pp}v1" if model_type == "INTERNLM" else f"ckpt_ref_pp{pp}") if pp > 1 else "ckpt_ref_moe" if model_type == "INTERNLM_MoE" else ("ckpt_ref_v1tp2" if tp > 1 else "ckpt_ref_v1") if model_type == "INTERNLM" else "ckpt_ref_llama_tp2" if model_type == "LLAMA2" else "ckpt_ref" if world == 1 else f"ckpt_ref_dp{world}_zo{zero1}" if zero1 else f"ckpt_ref_tp{tp}" if tp > 1 else f"ckpt_ref_dp{world}")
     if rank == 0:
         shutil.rmtree(folder, ignore_errors=True)
         os.makedirs(folder)
@@ -804,9 +819,11 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         dist.barrier()
         if world > 1 and model_type == "INTERNLM_MoE":   # `--ckpt-moe-mp`: every rank's record (each holds two of the four experts)
             rec["files"] = sorted(os.listdir(folder))
-            rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.DATA, ParallelMode.ZERO1, ParallelMode.EXPERT, ParallelMode.EXPERT_DATA)}
+            rec["ranks"] = {m.name: [gpc.get_local_rank(m), gpc.get_world_size(m)] for m in (ParallelMode.DATA, ParallelMode.ZERO1, ParallelMode.EXPERT, ParallelMode.EXPERT_DATA,
+                                                                                            ParallelMode.TENSOR)}
             rec["rank_unique_id"] = optimizer.rank_unique_id
-            with open(os.path.join(HERE, f"ckpt_moe_dp{world}_rank{rank}.json"), "w") as f:
+            tag_ = (f"tp{tp}" + (f"dp{world // tp}" if world > tp else "")) if tp > 1 else f"dp{world}"
+            with open(os.path.join(HERE, f"ckpt_moe_{tag_}_rank{rank}.json"), "w") as f:
                 json.dump(rec, f, indent=1, default=str)
             return
         if isp and world >= 4:   # every rank's view of its optimizer state (three groups, each with its own zero world)
@@ -1562,6 +1579,18 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe4-rank":   # four ranks, two gate parameters: two ranks hold NO parameter of the fp32 group (hybrid_zero_optim.py:254-284)
         gen_checkpoint(port=29786, rank=int(sys.argv[2]), world=4, model_type="INTERNLM_MoE")
         sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe-tp-rank":   # the MoE model on two TENSOR ranks: every expert a FeedForward cut over them (gshard_layer.py:421-433)
+        gen_checkpoint(port=29782, rank=int(sys.argv[2]), world=2, tp=2, model_type="INTERNLM_MoE")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-tp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe-tp-rank", str(r)]) for r in range(2)]
+        sys.exit(max(p.wait() for p in procs))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--ckpt-moe-tpdp-rank":   # ... and data parallel 2 x tensor 2 on four ranks: expert groups inside the data-parallel groups
+        gen_checkpoint(port=29780, rank=int(sys.argv[2]), world=4, tp=2, model_type="INTERNLM_MoE")
+        sys.exit(0)
+    if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-tpdp":
+        procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe-tpdp-rank", str(r)]) for r in range(4)]
+        sys.exit(max(p.wait() for p in procs))
     if len(sys.argv) >= 2 and sys.argv[1] == "--ckpt-moe-mp4":
         procs = [subprocess.Popen([sys.executable, __file__, "--ckpt-moe4-rank", str(r)]) for r in range(4)]
         sys.exit(max(p.wait() for p in procs))

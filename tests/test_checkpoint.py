@@ -1252,6 +1252,45 @@ def test_moe_four_rank_reference_checkpoint_with_ranks_that_hold_no_gate(tmp_pat
             _deep_equal(ld(os.path.join(tmp_path, fn)), ld(os.path.join(ref, fn)), fn)
 
 
+def test_moe_tensor_parallel_reference_checkpoint_merges_and_is_reproduced(tmp_path):
+    """tests/golden/ckpt_ref_moe_tp2dp2/ = a real FOUR-rank run of the reference's INTERNLM_MoE model under data parallel 2 x Megatron tensor parallel 2
+    (make_golden.py --ckpt-moe-tpdp): every expert a FeedForward over the tensor group (gshard_layer.py:421-433), expert parallelism 2 inside the data-parallel groups.
+    Per tensor rank t: `model_tp{t}_pp0.pt` (its local parts; out_proj's bias on tensor rank 0 only), one `model_moe_layer{l}_expert{e}_tp{t}.pt` per expert, and per data rank
+    d `optimizer_tp{t}_pp0_zo{d}.pt` + plan with the three groups partitioned from the LOCAL shapes.  The reader merges the four ranks into FULL tensors (the master weights
+    round to the model bit for bit); cutting them again and writing every rank's files reproduces the reference's twenty-eight files tensor for tensor."""
+    from internevo_amd import checkpoint as C
+    from internevo_amd.config import ModelConfig
+    from oracle.moe_model import param_shapes as moe_shapes
+
+    gold = [json.load(open(os.path.join(G, f"ckpt_moe_tp2dp2_rank{r}.json"))) for r in range(4)]
+    c = gold[0]["config"]
+    mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                     mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
+    ref = os.path.join(G, "ckpt_ref_moe_tp2dp2")
+    for r, g_ in enumerate(gold):   # ranks: tensor groups are consecutive ranks, the expert groups live inside the data-parallel groups {t, t + 2}
+        rk = g_["ranks"]
+        assert (rk["TENSOR"], rk["DATA"], rk["EXPERT"], rk["EXPERT_DATA"]) == ([r % 2, 2], [r // 2, 2], [r // 2, 2], [0, 1])
+        assert g_["rank_unique_id"] == f"gpus-4_wp-0_tp-{r % 2}_dp-{r // 2}_pp-0_zo-{r // 2}.pt"
+    ck = C.load_moe_checkpoint(ref, mc)
+    assert (ck["adam_step"], ck["zero_world"], ck["tp_world"]) == (2, 2, 2)
+    full_shapes = moe_shapes(mc)
+    assert {n: tuple(t.shape) for n, t in ck["params"].items()} == {n: tuple(s_) for n, s_ in full_shapes.items()}
+    for n in ck["params"]:
+        assert torch.equal(ck["master"][n].to(ck["params"][n].dtype), ck["params"][n]), n
+    hyper = dict(weight_decay=0.01, betas=(0.9, 0.95), eps=1e-8, initial_lr=1e-3)
+    for t in range(2):
+        for d in range(2):   # (a rank passes what it holds: its parts of everything dense and of its own two experts)
+            mine = {n for _, names in C.moe_groups(mc, 2, d, t) for n in names}
+            part = lambda dd: {n: C.tp_shard(n, x, t, 2, mc.head_dim).contiguous() for n, x in dd.items() if n in mine}  # noqa: E731
+            C.save_moe_checkpoint(str(tmp_path), mc, part(ck["params"]), part(ck["master"]), part(ck["exp_avg"]), part(ck["exp_avg_sq"]), ck["adam_step"], ck["scaler"],
+                                  ck["lr"], hyper, world=2, rank=d, tp_world=2, tp_rank=t)
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(ref)) == gold[0]["files"] and len(gold[0]["files"]) == 28
+    for fn in gold[0]["files"]:
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(tmp_path, fn)), ld(os.path.join(ref, fn)), fn)
+
+
 def test_stale_files_of_another_layout_are_removed_before_a_save(tmp_path):
     """A folder that held an ISP-layout save (or the expert files of a MoE save) and is written again in the plain layout must not keep the old files: load_checkpoint
     takes the ISP branch as soon as ANY model_tp*_wp* file is present and would load the stale weights (and the other way round)."""

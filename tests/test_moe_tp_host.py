@@ -24,7 +24,7 @@ class _Stub:
     wait_event = record = synchronize = wait_stream
 
 
-def _worker(rank, world, port, q, tp=2, ckpt=None):
+def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -64,7 +64,7 @@ def _worker(rank, world, port, q, tp=2, ckpt=None):
         batch, labels = next(loader)
         eng.forward_backward(batch, labels)
         eng.step()
-        if tp == 1 and ckpt:   # the checkpoint round trip of the expert-parallel layout: model file without experts, one file per expert, the optimizer partitions of every rank
+        if ckpt:   # the checkpoint round trip of the layout: model file(s) without experts, one file per expert (and tensor rank), the optimizer partitions of every rank
             import internevo_amd.checkpoint as C
 
             def fill(flat, gates, j):   # a value per (buffer, position): the replicated parameters agree between the ranks; a rank's own experts carry its expert rank
@@ -72,6 +72,8 @@ def _worker(rank, world, port, q, tp=2, ckpt=None):
                 for n, v in eng._views(flat).items():
                     if n.endswith(("mlp.w13", "mlp.w2")):
                         v += 0.25 * (eng.ep_rank + 1)
+                    if n.endswith(("mlp.w13", "mlp.w2", "mixer.out_proj.weight", "head.weight")) or "mixer.Wqkv" in n:   # the tensors cut over the tensor group
+                        v += 0.125 * eng.tp_rank
                 if gates is not None:
                     gates.copy_((torch.arange(gates.numel()) % 83).float().view_as(gates) / 128 + j)
 
@@ -91,6 +93,21 @@ def _worker(rank, world, port, q, tp=2, ckpt=None):
                 experts = {n for n in ck["params"] if ".experts." in n}
                 assert len(experts) == mc.num_layers * mc.num_experts * 3, sorted(experts)
                 assert set(ck["master"]) == set(ck["params"]) == set(ck["exp_avg"]) == set(ck["exp_avg_sq"])
+        for i, tp_next in enumerate(chain or ()):   # the files as the exchange format between layouts: every next layout resumes from the previous folder and saves its own;
+            import internevo_amd.checkpoint as C   # whatever layout wrote a folder, the merged FULL tensors must be the first folder's
+
+            nxt = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=tp_next)
+            nxt.load_checkpoint(ckpt if i == 0 else f"{ckpt}_hop{i - 1}")
+            nxt.save_checkpoint(f"{ckpt}_hop{i}")
+            dist.barrier()
+            if rank == 0:
+                a, b = C.load_moe_checkpoint(ckpt, mc), C.load_moe_checkpoint(f"{ckpt}_hop{i}", mc)
+                assert b["tp_world"] == tp_next and (a["adam_step"], a["scaler"]) == (b["adam_step"], b["scaler"])
+                for key in ("params", "master", "exp_avg", "exp_avg_sq"):
+                    assert set(a[key]) == set(b[key])
+                    for n in a[key]:
+                        assert torch.equal(a[key][n].float(), b[key][n].float()), f"hop {i} (tp {tp_next}): {key}[{n}] is not what the first layout saved"
+            dist.barrier()
         q.put((rank, {n: tuple(p.shape) for n, p in eng.named_parameters()}, (eng.tp, eng.tp_rank, eng.dp_world, eng.ep, eng.H, eng.F, eng.Vl)))
     except Exception:
         import traceback
@@ -103,12 +120,12 @@ def _worker(rank, world, port, q, tp=2, ckpt=None):
         dist.destroy_process_group()
 
 
-def _run(world, port, tp=2, ckpt=None):
+def _run(world, port, tp=2, ckpt=None, chain=None):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt, chain)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -122,9 +139,9 @@ def _run(world, port, tp=2, ckpt=None):
 
 
 @pytest.mark.timeout(300)
-def test_moe_engine_tensor_2_x_expert_parallel_2_host_logic_on_four_gloo_ranks():
+def test_moe_engine_tensor_2_x_expert_parallel_2_host_logic_on_four_gloo_ranks(tmp_path):
     """data parallel 2 x tensor 2: expert groups inside the data-parallel groups [0, 2] / [1, 3] (process_group_initializer.py:493-524)."""
-    res = _run(4, 29933)
+    res = _run(4, 29933, ckpt=str(tmp_path / "tp2ep2"), chain=(1, 2, 1))   # ... then ep 4, tp 2 x ep 2 again, ep 4 again, each from the previous one's files
     #                      tp, tp_rank, dp_world, ep, heads, FFN units, vocabulary rows
     assert [res[r][1] for r in range(4)] == [(2, 0, 2, 2, 2, 256, 256), (2, 1, 2, 2, 2, 256, 256), (2, 0, 2, 2, 2, 256, 256), (2, 1, 2, 2, 2, 256, 256)]
     assert res[0][0] == res[1][0] and res[2][0] == res[3][0] and len(res[0][0]) == 41 - 2 * 2 * 3   # two of the four experts of each layer
@@ -133,8 +150,8 @@ def test_moe_engine_tensor_2_x_expert_parallel_2_host_logic_on_four_gloo_ranks()
 
 
 @pytest.mark.timeout(300)
-def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks():
-    res = _run(2, 29931)
+def test_moe_engine_tensor_parallel_host_logic_on_two_gloo_ranks(tmp_path):
+    res = _run(2, 29931, ckpt=str(tmp_path / "tp2"))
     assert res[0][1] == (2, 0, 1, 1, 2, 256, 256) and res[1][1] == (2, 1, 1, 1, 2, 256, 256)
     s0, s1 = res[0][0], res[1][0]
     assert s0 == s1 and len(s0) == 41

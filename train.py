@@ -109,7 +109,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
     """The hot loop for model_type INTERNLM_MoE (configs/7B_MoE4_sft.py) on internevo_amd.moe_engine.MoEEngine: synthetic RandomDataset batches,
     forward / backward with the moe loss, the three-group optimizer step, one log line per step with the reference's loss / moe_loss /
     per-group grad_norm keys (train/pipeline.py:494-530); InternEvo checkpoints (model + expert + optimizer files and the run state: scheduler, sampler,
-    context) at any data-parallel size.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
+    context) at any data-parallel and tensor-parallel size.  Validation and tokenized folders are the InternLM2 engine's: refused.  (The dense INTERNLM model runs on
     engine.InternLM2Engine like every other dense family.)"""
     from internevo_amd.data import BatchSkipper, SyntheticLoader
     from internevo_amd.moe_engine import MoEEngine
@@ -123,8 +123,6 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
         raise NotImplementedError("INTERNLM_MoE runs: set data.train_folder=None and data.valid_every=0 (validation / tokenized folders are implemented for "
                                   "the dense engine)")
     tc = cfg.train
-    if getattr(tc, "tp_size", 1) > 1 and (load_folder or save_folder):
-        raise NotImplementedError("INTERNLM_MoE under tensor parallelism: checkpoints are not written / read (set ckpt.enable_save_ckpt=False and no load folder)")
     eng = MoEEngine(cfg, dev, None, world, rank, seed=args.seed)
     eng.sync_replicas()   # sync_model_param (utils/parallel.py:71-107)
     # (the ranks of a tensor group read the same micro-batches: the data stream is split over the data-parallel ranks)
