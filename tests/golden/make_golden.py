@@ -642,8 +642,6 @@ def gen_checkpoint(port=29795, rank=0, world=1, tp=1, model_type=None, pp=1, isp
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=2, sp=2, wp=2, seq_len=128)
     if tp > 1:  # `--ckpt-tp`: two tensor-parallel ranks (one data-parallel rank) -> ckpt_ref_tp2/: one model + optimizer + plan + topo file per tensor rank
         kw = dict(kw, hidden=128, heads=2, kv_heads=2, vocab=256, layers=4 if pp > 1 else 2 if model_type in ("INTERNLM", "INTERNLM_MoE") else 1, tp=tp)   # (`--ckpt-pptp`: tensor 2 x pipeline 2 on four processes -> ckpt_ref_pp2tp2/)
-        if model_type == "INTERNLM_MoE":   # (file-format fixtures, read and written on the host only: the smallest shapes the model takes)
-            kw = dict(kw, hidden=64)
     bdl.RandomDataset = lambda num_samples, max_len, fixed_seqlen: RandomDataset(num_samples=NUM_SAMPLES, max_len=max_len, fixed_seqlen=fixed_seqlen)
     cfg = tiny_config("torch.bfloat16", **kw)
     if zero1:   # `--ckpt-hz`: hybrid ZeRO (parallel.zero1.size < the data-parallel size): four data ranks, optimizer state sharded over groups of two -> ckpt_ref_dp4_zo2/

@@ -24,7 +24,7 @@ class _Stub:
     wait_event = record = synchronize = wait_stream
 
 
-def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None):
+def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None, fixture=None):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None):
         from internevo_amd.data import SyntheticLoader
         from oracle.model import moe_formula_init
 
-        gold = json.load(open(os.path.join(HERE, "golden", "train_moe_tp2_bf16_rank0.json")))
+        gold = json.load(open(os.path.join(HERE, "golden", "ckpt_moe_tp2dp2_rank0.json" if fixture else "train_moe_tp2_bf16_rank0.json")))
         c = gold["config"]
         mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
                          mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
@@ -60,6 +60,11 @@ def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None):
         K._contig = lambda t, n: t
         K._p = lambda t: None
         eng = ME.MoEEngine(cfg, torch.device("cpu"), None, world, rank, init_fn=moe_formula_init, tp_size=tp)
+        if fixture:   # the reference's own dp 2 x tp 2 checkpoint into the engine's buffers and straight back out: names, cuts, fused layouts, partitions, files
+            eng.load_checkpoint(os.path.join(HERE, "golden", fixture))
+            eng.save_checkpoint(ckpt)
+            q.put((rank, {}, (eng.tp, eng.tp_rank, eng.dp_world, eng.ep, eng.step_count, eng.lr_sched.lr())))
+            return
         loader = iter(SyntheticLoader(cfg.train.seq_len, 1, cfg.train.micro_num, True, gold["num_samples"], data_rank=rank // tp, data_world_size=world // tp))
         batch, labels = next(loader)
         eng.forward_backward(batch, labels)
@@ -120,12 +125,12 @@ def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None):
         dist.destroy_process_group()
 
 
-def _run(world, port, tp=2, ckpt=None, chain=None):
+def _run(world, port, tp=2, ckpt=None, chain=None, fixture=None):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt, chain)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt, chain, fixture)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -181,3 +186,24 @@ def test_moe_engine_eight_ranks_four_experts_host_logic(tmp_path):
     assert [res[r][1] for r in range(8)] == [(1, 0, 8, 4, 4, 512, 512)] * 8
     held = lambda r: sorted({n.split("wrapped_experts.")[1].split(".")[0] for n in res[r][0] if ".experts." in n})  # noqa: E731
     assert [held(r) for r in range(8)] == [["0"], ["1"], ["2"], ["3"]] * 2
+
+
+@pytest.mark.timeout(300)
+def test_moe_engine_writes_the_reference_dp2_x_tp2_checkpoint_back_file_for_file(tmp_path):
+    """tests/golden/ckpt_ref_moe_tp2dp2/ (a real four-process data 2 x tensor 2 run of the reference's INTERNLM_MoE model, after two steps) into MoEEngine on four gloo
+    ranks -- every rank takes its heads, its FFN units of ITS two experts, its vocabulary rows, the embedding whole -- and save_checkpoint straight after the load:
+    the reference's twenty-eight files come back tensor for tensor (param_groups, plans, learning rate and scaler included).  Launches stubbed: the host side only."""
+    sys.path.insert(0, HERE)
+    from test_checkpoint import _deep_equal
+
+    from internevo_amd import checkpoint as C
+
+    out = str(tmp_path / "back")
+    res = _run(4, 29941, ckpt=out, fixture="ckpt_ref_moe_tp2dp2")
+    assert [res[r][1][:5] for r in range(4)] == [(2, 0, 2, 2, 2), (2, 1, 2, 2, 2)] * 2
+    ref = os.path.join(HERE, "golden", "ckpt_ref_moe_tp2dp2")
+    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+    for fn in sorted(os.listdir(ref)):
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(out, fn)), ld(os.path.join(ref, fn)), fn)
