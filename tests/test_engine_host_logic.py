@@ -150,6 +150,90 @@ def _chain_worker(rank, world, port, chain, folder, q):
         dist.destroy_process_group()
 
 
+def _fixture_worker(rank, world, port, fixture, record, kw, out, q):
+    """A reference checkpoint into the engine's buffers and straight back out (names, cuts, fused layouts, partitions, files); launches stubbed."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        E = _stub_launches()
+        from internevo_amd.config import ModelConfig, PathConfig, TrainConfig, tiny
+
+        c = json.load(open(os.path.join(HERE, "golden", record.format(rank=rank))))["config"]
+        if c.get("model_type") == "INTERNLM":
+            mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
+                             mlp_ratio=8 / 3, model_type="INTERNLM", num_experts=1)
+            cfg = PathConfig(mc, TrainConfig(seq_len=c["seq_len"], micro_bsz=1, micro_num=c["micro_num"], total_steps=c["total_steps"], lr=1e-3, fixed_random_dataset_seqlen=True))
+        else:
+            cfg = tiny(hidden=c["hidden"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"], seq_len=c["seq_len"], micro_num=c["micro_num"],
+                       lr=1e-3, total_steps=c["total_steps"], **({"model_type": c["model_type"]} if c.get("model_type") else {}))
+        if "wp" in c:
+            cfg.train.wp_size = c["wp"]
+        eng = E.InternLM2Engine(cfg, torch.device("cpu"), None, world, rank, seed=11 + rank, **kw)
+        eng.load_checkpoint(os.path.join(HERE, "golden", fixture))
+        eng.save_checkpoint(out)
+        q.put((rank, "ok", eng.step_count))
+    except Exception:
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+FIXTURES = {   # reference checkpoint folder -> (world, the per-rank record with the run's config, the engine's layout)
+    "ckpt_ref_isp6v1": (6, "ckpt_isp6v1_rank{rank}.json", dict(sp_size=2, weight_parallel=True)),   # three data replicas: data rank 2 holds neither embedding nor head
+    "ckpt_ref_isp4v1": (4, "ckpt_isp4v1_rank{rank}.json", dict(sp_size=2, weight_parallel=True)),
+    "ckpt_ref_dp4_zo2": (4, "ckpt_dp4_zo2_rank{rank}.json", dict(zero_size=2)),
+    "ckpt_ref_pp2tp2": (4, "ckpt_pp2tp2_rank{rank}.json", dict(pp_size=2, tp_size=2)),
+    "ckpt_ref_pp2i": (2, "ckpt_pp2i_rank{rank}.json", dict(pp_size=2, num_chunks=2)),
+    "ckpt_ref_v1tp2": (2, "ckpt_v1tp2_rank{rank}.json", dict(tp_size=2)),
+    "ckpt_ref_llama_tp2": (2, "ckpt_llama_tp2.json", dict(tp_size=2)),
+    "ckpt_ref_dp2": (2, "ckpt_dp2.json", {}),
+}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fixture", list(FIXTURES))
+def test_engine_writes_a_reference_checkpoint_back_file_for_file_on_gloo_ranks(fixture, tmp_path):
+    """The checkpoint folders real multi-process runs of the reference wrote (tests/golden/ckpt_ref_*/), loaded by the engine in the same layout on gloo ranks and saved
+    straight away: every file comes back tensor for tensor (param_groups, plans, learning rate, scaler included).  Launches stubbed: the host side only -- the GPU tests
+    repeat some of these and train on from them."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, HERE)
+    from test_checkpoint import _deep_equal
+
+    from internevo_amd import checkpoint as C
+
+    world, record, kw = FIXTURES[fixture]
+    out = str(tmp_path / "back")
+    port = 29960 + list(FIXTURES).index(fixture) + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fixture_worker, args=(r, world, port, fixture, record, kw, out, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        r, status, meta = q.get(timeout=240)
+        assert meta == 2, f"{fixture}: rank {r}:\n{status}"
+    for p in procs:
+        p.join(30)
+    ref = os.path.join(HERE, "golden", fixture)
+    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+    for fn in sorted(os.listdir(ref)):
+        if not fn.endswith(".json"):
+            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+            _deep_equal(ld(os.path.join(out, fn)), ld(os.path.join(ref, fn)), fn)
+
+
 CHAIN = [dict(tp_size=2), {}, dict(pp_size=2), dict(zero_size=2), dict(sp_size=2, weight_parallel=True), dict(tp_size=2, tp_mode="msp"), dict(pp_size=2, tp_size=2),
          dict(sp_size=2), dict(tp_size=2, tp_mode="fsp"), dict(pp_size=2, num_chunks=2), dict(sp_size=4, weight_parallel=True), dict(pp_size=4)]
 CHAIN = [dict(kw, cfg=dict(layers=4, micro_num=4)) for kw in CHAIN]   # (one model for every hop; four layers / four micro-batches: what the interleaved and the 4-stage hops need)

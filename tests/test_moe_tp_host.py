@@ -38,7 +38,7 @@ def _worker(rank, world, port, q, tp=2, ckpt=None, chain=None, fixture=None):
         from internevo_amd.data import SyntheticLoader
         from oracle.model import moe_formula_init
 
-        gold = json.load(open(os.path.join(HERE, "golden", "ckpt_moe_tp2dp2_rank0.json" if fixture else "train_moe_tp2_bf16_rank0.json")))
+        gold = json.load(open(os.path.join(HERE, "golden", fixture.replace("ckpt_ref_", "ckpt_") + "_rank0.json" if fixture else "train_moe_tp2_bf16_rank0.json")))
         c = gold["config"]
         mc = ModelConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_layers=c["layers"], num_attention_heads=c["heads"], num_kv_attention_heads=c["heads"],
                          mlp_ratio=4 / 3, model_type="INTERNLM_MoE", num_experts=c["num_experts"], moe_capacity_factor=c["capacity_factor"], moe_loss_coeff=0.1)
@@ -189,7 +189,7 @@ def test_moe_engine_eight_ranks_four_experts_host_logic(tmp_path):
 
 
 @pytest.mark.timeout(300)
-def test_moe_engine_writes_the_reference_dp2_x_tp2_checkpoint_back_file_for_file(tmp_path):
+def test_moe_engine_writes_the_reference_checkpoints_back_file_for_file(tmp_path):
     """tests/golden/ckpt_ref_moe_tp2dp2/ (a real four-process data 2 x tensor 2 run of the reference's INTERNLM_MoE model, after two steps) into MoEEngine on four gloo
     ranks -- every rank takes its heads, its FFN units of ITS two experts, its vocabulary rows, the embedding whole -- and save_checkpoint straight after the load:
     the reference's twenty-eight files come back tensor for tensor (param_groups, plans, learning rate and scaler included).  Launches stubbed: the host side only."""
@@ -198,12 +198,19 @@ def test_moe_engine_writes_the_reference_dp2_x_tp2_checkpoint_back_file_for_file
 
     from internevo_amd import checkpoint as C
 
-    out = str(tmp_path / "back")
-    res = _run(4, 29941, ckpt=out, fixture="ckpt_ref_moe_tp2dp2")
-    assert [res[r][1][:5] for r in range(4)] == [(2, 0, 2, 2, 2), (2, 1, 2, 2, 2)] * 2
-    ref = os.path.join(HERE, "golden", "ckpt_ref_moe_tp2dp2")
-    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
-    for fn in sorted(os.listdir(ref)):
-        if not fn.endswith(".json"):
-            ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
-            _deep_equal(ld(os.path.join(out, fn)), ld(os.path.join(ref, fn)), fn)
+    def back(fixture, world, tp, port, want):
+        out = str(tmp_path / fixture)
+        res = _run(world, port, tp=tp, ckpt=out, fixture=fixture)
+        assert [res[r][1][:5] for r in range(world)] == want
+        ref = os.path.join(HERE, "golden", fixture)
+        assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+        for fn in sorted(os.listdir(ref)):
+            if not fn.endswith(".json"):
+                ld = C._load if fn.startswith(("optimizer", "gpus")) else (lambda p_: torch.load(p_, weights_only=False))
+                _deep_equal(ld(os.path.join(out, fn)), ld(os.path.join(ref, fn)), fn)
+
+    #                                                   tp, tp_rank, dp_world, ep, step
+    back("ckpt_ref_moe_tp2dp2", 4, 2, 29941, [(2, 0, 2, 2, 2), (2, 1, 2, 2, 2)] * 2)
+    # ... and the reference's plain expert-parallel checkpoints: two ranks with two experts each; four ranks with one each, two of which hold no gate
+    back("ckpt_ref_moe_dp2", 2, 1, 29943, [(1, 0, 2, 2, 2)] * 2)
+    back("ckpt_ref_moe_dp4", 4, 1, 29945, [(1, 0, 4, 4, 2)] * 4)
