@@ -9,6 +9,7 @@ import sys
 
 import pytest
 import torch
+from conftest import xport
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -215,7 +216,7 @@ def test_engine_writes_a_reference_checkpoint_back_file_for_file_on_gloo_ranks(f
 
     world, record, kw = FIXTURES[fixture]
     out = str(tmp_path / "back")
-    port = 29960 + list(FIXTURES).index(fixture) + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    port = xport(29950 + list(FIXTURES).index(fixture))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_fixture_worker, args=(r, world, port, fixture, record, kw, out, q)) for r in range(world)]
@@ -244,7 +245,7 @@ def test_checkpoints_carry_the_state_from_layout_to_layout_on_four_gloo_ranks(tm
     import torch.multiprocessing as mp
 
     world = 4
-    port = 29990 + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    port = xport(29960)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_chain_worker, args=(r, world, port, CHAIN, str(tmp_path), q)) for r in range(world)]
@@ -292,7 +293,7 @@ def test_engine_host_logic_on_gloo_ranks(name, tmp_path):
     world, kw = LAYOUTS[name]
     if name in CKPT_LAYOUTS:
         kw = dict(kw, _ckpt=str(tmp_path / "ckpt"))
-    port = 29940 + list(LAYOUTS).index(name) + 20 * int(os.environ.get("PYTEST_XDIST_WORKER", "gw0")[2:] or 0)
+    port = xport(29900 + list(LAYOUTS).index(name))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, kw, q)) for r in range(world)]

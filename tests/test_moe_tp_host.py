@@ -10,6 +10,7 @@ import sys
 
 import pytest
 import torch
+from conftest import xport
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -130,7 +131,7 @@ def _run(world, port, tp=2, ckpt=None, chain=None, fixture=None):
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tp, ckpt, chain, fixture)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, xport(port), q, tp, ckpt, chain, fixture)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
