@@ -154,6 +154,11 @@ def main():
                     "communicator is created): fewer channels = fewer CUs held by a collective, for longer (DESIGN.md section 6); 0 = RCCL's default")
     ap.add_argument("--rs-under-w13-only", action="store_true", help="N > 1 diagnostics: launch a layer bucket's gradient reduce-scatter in front of the next layer's "
                     "w1 | w3 backward products instead of right behind its last weight gradient (engine rs_under_w13)")
+    ap.add_argument("--hold-cus", default=None, help="DIAGNOSTIC, one GPU: 'n' or 'n,link_GBps' -- where an 8-GPU run would launch a bucket's reduce-scatter / all-gather, n "
+                    "idle workgroups hold n CUs for the time the collective would take (a bucket's 1/8 per xGMI link at link_GBps, default 100), on a side stream: the "
+                    "price of a collective's CUs for the products beside it (DESIGN.md section 6.2).  The line says so; results are unchanged")
+    ap.add_argument("--gemm-persistent-skip-n", type=int, default=None, help="A/B only: products with this many output columns stay on the plain launch")
+    ap.add_argument("--ffn-fuse", type=int, default=None, help="A/B only: ie_tune_ffn_fuse mode (bit 0 forward gate, bit 1 the w2 input-gradient epilogue)")
     args = ap.parse_args()
     if args.rccl_channels > 0:   # (inherited by the ranks of a self-launched run; read by RCCL when the communicator is created)
         os.environ["NCCL_MAX_NCHANNELS"] = os.environ["NCCL_MIN_NCHANNELS"] = str(args.rccl_channels)
@@ -168,6 +173,14 @@ def main():
         assert K._L().ie_tune_gemm_tail_split(args.gemm_tail_split) == 0
     if args.gemm_persistent is not None:
         assert K._L().ie_tune_gemm_persistent(args.gemm_persistent) == 0
+    if args.gemm_persistent_skip_n is not None:
+        assert K._L().ie_tune_gemm_persistent_skip_n(args.gemm_persistent_skip_n) == 0
+    if args.ffn_fuse is not None:
+        assert K._L().ie_tune_ffn_fuse(args.ffn_fuse) == 0
+    if args.hold_cus:
+        if args.gpus != 1:
+            raise SystemExit("--hold-cus is the one-GPU stand-in for a collective's CUs")
+        os.environ["IE_HOLD_CUS"] = args.hold_cus
     if args.attn_fwd_variant is not None:
         assert K._L().ie_tune_flash_fwd_variant(args.attn_fwd_variant) == 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -303,6 +316,9 @@ def main():
         "total_max_over_ranks": round(float(exp_max[: len(kinds)].sum()), 3), "total_mean_over_ranks": round(float(exp_sum[: len(kinds)].sum()) / world, 3),
         "waits_per_step_mean": round(float(exp_sum[-1]) / world, 1)}
     comm_info["rccl_channels"] = args.rccl_channels or "default"
+    if eng.hold is not None:
+        comm_info["DIAGNOSTIC_held_cus"] = (f"{eng.hold[0]} CUs held by idle workgroups where a data-parallel run launches each bucket's reduce-scatter and all-gather, for the "
+                                            f"collective's time at {eng.hold[1]:g} GB/s per xGMI link (bench.py --hold-cus): NOT the default benchmark")
     comm_info["gradient_reduce_scatter_launch"] = "in front of the next layer's w1|w3 backward products" if eng.rs_under_w13 else "behind the bucket's last weight gradient"
     if world > 1 and args.tp == 1 and args.pp == 1 and not eng.wp_mode:
         # data-parallel replicas must hold bit-identical parameters after the timed steps (reduce-scatter -> AdamW on the shard -> all-gather):

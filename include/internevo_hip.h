@@ -113,8 +113,9 @@ int ie_swiglu_bwd(const void* dout, int64_t lddo, const void* a, int64_t lda, co
  *   fwd: h13[M, 2F] = x[M, K] @ w13[2F, K]^T (rows 0..F-1 = w1, F..2F-1 = w3);  act[M, F] = bf16(bf16(silu(h13[:, :F])) * h13[:, F:])
  *   bwd: dh13[M, 2F] = (d gate | d up) of the gate at h13 for d(act) = dy[M, K] @ w2[K, F]; d(act) itself is written only on the two-launch path
  *        (dact_scratch [M, F], always required).
- * ie_tune_ffn_fuse(mode): bit 0 = fuse the forward product (default on), bit 1 = fuse the input-gradient product (default off: measured no faster,
- * profiles/r03_ffn_fuse_ab.jsonl); 0 forces the two-launch path everywhere. */
+ * ie_tune_ffn_fuse(mode): bit 0 = fuse the forward product (default on), bit 1 = fuse the input-gradient product on every eligible shape (default off: on the
+ * plain launch measured no faster, profiles/r03_ffn_fuse_ab.jsonl), bit 2 = fuse it where the persistent GEMM frame takes the product (default on since round 6:
+ * -0.7 % of the training step, profiles/r06_step_ffn_fuse_bwd_abab.log); 0 forces the two-launch path everywhere.  Default 5. */
 int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, int64_t ldw, void* h13, int64_t ldh, void* act, int64_t ld_act,
                        int64_t M, int64_t F, int64_t K, void* stream);
 int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, int64_t ldw, const void* h13, int64_t ldh, void* dh13, int64_t ldd,
@@ -359,6 +360,10 @@ int ie_moe_gate_fwd(const void* x, int64_t x_ld, const float* wg, const float* n
 /* slots in token order, capacity drop, renormalised weights, l_aux (1 float, rounded to bf16), exp_counts [E]. */
 int ie_moe_route(const float* gates, const int32_t* expert, int64_t S, int E, int capacity, int32_t* row, float* weight,
                  int32_t* token_of, float* l_aux, int32_t* exp_counts, void* stream);
+/* The expert buffers' rows in chunk-major order (the expert exchange in `nchunk` pieces, each piece's all_to_all overlapped with the expert products of the piece
+ * before it; the reference's exchange is blocking: moe/gshard_layer.py:465-498): slot c of expert e moves from row e C + c to row k E Cn + e Cn + (c mod Cn),
+ * Cn = capacity / nchunk, k = c / Cn.  row [2, S] is rewritten in place, token_of_in [E C] copied to token_of_out in the new order (must not alias). */
+int ie_moe_chunk_rows(int32_t* row, const int32_t* token_of_in, int32_t* token_of_out, int64_t S, int E, int capacity, int nchunk, void* stream);
 int ie_moe_dispatch(const void* x, int64_t x_ld, const int32_t* token_of, int64_t rows, int M, void* expert_in, void* stream);
 int ie_moe_combine_fwd(const void* expert_out, const int32_t* row, const float* weight, int64_t S, int M, void* out,
                        int64_t out_ld, void* stream);
@@ -392,6 +397,7 @@ int ie_tune_gemm_tail_split(int mode);
 int ie_tune_gemm_persistent(int mode);
 /* (internal: the block count behind ie_tune_gemm_persistent; exported because two translation units share it) */
 int ie_gemm_dma_set_persistent_grid(int blocks);
+int ie_gemm_dma_persistent_takes(int64_t M, int64_t N, int64_t K);   /* (internal, shared by two translation units: 1 when the persistent frame takes the product) */
 /* Tuning hook (A/B benchmarking): occupancy the dQ kernel of ie_flash_attn_bwd is compiled for, 1 or 2 waves/SIMD. */
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
 /* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */
@@ -423,6 +429,13 @@ int ie_acc_bf16(float* dst, const void* src, int64_t n, void* stream);
  * bf16 rounding, deterministic; measured 2-4 % faster than the default at 4 x 4096 tokens and not the default: profiles/r05_flash_bwd_spill.md. */
 int64_t ie_flash_attn_bwd_spill_bytes(int nseq, int max_seqlen, int hq, int causal);
 int ie_flash_attn_bwd_set_spill(void* buf, int64_t bytes);
+
+/* Diagnostic (bench.py --hold-cus): `blocks` idle workgroups that each occupy one CU for `usec` microseconds on `stream` -- what a
+ * collective's kernels take away from the products beside them, reproduced on a one-GPU box (the reference overlaps its gradient reduction with backward the same
+ * way: hybrid_zero_optim.py:290-367).  No memory traffic, no result. */
+int ie_hold_cus(int blocks, int usec, void* stream);
+/* Tuning hook (A/B): products with exactly this many output columns stay on the plain launch although ie_tune_gemm_persistent would take them (0 = none). */
+int ie_tune_gemm_persistent_skip_n(int64_t n_cols);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

@@ -110,6 +110,9 @@ SIGNATURES = {
     "ie_gemm_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "ie_tune_gemm_tail_split": (I, [I]),
     "ie_tune_gemm_persistent": (I, [I]),
+    "ie_tune_gemm_persistent_skip_n": (I, [I64]),
+    "ie_gemm_dma_persistent_takes": (I, [I64, I64, I64]),
+    "ie_hold_cus": (I, [I, I, P]),
     "ie_gemm_dma_set_persistent_grid": (I, [I]),
     "ie_tune_flash_dkdv_split": (I, [I]),
     "ie_bias_add_bf16": (I, [P, I64, P, I64, I64, P]),
@@ -118,6 +121,7 @@ SIGNATURES = {
     "ie_moe_gumbel_noise": (I, [P, I64, ctypes.c_uint32, ctypes.c_uint64, P]),
     "ie_moe_gate_fwd": (I, [P, I64, P, P, I64, I, I, P, P, P, P]),
     "ie_moe_route": (I, [P, P, I64, I, I, P, P, P, P, P, P]),
+    "ie_moe_chunk_rows": (I, [P, P, P, I64, I, I, I, P]),
     "ie_moe_dispatch": (I, [P, I64, P, I64, I, P, P]),
     "ie_moe_combine_fwd": (I, [P, P, P, I64, I, P, I64, P]),
     "ie_moe_combine_bwd": (I, [P, I64, P, P, P, I64, I64, I, P, P, P]),

@@ -932,10 +932,14 @@ def _load_moe_tp_rank(folder, model_cfg, t):
                 if o != vec.numel():
                     raise ValueError(f"{fn} group {g}: the flat vector holds {vec.numel()} elements, this rank's partition {o}")
         gs, base = st["grad_scaler"], st["base_optim_states"]
-        here = (int(float(base["state"][0]["step"])), float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]), int(gs["_hysteresis_step"]))
-        if meta is not None and here != meta:
+        # (a data rank whose partition of the default group is empty writes no state entry 0 -- the writer keys the state by the first id of each non-empty
+        # group: the step comes from ANY entry present, as load_isp_optimizer reads it; a shard without any state entry names no step)
+        any_state = next(iter(base["state"].values()), None)
+        here = (int(float(any_state["step"])) if any_state is not None else None, float(base["param_groups"][0]["lr"]), float(gs["_scale"]), int(gs["_growth_step"]),
+                int(gs["_hysteresis_step"]))
+        if meta is not None and (here[1:] != meta[1:] or (here[0] is not None and meta[0] is not None and here[0] != meta[0])):
             raise ValueError("the optimizer shards disagree on step / lr / loss scale")
-        meta = here
+        meta = here if (meta is None or meta[0] is None) else meta
     missing = [n for n in order if n not in merged["master"]]
     if missing:
         raise FileNotFoundError(f"{folder}: the optimizer shards present do not cover {missing[:3]} ...")

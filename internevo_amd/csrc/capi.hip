@@ -43,3 +43,20 @@ extern "C" int ie_mfma_probe(const void* a, const void* b, float* c, void* strea
     hipLaunchKernelGGL(mfma_probe_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, c);
     return ie_launch_status("ie_mfma_probe launch");
 }
+
+// Diagnostic (bench.py --hold-cus): `blocks` workgroups that each take a whole CU out of the products' reach for `usec` microseconds and
+// do nothing -- a stand-in, on a one-GPU box, for the CUs an RCCL collective holds while it runs beside the step (a GEMM workgroup of this library needs a CU
+// to itself: one 512-register wave per SIMD and 144 KB of LDS, so any resident wave keeps it away; here 256 threads = one wave per SIMD and 96 KB of LDS = one
+// such block per CU).  The blocks sleep between looks at the 100 MHz wall clock (s_sleep: no issue slots, no memory traffic, next to no power).
+__global__ __launch_bounds__(256) void hold_cu_k(long long ticks) {
+    __shared__ unsigned char pad[96 * 1024];
+    if (ticks < 0) pad[threadIdx.x] = 0;   // (keeps the allocation)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int ie_hold_cus(int blocks, int usec, void* stream) {
+    IE_CHECK_ARG(blocks >= 1 && blocks <= 256 && usec >= 1 && usec <= 1000000, "ie_hold_cus: 1..256 blocks, 1..1e6 microseconds");
+    hipLaunchKernelGGL(hold_cu_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)usec * 100ll);
+    return ie_launch_status("ie_hold_cus launch");
+}

@@ -368,6 +368,7 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, 
 // on n blocks (tests: small products then walk several tiles per block); 0: the plain launch.  In the training step (same box, A B A B under rocprofv3,
 // profiles/r05_step_gemm_persistent_abab.log): the plain forward products 800 -> 758 us per launch (-5.3 %), the step 676.8 -> 673.8 ms, the same loss bit for bit.
 int g_gemm_persistent = 1;
+int64_t g_gemm_persistent_skip_n = 0;   // (A/B hook: products with this many output columns stay on the plain launch)
 int g_tail_split = 0;  // 0 = off, 1 = remainder by variant 14 if an operand is k-major else 12 (as measured), 2 = always 14, 3 = always 12
 struct TailSplit {
     bool on, along_n;
@@ -407,7 +408,8 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
         // (measured at 16 384 rows, profiles/r05_gemm_persistent_kbench.log, r05_gemm_persistent_k_rule.log: K = 2048 / 4096 -2 ... -2.4 %, 14 336 -1.2 %, 28 672 level,
         // but K = 6144 +1 % and 8192 level on both layouts: the frame is taken where it was seen to pay)
         if (g_gemm_persistent && variant == 20 && bt.count == 1 && M % 256 == 0 && N % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 &&
-            (g_gemm_persistent > 1 || K <= 4096 || K >= 12288) && (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent))
+            (g_gemm_persistent > 1 || K <= 4096 || K >= 12288) && (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent) &&
+            N != g_gemm_persistent_skip_n)
             variant = 22;
         const TailSplit ts = (g_tail_split && bt.count == 1 && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
@@ -463,19 +465,24 @@ extern "C" int ie_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void
 // ---- the FFN products with the SwiGLU arithmetic fused into their epilogues (a7) ---------------------------------------------------
 // Fused (one launch, the refill-schedule kernel with EPI 1 / 2) when the plain dispatcher would have picked that schedule for the shape;
 // otherwise the same two launches as before (product, then the elementwise kernel).  Results are bit-identical either way.
-// bit 0: the forward product (on: -134 us per 16 384-row layer call, profiles/r03_ffn_fuse_ab.jsonl); bit 1: the w2 input-gradient product (off:
-// measured level to slower -- the epilogues of all CUs coincide, gemm_bf16_dma.hip EPI 2)
-static int g_ffn_fuse = 1;
+// bit 0: the forward product (on: -134 us per 16 384-row layer call, profiles/r03_ffn_fuse_ab.jsonl); bit 1: the w2 input-gradient product on EVERY shape of the
+// refill schedule (off: on the plain launch measured level to slower -- the epilogues of all CUs coincide, gemm_bf16_dma.hip EPI 2); bit 2 (round 6, on): the w2
+// input-gradient product where the PERSISTENT frame takes it (gemm_p5_k<true, 2>): in the training step (A B A B on one box under rocprofv3,
+// profiles/r06_step_ffn_fuse_bwd_abab.log) the product goes 1326 -> 1624 us per launch and the 410-us swiglu_bwd_k launch behind it disappears:
+// 672.3 / 672.6 -> 668.5 / 667.1 ms per step (-0.7 %), the same loss bit for bit.  (The epilogue's 134 MB per tile round move at HBM speed: it cannot get shorter, only hidden.)
+static int g_ffn_fuse = 5;
+extern "C" int ie_gemm_dma_persistent_takes(int64_t M, int64_t N, int64_t K);   // (gemm_bf16_dma.hip: would the persistent frame take this [M, N, K] product?)
 extern "C" int ie_tune_ffn_fuse(int mode) {
-    if (mode < 0 || mode > 3) return IE_ERR_INVALID;
+    if (mode < 0 || mode > 7) return IE_ERR_INVALID;
     g_ffn_fuse = mode;
     return IE_OK;
 }
 
 // 1 when the shape takes the one-launch path (contiguous, 16-byte aligned operands assumed), 0 when it takes two launches
 extern "C" int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K) {
-    if (!(g_ffn_fuse & (bwd ? 2 : 1)) || K <= 0 || K % 64 != 0 || M < 8 || F < 8) return 0;
-    if (bwd) return pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on);
+    if (!(g_ffn_fuse & (bwd ? 6 : 1)) || K <= 0 || K % 64 != 0 || M < 8 || F < 8) return 0;
+    if (bwd) return pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on) &&
+                    ((g_ffn_fuse & 2) || ie_gemm_dma_persistent_takes(M, F, K));
     return F % 128 == 0 && pick_variant(M, 2 * F, K, false, false) == 20 && !(g_tail_split && tail_split(M, 2 * F).on);
 }
 
@@ -504,8 +511,10 @@ extern "C" int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, i
                        "ie_gemm_swiglu_bwd: h13 / dh13 must be 16-byte aligned, F and the leading dimensions multiples of 8");
     if (M == 0 || F == 0) return IE_OK;
     const bool fits32 = M * ldy * 2 < (1ll << 32) && K * ldw * 2 < (1ll << 32);
-    const bool fuse = (g_ffn_fuse & 2) && K > 0 && K % 64 == 0 && M >= 8 && F >= 8 && fits32 && aligned16(dy) && aligned16(w2) && ldy % 8 == 0 && ldw % 8 == 0 &&
-                      pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on);
+    const bool fits_h = M * ldh * 2 < (1ll << 31) && M * ldd * 2 < (1ll << 31);   // (the persistent epilogue addresses a wave's corner of h13 / dh13 by 32-bit offsets)
+    const bool fuse = (g_ffn_fuse & 6) && K > 0 && K % 64 == 0 && M >= 8 && F >= 8 && fits32 && aligned16(dy) && aligned16(w2) && ldy % 8 == 0 && ldw % 8 == 0 &&
+                      pick_variant(M, F, K, false, true) == IE_DGRAD_REFILL && !(g_tail_split && tail_split(M, F).on) &&
+                      ((g_ffn_fuse & 2) || (fits_h && ie_gemm_dma_persistent_takes(M, F, K)));
     if (fuse) return ie_gemm_swiglu_dma_launch(1, dy, ldy, w2, ldw, dh13, ldd, h13, ldh, nullptr, 0, M, F, K, stream);
     const int rc = gemm_dispatch(-1, dy, ldy, 0, w2, ldw, 1, dact_scratch, ld_scratch, M, F, K, 0, stream);
     if (rc != IE_OK) return rc;
@@ -529,6 +538,12 @@ extern "C" int ie_tune_gemm_persistent(int mode) {
     if (mode < 0 || mode > 1024 || (mode > 1 && mode % 8)) return IE_ERR_INVALID;
     g_gemm_persistent = mode;
     return ie_gemm_dma_set_persistent_grid(mode == 0 ? 0 : mode > 1 ? mode : 256);
+}
+
+extern "C" int ie_tune_gemm_persistent_skip_n(int64_t n_cols) {
+    if (n_cols < 0) return IE_ERR_INVALID;
+    g_gemm_persistent_skip_n = n_cols;
+    return IE_OK;
 }
 
 extern "C" int ie_tune_gemm_tail_split(int mode) {

@@ -19,6 +19,7 @@
 #include "ie_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1285,11 +1286,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 // [192, 256) = w3 rows n0 + 64 .. + 128 (a row offset on B's transfer pieces, as in gemm_dma_k's EPI 1) -- accumulator blocks j = 0 .. 3 are gate, 4 .. 7 up
 // columns of one lane's rows.  The epilogue writes h13 (both halves) and act = silu(gate) * up, computed from the bf16-rounded gate / up exactly as the
 // separate kernel and gemm_dma_k's fused epilogue do.  N = 2F; tiles_n = F / 128.
+// EPI 2 (round 6; the w2 input-gradient product with the SwiGLU backward): the tile is d(act) [256 x 256] of dy @ w2; ACT / ld_act carry h13 [M, 2F] (gate | up,
+// read), C = dh13 [M, 2F]: every 16-byte piece of a wave's 16-row turn is joined by the gate and up values of its eight columns and leaves as d(gate) and d(up)
+// (swiglu_bwd1 on the bf16-rounded d(act): the arithmetic of swiglu_bwd_k and of gemm_dma_k's EPI 2, bit for bit).  The h13 pieces of a turn are requested
+// before the turn's accumulators are packed.  N = F; tiles_n = F / 256.
 template <bool B_KM, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C,
                                                  int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n, bf16_t* __restrict__ ACT,
                                                  int64_t ld_act, int F, unsigned* __restrict__ queue) {
-    static_assert(EPI == 0 || !B_KM, "EPI 1: the forward product");
+    static_assert(EPI == 0 || (EPI == 1 && !B_KM) || (EPI == 2 && B_KM), "EPI 1: the forward product; EPI 2: the w2 input-gradient product");
     using G = DCfg<256, 256, 2, 2>;
     constexpr int NW = 4;
     constexpr int EP = 256 + 16;                      // pitch of a wave's private epilogue rows (16 rows x 128 bf16 columns)
@@ -1377,12 +1382,16 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
     if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // one k-tile (the table of SPREAD -5, its evenly spread transfer pieces).  more1 / more2: the k-tiles one / two ahead exist -- of this output tile or of the next
-    constexpr int NST = EPI == 1 ? 48 : 32;   // stores of a wave's epilogue
+    constexpr int NST = EPI == 1 ? 48 : EPI == 2 ? 48 : 32;   // stores of a wave's epilogue that the first counted waits behind it may leave in flight (EPI 2 issues 64:
+                                                              // the field ends at 63 = 15 + 48 -- a smaller count only waits for more)
     bool behind_stores = false;   // this k-tile follows an epilogue: 32 stores of this wave sit between the transfers the counted waits name and the younger ones
-    auto tile = [&](int t, auto fast_, bool more1_, bool more2_, auto zero_) {
+    // EPI 2's epilogue needs registers for the gate / up pieces of a turn: an output tile's LAST k-tile then leaves the next tile's first fragments in the LDS
+    // (rd_next false; its waits and barriers still say that k-tile is complete) and they are read behind the epilogue, as the prologue reads the first tile's.
+    auto tile = [&](int t, auto fast_, bool more1_, bool more2_, auto zero_, bool rd_next_ = true) {
         constexpr bool FAST = decltype(fast_)::value;
         constexpr bool ZERO = decltype(zero_)::value;   // the output tile's first k-tile
         const bool more1 = FAST || more1_, more2 = FAST || more2_;
+        const bool rd_next = more1 && (FAST || rd_next_);
         unsigned char* cur = smem + (t & 1) * G::STAGE_BYTES;
         const unsigned char* nxt = smem + ((t + 1) & 1) * G::STAGE_BYTES;
         __builtin_amdgcn_sched_barrier(0);
@@ -1410,7 +1419,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                     __builtin_amdgcn_s_barrier();                   // 3: B(t+1) complete
                 }
             } else if (m >= 29 && m < 37) {
-                if (more1) rdB(nxt, 0, m - 29);
+                if (rd_next) rdB(nxt, 0, m - 29);
             } else if (m == 42) {
                 if (more1) {
                     if (ZERO && behind_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + NST) : "memory");
@@ -1419,7 +1428,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                     __builtin_amdgcn_s_barrier();                   // 4: A(t+1) complete
                 }
             } else if (m >= 43 && m < 51) {
-                if (more1) rdA(nxt, 0, m - 43);
+                if (rd_next) rdA(nxt, 0, m - 43);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (ZERO && ks == 0) mfma16z(acc16[i][j + 1], bfr[ks][j + 1], af[ks][i]);
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
         }
         // (ONE copy of the last two k-tiles with run-time flags: a second copy in another branch would merge 256 accumulator registers where the paths join)
         tile(t, no, true, has_next, no);
-        tile(t + 1, no, has_next, has_next, no);
+        tile(t + 1, no, has_next, has_next, no, EPI != 2);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: no hazard bookkeeping by the compiler) before they are read
         // ---- this tile's accumulators to memory.  Straight from the registers a lane has 8-byte pieces of sixteen different rows per store (measured: 9 us per
         // tile round, twice the plain kernel's LDS-staged epilogue -- it ate what the continued transfers gain); so every WAVE turns one 16-row block at a time
@@ -1473,14 +1482,57 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
             unsigned char* wr = ep + (lane & 15) * EP + 8 * (lane >> 4);                 // row m = lane & 15, columns 4 (lane >> 4) .. + 3 of a 16-column block
             const unsigned char* rd = ep + (lane >> 4) * EP + (lane & 15) * 16;          // piece p = lane + 64 q: row p / 16, 16-byte column p % 16
             bf16_t* cdst = C + (int64_t)(m0 + wm * G::WM + (lane >> 4)) * ldc + n0 + wn * G::WN + (lane & 15) * 8;
+            // EPI 2 addresses h13 and dh13 through buffer descriptors at the wave's corner of the tile (wave-uniform: m0, n0 per block, wm, wn from the
+            // readfirstlane'd wave number): ONE per-lane byte offset each, the turn's / piece's row in the scalar offset -- no 64-bit per-lane addresses for the
+            // sixteen loads and stores of a turn (the kernel is at the register cap)
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+            const int h_row = (int)ld_act * 2, c_row = (int)ldc * 2;
+            const int h_voff = (lane >> 4) * h_row + (lane & 15) * 16, c_voff = (lane >> 4) * c_row + (lane & 15) * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int64_t corner_h = (int64_t)(m0 + wm * G::WM) * ld_act + n0 + wn * G::WN, corner_c = (int64_t)(m0 + wm * G::WM) * ldc + n0 + wn * G::WN;
+            auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 2 ? (bf16_t*)ACT + corner_h : C), 0, EPI == 2 ? 128 * h_row : 0, 0x00020000);
+            auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (EPI == 2 ? corner_c : 0)), 0, EPI == 2 ? 128 * c_row : 0, 0x00020000);
+#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                u32x4_t hg[4], hu[4];   // EPI 2: gate / up of this turn's four pieces per lane, requested first
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        hg[q] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_voff, (i * 16 + q * 4) * h_row, 0);
+                        hu[q] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, h_voff, (i * 16 + q * 4) * h_row + 2 * F, 0);
+                    }
+                }
+#endif
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     uint2 v;
                     v.x = pack2bf(acc16[i][j][0], acc16[i][j][1]);
                     v.y = pack2bf(acc16[i][j][2], acc16[i][j][3]);
                     *reinterpret_cast<uint2*>(wr + j * 32) = v;
+                }
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {   // (dword by dword: two elements' temporaries live at a time -- the kernel sits at the register cap)
+                        const uint4 g4 = *reinterpret_cast<const uint4*>(rd + q * 4 * EP);
+                        const unsigned gw[4] = {g4.x, g4.y, g4.z, g4.w};
+                        u32x4_t da, db;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float a0, b0, a1, b1, oc;
+                            swiglu_bwd1(bflo(gw[e]), bflo(hg[q][e]), bflo(hu[q][e]), a0, b0, oc);
+                            swiglu_bwd1(bfhi(gw[e]), bfhi(hg[q][e]), bfhi(hu[q][e]), a1, b1, oc);
+                            da[e] = pack2bf(a0, a1);
+                            db[e] = pack2bf(b0, b1);
+                        }
+#if defined(__HIP_DEVICE_COMPILE__)
+                        __builtin_amdgcn_raw_buffer_store_b128(da, c_rsrc, c_voff, (i * 16 + q * 4) * c_row, 2);           // (aux 2 = nt, as st16_c)
+                        __builtin_amdgcn_raw_buffer_store_b128(db, c_rsrc, c_voff, (i * 16 + q * 4) * c_row + 2 * F, 2);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // (as EPI 1: one turn's arithmetic at a time)
+                    continue;
                 }
                 if constexpr (EPI == 1) {   // a row = [gate 64 | up 64]; pair p = lane + 64 q: row p / 8, 8-column piece p % 8
 #pragma unroll 1
@@ -1526,6 +1578,13 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
             }
             break;
         }
+        if constexpr (EPI == 2) {   // the next tile's first fragments (its k-tile 0 is complete in stage 0 since the last k-tile's barriers; nk is even)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rdA(smem, 0, i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rdB(smem, 0, j);
+            if (B_KM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         behind_stores = !accumulate && !((abl & 8) && M != -12345);   // (accumulating epilogues read C: their waits have drained everything)
         b = bn;
         m0 = m0n;
@@ -1555,16 +1614,21 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
 }
 
 static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
-// tile queues of the persistent kernel: 64 slots of 16 words handed out round-robin (a launch's last block zeroes its slot; 64 launches later the slot is
-// taken again -- stream order, or far apart in time on different streams); module-global device memory, zero at load: no allocation
+// tile queues of the persistent kernel: 64 slots of 16 words handed out round-robin (an atomic counter: launches may come from several host threads);
+// module-global device memory: no allocation.  Every launch ZEROES its slot in stream order first (a 36-byte hipMemsetAsync): a launch that faulted or was
+// aborted, or more than 64 launches in flight across streams, can no longer leave counters behind that make a later launch skip tiles silently (the
+// kernel's last block still zeroes the slot, which costs nothing).  In stream order the memset sits behind the previous launch on that stream; a slot is
+// taken again 64 launches later.
 __device__ unsigned g_p5_queues[64 * 16];
-static unsigned* p5_queue_slot() {
+static unsigned* p5_queue_slot(hipStream_t st) {
     static unsigned* base[16] = {};   // per device: a module-global has one address on every device of the process
-    static unsigned n = 0;
+    static std::atomic<unsigned> n{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
-    return base[dev] + 16 * (n++ & 63);
+    unsigned* slot = base[dev] + 16 * (n.fetch_add(1u, std::memory_order_relaxed) & 63u);
+    if (hipMemsetAsync(slot, 0, 9 * sizeof(unsigned), st) != hipSuccess) return nullptr;
+    return slot;
 }
 static int g_gemm_persistent_on = 1;        // ie_tune_gemm_persistent's mode (the fused w1 | w3 product is launched from this file)
 extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent: 0 = off, 8 .. 1024 = that many blocks (mode > 1), 256 + on for mode 1)
@@ -1573,6 +1637,12 @@ extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_
     g_gemm_persistent_on = blocks == 256 ? 1 : blocks;
     g_gemm_persistent_grid = blocks;
     return IE_OK;
+}
+// would the persistent frame take an [M, N, K] product of the 16x16x32 refill schedule?  (whole tiles, an even number of k-tiles, the K rule of gemm_bf16.hip's
+// dispatcher, more tiles than blocks)
+extern "C" int ie_gemm_dma_persistent_takes(int64_t M, int64_t N, int64_t K) {
+    return g_gemm_persistent_on && M % 256 == 0 && N % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 && (K <= 4096 || K >= 12288 || g_gemm_persistent_on > 1) &&
+           (M / 256) * (N / 256) > g_gemm_persistent_grid;
 }
 static int g_gemm_group = 0;  // 0 = the kernel's default (4 tile rows per group)
 extern "C" int ie_tune_gemm_group(int gm) {
@@ -1638,7 +1708,7 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
         ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, b_kmajor != 0, -7, 0);
         const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
         const unsigned grid = (unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid);
-        unsigned* qslot = p5_queue_slot();
+        unsigned* qslot = p5_queue_slot(st);
         if (!qslot) return IE_ERR_LAUNCH;
         if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
                                          (bf16_t*)nullptr, (int64_t)0, 0, qslot);
@@ -1679,7 +1749,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
         if (g_gemm_persistent_on && M % 256 == 0 && K >= 256 && (K / 64) % 2 == 0 && (K <= 4096 || K >= 12288 || g_gemm_persistent_on > 1) &&
             tiles_m * tiles_n > g_gemm_persistent_grid) {
             ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 0, -7, 1);
-            unsigned* qslot = p5_queue_slot();
+            unsigned* qslot = p5_queue_slot(st);
             if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<false, 1>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
                                (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F, qslot);
@@ -1689,6 +1759,15 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
                            (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, bt);
     } else {
         const int tiles_n = (int)((F + 255) / 256);
+        // the persistent frame with the SwiGLU backward in its wave-private epilogue (gemm_p5_k<true, 2>), where gemm_bf16.hip's rule sends the plain product there
+        if (ie_gemm_dma_persistent_takes(M, F, K) && M * ld_h13 * 2 < (1ll << 31) && M * ldc * 2 < (1ll << 31)) {
+            ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 1, -7, 2);
+            unsigned* qslot = p5_queue_slot(st);
+            if (!qslot) return IE_ERR_LAUNCH;
+            hipLaunchKernelGGL((gemm_p5_k<true, 2>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
+                               (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, (bf16_t*)const_cast<void*>(h13), ld_h13, (int)F, qslot);
+            return ie_launch_status("ie_gemm_swiglu bwd (persistent) launch");
+        }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, true, -4, 2>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, bt);
     }

@@ -21,6 +21,8 @@
 // Roofline: all kernels HBM-bound; algorithmic bytes per token: gate 2M (+4E..), dispatch / combine 2 * 2 * 2M each.
 #include "ie_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int kMaxE = 16;
@@ -370,6 +372,30 @@ extern "C" int ie_moe_route(const float* gates, const int32_t* expert, int64_t S
     IE_CHECK_SUPPORTED(E >= 2 && E <= kMaxE && S < (1 << 30), "ie_moe_route: 2 <= experts <= 16");
     hipLaunchKernelGGL(moe_route_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, gates, expert, (int)S, E, capacity, row, weight, token_of, l_aux, exp_counts);
     return ie_launch_status("ie_moe_route launch");
+}
+
+// Expert-buffer rows in CHUNK-major order (round 6: the expert exchange in pieces, every piece's all_to_all under the expert products of the piece before it --
+// gshard_layer.py:465-498 is blocking).  Slot c of expert e, logical row e C + c, lives at row k E Cn + e Cn + (c mod Cn) with Cn = C / nchunk, k = c / Cn: piece k
+// = the rows [k E Cn, (k + 1) E Cn) = [expert][Cn slots] -- contiguous, so it is one all_to_all_single of its own.  row[2 S] is rewritten in place, token_of
+// copied into the new order; every later kernel of the layer only ever uses the two arrays as opaque indices.
+__global__ __launch_bounds__(256) void moe_chunk_rows_k(int32_t* __restrict__ row, const int32_t* __restrict__ token_in, int32_t* __restrict__ token_out, int64_t S, int E,
+                                                        int C, int nchunk) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    const int Cn = C / nchunk;
+    auto phys = [&](int r) { const int e = r / C, c = r - e * C, k = c / Cn; return k * E * Cn + e * Cn + (c - k * Cn); };
+    if (i < (int64_t)E * C) token_out[phys((int)i)] = token_in[i];
+    if (i < 2 * S) {
+        const int r = row[i];
+        if (r >= 0) row[i] = phys(r);
+    }
+}
+
+extern "C" int ie_moe_chunk_rows(int32_t* row, const int32_t* token_of_in, int32_t* token_of_out, int64_t S, int E, int capacity, int nchunk, void* stream) {
+    IE_CHECK_ARG(row && token_of_in && token_of_out && token_of_in != token_of_out && S > 0 && E >= 1 && capacity > 0, "ie_moe_chunk_rows: bad arguments");
+    IE_CHECK_ARG(nchunk >= 1 && capacity % nchunk == 0 && (int64_t)E * capacity < (1ll << 31), "ie_moe_chunk_rows: the chunk count must divide the capacity");
+    const int64_t n = std::max<int64_t>((int64_t)E * capacity, 2 * S);
+    hipLaunchKernelGGL(moe_chunk_rows_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row, token_of_in, token_of_out, S, E, capacity, nchunk);
+    return ie_launch_status("ie_moe_chunk_rows launch");
 }
 
 extern "C" int ie_moe_dispatch(const void* x, int64_t x_ld, const int32_t* token_of, int64_t rows, int M, void* expert_in, void* stream) {

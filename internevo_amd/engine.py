@@ -45,6 +45,16 @@ _LN2, _LOG2E = 0.6931471805599453, 1.4426950408889634
 _HIP_RT = None
 
 
+def _mem_budget(device):
+    """Bytes the engine may still plan with when it decides its two memory-dependent switches (batched weight gradients, the kept SwiGLU product).  Default:
+    what the device reports free now.  IE_MEM_BUDGET=own (tests/conftest.py: several test processes share one device): the device's total memory minus what
+    THIS process has reserved -- the decision then depends on the engine's own sizes only, and a configuration that does not fit beside its neighbours
+    fails with an out-of-memory error instead of silently running the other mode."""
+    if os.environ.get("IE_MEM_BUDGET") == "own":
+        return torch.cuda.get_device_properties(device).total_memory - torch.cuda.memory_reserved(device)
+    return torch.cuda.mem_get_info(device)[0]
+
+
 def _optimizer_stream(device):
     """The optimizer's HIP stream.  IE_ADAMW_CUS=n (A/B switch, default 0 = an ordinary stream): a stream whose kernels may only use n of the 256 CUs
     (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD), so that the HBM-bound AdamW keeps to its CUs beside the next step's forward products instead of
@@ -148,6 +158,14 @@ class InternLM2Engine:
         self.embed_split = self.tpar.embed_split
         self.tp = tp_size
         self.rs_under_w13 = bool(int(os.environ.get("IE_RS_UNDER_W13", "0")) if rs_under_w13 is None else rs_under_w13)
+        # DIAGNOSTIC (bench.py --hold-cus n; one rank only): where a data-parallel run would launch a bucket's reduce-scatter / all-gather, launch instead n idle
+        # workgroups that each occupy a CU for the time the collective would take at `link` GB/s per xGMI link (a bucket's 1 / 8 per link), on a side stream as
+        # RCCL's kernels run -- prices what the CUs a collective holds cost the products beside it.  No effect on any result.
+        self.hold = None
+        if os.environ.get("IE_HOLD_CUS") and world_size == 1:
+            n_, link_ = (os.environ["IE_HOLD_CUS"].split(",") + ["100"])[:2]
+            self.hold = (int(n_), float(link_))
+            self._hold_rs, self._hold_ag = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
         self._rs_deferred = None
         self.bias = bool(getattr(mc, "attn_bias", False))   # the InternLM-1 block: Wqkv / out_proj with bias (model_type INTERNLM)
         self.ss = tp_ss   # sequence-sharded activations
@@ -313,7 +331,7 @@ class InternLM2Engine:
             # under pipeline parallelism a stage keeps one activation SET per in-flight micro-batch (up to pp, or the interleaved plan's slot count)
             sets = 1 if pp_size == 1 else (min(pp_size - self.pipe.stage, tc.micro_num) if self.nch == 1 else tc.micro_num)
             need = 2 * nslot * self.T * lm.ffn_dim * sets
-            if need + (24 << 30) < torch.cuda.mem_get_info(device)[0]:
+            if need + (24 << 30) < _mem_budget(device):
                 self.a_act = [torch.empty(self.T, lm.ffn_dim, dtype=BF16, device=device) for _ in range(nslot)]
         self.loss_acc = torch.zeros(1, dtype=torch.float32, device=device)  # sum over micro-batches of loss/micro_num
         # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
@@ -492,7 +510,7 @@ class InternLM2Engine:
         need = 2 * M * T * cols
         possible = M > 1 and mc.checkpoint_layers == 0
         if want is None:
-            free = torch.cuda.mem_get_info(self.dev)[0] if self.dev.type == "cuda" else 0
+            free = _mem_budget(self.dev) if self.dev.type == "cuda" else 0
             want = possible and need + (16 << 30) < free
         elif want and not possible:
             raise ValueError("batch_wgrad needs micro_num > 1 and no activation checkpointing")
@@ -605,6 +623,18 @@ class InternLM2Engine:
         b = self.layout.buckets[bi]
         if self.comm.active and b.size:
             self.comm.pending.append(self.comm.reduce_scatter_async(self._full(self.grads, b), self._shard(self.grads, b)))
+        elif self.hold is not None and b.size:
+            self._hold(self._hold_rs, b)
+
+    def _hold(self, side, b):
+        """(diagnostic) n CUs held on `side`, behind what the current stream holds now, for the time bucket b's collective would run on 8 ranks."""
+        n, link = self.hold
+        usec = max(int(2.0 * b.size / 8 / (link * 1e3)), 1)   # bytes per link / (GB/s) -> microseconds
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            K.hold_cus(n, usec)
 
     def _gathered_rows(self, x, product):
         """msp / fsp: `x` [T, C] holds this rank's token rows; product(rows) is a row-wise product that reads x[rows] (a column-parallel linear's forward,
@@ -1321,6 +1351,8 @@ class InternLM2Engine:
                              self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
                 if b.index not in self._wp_buckets and self.comm.active:   # (a weight-parallel layer is gathered when it runs, into its pool slot)
                     self.comm.gathers[b.index] = self.comm.all_gather_async(self._full(self.params, b), self._shard(self.params, b))
+                elif self.hold is not None:
+                    self._hold(self._hold_ag, b)
                 done = torch.cuda.Event()
                 done.record(opt_stream)
                 self._bucket_ready[b.index] = done
@@ -1689,7 +1721,7 @@ class InternLM2Engine:
         W, r = self.job_world, self.job_rank
         sp, wp = self.sp, max(int(getattr(tc, "wp_size", 1) or 1), 1)
         if r == 0:   # files of another layout (or of a larger ISP job) in the folder would be loaded instead of / merged into this save
-            gone = C.remove_stale_shards(folder, 1, sp, 1, job_world=W, layout="isp", wp_world=wp)
+            gone = C.remove_stale_shards(folder, 1, sp, 1, job_world=W, layout="isp", wp_world=wp, dp_world=W // sp)   # (dp shards / plans d >= W / sp of a smaller-sp save go too)
             if gone:
                 print(f"[internevo_amd] save_checkpoint({folder}): removed {len(gone)} files of an earlier layout: {', '.join(gone)}", flush=True)
         if W > 1:                # (the job is the default group under ISP: behind this barrier every rank has been here, nobody writes before the cleanup)

@@ -584,6 +584,11 @@ def gemm_batched(A, B, out, a_kmajor=False, b_kmajor=False, accumulate=False):
     return out
 
 
+def hold_cus(blocks, usec):
+    """(diagnostic) `blocks` idle workgroups, one CU each, for `usec` microseconds on the current stream (ie_hold_cus)."""
+    check(_L().ie_hold_cus(int(blocks), int(usec), _stream()), "ie_hold_cus")
+
+
 def bias_add(y, bias):
     """y [rows, cols] += bias [cols] in place (bf16): the linear biases of the InternLM-1 block (multi_head_attention.py:371-408)."""
     rows, cols, ld = _rows_ld(y)

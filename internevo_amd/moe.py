@@ -33,11 +33,17 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity, top_k=2):
 
 class MoELayer:
     def __init__(self, hidden, ffn, num_experts, tokens, device, capacity_factor=1.0, min_capacity=4, seed=0, layer_index=0, ep_group=None,
-                 ep_size=1, ep_rank=0, tpar=None):
+                 ep_size=1, ep_rank=0, tpar=None, a2a_chunks=None, a2a_overlap=True):
         """tpar (tensorpar.TensorParallel, tp > 1): every expert is a FeedForward over the TENSOR group (gshard_layer.py:421-433 -> modules/mlp.py:40-86):
         `ffn` is then this rank's F / tp units (w1 / w3 cut by rows, w2 by columns), the experts' outputs are partial sums that are all-reduced over the
         group before the combine (RowParallelLinearTorch), and so is the gradient of the dispatched tokens behind the w1 | w3 products
         (ColumnParallelLinearTorch's backward); gate, routing, dispatch and combine run replicated on the same tokens with the same noise.
+        a2a_chunks (expert parallelism only; default 2 where the capacity divides, IE_MOE_A2A_CHUNKS overrides): the exchange of the expert buffers runs in that
+        many pieces along the capacity, piece k + 1's all_to_all under piece k's expert products and piece k's way back under piece k + 1's -- the reference's
+        dispatch / combine exchanges are blocking (gshard_layer.py:465-498, moe/utils.py:8-63).  The buffers are then kept chunk-major (ie_moe_chunk_rows).
+        a2a_overlap=False: the same pieces, every exchange waited for at once (what the overlapped form must equal bit for bit).  The pieces' rows are the
+        same rows either way: outputs and input gradients do not depend on the chunk count; the weight gradients add their pieces up in bf16 like the blocks
+        of the source ranks do, so they depend on it in the last bf16 bit.
         tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
         backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F].
         (The fp8 expert route of round 4 was removed in round 5: it lost 3 % in the step; the e4m3 product itself stays in the library, kernels.gemm_fp8.)"""
@@ -53,6 +59,12 @@ class MoELayer:
         self.ep_group, self.ep, self.ep_rank = ep_group, ep_size, ep_rank
         self.tpar = tpar if tpar is not None and tpar.tp > 1 else None
         self.El = num_experts // ep_size
+        import os
+
+        nch = a2a_chunks if a2a_chunks is not None else int(os.environ.get("IE_MOE_A2A_CHUNKS", "2"))
+        if ep_size <= 1 or nch < 1 or self.C % nch or (self.C // nch) % 8:
+            nch = 1   # (no exchange to hide, or the capacity does not cut into whole 8-row pieces)
+        self.nch, self.overlap = nch, bool(a2a_overlap)
         self.seed, self.layer, self.calls = int(seed), int(layer_index), 0
         self.dev = device
         E, S, C, M, F = self.E, self.S, self.C, hidden, ffn
@@ -63,6 +75,7 @@ class MoELayer:
         self.expert, self.row = torch.empty(2, S, **i32), torch.empty(2, S, **i32)
         self.weight, self.d_weight = torch.empty(2, S, **f32), torch.empty(2, S, **f32)
         self.token_of = torch.empty(E * C, **i32)
+        self.token_of_raw = torch.empty(E * C, **i32) if self.nch > 1 else self.token_of   # (expert-major, as ie_moe_route writes it)
         self.l_aux = torch.empty(1, **f32)
         self.exp_counts = torch.empty(E, **i32)
         self.d_logits = torch.empty(S, E, **f32)
@@ -85,12 +98,29 @@ class MoELayer:
     # ---- expert parallel exchange: [ep][El*C rows] send blocks <-> [ep][El*C] received (rank-major); the local experts then see,
     # for local expert j, the rows {g*El*C + j*C .. +C} of every source rank g -- processed as ep separate [C, M] GEMM operands
     def _a2a(self, send, recv):
+        """One piece of the expert exchange, started: -> the Work to wait for (waited for here unless the exchanges are overlapped)."""
         from .comm import backend_for
 
         if getattr(self, "_be", None) is None:
             self._be = backend_for(self.ep_group)
-        self._be.all_to_all(recv, send, self.ep_group).wait()
-        return recv
+        w = self._be.all_to_all(recv, send, self.ep_group)
+        if not self.overlap:
+            w.wait()
+        return w
+
+    def _pieces(self):
+        """Row ranges of the exchange pieces in the chunk-major expert buffers: piece k = rows [k E Cn, (k + 1) E Cn) = [ep][El][Cn] on the sending side,
+        [source rank][El][Cn] on the receiving side."""
+        n = self.E * (self.C // self.nch)
+        return [slice(k * n, (k + 1) * n) for k in range(self.nch)]
+
+    def _expert_blocks(self, piece):
+        """(rows, experts-batch shape) of the GEMM operands inside one piece: with ONE local expert all source ranks' rows are one operand of ep Cn rows;
+        with several, one strided batch over the local experts per source rank (as the unchunked layout had per source rank)."""
+        Cn, El, ep = self.C // self.nch, self.El, self.ep
+        if El == 1:
+            return [(piece, (1, ep * Cn))]
+        return [(slice(piece.start + g * El * Cn, piece.start + (g + 1) * El * Cn), (El, Cn)) for g in range(ep)]
 
     def forward(self, x, wg, w13, w2, out, noise=None):
         """x bf16 [S, M] -> out bf16 [S, M]; returns the device scalar l_aux (bf16-rounded fp32).  noise: fp32 [S, E] to inject."""
@@ -103,27 +133,54 @@ class MoELayer:
         self.x = x
         check(L.ie_moe_gate_fwd(K._p(x), x.stride(0), K._p(wg), K._p(noise), S, M, E, K._p(self.logits), K._p(self.gates), K._p(self.expert), st()),
               "ie_moe_gate_fwd")
-        check(L.ie_moe_route(K._p(self.gates), K._p(self.expert), S, E, C, K._p(self.row), K._p(self.weight), K._p(self.token_of), K._p(self.l_aux),
+        check(L.ie_moe_route(K._p(self.gates), K._p(self.expert), S, E, C, K._p(self.row), K._p(self.weight), K._p(self.token_of_raw), K._p(self.l_aux),
                              K._p(self.exp_counts), st()), "ie_moe_route")
+        if self.nch > 1:   # the expert buffers chunk-major from here on: row / token_of are only ever used as indices into them
+            check(L.ie_moe_chunk_rows(K._p(self.row), K._p(self.token_of_raw), K._p(self.token_of), S, E, C, self.nch, st()), "ie_moe_chunk_rows")
         check(L.ie_moe_dispatch(K._p(x), x.stride(0), K._p(self.token_of), E * C, M, K._p(self.ein), st()), "ie_moe_dispatch")
-        ein = self._a2a(self.ein, self.xin) if self.ep > 1 else self.ein
-        eo = self.xout if self.ep > 1 else self.eo
-        # the El local experts run as ONE strided-batched GEMM per product (and per source rank under expert parallelism): expert j's
-        # [C, M] block x its own weights; the SwiGLU gate covers all rows at once
-        El, ep = self.El, self.ep
-        for g in range(ep):
-            rows = slice(g * El * C, (g + 1) * El * C)
-            self._products(ein[rows].view(El, C, M), w13, self.h13[rows].view(El, C, 2 * F), "w13")
-        K.swiglu_fwd(self.h13[:, :F], self.h13[:, F:], self.act)
-        for g in range(ep):
-            rows = slice(g * El * C, (g + 1) * El * C)
-            self._products(self.act[rows].view(El, C, F), w2, eo[rows].view(El, C, M), "w2")
-        if self.tpar is not None:
-            self.tpar.all_reduce_sum(eo)          # w2 is row-parallel: every tensor rank holds a partial sum of the experts' outputs
-        if self.ep > 1:
-            self._a2a(self.xout, self.eo)
+        if self.ep == 1:
+            self._experts_fwd(self.ein, self.eo, slice(0, E * C), [(slice(0, E * C), (self.El, C))], w13, w2)
+        else:
+            # piece k + 1 is on its way while the experts work on piece k, piece k returns while they work on piece k + 1
+            pieces = self._pieces()
+            there = [self._a2a(self.ein[p], self.xin[p]) for p in pieces]
+            back = []
+            for p, w in zip(pieces, there):
+                w.wait()
+                self._experts_fwd(self.xin, self.xout, p, self._expert_blocks(p), w13, w2)
+                back.append(self._a2a(self.xout[p], self.eo[p]))
+            for w in back:
+                w.wait()
         check(L.ie_moe_combine_fwd(K._p(self.eo), K._p(self.row), K._p(self.weight), S, M, K._p(out), out.stride(0), st()), "ie_moe_combine_fwd")
         return self.l_aux
+
+    def _experts_fwd(self, ein, eo, rows, blocks, w13, w2):
+        """The local experts on the rows `rows` of their buffers: w1 | w3 products, the gate, w2 products (+ the tensor group's sum of the partial outputs)."""
+        M, F = self.M, self.F
+        for r, (nb, nr) in blocks:
+            self._products(ein[r].view(nb, nr, M), w13, self.h13[r].view(nb, nr, 2 * F), "w13")
+        K.swiglu_fwd(self.h13[rows, :F], self.h13[rows, F:], self.act[rows])
+        for r, (nb, nr) in blocks:
+            self._products(self.act[r].view(nb, nr, F), w2, eo[r].view(nb, nr, M), "w2")
+        if self.tpar is not None:
+            self.tpar.all_reduce_sum(eo[rows])          # w2 is row-parallel: every tensor rank holds a partial sum of the experts' outputs
+
+    def _experts_bwd(self, d_eo, ein, d_ein, rows, blocks, w13, w2, d_w13, d_w2, accumulate):
+        """Backward of _experts_fwd on the same rows: input gradients of w2, its weight gradient (the blocks of one expert add up), the gate's backward,
+        input gradients of w1 | w3 (summed over the tensor group under the weight gradient), their weight gradient."""
+        M, F = self.M, self.F
+        for r, (nb, nr) in blocks:      # dgrad of w2: d_act[e] = d_eo[e] @ w2[e]
+            K.gemm_batched(d_eo[r].view(nb, nr, M), w2, self.d_act[r].view(nb, nr, F), b_kmajor=True)
+        for g, (r, (nb, nr)) in enumerate(blocks):
+            K.gemm_batched(d_eo[r].view(nb, nr, M), self.act[r].view(nb, nr, F), d_w2, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
+        K.swiglu_bwd(self.d_act[rows], self.h13[rows, :F], self.h13[rows, F:], self.d_h13[rows, :F], self.d_h13[rows, F:])
+        for r, (nb, nr) in blocks:
+            K.gemm_batched(self.d_h13[r].view(nb, nr, 2 * F), w13, d_ein[r].view(nb, nr, M), b_kmajor=True)
+        h_ = self.tpar.all_reduce_sum_async(d_ein[rows]) if self.tpar is not None else None   # (w1 | w3 are column-parallel)
+        for g, (r, (nb, nr)) in enumerate(blocks):
+            K.gemm_batched(self.d_h13[r].view(nb, nr, 2 * F), ein[r].view(nb, nr, M), d_w13, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
+        if h_ is not None:
+            h_.wait()
 
     def _products(self, a, w, out, which):
         """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch."""
@@ -136,26 +193,18 @@ class MoELayer:
         L, st = K._L(), K._stream
         check(L.ie_moe_combine_bwd(K._p(dout), dout.stride(0), K._p(self.eo), K._p(self.token_of), K._p(self.weight), E * C, S, M, K._p(self.d_eo),
                                    K._p(self.d_weight), st()), "ie_moe_combine_bwd")
-        d_eo = self._a2a(self.d_eo, self.d_xout) if self.ep > 1 else self.d_eo
-        ein = self.xin if self.ep > 1 else self.ein
-        d_ein = self.d_xin if self.ep > 1 else self.d_ein
-        El, ep = self.El, self.ep
-        blocks = [slice(g * El * C, (g + 1) * El * C) for g in range(ep)]
-        for rows in blocks:      # dgrad of w2: d_act[e] = d_eo[e] @ w2[e]
-            K.gemm_batched(d_eo[rows].view(El, C, M), w2, self.d_act[rows].view(El, C, F), b_kmajor=True)
-        for g, rows in enumerate(blocks):   # the blocks of one expert coming from different source ranks add up
-            K.gemm_batched(d_eo[rows].view(El, C, M), self.act[rows].view(El, C, F), d_w2, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
-        K.swiglu_bwd(self.d_act, self.h13[:, :F], self.h13[:, F:], self.d_h13[:, :F], self.d_h13[:, F:])
-        for rows in blocks:
-            K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), w13, d_ein[rows].view(El, C, M), b_kmajor=True)
-        if self.tpar is not None:                 # w1 | w3 are column-parallel: the input gradient is summed over the tensor group, under the weight gradient
-            h_ = self.tpar.all_reduce_sum_async(d_ein)
-        for g, rows in enumerate(blocks):
-            K.gemm_batched(self.d_h13[rows].view(El, C, 2 * F), ein[rows].view(El, C, M), d_w13, a_kmajor=True, b_kmajor=True, accumulate=accumulate or g > 0)
-        if self.tpar is not None:
-            h_.wait()
-        if self.ep > 1:
-            self._a2a(self.d_xin, self.d_ein)
+        if self.ep == 1:
+            self._experts_bwd(self.d_eo, self.ein, self.d_ein, slice(0, E * C), [(slice(0, E * C), (self.El, C))], w13, w2, d_w13, d_w2, accumulate)
+        else:
+            pieces = self._pieces()
+            there = [self._a2a(self.d_eo[p], self.d_xout[p]) for p in pieces]
+            back = []
+            for k, (p, w) in enumerate(zip(pieces, there)):
+                w.wait()
+                self._experts_bwd(self.d_xout, self.xin, self.d_xin, p, self._expert_blocks(p), w13, w2, d_w13, d_w2, accumulate or k > 0)
+                back.append(self._a2a(self.d_xin[p], self.d_ein[p]))
+            for w in back:
+                w.wait()
         check(L.ie_moe_dispatch_bwd(K._p(self.d_ein), K._p(self.row), K._p(self.token_of), S, M, K._p(dx), dx.stride(0), st()), "ie_moe_dispatch_bwd")
         check(L.ie_moe_gate_bwd(K._p(self.x), self.x.stride(0), K._p(wg), K._p(self.gates), K._p(self.expert), K._p(self.row), K._p(self.d_weight),
                                 K._p(self.exp_counts), K._p(loss_scale_dev), float(aux_factor), S, M, E, K._p(self.d_logits), K._p(dx), dx.stride(0),

@@ -196,17 +196,18 @@ class RingAttention:
     def forward(self, q, kv, pl, out, lse):
         """q [Tl, hq, d], kv [Tl, 2, hkv, d] (this rank's tokens, all heads) -> out [Tl, hq, d] bf16, lse [hq, Tl] fp32 (of the whole rows)."""
         Tl, hq, d, Lq = self.Tl, self.hq, self.d, pl["Lq"]
+        # hop 1 leaves BEFORE the own block's kernel is launched (the exchange is ordered behind what the stream held when it was issued, not behind what
+        # follows): it travels under the own block; hop s + 1 is issued the moment block s is here, and travels under block s's rectangle
+        w = self._hop(kv, self.kv_ring[1]) if self.sp > 1 else None
         K.flash_attn_fwd(q, kv[:, 0], kv[:, 1], pl["cu_local_dev"], pl["max_local"], self.scale, True, out, lse)
-        held, merged = kv, False
+        merged = False
         for s in range(1, self.sp):
-            w = self._hop(held, self.kv_ring[s % 2])          # the block moves on while the rectangle of the block that is here is computed ...
-            _, koff, Lk = pl["steps"][s - 1]
-            if s > 1 and pl["steps"][s - 2][2]:               # ... i.e. the one received in the previous hop
-                merged = self._fold(q, held, pl, s - 2, out, lse, merged)
             w.wait()
-            held = self.kv_ring[s % 2]
-        if self.sp > 1 and pl["steps"][self.sp - 2][2]:
-            merged = self._fold(q, held, pl, self.sp - 2, out, lse, merged)
+            held = self.kv_ring[s % 2]                        # the block of rank j - s
+            if s + 1 < self.sp:                               # (into the buffer of block s - 1, whose rectangle was launched in the previous turn)
+                w = self._hop(held, self.kv_ring[(s + 1) % 2])
+            if pl["steps"][s - 1][2]:
+                merged = self._fold(q, held, pl, s - 1, out, lse, merged)
         if merged:
             K.cast(self.acc[:Lq], out.dtype, out[:Lq])
             lse[:, :Lq].copy_(self.lse_acc[: hq * Lq].view(hq, Lq))
@@ -225,31 +226,38 @@ class RingAttention:
     def backward(self, dout, q, kv, out, lse, pl, dq, dkv, delta_ws=None):
         """dout, q, out [Tl, hq, d]; kv [Tl, 2, hkv, d]; lse [hq, Tl] (forward's results) -> dq [Tl, hq, d], dkv [Tl, 2, hkv, d] (bf16, overwritten)."""
         Tl, hq, hkv, d, Lq, sp = self.Tl, self.hq, self.hkv, self.d, pl["Lq"], self.sp
+        # Two rings: the K / V blocks (as forward: hop 1 leaves before the own block's kernels are launched, hop s + 1 the moment block s is here) and, one
+        # rectangle behind them, the blocks' fp32 dK / dV sums -- a block's sums can only move on once this rank has added its share, so hop s + 1 of the sums
+        # is issued behind rectangle s's accumulation and waited for only where rectangle s + 1's accumulation needs it: both exchanges run under rectangles.
+        wk = self._hop(kv, self.kv_ring[1]) if sp > 1 else None
         K.flash_attn_bwd(dout, q, kv[:, 0], kv[:, 1], out, lse, pl["cu_local_dev"], pl["max_local"], self.scale, True, dq, dkv[:, 0], dkv[:, 1], delta_ws)
         if sp == 1:
             return dq, dkv
         home = self.dkv_acc[2]
         K.cast(dkv, home.dtype, home)                          # the own block's sums start with the own queries' share
+        wa = self._hop(home, self.dkv_acc[1])
         any_rect = any(Lk for _, _, Lk in pl["steps"])
         if any_rect:
             dq_acc = self.dq_acc[: Lq * hq * d]
             K.cast(dq[:Lq].reshape(-1), dq_acc.dtype, dq_acc)
             lse_sub = lse[:, :Lq].contiguous()
             dq_p = self.dq_p[: Lq * hq * d].view(Lq, hq, d)
-        held_kv, held_acc = kv, home
         for s in range(1, sp):
-            wk = self._hop(held_kv, self.kv_ring[s % 2])
-            wa = self._hop(held_acc, self.dkv_acc[s % 2])
             wk.wait()
-            wa.wait()
-            held_kv, held_acc = self.kv_ring[s % 2], self.dkv_acc[s % 2]
+            held_kv = self.kv_ring[s % 2]
+            if s + 1 < sp:
+                wk = self._hop(held_kv, self.kv_ring[(s + 1) % 2])
             _, koff, Lk = pl["steps"][s - 1]
             if Lk:
                 K.flash_attn_bwd_x(dout[:Lq], q[:Lq], held_kv[:, 0], held_kv[:, 1], out[:Lq], lse_sub, pl["cu_q_dev"], pl["cu_k_dev"][s - 1], Lq, Lk, self.scale,
                                    dq_p, self.dkv_p[:, 0], self.dkv_p[:, 1], delta_ws)
                 K.acc_bf16(dq_acc, dq_p.reshape(-1))
+            wa.wait()                                          # block s's sums, with the shares of the ranks they have passed
+            held_acc = self.dkv_acc[s % 2]
+            if Lk:
                 K.acc_bf16(held_acc[koff:].reshape(-1), self.dkv_p[koff:].reshape(-1))
-        self._hop(held_acc, home).wait()                       # the last hop brings every block's sums home
+            wa = self._hop(held_acc, self.dkv_acc[(s + 1) % 2] if s + 1 < sp else home)   # (the last hop brings every block's sums home)
+        wa.wait()
         K.cast(home, dkv.dtype, dkv)
         if any_rect:
             K.cast(dq_acc, dq.dtype, dq[:Lq].reshape(-1))

@@ -13,6 +13,9 @@ What an sp-rank ISP run of the reference computes, as its code reads and as its 
         chunk boundaries;
       - InternLM-1 (multi_head_attention.py:394, :634-660): `self.inner_attn(qkv)` IS DistributedAttention(SelfAttention): the qkv-packed all-to-all
         gathers the sequence and scatters the heads -> causal attention over the WHOLE sequence (with the restarting positions).
+      - InternLM2 WITH the exchange (round 6, train_isp2u_*): tests/golden/make_golden.py wraps the block's own CrossAttention in the reference's own
+        DistributedAttention (harness-side, the keywords of the packed path: q [b, S/sp, h, d] <-> [b, S, h/sp, d], kv [b, S/sp, 2, hkv, d] <-> [b, S, 2, hkv/sp, d]),
+        so the reference executes the Ulysses exchange of a GQA block on its CPU path -> causal attention over the WHOLE sequence, restarting positions.
   * gradient rule (engine._apply_isp_grad_rule): ISPLinear weights AND biases are reduce-scattered with AVG over the weight group (model/utils.py:556-561) and
     all-reduced AVG over WEIGHT_DATA (hybrid_zero_optim.py:98,169); norm weights AVG over the weight group (:318-324) -- per-rank gradients that each cover
     1 / sp of the tokens, so the result is 1 / sp of the mean gradient; embedding and head (the "embed_head" group, train/utils.py:42-43, reduced over DATA)
@@ -28,11 +31,13 @@ import torch
 from . import ops as O
 
 
-def isp_positions(seq_len, sp, family):
-    """(indexes [S], cu_seqlens) under which the single-process varlen model equals the reference's CPU-runnable sp-rank ISP forward."""
+def isp_positions(seq_len, sp, family, ulysses=False):
+    """(indexes [S], cu_seqlens) under which the single-process varlen model equals the reference's CPU-runnable sp-rank ISP forward.
+    ulysses: the InternLM2 runs whose CrossAttention the harness wrapped in the reference's DistributedAttention (make_golden.py `ulysses=True`,
+    train_isp2u_*): attention over the gathered sequence as for the InternLM-1 block, positions still restarting per rank."""
     chunk = seq_len // sp
     idx = torch.arange(chunk, dtype=torch.int64).repeat(sp)
-    if family == "INTERNLM":
+    if family == "INTERNLM" or ulysses:
         return idx, torch.tensor([0, seq_len], dtype=torch.int32)
     return idx, (torch.arange(sp + 1, dtype=torch.int32) * chunk)
 
@@ -41,8 +46,8 @@ class OracleISPTrainer:
     """base: an OracleTrainer (InternLM2 / LLAMA2) or an OracleMoETrainer of the dense InternLM-1 model -- its parameters, fp32 state, scaler and
     schedules are used; this class runs the step with the ISP positions, the gradient rule and the two clipping groups."""
 
-    def __init__(self, base, sp):
-        self.base, self.sp = base, sp
+    def __init__(self, base, sp, ulysses=False):
+        self.base, self.sp, self.ulysses = base, sp, ulysses
         self.family = "INTERNLM" if "embedding.weight" in base.params else "INTERNLM2"
         self.embed_head = ("embedding.weight", "head.weight") if self.family == "INTERNLM" else ("tok_embeddings.weight", "output.weight")
 
@@ -64,7 +69,7 @@ class OracleISPTrainer:
         for p in b.params.values():
             p.grad = None
         M, S = batch["input_ids"].shape
-        idx, cu = isp_positions(S, sp, self.family)
+        idx, cu = isp_positions(S, sp, self.family, self.ulysses)
         total = 0.0
         for i in range(M):
             loss = self._loss(batch["input_ids"][i], labels[i], idx, cu) / M

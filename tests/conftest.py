@@ -9,6 +9,10 @@ import pytest
 # threads per process (`profiles/r04_gpu_suite_timing.md`).  Set before torch is imported anywhere, inherited by every child process.
 for _k, _v in (("OMP_NUM_THREADS", "4"), ("MKL_NUM_THREADS", "4"), ("OMP_WAIT_POLICY", "PASSIVE")):
     os.environ.setdefault(_k, _v)
+# Four xdist workers (and their spawned ranks) share ONE device: the engine's two memory-dependent switches (batched weight gradients, the kept SwiGLU product:
+# engine.py `_mem_budget`) must not depend on what the neighbouring tests hold at that moment.  Under test they are decided from the device's total memory
+# minus what THIS process holds; a test that then does not fit fails loudly (out of memory) instead of silently running another mode.
+os.environ.setdefault("IE_MEM_BUDGET", "own")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -41,8 +45,14 @@ _LONGEST_FIRST = ("test_isp_config3_layout_seq32768_sp8_at_7b_width", "test_sequ
                   "test_weight_parallel_step_equals_resident_step", "test_moe_engine_expert_parallel_on_two_ranks_matches_the_reference_rules")
 
 
+# ... and these LAST, when the other workers are running out of work: four staged ranks on one device (each imports torch and builds an engine) beside three
+# busy workers hung once until its queue timeout (round 5); at the end of the run it has the box almost to itself.
+_LAST = ("test_moe_engine_tensor_parallel_2_x_expert_parallel_2_on_four_ranks",)
+
+
 def pytest_collection_modifyitems(config, items):
     rank = {n: i for i, n in enumerate(_LONGEST_FIRST)}
+    rank.update({n: len(_LONGEST_FIRST) + 1 + i for i, n in enumerate(_LAST)})
     if os.environ.get("IE_TEST_FULL") != "1":   # parametrisations whose layout another test of the default run covers (each names it): IE_TEST_FULL=1 runs them too
         for it in items:
             if it.get_closest_marker("extended") is not None:

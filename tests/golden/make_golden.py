@@ -31,6 +31,8 @@ What it pins
   eval.json            (--eval)  evaluate_on_val_dls of the reference on its default validation set, on two sets of weights
   (--run-mp isp2_* / isp2v1_*)  2-process ISP runs of the reference (InternLM2 / InternLM-1 blocks), fp32 and bf16 -> train_isp2*_rank{0,1}.json: pin the gradient rule, the
                        two clipping groups of a bf16 ISP run and (InternLM-1: its CPU path runs DistributedAttention) the exchange itself (oracle/isp.py)
+  (--run-mp isp2u_*)   the same on InternLM2 blocks with the reference's DistributedAttention wrapped round the block's CrossAttention by the harness (round 6): the
+                       Ulysses exchange of a GQA InternLM2 block executed by the reference -> train_isp2u_*_rank{0,1}.json
 
 The CPU accelerator shim is the one described in SURVEY.md section 8(c): the reference has no CPU backend,
 so the cached CUDA_Accelerator instance is re-pointed at torch CPU calls before launch().
@@ -185,7 +187,7 @@ NUM_SAMPLES = 4000  # the reference hard-codes 1_000_000 synthetic samples (buil
 
 
 def tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp=1, wp=1, model_type="INTERNLM2_PUBLIC", tp=1,
-                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False, pp=1, chunks=1, tp_mode="mtp"):
+                num_experts=1, capacity_factor=1.0, embed_grad_scale=1, norm_head=False, pp=1, chunks=1, tp_mode="mtp", ulysses=False):   # (ulysses: run_training's patch)
     cfg = _tiny_config(dtype, use_packed, seq_len, hidden, heads, kv_heads, vocab, layers, micro_num, total_steps, sp, wp, model_type, tp)
     if tp > 1 and tp_mode != "mtp":   # "msp" / "fsp": Megatron tensor parallelism with sequence-sharded activations between the linears
         cfg["parallel"]["tensor"]["mode"] = tp_mode
@@ -385,6 +387,29 @@ def run_training(tag, dtype, cfg_kw, port, rank=0, world=1):
     gpc.get_cpu_group = lambda mode: (_cpu_group(mode) if gpc._cpu_groups.get(mode) is not None else gpc.get_group(mode))
 
     model = initialize_model()
+    if cfg_kw.get("ulysses"):
+        # HARNESS-SIDE PATCH (round-5 review item 4a): the InternLM2 block's CPU-runnable (unpacked) path calls `self.inner_cross_attn(q, kv)`
+        # directly (modeling_internlm2.py:215-229) -- only its packed flash path goes through `self.attn` = DistributedAttention (:171-172, :446-468), which
+        # needs flash-attn.  Wrap the module's OWN CrossAttention in the reference's OWN DistributedAttention (multi_head_attention.py:56-135; its _SeqAllToAll
+        # over the harness's all_gather-emulated all_to_all), called with the keywords the packed path uses: q [b, S/sp, h, d] -> [b, S, h/sp, d], kv likewise,
+        # causal attention over the WHOLE sequence, context back to [b, S/sp, h, d] -- the Ulysses exchange of an InternLM2 block, executed by the reference.
+        from internlm.core.context import ParallelMode as _PM
+        from internlm.model.modules.multi_head_attention import DistributedAttention
+
+        class _Keywords(torch.nn.Module):
+            def __init__(self, dist_attn):
+                super().__init__()
+                self.dist_attn = dist_attn
+
+            def forward(self, q, kv, **kw):
+                return self.dist_attn(q=q, kv=kv, **kw)
+
+        n_patched = 0
+        for layer in model.model.layers:
+            mha = layer.attention
+            mha.inner_cross_attn = _Keywords(DistributedAttention(mha.inner_cross_attn, sequence_process_group=gpc.get_group(_PM.TENSOR)))
+            n_patched += 1
+        assert n_patched == cfg_kw["layers"]
     # overwrite the reference's random init with the closed-form one (same tensors on every side of the comparison)
     inner = model.model if not isinstance(model, torch.nn.ModuleList) else None   # (a pipeline stage with several chunks: a list of wrapped models)
     sp, wp = cfg_kw.get("sp", 1), cfg_kw.get("wp", 1)
@@ -1063,6 +1088,10 @@ RUNS_MP = {
     "pp2_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2), 2),
     "pp2i_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2, chunks=2), 2),
     "pp2i_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=4, micro_num=4, total_steps=6, pp=2, chunks=2), 2),
+    # the two-process ISP shape on InternLM2 blocks WITH the Ulysses exchange executed by the reference (run_training's harness-side patch: the block's CrossAttention
+    # inside the reference's DistributedAttention): causal attention over the gathered sequence, GQA heads scattered (4 q / 2 kv heads over 2 ranks)
+    "isp2u_fp32": ("torch.float32", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2, ulysses=True), 2),
+    "isp2u_bf16": ("torch.bfloat16", dict(use_packed=False, seq_len=128, hidden=256, heads=4, kv_heads=2, vocab=512, layers=2, micro_num=2, total_steps=6, sp=2, wp=2, ulysses=True), 2),
 }
 
 

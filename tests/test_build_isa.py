@@ -37,6 +37,12 @@ def test_kernels_with_untracked_lds_reads_use_no_scratch(tmp_path):
             checked += 1
             assert int(scratch) == 0 and int(spills) == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs next to untracked LDS reads"
     assert checked >= 10, checked
+    # the persistent frame (gemm_p5_k<B_KM, EPI>): its k-major instantiations read B with the same untracked loads -- plain and with the SwiGLU backward in
+    # the epilogue (round 6: that epilogue first overflowed the register file and parked the fragment ADDRESSES of the k-loop in scratch)
+    p5 = re.findall(r"\.name:\s+(\S*gemm_p5_kILb1E\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(p5) >= 2, p5
+    for name, scratch, spills in p5:
+        assert int(scratch) == 0 and int(spills) == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs next to untracked LDS reads"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -125,13 +125,14 @@ def test_internlm1_dense_engine_resumes_from_the_reference_checkpoint_and_its_ow
 
 
 # ---------------------------------------------------------------------------------------------------- ISP on two ranks against the reference's bf16 runs
-def _isp_batch(batch, sp, family):
+def _isp_batch(batch, sp, family, ulysses=False):
     """The micro-batches of the reference's CPU-runnable ISP path (oracle.isp.isp_positions: positions restart in every rank's chunk; InternLM2's
-    attention stays inside the chunk, the InternLM-1 block's runs over the gathered sequence) as a packed batch of this engine."""
+    attention stays inside the chunk, the InternLM-1 block's -- and, `ulysses`, the InternLM2 block's under the harness's DistributedAttention wrap -- runs
+    over the gathered sequence) as a packed batch of this engine."""
     from oracle.isp import isp_positions
 
     M, S = batch["input_ids"].shape
-    idx, cu = isp_positions(S, sp, family)
+    idx, cu = isp_positions(S, sp, family, ulysses)
     return dict(batch, indexes=idx.unsqueeze(0).repeat(M, 1), cu_seqlens=[cu.clone() for _ in range(M)])
 
 
@@ -144,19 +145,20 @@ def _isp_worker(rank, world, port, q, tag, wp_mode):
         from internevo_amd.engine import InternLM2Engine
         from oracle.model import formula_init, moe_formula_init
 
+        tag, _, attn = tag.partition("+")   # "isp2u_bf16+ring": the same reference run retraced with ring attention instead of the head exchange
         gold = json.load(open(os.path.join(G, f"train_{tag}_rank{rank}.json")))
         c = gold["config"]
         family = c.get("model_type", "INTERNLM2_PUBLIC")
         cfg = _gold_cfg(gold)
         cfg.train.wp_size = c["wp"]
         eng = InternLM2Engine(cfg, dev, None, world, rank, init_fn=moe_formula_init if family == "INTERNLM" else formula_init, sp_size=c["sp"],
-                              weight_parallel=wp_mode)
-        assert eng.sp == 2 and eng.wp_mode == wp_mode and eng.isp_groups and eng.bias == (family == "INTERNLM")
+                              weight_parallel=wp_mode, sp_attention=attn or None)
+        assert eng.sp == 2 and eng.wp_mode == wp_mode and eng.isp_groups and eng.bias == (family == "INTERNLM") and eng.ring_mode == (attn == "ring")
         loader = iter(SyntheticLoader(c["seq_len"], 1, c["micro_num"], True, gold["num_samples"], data_rank=eng.seqpar.data_rank, data_world_size=eng.seqpar.data_world))
         out = []
         for _ in gold["steps"]:
             batch, labels = next(loader)
-            loss = float(eng.forward_backward(_isp_batch(batch, c["sp"], family), labels))
+            loss = float(eng.forward_backward(_isp_batch(batch, c["sp"], family, bool(c.get("ulysses"))), labels))
             eng.step()
             st = eng.read_state()
             out.append((loss, dict(st.group_norms), st.loss_scale, st.skip))
@@ -167,23 +169,31 @@ def _isp_worker(rank, world, port, q, tag, wp_mode):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("tag,wp_mode", [("isp2_bf16", True), ("isp2v1_bf16", True), ("isp2v1_bf16", False)],
-                         ids=["internlm2_weight_parallel", "internlm1_weight_parallel", "internlm1_resident"])
+@pytest.mark.parametrize("tag,wp_mode", [("isp2_bf16", True), ("isp2v1_bf16", True), ("isp2v1_bf16", False), ("isp2u_bf16", True), ("isp2u_bf16", False),
+                                         ("isp2u_bf16+ring", False)],
+                         ids=["internlm2_weight_parallel", "internlm1_weight_parallel", "internlm1_resident", "internlm2_ulysses_weight_parallel", "internlm2_ulysses_resident",
+                              "internlm2_ring_attention_vs_the_reference_ulysses_run"])
 def test_isp_engine_retraces_the_reference_bf16_isp_runs(dev, backend, tag, wp_mode):  # noqa: F811
     """The HIP engine with tensor = dict(size=2, mode="isp") x weight = dict(size=2) on two ranks -- the Ulysses exchanges (seqpar.py), ISP's weight
     parallelism (two-slot pool, prefetch, reduce-scatter per micro-batch) or the resident layout, the gradient rule and the two clipping groups --
     against the UNMODIFIED reference's two-process bf16 ISP run of the same model, data and closed-form weights (make_golden.py --run-mp isp2_bf16 /
     isp2v1_bf16): six steps, loss <= 1e-3 (north_star), BOTH group norms <= 2e-2, loss scale, no skip; the trained parameters against the
-    reference's per-parameter fingerprint (its ranks hold weight-parallel row shards: summed over the ranks)."""
+    reference's per-parameter fingerprint (its ranks hold weight-parallel row shards: summed over the ranks).
+    isp2u_bf16 (round 6): the run in which the REFERENCE executes the Ulysses exchange of the GQA InternLM2 block (its DistributedAttention wrapped round the
+    block's CrossAttention by the harness, make_golden.py `ulysses=True`): the engine's head exchange around the flash kernels (seqpar.SeqParallel; 4 q / 2 kv
+    heads over two ranks, causal attention over the gathered sequence) against it -- until round 5 this combination was pinned HIP-vs-HIP only; "+ring": ring
+    attention (seqpar.RingAttention, the north star's mode, which the reference lacks) retraces the same reference run: its result must be DistributedAttention's."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_isp_worker, args=(r, world, 29771 + (tag == "isp2_bf16") + 2 * wp_mode, q, tag, wp_mode)) for r in range(world)]
+    procs = [ctx.Process(target=_isp_worker, args=(r, world, 29771 + (tag == "isp2_bf16") + 2 * wp_mode + 4 * tag.startswith("isp2u_bf16") + 8 * tag.endswith("ring"), q, tag, wp_mode))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(q, procs, world), key=lambda x: x[0])
     for p in procs:
         p.join(60)
+    tag = tag.partition("+")[0]
     gold = [json.load(open(os.path.join(G, f"train_{tag}_rank{r}.json"))) for r in range(world)]
     worst_loss = worst_norm = 0.0
     for k, w in enumerate(gold[0]["steps"]):

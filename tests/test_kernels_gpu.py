@@ -1005,12 +1005,15 @@ def test_ffn_products_with_the_swiglu_epilogues_equal_the_two_launch_path_bit_fo
     w2 = (torch.randn(Kd, F, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     dy = torch.randn(M, Kd, device=dev, generator=g).to(torch.bfloat16)
     out = {}
-    for mode in (0, 3):    # 0: two launches everywhere; 3: both products fused (the default, 1, fuses the forward product only)
-        L.ie_tune_ffn_fuse(mode)
+    for mode in (0, 3, 5):    # 0: two launches everywhere; 3: both products fused on every shape of the schedule; 5 (the default): the forward product, and the
+        L.ie_tune_ffn_fuse(mode)   # input-gradient product where the persistent frame takes it (gemm_p5_k<true, 2>: whole tiles, more than one round)
         try:
             if mode == 3:
                 fused = (int(L.ie_gemm_swiglu_is_fused(0, M, F, Kd)), int(L.ie_gemm_swiglu_is_fused(1, M, F, Kd)))
                 assert fused == ((0, 0) if F == 512 else (1, 1)), fused
+            if mode == 5:
+                fused = (int(L.ie_gemm_swiglu_is_fused(0, M, F, Kd)), int(L.ie_gemm_swiglu_is_fused(1, M, F, Kd)))
+                assert fused == ((0, 0) if F == 512 else (1, 1 if M % 256 == 0 else 0)), fused
             h13 = torch.full((M, 2 * F), 7.0, device=dev, dtype=torch.bfloat16)
             act = torch.full((M, F), 7.0, device=dev, dtype=torch.bfloat16)
             dh13 = torch.full((M, 2 * F), 7.0, device=dev, dtype=torch.bfloat16)
@@ -1020,9 +1023,10 @@ def test_ffn_products_with_the_swiglu_epilogues_equal_the_two_launch_path_bit_fo
             torch.cuda.synchronize()
             out[mode] = (h13, act, dh13)
         finally:
-            L.ie_tune_ffn_fuse(1)
-    for name, a, b in zip(("h13", "act", "dh13"), out[0], out[3]):
-        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ, max |diff| {float((a.float() - b.float()).abs().max())}"
+            L.ie_tune_ffn_fuse(5)
+    for other in (3, 5):
+        for name, a, b in zip(("h13", "act", "dh13"), out[0], out[other]):
+            assert torch.equal(a, b), f"mode {other} {name}: {int((a != b).sum())} of {a.numel()} elements differ, max |diff| {float((a.float() - b.float()).abs().max())}"
     # and the two-launch path is the plain product + the elementwise kernels
     ref = Kk.linear_fwd(x, w13)
     assert torch.equal(out[0][0], ref) and torch.equal(out[0][1], Kk.swiglu_fwd(ref[:, :F], ref[:, F:]))

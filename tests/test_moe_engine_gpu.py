@@ -563,7 +563,7 @@ def test_moe_engine_tensor_parallel_on_two_ranks_matches_the_reference_rules(dev
         assert got.shape == full.shape, (n, got.shape, full.shape)
         worst = max(worst, float(np.abs(got - full).max()))
     print("max |param diff| of the re-assembled shards vs the forced one-rank oracle after training:", worst)
-    assert worst <= 1e-1
+    assert worst <= 1e-2   # (measured 4.5e-3 on weights of std 0.02 after the training steps: profiles/r05_moe_tensor_parallel_parity.log)
 
 
 def _tp_dp_engine_worker(rank, world, port, q, steps):
@@ -611,10 +611,7 @@ def _tp_dp_engine_worker(rank, world, port, q, steps):
         dist.destroy_process_group()
 
 
-@pytest.mark.extended   # (four staged ranks on one GPU beside three other xdist workers: passed in two full-suite runs and stand-alone, hung once on a slow box until its queue
-#                         timeout -- a suite run with -x must not depend on it.  IE_TEST_FULL=1 runs it; its group logic also runs on CPU (tests/test_moe_tp_host.py), its
-#                         numbers are in profiles/r05_moe_tensor_parallel_parity.log)
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(1200)
 def test_moe_engine_tensor_parallel_2_x_expert_parallel_2_on_four_ranks(dev):
     """Two tensor groups side by side (data parallel 2 x tensor 2, four staged ranks): the expert groups live INSIDE the data-parallel groups [0, 2] and
     [1, 3] (process_group_initializer.py:493-524), so every rank holds its tensor part of two of the four experts; the dispatch buffers cross the data-parallel
@@ -634,7 +631,7 @@ def test_moe_engine_tensor_parallel_2_x_expert_parallel_2_on_four_ranks(dev):
         p.start()
     res = {}
     for _ in range(4):
-        r, out, params = q.get(timeout=300)
+        r, out, params = q.get(timeout=900)   # (four ranks import torch and build engines on one box, last in the suite's order: tests/conftest.py)
         assert params is not None, f"rank {r} failed:\n{out}"
         res[r] = (out, params)
     for p in procs:

@@ -132,6 +132,16 @@ def test_ring_attention_equals_one_rank_attention(dev, backend, sp, lens, hq, hk
     print(f"ring sp{sp} vs one rank (relative l2):", {k: f"{v:.2e}" for k, v in errs.items()})
     assert all(np.isfinite(g).all() for g in got)
     assert errs["out"] <= 5e-3 and errs["lse"] <= 1e-5 and errs["dq"] <= 5e-3 and errs["dk"] <= 5e-3 and errs["dv"] <= 5e-3, errs
+    # ... and DIRECTLY against the oracle (oracle.ops.attention_varlen = the reference's CrossAttention per packed sequence, multi_head_attention.py:195-237,
+    # in fp32 on the same bf16 inputs, gradients by autograd), at the flash tests' own bound: not only transitively through the one-rank kernels
+    from oracle import ops as O
+
+    qf, kvf = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = O.attention_varlen(qf, kvf, cu, True, None)
+    ref.backward(do.float())
+    oerr = {"out": rel(got[0], ref.detach()), "dq": rel(got[2], qf.grad), "dk": rel(got[3][:, 0], kvf.grad[:, 0]), "dv": rel(got[3][:, 1], kvf.grad[:, 1])}
+    print(f"ring sp{sp} vs the dense fp32 oracle (relative l2):", {k: f"{v:.2e}" for k, v in oerr.items()})
+    assert all(v <= 5e-3 for v in oerr.values()), oerr
 
 
 def _engine_worker(rank, world, port, qu, sp, heads, kv_heads, micro_num):

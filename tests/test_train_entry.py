@@ -247,3 +247,40 @@ def test_bench_line_contract(dev):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["launches"] > 0
     c = d["cpu_baseline"]
     assert set(c) >= {"value", "unit", "cores", "kind", "sample"} and c["kind"] == "port" and c["unit"] == "tokens/s" and c["value"] > 0 and c["cores"] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_line_of_two_staged_ranks(dev):
+    """bench.py's OWN N > 1 code -- the self-launch under torch.distributed.run on 127.0.0.1, the barrier + max-over-ranks timing, the one-hot world-size
+    vector, `params_in_sync_across_ranks`, the exposed-wait reduction -- on a one-GPU box: two ranks on cuda:0 with host-staged collectives (the
+    IE_BENCH_BACKEND=gloo + --staged-test hook).  What the first 8-GPU run of the driver executes on RCCL is this code path with the other Backend; the line
+    must say that THIS run is not a measurement.  (Metric definition: train/pipeline.py:506-509,550-556.)"""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", IE_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--staged-test", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    c = d["comm"]
+    assert c["rccl_world_size_per_rank"] == [2, 2], c
+    assert c["params_in_sync_across_ranks"] is True
+    assert "NOT a measurement" in c["backend"] and "gloo" in c["backend"]
+    assert c["data_parallel_size"] == 2 and c["zero_shards_per_bucket"] == 2 and c["zero_replicas"] == 1
+    # two ranks = twice the tokens of one rank per step (weak scaling: per-GPU work fixed), value = whole-job tokens / the slowest rank's time
+    assert d["config"]["tokens_per_step"] > 0 and d["config"]["tokens_per_step"] % 2 == 0
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["tokens_per_step"]) <= 1e-6 * d["config"]["tokens_per_step"]
+    assert abs(d["tgs"] * 2 - d["value"]) <= 1e-9 * d["value"]
+    w = c["exposed_wait_ms_per_step"]
+    assert w["waits_per_step_mean"] > 0 and set(w["max_over_ranks"]) >= {"reduce_scatter", "all_gather"}, w   # the staged collectives are waited for on the stream
+    # the same launch WITHOUT the command-line flag must refuse (a stray environment variable must not turn a benchmark into a host-staged run)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert bad.returncode != 0

@@ -55,7 +55,7 @@ for kind, (fn, outs, flops, is_bwd) in cases.items():
         for mode in (0, 3):
             L.ie_tune_ffn_fuse(mode)
             times[mode].append(t_once(fn, 5))
-    L.ie_tune_ffn_fuse(1)
+    L.ie_tune_ffn_fuse(5)
     t0, t1 = statistics.median(times[0]), statistics.median(times[3])
     print(json.dumps({"product": kind, "rows": T, "F": F, "h": H, "one_launch_for_this_shape": fused, "bit_identical": same, "two_launches_us": round(t0 * 1e6, 1),
                       "fused_us": round(t1 * 1e6, 1), "saved_us": round((t0 - t1) * 1e6, 1), "fused_tflops_of_the_product": round(flops / t1 / 1e12, 1)}), flush=True)

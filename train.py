@@ -116,7 +116,7 @@ def _train_moe(cfg, raw, dev, world, rank, args, log):
 
     data_raw, ck = raw.get("data", {}) or {}, raw.get("ckpt", {}) or {}
     load_folder, model_only = resolve_load(ck, log if rank == 0 else (lambda m: None))
-    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", True) else None   # (launch.py:189-190: the key defaults to True)
     if model_only:
         raise NotImplementedError("INTERNLM_MoE: load_ckpt_info content = ('model',) (weights-only loads are the dense engine's)")
     if data_raw.get("train_folder") or int(data_raw.get("valid_every", 0) or 0) > 0:
@@ -270,7 +270,7 @@ def main(argv=None, log=print):
                 log(f"skip validate {name}.")
                 continue
             val_loaders[name] = vl
-    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", False) else None
+    save_folder = _local(ck.get("save_ckpt_folder")) if ck.get("enable_save_ckpt", True) else None   # (launch.py:189-190: the key defaults to True)
     if save_folder:
         # say so at start-up instead of training until the first checkpoint_every step and dying there
         try:
