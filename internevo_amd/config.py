@@ -40,6 +40,7 @@ class ModelConfig:
     # model_type "INTERNLM_MoE" (modeling_moe.py, configs/7B_MoE4_sft.py): InternLM-1 block (MHA with biases, no GQA) + GShard top-2 MoE
     num_experts: int = 1
     moe_capacity_factor: float = 1.0     # moe = dict(capacity_factor, min_capacity, ...)
+    moe_expert_fp8: bool = False         # moe = dict(..., expert_fp8=True): THIS repo's opt-in (the reference has no fp8 linear): the experts' forward products on e4m3
     moe_min_capacity: int = 4
     moe_loss_coeff: float = 1.0          # loss.moe_loss_coeff (launch.py:433-434 default)
     # ScaleColumnParallelLinearWithNormHead (ops/linear.py:79-153) and the embedding's gradient scale (modeling_internlm2.py:970-973)
@@ -232,7 +233,8 @@ def from_reference_dict(cfg: dict, seq_len: Optional[int] = None) -> PathConfig:
         if not m.get("use_swiglu", True) or m.get("residual_in_fp32", False):
             raise NotImplementedError(f"{_UNSUPPORTED}: INTERNLM_MoE with use_swiglu=False / residual_in_fp32")
         moe_kw = dict(num_experts=int(m["num_experts"]), moe_capacity_factor=float(moe.get("capacity_factor", 1.0)),
-                      moe_min_capacity=int(moe.get("min_capacity", 4)), moe_loss_coeff=float(cfg.get("loss", {}).get("moe_loss_coeff", 1.0)))
+                      moe_min_capacity=int(moe.get("min_capacity", 4)), moe_loss_coeff=float(cfg.get("loss", {}).get("moe_loss_coeff", 1.0)),
+                      moe_expert_fp8=bool(moe.get("expert_fp8", False)))
     elif m.get("num_experts", 1) > 1:
         raise NotImplementedError(f"{_UNSUPPORTED}: num_experts > 1 outside model_type INTERNLM_MoE")
     ck = m.get("checkpoint", False)

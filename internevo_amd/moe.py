@@ -33,7 +33,7 @@ def capacity(num_tokens, num_experts, capacity_factor, min_capacity, top_k=2):
 
 class MoELayer:
     def __init__(self, hidden, ffn, num_experts, tokens, device, capacity_factor=1.0, min_capacity=4, seed=0, layer_index=0, ep_group=None,
-                 ep_size=1, ep_rank=0, tpar=None, a2a_chunks=None, a2a_overlap=True):
+                 ep_size=1, ep_rank=0, tpar=None, a2a_chunks=None, a2a_overlap=True, expert_fp8=False):
         """tpar (tensorpar.TensorParallel, tp > 1): every expert is a FeedForward over the TENSOR group (gshard_layer.py:421-433 -> modules/mlp.py:40-86):
         `ffn` is then this rank's F / tp units (w1 / w3 cut by rows, w2 by columns), the experts' outputs are partial sums that are all-reduced over the
         group before the combine (RowParallelLinearTorch), and so is the gradient of the dispatched tokens behind the w1 | w3 products
@@ -46,7 +46,16 @@ class MoELayer:
         of the source ranks do, so they depend on it in the last bf16 bit.
         tokens: tokens per forward call (one micro-batch: the reference gates per call).  Parameters are NOT owned here: forward /
         backward take views (the engine keeps them in its flat buffers): wg fp32 [E, M]; w13 bf16 [E_local, 2F, M]; w2 bf16 [E_local, M, F].
-        (The fp8 expert route of round 4 was removed in round 5: it lost 3 % in the step; the e4m3 product itself stays in the library, kernels.gemm_fp8.)"""
+        expert_fp8 (OPT-IN, BASELINE configs[4] "fp8 MFMA linear layers"; the reference has no fp8 linear, SURVEY.md section 8f rank 2, so the tolerance is this
+        repo's own, tests/test_fp8_gpu.py): the two FORWARD products of every expert run on OCP e4m3 operands (ie_gemm_fp8_batched on v_mfma_f32_32x32x64_f8f6f4:
+        per-tensor dynamic scales per expert block and per expert weight, fp32 accumulation, bf16 results); the backward keeps the bf16 weights and the saved bf16
+        activations (straight-through).  Needs hidden % 128 == 0 and ffn % 128 == 0.  An expert's quantised weights are kept until invalidate_fp8() (the engine
+        calls it after every optimizer step).  Not the default: the separate amax / convert passes cost the MoE step what the products save
+        (profiles/r04_fp8_expert_gemm.md: 224 vs 217 ms on 8 layers) -- round 5 had deleted the route for that, round 6 restored it as the opt-in it is."""
+        if expert_fp8 and (hidden % 128 or ffn % 128):
+            raise ValueError(f"expert_fp8: hidden ({hidden}) and ffn ({ffn}) must be multiples of 128 (one LDS row of e4m3 values)")
+        self.fp8 = bool(expert_fp8)
+        self._wq, self._qa = {}, {}   # quantised weights (until invalidate_fp8) / the quantised-activation buffers
         if not 2 <= num_experts <= 16:
             raise NotImplementedError("2 <= num_experts <= 16")
         if num_experts % ep_size:
@@ -183,8 +192,25 @@ class MoELayer:
             h_.wait()
 
     def _products(self, a, w, out, which):
-        """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch."""
-        K.gemm_batched(a, w, out)
+        """out[j] = a[j] @ w[j]^T for the local experts j in ONE strided-batched launch: bf16, or (expert_fp8) the e4m3 products of the blocks quantised now (a
+        scale per expert block) and the weights quantised since the last invalidate_fp8() (a scale per expert)."""
+        if not self.fp8:
+            K.gemm_batched(a, w, out)
+            return
+        nb = a.shape[0]
+        key = (which, w.data_ptr())
+        if key not in self._wq:
+            self._wq[key] = K.fp8_quantize(w, per_slice=True)
+        buf = self._qa.get((which, tuple(a.shape)))
+        if buf is None:
+            f32 = dict(dtype=torch.float32, device=a.device)
+            buf = self._qa[(which, tuple(a.shape))] = (torch.empty(a.shape, dtype=torch.uint8, device=a.device), torch.empty(nb, **f32), torch.empty(nb, **f32))
+        qa, da = K.fp8_quantize(a.contiguous(), per_slice=True, out=buf)
+        K.gemm_fp8_batched(qa, da, *self._wq[key], out)
+
+    def invalidate_fp8(self):
+        """The expert weights have changed (optimizer step, checkpoint load): quantise them again at the next forward."""
+        self._wq = {}
 
     def backward(self, dout, wg, w13, w2, dx, d_wg, d_w13, d_w2, accumulate, loss_scale_dev=None, aux_factor=0.0):
         """dout bf16 [S, M] -> dx bf16 [S, M] (overwritten).  d_wg fp32 [E, M], d_w13 / d_w2 bf16 like the weights: written, or added to

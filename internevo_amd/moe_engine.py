@@ -56,7 +56,7 @@ def group_of(name):
 
 
 class MoEEngine:
-    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, seed=1024, init_fn=None, noise_fn=None, tp_size=None):
+    def __init__(self, cfg: PathConfig, device, process_group=None, world_size=1, rank=0, seed=1024, init_fn=None, noise_fn=None, tp_size=None, expert_fp8=None):
         """tp_size: Megatron tensor-parallel size (default: cfg.train.tp_size).
         noise_fn(call_index, S, E) -> fp32 [S, E] device tensor: test hook that injects the Gumbel noise of the call-th gating call of the
         run (layer-major inside a micro-batch); None = generated on the device from (seed, layer, call)."""
@@ -67,6 +67,10 @@ class MoEEngine:
         # dense: the InternLM-1 model proper (modeling_internlm.py; INTERNLM_MoE with num_experts = 1 builds the same block, modeling_moe.py:120-140):
         # a plain SwiGLU FeedForward in place of the MoE -- no gate, no auxiliary loss, one optimizer group
         self.dense = mc.model_type == "INTERNLM" or mc.num_experts < 2
+        # expert_fp8 (OPT-IN: this argument, `moe = dict(..., expert_fp8=True)` in the config, or IE_EXPERT_FP8=1): the experts' two FORWARD products on OCP e4m3
+        # operands (moe.MoELayer; BASELINE configs[4] "fp8 MFMA linear layers").  Off by default: slower in the step, and the reference has no fp8 arithmetic to pin
+        want_fp8 = (bool(int(os.environ.get("IE_EXPERT_FP8", "0"))) or bool(getattr(mc, "moe_expert_fp8", False))) if expert_fp8 is None else bool(expert_fp8)
+        self.expert_fp8 = want_fp8 and not self.dense
         if mc.num_kv_attention_heads != mc.num_attention_heads:
             raise NotImplementedError("the InternLM-1 block has no grouped-query attention")
         K._L()
@@ -207,7 +211,7 @@ class MoEEngine:
             self.t_act, self.t_dact, self.t_dh13 = e(T, F), e(T, F), e(T, 2 * F)
         else:
             self.moe = [MoELayer(h, F, E, T, device, mc.moe_capacity_factor, mc.moe_min_capacity, seed=seed + 7919 * dpr, layer_index=l, ep_group=self.ep_group,
-                                 ep_size=self.ep, ep_rank=self.ep_rank, tpar=self.tpar) for l in range(L)]
+                                 ep_size=self.ep, ep_rank=self.ep_rank, tpar=self.tpar, expert_fp8=self.expert_fp8) for l in range(L)]
             # (every DATA-parallel rank gates its own tokens with its own noise; the ranks of a tensor group gate the same tokens with the same noise)
         self.a_xf, self.a_nf, self.a_rstdf = e(T, h), e(T, h), e(T, dtype=torch.float32)
         self.t_qkv, self.t_h0, self.t_h1, self.t_h2 = e(T, 3 * hl), e(T, h), e(T, h), e(T, h)
@@ -267,6 +271,8 @@ class MoEEngine:
         buffer of the same layout and the [L, E, h] fp32 tensor to fill instead of the bf16 parameters and the gate weights (checkpoints: master
         weights, moments)."""
         self._wait_optimizer()
+        for lay in getattr(self, "moe", None) or ():   # (the constructor initialises the weights before the layers exist)
+            lay.invalidate_fp8()
         F = self.F
         P = self.p if views is None else views
         WG = self.wg if gates is None else gates
@@ -545,6 +551,8 @@ class MoEEngine:
     def step(self):
         """HybridZeroOptimizer.step with the three parameter groups; stream-ordered, no host sync."""
         tc = self.tc
+        for lay in self.moe or ():
+            lay.invalidate_fp8()   # (expert_fp8: the experts' weights are about to change)
         # data parallel, every rank keeps the (replicated) optimizer state of what it holds.  Dense parameters and gates: AVG over all ranks.
         # Experts: an expert's gradient already sums what the tokens of every rank of its expert group contributed (one copy, one backward);
         # the reference averages it over the expert-data group only (hybrid_zero_optim.py:166-167) -- no 1 / ep.

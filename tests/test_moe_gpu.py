@@ -173,7 +173,7 @@ def test_gumbel_noise_is_reproducible_and_gumbel_distributed(dev):
     assert abs(float(a.mean()) - 0.5772) < 5e-3 and abs(float(a.var()) - 1.6449) < 2e-2
 
 
-def _ep_worker(rank, world, port, q):
+def _ep_worker(rank, world, port, q, E=4):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -187,7 +187,7 @@ def _ep_worker(rank, world, port, q):
         from internevo_amd.moe import MoELayer
 
         g = torch.Generator().manual_seed(17)
-        S, E, M, F = 512, 4, 256, 512
+        S, M, F = 512, 256, 512
         wg = torch.randn(E, M, generator=g) * 0.05
         w1, w3 = (torch.randn(E, F, M, generator=g) * 0.03).to(BF16), (torch.randn(E, F, M, generator=g) * 0.03).to(BF16)
         w2 = (torch.randn(E, M, F, generator=g) * 0.03).to(BF16)
@@ -197,42 +197,73 @@ def _ep_worker(rank, world, port, q):
         noise = MO.gumbel_noise((S, E), 30 + rank)
         one = _run_layer(dev, x, dy, wg, w1, w3, w2, noise, 1.0, 4, 0.01)[1:]   # all experts local: what this rank's tokens must get
         El = E // world
-        lay = MoELayer(M, F, E, S, dev, 1.0, 4, ep_group=dist.group.WORLD, ep_size=world, ep_rank=rank)
         mine = slice(rank * El, (rank + 1) * El)
         w13 = torch.cat([w1, w3], dim=1)[mine].contiguous().to(dev)
         w2d, wgd, xd, dyd = w2[mine].contiguous().to(dev), wg.to(dev), x.to(dev), dy.to(dev)
-        out = torch.empty(S, M, dtype=BF16, device=dev)
-        l_aux = lay.forward(xd, wgd, w13, w2d, out, noise=noise.to(dev))
-        dx = torch.empty(S, M, dtype=BF16, device=dev)
-        d_wg, d_w13, d_w2 = torch.empty_like(wgd), torch.empty_like(w13), torch.empty_like(w2d)
-        lay.backward(dyd, wgd, w13, w2d, dx, d_wg, d_w13, d_w2, accumulate=False, loss_scale_dev=None, aux_factor=0.01)
+
+        def run(chunks, overlap):
+            lay = MoELayer(M, F, E, S, dev, 1.0, 4, ep_group=dist.group.WORLD, ep_size=world, ep_rank=rank, a2a_chunks=chunks, a2a_overlap=overlap)
+            assert lay.nch == (chunks or 2) and lay.overlap == overlap
+            out = torch.full((S, M), 7.0, dtype=BF16, device=dev)
+            l_aux = lay.forward(xd, wgd, w13, w2d, out, noise=noise.to(dev))
+            dx = torch.full((S, M), 7.0, dtype=BF16, device=dev)
+            d_wg, d_w13, d_w2 = torch.empty_like(wgd), torch.empty_like(w13), torch.empty_like(w2d)
+            lay.backward(dyd, wgd, w13, w2d, dx, d_wg, d_w13, d_w2, accumulate=False, loss_scale_dev=None, aux_factor=0.01)
+            torch.cuda.synchronize()
+            return lay, [out, l_aux.clone(), dx, d_wg, d_w13, d_w2]
+
+        lay, got = run(None, True)            # the default: two pieces, every exchange under the other piece's expert products
+        _, blocking = run(2, False)           # the same pieces, every exchange waited for at once
+        lay1, whole = run(1, True)            # one piece: the round-5 layout
+        same = [bool(torch.equal(a, b)) for a, b in zip(got, blocking)]
+        rowwise = [bool(torch.equal(a, b)) for a, b in zip(got[:4], whole[:4])]   # outputs, l_aux, input and gate gradients do not depend on the piece count
+        wdiff = [float((a.float() - b.float()).abs().max() / b.float().abs().max()) for a, b in zip(got[4:], whole[4:])]   # the weight gradients: bf16 sum order
+        # the chunk-major rows (ie_moe_chunk_rows) against the formula: slot c of expert e at k E Cn + e Cn + (c mod Cn)
+        C, Cn = lay.C, lay.C // 2
+        r1 = lay1.row.cpu().long()
+        e_, c_ = r1 // C, r1 % C
+        want_row = torch.where(r1 >= 0, (c_ // Cn) * E * Cn + e_ * Cn + c_ % Cn, r1)
+        t1 = lay1.token_of.cpu()
+        want_tok = torch.empty_like(t1)
+        rr = torch.arange(E * C)
+        want_tok[(rr % C // Cn) * E * Cn + (rr // C) * Cn + rr % C % Cn] = t1
+        perm_ok = bool(torch.equal(lay.row.cpu().long(), want_row)) and bool(torch.equal(lay.token_of.cpu(), want_tok))
+        out, l_aux, dx, d_wg, d_w13, d_w2 = got
         q.put((rank, [t.float().numpy() if torch.is_tensor(t) else t for t in one],
                [out.float().cpu().numpy(), float(l_aux), dx.float().cpu().numpy(), d_wg.cpu().numpy(), d_w13[:, :F].float().cpu().numpy(),
-                d_w13[:, F:].float().cpu().numpy(), d_w2.float().cpu().numpy()]))
+                d_w13[:, F:].float().cpu().numpy(), d_w2.float().cpu().numpy()], dict(same=same, rowwise=rowwise, wdiff=wdiff, perm_ok=perm_ok)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_expert_parallel_layer_equals_the_all_local_layer(dev):
+@pytest.mark.parametrize("E", [4, 2], ids=["two_experts_per_rank", "one_expert_per_rank"])
+def test_expert_parallel_layer_equals_the_all_local_layer(dev, E):
     """Expert parallelism (parallel.expert; gshard_layer.py:453-474: all_to_all of the [E, C, M] dispatch buffer) on two ranks, two of the four
-    experts each, every rank routing its OWN tokens: a rank's output, input gradient and gate gradient equal the layer that holds all
-    experts locally (same kernels, same routing), and the gradient of an expert's weights is the SUM of what the two ranks' tokens
-    contribute to it."""
+    experts each (or one of two: all source ranks' rows of a piece are then ONE product's operand), every rank routing its OWN tokens: a rank's output,
+    input gradient and gate gradient equal the layer that holds all experts locally (same kernels, same routing), and the gradient of an expert's weights is
+    the SUM of what the two ranks' tokens contribute to it.  Round 6 -- the exchange in two pieces along the capacity, piece k + 1 on its way under piece k's
+    expert products (the reference's exchange is blocking, gshard_layer.py:465-498): the overlapped form equals the same pieces exchanged one after the
+    other BIT FOR BIT in every output; against ONE piece the outputs, the auxiliary loss, the input and the gate gradient are bit-identical (row-wise
+    work) and the weight gradients differ in their bf16 summation order only; the chunk-major row numbering equals its formula."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ep_worker, args=(r, 2, 29891, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ep_worker, args=(r, 2, 29891 + E, q, E)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(2):
-        r, one, ep = q.get(timeout=240)
+        r, one, ep, chk = q.get(timeout=240)
         res[r] = (one, ep)
+        assert all(chk["same"]), f"rank {r}: overlapped exchange differs from the blocking one: {chk['same']}"
+        assert all(chk["rowwise"]), f"rank {r}: outputs / input gradients depend on the piece count: {chk['rowwise']}"
+        assert max(chk["wdiff"]) <= 1e-2, chk["wdiff"]
+        assert chk["perm_ok"], "ie_moe_chunk_rows: rows / inverse map differ from the chunk-major formula"
     for p in procs:
         p.join(60)
-    E, El = 4, 2
+    El = E // 2
     for r in range(2):
         one, ep = res[r]
         for k, what in ((0, "output"), (2, "d input"), (3, "d gate weight")):

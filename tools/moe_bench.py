@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--expert-fp8", action="store_true", help="OPT-IN: the experts' forward products on e4m3 operands (MoEEngine(expert_fp8=True))")
     args = ap.parse_args()
     from internevo_amd.config import ModelConfig, PathConfig, TrainConfig
     from internevo_amd.data import SyntheticLoader
@@ -31,7 +32,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     t0 = time.time()
-    eng = MoEEngine(PathConfig(mc, tc), dev, seed=1024)
+    eng = MoEEngine(PathConfig(mc, tc), dev, seed=1024, expert_fp8=args.expert_fp8)
     build_s = time.time() - t0
     loader = iter(SyntheticLoader(tc.seq_len, tc.micro_bsz, tc.micro_num, True))
     tokens = tc.seq_len * tc.micro_bsz * tc.micro_num
