@@ -158,7 +158,6 @@ def main():
                     "idle workgroups hold n CUs for the time the collective would take (a bucket's 1/8 per xGMI link at link_GBps, default 100), on a side stream: the "
                     "price of a collective's CUs for the products beside it (DESIGN.md section 6.2).  The line says so; results are unchanged")
     ap.add_argument("--gemm-persistent-skip-n", type=int, default=None, help="A/B only: products with this many output columns stay on the plain launch")
-    ap.add_argument("--adamw-vec", type=int, default=None, choices=[4, 8], help="A/B only: 4 = the 8-byte-access AdamW kernel of rounds 1-5 on everything (IE_ADAMW_VEC=4)")
     ap.add_argument("--ffn-fuse", type=int, default=None, help="A/B only: ie_tune_ffn_fuse mode (bit 0 forward gate, bit 1 the w2 input-gradient epilogue)")
     args = ap.parse_args()
     if args.rccl_channels > 0:   # (inherited by the ranks of a self-launched run; read by RCCL when the communicator is created)
@@ -178,8 +177,6 @@ def main():
         assert K._L().ie_tune_gemm_persistent_skip_n(args.gemm_persistent_skip_n) == 0
     if args.ffn_fuse is not None:
         assert K._L().ie_tune_ffn_fuse(args.ffn_fuse) == 0
-    if args.adamw_vec is not None:
-        os.environ["IE_ADAMW_VEC"] = str(args.adamw_vec)   # (read once, at the first AdamW launch)
     if args.hold_cus:
         if args.gpus != 1:
             raise SystemExit("--hold-cus is the one-GPU stand-in for a collective's CUs")

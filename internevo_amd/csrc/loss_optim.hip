@@ -406,69 +406,9 @@ __device__ __forceinline__ void adam_one(float g, float& p, float& m, float& v, 
     p = p - c.step_size * (m / denom);
 }
 
-// Eight elements per thread and trip (round 6): every access of the stream is 16 bytes wide -- the bf16 gradient and the bf16 shadow were 8-byte accesses in
-// adamw_k, which the memory system serves at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md, load / store flavours) -- and two independent groups of
-// p / m / v are in flight per thread.  Same arithmetic per element, same results bit for bit; the tail (n % 8) and unaligned buffers stay with adamw_k.
-template <bool GBF>
-__global__ __launch_bounds__(256) void adamw8_k(const void* __restrict__ g, float* __restrict__ p32, float* __restrict__ m, float* __restrict__ v,
-                                                bf16_t* __restrict__ p16, int64_t n8, const IeStepState* __restrict__ state, double lr, double beta1, double beta2,
-                                                float eps, double wd, const float* __restrict__ inv_scale_group) {
-    __shared__ AdamConsts sc;
-    __shared__ int skip;
-    if (threadIdx.x == 0) {
-        skip = state->skip;
-        const int step = state->adam_step;
-        const double bc1 = 1.0 - pow(beta1, (double)step);
-        const double bc2 = 1.0 - pow(beta2, (double)step);
-        sc.decay = (float)(1.0 - lr * wd);
-        sc.one_m_b1 = (float)(1.0 - beta1);
-        sc.beta2 = (float)beta2;
-        sc.one_m_b2 = (float)(1.0 - beta2);
-        sc.step_size = (float)(lr / bc1);
-        sc.bc2_sqrt = (float)sqrt(bc2);
-        sc.eps = eps;
-        sc.inv_scale = inv_scale_group ? inv_scale_group[0] : state->inv_scale;
-    }
-    __syncthreads();
-    if (skip) return;
-    const AdamConsts c = sc;
-    const int64_t nthreads = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += nthreads) {
-        float gv[8];
-        if (GBF) {
-            unpack8(ld16((const bf16_t*)g + i * 8), gv);
-        } else {
-            const float4 q0 = *reinterpret_cast<const float4*>((const float*)g + i * 8), q1 = *reinterpret_cast<const float4*>((const float*)g + i * 8 + 4);
-            gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
-        }
-        float4 pa = *reinterpret_cast<float4*>(p32 + i * 8), pb = *reinterpret_cast<float4*>(p32 + i * 8 + 4);
-        float4 ma = *reinterpret_cast<float4*>(m + i * 8), mb = *reinterpret_cast<float4*>(m + i * 8 + 4);
-        float4 va = *reinterpret_cast<float4*>(v + i * 8), vb = *reinterpret_cast<float4*>(v + i * 8 + 4);
-        adam_one(gv[0], pa.x, ma.x, va.x, c);
-        adam_one(gv[1], pa.y, ma.y, va.y, c);
-        adam_one(gv[2], pa.z, ma.z, va.z, c);
-        adam_one(gv[3], pa.w, ma.w, va.w, c);
-        adam_one(gv[4], pb.x, mb.x, vb.x, c);
-        adam_one(gv[5], pb.y, mb.y, vb.y, c);
-        adam_one(gv[6], pb.z, mb.z, vb.z, c);
-        adam_one(gv[7], pb.w, mb.w, vb.w, c);
-        *reinterpret_cast<float4*>(p32 + i * 8) = pa;
-        *reinterpret_cast<float4*>(p32 + i * 8 + 4) = pb;
-        *reinterpret_cast<float4*>(m + i * 8) = ma;
-        *reinterpret_cast<float4*>(m + i * 8 + 4) = mb;
-        *reinterpret_cast<float4*>(v + i * 8) = va;
-        *reinterpret_cast<float4*>(v + i * 8 + 4) = vb;
-        if (p16) {
-            uint4 o;
-            o.x = pack2bf(pa.x, pa.y);
-            o.y = pack2bf(pa.z, pa.w);
-            o.z = pack2bf(pb.x, pb.y);
-            o.w = pack2bf(pb.z, pb.w);
-            st16(p16 + i * 8, o);
-        }
-    }
-}
-
+// (Round 6 tried every access of the stream 16 bytes wide -- eight elements per thread and trip, the bf16 gradient and shadow as 16-byte accesses, two
+// independent groups of p / m / v in flight: in the training step 1279-1284 us per bucket against this kernel's 1233-1237, A B A B on one box,
+// profiles/r06_step_adamw_16byte_abab.log.  More bytes in flight per thread is not what this stream lacks; the kernel below stays.)
 template <bool GBF>
 __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float* __restrict__ p32, float* __restrict__ m,
                                                float* __restrict__ v, bf16_t* __restrict__ p16, int64_t n,
@@ -685,25 +625,6 @@ static int adamw_launch(const void* g, int g_dtype, float* p32, float* m, float*
     if (n == 0) return IE_OK;
     const int vec_ok = aligned16(p32) && aligned16(m) && aligned16(v) && ((((uintptr_t)g) & (g_dtype == IE_BF16 ? 7u : 15u)) == 0) &&
                        (!p16 || (((uintptr_t)p16) & 7u) == 0);
-    // the 16-byte-per-access form on the whole eights of an aligned stream, adamw_k on what is left (IE_ADAMW_VEC=4: A/B switch, adamw_k on everything)
-    static const bool vec8 = !(getenv("IE_ADAMW_VEC") && atoi(getenv("IE_ADAMW_VEC")) == 4);
-    if (vec8 && vec_ok && n >= 8 && aligned16(g) && (!p16 || aligned16(p16))) {
-        const int64_t n8 = n / 8;
-        int64_t blocks8 = std::min<int64_t>((n8 + 255) / 256, 16384);
-        if (g_dtype == IE_BF16)
-            hipLaunchKernelGGL((adamw8_k<true>), dim3((unsigned)blocks8), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n8, state_dev, lr, beta1, beta2,
-                               (float)eps, weight_decay, inv_scale_group);
-        else
-            hipLaunchKernelGGL((adamw8_k<false>), dim3((unsigned)blocks8), dim3(256), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n8, state_dev, lr, beta1, beta2,
-                               (float)eps, weight_decay, inv_scale_group);
-        const int64_t done = n8 * 8;
-        if (done == n) return ie_launch_status("ie_adamw_step launch");
-        const int esz = g_dtype == IE_BF16 ? 2 : 4;
-        g = (const char*)g + done * esz;
-        p32 += done; m += done; v += done;
-        if (p16) p16 = (char*)p16 + done * 2;
-        n -= done;
-    }
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
