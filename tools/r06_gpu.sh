@@ -8,6 +8,7 @@
 #   cycle      the validation cycle: GPU suite, smoke, default bench line, the same under rocprofv3 --kernel-trace --stats, two PMC traffic passes
 #   abab       in-step A B A B of one bench.py flag under rocprofv3 --kernel-trace:  abab <tag> "<flag> <value A>" "<flag> <value B>" [kernel grep]
 #   hold       the step with 0 / 16 / 32 CUs held where the collectives of an 8-GPU run would be, persistent GEMM frame on / off, twice
+#   extras     bench.py --seq-len 32768 --checkpoint 1.0 --micro-num 1; tools/moe_bench.py with bf16 and with opt-in fp8 experts
 #   kab        kbench lines:  kab <tag> <kbench arguments ...>
 #   tests      a subset of the GPU suite:  tests <tag> <pytest -k expression>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
@@ -92,6 +93,11 @@ hold)   # what the CUs a collective holds cost the step: bench.py --hold-cus n (
       done
     done
   done 2>&1 | tee "$O/hold.log"
+  ;;
+extras)   # the long-context data point (seq 32768, every layer checkpointed, one sequence per step) and the MoE family at full size (bf16 experts; opt-in fp8 experts)
+  timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --seq-len 32768 --checkpoint 1.0 --micro-num 1 > "$O/long_context_line.json" 2> "$O/long_context.err"; cut -c1-400 "$O/long_context_line.json"
+  timeout 900 python tools/moe_bench.py --steps 4 --warmup 2 > "$O/moe_bench_line.json" 2> "$O/moe_bench.err"; cat "$O/moe_bench_line.json"
+  timeout 900 python tools/moe_bench.py --steps 4 --warmup 2 --expert-fp8 > "$O/moe_bench_fp8_line.json" 2> "$O/moe_bench_fp8.err"; cat "$O/moe_bench_fp8_line.json"
   ;;
 kab)
   timeout 600 $K "$@" 2>&1 | tee "$O/kbench.log"
