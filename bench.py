@@ -158,6 +158,7 @@ def main():
                     "idle workgroups hold n CUs for the time the collective would take (a bucket's 1/8 per xGMI link at link_GBps, default 100), on a side stream: the "
                     "price of a collective's CUs for the products beside it (DESIGN.md section 6.2).  The line says so; results are unchanged")
     ap.add_argument("--gemm-persistent-skip-n", type=int, default=None, help="A/B only: products with this many output columns stay on the plain launch")
+    ap.add_argument("--qkv-rotary-fuse", type=int, default=None, help="A/B only: ie_tune_qkv_rotary_fuse (1 = split + rotary in the wqkv product's epilogue, 0 = two launches)")
     ap.add_argument("--ffn-fuse", type=int, default=None, help="A/B only: ie_tune_ffn_fuse mode (bit 0 forward gate, bit 1 the w2 input-gradient epilogue)")
     args = ap.parse_args()
     if args.rccl_channels > 0:   # (inherited by the ranks of a self-launched run; read by RCCL when the communicator is created)
@@ -177,6 +178,8 @@ def main():
         assert K._L().ie_tune_gemm_persistent_skip_n(args.gemm_persistent_skip_n) == 0
     if args.ffn_fuse is not None:
         assert K._L().ie_tune_ffn_fuse(args.ffn_fuse) == 0
+    if args.qkv_rotary_fuse is not None:
+        assert K._L().ie_tune_qkv_rotary_fuse(args.qkv_rotary_fuse) == 0
     if args.hold_cus:
         if args.gpus != 1:
             raise SystemExit("--hold-cus is the one-GPU stand-in for a collective's CUs")
@@ -385,7 +388,7 @@ def main():
             # measured on THIS workload -- two PMC passes of bench.py itself, every GEMM launch of the step as it runs (tools/gemm_traffic_in_step.py) --
             # and only reported if the measurement is of the kernels THIS run launched (ie_gemm_last_kernel after every timed launch): a file of other
             # schedules is refused (traffic: null), never passed on as this run's number
-            TRAFFIC_FILE = "r05_gemm_hbm_traffic.json"
+            TRAFFIC_FILE = "r06_gemm_hbm_traffic.json"
             with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                 tj = json.load(f)
             measured = {k.replace("void ", "").strip() for k in tj["kernels"]}

@@ -121,6 +121,17 @@ int ie_gemm_swiglu_fwd(const void* x, int64_t ldx, const void* w13, int64_t ldw,
 int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, int64_t ldw, const void* h13, int64_t ldh, void* dh13, int64_t ldd,
                        void* dact_scratch, int64_t ld_scratch, int64_t M, int64_t F, int64_t K, void* stream);
 int ie_tune_ffn_fuse(int mode);
+/* a3 + a4 in one launch (round 6): q [T, hkv q_per_kv, d], kv [T, 2, hkv, d] = split + de-interleave + rotary (ie_qkv_rotary_fwd_scaled's arithmetic) of
+ * x[M, K] @ wqkv[hkv (q_per_kv + 2) d, K]^T -- MHA._packed_forward's wqkv linear, GQA un-interleave and rotary embedding (modeling_internlm2.py:404-445,
+ * modules/embedding.py:89-166).  With d = 128 and a product the persistent GEMM frame takes (whole 256-row / 256-column tiles, more than 256 of them) the
+ * arithmetic sits in the product's epilogue and the [M, N] product never reaches memory; otherwise the product is written to qkv_scratch [M, N] (contiguous,
+ * always required) and ie_qkv_rotary_fwd_scaled follows.  Bit-identical either way.  ie_tune_qkv_rotary_fuse(0) forces the two launches; ie_gemm_qkv_rotary_is_fused
+ * says which path a shape takes. */
+int ie_gemm_qkv_rotary_fwd(const void* x, int64_t ldx, const void* wqkv, int64_t ldw, const void* cos_table, const void* sin_table, const int64_t* pos, void* q_out,
+                           void* kv_out, void* qkv_scratch, int64_t ld_scratch, int64_t M, int hkv, int q_per_kv, int d, int64_t K, int interleaved, float q_scale,
+                           void* stream);
+int ie_tune_qkv_rotary_fuse(int mode);
+int ie_gemm_qkv_rotary_is_fused(int64_t M, int hkv, int q_per_kv, int d, int64_t K);
 int ie_gemm_swiglu_is_fused(int bwd, int64_t M, int64_t F, int64_t K);   /* 1 = one launch for this shape */
 
 /* ------------------------------------------------------------------------------------------------

@@ -105,6 +105,9 @@ SIGNATURES = {
     "ie_tune_flash_dq_occupancy": (I, [I]),
     "ie_tune_gemm_group": (I, [I]),
     "ie_tune_ffn_fuse": (I, [I]),
+    "ie_gemm_qkv_rotary_fwd": (I, [P, I64, P, I64, P, P, P, P, P, P, I64, I64, I, I, I, I64, I, F, P]),
+    "ie_tune_qkv_rotary_fuse": (I, [I]),
+    "ie_gemm_qkv_rotary_is_fused": (I, [I64, I, I, I, I64]),
     "ie_gemm_swiglu_is_fused": (I, [I, I64, I64, I64]),
     "ie_gemm_swiglu_fwd": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "ie_gemm_swiglu_bwd": (I, [P, I64, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),

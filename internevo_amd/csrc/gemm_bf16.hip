@@ -521,6 +521,46 @@ extern "C" int ie_gemm_swiglu_bwd(const void* dy, int64_t ldy, const void* w2, i
     return ie_swiglu_bwd(dact_scratch, ld_scratch, h13, ldh, (const bf16_t*)h13 + F, ldh, dh13, ldd, (bf16_t*)dh13 + F, ldd, nullptr, 0, M, F, stream);
 }
 
+// ---- the wqkv forward product with the GQA split + rotary embedding in its epilogue (a3 / a4; round 6) --------------------------------------------
+// One launch (gemm_p5_k<false, 3>) when the head dimension is 128 and the persistent frame takes the [M, hkv (qpk + 2) 128, K] product; otherwise the product
+// into `qkv_scratch` followed by ie_qkv_rotary_fwd_scaled -- bit-identical results either way (same arithmetic on the same bf16-rounded products).
+// ie_tune_qkv_rotary_fuse(0) forces the two launches (A/B, tests).
+extern "C" int ie_gemm_qkv_rotary_dma_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, IeRotaryEpi rot, void* stream);
+extern "C" int ie_qkv_rotary_fwd_scaled(const void* qkv, const void* cos_, const void* sin_, const int64_t* pos, void* q_out, void* kv_out, int64_t T, int hkv,
+                                        int q_per_kv, int d, int interleaved, float q_scale, void* stream);
+static int g_qkv_rotary_fuse = 1;
+extern "C" int ie_tune_qkv_rotary_fuse(int mode) {
+    if (mode < 0 || mode > 1) return IE_ERR_INVALID;
+    g_qkv_rotary_fuse = mode;
+    return IE_OK;
+}
+static bool qkv_rotary_fusable(int64_t M, int64_t N, int64_t K, int d) {
+    return g_qkv_rotary_fuse && d == 128 && K > 0 && K % 64 == 0 && M * K * 2 < (1ll << 32) && N * K * 2 < (1ll << 32) &&
+           pick_variant(M, N, K, false, false) == 20 && !(g_tail_split && tail_split(M, N).on) && N != g_gemm_persistent_skip_n && ie_gemm_dma_persistent_takes(M, N, K);
+}
+extern "C" int ie_gemm_qkv_rotary_is_fused(int64_t M, int hkv, int q_per_kv, int d, int64_t K) {
+    return qkv_rotary_fusable(M, (int64_t)hkv * (q_per_kv + 2) * d, K, d) ? 1 : 0;
+}
+extern "C" int ie_gemm_qkv_rotary_fwd(const void* x, int64_t ldx, const void* wqkv, int64_t ldw, const void* cos_, const void* sin_, const int64_t* pos, void* q_out,
+                                      void* kv_out, void* qkv_scratch, int64_t ld_scratch, int64_t M, int hkv, int q_per_kv, int d, int64_t K, int interleaved,
+                                      float q_scale, void* stream) {
+    IE_CHECK_ARG(x && wqkv && cos_ && sin_ && pos && q_out && kv_out && qkv_scratch, "ie_gemm_qkv_rotary_fwd: null pointer");
+    IE_CHECK_ARG(M >= 0 && hkv > 0 && q_per_kv > 0 && K >= 0 && q_scale > 0.f && M < (1ll << 30) && K < (1ll << 30), "ie_gemm_qkv_rotary_fwd: bad shape");
+    IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_gemm_qkv_rotary_fwd: head dim must be 64 or 128");
+    const int64_t N = (int64_t)hkv * (q_per_kv + 2) * d;
+    IE_CHECK_ARG(ldx >= K && ldw >= K && ld_scratch == N, "ie_gemm_qkv_rotary_fwd: leading dimensions (the scratch product must be contiguous)");
+    if (M == 0) return IE_OK;
+    const bool fuse = qkv_rotary_fusable(M, N, K, d) && ldx == K && ldw == K && aligned16(x) && aligned16(wqkv) && aligned16(cos_) && aligned16(sin_) &&
+                      aligned16(q_out) && aligned16(kv_out);
+    if (fuse) {
+        IeRotaryEpi rot{cos_, sin_, pos, q_out, kv_out, hkv, q_per_kv, interleaved ? 1 : 0, q_scale};
+        return ie_gemm_qkv_rotary_dma_launch(x, ldx, wqkv, ldw, M, N, K, rot, stream);
+    }
+    const int rc = gemm_dispatch(-1, x, ldx, 0, wqkv, ldw, 0, qkv_scratch, ld_scratch, M, N, K, 0, stream);
+    if (rc != IE_OK) return rc;
+    return ie_qkv_rotary_fwd_scaled(qkv_scratch, cos_, sin_, pos, q_out, kv_out, M, hkv, q_per_kv, d, interleaved, q_scale, stream);
+}
+
 extern "C" int ie_gemm_bf16_tile(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C,
                                  int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* stream) {
     return gemm_dispatch(variant, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, accumulate, stream);

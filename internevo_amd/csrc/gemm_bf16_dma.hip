@@ -1290,11 +1290,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_dma_k(const bf16_
 // read), C = dh13 [M, 2F]: every 16-byte piece of a wave's 16-row turn is joined by the gate and up values of its eight columns and leaves as d(gate) and d(up)
 // (swiglu_bwd1 on the bf16-rounded d(act): the arithmetic of swiglu_bwd_k and of gemm_dma_k's EPI 2, bit for bit).  The h13 pieces of a turn are requested
 // before the turn's accumulators are packed.  N = F; tiles_n = F / 256.
+// EPI 3 (round 6; the wqkv forward product of a d = 128 model): a wave's 128 columns are ONE head slot of the [kv group][qpk query heads, k, v][128] row layout
+// (modeling_internlm2.py:416-420), so the wave-private turn holds 16 rows of one slot: q and k slots are de-interleaved (even | odd, :425-427), rotated with the
+// cos / sin rows of the token's position (embedding.py:89-166) and stored into q [T, hkv qpk, 128] / kv [T, 2, hkv, 128]; v slots are copied.  The arithmetic is
+// qkv_rotary_fwd_k's on the same bf16-rounded products: bit-identical to product + that kernel.  C is not written.  N = hkv (qpk + 2) 128.
 template <bool B_KM, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, bf16_t* __restrict__ C,
                                                  int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n, bf16_t* __restrict__ ACT,
-                                                 int64_t ld_act, int F, unsigned* __restrict__ queue) {
-    static_assert(EPI == 0 || (EPI == 1 && !B_KM) || (EPI == 2 && B_KM), "EPI 1: the forward product; EPI 2: the w2 input-gradient product");
+                                                 int64_t ld_act, int F, unsigned* __restrict__ queue, IeRotaryEpi rot) {
+    static_assert(EPI == 0 || ((EPI == 1 || EPI == 3) && !B_KM) || (EPI == 2 && B_KM), "EPI 1 / 3: forward products; EPI 2: the w2 input-gradient product");
     using G = DCfg<256, 256, 2, 2>;
     constexpr int NW = 4;
     constexpr int EP = 256 + 16;                      // pitch of a wave's private epilogue rows (16 rows x 128 bf16 columns)
@@ -1512,6 +1516,55 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                     v.y = pack2bf(acc16[i][j][2], acc16[i][j][3]);
                     *reinterpret_cast<uint2*>(wr + j * 32) = v;
                 }
+                if constexpr (EPI == 3) {
+                    const int slot = (n0 + wn * G::WN) >> 7, gs = rot.qpk + 2;
+                    const int g = slot / gs, sl = slot - g * gs;              // kv group, slot inside it (wave-uniform)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int pc = lane + 64 * q, prow = pc >> 3, sp = pc & 7;          // 16-column span sp of row prow of the turn
+                        const int64_t t = m0 + wm * G::WM + i * 16 + prow;
+                        bf16_t* dst;
+                        if (sl < rot.qpk) dst = (bf16_t*)rot.q + (t * (int64_t)(rot.hkv * rot.qpk) + (g * rot.qpk + sl)) * 128;
+                        else dst = (bf16_t*)rot.kv + ((t * 2 + (sl - rot.qpk)) * rot.hkv + g) * 128;
+                        if (sl == rot.qpk + 1) {   // v: plain copy
+                            st16_c(dst + sp * 16, *reinterpret_cast<const uint4*>(ep + prow * EP + sp * 32));
+                            st16_c(dst + sp * 16 + 8, *reinterpret_cast<const uint4*>(ep + prow * EP + sp * 32 + 16));
+                            continue;
+                        }
+                        const int i0 = sp * 8;   // first rotary-pair index of this span
+                        float x1[8], x2[8];
+                        if (rot.interleaved) {
+                            float lo[8], hi[8];
+                            unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + sp * 32), lo);
+                            unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + sp * 32 + 16), hi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                x1[e] = lo[2 * e]; x2[e] = lo[2 * e + 1];
+                                x1[4 + e] = hi[2 * e]; x2[4 + e] = hi[2 * e + 1];
+                            }
+                        } else {
+                            unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + i0 * 2), x1);
+                            unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + (64 + i0) * 2), x2);
+                        }
+                        const int64_t ps = rot.pos[t];
+                        float co[8], si[8], o1[8], o2[8];
+                        unpack8(ld16((const bf16_t*)rot.cos + ps * 64 + i0), co);
+                        unpack8(ld16((const bf16_t*)rot.sin + ps * 64 + i0), si);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            o1[e] = x1[e] * co[e] - x2[e] * si[e];
+                            o2[e] = x1[e] * si[e] + x2[e] * co[e];
+                        }
+                        if (sl < rot.qpk && rot.q_scale != 1.f) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o1[e] *= rot.q_scale, o2[e] *= rot.q_scale;
+                        }
+                        st16_c(dst + i0, pack8(o1));
+                        st16_c(dst + 64 + i0, pack8(o2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 if constexpr (EPI == 2) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {   // (dword by dword: two elements' temporaries live at a time -- the kernel sits at the register cap)
@@ -1711,9 +1764,9 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
         unsigned* qslot = p5_queue_slot(st);
         if (!qslot) return IE_ERR_LAUNCH;
         if (b_kmajor) hipLaunchKernelGGL((gemm_p5_k<true, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
-                                         (bf16_t*)nullptr, (int64_t)0, 0, qslot);
+                                         (bf16_t*)nullptr, (int64_t)0, 0, qslot, IeRotaryEpi{});
         else hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
-                                (bf16_t*)nullptr, (int64_t)0, 0, qslot);
+                                (bf16_t*)nullptr, (int64_t)0, 0, qslot, IeRotaryEpi{});
     }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
@@ -1730,6 +1783,19 @@ extern "C" int ie_gemm_fp8_dma_launch(const void* A, int64_t lda, int64_t sa, co
     hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -6>), dim3((unsigned)(tiles_m * tiles_n * count)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
                        lda / 2, (const bf16_t*)B, ldb / 2, (bf16_t*)C, ldc, (int)M, (int)N, (int)(K / 2), (accumulate ? 1 : 0) | (g_gemm_group << 8), tiles_m, tiles_n, bt);
     return ie_launch_status("ie_gemm_fp8 launch");
+}
+
+// The wqkv forward product with the GQA split + rotary embedding in the persistent frame's epilogue (gemm_p5_k<false, 3>).  The caller (gemm_bf16.hip) has checked
+// that the frame takes the product and that the head dimension is 128.
+extern "C" int ie_gemm_qkv_rotary_dma_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, IeRotaryEpi rot, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
+    ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 0, -7, 3);
+    unsigned* qslot = p5_queue_slot(st);
+    if (!qslot) return IE_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_p5_k<false, 3>), dim3((unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid)), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                       (bf16_t*)nullptr, (int64_t)N, (int)M, (int)N, (int)K, (g_gemm_group << 8), tiles_m, tiles_n, (bf16_t*)nullptr, (int64_t)0, 0, qslot, rot);
+    return ie_launch_status("ie_gemm_qkv_rotary (persistent) launch");
 }
 
 // The two FFN products with the SwiGLU arithmetic in their epilogues (refill schedule, 256x256 tiles; the caller has checked K % 64 == 0,
@@ -1752,7 +1818,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
             unsigned* qslot = p5_queue_slot(st);
             if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<false, 1>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
-                               (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F, qslot);
+                               (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F, qslot, IeRotaryEpi{});
             return ie_launch_status("ie_gemm_swiglu (persistent) launch");
         }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
@@ -1765,7 +1831,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
             unsigned* qslot = p5_queue_slot(st);
             if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<true, 2>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
-                               (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, (bf16_t*)const_cast<void*>(h13), ld_h13, (int)F, qslot);
+                               (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, (bf16_t*)const_cast<void*>(h13), ld_h13, (int)F, qslot, IeRotaryEpi{});
             return ie_launch_status("ie_gemm_swiglu bwd (persistent) launch");
         }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, true, -4, 2>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,

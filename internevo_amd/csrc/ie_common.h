@@ -142,6 +142,18 @@ struct IeGemmBatch {
     int64_t ld_act;
 };
 
+// EPI 3 of the persistent GEMM frame (gemm_p5_k<false, 3>, round 6): the wqkv product's epilogue does what qkv_rotary_fwd_k does -- GQA split, even / odd
+// de-interleave, cos / sin gather by position, rotation -- and writes q / kv directly; the [T, hkv (qpk + 2) d] product never reaches memory.
+struct IeRotaryEpi {
+    const void* cos;      // bf16 [max position, d / 2]
+    const void* sin;
+    const int64_t* pos;   // [T] position of every token row
+    void* q;              // bf16 [T, hkv * qpk, d]
+    void* kv;             // bf16 [T, 2, hkv, d]
+    int hkv, qpk, interleaved;
+    float q_scale;
+};
+
 // SwiGLU element arithmetic shared by the elementwise kernels and the fused GEMM epilogues (bit-identical by construction).
 // Reference: Silu(w1_o, w3_o) = F.silu(w1_o) * w3_o on bf16 tensors (model/utils.py:684-688): silu evaluated in fp32, rounded to bf16,
 // product rounded to bf16; the backward sees the bf16 silu(a) autograd saved and the bf16 gradient of the product.

@@ -681,13 +681,18 @@ class InternLM2Engine:
             K.add_rmsnorm_fwd(prev_ffn_out[rl], self.a_r2[self.slot[l - 1]][rl], p[pre + "attention_norm.weight"], eps, self.a_x[l][rl], self.a_n1[s][rl],
                               self.a_rstd1[s][rl])
         # (msp / fsp: all-gather in front of the column-parallel wqkv, under the product of the local rows; the gathered rows are kept: its weight gradient reads them)
-        self._gathered_rows(self.a_n1[s], lambda r: K.linear_fwd(self.a_n1[s][r], p[pre + "attention.wqkv.weight"], self.t_qkv[r]))
-        if self.bias:   # the InternLM-1 block (multi_head_attention.py:371-396): Wqkv carries a bias
-            K.bias_add(self.t_qkv, p[pre + "attention.wqkv.bias"])
-        if self.sp == 1 or self.ring_mode:   # (ring attention: the local tokens keep all their heads)
-            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.a_q[s], self.a_kv[s], self.q_scale)
-        else:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
-            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, self.t_ql, self.t_kvl, self.q_scale)
+        local = self.sp == 1 or self.ring_mode   # (ring attention: the local tokens keep all their heads)
+        q_dst, kv_dst = (self.a_q[s], self.a_kv[s]) if local else (self.t_ql, self.t_kvl)
+        if not self.bias and not self.ss:
+            # wqkv product + GQA split + rotary in ONE launch where the persistent GEMM frame takes the product (d = 128): the [T, N] product never reaches memory
+            K.linear_qkv_rotary_fwd(self.a_n1[s], p[pre + "attention.wqkv.weight"], self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, q_dst, kv_dst, self.t_qkv,
+                                    self.q_scale)
+        else:
+            self._gathered_rows(self.a_n1[s], lambda r: K.linear_fwd(self.a_n1[s][r], p[pre + "attention.wqkv.weight"], self.t_qkv[r]))
+            if self.bias:   # the InternLM-1 block (multi_head_attention.py:371-396): Wqkv carries a bias
+                K.bias_add(self.t_qkv, p[pre + "attention.wqkv.bias"])
+            K.qkv_rotary_fwd(self.t_qkv, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, q_dst, kv_dst, self.q_scale)
+        if not local:  # DistributedAttention: my tokens / all heads -> all tokens / my heads (multi_head_attention.py:117-126)
             xq = self.seqpar.scatter_heads_gather_seq_async(self.t_ql, 1, self.t_xq, self.a_q[s])     # q's exchange runs under kv's packing copy
             xkv = self.seqpar.scatter_heads_gather_seq_async(self.t_kvl, 2, self.t_xkv, self.a_kv[s])  # and the two exchanges beside each other
             xq.wait()

@@ -139,6 +139,24 @@ def qkv_rotary_fwd(qkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, q_out
     return q_out, kv_out
 
 
+def linear_qkv_rotary_fwd(x, wqkv, cos, sin, pos, hkv, q_per_kv, d, interleaved, q_out, kv_out, qkv_scratch, q_scale=1.0):
+    """q_out [T, hkv q_per_kv, d], kv_out [T, 2, hkv, d] = GQA split + rotary of x [T, K] @ wqkv [N, K]^T in ONE launch where the persistent GEMM frame takes the
+    product and d = 128 (ie_gemm_qkv_rotary_fwd: the split / rotation sits in the product's epilogue, the [T, N] product is never written), else the product into
+    qkv_scratch [T, N] + qkv_rotary_fwd; bit-identical either way."""
+    M, Kd = x.shape
+    N = hkv * (q_per_kv + 2) * d
+    if wqkv.shape != (N, Kd) or qkv_scratch.shape != (M, N) or any(t.stride(-1) != 1 for t in (x, wqkv, qkv_scratch)) or not q_out.is_contiguous() or not kv_out.is_contiguous():
+        raise ValueError("linear_qkv_rotary_fwd: bad shapes")
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
+    check(_L().ie_gemm_qkv_rotary_fwd(_p(x), x.stride(0), _p(wqkv), wqkv.stride(0), _p(cos), _p(sin), _p(pos), _p(q_out), _p(kv_out), _p(qkv_scratch),
+                                      qkv_scratch.stride(0), M, hkv, q_per_kv, d, Kd, int(interleaved), float(q_scale), _stream()), "ie_gemm_qkv_rotary_fwd")
+    if prof is not None:
+        prof.end(2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd + M * N))
+    return q_out, kv_out
+
+
 def qkv_rotary_bwd(dq, dkv, cos, sin, pos, hkv, q_per_kv, d, interleaved=True, dqkv_out=None, dq_scale=1.0):
     _contig(dq, "dq"); _contig(dkv, "dkv")
     T = dq.numel() // (hkv * q_per_kv * d)

@@ -175,6 +175,52 @@ def test_qkv_rotary_fwd_bwd(dev, d, hkv, qpk, T, interleaved):
     close(dqkv, x32.grad, 8e-3, 1e-6, "qkv_rotary bwd")
 
 
+@pytest.mark.parametrize("T,hkv,qpk,d,Kd,interleaved,scale,fused", [
+    (4096, 8, 4, 128, 1024, True, 1.0, 1),      # 16 x 24 tiles: the persistent frame takes it -- the epilogue form (InternLM2-7B's head geometry)
+    (4096, 8, 4, 128, 1024, False, 1.0, 1),     # adapt_hf: halves instead of even / odd pairs
+    (4096, 8, 4, 128, 1024, True, 0.1275, 1),   # the scale_on_q arrangement: the factor on the rotated q before its one rounding
+    (2048, 4, 1, 128, 512, True, 1.0, 0),       # 8 x 6 = 48 tiles: one round, the frame does not take it -> two launches
+    (1000, 8, 4, 128, 1024, True, 1.0, 0),      # ragged rows -> two launches
+    (2048, 4, 4, 64, 512, True, 1.0, 0),        # head dim 64 -> two launches
+    (16384, 8, 4, 128, 4096, True, 1.0, 1),     # the benchmark's own product
+], ids=["frame", "frame_adapt_hf", "frame_scaled_q", "one_round", "ragged_rows", "d64", "7b_shape"])
+def test_wqkv_product_with_split_and_rotary_in_its_epilogue_equals_the_two_launches_bit_for_bit(dev, T, hkv, qpk, d, Kd, interleaved, scale, fused):
+    """ie_gemm_qkv_rotary_fwd (a3 + a4; round 6): where the persistent GEMM frame takes the wqkv product of a d = 128 model, the GQA split, the even / odd
+    de-interleave, the cos / sin gather by position and the rotation sit in the product's epilogue (gemm_p5_k<false, 3>) and the [T, N] product never reaches
+    memory; elsewhere product + ie_qkv_rotary_fwd_scaled.  Same arithmetic on the same bf16-rounded products: q and kv must be IDENTICAL to the two launches
+    (which the oracle test above pins), for both slot orders, with the q scale, and the dispatch must be what the shape says."""
+    Kk = K()
+    L = Kk._L()
+    N = hkv * (qpk + 2) * d
+    gen = torch.Generator(device=dev).manual_seed(23)
+    x = torch.randn(T, Kd, device=dev, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(N, Kd, device=dev, generator=gen) * 0.05).to(torch.bfloat16)
+    cos, sin = O.rotary_cos_sin(8192, d)
+    cos, sin = cos.to(dev), sin.to(dev)
+    pos = torch.randint(0, 8192, (T,), device=dev, generator=gen)
+    assert int(L.ie_gemm_qkv_rotary_is_fused(T, hkv, qpk, d, Kd)) == fused
+    out = {}
+    for mode in (0, 1):
+        L.ie_tune_qkv_rotary_fuse(mode)
+        try:
+            q = torch.full((T, hkv * qpk, d), 7.0, device=dev, dtype=torch.bfloat16)
+            kv = torch.full((T, 2, hkv, d), 7.0, device=dev, dtype=torch.bfloat16)
+            scratch = torch.full((T, N), 7.0, device=dev, dtype=torch.bfloat16)
+            Kk.linear_qkv_rotary_fwd(x, w, cos, sin, pos, hkv, qpk, d, interleaved, q, kv, scratch, scale)
+            torch.cuda.synchronize()
+            out[mode] = (q, kv, scratch)
+        finally:
+            L.ie_tune_qkv_rotary_fuse(1)
+    for name, a, b in zip(("q", "kv"), out[0], out[1]):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ, max |diff| {float((a.float() - b.float()).abs().max())}"
+    # the two-launch path IS product + the rotary kernel; the epilogue form leaves the scratch product untouched
+    ref = Kk.linear_fwd(x, w)
+    q2, kv2 = Kk.qkv_rotary_fwd(ref, cos, sin, pos, hkv, qpk, d, interleaved, q_scale=scale)
+    assert torch.equal(out[0][2], ref) and torch.equal(out[0][0], q2) and torch.equal(out[0][1], kv2)
+    if fused:
+        assert bool((out[1][2] == 7.0).all()), "the fused form must not write the [T, N] product"
+
+
 # ---------------------------------------------------------------------------------------------- K8
 @pytest.mark.parametrize("rows,cols", [(16, 1792), (4096, 14336), (3, 8)])
 def test_swiglu(dev, rows, cols):
