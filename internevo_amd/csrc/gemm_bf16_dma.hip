@@ -1497,6 +1497,23 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
             auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 2 ? (bf16_t*)ACT + corner_h : C), 0, EPI == 2 ? 128 * h_row : 0, 0x00020000);
             auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (EPI == 2 ? corner_c : 0)), 0, EPI == 2 ? 128 * c_row : 0, 0x00020000);
 #endif
+            // EPI 3: the positions of this lane's two rows of every turn, and the cos / sin pieces of a turn, one turn ahead
+            int64_t rps[8][2];
+            uint4 rcs[2][2], rsn[2][2];
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) rps[i][q] = rot.pos[m0 + wm * G::WM + i * 16 + ((lane + 64 * q) >> 3)];
+            }
+            auto rot_fetch = [&](int i) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int i0 = ((lane + 64 * q) & 7) * 8;
+                    rcs[i & 1][q] = ld16((const bf16_t*)rot.cos + rps[i][q] * 64 + i0);
+                    rsn[i & 1][q] = ld16((const bf16_t*)rot.sin + rps[i][q] * 64 + i0);
+                }
+            };
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 u32x4_t hg[4], hu[4];   // EPI 2: gate / up of this turn's four pieces per lane, requested first
@@ -1519,6 +1536,12 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                 if constexpr (EPI == 3) {
                     const int slot = (n0 + wn * G::WN) >> 7, gs = rot.qpk + 2;
                     const int g = slot / gs, sl = slot - g * gs;              // kv group, slot inside it (wave-uniform)
+                    // the table rows of turn i + 1 are requested before turn i is worked on (their positions were read in front of the first turn): a turn's
+                    // two dependent round trips (position, then its cos / sin rows) would otherwise be exposed eight times per tile
+                    if (sl <= rot.qpk) {
+                        if (i == 0) rot_fetch(0);
+                        if (i + 1 < 8) rot_fetch(i + 1);
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int pc = lane + 64 * q, prow = pc >> 3, sp = pc & 7;          // 16-column span sp of row prow of the turn
@@ -1546,10 +1569,9 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                             unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + i0 * 2), x1);
                             unpack8(*reinterpret_cast<const uint4*>(ep + prow * EP + (64 + i0) * 2), x2);
                         }
-                        const int64_t ps = rot.pos[t];
                         float co[8], si[8], o1[8], o2[8];
-                        unpack8(ld16((const bf16_t*)rot.cos + ps * 64 + i0), co);
-                        unpack8(ld16((const bf16_t*)rot.sin + ps * 64 + i0), si);
+                        unpack8(rcs[i & 1][q], co);
+                        unpack8(rsn[i & 1][q], si);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             o1[e] = x1[e] * co[e] - x2[e] * si[e];
