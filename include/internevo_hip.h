@@ -447,6 +447,9 @@ int ie_flash_attn_bwd_set_spill(void* buf, int64_t bytes);
 int ie_hold_cus(int blocks, int usec, void* stream);
 /* Tuning hook (A/B): products with exactly this many output columns stay on the plain launch although ie_tune_gemm_persistent would take them (0 = none). */
 int ie_tune_gemm_persistent_skip_n(int64_t n_cols);
+/* Tuning hook (A/B): 1 = every input-gradient product (A k-contiguous, B k-major) takes the refill schedule (and with it the persistent frame where that applies),
+ * not only the long / wide ones (K >= 6144 or N >= 8192); 0 (default) = the others on the 8-wave k32 ring. */
+int ie_tune_gemm_dgrad_refill_all(int on);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

@@ -317,6 +317,7 @@ inline double shape_cost(int64_t M, int64_t N, int bm, int bn, int blocks_per_cu
     return (double)rounds * slots * bm * bn / eff;  // ~ time: rounds x work per round / efficiency
 }
 
+int g_dgrad_refill_all = 0;   // (A/B hook ie_tune_gemm_dgrad_refill_all: every input-gradient product on the refill schedule, not only the long / wide ones)
 int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, int batch = 1) {
     const bool any_kmajor = a_kmajor || b_kmajor;
     // priors from the round-1 micro-benchmarks (profiles/r01_gemm_tile_tuning.json): relative MFMA efficiency per tile shape
@@ -340,7 +341,7 @@ int pick_variant(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, 
 #ifndef IE_DGRAD_REFILL   // (A/B builds: -DIE_DGRAD_REFILL=19 keeps the long input-gradient products on the 32x32x16 refill schedule)
 #define IE_DGRAD_REFILL 20
 #endif
-            return (!a_kmajor && (K >= 6144 || N >= 8192)) ? IE_DGRAD_REFILL : 15;   // (20 on a k-major B: +1 ... +2 % over 19, profiles/r04_gemm_mfma16_ab.md)
+            return (!a_kmajor && (K >= 6144 || N >= 8192 || g_dgrad_refill_all)) ? IE_DGRAD_REFILL : 15;   // (20 on a k-major B: +1 ... +2 % over 19, profiles/r04_gemm_mfma16_ab.md)
         }
         return any_kmajor ? 5 : 8;    // 128x128: spreading helps the k-contiguous product only
     }
@@ -578,6 +579,11 @@ extern "C" int ie_tune_gemm_persistent(int mode) {
     if (mode < 0 || mode > 1024 || (mode > 1 && mode % 8)) return IE_ERR_INVALID;
     g_gemm_persistent = mode;
     return ie_gemm_dma_set_persistent_grid(mode == 0 ? 0 : mode > 1 ? mode : 256);
+}
+
+extern "C" int ie_tune_gemm_dgrad_refill_all(int on) {
+    g_dgrad_refill_all = on ? 1 : 0;
+    return IE_OK;
 }
 
 extern "C" int ie_tune_gemm_persistent_skip_n(int64_t n_cols) {
