@@ -16,6 +16,8 @@ blocks of its E/ep experts from every rank), mirrored in backward.
 The Gumbel noise of the second choice is generated on the device from (seed, layer, call counter) unless the caller supplies it
 (the parity tests inject the oracle's noise so that HIP, oracle and the real reference route identically).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -68,8 +70,6 @@ class MoELayer:
         self.ep_group, self.ep, self.ep_rank = ep_group, ep_size, ep_rank
         self.tpar = tpar if tpar is not None and tpar.tp > 1 else None
         self.El = num_experts // ep_size
-        import os
-
         nch = a2a_chunks if a2a_chunks is not None else int(os.environ.get("IE_MOE_A2A_CHUNKS", "2"))
         if ep_size <= 1 or nch < 1 or self.C % nch or (self.C // nch) % 8:
             nch = 1   # (no exchange to hide, or the capacity does not cut into whole 8-row pieces)
