@@ -9,6 +9,7 @@
 #   abab       in-step A B A B of one bench.py flag under rocprofv3 --kernel-trace:  abab <tag> "<flag> <value A>" "<flag> <value B>" [kernel grep]
 #   hold       the step with 0 / 16 / 32 CUs held where the collectives of an 8-GPU run would be, persistent GEMM frame on / off, twice
 #   extras     bench.py --seq-len 32768 --checkpoint 1.0 --micro-num 1; tools/moe_bench.py with bf16 and with opt-in fp8 experts
+#   sq         SQ counters of the matrix kernels in the step (one PMC pass of bench.py)
 #   kab        kbench lines:  kab <tag> <kbench arguments ...>
 #   tests      a subset of the GPU suite:  tests <tag> <pytest -k expression>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
@@ -98,6 +99,11 @@ extras)   # the long-context data point (seq 32768, every layer checkpointed, on
   timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --seq-len 32768 --checkpoint 1.0 --micro-num 1 > "$O/long_context_line.json" 2> "$O/long_context.err"; cut -c1-400 "$O/long_context_line.json"
   timeout 900 python tools/moe_bench.py --steps 4 --warmup 2 > "$O/moe_bench_line.json" 2> "$O/moe_bench.err"; cat "$O/moe_bench_line.json"
   timeout 900 python tools/moe_bench.py --steps 4 --warmup 2 --expert-fp8 > "$O/moe_bench_fp8_line.json" 2> "$O/moe_bench_fp8.err"; cat "$O/moe_bench_fp8_line.json"
+  ;;
+sq)   # SQ counters (matrix pipe busy, waits, LDS conflicts) of the matrix kernels in the step: one PMC pass of bench.py itself, counters only
+  rm -rf /tmp/sq
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/sq -o r -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$O/line.json" 2> "$O/pmc.err"
+  python3 tools/sq_counters_in_step.py "$(find /tmp/sq -name '*.db' | head -1)" "$O/sq_counters_in_step.md"
   ;;
 kab)
   timeout 600 $K "$@" 2>&1 | tee "$O/kbench.log"
