@@ -63,6 +63,20 @@ def _optimizer_stream(device):
     lose more to the CUs that are not theirs, for the longer update, than the update costs in turns.  Off."""
     global _HIP_RT
     n = int(os.environ.get("IE_ADAMW_CUS", "0") or 0)
+    prio = os.environ.get("IE_ADAMW_STREAM_PRIORITY")   # (A/B switch, round 6: "low" / "high" = the ends of hipDeviceGetStreamPriorityRange)
+    if prio and device.type == "cuda":
+        import ctypes
+
+        if _HIP_RT is None:
+            _HIP_RT = ctypes.CDLL("libamdhip64.so")
+        least, greatest, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = _HIP_RT.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest))
+            rc = rc or _HIP_RT.hipStreamCreateWithPriority(ctypes.byref(st), ctypes.c_uint32(1), ctypes.c_int(least.value if prio == "low" else greatest.value))   # 1 = non-blocking
+        if rc != 0 or not st.value:
+            raise RuntimeError(f"hipStreamCreateWithPriority({prio}) failed with {rc}")
+        print(f"[internevo_amd] optimizer stream priority {prio} ({least.value if prio == 'low' else greatest.value} of [{greatest.value}, {least.value}])", flush=True)
+        return torch.cuda.ExternalStream(st.value, device=device)
     if n <= 0 or device.type != "cuda":
         return torch.cuda.Stream(device=device)
     import ctypes

@@ -10,6 +10,7 @@
 #   hold       the step with 0 / 16 / 32 CUs held where the collectives of an 8-GPU run would be, persistent GEMM frame on / off, twice
 #   extras     bench.py --seq-len 32768 --checkpoint 1.0 --micro-num 1; tools/moe_bench.py with bf16 and with opt-in fp8 experts
 #   sq         SQ counters of the matrix kernels in the step (one PMC pass of bench.py)
+#   envab      in-step A B A B of an environment setting:  envab <tag> "VAR=a" "VAR=b"
 #   kab        kbench lines:  kab <tag> <kbench arguments ...>
 #   tests      a subset of the GPU suite:  tests <tag> <pytest -k expression>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
@@ -104,6 +105,14 @@ sq)   # SQ counters (matrix pipe busy, waits, LDS conflicts) of the matrix kerne
   rm -rf /tmp/sq
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/sq -o r -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$O/line.json" 2> "$O/pmc.err"
   python3 tools/sq_counters_in_step.py "$(find /tmp/sq -name '*.db' | head -1)" "$O/sq_counters_in_step.md"
+  ;;
+envab)   # in-step A B A B of an ENVIRONMENT setting (plain bench lines, 8 timed steps):  envab <tag> "VAR=a" "VAR=b"
+  for rep in 1 2; do
+    for arm in "$1" "$2"; do
+      env $arm timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing > "$O/line.json" 2> "$O/err.log"
+      echo "$arm rep $rep: $(grep -o '"ms_per_step": [0-9.]*' "$O/line.json") $(grep -o 'optimizer stream priority[^)]*)' "$O/err.log" "$O/line.json" 2>/dev/null | head -1)"
+    done
+  done 2>&1 | tee "$O/envab.log"
   ;;
 kab)
   timeout 600 $K "$@" 2>&1 | tee "$O/kbench.log"
