@@ -60,7 +60,9 @@ def _optimizer_stream(device):
     (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD), so that the HBM-bound AdamW keeps to its CUs beside the next step's forward products instead of
     taking turns with them for whole CUs (a GEMM workgroup needs a CU to itself: profiles/HISTORY.md section 3.4, profiles/r05_power_clock.md section 4).
     Measured (profiles/r05_adamw_cu_mask_ab.log, A B A B on one box): 32 / 64 / 96 CUs -> 722-726 ms per step against 671-674 ms unmasked: the products
-    lose more to the CUs that are not theirs, for the longer update, than the update costs in turns.  Off."""
+    lose more to the CUs that are not theirs, for the longer update, than the update costs in turns.  Off.
+    IE_ADAMW_STREAM_PRIORITY=low | high (A/B switch, round 6): the stream at the end of hipDeviceGetStreamPriorityRange -- six A B pairs on two boxes: level (mean +0.1 ms
+    of 655), as is IE_SERIAL_ADAMW=1 against the side stream at round 6's kernel speeds (profiles/r06_step_adamw_stream_ab.log).  Default: an ordinary stream."""
     global _HIP_RT
     n = int(os.environ.get("IE_ADAMW_CUS", "0") or 0)
     prio = os.environ.get("IE_ADAMW_STREAM_PRIORITY")   # (A/B switch, round 6: "low" / "high" = the ends of hipDeviceGetStreamPriorityRange)
