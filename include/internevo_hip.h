@@ -450,6 +450,12 @@ int ie_tune_gemm_persistent_skip_n(int64_t n_cols);
 /* Tuning hook (A/B): 1 = every input-gradient product (A k-contiguous, B k-major) takes the refill schedule (and with it the persistent frame where that applies),
  * not only the long / wide ones (K >= 6144 or N >= 8192); 0 (default) = the others on the 8-wave k32 ring. */
 int ie_tune_gemm_dgrad_refill_all(int on);
+/* The weight-gradient products' tail k-split (round 6; internlm/model/utils.py:293-299,336-340 `linear_bias_wgrad`): with a caller-owned workspace registered here
+ * (16-byte aligned; 32 MiB covers every remainder of <= 128 tiles; NULL, 0 takes it back) a weight-gradient product (both operands k-major, K % 128 == 0) whose
+ * 256x256 tiling ends in a round that is at most half full computes that remainder as two half-k products in ONE launch + a fixed-order fp32 fix-up: the
+ * remainder's 128 tiles occupy all 256 CUs for half a tile time instead of half of them for a whole one.  Deterministic; one extra bf16 rounding of the two partial
+ * sums against the unsplit product.  The workspace is used in stream order by every such product: one stream at a time. */
+int ie_gemm_set_wgrad_ksplit_workspace(void* ws, int64_t bytes);
 
 /* Diagnostic: runs one v_mfma_f32_32x32x16_bf16 with A[i][k], B[k][j] taken from a[32*16], b[16*32]
  * (row-major, bf16) using the operand/accumulator lane maps the kernels assume, writes c[32*32] fp32.

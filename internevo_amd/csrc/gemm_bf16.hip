@@ -385,6 +385,35 @@ inline TailSplit tail_split(int64_t M, int64_t N) {
     return s;
 }
 
+// ---- tail k-split of the weight-gradient products (round 6).  A 256x256 tiling whose last round is at most half full (wqkv: 384 tiles = 1.5 rounds) leaves half the
+// chip to the other half for a whole tile time -- and a weight-gradient tile is 256 k-tiles long.  With a workspace registered (ie_gemm_set_wgrad_ksplit_workspace) the
+// remainder region (<= 128 tiles, a rectangle: tail_split) is computed as a strided BATCH OF TWO products over the two halves of the contraction -- 256 blocks, one
+// round of half length, in ONE launch of the same kernel (both operands are k-major: a half is a pointer offset) -- into bf16 partial tiles, and a small kernel adds
+// the halves in fp32 in fixed order (half 0 + half 1, then the old gradient if the product accumulates) and rounds once more.  Deterministic; differs from the
+// unsplit product by that one extra bf16 rounding of the two partial sums (the reference itself adds one bf16 partial per micro-batch: hybrid_zero_optim.py's
+// AccumulateGrad on bf16 .grad).  Emulated first on the GPU (profiles/r06_wgrad_round_emulation.log): wqkv 734 -> 658 us, w2 1453 -> 1432 us.
+void* g_ksplit_ws = nullptr;
+int64_t g_ksplit_ws_bytes = 0;
+__global__ __launch_bounds__(256) void ksplit_fixup_k(const bf16_t* __restrict__ p0, const bf16_t* __restrict__ p1, bf16_t* __restrict__ C, int64_t ldc, int64_t rows,
+                                                      int64_t cols8, int accumulate) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const int64_t r = i / cols8, c = (i - r * cols8) * 8;
+    float a[8], b2[8], o[8];
+    unpack8(ld16(p0 + r * cols8 * 8 + c), a);
+    unpack8(ld16(p1 + r * cols8 * 8 + c), b2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] + b2[e];
+    bf16_t* dst = C + r * ldc + c;
+    if (accumulate) {   // bf16(old + bf16(sum)): the accumulate epilogue's arithmetic on the rounded sum
+        float old[8];
+        unpack8(ld16(dst), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = old[e] + rbf(o[e]);
+    }
+    st16(dst, pack8(o));
+}
+
 int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, int accumulate, void* stream, IeGemmBatch bt = IeGemmBatch{1, 0, 0, 0}) {
     IE_CHECK_ARG(bt.count >= 1 && bt.count <= 4096, "ie_gemm_bf16_batched: batch count out of range");
@@ -412,6 +441,30 @@ int gemm_dispatch(int variant, const void* A, int64_t lda, int a_kmajor, const v
             (g_gemm_persistent > 1 || K <= 4096 || K >= 12288) && (M / 256) * (N / 256) > (g_gemm_persistent == 1 ? 256 : g_gemm_persistent) &&
             N != g_gemm_persistent_skip_n)
             variant = 22;
+        if (g_ksplit_ws && variant == 17 && bt.count == 1 && K % 128 == 0 && K >= 1024 && fits32) {   // the weight-gradient ring, both operands k-major
+            const TailSplit ks = tail_split(M, N);
+            const int64_t rm = ks.on ? (ks.along_n ? M : M - ks.cut) : 0, rn = ks.on ? (ks.along_n ? N - ks.cut : N) : 0;
+            if (ks.on && 2 * rm * rn * 2 <= g_ksplit_ws_bytes) {
+                const char* a = (const char*)A;
+                const char* b = (const char*)B;
+                char* c = (char*)C;
+                // whole rounds: the plain product on the rectangle in front of the cut
+                int rc = ks.along_n ? gemm_dispatch(variant, A, lda, 1, B, ldb, 1, C, ldc, M, ks.cut, K, accumulate, stream)
+                                    : gemm_dispatch(variant, A, lda, 1, B, ldb, 1, C, ldc, ks.cut, N, K, accumulate, stream);
+                if (rc != IE_OK) return rc;
+                // the remainder: two half-k products as one strided batch into the workspace, then the fix-up
+                const void* ar = ks.along_n ? A : (const void*)(a + 2 * ks.cut);          // (k-major: a column offset)
+                const void* br = ks.along_n ? (const void*)(b + 2 * ks.cut) : B;
+                bf16_t* ws = (bf16_t*)g_ksplit_ws;
+                IeGemmBatch two{2, (K / 2) * lda, (K / 2) * ldb, rm * rn, 0, nullptr, 0, nullptr, 0};
+                rc = ie_gemm_dma_launch(variant - 4, ar, lda, 1, br, ldb, 1, ws, rn, rm, rn, K / 2, 0, stream, two);
+                if (rc != IE_OK) return rc;
+                bf16_t* cr = (bf16_t*)(ks.along_n ? c + 2 * ks.cut : c + 2 * ks.cut * ldc);
+                const int64_t n8 = rm * (rn / 8);
+                hipLaunchKernelGGL(ksplit_fixup_k, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, ws + rm * rn, cr, ldc, rm, rn / 8, accumulate ? 1 : 0);
+                return ie_launch_status("ie_gemm_bf16 (k-split fix-up) launch");
+            }
+        }
         const TailSplit ts = (g_tail_split && bt.count == 1 && (variant == 11 || variant == 13 || variant >= 15)) ? tail_split(M, N) : TailSplit{false, false, 0};
         if (ts.on) {
             const int tail_variant = g_tail_split == 2 ? 14 : g_tail_split == 3 ? 12 : ((a_kmajor || b_kmajor) ? 14 : 12);
@@ -579,6 +632,13 @@ extern "C" int ie_tune_gemm_persistent(int mode) {
     if (mode < 0 || mode > 1024 || (mode > 1 && mode % 8)) return IE_ERR_INVALID;
     g_gemm_persistent = mode;
     return ie_gemm_dma_set_persistent_grid(mode == 0 ? 0 : mode > 1 ? mode : 256);
+}
+
+extern "C" int ie_gemm_set_wgrad_ksplit_workspace(void* ws, int64_t bytes) {
+    if ((ws == nullptr) != (bytes == 0) || bytes < 0 || (((uintptr_t)ws) & 15u)) return IE_ERR_INVALID;
+    g_ksplit_ws = ws;
+    g_ksplit_ws_bytes = bytes;
+    return IE_OK;
 }
 
 extern "C" int ie_tune_gemm_dgrad_refill_all(int on) {

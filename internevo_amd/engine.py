@@ -174,6 +174,9 @@ class InternLM2Engine:
         self.embed_split = self.tpar.embed_split
         self.tp = tp_size
         self.rs_under_w13 = bool(int(os.environ.get("IE_RS_UNDER_W13", "0")) if rs_under_w13 is None else rs_under_w13)
+        # the weight-gradient products' tail k-split (kernels.enable_wgrad_ksplit; IE_WGRAD_KSPLIT=0: A/B switch): a process-wide setting of the library
+        if device.type == "cuda":
+            K.enable_wgrad_ksplit(device, os.environ.get("IE_WGRAD_KSPLIT", "1") != "0")
         # DIAGNOSTIC (bench.py --hold-cus n; one rank only): where a data-parallel run would launch a bucket's reduce-scatter / all-gather, launch instead n idle
         # workgroups that each occupy a CU for the time the collective would take at `link` GB/s per xGMI link (a bucket's 1 / 8 per link), on a side stream as
         # RCCL's kernels run -- prices what the CUs a collective holds cost the products beside it.  No effect on any result.

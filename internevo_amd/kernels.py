@@ -602,6 +602,21 @@ def gemm_batched(A, B, out, a_kmajor=False, b_kmajor=False, accumulate=False):
     return out
 
 
+_ksplit_ws = {}   # device index -> the 32-MiB workspace of the weight-gradient tail k-split (kept for the life of the process: the library holds its address)
+
+
+def enable_wgrad_ksplit(device, on=True):
+    """Registers (or takes back) the workspace of the weight-gradient products' tail k-split (ie_gemm_set_wgrad_ksplit_workspace): a remainder of at most 128 tiles
+    is then computed as two half-k products in one launch + a fixed-order fix-up (InternLM2-7B: the wqkv and w2 weight gradients, 384 and 896 tiles)."""
+    if not on:
+        check(_L().ie_gemm_set_wgrad_ksplit_workspace(None, 0), "ie_gemm_set_wgrad_ksplit_workspace")
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ksplit_ws:
+        _ksplit_ws[idx] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
+    check(_L().ie_gemm_set_wgrad_ksplit_workspace(_ksplit_ws[idx].data_ptr(), _ksplit_ws[idx].numel()), "ie_gemm_set_wgrad_ksplit_workspace")
+
+
 def hold_cus(blocks, usec):
     """(diagnostic) `blocks` idle workgroups, one CU each, for `usec` microseconds on the current stream (ie_hold_cus)."""
     check(_L().ie_hold_cus(int(blocks), int(usec), _stream()), "ie_hold_cus")

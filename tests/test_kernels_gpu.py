@@ -221,6 +221,47 @@ def test_wqkv_product_with_split_and_rotary_in_its_epilogue_equals_the_two_launc
         assert bool((out[1][2] == 7.0).all()), "the fused form must not write the [T, N] product"
 
 
+@pytest.mark.parametrize("M,N,Kd,rows,cols", [(6144, 4096, 2048, slice(4096, 6144), slice(None)), (4096, 14336, 1024, slice(None), slice(12288, 14336)),
+                                              (4096, 4096, 2048, None, None)], ids=["wqkv_384_tiles", "w2_896_tiles", "whole_round_no_split"])
+def test_weight_gradient_tail_k_split_is_the_two_half_products_added_in_fixed_order(dev, M, N, Kd, rows, cols):
+    """ie_gemm_set_wgrad_ksplit_workspace (round 6; linear_bias_wgrad, model/utils.py:293-299): a weight-gradient product whose 256x256 tiling ends in a round that is
+    at most half full computes the remainder rectangle as two half-k products in one launch + a fix-up.  Pinned: the rectangle in front of the cut is the unsplit
+    product bit for bit; the remainder is EXACTLY bf16(p0 + p1) of the two half products computed on their own (and bf16(old + that) when accumulating), within two
+    bf16 ulps of the unsplit product; a tiling of whole rounds is untouched; two runs give the same bits."""
+    Kk = K()
+    gen = torch.Generator(device=dev).manual_seed(29)
+    dy = torch.randn(Kd, M, device=dev, generator=gen).to(torch.bfloat16)      # [tokens, out features]: A k-major
+    x = torch.randn(Kd, N, device=dev, generator=gen).to(torch.bfloat16)       # [tokens, in features]: B k-major
+    old = (torch.randn(M, N, device=dev, generator=gen) * 4).to(torch.bfloat16)
+    Kk.enable_wgrad_ksplit(dev, False)
+    try:
+        plain = Kk.linear_wgrad(dy, x)
+        plain_acc = Kk.linear_wgrad(dy, x, old.clone(), accumulate=True)
+        h = Kd // 2
+        p0, p1 = Kk.linear_wgrad(dy[:h], x[:h]), Kk.linear_wgrad(dy[h:], x[h:])
+        Kk.enable_wgrad_ksplit(dev, True)
+        split = Kk.linear_wgrad(dy, x)
+        again = Kk.linear_wgrad(dy, x)
+        split_acc = Kk.linear_wgrad(dy, x, old.clone(), accumulate=True)
+    finally:
+        Kk.enable_wgrad_ksplit(dev, True)    # (the engines' default)
+    assert torch.equal(split, again)
+    if rows is None:
+        assert torch.equal(split, plain) and torch.equal(split_acc, plain_acc)
+        return
+    mask = torch.zeros(M, N, dtype=torch.bool, device=dev)
+    mask[rows, cols] = True
+    assert torch.equal(split[~mask], plain[~mask]) and torch.equal(split_acc[~mask], plain_acc[~mask]), "the whole rounds must be the unsplit product"
+    want = (p0.float() + p1.float()).to(torch.bfloat16)
+    assert torch.equal(split[mask], want[mask]), "remainder != bf16(half 0 + half 1)"
+    want_acc = (old.float() + want.float()).to(torch.bfloat16)
+    assert torch.equal(split_acc[mask], want_acc[mask]), "accumulating remainder != bf16(old + bf16(half 0 + half 1))"
+    assert not torch.equal(split[mask], plain[mask]) or Kd < 256   # (it IS another rounding order ...)
+    err = (split.float() - plain.float()).abs()
+    ulp = plain.float().abs().clamp_min(1e-3) * 2.0 ** -7
+    assert bool((err <= 2 * ulp + 1e-2).all()), f"... within two bf16 ulps of the unsplit product: worst {float((err / ulp).max()):.2f} ulp"
+
+
 # ---------------------------------------------------------------------------------------------- K8
 @pytest.mark.parametrize("rows,cols", [(16, 1792), (4096, 14336), (3, 8)])
 def test_swiglu(dev, rows, cols):
