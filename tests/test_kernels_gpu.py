@@ -226,8 +226,9 @@ def test_wqkv_product_with_split_and_rotary_in_its_epilogue_equals_the_two_launc
 def test_weight_gradient_tail_k_split_is_the_two_half_products_added_in_fixed_order(dev, M, N, Kd, rows, cols):
     """ie_gemm_set_wgrad_ksplit_workspace (round 6; linear_bias_wgrad, model/utils.py:293-299): a weight-gradient product whose 256x256 tiling ends in a round that is
     at most half full computes the remainder rectangle as two half-k products in one launch + a fix-up.  Pinned: the rectangle in front of the cut is the unsplit
-    product bit for bit; the remainder is EXACTLY bf16(p0 + p1) of the two half products computed on their own (and bf16(old + that) when accumulating), within two
-    bf16 ulps of the unsplit product; a tiling of whole rounds is untouched; two runs give the same bits."""
+    product bit for bit; the remainder is EXACTLY bf16(p0 + p1) of the two half products computed on their own (and bf16(old + that) when accumulating) -- so it
+    differs from the unsplit product by the bf16 rounding of the two PARTIAL sums (half a bf16 ulp of each, as every per-micro-batch partial of the reference's
+    bf16 `.grad +=` carries) and by nothing else; a tiling of whole rounds is untouched; two runs give the same bits."""
     Kk = K()
     gen = torch.Generator(device=dev).manual_seed(29)
     dy = torch.randn(Kd, M, device=dev, generator=gen).to(torch.bfloat16)      # [tokens, out features]: A k-major
@@ -258,8 +259,8 @@ def test_weight_gradient_tail_k_split_is_the_two_half_products_added_in_fixed_or
     assert torch.equal(split_acc[mask], want_acc[mask]), "accumulating remainder != bf16(old + bf16(half 0 + half 1))"
     assert not torch.equal(split[mask], plain[mask]) or Kd < 256   # (it IS another rounding order ...)
     err = (split.float() - plain.float()).abs()
-    ulp = plain.float().abs().clamp_min(1e-3) * 2.0 ** -7
-    assert bool((err <= 2 * ulp + 1e-2).all()), f"... within two bf16 ulps of the unsplit product: worst {float((err / ulp).max()):.2f} ulp"
+    bound = 2.0 ** -8 * (p0.float().abs() + p1.float().abs() + 2 * plain.float().abs()) + 1e-6   # half an ulp of each partial + the roundings of the two results
+    assert bool((err <= bound).all()), f"... beyond the partial sums' roundings: worst {float((err / bound).max()):.2f} x the bound"
 
 
 # ---------------------------------------------------------------------------------------------- K8
