@@ -23,7 +23,9 @@ def xport(port):
     """A rendezvous port private to this pytest-xdist worker (spawned ranks inherit PYTEST_XDIST_WORKER): tests that run at the same time are on
     different workers, so their process groups never meet on a port."""
     w = os.environ.get("PYTEST_XDIST_WORKER", "gw0")
-    return int(port) + 1000 * int(w[2:] or 0)
+    # (below the kernel's ephemeral range, 32768-60999: with `port + 1000 w` the fourth worker's ports sat inside it and a rendezvous once found its port taken by
+    # a gloo pair connection -- EADDRINUSE in the round-6 suite; the tests' base ports lie in [29500, 30000))
+    return 20000 + (int(port) - 29500) % 1000 + 1000 * (int(w[2:] or 0) % 12)
 
 
 @pytest.hookimpl(tryfirst=True)
