@@ -406,9 +406,10 @@ def main():
                 traffic_note = (f"profiles/{TRAFFIC_FILE} is not a measurement of this run's kernels (measured only: {sorted(measured - seen)}; launched only: "
                                 f"{sorted(seen - measured)}): no traffic reported -- re-measure with tools/gemm_traffic_in_step.py")
             else:
-                traffic = float(tj["traffic_bytes_per_launch"])
-                traffic_note = (f"{traffic / (s['bytes'] / max(s['launches'], 1)):.2f}x the algorithmic bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                                f"bench.py itself ({tj['gemm_launches']} GEMM launches of three steps; profiles/{TRAFFIC_FILE}: the same {len(seen)} kernel instantiations this run "
+                # per PRODUCT of this run (a product = one timed launch of this file; the k-split weight gradients are two kernel launches each)
+                traffic = float(tj.get("traffic_bytes_total", tj["traffic_bytes_per_launch"] * tj["gemm_launches"])) / (tj.get("steps_profiled", 3) * s["launches"] / args.steps)
+                traffic_note = (f"{traffic / (s['bytes'] / max(s['launches'], 1)):.2f}x the algorithmic bytes per product; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                                f"bench.py itself ({tj['gemm_launches']} GEMM kernel launches of {tj.get('steps_profiled', 3)} steps, summed and divided by this run's products per step; profiles/{TRAFFIC_FILE}: the same {len(seen)} kernel instantiations this run "
                                 "launched, checked by name -- a committed measurement of this workload, not re-measured by this run; fabric-side L2 misses incl. "
                                 "Infinity-Cache hits, FETCH_SIZE doubled per MI355X_MICROARCH.md)")
         except (OSError, KeyError, ValueError) as e:

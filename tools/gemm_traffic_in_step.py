@@ -37,7 +37,10 @@ def main():
                      "(incl. the w1|w3 forward product with the SwiGLU gate in its epilogue, EPI = 1)",
            "correction": "MI355X_MICROARCH.md section HBM: fetch bytes = 2 x FETCH_SIZE x 1024 (wide coalesced streaming reads report 1/2 on gfx950), WRITE_SIZE x 1024 as "
                          "is; FETCH counts fabric-side L2 misses, Infinity-Cache hits included",
-           "kernels": kernels, "gemm_launches": tot_launch, "traffic_bytes_per_launch": round(tot_bytes / max(tot_launch, 1))}
+           "kernels": kernels, "gemm_launches": tot_launch, "traffic_bytes_per_launch": round(tot_bytes / max(tot_launch, 1)),
+           # (a PRODUCT can be more than one kernel launch since round 6 -- the weight gradients' tail k-split runs the whole rounds and the two half-k remainders as
+           # two launches: bench.py divides the run's total by ITS products, three steps' worth of them)
+           "steps_profiled": 3, "traffic_bytes_total": round(tot_bytes)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1)[:3000])
 
