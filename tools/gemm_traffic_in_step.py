@@ -16,18 +16,22 @@ import sys
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    return {n: (v, k) for n, v, k in rows if "gemm_dma_k" in n or "gemm_bf16_k" in n or "gemm_p5_k" in n}
+    return {n: (v, k) for n, v, k in rows if "gemm_dma_k" in n or "gemm_bf16_k" in n or "gemm_p5_k" in n or "ksplit_fixup_k" in n}
 
 
 def main():
     fdb, wdb, out = sys.argv[1], sys.argv[2], sys.argv[3]
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
-    kernels, tot_bytes, tot_launch = {}, 0.0, 0
+    kernels, extra, tot_bytes, tot_launch = {}, {}, 0.0, 0
     for name in sorted(f):
         fv, fk = f[name]
         wv, wk = w.get(name, (0.0, fk))
         fetch_b, write_b = 2.0 * fv * 1024 / fk, wv * 1024 / max(wk, 1)
         short = name.replace("(anonymous namespace)::", "").split("(")[0]
+        if "ksplit_fixup_k" in name:   # part of a k-split product, not a product kernel of its own: its bytes count, its launches do not (bench.py checks `kernels` by name)
+            extra[short] = {"dispatches": fk, "traffic_bytes_per_launch": round(fetch_b + write_b)}
+            tot_bytes += (fetch_b + write_b) * fk
+            continue
         kernels[short] = {"dispatches": fk, "FETCH_SIZE_KB_avg": round(fv / fk, 1), "WRITE_SIZE_KB_avg": round(wv / max(wk, 1), 1),
                           "traffic_bytes_per_launch": round(fetch_b + write_b)}
         tot_bytes += (fetch_b + write_b) * fk
@@ -37,7 +41,7 @@ def main():
                      "(incl. the w1|w3 forward product with the SwiGLU gate in its epilogue, EPI = 1)",
            "correction": "MI355X_MICROARCH.md section HBM: fetch bytes = 2 x FETCH_SIZE x 1024 (wide coalesced streaming reads report 1/2 on gfx950), WRITE_SIZE x 1024 as "
                          "is; FETCH counts fabric-side L2 misses, Infinity-Cache hits included",
-           "kernels": kernels, "gemm_launches": tot_launch, "traffic_bytes_per_launch": round(tot_bytes / max(tot_launch, 1)),
+           "kernels": kernels, "fixups_of_k_split_products": extra, "gemm_launches": tot_launch, "traffic_bytes_per_launch": round(tot_bytes / max(tot_launch, 1)),
            # (a PRODUCT can be more than one kernel launch since round 6 -- the weight gradients' tail k-split runs the whole rounds and the two half-k remainders as
            # two launches: bench.py divides the run's total by ITS products, three steps' worth of them)
            "steps_profiled": 3, "traffic_bytes_total": round(tot_bytes)}
