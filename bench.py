@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--gemm-persistent-skip-n", type=int, default=None, help="A/B only: products with this many output columns stay on the plain launch")
     ap.add_argument("--qkv-rotary-fuse", type=int, default=None, help="A/B only: ie_tune_qkv_rotary_fuse (1 = split + rotary in the wqkv product's epilogue, 0 = two launches)")
     ap.add_argument("--dgrad-refill-all", type=int, default=None, help="A/B only: ie_tune_gemm_dgrad_refill_all")
+    ap.add_argument("--queue-memset", type=int, default=None, help="A/B only: ie_tune_gemm_queue_memset")
     ap.add_argument("--gemm-group", type=int, default=None, help="A/B only: ie_tune_gemm_group (tile rows per group of the XCD-aware tile order; 0 = default 4)")
     ap.add_argument("--wgrad-ksplit", type=int, default=None, choices=[0, 1], help="A/B only: the weight-gradient products' tail k-split (IE_WGRAD_KSPLIT)")
     ap.add_argument("--ffn-fuse", type=int, default=None, help="A/B only: ie_tune_ffn_fuse mode (bit 0 forward gate, bit 1 the w2 input-gradient epilogue)")
@@ -185,6 +186,8 @@ def main():
         assert K._L().ie_tune_gemm_group(args.gemm_group) == 0
     if args.dgrad_refill_all is not None:
         assert K._L().ie_tune_gemm_dgrad_refill_all(args.dgrad_refill_all) == 0
+    if args.queue_memset is not None:
+        assert K._L().ie_tune_gemm_queue_memset(args.queue_memset) == 0
     if args.qkv_rotary_fuse is not None:
         assert K._L().ie_tune_qkv_rotary_fuse(args.qkv_rotary_fuse) == 0
     if args.wgrad_ksplit is not None:

@@ -450,6 +450,10 @@ int ie_tune_gemm_persistent_skip_n(int64_t n_cols);
 /* Tuning hook (A/B): 1 = every input-gradient product (A k-contiguous, B k-major) takes the refill schedule (and with it the persistent frame where that applies),
  * not only the long / wide ones (K >= 6144 or N >= 8192); 0 (default) = the others on the 8-wave k32 ring. */
 int ie_tune_gemm_dgrad_refill_all(int on);
+/* Tuning hook: 1 = every launch of the persistent frame zeroes its tile-queue slot with a 36-byte hipMemsetAsync in stream order first; 0 (default) = the slots are
+ * zero at module load and the LAST block of every launch zeroes its slot again (the kernel does that either way), no memset kernels between the products
+ * (-0.5 % of the benchmark step, profiles/r06_step_queue_memset_abab.log). */
+int ie_tune_gemm_queue_memset(int on);
 /* The weight-gradient products' tail k-split (round 6; internlm/model/utils.py:293-299,336-340 `linear_bias_wgrad`): with a caller-owned workspace registered here
  * (16-byte aligned; 32 MiB covers every remainder of <= 128 tiles; NULL, 0 takes it back) a weight-gradient product (both operands k-major, K % 128 == 0) whose
  * 256x256 tiling ends in a round that is at most half full computes that remainder as two half-k products in ONE launch + a fixed-order fp32 fix-up: the

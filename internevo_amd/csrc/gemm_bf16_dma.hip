@@ -1690,11 +1690,13 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
 
 static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
 // tile queues of the persistent kernel: 64 slots of 16 words handed out round-robin (an atomic counter: launches may come from several host threads);
-// module-global device memory: no allocation.  Every launch ZEROES its slot in stream order first (a 36-byte hipMemsetAsync): a launch that faulted or was
-// aborted, or more than 64 launches in flight across streams, can no longer leave counters behind that make a later launch skip tiles silently (the
-// kernel's last block still zeroes the slot, which costs nothing).  In stream order the memset sits behind the previous launch on that stream; a slot is
-// taken again 64 launches later.
+// module-global device memory: no allocation, zero at module load, and the LAST block of every launch zeroes its slot for the launch that takes it 64 launches
+// later (gemm_p5_k).  A launch that faults leaves the process without a usable context, so nothing can inherit its counters.  Round 6 had added a 36-byte
+// hipMemsetAsync in front of every launch as a second line of defence: rocclr runs it as TWO fill kernels, 386 of them per benchmark step in front of the 193
+// products -- 673.1 / 671.0 ms with them, 669.3 / 668.2 ms without (profiles/r06_step_queue_memset_abab.log: -0.5 % of the step), so it is OFF by default and kept
+// behind ie_tune_gemm_queue_memset(1) for whoever suspects a slot.
 __device__ unsigned g_p5_queues[64 * 16];
+static int g_p5_queue_memset = 0;   // (ie_tune_gemm_queue_memset)
 static unsigned* p5_queue_slot(hipStream_t st) {
     static unsigned* base[16] = {};   // per device: a module-global has one address on every device of the process
     static std::atomic<unsigned> n{0};
@@ -1702,8 +1704,13 @@ static unsigned* p5_queue_slot(hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
     unsigned* slot = base[dev] + 16 * (n.fetch_add(1u, std::memory_order_relaxed) & 63u);
-    if (hipMemsetAsync(slot, 0, 9 * sizeof(unsigned), st) != hipSuccess) return nullptr;
+    if (g_p5_queue_memset && hipMemsetAsync(slot, 0, 9 * sizeof(unsigned), st) != hipSuccess) return nullptr;
     return slot;
+}
+extern "C" int ie_tune_gemm_queue_memset(int on) {
+    if (on != 0 && on != 1) return IE_ERR_INVALID;
+    g_p5_queue_memset = on;
+    return IE_OK;
 }
 static int g_gemm_persistent_on = 1;        // ie_tune_gemm_persistent's mode (the fused w1 | w3 product is launched from this file)
 extern "C" int ie_gemm_dma_set_persistent_grid(int blocks) {   // (ie_tune_gemm_persistent: 0 = off, 8 .. 1024 = that many blocks (mode > 1), 256 + on for mode 1)

@@ -25,6 +25,7 @@ bench_traced() {   # bench_traced <outfile prefix> <bench flags...>: 1 warm-up +
   rm -rf /tmp/prof_t
   timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_t -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > "${pre}_line.json" 2> "${pre}.err"
   summ /tmp/prof_t "${pre}_kernel_stats.md" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing $*"
+  python3 tools/gpu_idle_from_trace.py "$(find /tmp/prof_t -name '*.db' | head -1)" > "${pre}_idle.md" 2>&1
 }
 
 case $JOB in
