@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--qkv-rotary-fuse", type=int, default=None, help="A/B only: ie_tune_qkv_rotary_fuse (1 = split + rotary in the wqkv product's epilogue, 0 = two launches)")
     ap.add_argument("--dgrad-refill-all", type=int, default=None, help="A/B only: ie_tune_gemm_dgrad_refill_all")
     ap.add_argument("--queue-memset", type=int, default=None, help="A/B only: ie_tune_gemm_queue_memset")
+    ap.add_argument("--adamw-cus", type=int, default=None, help="A/B only: the CUs AdamW may occupy beside the next forward (IE_ADAMW_CUS; 0 = whole chip)")
+    ap.add_argument("--adamw-full-buckets", type=int, default=None, help="A/B only: the first buckets' AdamW over the whole chip (IE_ADAMW_FULL_BUCKETS)")
     ap.add_argument("--gemm-group", type=int, default=None, help="A/B only: ie_tune_gemm_group (tile rows per group of the XCD-aware tile order; 0 = default 4)")
     ap.add_argument("--wgrad-ksplit", type=int, default=None, choices=[0, 1], help="A/B only: the weight-gradient products' tail k-split (IE_WGRAD_KSPLIT)")
     ap.add_argument("--ffn-fuse", type=int, default=None, help="A/B only: ie_tune_ffn_fuse mode (bit 0 forward gate, bit 1 the w2 input-gradient epilogue)")
@@ -192,6 +194,10 @@ def main():
         assert K._L().ie_tune_qkv_rotary_fuse(args.qkv_rotary_fuse) == 0
     if args.wgrad_ksplit is not None:
         os.environ["IE_WGRAD_KSPLIT"] = str(args.wgrad_ksplit)
+    if args.adamw_cus is not None:
+        os.environ["IE_ADAMW_CUS"] = str(args.adamw_cus)
+    if args.adamw_full_buckets is not None:
+        os.environ["IE_ADAMW_FULL_BUCKETS"] = str(args.adamw_full_buckets)
     if args.hold_cus:
         if args.gpus != 1:
             raise SystemExit("--hold-cus is the one-GPU stand-in for a collective's CUs")

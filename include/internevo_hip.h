@@ -229,6 +229,11 @@ int ie_step_control(IeStepState* state_dev, const float* sumsq_dev, const IeScal
 int ie_adamw_step(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n,
                   const IeStepState* state_dev, double lr, double beta1, double beta2, double eps,
                   double weight_decay, void* stream);
+/* How many CUs the following ie_adamw_step / ie_adamw_step_group launches may occupy: 0 (default) = the whole chip (16 384 grid-stride workgroups), n = 1 .. 256 =
+ * n workgroups of 1024 threads, each alone on a CU.  Same arithmetic element by element, bit-identical results.  For an update that runs BESIDE the next step's
+ * forward (hybrid_zero_optim.py:787 steps after the backward; the reference has nothing beside it): the matrix kernels need whole CUs and only get them between two
+ * whole-chip launches.  Read at launch time on the calling thread. */
+int ie_tune_adamw_cus(int cus);
 
 /* ------------------------------------------------------------------------------------------------
  * a10 Embedding.  F.embedding fwd (internlm/model/modules/embedding.py:52-60) and its dense

@@ -49,7 +49,7 @@ extern "C" int ie_mfma_probe(const void* a, const void* b, float* c, void* strea
 // to itself: one 512-register wave per SIMD and 144 KB of LDS, so any resident wave keeps it away; here 256 threads = one wave per SIMD and 96 KB of LDS = one
 // such block per CU).  The blocks sleep between looks at the 100 MHz wall clock (s_sleep: no issue slots, no memory traffic, next to no power).
 __global__ __launch_bounds__(256) void hold_cu_k(long long ticks) {
-    __shared__ unsigned char pad[96 * 1024];
+    __shared__ volatile unsigned char pad[96 * 1024];
     if (ticks < 0) pad[threadIdx.x] = 0;   // (keeps the allocation)
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);

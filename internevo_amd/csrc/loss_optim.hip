@@ -397,13 +397,16 @@ struct AdamConsts {
     float inv_scale;
 };
 
+// Every rounding of the update is written out (no contraction left to the compiler: `v * beta2 + one_m_b2 * g * g` can be fused two ways, and round 6 found two
+// kernels inlining this function one ulp apart in v): the whole-chip kernel, the few-CU kernel and the scalar tails give the same bits for the same element.
 __device__ __forceinline__ void adam_one(float g, float& p, float& m, float& v, const AdamConsts& c) {
-    g *= c.inv_scale;
-    p *= c.decay;
-    m = m + c.one_m_b1 * (g - m);
-    v = v * c.beta2 + c.one_m_b2 * g * g;
+#pragma clang fp contract(off)
+    g = g * c.inv_scale;
+    p = p * c.decay;
+    m = __builtin_fmaf(c.one_m_b1, g - m, m);
+    v = __builtin_fmaf(c.one_m_b2 * g, g, v * c.beta2);
     const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-    p = p - c.step_size * (m / denom);
+    p = __builtin_fmaf(-c.step_size, m / denom, p);
 }
 
 // (Round 6 tried every access of the stream 16 bytes wide -- eight elements per thread and trip, the bf16 gradient and shadow as 16-byte accesses, two
@@ -460,6 +463,99 @@ __global__ __launch_bounds__(256) void adamw_k(const void* __restrict__ g, float
             o.x = pack2bf(pp.x, pp.y);
             o.y = pack2bf(pp.z, pp.w);
             st8(p16 + i * 4, o);
+        }
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) {
+        const float gg = GBF ? bf2f(((const bf16_t*)g)[i]) : ((const float*)g)[i];
+        float pp = p32[i], mm = m[i], vv = v[i];
+        adam_one(gg, pp, mm, vv, c);
+        p32[i] = pp; m[i] = mm; v[i] = vv;
+        if (p16) p16[i] = f2bf(pp);
+    }
+}
+
+// AdamW ON A FEW CUs (round 6; ie_tune_adamw_cus).  The update overlaps the next step's first forward layers, and a GEMM workgroup of this library needs a CU to
+// itself (one 512-register wave per SIMD, 144 KB of LDS): beside adamw_k's 16 384 grid-stride blocks, which fill every wave slot of every CU for a whole bucket,
+// the forward kernels only get CUs in the gaps between two buckets' launches (profiles/r06_step_sequence_adamw_beside_forward.txt: the attention forward 9.2 ms
+// instead of 0.6, w2 2.8 ms instead of 1.3 while the update runs).  This kernel is the same arithmetic element by element (adam_one: results bit-identical) as
+// `blocks` workgroups, each pinned to a CU of its own by 96 KB of LDS nobody reads (the dispatcher spreads them over the XCDs): the update keeps to its CUs, the
+// persistent GEMM frame's queues hand the tiles to the blocks that did get a CU.  A CU streams about 28 GB/s of this mix, so the update needs 96 or more CUs to
+// stay ahead of the forward (profiles/r06_step_adamw_cus_sweep.log: 16 CUs 732 ms, 32 666, 64 656, 96 ... 192 650 ... 651, the whole chip 654 ... 657 ms per step);
+// the shape measured best is 512 threads x four 16-byte groups of every stream in flight, p / m / v / g non-temporal (they are not read again this step; the
+// forward's weight panels keep the L2s) -- 1024 threads x two groups with ordinary accesses: + 1.5 ms, non-temporal: + 0.5 ms.
+template <bool GBF, int U, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void adamw_cus_k(const void* __restrict__ g, float* __restrict__ p32, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ p16, int64_t n, const IeStepState* __restrict__ state, double lr, double beta1,
+                                                    double beta2, float eps, double wd, const float* __restrict__ inv_scale_group) {
+    __shared__ volatile unsigned char pin[96 * 1024];
+    __shared__ AdamConsts sc;
+    __shared__ int skip;
+    if (n < 0) pin[threadIdx.x] = 0;   // (keeps the allocation)
+    if (threadIdx.x == 0) {
+        skip = state->skip;
+        const int step = state->adam_step;
+        const double bc1 = 1.0 - pow(beta1, (double)step);
+        const double bc2 = 1.0 - pow(beta2, (double)step);
+        sc.decay = (float)(1.0 - lr * wd);
+        sc.one_m_b1 = (float)(1.0 - beta1);
+        sc.beta2 = (float)beta2;
+        sc.one_m_b2 = (float)(1.0 - beta2);
+        sc.step_size = (float)(lr / bc1);
+        sc.bc2_sqrt = (float)sqrt(bc2);
+        sc.eps = eps;
+        sc.inv_scale = inv_scale_group ? inv_scale_group[0] : state->inv_scale;
+    }
+    __syncthreads();
+    if (skip) return;
+    const AdamConsts c = sc;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * THREADS;
+    const int64_t n4 = n / 4;
+    auto ld4 = [](const float* q) -> f32x4 {
+        return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q);
+    };
+    auto st4 = [](float* q, f32x4 x) {
+        if (NT) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(q));
+        else *reinterpret_cast<f32x4*>(q) = x;
+    };
+    for (int64_t i0 = tid; i0 < n4; i0 += U * nthreads) {
+        f32x4 gg[U], pp[U], mm[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // U 16-byte groups of every stream in flight per thread
+            const int64_t i = i0 + u * nthreads;
+            if (i < n4) {
+                if (GBF) {
+                    const bf16_t* q = (const bf16_t*)g + i * 4;
+                    const u32x2 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(q)) : *reinterpret_cast<const u32x2*>(q);
+                    gg[u] = f32x4{bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+                } else {
+                    gg[u] = ld4((const float*)g + i * 4);
+                }
+                pp[u] = ld4(p32 + i * 4);
+                mm[u] = ld4(m + i * 4);
+                vv[u] = ld4(v + i * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * nthreads;
+            if (i < n4) {
+                float P[4] = {pp[u].x, pp[u].y, pp[u].z, pp[u].w}, M[4] = {mm[u].x, mm[u].y, mm[u].z, mm[u].w}, V[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                const float G[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) adam_one(G[e], P[e], M[e], V[e], c);
+                st4(p32 + i * 4, f32x4{P[0], P[1], P[2], P[3]});
+                st4(m + i * 4, f32x4{M[0], M[1], M[2], M[3]});
+                st4(v + i * 4, f32x4{V[0], V[1], V[2], V[3]});
+                if (p16) {   // (the next forward reads the shadow: an ordinary store)
+                    uint2 o;
+                    o.x = pack2bf(P[0], P[1]);
+                    o.y = pack2bf(P[2], P[3]);
+                    st8(p16 + i * 4, o);
+                }
+            }
         }
     }
     for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) {
@@ -605,6 +701,13 @@ extern "C" int ie_step_control_groups(IeStepState* state_dev, const float* sumsq
 static int adamw_launch(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n, const IeStepState* state_dev,
                         const float* inv_scale_group, double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
+static int g_adamw_cus = 0;   // ie_tune_adamw_cus: 0 = adamw_k over the whole chip, n = adamw_cus_k on n CUs
+extern "C" int ie_tune_adamw_cus(int cus) {
+    if (cus < 0 || cus > 256) return IE_ERR_INVALID;
+    g_adamw_cus = cus;
+    return IE_OK;
+}
+
 extern "C" int ie_adamw_step_group(const void* g, int g_dtype, float* p32, float* m, float* v, void* p16, int64_t n, const IeStepState* state_dev,
                                    const float* inv_scale_group_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
                                    void* stream) {
@@ -625,6 +728,16 @@ static int adamw_launch(const void* g, int g_dtype, float* p32, float* m, float*
     if (n == 0) return IE_OK;
     const int vec_ok = aligned16(p32) && aligned16(m) && aligned16(v) && ((((uintptr_t)g) & (g_dtype == IE_BF16 ? 7u : 15u)) == 0) &&
                        (!p16 || (((uintptr_t)p16) & 7u) == 0);
+    const int cus = g_adamw_cus;
+    if (cus > 0 && vec_ok && n >= (int64_t)cus * 8192) {   // (a short vector is not worth pinning CUs for)
+        if (g_dtype == IE_BF16)
+            hipLaunchKernelGGL((adamw_cus_k<true, 4, true, 512>), dim3((unsigned)cus), dim3(512), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n, state_dev, lr,
+                               beta1, beta2, (float)eps, weight_decay, inv_scale_group);
+        else
+            hipLaunchKernelGGL((adamw_cus_k<false, 4, true, 512>), dim3((unsigned)cus), dim3(512), 0, (hipStream_t)stream, g, p32, m, v, (bf16_t*)p16, n, state_dev, lr,
+                               beta1, beta2, (float)eps, weight_decay, inv_scale_group);
+        return ie_launch_status("ie_adamw_step launch (few CUs)");
+    }
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;

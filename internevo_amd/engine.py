@@ -56,15 +56,13 @@ def _mem_budget(device):
 
 
 def _optimizer_stream(device):
-    """The optimizer's HIP stream.  IE_ADAMW_CUS=n (A/B switch, default 0 = an ordinary stream): a stream whose kernels may only use n of the 256 CUs
-    (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD), so that the HBM-bound AdamW keeps to its CUs beside the next step's forward products instead of
-    taking turns with them for whole CUs (a GEMM workgroup needs a CU to itself: profiles/HISTORY.md section 3.4, profiles/r05_power_clock.md section 4).
-    Measured (profiles/r05_adamw_cu_mask_ab.log, A B A B on one box): 32 / 64 / 96 CUs -> 722-726 ms per step against 671-674 ms unmasked: the products
-    lose more to the CUs that are not theirs, for the longer update, than the update costs in turns.  Off.
+    """The optimizer's HIP stream: an ordinary stream.
+    Round 5 tried a stream whose kernels may only use n of the 256 CUs (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD): 32 / 64 / 96 CUs -> 722-726 ms per
+    step against 671-674 ms unmasked (profiles/r05_adamw_cu_mask_ab.log) -- the same loss whatever n: not what fewer CUs for the update should do, the masked queue
+    itself cost the step.  Round 6 restricts the update by its LAUNCH SHAPE instead (ie_tune_adamw_cus: n workgroups, each alone on a CU; InternLM2Engine.adamw_cus).
     IE_ADAMW_STREAM_PRIORITY=low | high (A/B switch, round 6): the stream at the end of hipDeviceGetStreamPriorityRange -- six A B pairs on two boxes: level (mean +0.1 ms
     of 655), as is IE_SERIAL_ADAMW=1 against the side stream at round 6's kernel speeds (profiles/r06_step_adamw_stream_ab.log).  Default: an ordinary stream."""
     global _HIP_RT
-    n = int(os.environ.get("IE_ADAMW_CUS", "0") or 0)
     prio = os.environ.get("IE_ADAMW_STREAM_PRIORITY")   # (A/B switch, round 6: "low" / "high" = the ends of hipDeviceGetStreamPriorityRange)
     if prio and device.type == "cuda":
         import ctypes
@@ -79,20 +77,7 @@ def _optimizer_stream(device):
             raise RuntimeError(f"hipStreamCreateWithPriority({prio}) failed with {rc}")
         print(f"[internevo_amd] optimizer stream priority {prio} ({least.value if prio == 'low' else greatest.value} of [{greatest.value}, {least.value}])", flush=True)
         return torch.cuda.ExternalStream(st.value, device=device)
-    if n <= 0 or device.type != "cuda":
-        return torch.cuda.Stream(device=device)
-    import ctypes
-
-    if _HIP_RT is None:
-        _HIP_RT = ctypes.CDLL("libamdhip64.so")
-    per = max(1, min(32, n // 8))
-    words = (ctypes.c_uint32 * 8)(*([(1 << per) - 1 if per < 32 else 0xFFFFFFFF] * 8))
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = _HIP_RT.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(8), words)
-    if rc != 0 or not st.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n} CUs) failed with {rc}")
-    return torch.cuda.ExternalStream(st.value, device=device)
+    return torch.cuda.Stream(device=device)
 
 
 class InternLM2Engine:
@@ -356,6 +341,9 @@ class InternLM2Engine:
         # The optimizer runs on its own HIP stream: AdamW is HBM-bound (28 B per parameter), the next step's first forward
         # GEMMs are MFMA-bound, so bucket b+1's update overlaps the forward of layer b; per-bucket events order the two.
         self.opt_stream = _optimizer_stream(device)
+        # AdamW beside the next step's forward (step()): the buckets behind the first adamw_full_buckets run on adamw_cus CUs (ie_tune_adamw_cus; 0 = whole chip)
+        self.adamw_cus = int(os.environ.get("IE_ADAMW_CUS", "128") or 0)
+        self.adamw_full_buckets = int(os.environ.get("IE_ADAMW_FULL_BUCKETS", "2") or 0)
         self._bucket_ready = [None] * len(self.layout.buckets)
         self._opt_done = None
         self.metric = None  # optional internevo_amd.metrics.AccPerplex (attach_metric)
@@ -1367,10 +1355,15 @@ class InternLM2Engine:
         opt_stream = main if os.environ.get("IE_SERIAL_ADAMW") == "1" else self.opt_stream   # (A/B switch: AdamW in line with the step)
         with torch.cuda.stream(opt_stream):
             opt_stream.wait_event(ev)  # gradients, norm and step control are final
+            launched = 0
             for b, lo, gsh in zip(L.buckets, L.local_offsets(), shards):
                 n = b.size // self.world
                 if n == 0:   # a bucket this pipeline stage does not own
                     continue
+                # the first buckets over the whole chip (the next forward has nothing to run until they are done), the others on adamw_cus CUs beside it
+                if self.adamw_cus and opt_stream is not main:
+                    K.tune_adamw_cus(self.adamw_cus if launched >= self.adamw_full_buckets else 0)
+                launched += 1
                 K.adamw_step(gsh, self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n], self._shard(self.params, b),
                              self.state, lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
                 if b.index not in self._wp_buckets and self.comm.active:   # (a weight-parallel layer is gathered when it runs, into its pool slot)
@@ -1381,6 +1374,8 @@ class InternLM2Engine:
                 done.record(opt_stream)
                 self._bucket_ready[b.index] = done
             self._opt_done = done
+            if self.adamw_cus:
+                K.tune_adamw_cus(0)
         if self.wp_mode:
             self._slot_layer = [None, None]   # the pool holds the weights of before this update
         # the all-gathers are NOT waited for here: the next forward waits per bucket (comm.wait_gather), so the parameter
@@ -1439,6 +1434,8 @@ class InternLM2Engine:
             done = None
             for i, (b, o, n, grp) in enumerate(pieces):
                 lo = offs[b.index] + o
+                if self.adamw_cus and opt_stream is not main:   # (as in step(): the first buckets over the whole chip, the others beside the forward)
+                    K.tune_adamw_cus(self.adamw_cus if b.index >= self.adamw_full_buckets else 0)
                 K.adamw_step_group(shards[b.index][o : o + n], self.master[lo : lo + n], self.exp_avg[lo : lo + n], self.exp_avg_sq[lo : lo + n],
                                    self._shard(self.params, b)[o : o + n], self.state, self.group_inv[grp : grp + 1], lr, tc.adam_beta1, beta2, tc.adam_eps, tc.weight_decay)
                 if i + 1 < len(pieces) and pieces[i + 1][0] is b:
@@ -1449,6 +1446,8 @@ class InternLM2Engine:
                 done.record(opt_stream)
                 self._bucket_ready[b.index] = done
             self._opt_done = done
+            if self.adamw_cus:
+                K.tune_adamw_cus(0)
         if self.wp_mode:
             self._slot_layer = [None, None]
         self.lr_sched.step()

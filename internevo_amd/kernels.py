@@ -343,6 +343,11 @@ def adamw_step(g, p32, m, v, p16, st, lr, beta1, beta2, eps, weight_decay):
           "ie_adamw_step")
 
 
+def tune_adamw_cus(cus):
+    """How many CUs the following adamw_step launches of this thread's process may occupy (0 = the whole chip); include/internevo_hip.h."""
+    check(_L().ie_tune_adamw_cus(int(cus)), "ie_tune_adamw_cus")
+
+
 def step_control_groups(st, sumsq_dev, cfg: IeScalerConfig, group_inv, group_norm):
     """HybridZeroOptimizer._step with several parameter groups: one overflow decision / scaler update over all of them, every group unscaled and
     clipped by its OWN norm (hybrid_zero_optim.py:760-779,863-876).  sumsq_dev [n]; group_inv / group_norm [n] fp32 outputs on the device."""

@@ -113,3 +113,19 @@ def test_dkdv_kernel_keeps_its_register_files(tmp_path):
         assert "vmcnt" not in own, f"{m.group(1)}: compiler-inserted vmcnt wait inside the tile loop"
         checked += 1
     assert checked >= 24, checked
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.timeout(300)
+def test_workgroups_that_must_sit_alone_on_a_cu_really_allocate_their_lds(tmp_path):
+    """hold_cu_k (capi.hip) and adamw_cus_k (loss_optim.hip) pin one workgroup per CU with 96 KB of LDS nobody reads.  The compiler removes an array whose only
+    store is dead (round 6 found hold_cu_k built with 0 bytes: the array has to be volatile): the code object's group segment size is the guarantee."""
+    for fname, kernel in (("capi.hip", "hold_cu_k"), ("loss_optim.hip", "adamw_cus_k")):
+        out = tmp_path / (fname + ".s")
+        src = os.path.join(ROOT, "internevo_amd", "csrc", fname)
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.dirname(src), src, "-o", str(out)], check=True, capture_output=True)
+        found = re.findall(r"\.group_segment_fixed_size:\s+(\d+)\n(?:(?!.*group_segment_fixed_size).*\n)*?\s+\.name:\s+(\S*" + kernel + r"\S*)\n", out.read_text())
+        assert found, f"{kernel}: metadata not parsed"
+        for lds, name in found:
+            assert 96 * 1024 <= int(lds) <= 160 * 1024, f"{name}: {lds} B of LDS -- more than one such workgroup fits on a CU"

@@ -380,6 +380,42 @@ def test_adamw_matches_torch(dev):
     assert torch.equal(before, p32)
 
 
+@pytest.mark.parametrize("how", [1, 16, 64, 128])
+@pytest.mark.parametrize("gdt", ["bf16", "f32"])
+def test_adamw_on_a_few_cus_is_bit_identical_to_the_whole_chip_kernel(dev, how, gdt):
+    """ie_tune_adamw_cus(n): n workgroups pinned to a CU each -- the same arithmetic element by element (p, m, v, the bf16 shadow and a skipped step),
+    sizes with a ragged tail, odd multiples of the workgroup stride, and below the size the few-CU path takes at all."""
+    k = K()
+    from internevo_amd._lib import IeScalerConfig
+
+    cfg = IeScalerConfig(2.0, 0.5, 1.0, float(2**24), 1000, 2, 1.0, 1)
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.95, 1e-8, 0.01
+    cus = how
+    for n in (cus * 8192 - 5, cus * 8192, cus * 8192 * 3 + 4 * 1024 * cus + 7, 1_000_003 if cus <= 16 else 2_000_003):
+        runs = []
+        for c in (0, how):
+            p32 = torch.randn(n, generator=g(50)).to(dev)
+            m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+            st = k.step_state_new(dev, 65536.0)
+            try:
+                k.tune_adamw_cus(c)
+                for step in range(1, 3):
+                    gr = bf(torch.randn(n, generator=g(50 + step)) * 65536 * 0.01)
+                    gr = gr.to(dev) if gdt == "bf16" else gr.float().to(dev)
+                    k.step_control(st, k.sumsq(gr), cfg)
+                    k.adamw_step(gr, p32, m, v, p16, st, lr, b1, b2, eps, wd)
+                kept = p32.clone()
+                k.step_control(st, torch.tensor([float("inf")], device=dev), cfg)
+                k.adamw_step(gr, p32, m, v, p16, st, lr, b1, b2, eps, wd)
+                assert torch.equal(kept, p32), "a skipped step touched the parameters"
+            finally:
+                k.tune_adamw_cus(0)
+            runs.append((p32, m, v, p16))
+        for a, b_, what in zip(runs[0], runs[1], ("p", "m", "v", "bf16 shadow")):
+            assert torch.equal(a, b_), f"{what} differs at n = {n}, {cus} CUs"
+
+
 # ---------------------------------------------------------------------------------------------- a10
 def test_embedding(dev):
     V, dim, T = 1000, 512, 300

@@ -11,6 +11,8 @@
 #   extras     bench.py --seq-len 32768 --checkpoint 1.0 --micro-num 1; tools/moe_bench.py with bf16 and with opt-in fp8 experts
 #   sq         SQ counters of the matrix kernels in the step (one PMC pass of bench.py)
 #   envab      in-step A B A B of an environment setting:  envab <tag> "VAR=a" "VAR=b"
+#   flagab     A B A B of two bench.py flag sets without the profiler:  flagab <tag> "<flags A>" "<flags B>"
+#   sweep      one bench.py flag over several values without the profiler, the list twice:  sweep <tag> <flag> <v1> <v2> ...
 #   kab        kbench lines:  kab <tag> <kbench arguments ...>
 #   tests      a subset of the GPU suite:  tests <tag> <pytest -k expression>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
@@ -26,6 +28,7 @@ bench_traced() {   # bench_traced <outfile prefix> <bench flags...>: 1 warm-up +
   timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_t -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > "${pre}_line.json" 2> "${pre}.err"
   summ /tmp/prof_t "${pre}_kernel_stats.md" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing $*"
   python3 tools/gpu_idle_from_trace.py "$(find /tmp/prof_t -name '*.db' | head -1)" > "${pre}_idle.md" 2>&1
+  python3 tools/step_sequence.py "$(find /tmp/prof_t -name '*.db' | head -1)" "${pre}_sequence.txt" 2>&1 | tail -2
 }
 
 case $JOB in
@@ -114,6 +117,24 @@ envab)   # in-step A B A B of an ENVIRONMENT setting (plain bench lines, 8 timed
       echo "$arm rep $rep: $(grep -o '"ms_per_step": [0-9.]*' "$O/line.json") $(grep -o 'optimizer stream priority[^)]*)' "$O/err.log" "$O/line.json" 2>/dev/null | head -1)"
     done
   done 2>&1 | tee "$O/envab.log"
+  ;;
+flagab)   # A B A B of two bench.py flag sets WITHOUT the profiler (plain bench lines, 8 timed steps; the flags are all of the run's extra flags):  flagab <tag> "<flags A>" "<flags B>"
+  for rep in 1 2; do
+    for arm in A B; do
+      [ $arm = A ] && F=$1 || F=$2
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline $F > "$O/${arm}${rep}_line.json" 2> "$O/${arm}${rep}.err"
+      echo "$arm ($F) rep $rep: $(grep -o '"ms_per_step": [0-9.]*' "$O/${arm}${rep}_line.json")"
+    done
+  done 2>&1 | tee "$O/flagab.log"
+  ;;
+sweep)   # one bench.py flag over several values, without the profiler, the whole list twice:  sweep <tag> <flag> <v1> <v2> ...
+  FL=$1; shift
+  for rep in 1 2; do
+    for v in "$@"; do
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing $FL $v > "$O/v${v}_${rep}_line.json" 2> "$O/v${v}_${rep}.err"
+      echo "$FL $v rep $rep: $(grep -o '"ms_per_step": [0-9.]*' "$O/v${v}_${rep}_line.json")"
+    done
+  done 2>&1 | tee "$O/sweep.log"
   ;;
 kab)
   timeout 600 $K "$@" 2>&1 | tee "$O/kbench.log"
