@@ -380,6 +380,28 @@ def test_adamw_matches_torch(dev):
     assert torch.equal(before, p32)
 
 
+@pytest.mark.parametrize("dim", [4096, 6144, 520, 516])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_embedding_backward_is_the_fp32_sum_in_token_order_bit_for_bit(dev, dim, accumulate):
+    """embedding_bwd_row_k (one block per referenced row, all its columns; dim % 8 == 0) and embedding_bwd_k (the fallback: dim = 516 here): per vocabulary row
+    the fp32 sum of its tokens' gradient rows IN TOKEN ORDER, rounded to bf16 once (+ the old gradient when accumulating) -- torch's CPU index_add_ in fp32 walks
+    the index in order, so the comparison is exact.  Heavy duplication (300 tokens on 7 ids), an id at the end of the vocabulary, untouched rows."""
+    V, T = 1000, 1300
+    ids = torch.randint(0, 200, (T,), generator=g(60))
+    ids[:300] = torch.randint(0, 7, (300,), generator=g(61))
+    ids[77] = V - 1
+    dout = bf(torch.randn(T, dim, generator=g(62)))
+    old = bf(torch.randn(V, dim, generator=g(63)))
+    dw = old.to(dev).clone() if accumulate else torch.full((V, dim), 7.0, dtype=torch.bfloat16, device=dev)
+    K().embedding_bwd(dout.to(dev), ids.to(dev), dw, accumulate=accumulate)
+    summed = torch.zeros(V, dim).index_add_(0, ids, dout.float()).to(torch.bfloat16)
+    ref = (summed.float() + old.float()).to(torch.bfloat16) if accumulate else summed
+    touched = torch.zeros(V, dtype=torch.bool).index_fill_(0, ids, True)
+    if accumulate:
+        ref[~touched] = old[~touched]
+    assert torch.equal(dw.cpu(), ref), f"max diff {(dw.cpu().float() - ref.float()).abs().max()}"
+
+
 @pytest.mark.parametrize("how", [1, 16, 64, 128])
 @pytest.mark.parametrize("gdt", ["bf16", "f32"])
 def test_adamw_on_a_few_cus_is_bit_identical_to_the_whole_chip_kernel(dev, how, gdt):
