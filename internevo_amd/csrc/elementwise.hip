@@ -304,26 +304,41 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const bf16_t* __restrict_
                                                        int64_t dim, int accumulate) {
     if ((int)blockIdx.x >= ws[vocab]) return;
     __shared__ unsigned long long masks[4];
+    __shared__ unsigned short hits[256];
     const int64_t v = ws[vocab + 1 + blockIdx.x];
     const int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
-    // 256 ids per pass: every thread tests one id, the 4 wave ballots go through LDS, then all threads walk the
-    // set bits IN TOKEN ORDER (deterministic sum) and add their column of the matching rows.
+    // 256 ids per pass: every thread tests one id, the 4 wave ballots go through LDS, the hits are listed IN TOKEN ORDER (a hit's place = the hits in
+    // front of it), then all threads add their column of the listed rows in that order -- sixteen loads in flight before the sixteen adds (round 6: the
+    // benchmark's data, dummy_dataset.py, has fewer than 30 distinct ids, some of them thousands of times; one load per add made the kernel a chain of HBM
+    // latencies, 1.25 ms per step).  Same adds in the same order: the sum is unchanged bit for bit.
     for (int64_t base = 0; base < T; base += 256) {
         const int64_t t = base + threadIdx.x;
         const bool hit = t < T && ids[t] == v;
         const unsigned long long m = __ballot(hit);
-        __syncthreads();
+        __syncthreads();   // (the list of the pass before has been read)
         if (lane == 0) masks[wave] = m;
         __syncthreads();
+        int before = 0, nh = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            unsigned long long mm = masks[w];
-            while (mm) {
-                const int b = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                if (c < dim) acc += bf2f(dout[(base + w * 64 + b) * dim + c]);
+            const int k = __popcll(masks[w]);
+            if (w < wave) before += k;
+            nh += k;
+        }
+        if (hit) hits[before + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+        if (nh == 0) continue;   // (uniform: every thread read the same four masks)
+        __syncthreads();
+        if (c < dim) {
+            for (int k0 = 0; k0 < nh; k0 += 16) {
+                bf16_t x[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k0 + k < nh) x[k] = dout[(base + hits[k0 + k]) * dim + c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k0 + k < nh) acc += bf2f(x[k]);
             }
         }
     }
@@ -331,66 +346,6 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(const bf16_t* __restrict_
         float r = rbf(acc);
         if (accumulate) r += bf2f(dw[v * dim + c]);
         dw[v * dim + c] = f2bf(r);
-    }
-}
-
-// The same sum with ONE block per referenced row for all its columns (round 6): the id scan is what the kernel above spends its time in (every block tests all T
-// ids; with a block per 256 columns a 4096-wide row is scanned 16 times: 1.25 ms per step at 16 384 tokens), so here a thread owns 8 consecutive columns of up to
-// four 2048-column chunks (16-byte accesses) and the row is scanned once.  Same tokens in the same order into fp32: bit-identical to embedding_bwd_k.
-__global__ __launch_bounds__(256) void embedding_bwd_row_k(const bf16_t* __restrict__ dout, const int64_t* __restrict__ ids, bf16_t* __restrict__ dw,
-                                                           const int* __restrict__ ws, int64_t T, int64_t vocab, int64_t dim, int accumulate) {
-    if ((int)blockIdx.x >= ws[vocab]) return;
-    __shared__ unsigned long long masks[4];
-    const int64_t v = ws[vocab + 1 + blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nch = (int)((dim + 2047) / 2048);   // <= 4 (the launcher)
-    float acc[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-    for (int64_t base = 0; base < T; base += 256) {
-        const int64_t t = base + threadIdx.x;
-        const bool hit = t < T && ids[t] == v;
-        const unsigned long long m = __ballot(hit);
-        __syncthreads();
-        if (lane == 0) masks[wave] = m;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            unsigned long long mm = masks[w];
-            while (mm) {
-                const int b = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const bf16_t* row = dout + (base + w * 64 + b) * dim;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t c = (int64_t)j * 2048 + threadIdx.x * 8;
-                    if (j < nch && c < dim) {
-                        float f[8];
-                        unpack8(*reinterpret_cast<const uint4*>(row + c), f);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[j][e] += f[e];
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t c = (int64_t)j * 2048 + threadIdx.x * 8;
-        if (j < nch && c < dim) {
-            float r[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = rbf(acc[j][e]);
-            if (accumulate) {
-                float o[8];
-                unpack8(*reinterpret_cast<const uint4*>(dw + v * dim + c), o);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r[e] += o[e];
-            }
-            *reinterpret_cast<uint4*>(dw + v * dim + c) = pack8(r);
-        }
     }
 }
 
@@ -691,12 +646,8 @@ extern "C" int ie_embedding_bwd(const void* dout, const int64_t* ids, void* dwei
     if (T == 0) return IE_OK;
     hipLaunchKernelGGL(embedding_mark_k, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, ids, ws, T, vocab);
     const int64_t max_rows = T < vocab ? T : vocab;
-    if (dim % 8 == 0 && dim <= 8192 && aligned16(dout) && aligned16(dweight))
-        hipLaunchKernelGGL(embedding_bwd_row_k, dim3((unsigned)max_rows), dim3(256), 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, ws, T, vocab, dim,
-                           accumulate);
-    else
-        hipLaunchKernelGGL(embedding_bwd_k, dim3((unsigned)max_rows, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, (const bf16_t*)dout, ids,
-                           (bf16_t*)dweight, ws, T, vocab, dim, accumulate);
+    hipLaunchKernelGGL(embedding_bwd_k, dim3((unsigned)max_rows, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, (const bf16_t*)dout, ids,
+                       (bf16_t*)dweight, ws, T, vocab, dim, accumulate);
     return ie_launch_status("ie_embedding_bwd launch");
 }
 

@@ -383,9 +383,10 @@ def test_adamw_matches_torch(dev):
 @pytest.mark.parametrize("dim", [4096, 6144, 520, 516])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_embedding_backward_is_the_fp32_sum_in_token_order_bit_for_bit(dev, dim, accumulate):
-    """embedding_bwd_row_k (one block per referenced row, all its columns; dim % 8 == 0) and embedding_bwd_k (the fallback: dim = 516 here): per vocabulary row
-    the fp32 sum of its tokens' gradient rows IN TOKEN ORDER, rounded to bf16 once (+ the old gradient when accumulating) -- torch's CPU index_add_ in fp32 walks
-    the index in order, so the comparison is exact.  Heavy duplication (300 tokens on 7 ids), an id at the end of the vocabulary, untouched rows."""
+    """embedding_bwd_k: per vocabulary row the fp32 sum of its tokens' gradient rows IN TOKEN ORDER, rounded to bf16 once (+ the old gradient when
+    accumulating) -- torch's CPU index_add_ in fp32 walks the index in order, so the comparison is exact (the kernel lists a pass's hits and loads sixteen
+    rows before the sixteen adds: the order of the adds must not change).  Heavy duplication (300 tokens on 7 ids: more than sixteen hits per pass), an id at
+    the end of the vocabulary, untouched rows, widths off the 256-column block."""
     V, T = 1000, 1300
     ids = torch.randint(0, 200, (T,), generator=g(60))
     ids[:300] = torch.randint(0, 7, (300,), generator=g(61))
