@@ -597,10 +597,17 @@ class MoEEngine:
                 adam(self.d_wg.view(-1), self.wg.view(-1), self.wg_m.view(-1), self.wg_v.view(-1), None, 1)
             events["gate"] = torch.cuda.Event()
             events["gate"].record(self.opt_stream)
-            for a, b, grp in sorted((a, b, grp) for grp in (0, 2) for a, b in self.runs[grp]):
+            # (as engine.step(): the first runs over the whole chip -- the next forward has nothing to do until they are done --, the others on CUs of their own
+            # beside it: ie_tune_adamw_cus, IE_ADAMW_CUS, default 128; same results bit for bit)
+            cus, full = int(os.environ.get("IE_ADAMW_CUS", "128") or 0), int(os.environ.get("IE_ADAMW_FULL_BUCKETS", "2") or 0)
+            for i, (a, b, grp) in enumerate(sorted((a, b, grp) for grp in (0, 2) for a, b in self.runs[grp])):
+                if cus:
+                    K.tune_adamw_cus(cus if i >= full else 0)
                 adam(self.grads[a:b], self.master[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.params[a:b], grp)
                 events[a] = torch.cuda.Event()
                 events[a].record(self.opt_stream)
+            if cus:
+                K.tune_adamw_cus(0)
         self._opt_events = events
         self.lr_sched.step()
         self.beta2_sched.step()
