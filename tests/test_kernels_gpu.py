@@ -590,6 +590,39 @@ def test_gemm_tail_split_is_bit_identical(dev, M, N):
     assert lib().ie_tune_gemm_tail_split(4) != 0
 
 
+@pytest.mark.parametrize("memset", [0, 1])
+def test_persistent_frame_recycles_its_queue_slots(dev, memset):
+    """The persistent kernel's tile queues: 64 slots handed out round-robin, zero at module load, every launch's LAST block zeroes its slot for the launch that
+    takes it 64 launches later (ie_tune_gemm_queue_memset(0), the default since round 6: no memset kernels between the products) -- 200 launches in a row on two
+    streams, different tile counts per launch, every result the plain launch's bit for bit; the same with the memset switched on."""
+    from internevo_amd._lib import load as lib
+    shapes = [(1024, 1024, 256), (2048, 1280, 256), (1536, 512, 512), (768, 2304, 256)]
+    ops = []
+    for i, (M, N, Kd) in enumerate(shapes):
+        A = bf(torch.randn(M, Kd, generator=g(80 + i))).to(dev)
+        B = bf(torch.randn(N, Kd, generator=g(90 + i))).to(dev)
+        ops.append((A, B, K().gemm(A, B, False, False, variant=20)))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    try:
+        assert lib().ie_tune_gemm_persistent(8) == 0 and lib().ie_tune_gemm_queue_memset(memset) == 0
+        outs = []
+        for n in range(200):
+            A, B, _ = ops[n % len(ops)]
+            if n % 3 == 2:
+                with torch.cuda.stream(side):
+                    outs.append((n, K().gemm(A, B, False, False, variant=22)))
+            else:
+                outs.append((n, K().gemm(A, B, False, False, variant=22)))
+        torch.cuda.synchronize()
+        for n, o in outs:
+            assert torch.equal(o, ops[n % len(ops)][2]), f"launch {n} (memset {memset})"
+    finally:
+        lib().ie_tune_gemm_persistent(1)
+        lib().ie_tune_gemm_queue_memset(0)
+    assert lib().ie_tune_gemm_queue_memset(2) != 0
+
+
 @pytest.mark.parametrize("M,N,Kd,grid", [(1024, 1024, 512, 8), (2048, 1280, 256, 8), (1536, 2560, 1152, 16), (4096, 4096, 1024, 1)])
 def test_gemm_persistent_frame_is_bit_identical(dev, M, N, Kd, grid):
     """gemm_p5_k (variant 22; the dispatcher's choice for the eligible forward / input-gradient products since round 5): the 16x16x32 refill schedule in its
