@@ -345,6 +345,17 @@ int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q, int64_t q_
                       float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
                       const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv,
                       int d, float softmax_scale, int causal, void* stream);
+/* The backward of MHA._packed_forward's attention block in one piece (round 6; internlm/model/modeling_internlm2.py:416-468 read upwards): the backward of
+ * flash_attn_varlen_kvpacked_func, of the rotary embedding on q and k (ApplyRotaryEmb.backward, modules/embedding.py:150-166) and of the GQA rearrange -- the two
+ * attention kernels write dQ, dK (rotated back) and dV straight into dqkv [T][hkv][hq / hkv + 2][d], the output gradient of the wqkv product; no [T, hq, d] /
+ * [T, 2, hkv, d] intermediates, no rotary launch.  cos / sin [positions][d / 2] bf16 (the forward's tables), positions int64[T].  Bit-identical to
+ * ie_flash_attn_bwd + ie_qkv_rotary_bwd (interleaved = 0, dq_scale = 1).  Only where ..._is_fused says so (head dim 128, causal, no head split of the dK / dV
+ * kernel, the default backward variant); elsewhere IE_ERR_UNSUPPORTED and the caller runs the two calls. */
+int ie_flash_attn_bwd_qkv_rotary_is_fused(int nseq, int max_seqlen, int hq, int hkv, int d, int causal);
+int ie_flash_attn_bwd_qkv_rotary(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts,
+                                 const void* out, int64_t o_ts, const float* lse, float* delta_ws, void* dqkv, const void* cos, const void* sin,
+                                 const int64_t* positions, const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv, int d,
+                                 float softmax_scale, int causal, void* stream);
 
 /* y[rows, cols] += bias[cols] in place (bf16): the attention biases of the InternLM-1 block (multi_head_attention.py:371-408). */
 int ie_bias_add_bf16(void* y, int64_t ld, const void* bias, int64_t rows, int64_t cols, void* stream);
@@ -418,7 +429,9 @@ int ie_gemm_dma_persistent_takes(int64_t M, int64_t N, int64_t K);   /* (interna
 int ie_tune_flash_dq_occupancy(int waves_per_simd);
 /* Tuning hook: how many blocks share the q heads of one kv head in the dK/dV kernel (0 = automatic, 1, 2 or 4). */
 int ie_tune_flash_dkdv_split(int split);
-/* Tuning hooks (A/B benchmarking, tools/kbench): kernel variant of the attention forward / backward (0 = default). */
+/* Tuning hooks (A/B benchmarking, tools/kbench): kernel variant of the attention forward / backward (0 = default).  Backward: bit 0 = four waves per dK/dV block,
+ * bit 1 = the five-product path (needs ie_flash_attn_bwd_set_spill), bit 2 = delta = sum_d dO * O by its own kernel in front of the dQ kernel (the default since
+ * round 6 computes it in the dQ kernel's prologue: the same bits). */
 int ie_tune_flash_fwd_variant(int variant);
 int ie_tune_flash_bwd_variant(int variant);
 /* Ring attention (the sequence-parallel attention whose K / V blocks travel around the ranks; internevo_amd/seqpar.py -- the reference has no

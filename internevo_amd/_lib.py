@@ -102,6 +102,8 @@ SIGNATURES = {
     "ie_colsum_bf16": (I, [P, I64, P, I64, I64, P]),
     "ie_flash_attn_fwd": (I, [P, I64, P, P, I64, P, I64, P, P, I, I64, I, I, I, I, F, I, P]),
     "ie_flash_attn_bwd": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, I64, P, P, I64, P, I, I64, I, I, I, I, F, I, P]),
+    "ie_flash_attn_bwd_qkv_rotary_is_fused": (I, [I, I, I, I, I, I]),
+    "ie_flash_attn_bwd_qkv_rotary": (I, [P, I64, P, I64, P, P, I64, P, I64, P, P, P, P, P, P, P, I, I64, I, I, I, I, F, I, P]),
     "ie_tune_flash_dq_occupancy": (I, [I]),
     "ie_tune_gemm_group": (I, [I]),
     "ie_tune_ffn_fuse": (I, [I]),

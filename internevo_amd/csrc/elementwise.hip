@@ -135,10 +135,7 @@ __global__ __launch_bounds__(256) void qkv_rotary_bwd_k(const bf16_t* __restrict
     unpack8(ld16(cs + p * H2 + i0), co);
     unpack8(ld16(sn + p * H2 + i0), si);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        x1[e] = d1[e] * co[e] + d2[e] * si[e];
-        x2[e] = -d1[e] * si[e] + d2[e] * co[e];
-    }
+    for (int e = 0; e < 8; ++e) rot_conj1(d1[e], d2[e], co[e], si[e], x1[e], x2[e]);
     if (s < qpk && dq_scale != 1.f) {   // chain rule of the forward's q_scale
 #pragma unroll
         for (int e = 0; e < 8; ++e) x1[e] *= dq_scale, x2[e] *= dq_scale;

@@ -58,6 +58,15 @@ namespace {
 
 using namespace fa;
 
+// one 8-element chunk of delta's dot product, every rounding written out: flash_delta_k and the dQ kernel's fused delta must give the same bits
+__device__ __forceinline__ float dot8(const float* a, const float* b) {
+#pragma clang fp contract(off)
+    float acc = a[0] * b[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) acc = __builtin_fmaf(a[e], b[e], acc);
+    return acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ out,
@@ -75,11 +84,10 @@ __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ 
         float a[8], b[8];
         unpack8(ld16(dout + t * do_ts + (int64_t)h * D + sub * 8), a);
         unpack8(ld16(out + t * o_ts + (int64_t)h * D + sub * 8), b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += a[e] * b[e];
+        acc = dot8(a, b);
     }
 #pragma unroll
-    for (int o = TPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    for (int o = TPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);   // (flash_dq_k's fused delta adds the sixteen chunk sums in exactly this tree)
     if (ok && sub == 0) {
         const int64_t t = pair / hq;
         const int h = (int)(pair % hq);
@@ -91,12 +99,18 @@ __global__ __launch_bounds__(256) void flash_delta_k(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL, int MINW>
+// FUSE_DELTA (round 6): the kernel computes delta = sum_d dO * O of its own query rows in its prologue -- a lane and its partner (lane ^ 32) hold the whole dO
+// row as MFMA fragments already, the O row is read the same way -- and writes delta, -delta and -lse / scale for the dK / dV kernel behind it: flash_delta_k
+// (54 us + a launch per call) is gone from the step.  The sixteen 8-element chunk sums are added in flash_delta_k's shuffle tree: the same bits.
+// ROT (round 6; ie_flash_attn_bwd_qkv_rotary): dQ leaves through store_row_block_rot into the wqkv product's output-gradient layout (flash_common.h: FaRotOut).
+template <int D, bool CAUSAL, int MINW, bool FUSE_DELTA, bool ROT = false>
 __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
                                                         int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                        int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        int64_t kv_ts, const float* __restrict__ lse, float* __restrict__ delta,
                                                         bf16_t* __restrict__ dq, int64_t dq_ts, const int32_t* __restrict__ cu, int64_t T,
-                                                        int hq, int hkv, float scale, const int32_t* __restrict__ cu_k, int64_t Tk) {
+                                                        int hq, int hkv, float scale, const int32_t* __restrict__ cu_k, int64_t Tk,
+                                                        const bf16_t* __restrict__ out, int64_t o_ts, float* __restrict__ nlse,
+                                                        float* __restrict__ ndelta, float inv_scale, FaRotOut ro) {
     // cu_k / Tk (full attention only; ie_flash_attn_bwd_x): the keys of sequence s are rows cu_k[s] .. cu_k[s + 1] of K / V tensors of Tk rows
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES;  // K image, V image
@@ -151,8 +165,37 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
             dof[ks] = b.s;
         }
     }
-    const float lse2 = q_valid ? lse[(int64_t)h * T + tok0 + my_q] * kLog2e : INFINITY;
-    const float dlt = q_valid ? delta[(int64_t)h * T + tok0 + my_q] : 0.f;
+    const float lse_q = q_valid ? lse[(int64_t)h * T + tok0 + my_q] : INFINITY;
+    const float lse2 = lse_q * kLog2e;
+    float dlt;
+    if constexpr (FUSE_DELTA) {
+        static_assert(G::KS == 8 || G::KS == 4, "head dim 128 or 64");
+        float pc[G::KS];   // chunk ks of this lane = chunk 2 ks + (lane >> 5) of the row
+        const bf16_t* op = out + (int64_t)(tok0 + my_q) * o_ts + (int64_t)h * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            float a[8], b[8];
+            union { s16x8 s; uint4 u; } d_;
+            d_.s = dof[ks];
+            unpack8(d_.u, a);
+            unpack8(q_valid ? ld16(op + ks * 16) : z4(), b);
+            pc[ks] = dot8(a, b);
+        }
+        // flash_delta_k's tree over the row's chunks c (xor 8, 4, 2, 1 for D = 128; 4, 2, 1 for D = 64) with c = 2 ks + half: the last level is the partner lane
+        float x;
+        if constexpr (G::KS == 8) x = ((pc[0] + pc[4]) + (pc[2] + pc[6])) + ((pc[1] + pc[5]) + (pc[3] + pc[7]));
+        else x = (pc[0] + pc[2]) + (pc[1] + pc[3]);
+        dlt = x + __shfl_xor(x, 32, 64);
+        if (q_valid && lane < 32) {
+            const int64_t at = (int64_t)h * T + tok0 + my_q;
+            delta[at] = dlt;
+            nlse[at] = -lse_q * inv_scale;
+            ndelta[at] = -dlt;
+        }
+        if (!q_valid) dlt = 0.f;
+    } else {
+        dlt = q_valid ? delta[(int64_t)h * T + tok0 + my_q] : 0.f;
+    }
     const float sc2 = scale * kLog2e;
 
     f32x16 dqacc[G::DB];
@@ -213,7 +256,13 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
         if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
-    store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
+    if constexpr (ROT) {
+        const int64_t p = q_valid ? ro.pos[tok0 + my_q] : 0;
+        store_row_block_rot<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)(h / ro.qpk) * ro.grp_stride + (int64_t)(h % ro.qpk) * D, dqacc, scale, lane, q_valid,
+                               ro.cs + p * (D / 2), ro.sn + p * (D / 2));
+    } else {
+        store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -242,14 +291,17 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 // of the chunk (the XORs spread the 32 lanes of a read over all banks; flash_dq_from_ds_k::DsOffs is the inverse map).  Four 16-byte stores per
 // wave and tile, from inline asm in the gaps of phase C1; the waits of the tile loop count them (vmcnt retires in order on gfx950: the
 // transfers they wait for are older than the stores).
-template <int D, bool CAUSAL, int HS, int DKV_WAVES, bool SPILL = false>
+template <int D, bool CAUSAL, int HS, int DKV_WAVES, bool SPILL = false, bool ROT = false>
 __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __restrict__ dout, int64_t do_ts, const bf16_t* __restrict__ q,
                                                                int64_t q_ts, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t kv_ts, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dkv_ts,
                                                                const int32_t* __restrict__ cu, int64_t T, int hq, int hkv, float scale,
                                                                float* __restrict__ part, unsigned char* __restrict__ ds_ws,
-                                                               int64_t ds_head_stride, int nq_max, const int32_t* __restrict__ cu_k, int64_t Tk) {
+                                                               int64_t ds_head_stride, int nq_max, const int32_t* __restrict__ cu_k, int64_t Tk,
+                                                               FaRotOut ro) {
+    // ROT (round 6; HS == 1): dk / dv point at the k / v slots of kv group 0 inside the wqkv output-gradient rows, a kv head's slot is ro.grp_stride further;
+    // dK leaves through store_row_block_rot (the key's position), dV as it is.
     // cu_k / Tk (full attention only; ie_flash_attn_bwd_x): the keys of sequence s are rows cu_k[s] .. cu_k[s + 1] of K / V / dK / dV tensors of Tk rows
     using G = Geo<D>;
     constexpr int STAGE = 2 * G::IMG_BYTES + 1024;  // Q image, dO image, -lse/scale [64], -delta [64] (+ pad to keep 1 KiB alignment)
@@ -300,8 +352,9 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
             f32x16 z[G::DB];
 #pragma unroll
             for (int db = 0; db < G::DB; ++db) z[db] = zero16();
-            store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
-            store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
+            const int64_t hoff = ROT ? (int64_t)hk * ro.grp_stride : (int64_t)hk * D;
+            store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + hoff, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
+            store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + hoff, z, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
         }
         return;
     }
@@ -724,7 +777,13 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         for (int i = 0; i < 7; ++i) atomicAdd(&g_dkdv_t[i], (unsigned long long)tacc[i]);
 #endif
 
-    if (HS == 1) {
+    if constexpr (ROT) {
+        static_assert(HS == 1, "the rotating store writes final gradients");
+        const int64_t hoff = (int64_t)hk * ro.grp_stride;
+        const int64_t p = k_valid ? ro.pos[tok0k + my_k] : 0;
+        store_row_block_rot<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dkacc, scale, lane, k_valid, ro.cs + p * (D / 2), ro.sn + p * (D / 2));
+        store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dvacc, 1.f, lane, k_valid, true);
+    } else if (HS == 1) {
         store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);
         store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dvacc, 1.f, lane, k_valid, (dkv_ts & 7) == 0);
     }
@@ -913,6 +972,7 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 int g_dkdv_split = 0;  // 0 = automatic (see dkdv_split), else the forced head split of the dK/dV kernel
 int g_dkdv_waves = 2;  // waves (x 32 keys) per dK/dV block
 int g_dq_minw = 2;  // waves/SIMD the dQ kernel is compiled for (2: 256 VGPRs with a small spill; 1: no spill, half the occupancy)
+int g_bwd_separate_delta = 0;  // 1: flash_delta_k in front of the dQ kernel instead of the delta in its prologue (ie_tune_flash_bwd_variant bit 2: A/B, tests)
 int g_bwd_spill = 0;  // 1: five-product backward (dS^T spilled by the dK/dV kernel, dQ formed from it): ie_tune_flash_bwd_variant bit 1, opt-in
 void* g_ds_ws = nullptr;     // the caller's spill buffer (ie_flash_attn_bwd_set_spill)
 int64_t g_ds_ws_bytes = 0;
@@ -957,7 +1017,7 @@ extern "C" int64_t ie_flash_attn_bwd_workspace(int64_t T, int hq, int hkv, int d
 static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts, const void* out,
                           int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_ts, void* dk, void* dv, int64_t dkv_ts,
                           const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv, int d, float softmax_scale, int causal,
-                          void* stream, const int32_t* cu_k, int64_t Tk, int max_seqlen_k) {
+                          void* stream, const int32_t* cu_k, int64_t Tk, int max_seqlen_k, const FaRotOut* rot = nullptr) {
     IE_CHECK_ARG(dout && q && k && v && out && lse && delta && dq && dk && dv && cu_seqlens, "ie_flash_attn_bwd: null pointer");
     IE_CHECK_ARG(nseq >= 0 && T >= 0 && max_seqlen >= 0 && hq > 0 && hkv > 0 && hq % hkv == 0, "ie_flash_attn_bwd: bad shape");
     IE_CHECK_SUPPORTED(d == 128 || d == 64, "ie_flash_attn_bwd: head dim must be 64 or 128");
@@ -970,7 +1030,18 @@ static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_
     // workspace layout: delta[hq*T] | -lse/scale [hq*T] | -delta [hq*T] | partial dK [hs][T][hkv][d] | partial dV [hs][T][hkv][d]
     float* nlse = delta + (int64_t)hq * T;
     float* ndelta = nlse + (int64_t)hq * T;
-    {
+    const int nq_max = (max_seqlen + 63) / 64;
+    const int64_t ds_head_stride = ((causal ? (int64_t)nq_max * (nq_max + 1) / 2 : (int64_t)nq_max * nq_max) + 1) * 8192;
+    const unsigned nkb0 = (unsigned)(((cu_k ? max_seqlen_k : max_seqlen) + 32 * g_dkdv_waves - 1) / (32 * g_dkdv_waves));
+    const int hs0 = cu_k ? 1 : dkdv_split(hq, hkv, causal, (int64_t)nkb0 * hkv * nseq);
+    const bool spill = g_bwd_spill && !cu_k && hs0 == 1 && ds_head_stride < (1ll << 31) && g_ds_ws && (int64_t)nseq * hq * ds_head_stride <= g_ds_ws_bytes;
+    const bool fuse_delta = !spill && !g_bwd_separate_delta;   // (the five-product path runs the dK / dV kernel FIRST: it keeps the delta kernel)
+    const FaRotOut ro = rot ? *rot : FaRotOut{nullptr, nullptr, nullptr, 1, 0};
+    if (rot) {   // (ie_flash_attn_bwd_qkv_rotary_is_fused says when)
+        IE_CHECK_SUPPORTED(d == 128 && causal && !cu_k && hs0 == 1 && !spill && fuse_delta && dq_ts % 8 == 0 && dkv_ts % 8 == 0,
+                           "ie_flash_attn_bwd_qkv_rotary: head dim 128, causal, no head split of the dK / dV kernel, the default backward path");
+    }
+    if (!fuse_delta) {
         const int64_t threads = T * hq * (d / 8);
         dim3 grid((unsigned)((threads + 255) / 256));
         if (d == 128)
@@ -990,11 +1061,15 @@ static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_
 #define IE_DKDV_W(DD, CA, HS_, NW_)                                                                                                \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, HS_, NW_>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
                        (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
-                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0, cu_k, Tk)
+                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0, cu_k, Tk, ro)
+#define IE_DKDV_ROT(NW_)                                                                                                           \
+    hipLaunchKernelGGL((flash_dkdv_k<128, true, 1, NW_, false, true>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
+                       softmax_scale, part, (unsigned char*)nullptr, (int64_t)0, 0, cu_k, Tk, ro)
 #define IE_DKDV_SPILL(DD, CA, NW_)                                                                                                 \
     hipLaunchKernelGGL((flash_dkdv_k<DD, CA, 1, NW_, true>), gk, dim3(64 * NW_), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, \
                        (const bf16_t*)k, (const bf16_t*)v, kv_ts, nlse, ndelta, (bf16_t*)dk, (bf16_t*)dv, dkv_ts, cu_seqlens, T, hq, hkv, \
-                       softmax_scale, part, (unsigned char*)ds_ws, ds_head_stride, nq_max, (const int32_t*)nullptr, (int64_t)0)
+                       softmax_scale, part, (unsigned char*)ds_ws, ds_head_stride, nq_max, (const int32_t*)nullptr, (int64_t)0, ro)
 #define IE_DQ_FROM_DS(DD, CA)                                                                                                      \
     hipLaunchKernelGGL((flash_dq_from_ds_k<DD, CA>), gds, dim3(256), 0, st, (const unsigned char*)ds_ws, ds_head_stride, nq_max,      \
                        (const bf16_t*)k, kv_ts, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, gw)
@@ -1014,22 +1089,18 @@ static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_
         else if (hs == 2) IE_DKDV_HS(DD, CA, 2);                                                                                   \
         else IE_DKDV_HS(DD, CA, 1);                                                                                                \
     } while (0)
+#define IE_DQ(DD, CA, MW, FD)                                                                                                      \
+    hipLaunchKernelGGL((flash_dq_k<DD, CA, MW, FD>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,         \
+                       (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, \
+                       cu_k, Tk, (const bf16_t*)out, o_ts, nlse, ndelta, 1.f / softmax_scale, ro)
 #define IE_L(DD, CA)                                                                                                               \
     do {                                                                                                                           \
-        if (g_dq_minw == 2)                                                                                                        \
-            hipLaunchKernelGGL((flash_dq_k<DD, CA, 2>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
-                               (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
-                               softmax_scale, cu_k, Tk);                                                                                      \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((flash_dq_k<DD, CA, 1>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts,    \
-                               (const bf16_t*)k, (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv,    \
-                               softmax_scale, cu_k, Tk);                                                                                      \
+        if (g_dq_minw == 2) { if (fuse_delta) IE_DQ(DD, CA, 2, true); else IE_DQ(DD, CA, 2, false); }                              \
+        else                { if (fuse_delta) IE_DQ(DD, CA, 1, true); else IE_DQ(DD, CA, 1, false); }                              \
         IE_DKDV(DD, CA);                                                                                                           \
     } while (0)
     // five-product path: dK/dV kernel with the dS^T spill, dQ from the spill.  Not with a head split (small problems, where the split is what matters).
-    const int nq_max = (max_seqlen + 63) / 64;
-    const int64_t ds_head_stride = ((causal ? (int64_t)nq_max * (nq_max + 1) / 2 : (int64_t)nq_max * nq_max) + 1) * 8192;
-    if (g_bwd_spill && !cu_k && hs == 1 && ds_head_stride < (1ll << 31) && g_ds_ws && (int64_t)nseq * hq * ds_head_stride <= g_ds_ws_bytes) {
+    if (spill) {
         void* ds_ws = g_ds_ws;
         const int group = hq / hkv, gw = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1), qw = 4 / gw;
         dim3 gds((unsigned)(hkv * (group / gw)), (unsigned)((nq_max + qw - 1) / qw), (unsigned)nseq);
@@ -1042,14 +1113,27 @@ static int flash_bwd_impl(const void* dout, int64_t do_ts, const void* q, int64_
         if (d == 128) { if (causal) IE_SP(128, true); else IE_SP(128, false); }
         else          { if (causal) IE_SP(64, true); else IE_SP(64, false); }
 #undef IE_SP
+    } else if (rot) {   // dQ and dK / dV straight into the wqkv output-gradient rows, rotated (d = 128, causal, hs = 1, delta in the dQ prologue: checked above)
+        if (g_dq_minw == 2)
+            hipLaunchKernelGGL((flash_dq_k<128, true, 2, true, true>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, (const bf16_t*)k,
+                               (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, cu_k, Tk, (const bf16_t*)out, o_ts,
+                               nlse, ndelta, 1.f / softmax_scale, ro);
+        else
+            hipLaunchKernelGGL((flash_dq_k<128, true, 1, true, true>), gq, dim3(256), 0, st, (const bf16_t*)dout, do_ts, (const bf16_t*)q, q_ts, (const bf16_t*)k,
+                               (const bf16_t*)v, kv_ts, lse, delta, (bf16_t*)dq, dq_ts, cu_seqlens, T, hq, hkv, softmax_scale, cu_k, Tk, (const bf16_t*)out, o_ts,
+                               nlse, ndelta, 1.f / softmax_scale, ro);
+        if (DKV_WAVES == 4) IE_DKDV_ROT(4);
+        else IE_DKDV_ROT(2);
     } else {
         if (d == 128) { if (causal) IE_L(128, true); else IE_L(128, false); }
         else          { if (causal) IE_L(64, true); else IE_L(64, false); }
     }
 #undef IE_L
+#undef IE_DQ
 #undef IE_DKDV
 #undef IE_DKDV_HS
 #undef IE_DKDV_W
+#undef IE_DKDV_ROT
 #if IE_DKDV_TIMING
     {
         hipStreamSynchronize(st);
@@ -1070,6 +1154,30 @@ extern "C" int ie_flash_attn_bwd(const void* dout, int64_t do_ts, const void* q,
                                  int hq, int hkv, int d, float softmax_scale, int causal, void* stream) {
     return flash_bwd_impl(dout, do_ts, q, q_ts, k, v, kv_ts, out, o_ts, lse, delta, dq, dq_ts, dk, dv, dkv_ts, cu_seqlens, nseq, T, max_seqlen, hq, hkv, d,
                           softmax_scale, causal, stream, nullptr, 0, 0);
+}
+
+// The backward of MHA._packed_forward's attention block in one piece (round 6): flash_attn_varlen_kvpacked_func's backward, the rotary embedding's backward on
+// dQ and dK and the backward of the GQA rearrange (modeling_internlm2.py:416-441 read upwards) -- the gradients leave the two attention kernels straight into
+// dqkv [T][hkv][hq / hkv + 2][d], the output gradient of the wqkv product.  Bit-identical to ie_flash_attn_bwd + ie_qkv_rotary_bwd (interleaved = 0).
+extern "C" int ie_flash_attn_bwd_qkv_rotary_is_fused(int nseq, int max_seqlen, int hq, int hkv, int d, int causal) {
+    if (nseq <= 0 || max_seqlen <= 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || d != 128 || !causal) return 0;
+    if (g_bwd_separate_delta || g_bwd_spill) return 0;
+    const unsigned nkb = (unsigned)((max_seqlen + 32 * g_dkdv_waves - 1) / (32 * g_dkdv_waves));
+    return dkdv_split(hq, hkv, causal, (int64_t)nkb * hkv * nseq) == 1;
+}
+extern "C" int ie_flash_attn_bwd_qkv_rotary(const void* dout, int64_t do_ts, const void* q, int64_t q_ts, const void* k, const void* v, int64_t kv_ts,
+                                            const void* out, int64_t o_ts, const float* lse, float* delta_ws, void* dqkv, const void* cos, const void* sin,
+                                            const int64_t* positions, const int32_t* cu_seqlens, int nseq, int64_t T, int max_seqlen, int hq, int hkv, int d,
+                                            float softmax_scale, int causal, void* stream) {
+    IE_CHECK_ARG(dqkv && cos && sin && positions && hq > 0 && hkv > 0 && hq % hkv == 0 && d > 0, "ie_flash_attn_bwd_qkv_rotary: bad argument");
+    IE_CHECK_SUPPORTED(ie_flash_attn_bwd_qkv_rotary_is_fused(nseq, max_seqlen, hq, hkv, d, causal) || nseq == 0 || T == 0 || max_seqlen == 0,
+                       "ie_flash_attn_bwd_qkv_rotary: not fused for this shape (ie_flash_attn_bwd_qkv_rotary_is_fused): call ie_flash_attn_bwd + ie_qkv_rotary_bwd");
+    const int qpk = hq / hkv;
+    const int64_t gs = (int64_t)(qpk + 2) * d, ts = (int64_t)hkv * gs;
+    const FaRotOut ro{(const bf16_t*)cos, (const bf16_t*)sin, positions, qpk, gs};
+    bf16_t* base = (bf16_t*)dqkv;
+    return flash_bwd_impl(dout, do_ts, q, q_ts, k, v, kv_ts, out, o_ts, lse, delta_ws, base, ts, base + (int64_t)qpk * d, base + (int64_t)(qpk + 1) * d, ts,
+                          cu_seqlens, nseq, T, max_seqlen, hq, hkv, d, softmax_scale, causal, stream, nullptr, 0, 0, &ro);
 }
 
 // Backward of ie_flash_attn_fwd_x (full attention of queries cu_q[s] .. cu_q[s + 1] against keys cu_k[s] .. cu_k[s + 1]).  `lse` and `out` are what
@@ -1101,10 +1209,12 @@ extern "C" int ie_flash_attn_bwd_set_spill(void* buf, int64_t bytes) {
     return IE_OK;
 }
 
-// tuning hook (A/B benchmarking only): bit 0: 0 = 2 waves x 32 keys per dK/dV block, 1 = 4 waves; bit 1: the five-product backward (needs a spill buffer)
+// tuning hook (A/B benchmarking only): bit 0: 0 = 2 waves x 32 keys per dK/dV block, 1 = 4 waves; bit 1: the five-product backward (needs a spill buffer);
+// bit 2: delta by its own kernel in front of the dQ kernel (the default since round 6 computes it in the dQ kernel's prologue: the same bits)
 extern "C" int ie_tune_flash_bwd_variant(int variant) {
-    IE_CHECK_ARG(variant >= 0 && variant <= 3, "ie_tune_flash_bwd_variant: 0 .. 3");
+    IE_CHECK_ARG(variant >= 0 && variant <= 7, "ie_tune_flash_bwd_variant: 0 .. 7");
     g_dkdv_waves = (variant & 1) ? 4 : 2;
     g_bwd_spill = (variant >> 1) & 1;
+    g_bwd_separate_delta = (variant >> 2) & 1;
     return IE_OK;
 }

@@ -224,6 +224,45 @@ __device__ __forceinline__ void store_row_block(bf16_t* row, const f32x16 (&acc)
     }
 }
 
+// ---- Round 6: the attention backward writing straight into the wqkv product's output-gradient layout [T][hkv][q heads per kv head + 2][D] with the rotary
+// embedding's backward applied to dQ and dK on the way out (ie_flash_attn_bwd_qkv_rotary): qkv_rotary_bwd_k and its launch are gone from the step.
+struct FaRotOut {
+    const bf16_t* cs;        // cos / sin tables [positions][D / 2] (the forward's)
+    const bf16_t* sn;
+    const int64_t* pos;      // position of every token row
+    int qpk;                 // q heads per kv head
+    int64_t grp_stride;      // elements from one kv group to the next inside an output row ((qpk + 2) * D)
+};
+
+// store_row_block with the conjugate rotation: the lane holds d = 32 db + 8 g + 4 (lane >> 5) + i of its row for db = 0 .. 3, so a pair (d, d + 64) = (db, db + 2)
+// sits in ONE lane.  The two-kernel path rounds the gradient to bf16 (store_row_block), reads it back, rotates in fp32 (rot_conj1) and rounds again: the same here.
+template <int D>
+__device__ __forceinline__ void store_row_block_rot(bf16_t* row, f32x16 (&acc)[Geo<D>::DB], float mul, int lane, bool valid, const bf16_t* cs_row,
+                                                    const bf16_t* sn_row) {
+    static_assert(D == 128, "pairs (d, d + 64) of a 128-wide head");
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 c2 = make_uint2(0u, 0u), s2 = make_uint2(0u, 0u);
+            if (valid) {
+                c2 = ld8(cs_row + 32 * db + 8 * g + 4 * hh);
+                s2 = ld8(sn_row + 32 * db + 8 * g + 4 * hh);
+            }
+            const float co[4] = {bflo(c2.x), bfhi(c2.x), bflo(c2.y), bfhi(c2.y)}, si[4] = {bflo(s2.x), bfhi(s2.x), bflo(s2.y), bfhi(s2.y)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d1 = rbf(acc[db][4 * g + i] * mul), d2 = rbf(acc[db + 2][4 * g + i] * mul);
+                float x1, x2;
+                rot_conj1(d1, d2, co[i], si[i], x1, x2);
+                acc[db][4 * g + i] = x1;
+                acc[db + 2][4 * g + i] = x2;
+            }
+        }
+    store_row_block<D>(row, acc, 1.f, lane, valid, true);
+}
+
 // ---- MFMAs with an explicit register file for every operand (kernels with one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
 // hipcc allocates every MFMA accumulator of a > 256-register kernel in the accumulation file and then copies whatever the vector
 // ALU touches back and forth (v_accvgpr_read / _write: > 1000 of them in this kernel); with the operand files spelled out the

@@ -158,6 +158,14 @@ struct IeRotaryEpi {
 // Reference: Silu(w1_o, w3_o) = F.silu(w1_o) * w3_o on bf16 tensors (model/utils.py:684-688): silu evaluated in fp32, rounded to bf16,
 // product rounded to bf16; the backward sees the bf16 silu(a) autograd saved and the bf16 gradient of the product.
 __device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + __expf(-a)); }
+// Backward of the rotary embedding on one (first half, second half) pair: the rotation by -theta (ApplyRotaryEmb.backward, modules/embedding.py:150-166:
+// conjugate=True).  Every rounding written out: qkv_rotary_bwd_k and the attention backward's fused stores (flash_common.h) must give the same bits.
+__device__ __forceinline__ void rot_conj1(float d1, float d2, float co, float si, float& x1, float& x2) {
+#pragma clang fp contract(off)
+    x1 = __builtin_fmaf(d1, co, d2 * si);
+    x2 = __builtin_fmaf(d2, co, -(d1 * si));
+}
+
 __device__ __forceinline__ float swiglu_fwd1(float a, float b) { return rbf(a * sigmoidf_(a)) * b; }
 __device__ __forceinline__ void swiglu_bwd1(float g, float a, float b, float& da, float& db, float& act) {
     const float sg = sigmoidf_(a);

@@ -343,6 +343,7 @@ class InternLM2Engine:
         self.opt_stream = _optimizer_stream(device)
         # AdamW beside the next step's forward (step()): the buckets behind the first adamw_full_buckets run on adamw_cus CUs (ie_tune_adamw_cus; 0 = whole chip)
         self.adamw_cus = int(os.environ.get("IE_ADAMW_CUS", "128") or 0)
+        self.attn_bwd_rotary_fuse = os.environ.get("IE_ATTN_BWD_ROTARY_FUSE", "1") != "0"   # (A/B switch: kernels.flash_attn_bwd_qkv_rotary in _layer_backward)
         self.adamw_full_buckets = int(os.environ.get("IE_ADAMW_FULL_BUCKETS", "2") or 0)
         self._bucket_ready = [None] * len(self.layout.buckets)
         self._opt_done = None
@@ -973,20 +974,31 @@ class InternLM2Engine:
             xc = self.seqpar.scatter_heads_gather_seq_async(d_ctx.view(T, -1, d), 1, self.t_xq, self.t_dctx_full) if head_x else None
             wgrad(d_r2, self.a_ctxl[sl].view(T, -1), g[pre + "attention.wo.weight"], self.st_dr2[l] if bw else None, self.st_ctx[l] if bw else None, acc_l)
             d_ctx_full = xc.wait() if head_x else d_ctx.view(T, -1, d)
+            fused_rot = False
             if self.ring_mode:
                 self.ring.backward(d_ctx_full, self.a_q[sl], self.a_kv[sl], self.a_ctx[sl], self.a_lse[sl], self.ring.plan(cu.host), self.t_dq, self.t_dkv, self.t_delta)
             else:
                 if self.attn_bwd_spill:   # (A/B switch IE_ATTN_BWD_SPILL=1: the five-product backward, kernels.flash_attn_bwd_spill; a no-op once the buffer fits)
                     K.flash_attn_bwd_spill(True, cu.numel() - 1, max_seqlen, self.a_q[sl].shape[1], True, self.dev)
-                K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
-                                 max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
-            if not head_x:
+                # round 6: the rotary embedding's backward and the GQA rearrange's in the attention kernels' stores, straight into the wqkv output gradient
+                # (bit-identical to the two calls below; where the library does not fuse the shape it says so and touches nothing)
+                if (self.attn_bwd_rotary_fuse and not head_x and mc.adapt_hf and self.dq_scale == 1.0 and not self.attn_bwd_spill
+                        and K.flash_attn_bwd_qkv_rotary(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
+                                                        max_seqlen, self.cos, self.sin, pos, t_qkv, self.attn_scale, self.t_delta)):
+                    fused_rot = True
+                else:
+                    K.flash_attn_bwd(d_ctx_full, self.a_q[sl], self.a_kv[sl][:, 0], self.a_kv[sl][:, 1], self.a_ctx[sl], self.a_lse[sl], cu,
+                                     max_seqlen, self.attn_scale, True, self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+            if fused_rot:
+                pass
+            elif not head_x:
                 dq_l, dkv_l = self.t_dq, self.t_dkv
             else:
                 xq = self.seqpar.scatter_seq_gather_heads_async(self.t_dq, 1, self.t_xq, self.t_ql)
                 xkv = self.seqpar.scatter_seq_gather_heads_async(self.t_dkv, 2, self.t_xkv, self.t_kvl)   # both in flight; dq unpacks under dkv's
                 dq_l, dkv_l = xq.wait(), xkv.wait()
-            K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv, self.dq_scale)
+            if not fused_rot:
+                K.qkv_rotary_bwd(dq_l, dkv_l, self.cos, self.sin, pos, hkv, qpk, d, not mc.adapt_hf, t_qkv, self.dq_scale)
             if self.bias:
                 bgrad(t_qkv, g[pre + "attention.wqkv.bias"], self.st_dqkv[l] if bw else None, acc_l)
             d_n1 = d_n2  # the full [T, h] buffer again (d_ctx was a view of its first 1/tp)

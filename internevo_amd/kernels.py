@@ -702,6 +702,32 @@ def flash_attn_bwd(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scal
     return dq, dk, dv
 
 
+def flash_attn_bwd_qkv_rotary(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, cos, sin, positions, dqkv, softmax_scale=None, delta_ws=None):
+    """The causal attention backward with the rotary embedding's backward and the GQA rearrange's in its stores (ie_flash_attn_bwd_qkv_rotary): dQ, dK (rotated
+    back) and dV go straight into dqkv [T, hkv * (hq / hkv + 2) * d], the wqkv product's output gradient.  Returns False -- and touches nothing -- where the
+    library does not fuse the shape (the caller then runs flash_attn_bwd + qkv_rotary_bwd: the same bits)."""
+    T, hq, d = q.shape
+    hkv = k.shape[1]
+    nseq = cu_seqlens.numel() - 1
+    L = _L()
+    if not L.ie_flash_attn_bwd_qkv_rotary_is_fused(nseq, int(max_seqlen), hq, hkv, d, 1):
+        return False
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(d)
+    if dqkv.numel() != T * hkv * (hq // hkv + 2) * d or not dqkv.is_contiguous() or positions.dtype != torch.int64 or positions.numel() != T:
+        raise ValueError("flash_attn_bwd_qkv_rotary: dqkv must be a contiguous [T, hkv * (hq / hkv + 2) * d] tensor, positions int64[T]")
+    need = L.ie_flash_attn_bwd_workspace(T, hq, hkv, d)
+    if delta_ws is None or delta_ws.numel() < need:
+        delta_ws = torch.empty(need, dtype=torch.float32, device=q.device)
+    kv_ts = _tok_stride(k, d)
+    if _tok_stride(v, d) != kv_ts:
+        raise ValueError("k and v must share the token stride")
+    check(L.ie_flash_attn_bwd_qkv_rotary(_p(dout), _tok_stride(dout, d), _p(q), _tok_stride(q, d), _p(k), _p(v), kv_ts, _p(out), _tok_stride(out, d), _p(lse),
+                                         _p(delta_ws), _p(dqkv), _p(cos), _p(sin), _p(positions), _p(cu_seqlens), nseq, T, int(max_seqlen), hq, hkv, d,
+                                         float(softmax_scale), 1, _stream()), "ie_flash_attn_bwd_qkv_rotary")
+    return True
+
+
 def flash_attn_fwd_x(q, k, v, cu_q, cu_k, max_seqlen_q, softmax_scale=None, out=None, lse=None):
     """Full attention of a rectangle of scores per sequence (ie_flash_attn_fwd_x): q [Tq, hq, d] rows cu_q[s] .. cu_q[s+1] against k / v [Tk, hkv, d] rows
     cu_k[s] .. cu_k[s+1] -> (out [Tq, hq, d], lse [hq, Tq] fp32; a sequence without keys: 0 and -inf)."""

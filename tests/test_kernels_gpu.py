@@ -969,6 +969,81 @@ def test_flash_bwd_four_wave_dkdv_blocks(dev, lens, hq, hkv, d, causal, split):
     assert torch.equal(got[0][1], dk) and torch.equal(got[0][2], dv), "the two block shapes must give bit-identical dK / dV"
 
 
+@pytest.mark.parametrize("lens,hq,hkv,fused", [
+    ([64, 65, 127, 128, 129, 5], 2, 2, 1),          # ragged sequences, rows past a tile's end, one q head per kv head
+    ([333, 90, 700, 1], 6, 2, 1),                   # three q heads per kv head (an odd group: no head split), a one-token sequence
+    ([4096, 2048], 32, 8, 1),                       # InternLM2-7B's head geometry, enough key blocks for no head split
+    ([4096, 4096, 4096, 4096], 32, 8, 1),           # the benchmark's own call
+    ([512, 256], 4, 2, 0),                          # a small problem whose dK / dV kernel splits the heads: not fused -> False, nothing touched
+], ids=["ragged", "odd_group", "7b_heads", "7b_call", "head_split"])
+def test_attention_backward_with_rotary_and_gqa_rearrange_in_its_stores_equals_the_two_calls_bit_for_bit(dev, lens, hq, hkv, fused):
+    """ie_flash_attn_bwd_qkv_rotary (round 6): dQ, dK (rotated back by the tokens' positions) and dV written by the two attention kernels straight into the wqkv
+    product's output gradient [T, hkv, hq / hkv + 2, d] -- against ie_flash_attn_bwd into [T, hq, d] / [T, 2, hkv, d] followed by ie_qkv_rotary_bwd: the same
+    roundings in the same order (gradient rounded to bf16, rotated in fp32, rounded), so not one bit may differ; packed position ids that restart per sequence."""
+    d, T = 128, sum(lens)
+    qpk = hq // hkv
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32).to(dev)
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int64).to(dev)
+    cos, sin = O.rotary_cos_sin(max(lens), d)
+    cos, sin = cos.to(dev), sin.to(dev)
+    q = bf(torch.randn(T, hq, d, generator=g(390))).to(dev)
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(391))).to(dev)
+    do = bf(torch.randn(T, hq, d, generator=g(392))).to(dev)
+    out, lse = K().flash_attn_fwd(q, kv[:, 0], kv[:, 1], cu, max(lens), None, True)
+    dqkv = torch.full((T, hkv * (qpk + 2) * d), 7.0, dtype=torch.bfloat16, device=dev)
+    took = K().flash_attn_bwd_qkv_rotary(do, q, kv[:, 0], kv[:, 1], out, lse, cu, max(lens), cos, sin, pos, dqkv)
+    assert bool(took) == bool(fused)
+    if not fused:
+        assert bool((dqkv == 7.0).all()), "the unfused shape must leave the output alone"
+        return
+    dq, dk, dv = K().flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], out, lse, cu, max(lens), None, True)
+    ref = K().qkv_rotary_bwd(dq.contiguous(), torch.stack([dk, dv], dim=1).contiguous(), cos, sin, pos, hkv, qpk, d, False)
+    if not torch.equal(dqkv, ref):
+        a, b_ = dqkv.view(T, hkv, qpk + 2, d), ref.view(T, hkv, qpk + 2, d)
+        bad = (a != b_).nonzero()
+        raise AssertionError(f"{bad.shape[0]} elements differ; first at (token, kv head, slot, d) = {bad[0].tolist()}: {a[tuple(bad[0])].item()} vs {b_[tuple(bad[0])].item()}")
+    # and against the delta kernel's path of the same library (ie_tune_flash_bwd_variant 4 switches the fused call off)
+    from internevo_amd import _lib
+    L = _lib.load()
+    try:
+        assert L.ie_tune_flash_bwd_variant(4) == 0
+        assert not K().flash_attn_bwd_qkv_rotary(do, q, kv[:, 0], kv[:, 1], out, lse, cu, max(lens), cos, sin, pos, torch.empty_like(dqkv))
+    finally:
+        L.ie_tune_flash_bwd_variant(0)
+
+
+@pytest.mark.parametrize("lens,hq,hkv,d,causal", [
+    ([1, 129, 64, 512], 4, 2, 64, True),
+    ([333, 90], 3, 3, 128, False),
+    ([2100], 8, 2, 128, True),
+    ([64, 65, 127, 128, 129, 5], 2, 1, 128, True),
+    ([4096], 8, 2, 128, True),
+])
+def test_flash_bwd_delta_in_the_dq_prologue_is_the_delta_kernels_bits(dev, lens, hq, hkv, d, causal):
+    """Round 6: the dQ kernel computes delta = sum_d dO * O of its query rows in its prologue (and -delta, -lse / scale for the dK / dV kernel behind it);
+    flash_delta_k stays behind ie_tune_flash_bwd_variant bit 2.  The sixteen (eight at d = 64) chunk sums are added in the delta kernel's shuffle tree, so dQ,
+    dK and dV of the two paths must agree bit for bit -- ragged sequences, rows past a tile's end, both head dims, causal and full attention."""
+    from internevo_amd import _lib
+
+    L = _lib.load()
+    T = sum(lens)
+    cu = torch.tensor([0] + [sum(lens[: i + 1]) for i in range(len(lens))], dtype=torch.int32).to(dev)
+    q = bf(torch.randn(T, hq, d, generator=g(290))).to(dev)
+    kv = bf(torch.randn(T, 2, hkv, d, generator=g(291))).to(dev)
+    do = bf(torch.randn(T, hq, d, generator=g(292))).to(dev)
+    out, lse = K().flash_attn_fwd(q, kv[:, 0], kv[:, 1], cu, max(lens), None, causal)
+    res = {}
+    try:
+        for variant in (0, 4):
+            assert L.ie_tune_flash_bwd_variant(variant) == 0
+            res[variant] = [t.clone() for t in K().flash_attn_bwd(do, q, kv[:, 0], kv[:, 1], out, lse, cu, max(lens), None, causal)]
+    finally:
+        L.ie_tune_flash_bwd_variant(0)
+    for a, b_, what in zip(res[0], res[4], ("dq", "dk", "dv")):
+        assert torch.equal(a, b_), f"{what}: delta in the dQ prologue differs from the delta kernel ({(a.float() - b_.float()).abs().max()})"
+    assert L.ie_tune_flash_bwd_variant(8) != 0
+
+
 @pytest.mark.parametrize("lens,hq,hkv,d,causal,four", [
     ([300, 700, 257], 4, 1, 128, True, False),          # ragged, one kv head for four q heads: a block of the dQ kernel = the four heads of one query tile
     ([300, 700, 257], 4, 1, 128, True, True),           # ... with four-wave dK/dV blocks (the upper key half above the diagonal goes to the spare image)
