@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--qkv-rotary-fuse", type=int, default=None, help="A/B only: ie_tune_qkv_rotary_fuse (1 = split + rotary in the wqkv product's epilogue, 0 = two launches)")
     ap.add_argument("--dgrad-refill-all", type=int, default=None, help="A/B only: ie_tune_gemm_dgrad_refill_all")
     ap.add_argument("--queue-memset", type=int, default=None, help="A/B only: ie_tune_gemm_queue_memset")
+    ap.add_argument("--res-in-epilogue", type=int, default=None, choices=[0, 1], help="A/B only: IE_RES_IN_EPILOGUE")
     ap.add_argument("--attn-bwd-rotary-fuse", type=int, default=None, choices=[0, 1], help="A/B only: IE_ATTN_BWD_ROTARY_FUSE")
     ap.add_argument("--flash-bwd-variant", type=int, default=None, help="A/B only: ie_tune_flash_bwd_variant (4 = delta by its own kernel)")
     ap.add_argument("--adamw-cus", type=int, default=None, help="A/B only: the CUs AdamW may occupy beside the next forward (IE_ADAMW_CUS; 0 = whole chip)")
@@ -198,6 +199,8 @@ def main():
         assert K._L().ie_tune_qkv_rotary_fuse(args.qkv_rotary_fuse) == 0
     if args.wgrad_ksplit is not None:
         os.environ["IE_WGRAD_KSPLIT"] = str(args.wgrad_ksplit)
+    if args.res_in_epilogue is not None:
+        os.environ["IE_RES_IN_EPILOGUE"] = str(args.res_in_epilogue)
     if args.attn_bwd_rotary_fuse is not None:
         os.environ["IE_ATTN_BWD_ROTARY_FUSE"] = str(args.attn_bwd_rotary_fuse)
     if args.adamw_cus is not None:

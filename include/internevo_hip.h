@@ -468,6 +468,12 @@ int ie_tune_gemm_persistent_skip_n(int64_t n_cols);
 /* Tuning hook (A/B): 1 = every input-gradient product (A k-contiguous, B k-major) takes the refill schedule (and with it the persistent frame where that applies),
  * not only the long / wide ones (K >= 6144 or N >= 8192); 0 (default) = the others on the 8-wave k32 ring. */
 int ie_tune_gemm_dgrad_refill_all(int on);
+/* out[M, N] = bf16(bf16(x[M, K] w[N, K]^T) + addend[M, N]) (round 6): the block's residual add -- `residual = dropout(hidden) + residual`,
+ * internlm/model/modeling_internlm2.py:707-717,728-737 -- in the epilogue of the product in front of it (wo, w2), with the roundings of the two-step form (the
+ * product rounded to bf16, the sum formed in fp32 and rounded): bit-identical to ie_gemm_bf16 + the add of ie_add_rmsnorm_fwd.  addend has out's leading dimension
+ * and must not be out.  Only where the persistent GEMM frame takes the product (ie_gemm_dma_persistent_takes(M, N, K)); elsewhere IE_ERR_UNSUPPORTED. */
+int ie_linear_fwd_add(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* addend, void* out, int64_t ld_out, int64_t M, int64_t N, int64_t K,
+                      void* stream);
 /* Tuning hook: 1 = every launch of the persistent frame zeroes its tile-queue slot with a 36-byte hipMemsetAsync in stream order first; 0 (default) = the slots are
  * zero at module load and the LAST block of every launch zeroes its slot again (the kernel does that either way), no memset kernels between the products
  * (-0.5 % of the benchmark step, profiles/r06_step_queue_memset_abab.log). */

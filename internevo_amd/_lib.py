@@ -118,6 +118,7 @@ SIGNATURES = {
     "ie_tune_gemm_persistent_skip_n": (I, [I64]),
     "ie_tune_gemm_dgrad_refill_all": (I, [I]),
     "ie_tune_gemm_queue_memset": (I, [I]),
+    "ie_linear_fwd_add": (I, [P, I64, P, I64, P, P, I64, I64, I64, I64, P]),
     "ie_tune_adamw_cus": (I, [I]),
     "ie_gemm_set_wgrad_ksplit_workspace": (I, [P, I64]),
     "ie_gemm_dma_persistent_takes": (I, [I64, I64, I64]),

@@ -1633,9 +1633,9 @@ __global__ __launch_bounds__(256) void gemm_p5_k(const bf16_t* __restrict__ A, i
                 for (int q = 0; q < 4; ++q) {
                     uint4 v = *reinterpret_cast<const uint4*>(rd + q * 4 * EP);
                     bf16_t* dst = cdst + (int64_t)(i * 16 + q * 4) * ldc;
-                    if (accumulate) {
+                    if (accumulate) {   // (EPI 0 with ACT: the addend is ANOTHER matrix of C's geometry -- C = bf16(bf16(A B) + ACT), ie_linear_fwd_add)
                         float o[8], n[8];
-                        unpack8(ld16(dst), o);
+                        unpack8(ld16((EPI == 0 && ACT) ? static_cast<const bf16_t*>(ACT) + (dst - C) : static_cast<const bf16_t*>(dst)), o);
                         unpack8(v, n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] += n[e];
@@ -1812,6 +1812,27 @@ extern "C" int ie_gemm_fp8_dma_launch(const void* A, int64_t lda, int64_t sa, co
     hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -6>), dim3((unsigned)(tiles_m * tiles_n * count)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
                        lda / 2, (const bf16_t*)B, ldb / 2, (bf16_t*)C, ldc, (int)M, (int)N, (int)(K / 2), (accumulate ? 1 : 0) | (g_gemm_group << 8), tiles_m, tiles_n, bt);
     return ie_launch_status("ie_gemm_fp8 launch");
+}
+
+// out = bf16(bf16(x w^T) + addend) in the persistent frame (round 6; ie_linear_fwd_add): the residual add of the transformer block in the row-parallel
+// product's epilogue -- `r = dropout(h) + residual` (modeling_internlm2.py:707-717,728-737) behind wo and behind w2 -- so that the norm behind it reads one matrix
+// instead of two.  The accumulating epilogue's arithmetic (the product rounded to bf16, added in fp32, rounded) with the addend read from another matrix of the
+// output's geometry.  Only where the frame takes the product (ie_gemm_dma_persistent_takes); elsewhere IE_ERR_UNSUPPORTED and the caller adds in the norm kernel.
+extern "C" int ie_linear_fwd_add(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* addend, void* out, int64_t ld_out, int64_t M, int64_t N,
+                                 int64_t K, void* stream) {
+    IE_CHECK_ARG(x && w && addend && out && addend != out && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ld_out >= N, "ie_linear_fwd_add: bad argument");
+    IE_CHECK_SUPPORTED(ie_gemm_dma_persistent_takes(M, N, K) && ldx % 8 == 0 && ldw % 8 == 0 && ld_out % 8 == 0 && (((uintptr_t)x) & 15u) == 0 && (((uintptr_t)w) & 15u) == 0 &&
+                           (((uintptr_t)addend) & 15u) == 0 && (((uintptr_t)out) & 15u) == 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31),
+                       "ie_linear_fwd_add: only where the persistent GEMM frame takes the product (ie_gemm_dma_persistent_takes), 16-byte aligned rows");
+    hipStream_t st = (hipStream_t)stream;
+    ie_gemm_note_kernel(1, 256, 256, 2, 2, 0, 0, -7, 0);
+    const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
+    unsigned* qslot = p5_queue_slot(st);
+    if (!qslot) return IE_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3((unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid)), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)w, ldw, (bf16_t*)out, ld_out, (int)M, (int)N, (int)K, 1 | (g_gemm_group << 8), tiles_m, tiles_n,
+                       const_cast<bf16_t*>((const bf16_t*)addend), (int64_t)0, 0, qslot, IeRotaryEpi{});
+    return ie_launch_status("ie_linear_fwd_add launch");
 }
 
 // The wqkv forward product with the GQA split + rotary embedding in the persistent frame's epilogue (gemm_p5_k<false, 3>).  The caller (gemm_bf16.hip) has checked

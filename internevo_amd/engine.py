@@ -55,6 +55,9 @@ def _mem_budget(device):
     return torch.cuda.mem_get_info(device)[0]
 
 
+_SUMMED = object()   # _layer_forward's return value when the layer has added its residual in w2's epilogue (the sum is where the caller said)
+
+
 def _optimizer_stream(device):
     """The optimizer's HIP stream: an ordinary stream.
     Round 5 tried a stream whose kernels may only use n of the 256 CUs (hipExtStreamCreateWithCUMask, n / 8 CUs of every XCD): 32 / 64 / 96 CUs -> 722-726 ms per
@@ -343,6 +346,10 @@ class InternLM2Engine:
         self.opt_stream = _optimizer_stream(device)
         # AdamW beside the next step's forward (step()): the buckets behind the first adamw_full_buckets run on adamw_cus CUs (ie_tune_adamw_cus; 0 = whole chip)
         self.adamw_cus = int(os.environ.get("IE_ADAMW_CUS", "128") or 0)
+        # the block's residual adds in the epilogues of wo / w2 (kernels.linear_fwd_add; opt-in IE_RES_IN_EPILOGUE=1): only where product and add are neighbours.
+        # Measured (profiles/r06_step_residual_in_epilogue_abab.log): the norm behind it 88 -> 46 us, the accumulating epilogue + 80 us per product (its reads of
+        # the addend sit in the wave-private turns with nothing to hide them): 655.7 / 657.0 -> 657.5 / 657.5 ms per step.  Off; bit-identical either way.
+        self.res_in_epilogue = os.environ.get("IE_RES_IN_EPILOGUE", "0") == "1" and self.tp == 1 and not self.bias and not self.ss
         self.attn_bwd_rotary_fuse = os.environ.get("IE_ATTN_BWD_ROTARY_FUSE", "1") != "0"   # (A/B switch: kernels.flash_attn_bwd_qkv_rotary in _layer_backward)
         self.adamw_full_buckets = int(os.environ.get("IE_ADAMW_FULL_BUCKETS", "2") or 0)
         self._bucket_ready = [None] * len(self.layout.buckets)
@@ -672,7 +679,7 @@ class InternLM2Engine:
         cu.host = cu_h
         return cu
 
-    def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute):
+    def _layer_forward(self, l, prev_ffn_out, cu, pos, max_seqlen, recompute, sum_dst=None):
         """One PackedFlashLlamaLayer1D (modeling_internlm2.py:684-740) into activation slot slot[l].
         recompute=False: the forward proper; the layer input a_x[l] = prev_ffn_out + previous layer's r2 is produced
         here (fused with the attention norm) and the w2 output is returned.
@@ -683,7 +690,8 @@ class InternLM2Engine:
         hkv, qpk, d = mc.num_kv_attention_heads, mc.q_per_kv, mc.head_dim
         p, s, rl = self.p, self.slot[l], self.rl
         pre = f"layers.{self.gid[l]}."   # (l counts this stage's layers; the names carry the reference's global layer numbers)
-        if prev_ffn_out is None or recompute:   # (the first layer of the model / of a pipeline stage / of a model chunk: its input is in a_x[l])
+        if prev_ffn_out is None or prev_ffn_out is _SUMMED or recompute:   # (the first layer of the model / of a pipeline stage / of a model chunk, or the
+            # layer below has added its residual in w2's epilogue: the input is in a_x[l])
             K.rmsnorm_fwd(self.a_x[l][rl], p[pre + "attention_norm.weight"], eps, self.a_n1[s][rl], self.a_rstd1[s][rl])
         else:
             K.add_rmsnorm_fwd(prev_ffn_out[rl], self.a_r2[self.slot[l - 1]][rl], p[pre + "attention_norm.weight"], eps, self.a_x[l][rl], self.a_n1[s][rl],
@@ -713,12 +721,17 @@ class InternLM2Engine:
         if self.sp > 1 and not self.ring_mode:    # ... and back: all tokens / my heads -> my tokens / all heads (:127)
             self.seqpar.scatter_seq_gather_heads(self.a_ctx[s], 1, self.t_xq, self.a_ctxl[s])
         attn_out = self.t_h3 if recompute else self.t_h0
-        K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
-        # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism); msp / fsp: summed into this rank's rows only
-        (self.tpar.reduce_scatter_rows_async(attn_out) if self.ss else self.tpar.all_reduce_sum_async(attn_out)).wait()
-        if self.bias:   # out_proj's bias, once, on the summed output (the reference's row-parallel linear holds it on tensor rank 0 only, ops/linear.py:318-324)
-            K.bias_add(attn_out[rl], p[pre + "attention.wo.bias"])
-        K.add_rmsnorm_fwd(attn_out[rl], self.a_x[l][rl], p[pre + "ffn_norm.weight"], eps, self.a_r2[s][rl], self.a_n2[s][rl], self.a_rstd2[s][rl])
+        # round 6: the residual add in the product's epilogue where nothing stands between product and add (no tensor-parallel sum, no bias) and the persistent
+        # GEMM frame takes the shape -- r2 = bf16(bf16(ctx wo^T) + x), the two-step form's roundings -- so the norm reads one matrix instead of two
+        if self.res_in_epilogue and K.linear_fwd_add(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], self.a_x[l], self.a_r2[s]):
+            K.rmsnorm_fwd(self.a_r2[s], p[pre + "ffn_norm.weight"], eps, self.a_n2[s], self.a_rstd2[s])
+        else:
+            K.linear_fwd(self.a_ctxl[s].view(self.T, -1), p[pre + "attention.wo.weight"], attn_out)
+            # row-parallel wo: partial sums over the tensor group (no-op without tensor parallelism); msp / fsp: summed into this rank's rows only
+            (self.tpar.reduce_scatter_rows_async(attn_out) if self.ss else self.tpar.all_reduce_sum_async(attn_out)).wait()
+            if self.bias:   # out_proj's bias, once, on the summed output (the reference's row-parallel linear holds it on tensor rank 0 only, ops/linear.py:318-324)
+                K.bias_add(attn_out[rl], p[pre + "attention.wo.bias"])
+            K.add_rmsnorm_fwd(attn_out[rl], self.a_x[l][rl], p[pre + "ffn_norm.weight"], eps, self.a_r2[s][rl], self.a_n2[s][rl], self.a_rstd2[s][rl])
         w13, _ = self._w13(l)
         if recompute:
             self._gathered_rows(self.a_n2[s], lambda r: K.linear_fwd(self.a_n2[s][r], w13, self.a_w13[s][r]))
@@ -726,6 +739,8 @@ class InternLM2Engine:
         act = self.t_act if self.a_act is None else self.a_act[s]
         # w1 | w3 product with the gate in its epilogue (one launch at the 7B shapes)
         self._gathered_rows(self.a_n2[s], lambda r: K.linear_swiglu_fwd(self.a_n2[s][r], w13, self.a_w13[s][r], act[r]))
+        if sum_dst is not None and self.res_in_epilogue and K.linear_fwd_add(act, p[pre + "feed_forward.w2.weight"], self.a_r2[s], sum_dst):
+            return _SUMMED   # (the next layer's input / the final norm's: ffn_out + r2 is in sum_dst already)
         K.linear_fwd(act, p[pre + "feed_forward.w2.weight"], self.t_h1)
         (self.tpar.reduce_scatter_rows_async(self.t_h1) if self.ss else self.tpar.all_reduce_sum_async(self.t_h1)).wait()   # row-parallel w2
         return self.t_h1
@@ -758,14 +773,18 @@ class InternLM2Engine:
         ffn_out = None
         for l in range(la, lb):
             self._layer_ready(l, l + 1 if l + 1 < lb else None)
-            ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False)
+            # (sum_dst: where ffn_out + r2 belongs -- the next layer's input, the final norm's input -- for the layer to add it in w2's epilogue if it can)
+            ffn_out = self._layer_forward(l, ffn_out, cu, pos, max_seqlen, False, self.a_x[l + 1] if l + 1 < lb else (self.a_xf if is_last else None))
         if not is_last:   # the output = the residual stream after the last layer; norm, head and loss live behind the model's last layer
             rl = self.rl    # (msp / fsp: this rank's token rows of it -- what travels to the same tensor rank of the next stage)
             torch.add(ffn_out[rl], self.a_r2[self.slot[lb - 1]][rl], out=self.t_send[rl])
             return
         self._wait_bucket(L + 1)
         rl = self.rl
-        K.add_rmsnorm_fwd(ffn_out[rl], self.a_r2[self.slot[L - 1]][rl], p["norm.weight"], eps, self.a_xf[rl], self.a_nf[rl], self.a_rstdf[rl])
+        if ffn_out is _SUMMED:
+            K.rmsnorm_fwd(self.a_xf, p["norm.weight"], eps, self.a_nf, self.a_rstdf)
+        else:
+            K.add_rmsnorm_fwd(ffn_out[rl], self.a_r2[self.slot[L - 1]][rl], p["norm.weight"], eps, self.a_xf[rl], self.a_nf[rl], self.a_rstdf[rl])
         if self.head_fn:
             K.head_weight_fwd(p["output.weight"], mc.embed_grad_scale, mc.norm_head, self.t_head_w, self.t_head_inv)
         # [T, V], or this tensor rank's [T, V / tp] columns (msp / fsp: the head is column-parallel: all-gather along the sequence in front of it, ops/linear.py:146-153)

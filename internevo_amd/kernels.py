@@ -535,6 +535,25 @@ def linear_fwd(x, w, out=None):
     return gemm(x, w, False, False, out, False, LINEAR_FWD_VARIANT)
 
 
+def linear_fwd_add(x, w, addend, out):
+    """out[T, N] = bf16(bf16(x[T, K] @ w[N, K]^T) + addend[T, N]) in ONE launch where the persistent GEMM frame takes the product (ie_linear_fwd_add: the block's
+    residual add in the epilogue of wo / w2).  Returns False -- and touches nothing -- elsewhere (the caller then adds in the norm kernel: the same bits)."""
+    M, Kd = x.shape
+    N = w.shape[0]
+    if w.shape != (N, Kd) or addend.shape != (M, N) or out.shape != (M, N) or any(t.stride(1) != 1 for t in (x, w, addend, out)) or addend.stride(0) != out.stride(0):
+        raise ValueError("linear_fwd_add: bad shapes")
+    L = _L()
+    if LINEAR_FWD_VARIANT != -1 or not L.ie_gemm_dma_persistent_takes(M, N, Kd) or any(t.stride(0) % 8 for t in (x, w, out)):
+        return False
+    prof = GEMM_PROFILER
+    if prof is not None:
+        prof.begin()
+    check(L.ie_linear_fwd_add(_p(x), x.stride(0), _p(w), w.stride(0), _p(addend), _p(out), out.stride(0), M, N, Kd, _stream()), "ie_linear_fwd_add")
+    if prof is not None:   # (the product's algorithmic work; the addend's 2 M N bytes ride along)
+        prof.end(2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd + M * N))
+    return True
+
+
 def linear_dgrad(dy, w, out=None):
     """dx[T,K] = dy[T,N] @ w[N,K]"""
     return gemm(dy, w, False, True, out)

@@ -440,6 +440,51 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
                                                      "norm.weight", "layers.0.ffn_norm.weight"), dev)
 
 
+def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeypatch):
+    """Round 6's engine-level switches that claim bit-identity, on the merged 16 384-row step at the model's full width (two layers, so that the layer-to-layer
+    hand-over of the w2 epilogue's sum runs): the residual adds in the epilogues of wo / w2 (IE_RES_IN_EPILOGUE=1, opt-in), the attention backward without the
+    rotary / GQA stores (IE_ATTN_BWD_ROTARY_FUSE=0), AdamW by the whole-chip kernel (IE_ADAMW_CUS=0) -- two steps each, then loss, gradient norm, the whole
+    gradient buffer and every parameter must equal the default engine's, bit for bit."""
+    from internevo_amd.config import internlm2_7b
+    from internevo_amd.data import SyntheticLoader
+    from internevo_amd.engine import InternLM2Engine
+    from oracle.model import formula_init
+
+    def run(env):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        try:
+            cfg = internlm2_7b(4096)
+            cfg.model.num_layers = 2
+            cfg.train.micro_num = 4
+            cfg.train.fixed_random_dataset_seqlen = True
+            eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
+            assert eng.mm == 4 and eng.Tg == 16384
+            loader = iter(SyntheticLoader(4096, 1, 4, True, 4000))
+            losses = []
+            for _ in range(2):
+                batch, labels = next(loader)
+                losses.append(float(eng.forward_backward(batch, labels)))
+                eng.step()
+            st = eng.read_state()
+            out = (losses, st.grad_norm, eng.grads.clone(), eng.params.clone(), eng.master.clone(), eng.res_in_epilogue, eng.attn_bwd_rotary_fuse, eng.adamw_cus)
+            del eng
+            torch.cuda.empty_cache()
+            return out
+        finally:
+            for k_ in env:
+                monkeypatch.delenv(k_, raising=False)
+
+    base = run({})
+    assert base[5:] == (False, True, 128), "the defaults this test is written against"
+    for env in ({"IE_RES_IN_EPILOGUE": "1"}, {"IE_ATTN_BWD_ROTARY_FUSE": "0"}, {"IE_ADAMW_CUS": "0"}):
+        other = run(env)
+        assert other[5:] != base[5:], f"{env}: the switch did not reach the engine"
+        assert other[0] == base[0] and other[1] == base[1], f"{env}: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
+        for a_, b_, what in zip(other[2:5], base[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
+            assert torch.equal(a_, b_), f"{env}: {what} differ"
+
+
 @pytest.mark.extended
 @pytest.mark.timeout(2400)
 def test_engine_7b_width_merged_benchmark_step_matches_the_live_oracle(dev):

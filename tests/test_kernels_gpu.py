@@ -590,6 +590,31 @@ def test_gemm_tail_split_is_bit_identical(dev, M, N):
     assert lib().ie_tune_gemm_tail_split(4) != 0
 
 
+@pytest.mark.parametrize("M,N,Kd,takes", [(4096, 8192, 1024, 1), (4352, 4352, 512, 1), (16384, 4096, 4096, 1), (4096, 4096, 1024, 0), (1000, 4096, 1024, 0)],
+                         ids=["frame", "uneven_walk", "7b_wo", "one_round", "ragged_rows"])
+def test_residual_add_in_the_product_epilogue_equals_product_then_add_bit_for_bit(dev, M, N, Kd, takes):
+    """ie_linear_fwd_add (round 6): out = bf16(bf16(x w^T) + addend) in the persistent frame's epilogue -- the block's residual add behind wo / w2 -- against the
+    two-step form the engine ran before (the product, then ie_add_rmsnorm_fwd's r = bf16(a + b)): identical r, and the plain norm of it identical to the fused
+    add + norm's y and rstd; on a strided x; where the frame does not take the product the call declines and leaves the output alone."""
+    xb = bf(torch.randn(M, Kd + 64, generator=g(100))).to(dev)
+    x = xb[:, :Kd]
+    w = bf(torch.randn(N, Kd, generator=g(101)) * 0.05).to(dev)
+    add = bf(torch.randn(M, N, generator=g(102))).to(dev)
+    nw = bf(1.0 + 0.1 * torch.randn(N, generator=g(103))).to(dev)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    took = K().linear_fwd_add(x, w, add, out)
+    assert bool(took) == bool(takes)
+    if not takes:
+        assert bool((out == 7.0).all())
+        return
+    prod = K().linear_fwd(x, w)
+    r_ref, y_ref, rstd_ref = K().add_rmsnorm_fwd(prod, add, nw, 1e-5)
+    assert torch.equal(out, r_ref), f"residual sum differs: {(out.float() - r_ref.float()).abs().max()}"
+    y, rstd = K().rmsnorm_fwd(out, nw, 1e-5)
+    assert torch.equal(y, y_ref) and torch.equal(rstd, rstd_ref), "the plain norm of the summed rows differs from the fused add + norm"
+    close(out, x.float().cpu() @ w.float().cpu().t() + add.float().cpu(), 8e-3, 2e-3 * math.sqrt(Kd), "against fp32")
+
+
 @pytest.mark.parametrize("memset", [0, 1])
 def test_persistent_frame_recycles_its_queue_slots(dev, memset):
     """The persistent kernel's tile queues: 64 slots handed out round-robin, zero at module load, every launch's LAST block zeroes its slot for the launch that
