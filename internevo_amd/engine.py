@@ -346,10 +346,10 @@ class InternLM2Engine:
         self.opt_stream = _optimizer_stream(device)
         # AdamW beside the next step's forward (step()): the buckets behind the first adamw_full_buckets run on adamw_cus CUs (ie_tune_adamw_cus; 0 = whole chip)
         self.adamw_cus = int(os.environ.get("IE_ADAMW_CUS", "128") or 0)
-        # the block's residual adds in the epilogues of wo / w2 (kernels.linear_fwd_add; opt-in IE_RES_IN_EPILOGUE=1): only where product and add are neighbours.
-        # Measured (profiles/r06_step_residual_in_epilogue_abab.log): the norm behind it 88 -> 46 us, the accumulating epilogue + 80 us per product (its reads of
-        # the addend sit in the wave-private turns with nothing to hide them): 655.7 / 657.0 -> 657.5 / 657.5 ms per step.  Off; bit-identical either way.
-        self.res_in_epilogue = os.environ.get("IE_RES_IN_EPILOGUE", "0") == "1" and self.tp == 1 and not self.bias and not self.ss
+        # the block's residual adds in the epilogues of wo / w2 (kernels.linear_fwd_add; IE_RES_IN_EPILOGUE=0: A/B switch): only where product and add are neighbours.
+        # Measured (profiles/r06_step_residual_in_epilogue_abab.log): first with the addend read where it is used: the norm behind it 88 -> 46 us, the product
+        # + 80 us, the step 0.15 % slower; with the addend requested one epilogue turn ahead: + 14 us per product, 653.6 / 653.8 -> 653.0 / 653.1 ms per step.
+        self.res_in_epilogue = os.environ.get("IE_RES_IN_EPILOGUE", "1") != "0" and self.tp == 1 and not self.bias and not self.ss
         self.attn_bwd_rotary_fuse = os.environ.get("IE_ATTN_BWD_ROTARY_FUSE", "1") != "0"   # (A/B switch: kernels.flash_attn_bwd_qkv_rotary in _layer_backward)
         self.adamw_full_buckets = int(os.environ.get("IE_ADAMW_FULL_BUCKETS", "2") or 0)
         self._bucket_ready = [None] * len(self.layout.buckets)

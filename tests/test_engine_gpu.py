@@ -442,7 +442,7 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
 
 def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeypatch):
     """Round 6's engine-level switches that claim bit-identity, on the merged 16 384-row step at the model's full width (two layers, so that the layer-to-layer
-    hand-over of the w2 epilogue's sum runs): the residual adds in the epilogues of wo / w2 (IE_RES_IN_EPILOGUE=1, opt-in), the attention backward without the
+    hand-over of the w2 epilogue's sum runs): the residual adds back in the norm kernels instead of the epilogues of wo / w2 (IE_RES_IN_EPILOGUE=0), the attention backward without the
     rotary / GQA stores (IE_ATTN_BWD_ROTARY_FUSE=0), AdamW by the whole-chip kernel (IE_ADAMW_CUS=0) -- two steps each, then loss, gradient norm, the whole
     gradient buffer and every parameter must equal the default engine's, bit for bit."""
     from internevo_amd.config import internlm2_7b
@@ -476,8 +476,8 @@ def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeyp
                 monkeypatch.delenv(k_, raising=False)
 
     base = run({})
-    assert base[5:] == (False, True, 128), "the defaults this test is written against"
-    for env in ({"IE_RES_IN_EPILOGUE": "1"}, {"IE_ATTN_BWD_ROTARY_FUSE": "0"}, {"IE_ADAMW_CUS": "0"}):
+    assert base[5:] == (True, True, 128), "the defaults this test is written against"
+    for env in ({"IE_RES_IN_EPILOGUE": "0"}, {"IE_ATTN_BWD_ROTARY_FUSE": "0"}, {"IE_ADAMW_CUS": "0"}):
         other = run(env)
         assert other[5:] != base[5:], f"{env}: the switch did not reach the engine"
         assert other[0] == base[0] and other[1] == base[1], f"{env}: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
