@@ -444,17 +444,18 @@ def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeyp
     """Round 6's engine-level switches that claim bit-identity, on the merged 16 384-row step at the model's full width (two layers, so that the layer-to-layer
     hand-over of the w2 epilogue's sum runs): the residual adds back in the norm kernels instead of the epilogues of wo / w2 (IE_RES_IN_EPILOGUE=0), the attention backward without the
     rotary / GQA stores (IE_ATTN_BWD_ROTARY_FUSE=0), AdamW by the whole-chip kernel (IE_ADAMW_CUS=0) -- two steps each, then loss, gradient norm, the whole
-    gradient buffer and every parameter must equal the default engine's, bit for bit."""
+    gradient buffer and every parameter must equal the default engine's, bit for bit; and the default engine with every layer checkpointed."""
     from internevo_amd.config import internlm2_7b
     from internevo_amd.data import SyntheticLoader
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
 
-    def run(env):
+    def run(env, checkpoint=0.0):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         try:
             cfg = internlm2_7b(4096)
+            cfg.model.checkpoint = checkpoint
             cfg.model.num_layers = 2
             cfg.train.micro_num = 4
             cfg.train.fixed_random_dataset_seqlen = True
@@ -483,6 +484,12 @@ def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeyp
         assert other[0] == base[0] and other[1] == base[1], f"{env}: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
         for a_, b_, what in zip(other[2:5], base[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
             assert torch.equal(a_, b_), f"{env}: {what} differ"
+    # every layer under activation checkpointing: the replayed forward takes the same fused launches (the w2 product is not replayed: its sum went to the next
+    # layer's input in the forward proper) -- still the default engine's bits
+    other = run({}, checkpoint=1.0)
+    assert other[0] == base[0] and other[1] == base[1], f"checkpoint 1.0: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
+    for a_, b_, what in zip(other[2:5], base[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
+        assert torch.equal(a_, b_), f"checkpoint 1.0: {what} differ"
 
 
 @pytest.mark.extended
