@@ -450,18 +450,18 @@ def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeyp
     from internevo_amd.engine import InternLM2Engine
     from oracle.model import formula_init
 
-    def run(env, checkpoint=0.0):
+    def run(env, checkpoint=0.0, seq=4096, micro=4):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         try:
-            cfg = internlm2_7b(4096)
+            cfg = internlm2_7b(seq)
             cfg.model.checkpoint = checkpoint
             cfg.model.num_layers = 2
-            cfg.train.micro_num = 4
+            cfg.train.micro_num = micro
             cfg.train.fixed_random_dataset_seqlen = True
             eng = InternLM2Engine(cfg, dev, init_fn=formula_init)
-            assert eng.mm == 4 and eng.Tg == 16384
-            loader = iter(SyntheticLoader(4096, 1, 4, True, 4000))
+            assert eng.mm == micro and eng.Tg == seq * micro
+            loader = iter(SyntheticLoader(seq, 1, micro, True, 4000))
             losses = []
             for _ in range(2):
                 batch, labels = next(loader)
@@ -484,11 +484,12 @@ def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeyp
         assert other[0] == base[0] and other[1] == base[1], f"{env}: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
         for a_, b_, what in zip(other[2:5], base[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
             assert torch.equal(a_, b_), f"{env}: {what} differ"
-    # every layer under activation checkpointing: the replayed forward takes the same fused launches (the w2 product is not replayed: its sum went to the next
-    # layer's input in the forward proper) -- still the default engine's bits
-    other = run({}, checkpoint=1.0)
-    assert other[0] == base[0] and other[1] == base[1], f"checkpoint 1.0: losses / gradient norm {other[0]} {other[1]} vs {base[0]} {base[1]}"
-    for a_, b_, what in zip(other[2:5], base[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
+    # every layer under activation checkpointing (no merged pass then: one 8192-token micro-batch per step, enough rows for the persistent frame and with it
+    # the fused launches): the replayed forward takes the same launches on the same values (the w2 product is not replayed: its sum went to the next layer's
+    # input in the forward proper) -- the un-checkpointed engine's bits
+    plain, ck = run({}, 0.0, 8192, 1), run({}, 1.0, 8192, 1)
+    assert ck[0] == plain[0] and ck[1] == plain[1], f"checkpoint 1.0: losses / gradient norm {ck[0]} {ck[1]} vs {plain[0]} {plain[1]}"
+    for a_, b_, what in zip(ck[2:5], plain[2:5], ("gradients", "bf16 parameters", "fp32 master parameters")):
         assert torch.equal(a_, b_), f"checkpoint 1.0: {what} differ"
 
 
