@@ -440,6 +440,7 @@ def test_engine_7b_width_merged_benchmark_step_matches_oracle(dev):
                                                      "norm.weight", "layers.0.ffn_norm.weight"), dev)
 
 
+@pytest.mark.timeout(900)
 def test_round6_step_switches_leave_the_7b_width_step_bit_identical(dev, monkeypatch):
     """Round 6's engine-level switches that claim bit-identity, on the merged 16 384-row step at the model's full width (two layers, so that the layer-to-layer
     hand-over of the w2 epilogue's sum runs): the residual adds back in the norm kernels instead of the epilogues of wo / w2 (IE_RES_IN_EPILOGUE=0), the attention backward without the
