@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
         dlt = q_valid ? delta[(int64_t)h * T + tok0 + my_q] : 0.f;
     }
     const float sc2 = scale * kLog2e;
+    // ROT: the row's position now (one register), so that the store's cos / sin reads are ONE round trip behind the last tile instead of two
+    int64_t rot_p = 0;
+    if constexpr (ROT) rot_p = q_valid ? ro.pos[tok0 + my_q] : 0;
 
     f32x16 dqacc[G::DB];
 #pragma unroll
@@ -257,9 +260,8 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     }
 
     if constexpr (ROT) {
-        const int64_t p = q_valid ? ro.pos[tok0 + my_q] : 0;
         store_row_block_rot<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)(h / ro.qpk) * ro.grp_stride + (int64_t)(h % ro.qpk) * D, dqacc, scale, lane, q_valid,
-                               ro.cs + p * (D / 2), ro.sn + p * (D / 2));
+                               ro.cs + rot_p * (D / 2), ro.sn + rot_p * (D / 2));
     } else {
         store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
     }
