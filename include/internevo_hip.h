@@ -475,8 +475,9 @@ int ie_tune_gemm_dgrad_refill_all(int on);
 int ie_linear_fwd_add(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* addend, void* out, int64_t ld_out, int64_t M, int64_t N, int64_t K,
                       void* stream);
 /* Tuning hook: 1 = every launch of the persistent frame zeroes its tile-queue slot with a 36-byte hipMemsetAsync in stream order first; 0 (default) = the slots are
- * zero at module load and the LAST block of every launch zeroes its slot again (the kernel does that either way), no memset kernels between the products
- * (-0.5 % of the benchmark step, profiles/r06_step_queue_memset_abab.log). */
+ * zero at module load, every STREAM has a slot of its own (the first 63 streams; later ones share the last slot and take turns on it) and the LAST block of every
+ * launch zeroes its slot again (the kernel does that either way), no memset kernels between the products (-0.5 % of the benchmark step,
+ * profiles/r06_step_queue_memset_abab.log). */
 int ie_tune_gemm_queue_memset(int on);
 /* The weight-gradient products' tail k-split (round 6; internlm/model/utils.py:293-299,336-340 `linear_bias_wgrad`): with a caller-owned workspace registered here
  * (16-byte aligned; 32 MiB covers every remainder of <= 128 tiles; NULL, 0 takes it back) a weight-gradient product (both operands k-major, K % 128 == 0) whose

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1704,23 +1705,58 @@ extern "C" int ie_gemm_last_kernel(char* buf, int n) {
 }
 
 static int g_gemm_persistent_grid = 256;   // blocks of the persistent kernel (one per CU; a multiple of 8: the XCD-contiguous numbering)
-// tile queues of the persistent kernel: 64 slots of 16 words handed out round-robin (an atomic counter: launches may come from several host threads);
-// module-global device memory: no allocation, zero at module load, and the LAST block of every launch zeroes its slot for the launch that takes it 64 launches
-// later (gemm_p5_k).  A launch that faults leaves the process without a usable context, so nothing can inherit its counters.  Round 6 had added a 36-byte
-// hipMemsetAsync in front of every launch as a second line of defence: rocclr runs it as TWO fill kernels, 386 of them per benchmark step in front of the 193
-// products -- 673.1 / 671.0 ms with them, 669.3 / 668.2 ms without (profiles/r06_step_queue_memset_abab.log: -0.5 % of the step), so it is OFF by default and kept
-// behind ie_tune_gemm_queue_memset(1) for whoever suspects a slot.
+// tile queues of the persistent kernel: 64 slots of 16 words in module-global device memory (no allocation, zero at module load), ONE SLOT PER STREAM: the
+// launches of a stream run one after the other, and the LAST block of every launch zeroes the slot (gemm_p5_k), so the next launch of that stream finds it clean
+// and no launch of another stream ever touches it.  (Rounds 5 / 6 handed the slots out round-robin over all launches: two products running at the same time on
+// two streams shared a slot once in 64 pairs and would have skipped tiles silently.)  The first 63 streams that launch a persistent product get a slot each; any
+// further stream shares the last one, zeroed in stream order in front of every launch (the only place the memset is still needed).  A launch that faults leaves
+// the process without a usable context, so nothing can inherit its counters.  ie_tune_gemm_queue_memset(1): the memset in front of EVERY launch -- rocclr runs
+// it as two fill kernels, 386 per benchmark step: 673.1 / 671.0 ms with them, 669.3 / 668.2 ms without (profiles/r06_step_queue_memset_abab.log) -- for whoever
+// suspects a slot.
 __device__ unsigned g_p5_queues[64 * 16];
 static int g_p5_queue_memset = 0;   // (ie_tune_gemm_queue_memset)
+static hipEvent_t g_p5_shared_ev[16] = {};   // (the event of the last launch on the shared slot, per device)
+static std::mutex g_p5_mu;
+static thread_local bool t_p5_shared = false;
 static unsigned* p5_queue_slot(hipStream_t st) {
     static unsigned* base[16] = {};   // per device: a module-global has one address on every device of the process
-    static std::atomic<unsigned> n{0};
+    static hipStream_t owner[16][63];
+    static int owners[16] = {};
+    thread_local hipStream_t last_st = nullptr;
+    thread_local int last_dev = -1, last_idx = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
-    unsigned* slot = base[dev] + 16 * (n.fetch_add(1u, std::memory_order_relaxed) & 63u);
-    if (g_p5_queue_memset && hipMemsetAsync(slot, 0, 9 * sizeof(unsigned), st) != hipSuccess) return nullptr;
+    int idx = (last_dev == dev && last_st == st && last_idx >= 0) ? last_idx : -1;
+    if (idx < 0) {
+        std::lock_guard<std::mutex> lk(g_p5_mu);
+        if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_p5_queues)) != hipSuccess) return nullptr;
+        for (int i = 0; i < owners[dev] && idx < 0; ++i)
+            if (owner[dev][i] == st) idx = i;
+        if (idx < 0 && owners[dev] < 63) {
+            idx = owners[dev]++;
+            owner[dev][idx] = st;
+        }
+        if (idx < 0) idx = 63;   // (the shared slot)
+        last_dev = dev; last_st = st; last_idx = idx;
+    }
+    unsigned* slot = base[dev] + 16 * idx;
+    t_p5_shared = idx == 63;
+    if (idx == 63) {   // the streams that share the last slot take turns: each launch waits for the event the launch before it on that slot recorded (p5_queue_done)
+        std::lock_guard<std::mutex> lk(g_p5_mu);
+        if (g_p5_shared_ev[dev] && hipStreamWaitEvent(st, g_p5_shared_ev[dev], 0) != hipSuccess) return nullptr;
+    }
+    if ((g_p5_queue_memset || idx == 63) && hipMemsetAsync(slot, 0, 9 * sizeof(unsigned), st) != hipSuccess) return nullptr;
     return slot;
+}
+// behind every launch of the persistent kernel: the shared slot's next user (any stream) must not start before this launch is through
+static void p5_queue_done(hipStream_t st, const unsigned* slot) {
+    if (!t_p5_shared) return;   // (set by p5_queue_slot on this thread for the launch just made)
+    (void)slot;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    std::lock_guard<std::mutex> lk(g_p5_mu);
+    if (!g_p5_shared_ev[dev] && hipEventCreateWithFlags(&g_p5_shared_ev[dev], hipEventDisableTiming) != hipSuccess) { g_p5_shared_ev[dev] = nullptr; return; }
+    (void)hipEventRecord(g_p5_shared_ev[dev], st);
 }
 extern "C" int ie_tune_gemm_queue_memset(int on) {
     if (on != 0 && on != 1) return IE_ERR_INVALID;
@@ -1811,6 +1847,7 @@ extern "C" int ie_gemm_dma_launch(int shape, const void* A, int64_t lda, int a_k
                                          (bf16_t*)nullptr, (int64_t)0, 0, qslot, IeRotaryEpi{});
         else hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3(grid), dim3(256), 0, st, a, lda, b, ldb, c, ldc, (int)M, (int)N, (int)K, accumulate, tiles_m, tiles_n,
                                 (bf16_t*)nullptr, (int64_t)0, 0, qslot, IeRotaryEpi{});
+        p5_queue_done(st, qslot);
     }
     else IE_SHAPE(256, 256, 2, 4, -11);
 #undef IE_SHAPE
@@ -1847,6 +1884,7 @@ extern "C" int ie_linear_fwd_add(const void* x, int64_t ldx, const void* w, int6
     hipLaunchKernelGGL((gemm_p5_k<false, 0>), dim3((unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid)), dim3(256), 0, st, (const bf16_t*)x, ldx,
                        (const bf16_t*)w, ldw, (bf16_t*)out, ld_out, (int)M, (int)N, (int)K, 1 | (g_gemm_group << 8), tiles_m, tiles_n,
                        const_cast<bf16_t*>((const bf16_t*)addend), (int64_t)0, 0, qslot, IeRotaryEpi{});
+    p5_queue_done(st, qslot);
     return ie_launch_status("ie_linear_fwd_add launch");
 }
 
@@ -1860,6 +1898,7 @@ extern "C" int ie_gemm_qkv_rotary_dma_launch(const void* A, int64_t lda, const v
     if (!qslot) return IE_ERR_LAUNCH;
     hipLaunchKernelGGL((gemm_p5_k<false, 3>), dim3((unsigned)std::min(tiles_m * tiles_n, g_gemm_persistent_grid)), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                        (bf16_t*)nullptr, (int64_t)N, (int)M, (int)N, (int)K, (g_gemm_group << 8), tiles_m, tiles_n, (bf16_t*)nullptr, (int64_t)0, 0, qslot, rot);
+    p5_queue_done(st, qslot);
     return ie_launch_status("ie_gemm_qkv_rotary (persistent) launch");
 }
 
@@ -1884,6 +1923,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
             if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<false, 1>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
                                (int)M, (int)(2 * F), (int)K, flags, tiles_m, tiles_n, (bf16_t*)act, ld_act, (int)F, qslot, IeRotaryEpi{});
+            p5_queue_done(st, qslot);
             return ie_launch_status("ie_gemm_swiglu (persistent) launch");
         }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, false, -5, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,
@@ -1897,6 +1937,7 @@ extern "C" int ie_gemm_swiglu_dma_launch(int bwd, const void* A, int64_t lda, co
             if (!qslot) return IE_ERR_LAUNCH;
             hipLaunchKernelGGL((gemm_p5_k<true, 2>), dim3((unsigned)g_gemm_persistent_grid), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
                                (int)M, (int)F, (int)K, flags, tiles_m, tiles_n, (bf16_t*)const_cast<void*>(h13), ld_h13, (int)F, qslot, IeRotaryEpi{});
+            p5_queue_done(st, qslot);
             return ie_launch_status("ie_gemm_swiglu bwd (persistent) launch");
         }
         hipLaunchKernelGGL((gemm_dma_k<256, 256, 2, 2, false, true, -4, 2>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, (const bf16_t*)A, lda,

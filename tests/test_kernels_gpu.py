@@ -617,9 +617,10 @@ def test_residual_add_in_the_product_epilogue_equals_product_then_add_bit_for_bi
 
 @pytest.mark.parametrize("memset", [0, 1])
 def test_persistent_frame_recycles_its_queue_slots(dev, memset):
-    """The persistent kernel's tile queues: 64 slots handed out round-robin, zero at module load, every launch's LAST block zeroes its slot for the launch that
-    takes it 64 launches later (ie_tune_gemm_queue_memset(0), the default since round 6: no memset kernels between the products) -- 200 launches in a row on two
-    streams, different tile counts per launch, every result the plain launch's bit for bit; the same with the memset switched on."""
+    """The persistent kernel's tile queues: one slot per stream (zero at module load, every launch's LAST block zeroes it for the next launch of that stream;
+    ie_tune_gemm_queue_memset(0), the default since round 6: no memset kernels between the products) -- 100 launches on each of three streams that run at the
+    same time (8 blocks per launch: a dozen launches fit on the chip side by side), different tile counts per launch, every result the plain launch's bit for
+    bit; then 70 more streams, one launch each: the 64th and later share the last slot and take turns on it.  The same with the memset switched on."""
     from internevo_amd._lib import load as lib
     shapes = [(1024, 1024, 256), (2048, 1280, 256), (1536, 512, 512), (768, 2304, 256)]
     ops = []
@@ -628,20 +629,22 @@ def test_persistent_frame_recycles_its_queue_slots(dev, memset):
         B = bf(torch.randn(N, Kd, generator=g(90 + i))).to(dev)
         ops.append((A, B, K().gemm(A, B, False, False, variant=20)))
     torch.cuda.synchronize()
-    side = torch.cuda.Stream(device=dev)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(2)]
     try:
         assert lib().ie_tune_gemm_persistent(8) == 0 and lib().ie_tune_gemm_queue_memset(memset) == 0
         outs = []
-        for n in range(200):
+        for n in range(300):
+            A, B, _ = ops[(n // 3 + n) % len(ops)]
+            with torch.cuda.stream(streams[n % 3]):
+                outs.append(((n // 3 + n) % len(ops), K().gemm(A, B, False, False, variant=22)))
+        more = [torch.cuda.Stream(device=dev) for _ in range(70)]
+        for n, st in enumerate(more):
             A, B, _ = ops[n % len(ops)]
-            if n % 3 == 2:
-                with torch.cuda.stream(side):
-                    outs.append((n, K().gemm(A, B, False, False, variant=22)))
-            else:
-                outs.append((n, K().gemm(A, B, False, False, variant=22)))
+            with torch.cuda.stream(st):
+                outs.append((n % len(ops), K().gemm(A, B, False, False, variant=22)))
         torch.cuda.synchronize()
-        for n, o in outs:
-            assert torch.equal(o, ops[n % len(ops)][2]), f"launch {n} (memset {memset})"
+        for n, (which, o) in enumerate(outs):
+            assert torch.equal(o, ops[which][2]), f"launch {n} (memset {memset})"
     finally:
         lib().ie_tune_gemm_persistent(1)
         lib().ie_tune_gemm_queue_memset(0)
