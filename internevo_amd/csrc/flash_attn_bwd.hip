@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     }
 
     if constexpr (ROT) {
+        static_assert(4 * FA_ROT_STAGE_BYTES <= 2 * STAGE, "the cos / sin staging rows of four waves in the K / V stages");
         store_row_block_rot<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)(h / ro.qpk) * ro.grp_stride + (int64_t)(h % ro.qpk) * D, dqacc, scale, lane, q_valid,
-                               ro.cs + rot_p * (D / 2), ro.sn + rot_p * (D / 2));
+                               ro.cs, ro.sn, (int)rot_p, smem + wave * FA_ROT_STAGE_BYTES);   // (the last tile ended with a barrier: the stages are free)
     } else {
         store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
     }
@@ -783,7 +784,9 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         static_assert(HS == 1, "the rotating store writes final gradients");
         const int64_t hoff = (int64_t)hk * ro.grp_stride;
         const int64_t p = k_valid ? ro.pos[tok0k + my_k] : 0;
-        store_row_block_rot<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dkacc, scale, lane, k_valid, ro.cs + p * (D / 2), ro.sn + p * (D / 2));
+        static_assert(DKV_WAVES * FA_ROT_STAGE_BYTES <= NST * STAGE, "the cos / sin staging rows in the Q / dO stages");
+        __syncthreads();   // (every wave is through its last tile: the stages are free)
+        store_row_block_rot<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dkacc, scale, lane, k_valid, ro.cs, ro.sn, (int)p, smem + wave * FA_ROT_STAGE_BYTES);
         store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dvacc, 1.f, lane, k_valid, true);
     } else if (HS == 1) {
         store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);

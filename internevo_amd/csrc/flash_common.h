@@ -236,20 +236,31 @@ struct FaRotOut {
 
 // store_row_block with the conjugate rotation: the lane holds d = 32 db + 8 g + 4 (lane >> 5) + i of its row for db = 0 .. 3, so a pair (d, d + 64) = (db, db + 2)
 // sits in ONE lane.  The two-kernel path rounds the gradient to bf16 (store_row_block), reads it back, rotates in fp32 (rot_conj1) and rounds again: the same here.
+// The cos / sin rows of the wave's 32 rows come through LDS (`stage`: FA_ROT_STAGE_BYTES of this wave's own, free at the end of the kernel): 16-byte pieces,
+// eight per lane, instead of sixteen 8-byte gathers per lane with 64 different cache lines each -- the gathers kept the CU's address path busy for 40 us of the
+// dQ kernel (measured: 810 -> 840 us with them).  pos_lane: the position of THIS lane's row (lane & 31); the others' come by shuffle.
+constexpr int FA_ROT_ROW = 272;                       // bytes per staged row: cos [64] at 0, sin [64] at 128, padded so that the 32 rows spread over the banks
+constexpr int FA_ROT_STAGE_BYTES = 32 * FA_ROT_ROW;   // per wave
 template <int D>
-__device__ __forceinline__ void store_row_block_rot(bf16_t* row, f32x16 (&acc)[Geo<D>::DB], float mul, int lane, bool valid, const bf16_t* cs_row,
-                                                    const bf16_t* sn_row) {
+__device__ __forceinline__ void store_row_block_rot(bf16_t* row, f32x16 (&acc)[Geo<D>::DB], float mul, int lane, bool valid, const bf16_t* cs, const bf16_t* sn,
+                                                    int pos_lane, unsigned char* stage) {
     static_assert(D == 128, "pairs (d, d + 64) of a 128-wide head");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int id = lane + 64 * j, r = id >> 4, sub = id & 15;          // piece `sub` (0 .. 7 cos, 8 .. 15 sin) of row r
+        const int pr = __shfl(pos_lane, r, 64);
+        const bf16_t* src = (sub < 8 ? cs : sn) + (int64_t)pr * (D / 2) + (sub & 7) * 8;
+        *reinterpret_cast<uint4*>(stage + r * FA_ROT_ROW + sub * 16) = ld16(src);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's own rows: no barrier)
     const int hh = lane >> 5;
+    const unsigned char* mine = stage + (lane & 31) * FA_ROT_ROW;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            uint2 c2 = make_uint2(0u, 0u), s2 = make_uint2(0u, 0u);
-            if (valid) {
-                c2 = ld8(cs_row + 32 * db + 8 * g + 4 * hh);
-                s2 = ld8(sn_row + 32 * db + 8 * g + 4 * hh);
-            }
+            const uint2 c2 = *reinterpret_cast<const uint2*>(mine + (32 * db + 8 * g + 4 * hh) * 2);
+            const uint2 s2 = *reinterpret_cast<const uint2*>(mine + 128 + (32 * db + 8 * g + 4 * hh) * 2);
             const float co[4] = {bflo(c2.x), bfhi(c2.x), bflo(c2.y), bfhi(c2.y)}, si[4] = {bflo(s2.x), bfhi(s2.x), bflo(s2.y), bfhi(s2.y)};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
