@@ -152,33 +152,42 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
     FragOffs<D> fo;
     fo.init(lane);
 
-    s16x8 qf[G::KS], dof[G::KS];
+    // Q, dO (and O for the fused delta) rows of this wave as fragments: whole-row pieces turned through the wave's quarter of LDS stage 1 (free until tile 0 requests
+    // tile 1 into it; flash_common.h: load_row_frags_staged)
+    constexpr int NROWT = FUSE_DELTA ? 3 : 2;
+    s16x8 rowf[NROWT][G::KS];
     {
-        const bf16_t* qp = q + (int64_t)(tok0 + my_q) * q_ts + (int64_t)h * D + (lane >> 5) * 8;
-        const bf16_t* dp = dout + (int64_t)(tok0 + my_q) * do_ts + (int64_t)h * D + (lane >> 5) * 8;
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            union { uint4 u; s16x8 s; } a, b;
-            a.u = q_valid ? ld16(qp + ks * 16) : z4();
-            b.u = q_valid ? ld16(dp + ks * 16) : z4();
-            qf[ks] = a.s;
-            dof[ks] = b.s;
+        static_assert(4 * 32 * 2 * D <= STAGE, "the four waves' row blocks in one stage");
+        const bf16_t* qr = q + (int64_t)(tok0 + qw0) * q_ts + (int64_t)h * D;
+        const bf16_t* dr = dout + (int64_t)(tok0 + qw0) * do_ts + (int64_t)h * D;
+        const int nv = min(max(len - qw0, 0), 32);
+        unsigned char* stg = smem + STAGE + wave * (32 * 2 * D);
+        if constexpr (FUSE_DELTA) {
+            const bf16_t* const row0[3] = {qr, dr, out + (int64_t)(tok0 + qw0) * o_ts + (int64_t)h * D};
+            const int64_t tss[3] = {q_ts, do_ts, o_ts};
+            load_row_frags_staged<D, 3>(row0, tss, nv, stg, lane, rowf);
+        } else {
+            const bf16_t* const row0[2] = {qr, dr};
+            const int64_t tss[2] = {q_ts, do_ts};
+            load_row_frags_staged<D, 2>(row0, tss, nv, stg, lane, rowf);
         }
     }
+    s16x8 (&qf)[G::KS] = rowf[0];
+    s16x8 (&dof)[G::KS] = rowf[1];
     const float lse_q = q_valid ? lse[(int64_t)h * T + tok0 + my_q] : INFINITY;
     const float lse2 = lse_q * kLog2e;
     float dlt;
     if constexpr (FUSE_DELTA) {
         static_assert(G::KS == 8 || G::KS == 4, "head dim 128 or 64");
         float pc[G::KS];   // chunk ks of this lane = chunk 2 ks + (lane >> 5) of the row
-        const bf16_t* op = out + (int64_t)(tok0 + my_q) * o_ts + (int64_t)h * D + (lane >> 5) * 8;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
             float a[8], b[8];
-            union { s16x8 s; uint4 u; } d_;
+            union { s16x8 s; uint4 u; } d_, o_;
             d_.s = dof[ks];
+            o_.s = rowf[NROWT - 1][ks];
             unpack8(d_.u, a);
-            unpack8(q_valid ? ld16(op + ks * 16) : z4(), b);
+            unpack8(o_.u, b);
             pc[ks] = dot8(a, b);
         }
         // flash_delta_k's tree over the row's chunks c (xor 8, 4, 2, 1 for D = 128; 4, 2, 1 for D = 64) with c = 2 ks + half: the last level is the partner lane
@@ -426,19 +435,16 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
     }
 
     // K, V fragments of this wave's 32 keys (B operands: lane = key)
-    s16x8 kf[G::KS], vf[G::KS];
+    // (whole-row pieces turned through a stage the tiles requested up front do not use: flash_common.h: load_row_frags_staged)
+    s16x8 kvf[2][G::KS];
     {
-        const bf16_t* kp = k + (int64_t)(tok0k + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
-        const bf16_t* vp = v + (int64_t)(tok0k + my_k) * kv_ts + (int64_t)hk * D + (lane >> 5) * 8;
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            union { uint4 u; s16x8 s; } a, b;
-            a.u = k_valid ? ld16(kp + ks * 16) : z4();
-            b.u = k_valid ? ld16(vp + ks * 16) : z4();
-            kf[ks] = a.s;
-            vf[ks] = b.s;
-        }
+        static_assert(PD < NST && DKV_WAVES * 32 * 2 * D <= STAGE, "a free stage holds the waves' row blocks");
+        const bf16_t* const row0[2] = {k + (int64_t)(tok0k + kw0) * kv_ts + (int64_t)hk * D, v + (int64_t)(tok0k + kw0) * kv_ts + (int64_t)hk * D};
+        const int64_t tss[2] = {kv_ts, kv_ts};
+        load_row_frags_staged<D, 2>(row0, tss, min(max(lenk - kw0, 0), 32), smem + (NST - 1) * STAGE + wave * (32 * 2 * D), lane, kvf);
     }
+    s16x8 (&kf)[G::KS] = kvf[0];
+    s16x8 (&vf)[G::KS] = kvf[1];
     const float sc2 = scale * kLog2e;
     f32x16 dkacc[G::DB], dvacc[G::DB];
 #pragma unroll

@@ -224,6 +224,44 @@ __device__ __forceinline__ void store_row_block(bf16_t* row, const f32x16 (&acc)
     }
 }
 
+// ---- Round 6: the 32 rows of a wave (row = lane & 31) as MFMA operand fragments -- frag[ks] = the 8 elements ks * 16 + (lane >> 5) * 8 .. of the lane's row --
+// fetched in 16-byte pieces that cover WHOLE rows (piece lane + 64 j: D / 8 pieces per row, 4 or 8 rows per instruction) and turned through a wave-private LDS
+// block, instead of one 32-byte segment of every row per instruction: those gathers keep a CU's address path busy for ~25 us of a 2048-block kernel per tensor
+// (measured on the dQ kernel: + 25 us for the O rows of the fused delta, + 30 us for the cos / sin gathers of the rotating store).  All NT tensors' pieces are
+// requested before the first is turned (one round trip).  stage: 32 * 2 D bytes of this wave's own, 16-byte slots XOR-swizzled by the row (the fragment reads of
+// 16 consecutive rows fall into 16 different slots); rows >= nvalid are zero.  Results: exactly the values the direct loads returned.
+template <int D, int NT>
+__device__ __forceinline__ void load_row_frags_staged(const bf16_t* const (&row0)[NT], const int64_t (&ts)[NT], int nvalid, unsigned char* stage, int lane,
+                                                      s16x8 (&out)[NT][Geo<D>::KS]) {
+    using G = Geo<D>;
+    constexpr int PPR = D / 8;   // 16-byte pieces per row
+    uint4 pc[NT][G::KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < G::KS; ++j) {
+            const int id = lane + 64 * j, r = id / PPR, sub = id % PPR;
+            pc[t][j] = r < nvalid ? ld16(row0[t] + (int64_t)r * ts[t] + sub * 8) : z4();
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < G::KS; ++j) {
+            const int id = lane + 64 * j, r = id / PPR, sub = id % PPR;
+            *reinterpret_cast<uint4*>(stage + r * (2 * D) + ((sub ^ (r & (PPR - 1))) * 16)) = pc[t][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            union { uint4 u; s16x8 s; } x;
+            x.u = *reinterpret_cast<const uint4*>(stage + r * (2 * D) + (((2 * ks + half) ^ (r & (PPR - 1))) * 16));
+            out[t][ks] = x.s;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next tensor overwrites the block)
+    }
+}
+
 // ---- Round 6: the attention backward writing straight into the wqkv product's output-gradient layout [T][hkv][q heads per kv head + 2][D] with the rotary
 // embedding's backward applied to dQ and dK on the way out (ie_flash_attn_bwd_qkv_rotary): qkv_rotary_bwd_k and its launch are gone from the step.
 struct FaRotOut {
