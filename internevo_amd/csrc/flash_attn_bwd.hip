@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256, MINW) void flash_dq_k(const bf16_t* __restrict
 
     if constexpr (ROT) {
         static_assert(4 * FA_ROT_STAGE_BYTES <= 2 * STAGE, "the cos / sin staging rows of four waves in the K / V stages");
-        store_row_block_rot<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)(h / ro.qpk) * ro.grp_stride + (int64_t)(h % ro.qpk) * D, dqacc, scale, lane, q_valid,
-                               ro.cs, ro.sn, (int)rot_p, smem + wave * FA_ROT_STAGE_BYTES);   // (the last tile ended with a barrier: the stages are free)
+        store_row_block_rot<D>(dq + (int64_t)(tok0 + qw0) * dq_ts + (int64_t)(h / ro.qpk) * ro.grp_stride + (int64_t)(h % ro.qpk) * D, dq_ts,
+                               min(max(len - qw0, 0), 32), dqacc, scale, lane, ro.cs, ro.sn, (int)rot_p,
+                               smem + wave * FA_ROT_STAGE_BYTES);   // (the last tile ended with a barrier: the stages are free)
     } else {
         store_row_block<D>(dq + (int64_t)(tok0 + my_q) * dq_ts + (int64_t)h * D, dqacc, scale, lane, q_valid, (dq_ts & 7) == 0);
     }
@@ -792,8 +793,9 @@ __global__ __launch_bounds__(64 * DKV_WAVES) void flash_dkdv_k(const bf16_t* __r
         const int64_t p = k_valid ? ro.pos[tok0k + my_k] : 0;
         static_assert(DKV_WAVES * FA_ROT_STAGE_BYTES <= NST * STAGE, "the cos / sin staging rows in the Q / dO stages");
         __syncthreads();   // (every wave is through its last tile: the stages are free)
-        store_row_block_rot<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dkacc, scale, lane, k_valid, ro.cs, ro.sn, (int)p, smem + wave * FA_ROT_STAGE_BYTES);
-        store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + hoff, dvacc, 1.f, lane, k_valid, true);
+        const int nvk = min(max(lenk - kw0, 0), 32);
+        store_row_block_rot<D>(dk + (int64_t)(tok0k + kw0) * dkv_ts + hoff, dkv_ts, nvk, dkacc, scale, lane, ro.cs, ro.sn, (int)p, smem + wave * FA_ROT_STAGE_BYTES);
+        store_rows_staged<D>(dv + (int64_t)(tok0k + kw0) * dkv_ts + hoff, dkv_ts, nvk, dvacc, 1.f, lane, smem + wave * FA_ROT_STAGE_BYTES);
     } else if (HS == 1) {
         store_row_block<D>(dk + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dkacc, scale, lane, k_valid, (dkv_ts & 7) == 0);
         store_row_block<D>(dv + (int64_t)(tok0k + my_k) * dkv_ts + (int64_t)hk * D, dvacc, 1.f, lane, k_valid, (dkv_ts & 7) == 0);

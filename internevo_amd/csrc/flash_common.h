@@ -277,11 +277,39 @@ struct FaRotOut {
 // The cos / sin rows of the wave's 32 rows come through LDS (`stage`: FA_ROT_STAGE_BYTES of this wave's own, free at the end of the kernel): 16-byte pieces,
 // eight per lane, instead of sixteen 8-byte gathers per lane with 64 different cache lines each -- the gathers kept the CU's address path busy for 40 us of the
 // dQ kernel (measured: 810 -> 840 us with them).  pos_lane: the position of THIS lane's row (lane & 31); the others' come by shuffle.
+// The 32 rows of a wave out of their accumulators as WHOLE-ROW 16-byte pieces (4 rows per store instruction) through a wave-private, XOR-swizzled LDS block of
+// 32 * 2 D bytes, instead of store_row_block's one 32-byte segment of every row per instruction (the store-side twin of load_row_frags_staged).  Rows >= nvalid
+// are not written.  Same bytes in memory.
+template <int D>
+__device__ __forceinline__ void store_rows_staged(bf16_t* row0, int64_t ts, int nvalid, const f32x16 (&acc)[Geo<D>::DB], float mul, int lane, unsigned char* stage) {
+    using G = Geo<D>;
+    constexpr int PPR = D / 8;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < G::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(stage + r * (2 * D) + (((4 * db + g) ^ (r & (PPR - 1))) * 16) + hh * 8) = w;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < G::KS; ++j) {
+        const int id = lane + 64 * j, rr = id / PPR, sub = id % PPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + rr * (2 * D) + ((sub ^ (rr & (PPR - 1))) * 16));
+        if (rr < nvalid) st16(row0 + (int64_t)rr * ts + sub * 8, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 constexpr int FA_ROT_ROW = 272;                       // bytes per staged row: cos [64] at 0, sin [64] at 128, padded so that the 32 rows spread over the banks
 constexpr int FA_ROT_STAGE_BYTES = 32 * FA_ROT_ROW;   // per wave
+// (row0 / ts / nvalid: the wave's 32 rows in memory -- the rotated rows leave through store_rows_staged, in the same LDS block)
 template <int D>
-__device__ __forceinline__ void store_row_block_rot(bf16_t* row, f32x16 (&acc)[Geo<D>::DB], float mul, int lane, bool valid, const bf16_t* cs, const bf16_t* sn,
-                                                    int pos_lane, unsigned char* stage) {
+__device__ __forceinline__ void store_row_block_rot(bf16_t* row0, int64_t ts, int nvalid, f32x16 (&acc)[Geo<D>::DB], float mul, int lane, const bf16_t* cs,
+                                                    const bf16_t* sn, int pos_lane, unsigned char* stage) {
     static_assert(D == 128, "pairs (d, d + 64) of a 128-wide head");
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -309,7 +337,8 @@ __device__ __forceinline__ void store_row_block_rot(bf16_t* row, f32x16 (&acc)[G
                 acc[db + 2][4 * g + i] = x2;
             }
         }
-    store_row_block<D>(row, acc, 1.f, lane, valid, true);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the cos / sin rows have been read: the block is free)
+    store_rows_staged<D>(row0, ts, nvalid, acc, 1.f, lane, stage);
 }
 
 // ---- MFMAs with an explicit register file for every operand (kernels with one wave per SIMD: 256 arch VGPRs + 256 accumulation VGPRs).
