@@ -454,9 +454,13 @@ class MoEEngine:
             d_ctx = d_n2.view(-1)[: T * H * d].view(T, H * d)   # (row-parallel backward: this rank's heads' columns, no exchange)
             K.linear_dgrad(d_r2, p[pre + "mixer.out_proj.weight"], d_ctx)
             K.linear_wgrad(d_r2, self.a_ctx[l].view(T, -1), g[pre + "mixer.out_proj.weight"], acc)
-            K.flash_attn_bwd(d_ctx.view(T, H, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu, max_seqlen, None, True,
-                             self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
-            K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, H, 1, d, False, self.t_qkv)
+            # (round 6: delta, the rotary backward and the q | k | v re-packing inside the two attention kernels where the library fuses the shape -- the same bits)
+            if not (os.environ.get("IE_ATTN_BWD_ROTARY_FUSE", "1") != "0" and
+                    K.flash_attn_bwd_qkv_rotary(d_ctx.view(T, H, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu, max_seqlen,
+                                                self.cos, self.sin, pos, self.t_qkv, None, self.t_delta)):
+                K.flash_attn_bwd(d_ctx.view(T, H, d), self.a_q[l], self.a_kv[l][:, 0], self.a_kv[l][:, 1], self.a_ctx[l], self.a_lse[l], cu, max_seqlen, None, True,
+                                 self.t_dq, self.t_dkv[:, 0], self.t_dkv[:, 1], self.t_delta)
+                K.qkv_rotary_bwd(self.t_dq, self.t_dkv, self.cos, self.sin, pos, H, 1, d, False, self.t_qkv)
             self._bias_grad(self.t_qkv, g[pre + "mixer.Wqkv.bias"], self.t_bias3, acc)
             d_n1 = d_n2
             K.linear_dgrad(self.t_qkv, p[pre + "mixer.Wqkv.weight"], d_n1)
