@@ -61,6 +61,29 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
         _lib.check(rc, "ie_gemm_bf16")
 
 
+def test_round6_host_side_decisions_without_a_gpu(lib):
+    """The host-only entry points of round 6 (no launch, no device): which shapes the fused attention backward and the residual-add epilogue take, and the
+    ranges of the new tuning hooks."""
+    fused = lib.ie_flash_attn_bwd_qkv_rotary_is_fused
+    assert fused(4, 4096, 32, 8, 128, 1) == 1          # the benchmark's call: enough key blocks for no head split
+    assert fused(3, 700, 6, 2, 128, 1) == 1            # an odd GQA group cannot be split
+    assert fused(2, 512, 4, 2, 128, 1) == 0            # a small problem: the dK / dV kernel splits the heads and sums partials
+    assert fused(4, 4096, 32, 8, 64, 1) == 0 and fused(4, 4096, 32, 8, 128, 0) == 0 and fused(0, 4096, 32, 8, 128, 1) == 0
+    try:
+        assert lib.ie_tune_flash_bwd_variant(4) == 0 and fused(4, 4096, 32, 8, 128, 1) == 0   # delta by its own kernel: the fused call steps aside
+    finally:
+        assert lib.ie_tune_flash_bwd_variant(0) == 0
+    assert lib.ie_tune_flash_bwd_variant(8) != 0
+    takes = lib.ie_gemm_dma_persistent_takes
+    assert takes(16384, 4096, 4096) == 1 and takes(16384, 4096, 14336) == 1      # wo, w2 of the 7B step
+    assert takes(4096, 4096, 1024) == 0 and takes(16384, 4096, 6144) == 0 and takes(1000, 4096, 4096) == 0   # one round; the frame's K rule; ragged rows
+    assert lib.ie_tune_adamw_cus(-1) != 0 and lib.ie_tune_adamw_cus(257) != 0
+    assert lib.ie_tune_adamw_cus(128) == 0 and lib.ie_tune_adamw_cus(0) == 0
+    assert lib.ie_tune_gemm_queue_memset(2) != 0 and lib.ie_tune_gemm_queue_memset(0) == 0
+    # a bad call of the fused backward is refused before anything is launched
+    assert lib.ie_flash_attn_bwd_qkv_rotary(None, 0, None, 0, None, None, 0, None, 0, None, None, None, None, None, None, None, 1, 16, 16, 4, 2, 128, 1.0, 1, None) != 0
+
+
 def test_struct_layouts_match_header():
     from internevo_amd import _lib
 
