@@ -433,7 +433,7 @@ def main():
         except (OSError, KeyError, ValueError) as e:
             traffic_note = f"no HBM-traffic measurement available ({type(e).__name__})"
         out["roofline"] = {
-            "kernel": "gemm_dma_k<256,256,...> / gemm_p5_k (LDS-DMA bf16 GEMM; fwd: one wave per SIMD, operand-wise refill of two 64-deep stages, v_mfma_f32_16x16x32_bf16, in a persistent frame where it applies (gemm_p5_k; its wave-private epilogue also carries the SwiGLU gate of the w1|w3 product, the SwiGLU backward of the w2 input gradient and the GQA split + rotary of the wqkv product -- those launches' extra work is inside their timed duration, their flops are the product's alone), also the long dgrads (B by transposing reads); other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring; of every linear layer)",
+            "kernel": "gemm_dma_k<256,256,...> / gemm_p5_k (LDS-DMA bf16 GEMM; fwd: one wave per SIMD, operand-wise refill of two 64-deep stages, v_mfma_f32_16x16x32_bf16, in a persistent frame where it applies (gemm_p5_k; its wave-private epilogue also carries the SwiGLU gate of the w1|w3 product, the SwiGLU backward of the w2 input gradient, the GQA split + rotary of the wqkv product and the residual adds behind wo / w2 -- those launches' extra work is inside their timed duration, their flops are the product's alone), also the long dgrads (B by transposing reads); other dgrads: 8-wave phased k32 ring; wgrad: one-wave-per-SIMD k32 ring, a half-empty last tile round as two half-k products + a fix-up, all inside the product's timed duration; of every linear layer)",
             "bound": "mfma",
             "achieved": ach / 1e12,
             "peak": MFMA_PEAK / 1e12,
